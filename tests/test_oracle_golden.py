@@ -1,0 +1,164 @@
+"""CPU: the oracle restatement (oracle/samnerf_oracle.py) against the committed golden vectors.
+
+The vectors were produced by importing the reference's own torch components
+(tests/golden/make_golden.py); these tests keep the oracle pinned to them everywhere.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import samnerf_oracle as O
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def close(a, b, tol=0.0):
+    a, b = torch.as_tensor(a), torch.as_tensor(b)
+    assert a.shape == b.shape
+    nan = torch.isnan(a) & torch.isnan(b)
+    d = torch.where(nan, torch.zeros_like(a, dtype=torch.float32), (a - b).abs().float())
+    assert float(d.max()) <= tol, float(d.max())
+
+
+@pytest.mark.parametrize("mode", ["train", "eval"])
+def test_spacing(golden, mode):
+    g = golden(f"spacing_{mode}")
+    t = T(g["t_rand"]) if mode == "train" else None
+    sb, eb = O.sample_spacing(T(g["nears"]), T(g["fars"]), 64, t)
+    close(sb.expand(64, -1), T(g["sbins"]))
+    close(eb, T(g["ebins"]))
+    close(O.sample_positions(T(g["origins"]), T(g["directions"]), eb), T(g["positions"]))
+
+
+def test_contraction(golden):
+    g = golden("contraction")
+    x = T(g["x"])
+    close(O.contract(x, float("inf")), T(g["linf"]))
+    close(O.contract(x, None), T(g["l2"]))
+    u, sel = O.normalize_positions(x, float("inf"), True)
+    close(u, T(g["u_linf_sel"]))
+    assert torch.equal(sel, T(g["selector"]))
+
+
+@pytest.mark.parametrize("name", ["prop", "field", "feat_a", "feat_b"])
+@pytest.mark.parametrize("log2_T", [10, 12])
+def test_hashgrid(golden, name, log2_T):
+    g = golden(f"hashgrid_{name}_T{log2_T}")
+    table = T(g["table"]).clone().requires_grad_(True)
+    out = O.hashgrid_fwd(T(g["u"]), table, T(g["scalings"]), int(g["log2_T"]))
+    close(out, T(g["out"]))
+    (out * T(g["grad_out"])).sum().backward()
+    close(table.grad, T(g["grad_table"]), 1e-7)
+
+
+def test_scalings_known_vectors():
+    assert O.hash_scalings(5, 16, 128).tolist() == [16, 26, 45, 76, 128]
+    assert O.hash_scalings(12, 128, 512).tolist()[-1] == 511  # fp32 rounding: not 512
+    assert O.hash_scalings(16, 16, 2048).tolist()[-1] == 2047
+
+
+@pytest.mark.parametrize("name", ["prop_nobias", "prop_bias", "base_nobias", "base_bias", "head_nobias",
+                                  "head_bias", "sam_nobias", "clipseg_nobias"])
+def test_mlp(golden, name):
+    g = golden("mlp_" + name)
+    n = int(g["n_layers"])
+    ws = [T(g[f"w{i}"]).clone().requires_grad_(True) for i in range(n)]
+    bs = [T(g[f"b{i}"]).clone().requires_grad_(True) for i in range(n)] if "b0" in g else None
+    x = T(g["x"]).clone().requires_grad_(True)
+    act = str(g["out_act"])
+    y = O.mlp_fwd(x, ws, bs, None if act == "none" else act)
+    close(y, T(g["y"]))
+    (y * T(g["grad_y"])).sum().backward()
+    close(x.grad, T(g["grad_x"]), 1e-7)
+    for i in range(n):
+        close(ws[i].grad, T(g[f"gw{i}"]), 1e-6)
+
+
+def test_sh16(golden):
+    g = golden("sh16")
+    close(O.sh16(T(g["directions"])), T(g["sh"]))
+
+
+def test_weights_and_trunc_exp(golden):
+    g = golden("weights")
+    d = T(g["density"]).clone().requires_grad_(True)
+    w = O.weights_from_density(d, T(g["deltas"]))
+    close(w, T(g["weights"]))
+    rows = T(g["finite_rows"]).long()
+    (w[rows] * T(g["grad_w"])[rows]).sum().backward()
+    close(torch.nan_to_num(d.grad), T(g["grad_density"]), 1e-6)
+    x = T(g["te_x"]).clone().requires_grad_(True)
+    y = O.trunc_exp(x)
+    close(y, T(g["te_y"]))
+    y.sum().backward()
+    close(x.grad, T(g["te_grad"]))
+
+
+@pytest.mark.parametrize("mode", ["train", "eval"])
+def test_pdf(golden, mode):
+    g = golden(f"pdf_{mode}")
+    u = T(g["u_rand"]) if mode == "train" else None
+    sb = O.pdf_resample(T(g["weights"]), T(g["sbins_in"]), int(g["num_samples"]), u)
+    close(sb, T(g["sbins"]))
+    close(O.s_to_euclid(sb, T(g["nears"]), T(g["fars"])), T(g["ebins"]))
+
+
+def test_render(golden):
+    g = golden("render")
+    w, rgb, eb = T(g["weights"]), T(g["rgb_samples"]), T(g["ebins"])
+    close(O.render_rgb(rgb.clone(), w, True), T(g["rgb_train"]))
+    close(O.render_rgb(rgb.clone(), w, False), T(g["rgb_eval"]))
+    close(O.render_accumulation(w), T(g["accumulation"]))
+    close(O.render_depth_median(w, eb), T(g["depth"]))
+
+
+def test_topk_mean_loss(golden):
+    g = golden("topk")
+    w, feats = T(g["weights"]), T(g["feats"])
+    sw, ids = O.topk_sharpen(w, int(g["k"]), float(g["temperature"]))
+    rows = [r for r in range(w.shape[0]) if r not in set(g["nan_rows"].tolist())]
+    assert torch.equal(torch.sort(ids, -1)[0][rows], torch.sort(T(g["ids"]), -1)[0][rows])
+    assert torch.isnan(sw[0]).all() and torch.isnan(sw[1]).all()
+    mean = O.feature_mean(torch.gather(feats, 1, ids[..., None].expand(-1, -1, feats.shape[-1])), sw)
+    close(mean, T(g["mean"]), 1e-6)
+    close(O.feature_loss(mean, T(g["target"])), T(g["loss"]), 1e-6)
+
+
+def test_losses(golden):
+    g = golden("losses")
+    wp = T(g["w_prop"]).clone().requires_grad_(True)
+    wf = T(g["w_fine"]).clone().requires_grad_(True)
+    li = O.interlevel_loss(T(g["sbins_fine"]), wf, T(g["sbins_prop"]), wp)
+    ld = O.distortion_loss(T(g["sbins_fine"]), wf)
+    close(li, T(g["interlevel"]), 1e-7)
+    close(ld, T(g["distortion"]), 1e-7)
+    (li + ld).backward()
+    close(wp.grad, T(g["grad_w_prop"]), 1e-7)
+    close(wf.grad, T(g["grad_w_fine"]), 1e-7)
+
+
+def test_ministep(golden):
+    g = golden("ministep")
+    cfg = O.PathConfig(num_proposal_samples=int(g["P"]), num_nerf_samples=int(g["S"]),
+                       num_sam_samples=int(g["K"]), patch_size=int(g["patch"])).small(int(g["log2_T"]))
+    params = O.init_params(cfg, seed=int(g["seed_params"]), table_scale=float(g["table_scale"]))
+    params = {k: v.requires_grad_(True) for k, v in params.items()}
+    o, d = O.synthetic_rays(int(g["num_rays"]), int(g["seed_rays"]))
+    close(o, T(g["origins"]))
+    batch = O.synthetic_batch(cfg, int(g["num_rays"]), int(g["seed_batch"]))
+    out = O.forward(params, cfg, o, d, True, T(g["t_rand"]), T(g["u_rand"]), float(g["anneal"]))
+    close(out["sbins_fine"], T(g["sbins_fine"]))
+    close(out["weights_fine"], T(g["w_fine"]), 1e-7)
+    close(out["rgb"], T(g["rgb"]), 1e-6)
+    close(out["depth"], T(g["depth"]))
+    close(out["prop_depth_0"], T(g["prop_depth_0"]))
+    close(out["sam"], T(g["sam"]), 1e-6)
+    close(out["clipseg"], T(g["clipseg"]), 1e-6)
+    ld = O.loss_dict(out, batch, cfg)
+    for k in ("rgb_loss", "interlevel_loss", "distortion_loss", "sam_loss", "clipseg_loss"):
+        close(ld[k], T(g[k]), 1e-6)
+    sum(ld.values()).backward()
+    for k, p in params.items():
+        close(p.grad, T(g["grad_" + k]), 2e-6)
