@@ -1,0 +1,160 @@
+/* samnerf_hip.h -- C ABI of libsamnerf_hip.so: the MI355X (gfx950) kernels of the SAM-NeRF
+ * render-and-distill hot path.
+ *
+ * This is the drop-in boundary.  The reference reaches its native code through the tiny-cuda-nn
+ * torch bindings (tcnn.Encoding / tcnn.Network / tcnn.NetworkWithInputEncoding modules) and through
+ * ordinary torch ops; citations below are relative to the reference repository root and name the
+ * interface each entry point replaces.
+ *
+ * Conventions (all entry points):
+ *   - every pointer is a DEVICE pointer to fp32 / int32 / uint8 data allocated by the caller
+ *     (PyTorch); the library never allocates, frees or retains a pointer past the call;
+ *   - `stream` is a hipStream_t (pass torch.cuda.current_stream().cuda_stream); kernels are
+ *     enqueued on it and the call returns without synchronising; all entry points are re-entrant;
+ *   - return value: 0 on success, negative on error (bad argument / launch failure); the message
+ *     is available from snf_last_error() on the calling thread.  No C++ exception crosses the ABI;
+ *   - tensors are row-major and contiguous unless a leading dimension (`ld*`, in elements) is given.
+ */
+#ifndef SAMNERF_HIP_H
+#define SAMNERF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SNF_OK 0
+#define SNF_ERR_ARG (-1)
+#define SNF_ERR_LAUNCH (-2)
+
+#define SNF_CONTRACT_NONE 0
+#define SNF_CONTRACT_LINF 1 /* SceneContraction(order=inf): nerfacto field + proposal nets (nerfstudio/models/nerfacto.py:156) */
+#define SNF_CONTRACT_L2 2   /* SceneContraction(): SAMField default (samnerf/sam_field.py:32) */
+
+#define SNF_ACT_NONE 0
+#define SNF_ACT_RELU 1
+#define SNF_ACT_SIGMOID 2
+
+typedef void* snf_stream_t;
+
+int snf_version(void);
+const char* snf_last_error(void);
+
+/* ---- a3: UniformLinDispPiecewiseSampler / SpacedSampler.generate_ray_samples
+ *      (nerfstudio/model_components/ray_samplers.py:79-126,223-246).
+ * nears,fars [R]; t_rand [R] single per-ray jitter or NULL (eval).  Out: sbins, ebins [R,P+1]. */
+int snf_sample_spacing(const float* nears, const float* fars, const float* t_rand, int R, int P,
+                       float* sbins, float* ebins, snf_stream_t stream);
+
+/* ---- a1+a4: Frustums.get_positions (nerfstudio/cameras/rays.py:48-57) fused with
+ *      SceneContraction.forward (field_components/spatial_distortions.py:66-69), the (x+2)/4
+ *      normalisation and the (0,1) selector (fields/nerfacto_field.py:244-252,
+ *      fields/density_fields.py:103-110, samnerf/sam_field.py:116-118).
+ * origins,dirs [R,3]; ebins [R,n+1]; ids [R,K] int32 sample indices or NULL (then K must equal n and
+ * every sample is taken in order: the top-K gather of samnerf/sam_model.py:250-255).
+ * Out: u [R*K,3] normalised positions, selector [R*K] uint8 (NULL when use_selector == 0). */
+int snf_positions(const float* origins, const float* dirs, const float* ebins, const int32_t* ids,
+                  int R, int n, int K, int contraction, int use_selector, float* u, uint8_t* selector,
+                  snf_stream_t stream);
+
+/* ---- a6: tcnn.Encoding(HashGrid) forward with the reference's torch semantics
+ *      (HashEncoding.pytorch_fwd, nerfstudio/field_components/encodings.py:289-349; call sites
+ *      samnerf/sam_field.py:99-109, fields/nerfacto_field.py:157-167, fields/density_fields.py:73-99).
+ * u [N,3] in [0,1]; table [L*2^log2_T, F] (level-major rows, feature-minor); scalings [L] (the
+ * reference's floor(min_res*g^l) vector, supplied by the caller).  F in {2,8}.
+ * Out: out[n*ld_out + col_off + l*F + f]. */
+int snf_hashgrid_fwd(const float* u, const float* table, const float* scalings, int N, int L, int F,
+                     int log2_T, float* out, int ld_out, int col_off, snf_stream_t stream);
+
+/* backward of the above w.r.t. the table only (positions are detached on this path: sam_field.py:116,
+ * ray_samplers.py:357): grad_table[row*F+f] += w_corner * grad_out[...]  (atomic accumulation;
+ * caller zero-fills grad_table). */
+int snf_hashgrid_bwd(const float* u, const float* grad_out, const float* scalings, int N, int L, int F,
+                     int log2_T, int ld_out, int col_off, float* grad_table, snf_stream_t stream);
+
+/* ---- a7: one layer of tcnn.Network (FullyFusedMLP / CutlassMLP) == nerfstudio MLP layer
+ *      (field_components/mlp.py:80-99): Y[N,O] = act(X[N,I] W[O,I]^T + bias).  bias may be NULL. */
+int snf_linear_fwd(const float* X, const float* W, const float* bias, int N, int I, int O, int ldx,
+                   int ldy, int act, float* Y, snf_stream_t stream);
+/* dX[N,I] = (dY * act'(Y)) W ;  Y is the layer OUTPUT (post-activation), may be NULL when act == NONE. */
+int snf_linear_bwd_data(const float* dY, const float* Y, const float* W, int N, int I, int O, int lddy,
+                        int ldy, int lddx, int act, float* dX, snf_stream_t stream);
+/* dW[O,I] += (dY * act'(Y))^T X ; dbias[O] += column sums (dbias may be NULL).  Atomic accumulation
+ * into caller-zeroed (or running) buffers. */
+int snf_linear_bwd_weight(const float* dY, const float* Y, const float* X, int N, int I, int O, int lddy,
+                          int ldy, int ldx, int act, float* dW, float* dbias, snf_stream_t stream);
+
+/* ---- a13: SH degree-4 basis of the raw unit direction (nerfstudio/utils/math.py:27-73) written to
+ *      the first 16 columns of the colour-MLP input, with the geo features copied behind it
+ *      (torch.cat of fields/nerfacto_field.py:336-343).  dirs [R,3]; geo points at h[:,1] of the
+ *      base-MLP output [R*S, ld_geo]; out [R*S, ld_out] gets 16 + n_geo columns. */
+int snf_head_input(const float* dirs, const float* geo, int R, int S, int n_geo, int ld_geo, float* out,
+                   int ld_out, snf_stream_t stream);
+
+/* ---- a8+a9: trunc_exp (field_components/activations.py:24-40), selector mask and
+ *      RaySamples.get_weights (nerfstudio/cameras/rays.py:141-163).
+ * raw[(r*n+i)*raw_stride] = pre-activation density; selector [R*n] uint8 or NULL; ebins [R,n+1].
+ * Out: weights [R,n]; density [R,n] (may be NULL). */
+int snf_weights_fwd(const float* raw, int raw_stride, const uint8_t* selector, const float* ebins, int R,
+                    int n, float* weights, float* density, snf_stream_t stream);
+/* grad_raw[(r*n+i)*raw_stride] = dL/draw  (overwrites that column only). */
+int snf_weights_bwd(const float* raw, int raw_stride, const uint8_t* selector, const float* ebins,
+                    const float* grad_weights, int R, int n, float* grad_raw, snf_stream_t stream);
+
+/* ---- a10: PDFSampler.generate_ray_samples, include_original=False, single jitter
+ *      (model_components/ray_samplers.py:298-367), preceded by the anneal pow of :583.
+ * weights [R,P]; sbins_in [R,P+1]; u_rand [R] or NULL (eval); nears,fars [R].
+ * Out: sbins, ebins [R,S+1]. */
+int snf_pdf_resample(const float* weights, const float* sbins_in, const float* u_rand, const float* nears,
+                     const float* fars, int R, int P, int S, float anneal, float histogram_padding,
+                     float* sbins, float* ebins, snf_stream_t stream);
+
+/* ---- a14+a15: RGBRenderer('last_sample'), AccumulationRenderer, DepthRenderer('median')
+ *      (model_components/renderers.py:97-140,218-223,260-270).
+ * rgb [R,S,3]; weights [R,S]; ebins [R,S+1].  Any of the outputs may be NULL. */
+int snf_composite_fwd(const float* rgb, const float* weights, const float* ebins, int R, int S,
+                      int training, float* out_rgb, float* out_acc, float* out_depth,
+                      snf_stream_t stream);
+/* training-mode backward of the RGB render: grad_rgb [R,S,3], grad_weights [R,S] (overwritten). */
+int snf_composite_bwd(const float* rgb, const float* weights, const float* grad_out_rgb, int R, int S,
+                      float* grad_rgb, float* grad_weights, snf_stream_t stream);
+
+/* ---- a16: torch.topk(weights, K) + sharpening + renormalisation (samnerf/sam_model.py:244-248).
+ * Out: ids [R,K] int32 (descending weight, ties -> lower index), sam_weights [R,K] (0/0 -> NaN kept). */
+int snf_topk_sharpen(const float* weights, int R, int S, int K, float temperature, int32_t* ids,
+                     float* sam_weights, snf_stream_t stream);
+
+/* ---- a18: MeanRenderer (samnerf/sam_model.py:126-137): out[r,c] = sum_k w[r,k] * embeds[r,k,c]. */
+int snf_feature_mean_fwd(const float* embeds, const float* w, int R, int K, int C, float* out,
+                         snf_stream_t stream);
+int snf_feature_mean_bwd(const float* grad_out, const float* w, int R, int K, int C, float* grad_embeds,
+                         snf_stream_t stream);
+
+/* ---- a20: interlevel_loss / lossfun_outer / outer (model_components/losses.py:46-120), one
+ *      proposal level.  Out: loss_rows [R] = sum_s clip(w-w_outer,0)^2/(w+1e-7) (caller takes the mean
+ *      over R*S); grad_w_prop [R,P] = d(mean loss)/d w_prop * grad_scale (NULL to skip). */
+int snf_interlevel(const float* sbins_fine, const float* w_fine, const float* sbins_prop,
+                   const float* w_prop, int R, int S, int P, float grad_scale, float* loss_rows,
+                   float* grad_w_prop, snf_stream_t stream);
+
+/* ---- a21: distortion_loss / lossfun_distortion (model_components/losses.py:124-143).
+ * Out: loss_rows [R]; grad_w [R,S] = d(loss_row)/dw * grad_scale (NULL to skip). */
+int snf_distortion(const float* sbins, const float* w, int R, int S, float grad_scale, float* loss_rows,
+                   float* grad_w, snf_stream_t stream);
+
+/* ---- optimiser side (nerfstudio/engine/optimizers.py:100-147; torch.optim.Adam, eps 1e-15,
+ *      samnerf/samconfigs.py:144-161): fused Adam over one contiguous parameter-arena slice.
+ * grads are multiplied by grad_scale first (1/world_size for the data-parallel mean) and are
+ * zeroed afterwards when zero_grad != 0. */
+int snf_adam_step(float* p, float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                  float eps, int step, float grad_scale, int zero_grad, snf_stream_t stream);
+
+/* Counter-based deterministic fill: x[i] = lo + (hi-lo)*U(seed,i); identical to the CPU restatement in
+ * the package (used to initialise full-size tables without shipping them). */
+int snf_fill_uniform(float* x, int64_t n, uint64_t seed, float lo, float hi, snf_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SAMNERF_HIP_H */

@@ -1,0 +1,81 @@
+// common.hpp -- shared helpers for the gfx950 kernels of libsamnerf_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <float.h>
+#include "samnerf_hip.h"
+
+namespace snf {
+
+void set_error(const char* fmt, ...);
+
+#define SNF_REQUIRE(cond, ...)                  \
+    do {                                        \
+        if (!(cond)) {                          \
+            snf::set_error(__VA_ARGS__);        \
+            return SNF_ERR_ARG;                 \
+        }                                       \
+    } while (0)
+
+#define SNF_LAUNCH_CHECK(name)                                                      \
+    do {                                                                            \
+        hipError_t e__ = hipGetLastError();                                         \
+        if (e__ != hipSuccess) {                                                    \
+            snf::set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+            return SNF_ERR_LAUNCH;                                                  \
+        }                                                                           \
+    } while (0)
+
+constexpr int WAVE = 64;
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
+
+// inclusive prefix sum across the 64 lanes of a wavefront
+__device__ __forceinline__ float wave_incl_scan(float v) {
+    const int lane = lane_id();
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+        float t = __shfl_up(v, d, WAVE);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+// inclusive suffix sum (lane i gets sum over lanes >= i)
+__device__ __forceinline__ float wave_incl_scan_rev(float v) {
+    const int lane = lane_id();
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+        float t = __shfl_down(v, d, WAVE);
+        if (lane + d < WAVE) v += t;
+    }
+    return v;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int d = WAVE / 2; d > 0; d >>= 1) v += __shfl_xor(v, d, WAVE);
+    return v;
+}
+
+__device__ __forceinline__ float nan_to_num(float x) {
+    if (x != x) return 0.f;
+    if (x == INFINITY) return FLT_MAX;
+    if (x == -INFINITY) return -FLT_MAX;
+    return x;
+}
+
+// spacing_fn / spacing_fn_inv of UniformLinDispPiecewiseSampler (ray_samplers.py:242-243)
+__device__ __forceinline__ float spacing_fn(float x) { return x < 1.f ? x / 2.f : 1.f - 1.f / (2.f * x); }
+__device__ __forceinline__ float spacing_fn_inv(float y) { return y < 0.5f ? 2.f * y : 1.f / (2.f - 2.f * y); }
+
+// torch.linspace(start, end, steps)[i] as the CPU kernel evaluates it (symmetric around the midpoint)
+__device__ __forceinline__ float linspace_at(float start, float end, int steps, int i) {
+    const float step = (end - start) / (float)(steps - 1);
+    return (i < steps / 2) ? start + step * (float)i : end - step * (float)(steps - 1 - i);
+}
+
+inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+}  // namespace snf

@@ -1,0 +1,309 @@
+// linear.hip -- the dense layers of the tiny MLPs on the fp32 matrix cores (gfx950).
+//
+// All three GEMMs of a layer are "tall-skinny": one dimension is the number of samples (10^5..10^6), the
+// other two are <= 256.  They run on v_mfma_f32_32x32x2_f32 (exact fp32: bitwise an fmaf chain), which is
+// what keeps rendered RGB / feature tensors within 1e-4 of the fp32 oracle.
+//
+//   k_gemm_rows<BT,DERIV> : C[M,Nc] = op(A)[M,K] * B      (forward: BT=1, B = W[O,I] read transposed;
+//                                                          data-grad: BT=0, B = W[O,I] read as [K=O][Nc=I])
+//   k_gemm_wgrad          : dW[O,I] += op(dY)^T[O,rows] * X[rows,I]   split over row chunks, fp32 atomics
+//
+// Workgroup = 256 threads = 4 waves.  k_gemm_rows: tile 128 rows x 64 cols x 32 k; wave w owns rows
+// [32w,32w+32) and two 32x32 accumulators.  Operands go through LDS k-major ([k][row]) so that an MFMA
+// operand read is one conflict-free ds_read_b32 per lane; the row pitch (129 / 65 floats) makes the
+// transposing ds_write_b32 pattern conflict-free as well.
+#include "common.hpp"
+
+namespace snf {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128, BN = 64, BK = 32;
+constexpr int LDA_S = BM + 1;  // 129: 4*129 mod 32 == 4 -> transposing stores hit 32 distinct banks
+constexpr int LDB_S = BN + 1;  // 65
+
+__device__ __forceinline__ float act_deriv(float y, int act) {
+    if (act == SNF_ACT_RELU) return y > 0.f ? 1.f : 0.f;
+    if (act == SNF_ACT_SIGMOID) return y * (1.f - y);
+    return 1.f;
+}
+
+__device__ __forceinline__ float act_apply(float x, int act) {
+    if (act == SNF_ACT_RELU) return fmaxf(x, 0.f);
+    if (act == SNF_ACT_SIGMOID) return 1.f / (1.f + expf(-x));
+    return x;
+}
+
+// load 4 consecutive k-elements of row `row` starting at k (zero outside the matrix)
+template <bool DERIV>
+__device__ __forceinline__ float4 load_a4(const float* __restrict__ A, const float* __restrict__ Aux, int row, int k,
+                                          int M, int K, int lda, int ldaux, int act, bool vec) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row >= M || k >= K) return v;
+    const float* p = A + (size_t)row * lda + k;
+    if (vec) {
+        v = *reinterpret_cast<const float4*>(p);
+    } else {
+        v.x = p[0];
+        if (k + 1 < K) v.y = p[1];
+        if (k + 2 < K) v.z = p[2];
+        if (k + 3 < K) v.w = p[3];
+    }
+    if constexpr (DERIV) {
+        if (act != SNF_ACT_NONE) {
+            const float* q = Aux + (size_t)row * ldaux + k;
+            float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (vec) {
+                y = *reinterpret_cast<const float4*>(q);
+            } else {
+                y.x = q[0];
+                if (k + 1 < K) y.y = q[1];
+                if (k + 2 < K) y.z = q[2];
+                if (k + 3 < K) y.w = q[3];
+            }
+            v.x *= act_deriv(y.x, act);
+            v.y *= act_deriv(y.y, act);
+            v.z *= act_deriv(y.z, act);
+            v.w *= act_deriv(y.w, act);
+        }
+    }
+    return v;
+}
+
+// generic 4-wide load along the contiguous dimension of a row-major matrix [R, C] at (r, c)
+__device__ __forceinline__ float4 load_b4(const float* __restrict__ B, int r, int c, int Rn, int Cn, int ldb, bool vec) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r >= Rn || c >= Cn) return v;
+    const float* p = B + (size_t)r * ldb + c;
+    if (vec) {
+        v = *reinterpret_cast<const float4*>(p);
+    } else {
+        v.x = p[0];
+        if (c + 1 < Cn) v.y = p[1];
+        if (c + 2 < Cn) v.z = p[2];
+        if (c + 3 < Cn) v.w = p[3];
+    }
+    return v;
+}
+
+template <bool BT, bool DERIV>
+__global__ __launch_bounds__(256) void k_gemm_rows(const float* __restrict__ A, const float* __restrict__ Aux,
+                                                   const float* __restrict__ B, const float* __restrict__ bias, int M,
+                                                   int K, int Nc, int lda, int ldaux, int ldb, int ldc, int act_in,
+                                                   int act_out, int vecA, int vecB, float* __restrict__ C) {
+    __shared__ float As[BK * LDA_S];
+    __shared__ float Bs[BK * LDB_S];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int row0 = blockIdx.x * BM;
+    const int col0 = blockIdx.y * BN;
+    const bool two = (col0 + 32) < Nc;  // second 32-column accumulator needed?
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+
+    const int a_kq = tid & 7, a_r = tid >> 3;  // A staging: 8 k-quads x 32 rows, 4 passes
+    for (int k0 = 0; k0 < K; k0 += BK) {
+        // ---- stage A (transposed into [k][row])
+        float4 av[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+            av[p] = load_a4<DERIV>(A, Aux, row0 + a_r + 32 * p, k0 + a_kq * 4, M, K, lda, ldaux, act_in, vecA);
+        float4 bv[2];
+        if constexpr (BT) {
+            // B = W[Nc, K] row-major: 8 k-quads x 32 cols, 2 passes
+#pragma unroll
+            for (int p = 0; p < 2; ++p) bv[p] = load_b4(B, col0 + a_r + 32 * p, k0 + a_kq * 4, Nc, K, ldb, vecB);
+        } else {
+            // B = W[K, Nc] row-major: 16 col-quads x 16 k, 2 passes
+            const int b_jq = tid & 15, b_k = tid >> 4;
+#pragma unroll
+            for (int p = 0; p < 2; ++p) bv[p] = load_b4(B, k0 + b_k + 16 * p, col0 + b_jq * 4, K, Nc, ldb, vecB);
+        }
+        __syncthreads();  // previous tile fully consumed
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int r = a_r + 32 * p;
+            As[(a_kq * 4 + 0) * LDA_S + r] = av[p].x;
+            As[(a_kq * 4 + 1) * LDA_S + r] = av[p].y;
+            As[(a_kq * 4 + 2) * LDA_S + r] = av[p].z;
+            As[(a_kq * 4 + 3) * LDA_S + r] = av[p].w;
+        }
+        if constexpr (BT) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int j = a_r + 32 * p;
+                Bs[(a_kq * 4 + 0) * LDB_S + j] = bv[p].x;
+                Bs[(a_kq * 4 + 1) * LDB_S + j] = bv[p].y;
+                Bs[(a_kq * 4 + 2) * LDB_S + j] = bv[p].z;
+                Bs[(a_kq * 4 + 3) * LDB_S + j] = bv[p].w;
+            }
+        } else {
+            const int b_jq = tid & 15, b_k = tid >> 4;
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                float* d = &Bs[(b_k + 16 * p) * LDB_S + b_jq * 4];
+                d[0] = bv[p].x; d[1] = bv[p].y; d[2] = bv[p].z; d[3] = bv[p].w;
+            }
+        }
+        __syncthreads();
+        // ---- 16 k-pairs on the matrix core
+        const int kh = lane >> 5, li = lane & 31;
+        const float* ap = &As[kh * LDA_S + wave * 32 + li];
+        const float* bp = &Bs[kh * LDB_S + li];
+        if (two) {
+#pragma unroll
+            for (int kk = 0; kk < BK / 2; ++kk) {
+                const float a = ap[kk * 2 * LDA_S];
+                const float b0 = bp[kk * 2 * LDB_S];
+                const float b1 = bp[kk * 2 * LDB_S + 32];
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < BK / 2; ++kk) {
+                const float a = ap[kk * 2 * LDA_S];
+                const float b0 = bp[kk * 2 * LDB_S];
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
+            }
+        }
+    }
+    // ---- epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    const int li = lane & 31, kh = lane >> 5;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int row = row0 + wave * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * kh;
+        if (row < M) {
+            const int c0 = col0 + li;
+            if (c0 < Nc) {
+                float v = acc0[reg];
+                if (bias) v += bias[c0];
+                C[(size_t)row * ldc + c0] = act_apply(v, act_out);
+            }
+            const int c1 = c0 + 32;
+            if (two && c1 < Nc) {
+                float v = acc1[reg];
+                if (bias) v += bias[c1];
+                C[(size_t)row * ldc + c1] = act_apply(v, act_out);
+            }
+        }
+    }
+}
+
+// dW[O,I] += sum over this block's rows of dZ[n,o] * X[n,i];   tile 64(o) x 64(i), waves 2x2.
+constexpr int WG_LD = 65;
+__global__ __launch_bounds__(256) void k_gemm_wgrad(const float* __restrict__ dY, const float* __restrict__ Y,
+                                                    const float* __restrict__ X, int N, int I, int O, int lddy, int ldy,
+                                                    int ldx, int act, int rows_per_block, int vecA, int vecB,
+                                                    float* __restrict__ dW, float* __restrict__ dbias) {
+    __shared__ float As[BK * WG_LD];  // [n][o]
+    __shared__ float Bs[BK * WG_LD];  // [n][i]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int o0 = blockIdx.x * 64, i0 = blockIdx.y * 64;
+    const int n_begin = blockIdx.z * rows_per_block;
+    const int n_end = min(N, n_begin + rows_per_block);
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    float bsum = 0.f;
+    const int q = tid & 15, kr = tid >> 4;  // 16 quads x 16 rows, 2 passes
+    for (int n0 = n_begin; n0 < n_end; n0 += BK) {
+        float4 av[2], bv[2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int n = n0 + kr + 16 * p;
+            const bool ok = n < n_end;
+            // A: dZ[n][o0 + q*4 ..]  (activation derivative folded in)
+            av[p] = ok ? load_a4<true>(dY, Y, n, o0 + q * 4, N, O, lddy, ldy, act, vecA) : make_float4(0, 0, 0, 0);
+            bv[p] = ok ? load_b4(X, n, i0 + q * 4, N, I, ldx, vecB) : make_float4(0, 0, 0, 0);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            float* da = &As[(kr + 16 * p) * WG_LD + q * 4];
+            da[0] = av[p].x; da[1] = av[p].y; da[2] = av[p].z; da[3] = av[p].w;
+            float* db = &Bs[(kr + 16 * p) * WG_LD + q * 4];
+            db[0] = bv[p].x; db[1] = bv[p].y; db[2] = bv[p].z; db[3] = bv[p].w;
+        }
+        __syncthreads();
+        const int kh = lane >> 5, li = lane & 31;
+        const float* ap = &As[kh * WG_LD + wm * 32 + li];
+        const float* bp = &Bs[kh * WG_LD + wn * 32 + li];
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; ++kk)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[kk * 2 * WG_LD], bp[kk * 2 * WG_LD], acc, 0, 0, 0);
+        if (dbias != nullptr && blockIdx.y == 0 && tid < 64) {
+#pragma unroll 8
+            for (int k = 0; k < BK; ++k) bsum += As[k * WG_LD + tid];
+        }
+    }
+    const int li = lane & 31, kh = lane >> 5;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int o = o0 + wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * kh;
+        const int i = i0 + wn * 32 + li;
+        if (o < O && i < I) unsafeAtomicAdd(&dW[(size_t)o * I + i], acc[reg]);
+    }
+    if (dbias != nullptr && blockIdx.y == 0 && tid < 64 && o0 + tid < O) unsafeAtomicAdd(&dbias[o0 + tid], bsum);
+}
+
+inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+}  // namespace snf
+
+using namespace snf;
+
+extern "C" int snf_linear_fwd(const float* X, const float* W, const float* bias, int N, int I, int O, int ldx, int ldy,
+                              int act, float* Y, snf_stream_t stream) {
+    SNF_REQUIRE(X && W && Y, "snf_linear_fwd: null pointer");
+    SNF_REQUIRE(N > 0 && I > 0 && O > 0 && ldx >= I && ldy >= O, "snf_linear_fwd: bad shape N=%d I=%d O=%d", N, I, O);
+    SNF_REQUIRE(act >= 0 && act <= 2, "snf_linear_fwd: bad activation %d", act);
+    const int vecA = aligned16(X) && (ldx % 4 == 0) && (I % 4 == 0);
+    const int vecB = aligned16(W) && (I % 4 == 0);
+    dim3 grid(ceil_div(N, BM), ceil_div(O, BN));
+    hipLaunchKernelGGL((k_gemm_rows<true, false>), grid, dim3(256), 0, (hipStream_t)stream, X, (const float*)nullptr, W,
+                       bias, N, I, O, ldx, 0, I, ldy, SNF_ACT_NONE, act, vecA, vecB, Y);
+    SNF_LAUNCH_CHECK("snf_linear_fwd");
+    return SNF_OK;
+}
+
+extern "C" int snf_linear_bwd_data(const float* dY, const float* Y, const float* W, int N, int I, int O, int lddy,
+                                   int ldy, int lddx, int act, float* dX, snf_stream_t stream) {
+    SNF_REQUIRE(dY && W && dX, "snf_linear_bwd_data: null pointer");
+    SNF_REQUIRE(act == SNF_ACT_NONE || Y, "snf_linear_bwd_data: Y required for activation derivative");
+    SNF_REQUIRE(N > 0 && I > 0 && O > 0 && lddy >= O && lddx >= I, "snf_linear_bwd_data: bad shape");
+    const int vecA = aligned16(dY) && (lddy % 4 == 0) && (O % 4 == 0) &&
+                     (act == SNF_ACT_NONE || (aligned16(Y) && ldy % 4 == 0));
+    const int vecB = aligned16(W) && (I % 4 == 0);
+    dim3 grid(ceil_div(N, BM), ceil_div(I, BN));
+    hipLaunchKernelGGL((k_gemm_rows<false, true>), grid, dim3(256), 0, (hipStream_t)stream, dY, Y, W,
+                       (const float*)nullptr, N, O, I, lddy, ldy, I, lddx, act, SNF_ACT_NONE, vecA, vecB, dX);
+    SNF_LAUNCH_CHECK("snf_linear_bwd_data");
+    return SNF_OK;
+}
+
+extern "C" int snf_linear_bwd_weight(const float* dY, const float* Y, const float* X, int N, int I, int O, int lddy,
+                                     int ldy, int ldx, int act, float* dW, float* dbias, snf_stream_t stream) {
+    SNF_REQUIRE(dY && X && dW, "snf_linear_bwd_weight: null pointer");
+    SNF_REQUIRE(act == SNF_ACT_NONE || Y, "snf_linear_bwd_weight: Y required for activation derivative");
+    SNF_REQUIRE(N > 0 && I > 0 && O > 0 && lddy >= O && ldx >= I, "snf_linear_bwd_weight: bad shape");
+    const int vecA = aligned16(dY) && (lddy % 4 == 0) && (O % 4 == 0) &&
+                     (act == SNF_ACT_NONE || (aligned16(Y) && ldy % 4 == 0));
+    const int vecB = aligned16(X) && (ldx % 4 == 0) && (I % 4 == 0);
+    const int to = ceil_div(O, 64), ti = ceil_div(I, 64);
+    // aim for ~2048 workgroups; every chunk is a multiple of BK rows
+    int chunks = 2048 / (to * ti);
+    if (chunks < 1) chunks = 1;
+    int rows = ceil_div(N, chunks);
+    rows = ((rows + BK - 1) / BK) * BK;
+    if (rows < 4 * BK) rows = 4 * BK;
+    chunks = ceil_div(N, rows);
+    dim3 grid(to, ti, chunks);
+    hipLaunchKernelGGL(k_gemm_wgrad, grid, dim3(256), 0, (hipStream_t)stream, dY, Y, X, N, I, O, lddy, ldy, ldx, act,
+                       rows, vecA, vecB, dW, dbias);
+    SNF_LAUNCH_CHECK("snf_linear_bwd_weight");
+    return SNF_OK;
+}

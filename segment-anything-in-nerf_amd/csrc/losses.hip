@@ -1,0 +1,135 @@
+// losses.hip -- the two per-ray regularisers of the nerfacto loss, forward + gradient in one pass (gfx950).
+//   snf_interlevel : interlevel_loss / lossfun_outer / outer   (model_components/losses.py:46-120)
+//   snf_distortion : distortion_loss / lossfun_distortion      (model_components/losses.py:124-143)
+// One wavefront per ray; bins, weights and the difference array live in LDS.
+#include "common.hpp"
+
+namespace snf {
+
+constexpr int RAYS_PER_BLOCK = 4;
+constexpr int MAXN = 260;  // S, P <= 256 (+1 bin edge, + slack)
+
+// searchsorted(a[0..n), v, side='right'): number of elements <= v
+__device__ __forceinline__ int upper_bound(const float* a, int n, float v) {
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (a[mid] <= v) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(256) void k_interlevel(const float* __restrict__ sb_f, const float* __restrict__ w_f,
+                                                    const float* __restrict__ sb_p, const float* __restrict__ w_p, int R,
+                                                    int S, int P, float grad_scale, float* __restrict__ loss_rows,
+                                                    float* __restrict__ grad_wp) {
+    __shared__ float s_cp[RAYS_PER_BLOCK][MAXN];    // proposal bin edges [P+1]
+    __shared__ float s_cy[RAYS_PER_BLOCK][MAXN];    // [0, cumsum(w_p)]  [P+1]
+    __shared__ float s_diff[RAYS_PER_BLOCK][MAXN];  // difference array for d loss / d w_p
+    const int wv = threadIdx.x >> 6;
+    const int r_raw = blockIdx.x * RAYS_PER_BLOCK + wv;
+    const bool active = r_raw < R;
+    const int r = active ? r_raw : R - 1;
+    const int lane = lane_id();
+    float* cp = s_cp[wv];
+    float* cy = s_cy[wv];
+    float* df = s_diff[wv];
+    for (int i = lane; i <= P; i += WAVE) { cp[i] = sb_p[(size_t)r * (P + 1) + i]; df[i] = 0.f; }
+    float carry = 0.f;
+    for (int base = 0; base < P; base += WAVE) {
+        const int i = base + lane;
+        const float v = (i < P) ? w_p[(size_t)r * P + i] : 0.f;
+        const float inc = wave_incl_scan(v) + carry;
+        if (i < P) cy[i + 1] = inc;
+        carry = __shfl(inc, WAVE - 1, WAVE);
+    }
+    if (lane == 0) cy[0] = 0.f;
+    __syncthreads();
+    float part = 0.f;
+    for (int s = lane; s < S; s += WAVE) {
+        const float t0 = sb_f[(size_t)r * (S + 1) + s];
+        const float t1 = sb_f[(size_t)r * (S + 1) + s + 1];
+        const float w = w_f[(size_t)r * S + s];
+        int lo = upper_bound(cp, P, t0) - 1;      // searchsorted(t1_starts = cp[0..P), t0, right) - 1
+        lo = min(max(lo, 0), P - 1);
+        int hi = upper_bound(cp + 1, P, t1);      // searchsorted(t1_ends = cp[1..P], t1, right)
+        hi = min(max(hi, 0), P - 1);
+        const float w_outer = cy[hi + 1] - cy[lo];
+        const float d = fmaxf(w - w_outer, 0.f);
+        part += d * d / (w + 1e-7f);
+        if (grad_wp && d > 0.f) {
+            const float g = -2.f * d / (w + 1e-7f) * grad_scale;  // d/d w_outer
+            atomicAdd(&df[lo], g);
+            atomicAdd(&df[hi + 1], -g);
+        }
+    }
+    part = wave_sum(part);
+    if (active && lane == 0) loss_rows[r] = part;
+    __syncthreads();
+    if (grad_wp) {
+        float c2 = 0.f;
+        for (int base = 0; base < P; base += WAVE) {
+            const int i = base + lane;
+            const float v = (i < P) ? df[i] : 0.f;
+            const float inc = wave_incl_scan(v) + c2;
+            if (active && i < P) grad_wp[(size_t)r * P + i] = inc;
+            c2 = __shfl(inc, WAVE - 1, WAVE);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_distortion(const float* __restrict__ sb, const float* __restrict__ w_in, int R,
+                                                    int S, float grad_scale, float* __restrict__ loss_rows,
+                                                    float* __restrict__ grad_w) {
+    __shared__ float s_u[RAYS_PER_BLOCK][MAXN];
+    __shared__ float s_w[RAYS_PER_BLOCK][MAXN];
+    const int wv = threadIdx.x >> 6;
+    const int r_raw = blockIdx.x * RAYS_PER_BLOCK + wv;
+    const bool active = r_raw < R;
+    const int r = active ? r_raw : R - 1;
+    const int lane = lane_id();
+    float* u = s_u[wv];
+    float* w = s_w[wv];
+    const float* t = sb + (size_t)r * (S + 1);
+    for (int i = lane; i < S; i += WAVE) {
+        u[i] = (t[i + 1] + t[i]) / 2.f;
+        w[i] = w_in[(size_t)r * S + i];
+    }
+    __syncthreads();
+    float part = 0.f;
+    for (int i = lane; i < S; i += WAVE) {
+        const float ui = u[i], wi = w[i];
+        float inner = 0.f;
+        for (int j = 0; j < S; ++j) inner += w[j] * fabsf(ui - u[j]);
+        const float width = t[i + 1] - t[i];
+        part += wi * inner + wi * wi * width / 3.f;
+        if (active && grad_w) grad_w[(size_t)r * S + i] = (2.f * inner + 2.f * wi * width / 3.f) * grad_scale;
+    }
+    part = wave_sum(part);
+    if (active && lane == 0) loss_rows[r] = part;
+}
+
+}  // namespace snf
+
+using namespace snf;
+
+extern "C" int snf_interlevel(const float* sbins_fine, const float* w_fine, const float* sbins_prop, const float* w_prop,
+                              int R, int S, int P, float grad_scale, float* loss_rows, float* grad_w_prop,
+                              snf_stream_t stream) {
+    SNF_REQUIRE(sbins_fine && w_fine && sbins_prop && w_prop && loss_rows, "snf_interlevel: null pointer");
+    SNF_REQUIRE(R > 0 && S >= 1 && P >= 1 && S <= 256 && P <= 256, "snf_interlevel: bad shape R=%d S=%d P=%d", R, S, P);
+    hipLaunchKernelGGL(k_interlevel, dim3(ceil_div(R, RAYS_PER_BLOCK)), dim3(256), 0, (hipStream_t)stream, sbins_fine,
+                       w_fine, sbins_prop, w_prop, R, S, P, grad_scale, loss_rows, grad_w_prop);
+    SNF_LAUNCH_CHECK("snf_interlevel");
+    return SNF_OK;
+}
+
+extern "C" int snf_distortion(const float* sbins, const float* w, int R, int S, float grad_scale, float* loss_rows,
+                              float* grad_w, snf_stream_t stream) {
+    SNF_REQUIRE(sbins && w && loss_rows, "snf_distortion: null pointer");
+    SNF_REQUIRE(R > 0 && S >= 1 && S <= 256, "snf_distortion: bad shape R=%d S=%d", R, S);
+    hipLaunchKernelGGL(k_distortion, dim3(ceil_div(R, RAYS_PER_BLOCK)), dim3(256), 0, (hipStream_t)stream, sbins, w, R,
+                       S, grad_scale, loss_rows, grad_w);
+    SNF_LAUNCH_CHECK("snf_distortion");
+    return SNF_OK;
+}

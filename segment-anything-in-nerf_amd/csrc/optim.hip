@@ -1,0 +1,106 @@
+// optim.hip -- parameter-arena kernels (gfx950): fused Adam and the counter-based initialiser.
+//   snf_adam_step    : torch.optim.Adam semantics (nerfstudio/engine/optimizers.py:100-147; eps 1e-15,
+//                      samnerf/samconfigs.py:144-161) over one contiguous slice of the flat fp32 arena;
+//                      streams p,g,m,v once (16 B/lane dwordx4), optionally folds the data-parallel 1/world
+//                      gradient scale and the zero_grad of the next step into the same pass.
+//   snf_fill_uniform : splitmix64 counter hash -> U[lo,hi); the package has the identical numpy expression.
+#include "common.hpp"
+#include <math.h>
+#include <stdarg.h>
+#include <string.h>
+
+namespace snf {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+__device__ __forceinline__ void adam1(float& p, float& g, float& m, float& v, float gs, float b1, float b2, float step_size,
+                                      float inv_sqrt_bc2, float eps) {
+    const float gg = g * gs;
+    m = m + (gg - m) * (1.f - b1);
+    v = v * b2 + (1.f - b2) * gg * gg;
+    const float denom = sqrtf(v) * inv_sqrt_bc2 + eps;
+    p = p - step_size * (m / denom);
+}
+
+__global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                              float* __restrict__ v, long long n, float b1, float b2, float step_size,
+                                              float inv_sqrt_bc2, float eps, float gs, int zero_grad) {
+    const long long n4 = n >> 2;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 P = reinterpret_cast<float4*>(p)[i];
+        float4 G = reinterpret_cast<float4*>(g)[i];
+        float4 M = reinterpret_cast<float4*>(m)[i];
+        float4 V = reinterpret_cast<float4*>(v)[i];
+        adam1(P.x, G.x, M.x, V.x, gs, b1, b2, step_size, inv_sqrt_bc2, eps);
+        adam1(P.y, G.y, M.y, V.y, gs, b1, b2, step_size, inv_sqrt_bc2, eps);
+        adam1(P.z, G.z, M.z, V.z, gs, b1, b2, step_size, inv_sqrt_bc2, eps);
+        adam1(P.w, G.w, M.w, V.w, gs, b1, b2, step_size, inv_sqrt_bc2, eps);
+        reinterpret_cast<float4*>(p)[i] = P;
+        reinterpret_cast<float4*>(m)[i] = M;
+        reinterpret_cast<float4*>(v)[i] = V;
+        if (zero_grad) reinterpret_cast<float4*>(g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    // tail (n not a multiple of 4)
+    const long long t = (n4 << 2) + (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) {
+        adam1(p[t], g[t], m[t], v[t], gs, b1, b2, step_size, inv_sqrt_bc2, eps);
+        if (zero_grad) g[t] = 0.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_fill_uniform(float* __restrict__ x, long long n, unsigned long long seed, float lo,
+                                                      float hi) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        unsigned long long z = seed + (unsigned long long)(i + 1) * 0x9E3779B97F4A7C15ULL;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+        z = z ^ (z >> 31);
+        const float u = (float)(z >> 40) * (1.0f / 16777216.0f);
+        x[i] = lo + (hi - lo) * u;
+    }
+}
+
+}  // namespace snf
+
+using namespace snf;
+
+extern "C" int snf_version(void) { return 100; }
+extern "C" const char* snf_last_error(void) { return g_err; }
+
+extern "C" int snf_adam_step(float* p, float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                             float eps, int step, float grad_scale, int zero_grad, snf_stream_t stream) {
+    SNF_REQUIRE(p && g && m && v, "snf_adam_step: null pointer");
+    SNF_REQUIRE(n > 0 && step >= 1, "snf_adam_step: bad n=%lld step=%d", (long long)n, step);
+    SNF_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0,
+                "snf_adam_step: arena slices must be 16-byte aligned");
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    const float step_size = (float)((double)lr / bc1);
+    const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+    long long blocks = (n / 4 + 255) / 256;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_adam, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long long)n, beta1,
+                       beta2, step_size, inv_sqrt_bc2, eps, grad_scale, zero_grad);
+    SNF_LAUNCH_CHECK("snf_adam_step");
+    return SNF_OK;
+}
+
+extern "C" int snf_fill_uniform(float* x, int64_t n, uint64_t seed, float lo, float hi, snf_stream_t stream) {
+    SNF_REQUIRE(x && n > 0, "snf_fill_uniform: bad argument");
+    long long blocks = (n + 255) / 256;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    hipLaunchKernelGGL(k_fill_uniform, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, (long long)n,
+                       (unsigned long long)seed, lo, hi);
+    SNF_LAUNCH_CHECK("snf_fill_uniform");
+    return SNF_OK;
+}

@@ -1,0 +1,412 @@
+"""Python face of the C-ABI: thin `torch.autograd.Function`s around libsamnerf_hip.so.
+
+PyTorch is plumbing here (device memory, streams, autograd bookkeeping); every numeric step runs in a
+hand-written gfx950 kernel.  There is no CPU / eager fallback: tensors must live on a ROCm device.
+
+Gradient-arena convention: a parameter tensor may carry a `main_grad` attribute (an fp32 view into the
+model's flat gradient arena, see `arena.py`).  When present, the backward kernels accumulate straight into
+it and autograd receives `None` for that parameter -- no per-step zero-filled temporaries, and the arena is
+the RCCL all-reduce buffer.  Without it the functions behave like ordinary autograd ops.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+
+CONTRACT_NONE, CONTRACT_LINF, CONTRACT_L2 = 0, 1, 2
+ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
+ACT_BY_NAME = {None: ACT_NONE, "None": ACT_NONE, "none": ACT_NONE, "ReLU": ACT_RELU, "relu": ACT_RELU,
+               "Sigmoid": ACT_SIGMOID, "sigmoid": ACT_SIGMOID}
+
+
+def _L():
+    return _lib.load()
+
+
+def _p(t: Optional[torch.Tensor]):
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: expected a ROCm device tensor; the MI355X path has no CPU fallback")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        t = t.contiguous()
+    return t
+
+
+def _grad_target(param: torch.Tensor) -> Tuple[torch.Tensor, bool]:
+    """(buffer to accumulate into, whether autograd should get None)."""
+    mg = getattr(param, "main_grad", None)
+    if mg is not None:
+        return mg, True
+    return torch.zeros_like(param), False
+
+
+# ---------------------------------------------------------------------------------------------
+# no-grad sampling ops
+# ---------------------------------------------------------------------------------------------
+@torch.no_grad()
+def sample_spacing(nears, fars, num_samples: int, t_rand=None):
+    nears, fars = _chk(nears.reshape(-1), "nears"), _chk(fars.reshape(-1), "fars")
+    R = nears.numel()
+    t = None if t_rand is None else _chk(t_rand.reshape(-1), "t_rand")
+    sb = torch.empty((R, num_samples + 1), device=nears.device, dtype=torch.float32)
+    eb = torch.empty_like(sb)
+    _lib.check(_L().snf_sample_spacing(_p(nears), _p(fars), _p(t), R, num_samples, _p(sb), _p(eb), _stream()),
+               "snf_sample_spacing")
+    return sb, eb
+
+
+@torch.no_grad()
+def positions(origins, directions, ebins, ids=None, contraction: int = CONTRACT_LINF, use_selector: bool = True):
+    """-> (u [R*K,3] normalised positions, selector [R*K] uint8 or None)."""
+    origins, directions, ebins = _chk(origins, "origins"), _chk(directions, "directions"), _chk(ebins, "ebins")
+    R, n = ebins.shape[0], ebins.shape[1] - 1
+    if ids is not None:
+        ids = _chk(ids, "ids", torch.int32)
+        K = ids.shape[1]
+    else:
+        K = n
+    u = torch.empty((R * K, 3), device=ebins.device, dtype=torch.float32)
+    sel = torch.empty((R * K,), device=ebins.device, dtype=torch.uint8) if use_selector else None
+    _lib.check(_L().snf_positions(_p(origins), _p(directions), _p(ebins), _p(ids), R, n, K, contraction,
+                                  int(use_selector), _p(u), _p(sel), _stream()), "snf_positions")
+    return u, sel
+
+
+@torch.no_grad()
+def pdf_resample(weights, sbins_in, nears, fars, num_samples: int, u_rand=None, anneal: float = 1.0,
+                 histogram_padding: float = 0.01):
+    weights, sbins_in = _chk(weights, "weights"), _chk(sbins_in, "sbins_in")
+    nears, fars = _chk(nears.reshape(-1), "nears"), _chk(fars.reshape(-1), "fars")
+    R, Pn = weights.shape
+    u = None if u_rand is None else _chk(u_rand.reshape(-1), "u_rand")
+    sb = torch.empty((R, num_samples + 1), device=weights.device, dtype=torch.float32)
+    eb = torch.empty_like(sb)
+    _lib.check(_L().snf_pdf_resample(_p(weights), _p(sbins_in), _p(u), _p(nears), _p(fars), R, Pn, num_samples,
+                                     float(anneal), float(histogram_padding), _p(sb), _p(eb), _stream()),
+               "snf_pdf_resample")
+    return sb, eb
+
+
+@torch.no_grad()
+def topk_sharpen(weights, k: int, temperature: float = 10.0):
+    weights = _chk(weights, "weights")
+    R, S = weights.shape
+    ids = torch.empty((R, k), device=weights.device, dtype=torch.int32)
+    w = torch.empty((R, k), device=weights.device, dtype=torch.float32)
+    _lib.check(_L().snf_topk_sharpen(_p(weights), R, S, k, float(temperature), _p(ids), _p(w), _stream()),
+               "snf_topk_sharpen")
+    return w, ids
+
+
+@torch.no_grad()
+def render_depth_acc(weights, ebins, want_acc: bool = True):
+    """median depth [R,1] (+ accumulation [R,1]); no gradient (as in the reference's use)."""
+    weights, ebins = _chk(weights, "weights"), _chk(ebins, "ebins")
+    R, S = weights.shape
+    depth = torch.empty((R, 1), device=weights.device, dtype=torch.float32)
+    acc = torch.empty((R, 1), device=weights.device, dtype=torch.float32) if want_acc else None
+    _lib.check(_L().snf_composite_fwd(_p(None), _p(weights), _p(ebins), R, S, 1, _p(None), _p(acc), _p(depth),
+                                      _stream()), "snf_composite_fwd")
+    return depth, acc
+
+
+# ---------------------------------------------------------------------------------------------
+# hash grid
+# ---------------------------------------------------------------------------------------------
+class _HashGridMulti(torch.autograd.Function):
+    """One or more hash grids evaluated at the same points, outputs concatenated along the feature axis."""
+
+    @staticmethod
+    def forward(ctx, u, specs, *tables):
+        # specs: tuple of (scalings tensor, L, F, log2_T) per grid
+        u = _chk(u, "u")
+        N = u.shape[0]
+        total = sum(L * F for (_, L, F, _) in specs)
+        out = torch.empty((N, total), device=u.device, dtype=torch.float32)
+        col = 0
+        for (sc, L, F, T), tab in zip(specs, tables):
+            tab = _chk(tab, "table")
+            assert tab.numel() == (L << T) * F, "table size does not match (levels, log2_T, features)"
+            _lib.check(_L().snf_hashgrid_fwd(_p(u), _p(tab), _p(sc), N, L, F, T, _p(out), total, col, _stream()),
+                       "snf_hashgrid_fwd")
+            col += L * F
+        ctx.specs = specs
+        ctx.tables = tables
+        ctx.save_for_backward(u)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (u,) = ctx.saved_tensors
+        g = _chk(g, "grad_out")
+        N, total = g.shape
+        grads: List[Optional[torch.Tensor]] = []
+        col = 0
+        for (sc, L, F, T), tab in zip(ctx.specs, ctx.tables):
+            if not tab.requires_grad:
+                grads.append(None)
+            else:
+                buf, fused = _grad_target(tab)
+                _lib.check(_L().snf_hashgrid_bwd(_p(u), _p(g), _p(sc), N, L, F, T, total, col, _p(buf), _stream()),
+                           "snf_hashgrid_bwd")
+                grads.append(None if fused else buf)
+            col += L * F
+        return (None, None, *grads)
+
+
+def hashgrid(u, tables: Sequence[torch.Tensor], specs) -> torch.Tensor:
+    return _HashGridMulti.apply(u, tuple(specs), *tables)
+
+
+# ---------------------------------------------------------------------------------------------
+# dense layer
+# ---------------------------------------------------------------------------------------------
+class _Linear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, act: int):
+        x, w = _chk(x, "x"), _chk(w, "w")
+        N, I = x.shape
+        O = w.shape[0]
+        assert w.shape[1] == I
+        y = torch.empty((N, O), device=x.device, dtype=torch.float32)
+        _lib.check(_L().snf_linear_fwd(_p(x), _p(w), _p(b), N, I, O, I, O, act, _p(y), _stream()), "snf_linear_fwd")
+        ctx.act = act
+        ctx.wref, ctx.bref = w, b
+        ctx.save_for_backward(x, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, y = ctx.saved_tensors
+        w, b, act = ctx.wref, ctx.bref, ctx.act
+        gy = _chk(gy, "grad_y")
+        N, I = x.shape
+        O = w.shape[0]
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty((N, I), device=x.device, dtype=torch.float32)
+            _lib.check(_L().snf_linear_bwd_data(_p(gy), _p(y), _p(w), N, I, O, O, O, I, act, _p(gx), _stream()),
+                       "snf_linear_bwd_data")
+        if w.requires_grad or (b is not None and b.requires_grad):
+            wbuf, wfused = _grad_target(w)
+            bbuf, bfused = (None, True) if b is None else _grad_target(b)
+            _lib.check(_L().snf_linear_bwd_weight(_p(gy), _p(y), _p(x), N, I, O, O, O, I, act, _p(wbuf), _p(bbuf),
+                                                  _stream()), "snf_linear_bwd_weight")
+            gw = None if wfused else wbuf
+            gb = None if bfused else bbuf
+        return gx, gw, gb, None
+
+
+def linear(x, w, b=None, act: int = ACT_NONE) -> torch.Tensor:
+    return _Linear.apply(x, w, b, act)
+
+
+def mlp(x, weights: Sequence[torch.Tensor], biases=None, out_act: int = ACT_NONE) -> torch.Tensor:
+    n = len(weights)
+    for i, w in enumerate(weights):
+        b = None if biases is None else biases[i]
+        x = linear(x, w, b, ACT_RELU if i < n - 1 else out_act)
+    return x
+
+
+# ---------------------------------------------------------------------------------------------
+# colour-MLP input: SH16(dir) ++ geo features (columns 1.. of the base-MLP output)
+# ---------------------------------------------------------------------------------------------
+class _HeadInput(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, dirs, h, R: int, S: int):
+        dirs, h = _chk(dirs, "dirs"), _chk(h, "h")
+        n_geo = h.shape[1] - 1
+        out = torch.empty((R * S, 16 + n_geo), device=h.device, dtype=torch.float32)
+        geo = ctypes.c_void_p(h.data_ptr() + 4)
+        _lib.check(_L().snf_head_input(_p(dirs), geo, R, S, n_geo, h.shape[1], _p(out), 16 + n_geo, _stream()),
+                   "snf_head_input")
+        ctx.n_geo = n_geo
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        # d h[:, 1:] = g[:, 16:], d h[:, 0] = 0 (the density column gets its gradient from weights_from_raw)
+        gh = torch.zeros((g.shape[0], 1 + ctx.n_geo), device=g.device, dtype=g.dtype)
+        gh[:, 1:] = g[:, 16:]
+        return None, gh, None, None
+
+
+def head_input(dirs, h, R: int, S: int) -> torch.Tensor:
+    return _HeadInput.apply(dirs, h, R, S)
+
+
+# ---------------------------------------------------------------------------------------------
+# trunc_exp * selector + get_weights
+# ---------------------------------------------------------------------------------------------
+class _Weights(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h, selector, ebins, R: int, n: int):
+        """h [R*n, C]: column 0 is the pre-activation density."""
+        h, ebins = _chk(h, "h"), _chk(ebins, "ebins")
+        C = h.shape[1]
+        w = torch.empty((R, n), device=h.device, dtype=torch.float32)
+        _lib.check(_L().snf_weights_fwd(_p(h), C, _p(selector), _p(ebins), R, n, _p(w), _p(None), _stream()),
+                   "snf_weights_fwd")
+        ctx.save_for_backward(h, ebins)
+        ctx.selector = selector
+        ctx.dims = (R, n, C)
+        return w
+
+    @staticmethod
+    def backward(ctx, gw):
+        h, ebins = ctx.saved_tensors
+        R, n, C = ctx.dims
+        gw = _chk(gw, "grad_w")
+        gh = torch.zeros_like(h) if C > 1 else torch.empty_like(h)
+        _lib.check(_L().snf_weights_bwd(_p(h), C, _p(ctx.selector), _p(ebins), _p(gw), R, n, _p(gh), _stream()),
+                   "snf_weights_bwd")
+        return gh, None, None, None, None
+
+
+def weights_from_raw(h, selector, ebins, R: int, n: int) -> torch.Tensor:
+    return _Weights.apply(h, selector, ebins, R, n)
+
+
+# ---------------------------------------------------------------------------------------------
+# RGB composite ('last_sample' background)
+# ---------------------------------------------------------------------------------------------
+class _CompositeRGB(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rgb, weights, training: bool):
+        rgb, weights = _chk(rgb, "rgb"), _chk(weights, "weights")
+        R, S = weights.shape
+        out = torch.empty((R, 3), device=rgb.device, dtype=torch.float32)
+        _lib.check(_L().snf_composite_fwd(_p(rgb), _p(weights), _p(None), R, S, int(training), _p(out), _p(None),
+                                          _p(None), _stream()), "snf_composite_fwd")
+        ctx.save_for_backward(rgb, weights)
+        ctx.training = training
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        if not ctx.training:
+            raise RuntimeError("composite_rgb backward is defined for training mode only (eval renders under no_grad)")
+        rgb, weights = ctx.saved_tensors
+        R, S = weights.shape
+        g = _chk(g, "grad_rgb")
+        grgb = torch.empty_like(rgb)
+        gw = torch.empty_like(weights)
+        _lib.check(_L().snf_composite_bwd(_p(rgb), _p(weights), _p(g), R, S, _p(grgb), _p(gw), _stream()),
+                   "snf_composite_bwd")
+        return grgb, gw, None
+
+
+def composite_rgb(rgb, weights, training: bool) -> torch.Tensor:
+    """rgb [R,S,3] (or [R*S,3]), weights [R,S] -> [R,3]."""
+    return _CompositeRGB.apply(rgb, weights, training)
+
+
+# ---------------------------------------------------------------------------------------------
+# MeanRenderer
+# ---------------------------------------------------------------------------------------------
+class _FeatureMean(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, embeds, w, R: int, K: int):
+        embeds, w = _chk(embeds, "embeds"), _chk(w, "w")
+        C = embeds.shape[-1]
+        out = torch.empty((R, C), device=embeds.device, dtype=torch.float32)
+        _lib.check(_L().snf_feature_mean_fwd(_p(embeds), _p(w), R, K, C, _p(out), _stream()), "snf_feature_mean_fwd")
+        ctx.save_for_backward(w)
+        ctx.dims = (R, K, C)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (w,) = ctx.saved_tensors
+        R, K, C = ctx.dims
+        g = _chk(g, "grad_out")
+        ge = torch.empty((R * K, C), device=g.device, dtype=torch.float32)
+        _lib.check(_L().snf_feature_mean_bwd(_p(g), _p(w), R, K, C, _p(ge), _stream()), "snf_feature_mean_bwd")
+        return ge, None, None, None
+
+
+def feature_mean(embeds, w, R: int, K: int) -> torch.Tensor:
+    """embeds [R*K, C]; w [R,K] (treated as a constant, as the reference detaches it)."""
+    return _FeatureMean.apply(embeds, w.detach(), R, K)
+
+
+# ---------------------------------------------------------------------------------------------
+# regularisers: value + gradient in one kernel pass each
+# ---------------------------------------------------------------------------------------------
+class _Interlevel(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, w_prop, sbins_prop, sbins_fine, w_fine):
+        w_prop, sbins_prop = _chk(w_prop, "w_prop"), _chk(sbins_prop, "sbins_prop")
+        sbins_fine, w_fine = _chk(sbins_fine, "sbins_fine"), _chk(w_fine, "w_fine")
+        R, Pn = w_prop.shape
+        S = w_fine.shape[1]
+        rows = torch.empty((R,), device=w_prop.device, dtype=torch.float32)
+        need = ctx.needs_input_grad[0]
+        gwp = torch.empty_like(w_prop) if need else None
+        _lib.check(_L().snf_interlevel(_p(sbins_fine), _p(w_fine), _p(sbins_prop), _p(w_prop), R, S, Pn,
+                                       1.0 / float(R * S), _p(rows), _p(gwp), _stream()), "snf_interlevel")
+        ctx.gwp = gwp
+        return rows.sum() / float(R * S)
+
+    @staticmethod
+    def backward(ctx, g):
+        return (ctx.gwp * g if ctx.gwp is not None else None), None, None, None
+
+
+def interlevel_loss(w_prop, sbins_prop, sbins_fine, w_fine) -> torch.Tensor:
+    """mean(clip(w - w_outer, 0)^2 / (w + 1e-7)); gradient flows to w_prop only (fine side is detached)."""
+    return _Interlevel.apply(w_prop, sbins_prop, sbins_fine.detach(), w_fine.detach())
+
+
+class _Distortion(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, w, sbins):
+        w, sbins = _chk(w, "w"), _chk(sbins, "sbins")
+        R, S = w.shape
+        rows = torch.empty((R,), device=w.device, dtype=torch.float32)
+        need = ctx.needs_input_grad[0]
+        gw = torch.empty_like(w) if need else None
+        _lib.check(_L().snf_distortion(_p(sbins), _p(w), R, S, 1.0 / float(R), _p(rows), _p(gw), _stream()),
+                   "snf_distortion")
+        ctx.gw = gw
+        return rows.sum() / float(R)
+
+    @staticmethod
+    def backward(ctx, g):
+        return (ctx.gw * g if ctx.gw is not None else None), None
+
+
+def distortion_loss(w, sbins) -> torch.Tensor:
+    return _Distortion.apply(w, sbins)
+
+
+# ---------------------------------------------------------------------------------------------
+# arena kernels
+# ---------------------------------------------------------------------------------------------
+@torch.no_grad()
+def adam_step_(p, g, m, v, lr: float, beta1: float, beta2: float, eps: float, step: int, grad_scale: float = 1.0,
+               zero_grad: bool = True) -> None:
+    for t in (p, g, m, v):
+        assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+    _lib.check(_L().snf_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), float(lr), float(beta1), float(beta2),
+                                  float(eps), int(step), float(grad_scale), int(zero_grad), _stream()), "snf_adam_step")
+
+
+@torch.no_grad()
+def fill_uniform_(x, seed: int, lo: float, hi: float) -> None:
+    assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
+    _lib.check(_L().snf_fill_uniform(_p(x), x.numel(), int(seed), float(lo), float(hi), _stream()), "snf_fill_uniform")

@@ -1,0 +1,316 @@
+"""GPU parity tests: every C-ABI kernel (called through samnerf_amd.ops) against the reference-generated golden
+vectors and against the CPU oracle on seeded inputs.  Tolerances are stated per test; the north-star bar is
+1e-4 on rendered RGB / feature tensors."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import samnerf_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def ops():
+    import samnerf_amd.ops as m
+    return m
+
+
+def G(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to(DEV)
+
+
+def maxdiff(a, b):
+    a, b = a.detach().cpu().double(), torch.as_tensor(b).detach().cpu().double()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    nan = torch.isnan(a) & torch.isnan(b)
+    d = torch.where(nan, torch.zeros_like(a), (a - b).abs())
+    assert not torch.isnan(d).any(), "NaN pattern differs"
+    return float(d.max()) if d.numel() else 0.0
+
+
+def specs_of(scalings, L, F, T):
+    return ((G(scalings), int(L), int(F), int(T)),)
+
+
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("mode", ["train", "eval"])
+def test_spacing_and_positions(golden, mode):
+    g = golden(f"spacing_{mode}")
+    t = G(g["t_rand"]) if mode == "train" else None
+    sb, eb = ops().sample_spacing(G(g["nears"]), G(g["fars"]), 64, t)
+    assert maxdiff(sb, np.broadcast_to(g["sbins"], sb.shape)) <= 1e-7
+    assert maxdiff(eb, g["ebins"]) <= 1e-4 * 1e-2  # |ebins| up to 1e3: relative check below
+    rel = (eb.cpu() - torch.from_numpy(g["ebins"])).abs() / torch.from_numpy(g["ebins"]).abs().clamp_min(1e-6)
+    assert float(rel.max()) <= 2e-6
+    u, sel = ops().positions(G(g["origins"]), G(g["directions"]), G(g["ebins"]), None, 0, False)
+    ref = (torch.from_numpy(g["positions"]).reshape(-1, 3) + 2.0) / 4.0
+    assert sel is None
+    assert maxdiff(u, ref) <= 1e-6 * float(ref.abs().max())
+
+
+def test_contraction(golden):
+    g = golden("contraction")
+    x = G(g["x"])
+    n = x.shape[0]
+    zeros = torch.zeros_like(x)
+    eb = torch.zeros((n, 2), device=DEV)
+    u, sel = ops().positions(x, zeros, eb, None, 1, True)
+    assert maxdiff(u, g["u_linf_sel"]) <= 1e-7
+    assert torch.equal(sel.cpu().bool(), torch.from_numpy(g["selector"]))
+    u2, _ = ops().positions(x, zeros, eb, None, 2, False)
+    assert maxdiff(u2, (torch.from_numpy(g["l2"]) + 2.0) / 4.0) <= 2e-7
+
+
+@pytest.mark.parametrize("name", ["prop", "field", "feat_a", "feat_b"])
+@pytest.mark.parametrize("log2_T", [10, 12])
+def test_hashgrid_golden(golden, name, log2_T):
+    g = golden(f"hashgrid_{name}_T{log2_T}")
+    table = G(g["table"]).requires_grad_(True)
+    sp = specs_of(g["scalings"], g["levels"], g["features"], g["log2_T"])
+    out = ops().hashgrid(G(g["u"]), [table], sp)
+    assert maxdiff(out, g["out"]) <= 1e-6
+    (out * G(g["grad_out"])).sum().backward()
+    assert maxdiff(table.grad, g["grad_table"]) <= 2e-5
+
+
+def test_hashgrid_two_grids_concat_and_large():
+    """two F=8 grids into one [N,192] buffer (the SAM head layout) at a size the oracle still handles."""
+    gen = torch.Generator().manual_seed(0)
+    N, T = 20000, 15
+    ga, gb = O.GridSpec(12, 8, T, 16, 128), O.GridSpec(12, 8, T, 128, 512)
+    ta = (torch.rand((ga.rows, 8), generator=gen) * 2 - 1) * 0.1
+    tb = (torch.rand((gb.rows, 8), generator=gen) * 2 - 1) * 0.1
+    u = torch.rand((N, 3), generator=gen)
+    gy = torch.randn((N, 192), generator=gen)
+    ta_c, tb_c = ta.clone().requires_grad_(True), tb.clone().requires_grad_(True)
+    ref = torch.cat([O.hashgrid_fwd(u, ta_c, ga.scalings(), T), O.hashgrid_fwd(u, tb_c, gb.scalings(), T)], -1)
+    (ref * gy).sum().backward()
+    ta_g, tb_g = ta.to(DEV).requires_grad_(True), tb.to(DEV).requires_grad_(True)
+    sp = ((ga.scalings().to(DEV), 12, 8, T), (gb.scalings().to(DEV), 12, 8, T))
+    out = ops().hashgrid(u.to(DEV), [ta_g, tb_g], sp)
+    assert maxdiff(out, ref) <= 1e-6
+    (out * gy.to(DEV)).sum().backward()
+    scale = float(ta_c.grad.abs().max())
+    assert maxdiff(ta_g.grad, ta_c.grad) <= 1e-5 * max(scale, 1.0)
+    assert maxdiff(tb_g.grad, tb_c.grad) <= 1e-5 * max(scale, 1.0)
+
+
+@pytest.mark.parametrize("name", ["prop_nobias", "prop_bias", "base_nobias", "base_bias", "head_nobias", "head_bias",
+                                  "sam_nobias", "clipseg_nobias"])
+def test_mlp_golden(golden, name):
+    g = golden("mlp_" + name)
+    n = int(g["n_layers"])
+    ws = [G(g[f"w{i}"]).requires_grad_(True) for i in range(n)]
+    bs = [G(g[f"b{i}"]).requires_grad_(True) for i in range(n)] if "b0" in g else None
+    x = G(g["x"]).requires_grad_(True)
+    act = ops().ACT_BY_NAME[str(g["out_act"])]
+    y = ops().mlp(x, ws, bs, act)
+    assert maxdiff(y, g["y"]) <= 2e-6
+    (y * G(g["grad_y"])).sum().backward()
+    assert maxdiff(x.grad, g["grad_x"]) <= 1e-5
+    for i in range(n):
+        ref = g[f"gw{i}"]
+        assert maxdiff(ws[i].grad, ref) <= 2e-5 * max(1.0, float(np.abs(ref).max()))
+        if bs is not None:
+            refb = g[f"gb{i}"]
+            assert maxdiff(bs[i].grad, refb) <= 2e-5 * max(1.0, float(np.abs(refb).max()))
+
+
+def test_linear_large_ragged():
+    """row counts that are not tile multiples, widths that are not multiples of 4."""
+    gen = torch.Generator().manual_seed(3)
+    for (N, I, Oo, act) in [(1000, 31, 64, "relu"), (4099, 192, 256, "relu"), (777, 256, 192, None),
+                            (513, 10, 16, "relu"), (2049, 64, 3, "sigmoid"), (300, 16, 1, None)]:
+        x = torch.randn((N, I), generator=gen) * 0.5
+        w = O._linear_init(Oo, I, gen)
+        gy = torch.randn((N, Oo), generator=gen)
+        xc, wc = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        yc = torch.nn.functional.linear(xc, wc)
+        yc = torch.relu(yc) if act == "relu" else (torch.sigmoid(yc) if act == "sigmoid" else yc)
+        (yc * gy).sum().backward()
+        xg, wg = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
+        yg = ops().linear(xg, wg, None, ops().ACT_BY_NAME[act])
+        assert maxdiff(yg, yc) <= 5e-6, (N, I, Oo)
+        (yg * gy.to(DEV)).sum().backward()
+        assert maxdiff(xg.grad, xc.grad) <= 1e-5, (N, I, Oo)
+        assert maxdiff(wg.grad, wc.grad) <= 1e-4 * max(1.0, float(wc.grad.abs().max())), (N, I, Oo)
+
+
+def test_head_input(golden):
+    g = golden("sh16")
+    d = G(g["directions"])
+    R, S = d.shape[0], 3
+    gen = torch.Generator().manual_seed(1)
+    h = torch.randn((R * S, 16), generator=gen).to(DEV).requires_grad_(True)
+    x = ops().head_input(d, h, R, S)
+    sh = torch.from_numpy(g["sh"])[:, None, :].expand(R, S, 16).reshape(-1, 16)
+    assert maxdiff(x[:, :16], sh) <= 1e-6
+    assert maxdiff(x[:, 16:], h.detach().cpu()[:, 1:]) == 0.0
+    gy = torch.randn(x.shape, generator=gen).to(DEV)
+    (x * gy).sum().backward()
+    assert maxdiff(h.grad[:, 1:], gy[:, 16:]) == 0.0
+    assert float(h.grad[:, 0].abs().max()) == 0.0
+
+
+def test_weights(golden):
+    g = golden("weights")
+    dens = torch.from_numpy(g["density"])
+    R, n = dens.shape
+    rows = torch.from_numpy(g["finite_rows"]).long()
+    # rebuild the inputs the kernel wants: raw = log(density) (finite rows), ebins from deltas
+    deltas = torch.from_numpy(g["deltas"])
+    eb = torch.cat([torch.zeros((R, 1)), torch.cumsum(deltas.double(), -1).float()], -1)
+    deltas_k = eb[:, 1:] - eb[:, :-1]  # what the kernel will see
+    good = [int(r) for r in rows if torch.isfinite(torch.log(dens[r])).all()]
+    raw = torch.log(dens[good]).reshape(-1, 1)
+    rc = raw.clone().requires_grad_(True)
+    wc = O.weights_from_density(O.trunc_exp(rc).reshape(len(good), n), deltas_k[good])
+    gw = torch.from_numpy(g["grad_w"])[good]
+    (wc * gw).sum().backward()
+    rg = raw.to(DEV).requires_grad_(True)
+    wg = ops().weights_from_raw(rg, None, eb[good].contiguous().to(DEV), len(good), n)
+    assert maxdiff(wg, wc) <= 2e-6
+    (wg * gw.to(DEV)).sum().backward()
+    assert maxdiff(rg.grad, rc.grad) <= 1e-5 * max(1.0, float(rc.grad.abs().max()))
+
+
+def test_weights_selector_and_stride():
+    gen = torch.Generator().manual_seed(9)
+    R, n, C = 37, 128, 16
+    h = torch.randn((R * n, C), generator=gen)
+    sel = (torch.rand((R * n,), generator=gen) > 0.2)
+    eb = torch.sort(torch.rand((R, n + 1), generator=gen) * 4, dim=-1)[0]
+    hc = h.clone().requires_grad_(True)
+    dens = (O.trunc_exp(hc[:, :1]) * sel[:, None]).reshape(R, n)
+    wc = O.weights_from_density(dens, eb[:, 1:] - eb[:, :-1])
+    gw = torch.randn((R, n), generator=gen)
+    (wc * gw).sum().backward()
+    hg = h.to(DEV).requires_grad_(True)
+    wg = ops().weights_from_raw(hg, sel.to(torch.uint8).to(DEV), eb.to(DEV), R, n)
+    assert maxdiff(wg, wc) <= 2e-6
+    (wg * gw.to(DEV)).sum().backward()
+    assert maxdiff(hg.grad, hc.grad) <= 1e-5 * max(1.0, float(hc.grad.abs().max()))
+
+
+@pytest.mark.parametrize("mode", ["train", "eval"])
+def test_pdf(golden, mode):
+    g = golden(f"pdf_{mode}")
+    u = G(g["u_rand"]) if mode == "train" else None
+    sb, eb = ops().pdf_resample(G(g["weights"]), G(g["sbins_in"]), G(g["nears"]), G(g["fars"]), int(g["num_samples"]), u)
+    assert maxdiff(sb, g["sbins"]) <= 2e-6
+    rel = (eb.cpu() - torch.from_numpy(g["ebins"])).abs() / torch.from_numpy(g["ebins"]).abs().clamp_min(1e-3)
+    assert float(rel.max()) <= 1e-3  # e(b) is steep near b -> 1 (far = 1000)
+
+
+def test_pdf_anneal_vs_oracle():
+    gen = torch.Generator().manual_seed(4)
+    R, Pn, S = 200, 64, 128
+    w = torch.rand((R, Pn), generator=gen) ** 3
+    nears, fars = O.collider_near_far(R, True)
+    sb_in, _ = O.sample_spacing(nears, fars, Pn, torch.rand((R, 1), generator=gen))
+    u = torch.rand((R, 1), generator=gen)
+    ref = O.pdf_resample(torch.pow(w, 0.37), sb_in, S, u)
+    sb, _ = ops().pdf_resample(w.to(DEV), sb_in.to(DEV), nears.to(DEV), fars.to(DEV), S, u.to(DEV), anneal=0.37)
+    assert maxdiff(sb, ref) <= 5e-6
+
+
+def test_render(golden):
+    g = golden("render")
+    w, rgb, eb = G(g["weights"]), G(g["rgb_samples"]), G(g["ebins"])
+    assert maxdiff(ops().composite_rgb(rgb, w, True), g["rgb_train"]) <= 2e-6
+    assert maxdiff(ops().composite_rgb(rgb, w, False), g["rgb_eval"]) <= 2e-6
+    depth, acc = ops().render_depth_acc(w, eb)
+    assert maxdiff(acc, g["accumulation"]) <= 2e-6
+    assert maxdiff(depth, g["depth"]) <= 1e-6 * float(np.abs(g["depth"]).max())
+
+
+def test_render_backward():
+    gen = torch.Generator().manual_seed(12)
+    R, S = 50, 128
+    rgb = torch.rand((R, S, 3), generator=gen)
+    w = torch.rand((R, S), generator=gen) / S
+    gy = torch.randn((R, 3), generator=gen)
+    rc, wc = rgb.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    (O.render_rgb(rc, wc, True) * gy).sum().backward()
+    rg, wg = rgb.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
+    (ops().composite_rgb(rg, wg, True) * gy.to(DEV)).sum().backward()
+    assert maxdiff(rg.grad, rc.grad) <= 1e-6
+    assert maxdiff(wg.grad, wc.grad) <= 1e-5
+
+
+def test_topk_mean(golden):
+    g = golden("topk")
+    w = G(g["weights"])
+    K = int(g["k"])
+    sw, ids = ops().topk_sharpen(w, K, float(g["temperature"]))
+    nan_rows = set(g["nan_rows"].tolist())
+    rows = [r for r in range(w.shape[0]) if r not in nan_rows]
+    assert torch.equal(torch.sort(ids.cpu().long(), -1)[0][rows], torch.sort(torch.from_numpy(g["ids"]), -1)[0][rows])
+    for r in nan_rows:
+        assert torch.isnan(sw[r]).all()
+    feats = G(g["feats"])
+    R, S, C = feats.shape
+    emb = torch.gather(feats, 1, ids.long()[..., None].expand(-1, -1, C)).reshape(R * K, C).contiguous().requires_grad_(True)
+    mean = ops().feature_mean(emb, sw, R, K)
+    assert maxdiff(mean, g["mean"]) <= 2e-6
+    # backward on finite rows
+    gy = torch.zeros((R, C), device=DEV)
+    gy[rows] = 1.0
+    mean.backward(gy)
+    ref = (sw[:, :, None] * gy[:, None, :]).reshape(R * K, C)
+    assert maxdiff(emb.grad[[r * K + k for r in rows for k in range(K)]],
+                   ref[[r * K + k for r in rows for k in range(K)]]) <= 1e-7
+
+
+def test_losses(golden):
+    g = golden("losses")
+    wp = G(g["w_prop"]).requires_grad_(True)
+    wf = G(g["w_fine"]).requires_grad_(True)
+    li = ops().interlevel_loss(wp, G(g["sbins_prop"]), G(g["sbins_fine"]), wf)
+    ld = ops().distortion_loss(wf, G(g["sbins_fine"]))
+    assert abs(float(li) - float(g["interlevel"])) <= 1e-6 * max(1.0, abs(float(g["interlevel"])))
+    assert abs(float(ld) - float(g["distortion"])) <= 1e-6 * max(1.0, abs(float(g["distortion"])))
+    (li + ld).backward()
+    assert maxdiff(wp.grad, g["grad_w_prop"]) <= 1e-6
+    assert maxdiff(wf.grad, g["grad_w_fine"]) <= 1e-6
+
+
+def test_adam_matches_torch():
+    gen = torch.Generator().manual_seed(5)
+    n = 10007
+    p0 = torch.randn((n,), generator=gen)
+    ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([ref], lr=1e-2, eps=1e-15)
+    p = torch.zeros((n + 1,), device=DEV)[:n]  # arena slices are 16-B aligned in the product; here offset 0
+    p.copy_(p0)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    for step in range(1, 6):
+        gr = torch.randn((n,), generator=gen)
+        ref.grad = gr.clone()
+        opt.step()
+        gbuf = gr.to(DEV)
+        ops().adam_step_(p, gbuf, m, v, 1e-2, 0.9, 0.999, 1e-15, step, 1.0, True)
+        assert float(gbuf.abs().max()) == 0.0
+    assert maxdiff(p, ref) <= 2e-6
+
+
+def test_fill_uniform_matches_numpy():
+    from samnerf_amd.arena import fill_uniform_reference
+    x = torch.empty((100003,), device=DEV)
+    ops().fill_uniform_(x, 1234, -1e-3, 1e-3)
+    ref = fill_uniform_reference(100003, 1234, -1e-3, 1e-3)
+    assert maxdiff(x, torch.from_numpy(ref)) == 0.0
+
+
+def test_bad_arguments_raise():
+    from samnerf_amd._lib import SnfError
+    w = torch.rand((4, 300), device=DEV)
+    with pytest.raises(SnfError):
+        ops().topk_sharpen(w, 16)  # S > 256
+    with pytest.raises(RuntimeError):
+        ops().sample_spacing(torch.zeros(4), torch.ones(4), 8)  # CPU tensors: no fallback
