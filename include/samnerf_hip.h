@@ -94,13 +94,15 @@ int snf_head_input(const float* dirs, const float* geo, int R, int S, int n_geo,
 
 /* ---- a8+a9: trunc_exp (field_components/activations.py:24-40), selector mask and
  *      RaySamples.get_weights (nerfstudio/cameras/rays.py:141-163).
- * raw[(r*n+i)*raw_stride] = pre-activation density; selector [R*n] uint8 or NULL; ebins [R,n+1].
- * Out: weights [R,n]; density [R,n] (may be NULL). */
-int snf_weights_fwd(const float* raw, int raw_stride, const uint8_t* selector, const float* ebins, int R,
-                    int n, float* weights, float* density, snf_stream_t stream);
+ * raw[(r*n+i)*raw_stride] = pre-activation density (is_density == 0: sigma = exp(raw)*selector, backward
+ * through the truncated exp) or the density itself (is_density == 1: plain get_weights(densities));
+ * selector [R*n] uint8 or NULL; ebins [R,n+1].  Out: weights [R,n]; density [R,n] (may be NULL). */
+int snf_weights_fwd(const float* raw, int raw_stride, int is_density, const uint8_t* selector,
+                    const float* ebins, int R, int n, float* weights, float* density, snf_stream_t stream);
 /* grad_raw[(r*n+i)*raw_stride] = dL/draw  (overwrites that column only). */
-int snf_weights_bwd(const float* raw, int raw_stride, const uint8_t* selector, const float* ebins,
-                    const float* grad_weights, int R, int n, float* grad_raw, snf_stream_t stream);
+int snf_weights_bwd(const float* raw, int raw_stride, int is_density, const uint8_t* selector,
+                    const float* ebins, const float* grad_weights, int R, int n, float* grad_raw,
+                    snf_stream_t stream);
 
 /* ---- a10: PDFSampler.generate_ray_samples, include_original=False, single jitter
  *      (model_components/ray_samplers.py:298-367), preceded by the anneal pow of :583.

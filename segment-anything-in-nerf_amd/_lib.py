@@ -90,8 +90,8 @@ SIGNATURES = {
     "snf_linear_bwd_data": [P, P, P, I, I, I, I, I, I, I, P, P],
     "snf_linear_bwd_weight": [P, P, P, I, I, I, I, I, I, I, P, P, P],
     "snf_head_input": [P, P, I, I, I, I, P, I, P],
-    "snf_weights_fwd": [P, I, P, P, I, I, P, P, P],
-    "snf_weights_bwd": [P, I, P, P, P, I, I, P, P],
+    "snf_weights_fwd": [P, I, I, P, P, I, I, P, P, P],
+    "snf_weights_bwd": [P, I, I, P, P, P, I, I, P, P],
     "snf_pdf_resample": [P, P, P, P, P, I, I, I, F, F, P, P, P],
     "snf_composite_fwd": [P, P, P, I, I, I, P, P, P, P],
     "snf_composite_bwd": [P, P, P, I, I, P, P, P],

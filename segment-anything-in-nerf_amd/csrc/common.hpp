@@ -53,6 +53,16 @@ __device__ __forceinline__ float wave_incl_scan_rev(float v) {
     return v;
 }
 
+// exclusive scans derived from an inclusive one by a lane shift (never by subtraction: inf - inf, cancellation)
+__device__ __forceinline__ float shift_up1(float incl) {
+    const float t = __shfl_up(incl, 1, WAVE);
+    return lane_id() == 0 ? 0.f : t;
+}
+__device__ __forceinline__ float shift_down1(float incl) {
+    const float t = __shfl_down(incl, 1, WAVE);
+    return lane_id() == WAVE - 1 ? 0.f : t;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int d = WAVE / 2; d > 0; d >>= 1) v += __shfl_xor(v, d, WAVE);

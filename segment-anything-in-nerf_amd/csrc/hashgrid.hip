@@ -39,6 +39,10 @@ struct Corners {
 };
 
 __device__ __forceinline__ Corners corners_of(const float* __restrict__ u, int n, float s, uint32_t mask) {
+    // separately rounded product (no FMA into the subtraction below): the reference rounds `scaled` before
+    // taking floor / the fractional offset, and at resolution 2047 one ulp of `scaled` is 1e-4 of a cell.
+    // (HIP's __fmul_rn is a plain `*`, so contraction has to be switched off with the pragma.)
+#pragma clang fp contract(off)
     const float px = u[(size_t)n * 3 + 0] * s;
     const float py = u[(size_t)n * 3 + 1] * s;
     const float pz = u[(size_t)n * 3 + 2] * s;

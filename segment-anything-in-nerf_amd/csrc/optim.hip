@@ -58,6 +58,7 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, float* __re
 
 __global__ __launch_bounds__(256) void k_fill_uniform(float* __restrict__ x, long long n, unsigned long long seed, float lo,
                                                       float hi) {
+#pragma clang fp contract(off)
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         unsigned long long z = seed + (unsigned long long)(i + 1) * 0x9E3779B97F4A7C15ULL;
@@ -65,7 +66,7 @@ __global__ __launch_bounds__(256) void k_fill_uniform(float* __restrict__ x, lon
         z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
         z = z ^ (z >> 31);
         const float u = (float)(z >> 40) * (1.0f / 16777216.0f);
-        x[i] = lo + (hi - lo) * u;
+        x[i] = lo + (hi - lo) * u;  // separately rounded, as numpy does
     }
 }
 

@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void k_head_input(const float* __restrict__ di
 }
 
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_weights_fwd(const float* __restrict__ raw, int raw_stride,
+__global__ __launch_bounds__(256) void k_weights_fwd(const float* __restrict__ raw, int raw_stride, int is_density,
                                                      const uint8_t* __restrict__ selector,
                                                      const float* __restrict__ ebins, int R, int n,
                                                      float* __restrict__ weights, float* __restrict__ density) {
@@ -55,12 +55,13 @@ __global__ __launch_bounds__(256) void k_weights_fwd(const float* __restrict__ r
         float dd = 0.f, sigma = 0.f;
         if (i < n) {
             const size_t s = (size_t)r * n + i;
-            sigma = expf(raw[s * raw_stride]);
+            sigma = raw[s * raw_stride];
+            if (!is_density) sigma = expf(sigma);
             if (selector) sigma *= (float)selector[s];
             dd = (eb[i + 1] - eb[i]) * sigma;
         }
         const float inc = wave_incl_scan(dd);
-        const float excl = carry + (inc - dd);
+        const float excl = carry + shift_up1(inc);
         if (i < n) {
             const float alpha = 1.f - expf(-dd);
             const float T = expf(-excl);
@@ -73,7 +74,7 @@ __global__ __launch_bounds__(256) void k_weights_fwd(const float* __restrict__ r
 
 // dL/ddd_k = g_k * T_k * exp(-dd_k) - sum_{i>k} g_i * alpha_i * T_i ;  then through sigma = exp(raw)*sel with the
 // truncated-exp backward g * exp(clamp(raw,-15,15)).
-__global__ __launch_bounds__(256) void k_weights_bwd(const float* __restrict__ raw, int raw_stride,
+__global__ __launch_bounds__(256) void k_weights_bwd(const float* __restrict__ raw, int raw_stride, int is_density,
                                                      const uint8_t* __restrict__ selector,
                                                      const float* __restrict__ ebins, const float* __restrict__ gw, int R,
                                                      int n, float* __restrict__ grad_raw) {
@@ -93,10 +94,10 @@ __global__ __launch_bounds__(256) void k_weights_bwd(const float* __restrict__ r
                 rawv[c] = raw[s * raw_stride];
                 selv[c] = selector ? (float)selector[s] : 1.f;
                 delta[c] = eb[i + 1] - eb[i];
-                dd[c] = delta[c] * (expf(rawv[c]) * selv[c]);
+                dd[c] = delta[c] * ((is_density ? rawv[c] : expf(rawv[c])) * selv[c]);
             }
             const float inc = wave_incl_scan(dd[c]);
-            const float excl = carry + (inc - dd[c]);
+            const float excl = carry + shift_up1(inc);
             carry += __shfl(inc, WAVE - 1, WAVE);
             if (i < n) {
                 T[c] = expf(-excl);
@@ -116,13 +117,13 @@ __global__ __launch_bounds__(256) void k_weights_bwd(const float* __restrict__ r
         if (c * WAVE < n) {
             const int i = c * WAVE + lane;
             const float incl = wave_incl_scan_rev(gwt[c]);
-            const float after = tail + (incl - gwt[c]);
+            const float after = tail + shift_down1(incl);
             tail += __shfl(incl, 0, WAVE);
             if (i < n) {
                 const float gdd = gk[c] * T[c] * expf(-dd[c]) - after;
                 const float gsigma = gdd * delta[c];
                 const float xr = fminf(fmaxf(rawv[c], -15.f), 15.f);
-                grad_raw[((size_t)r * n + i) * raw_stride] = gsigma * selv[c] * expf(xr);
+                grad_raw[((size_t)r * n + i) * raw_stride] = gsigma * selv[c] * (is_density ? 1.f : expf(xr));
             }
         }
     }
@@ -247,22 +248,23 @@ extern "C" int snf_head_input(const float* dirs, const float* geo, int R, int S,
     return SNF_OK;
 }
 
-extern "C" int snf_weights_fwd(const float* raw, int raw_stride, const uint8_t* selector, const float* ebins, int R,
-                               int n, float* weights, float* density, snf_stream_t stream) {
+extern "C" int snf_weights_fwd(const float* raw, int raw_stride, int is_density, const uint8_t* selector,
+                               const float* ebins, int R, int n, float* weights, float* density, snf_stream_t stream) {
     SNF_REQUIRE(raw && ebins && weights, "snf_weights_fwd: null pointer");
     SNF_REQUIRE(R > 0 && n > 0 && n <= MAXC * WAVE && raw_stride >= 1, "snf_weights_fwd: bad shape R=%d n=%d", R, n);
     hipLaunchKernelGGL(k_weights_fwd, dim3(ceil_div(R, RAYS_PER_BLOCK)), dim3(256), 0, (hipStream_t)stream, raw,
-                       raw_stride, selector, ebins, R, n, weights, density);
+                       raw_stride, is_density, selector, ebins, R, n, weights, density);
     SNF_LAUNCH_CHECK("snf_weights_fwd");
     return SNF_OK;
 }
 
-extern "C" int snf_weights_bwd(const float* raw, int raw_stride, const uint8_t* selector, const float* ebins,
-                               const float* grad_weights, int R, int n, float* grad_raw, snf_stream_t stream) {
+extern "C" int snf_weights_bwd(const float* raw, int raw_stride, int is_density, const uint8_t* selector,
+                               const float* ebins, const float* grad_weights, int R, int n, float* grad_raw,
+                               snf_stream_t stream) {
     SNF_REQUIRE(raw && ebins && grad_weights && grad_raw, "snf_weights_bwd: null pointer");
     SNF_REQUIRE(R > 0 && n > 0 && n <= MAXC * WAVE && raw_stride >= 1, "snf_weights_bwd: bad shape R=%d n=%d", R, n);
     hipLaunchKernelGGL(k_weights_bwd, dim3(ceil_div(R, RAYS_PER_BLOCK)), dim3(256), 0, (hipStream_t)stream, raw,
-                       raw_stride, selector, ebins, grad_weights, R, n, grad_raw);
+                       raw_stride, is_density, selector, ebins, grad_weights, R, n, grad_raw);
     SNF_LAUNCH_CHECK("snf_weights_bwd");
     return SNF_OK;
 }

@@ -6,6 +6,10 @@
 // One 64-lane wavefront owns one ray; a 256-thread workgroup carries 4 rays.
 #include "common.hpp"
 
+// Bin edges go through ill-conditioned maps (1/(2-2y) near the far plane); evaluate them with separately rounded
+// mul/add exactly like the torch reference so that sample positions agree to the last bit.
+#pragma clang fp contract(off)
+
 namespace snf {
 
 constexpr int RAYS_PER_BLOCK = 4;

@@ -254,31 +254,49 @@ def head_input(dirs, h, R: int, S: int) -> torch.Tensor:
 # ---------------------------------------------------------------------------------------------
 class _Weights(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, h, selector, ebins, R: int, n: int):
-        """h [R*n, C]: column 0 is the pre-activation density."""
+    def forward(ctx, h, selector, ebins, R: int, n: int, is_density: bool):
+        """h [R*n, C]: column 0 is the pre-activation density (or the density itself when is_density)."""
         h, ebins = _chk(h, "h"), _chk(ebins, "ebins")
         C = h.shape[1]
         w = torch.empty((R, n), device=h.device, dtype=torch.float32)
-        _lib.check(_L().snf_weights_fwd(_p(h), C, _p(selector), _p(ebins), R, n, _p(w), _p(None), _stream()),
-                   "snf_weights_fwd")
+        _lib.check(_L().snf_weights_fwd(_p(h), C, int(is_density), _p(selector), _p(ebins), R, n, _p(w), _p(None),
+                                        _stream()), "snf_weights_fwd")
         ctx.save_for_backward(h, ebins)
         ctx.selector = selector
-        ctx.dims = (R, n, C)
+        ctx.dims = (R, n, C, int(is_density))
         return w
 
     @staticmethod
     def backward(ctx, gw):
         h, ebins = ctx.saved_tensors
-        R, n, C = ctx.dims
+        R, n, C, is_density = ctx.dims
         gw = _chk(gw, "grad_w")
         gh = torch.zeros_like(h) if C > 1 else torch.empty_like(h)
-        _lib.check(_L().snf_weights_bwd(_p(h), C, _p(ctx.selector), _p(ebins), _p(gw), R, n, _p(gh), _stream()),
-                   "snf_weights_bwd")
-        return gh, None, None, None, None
+        _lib.check(_L().snf_weights_bwd(_p(h), C, is_density, _p(ctx.selector), _p(ebins), _p(gw), R, n, _p(gh),
+                                        _stream()), "snf_weights_bwd")
+        return gh, None, None, None, None, None
 
 
 def weights_from_raw(h, selector, ebins, R: int, n: int) -> torch.Tensor:
-    return _Weights.apply(h, selector, ebins, R, n)
+    """fused trunc_exp * selector + get_weights from the pre-activation density column h[:, 0]."""
+    return _Weights.apply(h, selector, ebins, R, n, False)
+
+
+def weights_from_density(density, ebins) -> torch.Tensor:
+    """RaySamples.get_weights(densities): density [R,n] (or [R,n,1]) -> weights [R,n]."""
+    R, n = ebins.shape[0], ebins.shape[1] - 1
+    return _Weights.apply(density.reshape(R * n, 1), None, ebins, R, n, True)
+
+
+@torch.no_grad()
+def density_from_raw(h, selector, ebins, R: int, n: int) -> torch.Tensor:
+    """trunc_exp(h[:,0]) * selector as [R,n] (inspection / API parity; the train path uses weights_from_raw)."""
+    h, ebins = _chk(h, "h"), _chk(ebins, "ebins")
+    w = torch.empty((R, n), device=h.device, dtype=torch.float32)
+    d = torch.empty((R, n), device=h.device, dtype=torch.float32)
+    _lib.check(_L().snf_weights_fwd(_p(h), h.shape[1], 0, _p(selector), _p(ebins), R, n, _p(w), _p(d), _stream()),
+               "snf_weights_fwd")
+    return d
 
 
 # ---------------------------------------------------------------------------------------------
