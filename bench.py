@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the SAM-NeRF render-and-distill TRAIN STEP on MI355X.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A step = one full train iteration of the `samnerf_distill` method on one batch of synthetic rays: proposal
+sampling, nerfacto field, compositing, top-K feature branch (SAM 256-d + ClipSeg 192-d heads, conv head),
+losses, backward, gradient mean across ranks (RCCL) and the fused Adam update of all ~221 M parameters.
+Metric (BASELINE.json): ray-samples/s = ranks * R * S / t_step.  Weak scaling: every rank draws its own R rays.
+
+One JSON line is printed by rank 0; besides the driver's contract it carries
+  roofline      -- the dominant kernel of the step: algorithmic bytes (or flops) per launch / its HIP-event
+                   duration measured live in the timed region, against the MI355X peak;
+  cpu_baseline  -- the CPU oracle (oracle/samnerf_oracle.py, a port of the reference's torch path) timed on
+                   the host cores on a bounded sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import copy
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+WORKLOADS = {
+    # BASELINE.json configs[1..3]
+    "no_distill_4096x128": dict(method="samnerf_no_distill", R=4096, P=64, S=128, K=3, patch=1),
+    "distill_4096x128": dict(method="samnerf_distill", R=4096, P=64, S=128, K=16, patch=4),
+    "distill_16384x128": dict(method="samnerf_distill", R=16384, P=64, S=128, K=16, patch=4),
+}
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
+FP32_MATRIX_PEAK_TFLOPS = 157.3  # v_mfma_f32_32x32x2_f32
+
+
+def algorithmic_model(key: str, w: dict):
+    """(bound, units per launch, unit) for a kernel key 'entry/tag' -- requested bytes, no cache credit
+    (8 corners x F floats x 4 B per level per sample; backward = read-modify-write)."""
+    R, P, S, K = w["R"], w["P"], w["S"], w["K"]
+    name, _, tag = key.partition("/")
+    if name in ("snf_hashgrid_fwd", "snf_hashgrid_bwd"):
+        F = int(tag[1:])
+        rw = 2 if name.endswith("bwd") else 1
+        if F == 8:
+            n, L = R * K, 12
+        else:
+            # F=2 launches: proposal (R*P samples, 5 levels) and field (R*S, 16 levels); report the field grid
+            n, L = R * S, 16
+        return "hbm", float(n * L * 8 * F * 4 * rw), "GB/s"
+    if name.startswith("snf_linear"):
+        i, o = (int(x) for x in tag.split("x"))
+        n = R * K if max(i, o) >= 192 else R * S
+        return "mfma", 2.0 * n * i * o, "TFLOP/s"
+    if name == "snf_adam_step":
+        return "hbm", None, "GB/s"
+    return None, None, None
+
+
+def build_trainer(w: dict, local_rank: int, world: int, seed: int = 0):
+    import samnerf_amd  # noqa: F401
+    from samnerf_amd import configs, tcnn_compat
+    tc = copy.deepcopy(configs.method_configs[w["method"]])
+    dm, mc = tc.pipeline.datamanager, tc.pipeline.model
+    dm.train_num_rays_per_batch = w["R"]
+    dm.seed = seed
+    mc.num_proposal_samples_per_ray = (w["P"],)
+    mc.num_nerf_samples_per_ray = w["S"]
+    mc.num_sam_samples = w["K"]
+    tcnn_compat.manual_seed(seed)
+    trainer = tc.setup(local_rank=local_rank, world_size=world, device=f"cuda:{local_rank}")
+    trainer.setup()
+    return trainer
+
+
+def cpu_baseline(w: dict, budget_s: float):
+    """Time the CPU oracle (fwd + bwd of the same step, full-size tables) on a bounded number of rays."""
+    from oracle import samnerf_oracle as O
+    # torch's CPU kernels stop scaling (and start thrashing) far below the 256 hardware threads of the GPU box
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    distill = w["method"] == "samnerf_distill"
+    cfg = O.PathConfig(num_proposal_samples=w["P"], num_nerf_samples=w["S"], num_sam_samples=w["K"],
+                       patch_size=w["patch"], distill_sam=distill, use_clipseg=distill)
+    R = 128
+    params = {k: v.requires_grad_(True) for k, v in O.init_params(cfg, seed=0).items()}
+    o, d = O.synthetic_rays(R, 0)
+    batch = O.synthetic_batch(cfg, R, 1)
+    gen = torch.Generator().manual_seed(2)
+    t_rand, u_rand = torch.rand((R, 1), generator=gen), torch.rand((R, 1), generator=gen)
+
+    def step():
+        for p in params.values():
+            p.grad = None
+        out = O.forward(params, cfg, o, d, True, t_rand, u_rand, 1.0)
+        sum(O.loss_dict(out, batch, cfg).values()).backward()
+
+    t_w = time.perf_counter()
+    step()  # warm-up (page faults of the 0.9 GB tables, thread pool)
+    t_w = time.perf_counter() - t_w
+    t0, n = time.perf_counter(), 0
+    while True:
+        step()
+        n += 1
+        el = time.perf_counter() - t0
+        if el + t_w >= budget_s or n >= 10:
+            break
+    return {"value": R * w["S"] * n / el, "unit": "ray-samples/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} fwd+bwd steps of {R} rays x {w['S']} samples (P={w['P']}, K={w['K']}), full-size fp32 "
+                      f"tables, no optimizer step, {el:.1f} s of CPU work"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="distill_4096x128", choices=sorted(WORKLOADS))
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0)
+    ap.add_argument("--roofline-kernel", default=None, help="kernel key 'entry/tag' to time live (default: auto)")
+    args = ap.parse_args()
+    w = WORKLOADS[args.workload]
+
+    import samnerf_amd  # noqa: F401
+    from samnerf_amd import distributed as D
+    from samnerf_amd import ops
+    import torch.distributed as dist
+
+    rank, local_rank, world = D.init_distributed()
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    trainer = build_trainer(w, local_rank, world)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    # ---- warm-up; its last steps run with every kernel timed, to find the dominant one
+    step = 0
+    n_break = min(3, max(args.warmup - 1, 1))
+    for i in range(args.warmup):
+        if i == args.warmup - n_break:
+            torch.cuda.synchronize()
+            ops.enable_kernel_timing("all")
+        trainer.train_iteration(step)
+        step += 1
+    breakdown = ops.kernel_timing_summary() if args.warmup > 0 else {}
+    ops.enable_kernel_timing(None)
+    per_step = {k: v["total_ms"] / n_break for k, v in breakdown.items()}
+    dom = args.roofline_kernel
+    if dom is None and per_step:
+        modelled = [k for k in per_step if algorithmic_model(k, w)[1]]
+        dom = max(modelled, key=lambda k: per_step[k]) if modelled else None
+    if dom is not None:
+        ops.enable_kernel_timing([dom])
+
+    # ---- timed region: EXACTLY --steps train iterations between barrier + synchronize
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        trainer.train_iteration(step)
+        step += 1
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    live = ops.kernel_timing_summary() if dom is not None else {}
+    ops.enable_kernel_timing(None)
+
+    if rank == 0:
+        R, S, K = w["R"], w["S"], w["K"]
+        ms = elapsed / args.steps * 1e3
+        roofline = None
+        if dom is not None and dom in live:
+            bound, units, unit = algorithmic_model(dom, w)
+            avg_ms = live[dom]["avg_ms"]
+            achieved = units / (avg_ms * 1e-3) / (1e9 if bound == "hbm" else 1e12)
+            peak = HBM_PEAK_GBPS if bound == "hbm" else FP32_MATRIX_PEAK_TFLOPS
+            roofline = {"kernel": dom, "bound": bound, "achieved": round(achieved, 2), "peak": peak, "unit": unit,
+                        "frac": round(achieved / peak, 4), "traffic": None,
+                        "avg_launch_ms": round(avg_ms, 4), "launches_timed": live[dom]["launches"],
+                        "algorithmic_units_per_launch": units}
+        # algorithmic bytes of the whole step, for the step-level fraction
+        feat = K * 12288 if w["method"] == "samnerf_distill" else 0
+        b_step = 3 * (w["P"] * 320 + S * 1024 + feat) * R
+        out = {
+            "metric": "ray-samples/sec (train step, samnerf_distill 256-d feat head)",
+            "value": world * R * S * args.steps / elapsed, "unit": "ray-samples/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{w['method']} R={R} rays/GPU x S={S} fine samples, P={w['P']} proposal samples, "
+                                   f"K={K} feature samples, patch {w['patch']}, SAM 256-d"
+                                   + (" + ClipSeg 192-d heads" if w["method"] == "samnerf_distill" else "")
+                                   + ", full-size fp32 tables (T=19), fwd+bwd+RCCL grad mean+fused Adam",
+                       "name": args.workload, "rays_per_gpu": R, "parallelism": f"ray-dp{world}"},
+            "rays_per_s": world * R * args.steps / elapsed,
+            "step_algorithmic_GBps": b_step / (ms * 1e-3) / 1e9,
+            "step_frac_of_hbm_peak": b_step / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+            "roofline": roofline,
+            "kernel_ms_per_step": {k: round(v, 4) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1])},
+        }
+        if world == 1 and args.cpu_baseline_seconds > 0:
+            out["cpu_baseline"] = cpu_baseline(w, args.cpu_baseline_seconds)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -104,6 +104,14 @@ int snf_weights_bwd(const float* raw, int raw_stride, int is_density, const uint
                     const float* ebins, const float* grad_weights, int R, int n, float* grad_raw,
                     snf_stream_t stream);
 
+/* ---- a8 alone: density = trunc_exp(raw) * selector, the tail of Field.get_density
+ *      (fields/nerfacto_field.py:260-265, fields/density_fields.py:120-124, activations.py:24-40).
+ * raw[t*raw_stride], selector [N] uint8 or NULL -> density [N]; backward writes grad_raw[t*raw_stride]. */
+int snf_trunc_exp_fwd(const float* raw, int raw_stride, const uint8_t* selector, int64_t N, float* density,
+                      snf_stream_t stream);
+int snf_trunc_exp_bwd(const float* raw, int raw_stride, const uint8_t* selector, const float* grad_density,
+                      int64_t N, float* grad_raw, snf_stream_t stream);
+
 /* ---- a10: PDFSampler.generate_ray_samples, include_original=False, single jitter
  *      (model_components/ray_samplers.py:298-367), preceded by the anneal pow of :583.
  * weights [R,P]; sbins_in [R,P+1]; u_rand [R] or NULL (eval); nears,fars [R].

@@ -92,6 +92,8 @@ SIGNATURES = {
     "snf_head_input": [P, P, I, I, I, I, P, I, P],
     "snf_weights_fwd": [P, I, I, P, P, I, I, P, P, P],
     "snf_weights_bwd": [P, I, I, P, P, P, I, I, P, P],
+    "snf_trunc_exp_fwd": [P, I, P, c_int64, P, P],
+    "snf_trunc_exp_bwd": [P, I, P, P, c_int64, P, P],
     "snf_pdf_resample": [P, P, P, P, P, I, I, I, F, F, P, P, P],
     "snf_composite_fwd": [P, P, P, I, I, I, P, P, P, P],
     "snf_composite_bwd": [P, P, P, I, I, P, P, P],
@@ -112,6 +114,9 @@ def load(auto_build: bool = True) -> ctypes.CDLL:
     global _LIB
     if _LIB is not None:
         return _LIB
+    # torch must come first: it brings its own HIP runtime (libamdhip64); dlopen-ing ours before torch would bind the
+    # process to a second runtime copy and torch then sees "no ROCm-capable device".
+    import torch  # noqa: F401
     if auto_build and needs_build():
         build()
     if not os.path.exists(LIB_PATH):

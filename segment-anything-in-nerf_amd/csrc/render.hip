@@ -130,6 +130,30 @@ __global__ __launch_bounds__(256) void k_weights_bwd(const float* __restrict__ r
 }
 
 // ------------------------------------------------------------------------------------------
+// density = trunc_exp(raw) * selector (Field.get_density tail: nerfacto_field.py:260-265, density_fields.py:120-124)
+__global__ __launch_bounds__(256) void k_trunc_exp_fwd(const float* __restrict__ raw, int raw_stride,
+                                                       const uint8_t* __restrict__ selector, long long N,
+                                                       float* __restrict__ density) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= N) return;
+    float d = expf(raw[t * raw_stride]);
+    if (selector) d *= (float)selector[t];
+    density[t] = d;
+}
+
+__global__ __launch_bounds__(256) void k_trunc_exp_bwd(const float* __restrict__ raw, int raw_stride,
+                                                       const uint8_t* __restrict__ selector,
+                                                       const float* __restrict__ gd, long long N,
+                                                       float* __restrict__ grad_raw) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= N) return;
+    const float x = fminf(fmaxf(raw[t * raw_stride], -15.f), 15.f);
+    float g = gd[t] * expf(x);
+    if (selector) g *= (float)selector[t];
+    grad_raw[t * raw_stride] = g;
+}
+
+// ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_composite_fwd(const float* __restrict__ rgb, const float* __restrict__ weights,
                                                        const float* __restrict__ ebins, int R, int S, int training,
                                                        float* __restrict__ out_rgb, float* __restrict__ out_acc,
@@ -266,6 +290,24 @@ extern "C" int snf_weights_bwd(const float* raw, int raw_stride, int is_density,
     hipLaunchKernelGGL(k_weights_bwd, dim3(ceil_div(R, RAYS_PER_BLOCK)), dim3(256), 0, (hipStream_t)stream, raw,
                        raw_stride, is_density, selector, ebins, grad_weights, R, n, grad_raw);
     SNF_LAUNCH_CHECK("snf_weights_bwd");
+    return SNF_OK;
+}
+
+extern "C" int snf_trunc_exp_fwd(const float* raw, int raw_stride, const uint8_t* selector, int64_t N, float* density,
+                                 snf_stream_t stream) {
+    SNF_REQUIRE(raw && density && N > 0 && raw_stride >= 1, "snf_trunc_exp_fwd: bad argument");
+    hipLaunchKernelGGL(k_trunc_exp_fwd, dim3(ceil_div(N, 256)), dim3(256), 0, (hipStream_t)stream, raw, raw_stride,
+                       selector, (long long)N, density);
+    SNF_LAUNCH_CHECK("snf_trunc_exp_fwd");
+    return SNF_OK;
+}
+
+extern "C" int snf_trunc_exp_bwd(const float* raw, int raw_stride, const uint8_t* selector, const float* grad_density,
+                                 int64_t N, float* grad_raw, snf_stream_t stream) {
+    SNF_REQUIRE(raw && grad_density && grad_raw && N > 0 && raw_stride >= 1, "snf_trunc_exp_bwd: bad argument");
+    hipLaunchKernelGGL(k_trunc_exp_bwd, dim3(ceil_div(N, 256)), dim3(256), 0, (hipStream_t)stream, raw, raw_stride,
+                       selector, grad_density, (long long)N, grad_raw);
+    SNF_LAUNCH_CHECK("snf_trunc_exp_bwd");
     return SNF_OK;
 }
 

@@ -1,0 +1,89 @@
+"""Optimiser / scheduler / trainer contract of the reference (nerfstudio/engine/optimizers.py:30-179,
+schedulers.py:60-109, trainer.py:409-440) on the flat arenas: one fused Adam launch per parameter group,
+gradient zeroing folded into it, learning rates from the reference's exponential-decay formula."""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Any, Dict, List, Optional, Type
+
+import numpy as np
+import torch
+
+from . import ops
+from .arena import ParamGroupArena
+
+
+@dataclass
+class AdamOptimizerConfig:
+    lr: float = 0.0005
+    eps: float = 1e-08
+    max_norm: Optional[float] = None
+    weight_decay: float = 0
+    betas: tuple = (0.9, 0.999)
+
+
+@dataclass
+class ExponentialDecaySchedulerConfig:
+    lr_pre_warmup: float = 1e-8
+    lr_final: Optional[float] = None
+    warmup_steps: int = 0
+    max_steps: int = 100000
+    ramp: str = "cosine"
+
+    def lr_at(self, step: int, lr_init: float) -> float:
+        """schedulers.py:86-105 (returns the learning rate, not the LambdaLR multiplier)."""
+        lr_final = lr_init if self.lr_final is None else self.lr_final
+        if step < self.warmup_steps:
+            if self.ramp == "cosine":
+                return (self.lr_pre_warmup + (1 - self.lr_pre_warmup)
+                        * np.sin(0.5 * np.pi * np.clip(step / self.warmup_steps, 0, 1)))
+            return self.lr_pre_warmup + (lr_init - self.lr_pre_warmup) * step / self.warmup_steps
+        t = np.clip((step - self.warmup_steps) / (self.max_steps - self.warmup_steps), 0, 1)
+        return float(np.exp(np.log(lr_init) * (1 - t) + np.log(lr_final) * t))
+
+
+class Optimizers:
+    """optimizers.py:92-179 with arenas instead of torch.optim objects."""
+
+    def __init__(self, config: Dict[str, Any], arenas: Dict[str, ParamGroupArena]) -> None:
+        missing = [k for k in arenas if k not in config]
+        if missing:
+            raise KeyError(f"no optimizer configured for parameter groups {missing}")
+        self.config = config
+        self.arenas = arenas
+        self.step_count = {k: 0 for k in arenas}
+        self.sched_step = {k: 0 for k in arenas}
+        for k, a in arenas.items():
+            if config[k]["optimizer"].weight_decay or config[k]["optimizer"].max_norm is not None:
+                raise NotImplementedError("weight decay / clipping are not used by the samnerf configs")
+            if a.exp_avg is None:
+                raise ValueError("arena built without optimizer state")
+
+    def lr(self, group: str) -> float:
+        oc, sc = self.config[group]["optimizer"], self.config[group].get("scheduler")
+        return oc.lr if sc is None else sc.lr_at(self.sched_step[group], oc.lr)
+
+    def zero_grad_all(self) -> None:
+        for a in self.arenas.values():
+            a.grad.zero_()
+
+    def optimizer_step_all(self, grad_scale: float = 1.0, zero_grad: bool = True) -> None:
+        for k, a in self.arenas.items():
+            oc = self.config[k]["optimizer"]
+            self.step_count[k] += 1
+            ops.adam_step_(a.param, a.grad, a.exp_avg, a.exp_avg_sq, self.lr(k), oc.betas[0], oc.betas[1], oc.eps,
+                           self.step_count[k], grad_scale, zero_grad)
+
+    def scheduler_step_all(self, step: int) -> None:
+        for k in self.sched_step:
+            self.sched_step[k] += 1
+
+    def state_dict(self) -> Dict[str, Any]:
+        return {k: {"exp_avg": a.exp_avg, "exp_avg_sq": a.exp_avg_sq, "step": self.step_count[k],
+                    "sched_step": self.sched_step[k]} for k, a in self.arenas.items()}
+
+    def load_optimizers(self, loaded_state: Dict[str, Any]) -> None:
+        for k, v in loaded_state.items():
+            self.arenas[k].exp_avg.copy_(v["exp_avg"])
+            self.arenas[k].exp_avg_sq.copy_(v["exp_avg_sq"])
+            self.step_count[k], self.sched_step[k] = v["step"], v["sched_step"]

@@ -1,0 +1,438 @@
+"""SAMModel / NerfactoModel surface of the reference (samnerf/sam_model.py:140-335, nerfstudio/models/nerfacto.py:68-344,
+nerfstudio/models/base_model.py:57-226) on the MI355X kernels.
+
+Same config field names and defaults, same method names / kwargs, same output-dict keys, same parameter groups
+(`proposal_networks`, `fields`, `sam_field`, `conv`).  Differences that are deliberate:
+  * perception models (SAM ViT-H predictor, ClipSeg decoder, LanguageSAM) are NOT loaded by `populate_modules`
+    -- they are outside the hot path and the reference cannot even be constructed without CUDA
+    and checkpoint files (sam_model.py:210-224);
+  * parameters live in flat per-group arenas (arena.py) so the optimiser and the RCCL all-reduce see four
+    contiguous buffers instead of dozens of tensors.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Any, Callable, Dict, List, Optional, Tuple, Type
+
+import numpy as np
+import torch
+from torch import nn
+from torch.nn import Parameter
+
+from . import ops
+from .arena import ParamGroupArena
+from .fields import FieldHeadNames, HashMLPDensityField, SAMField, TCNNNerfactoField
+from .losses import MSELoss, distortion_loss, interlevel_loss
+from .rays import RayBundle, RaySamples
+from .renderers import AccumulationRenderer, DepthRenderer, MeanRenderer, RGBRenderer
+from .samplers import ProposalNetworkSampler
+from .spatial_distortions import SceneContraction
+
+
+# ---------------------------------------------------------------------------------------------
+# config plumbing (nerfstudio/configs/base_config.py:52-59)
+# ---------------------------------------------------------------------------------------------
+@dataclass
+class InstantiateConfig:
+    _target: Type = None
+
+    def setup(self, **kwargs) -> Any:
+        return self._target(self, **kwargs)
+
+
+@dataclass
+class SceneBox:
+    """nerfstudio/data/scene_box.py: axis-aligned box [2,3]."""
+    aabb: torch.Tensor = field(default_factory=lambda: torch.tensor([[-1.0, -1.0, -1.0], [1.0, 1.0, 1.0]]))
+
+
+class NearFarCollider(nn.Module):
+    """nerfstudio/model_components/scene_colliders.py:170-189 (near plane 0 in eval mode)."""
+
+    def __init__(self, near_plane: float, far_plane: float) -> None:
+        super().__init__()
+        self.near_plane, self.far_plane = near_plane, far_plane
+
+    def set_nears_and_fars(self, ray_bundle: RayBundle) -> RayBundle:
+        ones = torch.ones_like(ray_bundle.origins[..., 0:1])
+        near_plane = self.near_plane if self.training else 0
+        ray_bundle.nears = ones * near_plane
+        ray_bundle.fars = ones * self.far_plane
+        return ray_bundle
+
+    def forward(self, ray_bundle: RayBundle) -> RayBundle:
+        if ray_bundle.nears is not None and ray_bundle.fars is not None:
+            return ray_bundle
+        return self.set_nears_and_fars(ray_bundle)
+
+
+@dataclass
+class ModelConfig(InstantiateConfig):
+    """nerfstudio/models/base_model.py:40-54."""
+    _target: Type = field(default_factory=lambda: Model)
+    enable_collider: bool = True
+    collider_params: Optional[Dict[str, float]] = field(default_factory=lambda: {"near_plane": 2.0, "far_plane": 6.0})
+    loss_coefficients: Dict[str, float] = field(default_factory=lambda: {"rgb_loss_coarse": 1.0, "rgb_loss_fine": 1.0})
+    eval_num_rays_per_chunk: int = 4096
+
+
+class Model(nn.Module):
+    """nerfstudio/models/base_model.py:57-226."""
+
+    config: ModelConfig
+
+    def __init__(self, config: ModelConfig, scene_box: SceneBox, num_train_data: int, **kwargs) -> None:
+        super().__init__()
+        self.config = config
+        self.scene_box = scene_box
+        self.num_train_data = num_train_data
+        self.kwargs = kwargs
+        self.collider = None
+        self.populate_modules()
+        self.callbacks = None
+        dev = kwargs.get("device", None) or ("cuda" if torch.cuda.is_available() else "cpu")
+        self.device_indicator_param = nn.Parameter(torch.empty(0, device=dev))
+
+    @property
+    def device(self):
+        return self.device_indicator_param.device
+
+    def populate_modules(self):
+        pass
+
+    def get_training_callbacks(self, training_callback_attributes=None) -> List:
+        return []
+
+    def get_param_groups(self) -> Dict[str, List[Parameter]]:  # pragma: no cover - interface
+        raise NotImplementedError
+
+    def get_outputs(self, ray_bundle: RayBundle) -> Dict[str, torch.Tensor]:  # pragma: no cover - interface
+        raise NotImplementedError
+
+    def forward(self, ray_bundle: RayBundle, **kwargs) -> Dict[str, torch.Tensor]:
+        if self.collider is not None:
+            ray_bundle = self.collider(ray_bundle)
+        return self.get_outputs(ray_bundle, **kwargs)
+
+    def get_metrics_dict(self, outputs, batch) -> Dict[str, torch.Tensor]:
+        return {}
+
+    def get_loss_dict(self, outputs, batch, metrics_dict=None) -> Dict[str, torch.Tensor]:  # pragma: no cover
+        raise NotImplementedError
+
+
+@dataclass
+class TrainingCallback:
+    """nerfstudio/engine/callbacks.py:28-103 (the subset the model registers)."""
+    where_to_run: List[str]
+    func: Callable
+    update_every_num_iters: Optional[int] = None
+
+    def run_callback_at_location(self, step: int, location: str) -> None:
+        if location in self.where_to_run and (self.update_every_num_iters is None or step % self.update_every_num_iters == 0):
+            self.func(step)
+
+
+BEFORE_TRAIN_ITERATION, AFTER_TRAIN_ITERATION = "before_train_iteration", "after_train_iteration"
+
+
+@dataclass
+class NerfactoModelConfig(ModelConfig):
+    """nerfstudio/models/nerfacto.py:68-144 (field names and defaults kept)."""
+    _target: Type = field(default_factory=lambda: NerfactoModel)
+    near_plane: float = 0.05
+    far_plane: float = 1000.0
+    background_color: str = "last_sample"
+    hidden_dim: int = 64
+    hidden_dim_color: int = 64
+    hidden_dim_transient: int = 64
+    num_levels: int = 16
+    max_res: int = 2048
+    log2_hashmap_size: int = 19
+    num_proposal_samples_per_ray: Tuple[int, ...] = (256, 96)
+    num_nerf_samples_per_ray: int = 48
+    proposal_update_every: int = 5
+    proposal_warmup: int = 5000
+    num_proposal_iterations: int = 2
+    use_same_proposal_network: bool = False
+    proposal_net_args_list: List[Dict] = field(default_factory=lambda: [
+        {"hidden_dim": 16, "log2_hashmap_size": 17, "num_levels": 5, "max_res": 128, "use_linear": False},
+        {"hidden_dim": 16, "log2_hashmap_size": 17, "num_levels": 5, "max_res": 256, "use_linear": False},
+    ])
+    proposal_initial_sampler: str = "piecewise"
+    interlevel_loss_mult: float = 1.0
+    distortion_loss_mult: float = 0.002
+    orientation_loss_mult: float = 0.0001
+    pred_normal_loss_mult: float = 0.001
+    use_proposal_weight_anneal: bool = True
+    use_average_appearance_embedding: bool = True
+    proposal_weights_anneal_slope: float = 10.0
+    proposal_weights_anneal_max_num_iters: int = 1000
+    use_single_jitter: bool = True
+    predict_normals: bool = False
+    disable_scene_contraction: bool = False
+    use_appearance_embedding: bool = True
+
+
+class NerfactoModel(Model):
+    """nerfstudio/models/nerfacto.py:147-344."""
+
+    config: NerfactoModelConfig
+
+    def populate_modules(self):
+        super().populate_modules()
+        c = self.config
+        if c.disable_scene_contraction:
+            raise NotImplementedError("scene contraction is always on in the samnerf configs")
+        if c.predict_normals:
+            raise NotImplementedError("predict_normals is off in the samnerf configs")
+        dev = self.kwargs.get("device", None)
+        scene_contraction = SceneContraction(order=float("inf"))
+        self.field = TCNNNerfactoField(
+            self.scene_box.aabb, hidden_dim=c.hidden_dim, num_levels=c.num_levels, max_res=c.max_res,
+            log2_hashmap_size=c.log2_hashmap_size, hidden_dim_color=c.hidden_dim_color,
+            hidden_dim_transient=c.hidden_dim_transient, spatial_distortion=scene_contraction,
+            num_images=self.num_train_data, use_pred_normals=c.predict_normals,
+            use_average_appearance_embedding=c.use_average_appearance_embedding,
+            use_appearance_embedding=c.use_appearance_embedding, device=dev)
+        self.density_fns = []
+        num_prop_nets = c.num_proposal_iterations
+        self.proposal_networks = torch.nn.ModuleList()
+        if c.use_same_proposal_network:
+            assert len(c.proposal_net_args_list) == 1, "Only one proposal network is allowed."
+            network = HashMLPDensityField(self.scene_box.aabb, spatial_distortion=scene_contraction, device=dev,
+                                          **c.proposal_net_args_list[0])
+            self.proposal_networks.append(network)
+            self.density_fns.extend([network.density_fn for _ in range(num_prop_nets)])
+        else:
+            for i in range(num_prop_nets):
+                prop_net_args = c.proposal_net_args_list[min(i, len(c.proposal_net_args_list) - 1)]
+                network = HashMLPDensityField(self.scene_box.aabb, spatial_distortion=scene_contraction, device=dev,
+                                              **prop_net_args)
+                self.proposal_networks.append(network)
+            self.density_fns.extend([network.density_fn for network in self.proposal_networks])
+        update_schedule = lambda step: np.clip(  # noqa: E731
+            np.interp(step, [0, c.proposal_warmup], [0, c.proposal_update_every]), 1, c.proposal_update_every)
+        if c.proposal_initial_sampler != "piecewise":
+            raise NotImplementedError("the samnerf configs use the piecewise initial sampler")
+        self.proposal_sampler = ProposalNetworkSampler(
+            num_nerf_samples_per_ray=c.num_nerf_samples_per_ray,
+            num_proposal_samples_per_ray=c.num_proposal_samples_per_ray,
+            num_proposal_network_iterations=c.num_proposal_iterations, single_jitter=c.use_single_jitter,
+            update_sched=update_schedule, initial_sampler=None)
+        self.collider = NearFarCollider(near_plane=c.near_plane, far_plane=c.far_plane)
+        self.renderer_rgb = RGBRenderer(background_color=c.background_color)
+        self.renderer_accumulation = AccumulationRenderer()
+        self.renderer_depth = DepthRenderer()
+        self.rgb_loss = MSELoss()
+        self.arenas: Dict[str, ParamGroupArena] = {}
+
+    # -- metrics --------------------------------------------------------------------------
+    @staticmethod
+    def psnr(pred: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+        """torchmetrics PeakSignalNoiseRatio(data_range=1.0) (nerfacto.py:232,319)."""
+        return -10.0 * torch.log10(torch.mean((pred - target) ** 2))
+
+    def get_param_groups(self) -> Dict[str, List[Parameter]]:
+        return {"proposal_networks": list(self.proposal_networks.parameters()),
+                "fields": list(self.field.parameters())}
+
+    def get_training_callbacks(self, training_callback_attributes=None) -> List[TrainingCallback]:
+        callbacks = []
+        if self.config.use_proposal_weight_anneal:
+            N = self.config.proposal_weights_anneal_max_num_iters
+
+            def set_anneal(step):
+                train_frac = np.clip(step / N, 0, 1)
+                bias = lambda x, b: (b * x) / ((b - 1) * x + 1)  # noqa: E731
+                self.proposal_sampler.set_anneal(bias(train_frac, self.config.proposal_weights_anneal_slope))
+
+            callbacks.append(TrainingCallback([BEFORE_TRAIN_ITERATION], set_anneal, 1))
+            callbacks.append(TrainingCallback([AFTER_TRAIN_ITERATION], self.proposal_sampler.step_cb, 1))
+        return callbacks
+
+    def get_outputs(self, ray_bundle: RayBundle):
+        ray_samples, weights_list, ray_samples_list = self.proposal_sampler(ray_bundle, density_fns=self.density_fns)
+        field_outputs = self.field(ray_samples, compute_normals=self.config.predict_normals)
+        weights = ray_samples.get_weights(field_outputs[FieldHeadNames.DENSITY])
+        weights_list.append(weights)
+        ray_samples_list.append(ray_samples)
+        outputs = {"rgb": self.renderer_rgb(rgb=field_outputs[FieldHeadNames.RGB], weights=weights),
+                   "accumulation": self.renderer_accumulation(weights=weights),
+                   "depth": self.renderer_depth(weights=weights, ray_samples=ray_samples)}
+        if self.training:
+            outputs["weights_list"] = weights_list
+            outputs["ray_samples_list"] = ray_samples_list
+        for i in range(self.config.num_proposal_iterations):
+            outputs[f"prop_depth_{i}"] = self.renderer_depth(weights=weights_list[i], ray_samples=ray_samples_list[i])
+        return outputs
+
+    def get_metrics_dict(self, outputs, batch):
+        metrics_dict = {}
+        image = batch["image"].to(self.device)
+        metrics_dict["psnr"] = self.psnr(outputs["rgb"].detach(), image)
+        if self.training:
+            metrics_dict["distortion"] = distortion_loss(outputs["weights_list"], outputs["ray_samples_list"])
+        return metrics_dict
+
+    def get_loss_dict(self, outputs, batch, metrics_dict=None):
+        loss_dict = {}
+        image = batch["image"].to(self.device)
+        loss_dict["rgb_loss"] = self.rgb_loss(image, outputs["rgb"])
+        if self.training:
+            loss_dict["interlevel_loss"] = self.config.interlevel_loss_mult * interlevel_loss(
+                outputs["weights_list"], outputs["ray_samples_list"])
+            assert metrics_dict is not None and "distortion" in metrics_dict
+            loss_dict["distortion_loss"] = self.config.distortion_loss_mult * metrics_dict["distortion"]
+        return loss_dict
+
+    # -- arenas ---------------------------------------------------------------------------
+    def build_arenas(self, with_optimizer_state: bool = True) -> Dict[str, ParamGroupArena]:
+        """Move every parameter of every group into a flat per-group arena (see arena.py)."""
+        self.arenas = {}
+        for gname, params in self.get_param_groups().items():
+            if len(params) == 0:
+                continue
+            dev = params[0].device
+            arena = ParamGroupArena(gname, [(str(i), tuple(p.shape)) for i, p in enumerate(params)], dev,
+                                    with_optimizer_state)
+            for i, p in enumerate(params):
+                view = arena.view(arena.param, str(i))
+                view.copy_(p.data)
+                p.data = view
+                p.main_grad = arena.view(arena.grad, str(i))
+                # autograd-produced gradients (conv head) accumulate in place into the same arena slice
+                p.grad = p.main_grad
+            self.arenas[gname] = arena
+        return self.arenas
+
+    @torch.no_grad()
+    def get_outputs_for_camera_ray_bundle(self, camera_ray_bundle: RayBundle, **kwargs) -> Dict[str, torch.Tensor]:
+        """base_model.py:166-188: chunked full-image render."""
+        num_rays_per_chunk = self.config.eval_num_rays_per_chunk
+        image_height, image_width = camera_ray_bundle.origins.shape[:2]
+        num_rays = len(camera_ray_bundle)
+        outputs_lists: Dict[str, List[torch.Tensor]] = {}
+        for i in range(0, num_rays, num_rays_per_chunk):
+            ray_bundle = camera_ray_bundle.get_row_major_sliced_ray_bundle(i, i + num_rays_per_chunk)
+            outputs = self.forward(ray_bundle=ray_bundle, **kwargs)
+            for name, out in outputs.items():
+                if torch.is_tensor(out):
+                    outputs_lists.setdefault(name, []).append(out)
+        return {name: torch.cat(lst).view(image_height, image_width, -1) for name, lst in outputs_lists.items()}
+
+
+@dataclass
+class SAMModelConfig(NerfactoModelConfig):
+    """samnerf/sam_model.py:140-162."""
+    _target: Type = field(default_factory=lambda: SAMModel)
+    sam_loss_weight: float = 1.0
+    use_dino_feature: bool = False
+    use_clipseg_feature: bool = False
+    dino_loss_weight: float = 1.0
+    clipseg_loss_weight: float = 1.0
+    n_scales: int = 30
+    max_scale: float = 1.5
+    num_sam_samples: int = 24
+    hidden_layers: int = 2
+    hashgrid_layers: Tuple[int, ...] = (12, 12)
+    hashgrid_resolutions: Tuple[Tuple[int, int], ...] = ((16, 128), (128, 512))
+    hashgrid_sizes: Tuple[int, ...] = (19, 19)
+    patch_size: int = 1
+    kernel_size: int = 3
+    distill_sam: bool = True
+    sam_checkpoint: str = "samnerf/segment_anything/sam_vit_h_4b8939.pth"
+    sharpening_temperature: float = 10.0
+
+
+class SAMModel(NerfactoModel):
+    """samnerf/sam_model.py:179-335."""
+
+    config: SAMModelConfig
+
+    def populate_modules(self):
+        super().populate_modules()
+        self.sam_capable = True
+        self.text_prompt_capable = True
+        self.prompts = None
+        self.renderer_mean = MeanRenderer()
+        c = self.config
+        dev = self.kwargs.get("device", None)
+        if c.distill_sam:
+            self.sam_field = SAMField(c.hashgrid_layers, c.hashgrid_sizes, c.hashgrid_resolutions,
+                                      hidden_layers=c.hidden_layers, use_dino_features=c.use_dino_feature,
+                                      use_clipseg_features=c.use_clipseg_feature, device=dev)
+            pad = (c.kernel_size - 1) // 2
+            self.conv_head = nn.Sequential(
+                nn.Conv2d(256, 256, c.kernel_size, stride=1, padding=pad), nn.ReLU(inplace=True),
+                nn.Conv2d(256, 256, c.kernel_size, stride=1, padding=pad))
+            if dev is not None:
+                self.conv_head.to(dev)
+            elif torch.cuda.is_available():
+                self.conv_head.to("cuda")
+            # The SAM ViT-H predictor / ClipSeg decoder of sam_model.py:210-222 are prompt-time tools outside the
+            # render-and-distill path; they are attached lazily by the caller (self.predictor, self.clipseg).
+            self.predictor = None
+            self.clipseg = None
+        else:
+            self.lang_sam = None  # LanguageSAM (sam_model.py:224): 2-D inference utility, not on the hot path
+
+    def get_outputs(self, ray_bundle: RayBundle, get_rgbsigma=True, get_feature=["sam", "dino", "clipseg"], fast=False):  # noqa: B006
+        ray_samples, weights_list, ray_samples_list = self.proposal_sampler(ray_bundle, density_fns=self.density_fns)
+        ray_samples_list.append(ray_samples)
+        nerfacto_field_outputs, outputs, weights = self._get_outputs_nerfacto(ray_samples, fast=fast)
+        weights_list.append(weights)
+        if self.training:
+            outputs["weights_list"] = weights_list
+            outputs["ray_samples_list"] = ray_samples_list
+        if not fast:
+            for i in range(self.config.num_proposal_iterations):
+                outputs[f"prop_depth_{i}"] = self.renderer_depth(weights=weights_list[i], ray_samples=ray_samples_list[i])
+        if self.config.distill_sam and len(get_feature) > 0:
+            # top-K by weight, sharpen w^T, renormalise (sam_model.py:244-248) -- one kernel
+            sam_weights, best_ids = ops.topk_sharpen(weights[..., 0].detach(), self.config.num_sam_samples,
+                                                     self.config.sharpening_temperature)
+            sam_samples = ray_samples.gather(best_ids)
+            sam_weights = sam_weights[..., None]
+            sam_field_outputs = None
+            if "sam" in get_feature:
+                sam_field_outputs = self.sam_field.get_outputs(sam_samples, get_feautre=get_feature)
+                feat_out = self.renderer_mean(embeds=sam_field_outputs["sam"], weights=sam_weights.detach())
+                if self.config.patch_size > 1:
+                    p = self.config.patch_size
+                    feat_out = feat_out.reshape(-1, p, p, feat_out.shape[-1]).permute(0, 3, 1, 2)
+                    feat_out = self.conv_head(feat_out).mean(dim=[2, 3])
+                outputs["sam"] = feat_out
+            if "clipseg" in get_feature and self.config.use_clipseg_feature:
+                if sam_field_outputs is None:
+                    sam_field_outputs = self.sam_field.get_outputs(sam_samples, get_feautre=get_feature)
+                outputs["clipseg"] = self.renderer_mean(embeds=sam_field_outputs["clipseg"], weights=sam_weights.detach())
+        return outputs
+
+    def _get_outputs_nerfacto(self, ray_samples: RaySamples, fast=False):
+        field_outputs = self.field(ray_samples, compute_normals=self.config.predict_normals)
+        weights = ray_samples.get_weights(field_outputs[FieldHeadNames.DENSITY])
+        rgb = self.renderer_rgb(rgb=field_outputs[FieldHeadNames.RGB], weights=weights)
+        depth = self.renderer_depth(weights=weights, ray_samples=ray_samples)
+        if not fast:
+            outputs = {"rgb": rgb, "accumulation": self.renderer_accumulation(weights=weights), "depth": depth}
+        else:
+            outputs = {"rgb": rgb, "depth": depth}
+        return field_outputs, outputs, weights
+
+    def get_loss_dict(self, outputs, batch, metrics_dict=None):
+        loss_dict = super().get_loss_dict(outputs, batch, metrics_dict)
+        if self.training and self.config.distill_sam:
+            unreduced_sam = torch.nn.functional.mse_loss(outputs["sam"], batch["sam"], reduction="none")
+            loss_dict["sam_loss"] = self.config.sam_loss_weight * unreduced_sam.mean(dim=-1).nanmean()
+            if self.config.use_clipseg_feature:
+                unreduced = torch.nn.functional.mse_loss(outputs["clipseg"], batch["clipseg"], reduction="none")
+                loss_dict["clipseg_loss"] = self.config.clipseg_loss_weight * unreduced.mean(dim=-1).nanmean()
+        return loss_dict
+
+    def get_param_groups(self) -> Dict[str, List[Parameter]]:
+        param_groups = super().get_param_groups()
+        if self.config.distill_sam:
+            param_groups["sam_field"] = list(self.sam_field.parameters())
+            param_groups["conv"] = list(self.conv_head.parameters())
+        return param_groups

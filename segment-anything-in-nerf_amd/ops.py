@@ -45,6 +45,42 @@ def _chk(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:
     return t
 
 
+# --- per-kernel HIP-event timing (bench.py): events are recorded on torch's current stream, which is the stream
+# every kernel is launched on (see _stream()).
+_TIMING = {"names": None, "events": {}}
+
+
+def enable_kernel_timing(names=None) -> None:
+    """names: iterable of C-ABI entry-point names (optionally 'name/tag'), or 'all'."""
+    _TIMING["names"] = None if names is None else ("all" if names == "all" else set(names))
+    _TIMING["events"] = {}
+
+
+def kernel_timing_summary() -> dict:
+    """-> {name: {"launches": n, "total_ms": t, "avg_ms": t/n}} (synchronises)."""
+    torch.cuda.synchronize()
+    out = {}
+    for name, evs in _TIMING["events"].items():
+        tot = sum(a.elapsed_time(b) for a, b in evs)
+        out[name] = {"launches": len(evs), "total_ms": tot, "avg_ms": tot / max(len(evs), 1)}
+    return out
+
+
+def _launch(name: str, *args, tag: str = "") -> None:
+    fn = getattr(_L(), name)
+    sel = _TIMING["names"]
+    key = name + ("/" + tag if tag else "")
+    if sel is not None and (sel == "all" or key in sel or name in sel):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        rc = fn(*args)
+        b.record()
+        _TIMING["events"].setdefault(key, []).append((a, b))
+    else:
+        rc = fn(*args)
+    _lib.check(rc, name)
+
+
 def _grad_target(param: torch.Tensor) -> Tuple[torch.Tensor, bool]:
     """(buffer to accumulate into, whether autograd should get None)."""
     mg = getattr(param, "main_grad", None)
@@ -63,8 +99,7 @@ def sample_spacing(nears, fars, num_samples: int, t_rand=None):
     t = None if t_rand is None else _chk(t_rand.reshape(-1), "t_rand")
     sb = torch.empty((R, num_samples + 1), device=nears.device, dtype=torch.float32)
     eb = torch.empty_like(sb)
-    _lib.check(_L().snf_sample_spacing(_p(nears), _p(fars), _p(t), R, num_samples, _p(sb), _p(eb), _stream()),
-               "snf_sample_spacing")
+    _launch("snf_sample_spacing", _p(nears), _p(fars), _p(t), R, num_samples, _p(sb), _p(eb), _stream())
     return sb, eb
 
 
@@ -80,8 +115,8 @@ def positions(origins, directions, ebins, ids=None, contraction: int = CONTRACT_
         K = n
     u = torch.empty((R * K, 3), device=ebins.device, dtype=torch.float32)
     sel = torch.empty((R * K,), device=ebins.device, dtype=torch.uint8) if use_selector else None
-    _lib.check(_L().snf_positions(_p(origins), _p(directions), _p(ebins), _p(ids), R, n, K, contraction,
-                                  int(use_selector), _p(u), _p(sel), _stream()), "snf_positions")
+    _launch("snf_positions", _p(origins), _p(directions), _p(ebins), _p(ids), R, n, K, contraction,
+                                  int(use_selector), _p(u), _p(sel), _stream())
     return u, sel
 
 
@@ -94,9 +129,8 @@ def pdf_resample(weights, sbins_in, nears, fars, num_samples: int, u_rand=None, 
     u = None if u_rand is None else _chk(u_rand.reshape(-1), "u_rand")
     sb = torch.empty((R, num_samples + 1), device=weights.device, dtype=torch.float32)
     eb = torch.empty_like(sb)
-    _lib.check(_L().snf_pdf_resample(_p(weights), _p(sbins_in), _p(u), _p(nears), _p(fars), R, Pn, num_samples,
-                                     float(anneal), float(histogram_padding), _p(sb), _p(eb), _stream()),
-               "snf_pdf_resample")
+    _launch("snf_pdf_resample", _p(weights), _p(sbins_in), _p(u), _p(nears), _p(fars), R, Pn, num_samples,
+                                     float(anneal), float(histogram_padding), _p(sb), _p(eb), _stream())
     return sb, eb
 
 
@@ -106,8 +140,7 @@ def topk_sharpen(weights, k: int, temperature: float = 10.0):
     R, S = weights.shape
     ids = torch.empty((R, k), device=weights.device, dtype=torch.int32)
     w = torch.empty((R, k), device=weights.device, dtype=torch.float32)
-    _lib.check(_L().snf_topk_sharpen(_p(weights), R, S, k, float(temperature), _p(ids), _p(w), _stream()),
-               "snf_topk_sharpen")
+    _launch("snf_topk_sharpen", _p(weights), R, S, k, float(temperature), _p(ids), _p(w), _stream())
     return w, ids
 
 
@@ -118,8 +151,8 @@ def render_depth_acc(weights, ebins, want_acc: bool = True):
     R, S = weights.shape
     depth = torch.empty((R, 1), device=weights.device, dtype=torch.float32)
     acc = torch.empty((R, 1), device=weights.device, dtype=torch.float32) if want_acc else None
-    _lib.check(_L().snf_composite_fwd(_p(None), _p(weights), _p(ebins), R, S, 1, _p(None), _p(acc), _p(depth),
-                                      _stream()), "snf_composite_fwd")
+    _launch("snf_composite_fwd", _p(None), _p(weights), _p(ebins), R, S, 1, _p(None), _p(acc), _p(depth),
+                                      _stream())
     return depth, acc
 
 
@@ -140,8 +173,7 @@ class _HashGridMulti(torch.autograd.Function):
         for (sc, L, F, T), tab in zip(specs, tables):
             tab = _chk(tab, "table")
             assert tab.numel() == (L << T) * F, "table size does not match (levels, log2_T, features)"
-            _lib.check(_L().snf_hashgrid_fwd(_p(u), _p(tab), _p(sc), N, L, F, T, _p(out), total, col, _stream()),
-                       "snf_hashgrid_fwd")
+            _launch("snf_hashgrid_fwd", _p(u), _p(tab), _p(sc), N, L, F, T, _p(out), total, col, _stream(), tag=f"F{F}")
             col += L * F
         ctx.specs = specs
         ctx.tables = tables
@@ -160,8 +192,7 @@ class _HashGridMulti(torch.autograd.Function):
                 grads.append(None)
             else:
                 buf, fused = _grad_target(tab)
-                _lib.check(_L().snf_hashgrid_bwd(_p(u), _p(g), _p(sc), N, L, F, T, total, col, _p(buf), _stream()),
-                           "snf_hashgrid_bwd")
+                _launch("snf_hashgrid_bwd", _p(u), _p(g), _p(sc), N, L, F, T, total, col, _p(buf), _stream(), tag=f"F{F}")
                 grads.append(None if fused else buf)
             col += L * F
         return (None, None, *grads)
@@ -182,7 +213,7 @@ class _Linear(torch.autograd.Function):
         O = w.shape[0]
         assert w.shape[1] == I
         y = torch.empty((N, O), device=x.device, dtype=torch.float32)
-        _lib.check(_L().snf_linear_fwd(_p(x), _p(w), _p(b), N, I, O, I, O, act, _p(y), _stream()), "snf_linear_fwd")
+        _launch("snf_linear_fwd", _p(x), _p(w), _p(b), N, I, O, I, O, act, _p(y), _stream(), tag=f"{I}x{O}")
         ctx.act = act
         ctx.wref, ctx.bref = w, b
         ctx.save_for_backward(x, y)
@@ -198,13 +229,12 @@ class _Linear(torch.autograd.Function):
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             gx = torch.empty((N, I), device=x.device, dtype=torch.float32)
-            _lib.check(_L().snf_linear_bwd_data(_p(gy), _p(y), _p(w), N, I, O, O, O, I, act, _p(gx), _stream()),
-                       "snf_linear_bwd_data")
+            _launch("snf_linear_bwd_data", _p(gy), _p(y), _p(w), N, I, O, O, O, I, act, _p(gx), _stream(), tag=f"{I}x{O}")
         if w.requires_grad or (b is not None and b.requires_grad):
             wbuf, wfused = _grad_target(w)
             bbuf, bfused = (None, True) if b is None else _grad_target(b)
-            _lib.check(_L().snf_linear_bwd_weight(_p(gy), _p(y), _p(x), N, I, O, O, O, I, act, _p(wbuf), _p(bbuf),
-                                                  _stream()), "snf_linear_bwd_weight")
+            _launch("snf_linear_bwd_weight", _p(gy), _p(y), _p(x), N, I, O, O, O, I, act, _p(wbuf), _p(bbuf), _stream(),
+                    tag=f"{I}x{O}")
             gw = None if wfused else wbuf
             gb = None if bfused else bbuf
         return gx, gw, gb, None
@@ -232,8 +262,7 @@ class _HeadInput(torch.autograd.Function):
         n_geo = h.shape[1] - 1
         out = torch.empty((R * S, 16 + n_geo), device=h.device, dtype=torch.float32)
         geo = ctypes.c_void_p(h.data_ptr() + 4)
-        _lib.check(_L().snf_head_input(_p(dirs), geo, R, S, n_geo, h.shape[1], _p(out), 16 + n_geo, _stream()),
-                   "snf_head_input")
+        _launch("snf_head_input", _p(dirs), geo, R, S, n_geo, h.shape[1], _p(out), 16 + n_geo, _stream())
         ctx.n_geo = n_geo
         return out
 
@@ -259,8 +288,8 @@ class _Weights(torch.autograd.Function):
         h, ebins = _chk(h, "h"), _chk(ebins, "ebins")
         C = h.shape[1]
         w = torch.empty((R, n), device=h.device, dtype=torch.float32)
-        _lib.check(_L().snf_weights_fwd(_p(h), C, int(is_density), _p(selector), _p(ebins), R, n, _p(w), _p(None),
-                                        _stream()), "snf_weights_fwd")
+        _launch("snf_weights_fwd", _p(h), C, int(is_density), _p(selector), _p(ebins), R, n, _p(w), _p(None),
+                                        _stream())
         ctx.save_for_backward(h, ebins)
         ctx.selector = selector
         ctx.dims = (R, n, C, int(is_density))
@@ -272,8 +301,8 @@ class _Weights(torch.autograd.Function):
         R, n, C, is_density = ctx.dims
         gw = _chk(gw, "grad_w")
         gh = torch.zeros_like(h) if C > 1 else torch.empty_like(h)
-        _lib.check(_L().snf_weights_bwd(_p(h), C, is_density, _p(ctx.selector), _p(ebins), _p(gw), R, n, _p(gh),
-                                        _stream()), "snf_weights_bwd")
+        _launch("snf_weights_bwd", _p(h), C, is_density, _p(ctx.selector), _p(ebins), _p(gw), R, n, _p(gh),
+                                        _stream())
         return gh, None, None, None, None, None
 
 
@@ -294,9 +323,34 @@ def density_from_raw(h, selector, ebins, R: int, n: int) -> torch.Tensor:
     h, ebins = _chk(h, "h"), _chk(ebins, "ebins")
     w = torch.empty((R, n), device=h.device, dtype=torch.float32)
     d = torch.empty((R, n), device=h.device, dtype=torch.float32)
-    _lib.check(_L().snf_weights_fwd(_p(h), h.shape[1], 0, _p(selector), _p(ebins), R, n, _p(w), _p(d), _stream()),
-               "snf_weights_fwd")
+    _launch("snf_weights_fwd", _p(h), h.shape[1], 0, _p(selector), _p(ebins), R, n, _p(w), _p(d), _stream())
     return d
+
+
+class _TruncExpSel(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h, selector):
+        h = _chk(h, "h")
+        N, C = h.shape
+        d = torch.empty((N,), device=h.device, dtype=torch.float32)
+        _launch("snf_trunc_exp_fwd", _p(h), C, _p(selector), N, _p(d), _stream())
+        ctx.save_for_backward(h)
+        ctx.selector = selector
+        return d
+
+    @staticmethod
+    def backward(ctx, gd):
+        (h,) = ctx.saved_tensors
+        N, C = h.shape
+        gd = _chk(gd, "grad_density")
+        gh = torch.zeros_like(h) if C > 1 else torch.empty_like(h)
+        _launch("snf_trunc_exp_bwd", _p(h), C, _p(ctx.selector), _p(gd), N, _p(gh), _stream())
+        return gh, None
+
+
+def trunc_exp_sel(h, selector=None) -> torch.Tensor:
+    """density [N] = trunc_exp(h[:, 0]) * selector (h is the [N, C] base-MLP output; column 0 = raw density)."""
+    return _TruncExpSel.apply(h, selector)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -308,8 +362,8 @@ class _CompositeRGB(torch.autograd.Function):
         rgb, weights = _chk(rgb, "rgb"), _chk(weights, "weights")
         R, S = weights.shape
         out = torch.empty((R, 3), device=rgb.device, dtype=torch.float32)
-        _lib.check(_L().snf_composite_fwd(_p(rgb), _p(weights), _p(None), R, S, int(training), _p(out), _p(None),
-                                          _p(None), _stream()), "snf_composite_fwd")
+        _launch("snf_composite_fwd", _p(rgb), _p(weights), _p(None), R, S, int(training), _p(out), _p(None),
+                                          _p(None), _stream())
         ctx.save_for_backward(rgb, weights)
         ctx.training = training
         return out
@@ -323,8 +377,7 @@ class _CompositeRGB(torch.autograd.Function):
         g = _chk(g, "grad_rgb")
         grgb = torch.empty_like(rgb)
         gw = torch.empty_like(weights)
-        _lib.check(_L().snf_composite_bwd(_p(rgb), _p(weights), _p(g), R, S, _p(grgb), _p(gw), _stream()),
-                   "snf_composite_bwd")
+        _launch("snf_composite_bwd", _p(rgb), _p(weights), _p(g), R, S, _p(grgb), _p(gw), _stream())
         return grgb, gw, None
 
 
@@ -342,7 +395,7 @@ class _FeatureMean(torch.autograd.Function):
         embeds, w = _chk(embeds, "embeds"), _chk(w, "w")
         C = embeds.shape[-1]
         out = torch.empty((R, C), device=embeds.device, dtype=torch.float32)
-        _lib.check(_L().snf_feature_mean_fwd(_p(embeds), _p(w), R, K, C, _p(out), _stream()), "snf_feature_mean_fwd")
+        _launch("snf_feature_mean_fwd", _p(embeds), _p(w), R, K, C, _p(out), _stream())
         ctx.save_for_backward(w)
         ctx.dims = (R, K, C)
         return out
@@ -353,7 +406,7 @@ class _FeatureMean(torch.autograd.Function):
         R, K, C = ctx.dims
         g = _chk(g, "grad_out")
         ge = torch.empty((R * K, C), device=g.device, dtype=torch.float32)
-        _lib.check(_L().snf_feature_mean_bwd(_p(g), _p(w), R, K, C, _p(ge), _stream()), "snf_feature_mean_bwd")
+        _launch("snf_feature_mean_bwd", _p(g), _p(w), R, K, C, _p(ge), _stream())
         return ge, None, None, None
 
 
@@ -375,8 +428,8 @@ class _Interlevel(torch.autograd.Function):
         rows = torch.empty((R,), device=w_prop.device, dtype=torch.float32)
         need = ctx.needs_input_grad[0]
         gwp = torch.empty_like(w_prop) if need else None
-        _lib.check(_L().snf_interlevel(_p(sbins_fine), _p(w_fine), _p(sbins_prop), _p(w_prop), R, S, Pn,
-                                       1.0 / float(R * S), _p(rows), _p(gwp), _stream()), "snf_interlevel")
+        _launch("snf_interlevel", _p(sbins_fine), _p(w_fine), _p(sbins_prop), _p(w_prop), R, S, Pn,
+                                       1.0 / float(R * S), _p(rows), _p(gwp), _stream())
         ctx.gwp = gwp
         return rows.sum() / float(R * S)
 
@@ -398,8 +451,7 @@ class _Distortion(torch.autograd.Function):
         rows = torch.empty((R,), device=w.device, dtype=torch.float32)
         need = ctx.needs_input_grad[0]
         gw = torch.empty_like(w) if need else None
-        _lib.check(_L().snf_distortion(_p(sbins), _p(w), R, S, 1.0 / float(R), _p(rows), _p(gw), _stream()),
-                   "snf_distortion")
+        _launch("snf_distortion", _p(sbins), _p(w), R, S, 1.0 / float(R), _p(rows), _p(gw), _stream())
         ctx.gw = gw
         return rows.sum() / float(R)
 
@@ -420,11 +472,11 @@ def adam_step_(p, g, m, v, lr: float, beta1: float, beta2: float, eps: float, st
                zero_grad: bool = True) -> None:
     for t in (p, g, m, v):
         assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
-    _lib.check(_L().snf_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), float(lr), float(beta1), float(beta2),
-                                  float(eps), int(step), float(grad_scale), int(zero_grad), _stream()), "snf_adam_step")
+    _launch("snf_adam_step", _p(p), _p(g), _p(m), _p(v), p.numel(), float(lr), float(beta1), float(beta2),
+                                  float(eps), int(step), float(grad_scale), int(zero_grad), _stream())
 
 
 @torch.no_grad()
 def fill_uniform_(x, seed: int, lo: float, hi: float) -> None:
     assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
-    _lib.check(_L().snf_fill_uniform(_p(x), x.numel(), int(seed), float(lo), float(hi), _stream()), "snf_fill_uniform")
+    _launch("snf_fill_uniform", _p(x), x.numel(), int(seed), float(lo), float(hi), _stream())

@@ -1,0 +1,174 @@
+"""DataManager / Pipeline / Trainer surface (samnerf/datamanager.py:35-117, samnerf/sam_pipeline.py,
+nerfstudio/pipelines/base_pipeline.py:203-281, nerfstudio/engine/trainer.py:409-440).
+
+The datamanager here is the SYNTHETIC one of SURVEY.md 8(d): seeded random rays and targets generated on the
+device.  Disk formats (transforms.json, SAM .npy, ClipSeg .pt) are a 'next' row."""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Any, Dict, List, Optional, Tuple, Type
+
+import torch
+
+from . import distributed as D
+from .engine import AdamOptimizerConfig, ExponentialDecaySchedulerConfig, Optimizers
+from .model import (AFTER_TRAIN_ITERATION, BEFORE_TRAIN_ITERATION, InstantiateConfig, SAMModelConfig, SceneBox)
+from .rays import RayBundle
+
+
+@dataclass
+class CameraOptimizerConfig:
+    mode: str = "off"
+
+
+@dataclass
+class SAMDataManagerConfig(InstantiateConfig):
+    """samnerf/datamanager.py (config fields used by the samnerf method configs)."""
+    _target: Type = field(default_factory=lambda: SyntheticSAMDataManager)
+    train_num_rays_per_batch: int = 4096 * 4
+    eval_num_rays_per_batch: int = 4096 * 4
+    camera_optimizer: CameraOptimizerConfig = field(default_factory=CameraOptimizerConfig)
+    patch_size: int = 1
+    distill_sam: bool = True
+    use_dino_feature: bool = False
+    use_clipseg_feature: bool = False
+    num_train_images: int = 2
+    seed: int = 0
+
+
+class SyntheticSAMDataManager:
+    """next_train(step) -> (RayBundle, batch) with batch keys image / indices / sam / clipseg
+    (samnerf/datamanager.py:97-117).  Rays: origins U(-.5,.5)^3, unit-normal directions; targets random."""
+
+    def __init__(self, config: SAMDataManagerConfig, device="cuda", world_size: int = 1, local_rank: int = 0, **kw):
+        self.config = config
+        self.device = torch.device(device)
+        self.gen = torch.Generator(device=self.device)
+        self.gen.manual_seed(config.seed + local_rank)  # per-rank ray draws (samnerf/train.py:87)
+        self.train_count = 0
+        self.num_train_data = config.num_train_images
+
+    def _bundle(self, R: int) -> RayBundle:
+        o = torch.rand((R, 3), device=self.device, generator=self.gen) - 0.5
+        d = torch.randn((R, 3), device=self.device, generator=self.gen)
+        d = d / torch.linalg.norm(d, dim=-1, keepdim=True)
+        return RayBundle(origins=o, directions=d, pixel_area=torch.full((R, 1), 1e-6, device=self.device),
+                         camera_indices=torch.zeros((R, 1), dtype=torch.long, device=self.device))
+
+    def next_train(self, step: int) -> Tuple[RayBundle, Dict]:
+        self.train_count += 1
+        c = self.config
+        R = c.train_num_rays_per_batch
+        batch = {"image": torch.rand((R, 3), device=self.device, generator=self.gen),
+                 "indices": torch.zeros((R, 3), dtype=torch.long, device=self.device)}
+        if c.distill_sam:
+            n_sam = R // (c.patch_size ** 2) if c.patch_size > 1 else R
+            batch["sam"] = torch.randn((n_sam, 256), device=self.device, generator=self.gen)
+            if c.use_clipseg_feature:
+                batch["clipseg"] = torch.randn((R, 192), device=self.device, generator=self.gen)
+        return self._bundle(R), batch
+
+    def get_param_groups(self) -> Dict[str, List]:
+        return {}
+
+
+@dataclass
+class SamPipelineConfig(InstantiateConfig):
+    _target: Type = field(default_factory=lambda: SamPipeline)
+    datamanager: SAMDataManagerConfig = field(default_factory=SAMDataManagerConfig)
+    model: SAMModelConfig = field(default_factory=SAMModelConfig)
+
+
+class SamPipeline(torch.nn.Module):
+    """VanillaPipeline.get_train_loss_dict (base_pipeline.py:256-281) around SAMModel."""
+
+    def __init__(self, config: SamPipelineConfig, device="cuda", test_mode="val", world_size: int = 1, local_rank: int = 0):
+        super().__init__()
+        self.config = config
+        self.datamanager = config.datamanager.setup(device=device, world_size=world_size, local_rank=local_rank)
+        self._model = config.model.setup(scene_box=SceneBox(), num_train_data=self.datamanager.num_train_data,
+                                         device=device)
+        self.world_size = world_size
+
+    @property
+    def model(self):
+        return self._model
+
+    @property
+    def device(self):
+        return self.model.device
+
+    def get_train_loss_dict(self, step: int):
+        ray_bundle, batch = self.datamanager.next_train(step)
+        model_outputs = self.model(ray_bundle)
+        metrics_dict = self.model.get_metrics_dict(model_outputs, batch)
+        loss_dict = self.model.get_loss_dict(model_outputs, batch, metrics_dict)
+        return model_outputs, loss_dict, metrics_dict
+
+    def get_param_groups(self):
+        return {**self.datamanager.get_param_groups(), **self.model.get_param_groups()}
+
+    def get_training_callbacks(self, attrs=None):
+        return self.model.get_training_callbacks(attrs)
+
+
+@dataclass
+class TrainerConfig(InstantiateConfig):
+    """nerfstudio/engine/trainer.py TrainerConfig / configs/experiment_config.py (fields the samnerf configs set)."""
+    _target: Type = field(default_factory=lambda: Trainer)
+    method_name: Optional[str] = None
+    steps_per_eval_batch: int = 500
+    steps_per_eval_image: int = 500
+    steps_per_save: int = 2000
+    max_num_iterations: int = 1000000
+    mixed_precision: bool = False
+    pipeline: SamPipelineConfig = field(default_factory=SamPipelineConfig)
+    optimizers: Dict[str, Any] = field(default_factory=dict)
+    vis: str = "viewer+wandb"
+    wandb_name: Optional[str] = None
+    seed: int = 42
+
+
+class Trainer:
+    """Trainer.setup / train_iteration (trainer.py:137-205,409-440): callbacks, forward, summed loss, backward,
+    gradient mean across ranks, fused Adam, scheduler step.  mixed_precision is accepted and ignored: the kernels
+    compute in fp32 (the parity mode of SURVEY.md 7.1), so no GradScaler is needed."""
+
+    def __init__(self, config: TrainerConfig, local_rank: int = 0, world_size: int = 1, device="cuda") -> None:
+        self.config = config
+        self.local_rank, self.world_size = local_rank, world_size
+        self.device = device
+        self._start_step = 0
+
+    def setup(self, test_mode="val") -> None:
+        self.pipeline = self.config.pipeline.setup(device=self.device, test_mode=test_mode, world_size=self.world_size,
+                                                   local_rank=self.local_rank)
+        self.pipeline.model.train()
+        arenas = self.pipeline.model.build_arenas(with_optimizer_state=True)
+        self.optimizers = Optimizers(self.config.optimizers, arenas)
+        D.broadcast_parameters([a.param for a in arenas.values()])
+        self.callbacks = self.pipeline.get_training_callbacks()
+
+    def train_iteration(self, step: int):
+        for cb in self.callbacks:
+            cb.run_callback_at_location(step, BEFORE_TRAIN_ITERATION)
+        _, loss_dict, metrics_dict = self.pipeline.get_train_loss_dict(step=step)
+        loss = sum(loss_dict.values())
+        loss.backward()
+        D.allreduce_gradients([a.grad for a in self.optimizers.arenas.values()])
+        self.optimizers.optimizer_step_all(grad_scale=1.0 / D.world_size(), zero_grad=True)
+        self.optimizers.scheduler_step_all(step)
+        for cb in self.callbacks:
+            cb.run_callback_at_location(step, AFTER_TRAIN_ITERATION)
+        return loss, loss_dict, metrics_dict
+
+    def save_checkpoint(self, path: str, step: int) -> None:
+        """trainer.py:379-406: {step, pipeline state_dict, optimizers}."""
+        torch.save({"step": step, "pipeline": self.pipeline.state_dict(), "optimizers": self.optimizers.state_dict()}, path)
+
+    def load_checkpoint(self, path: str) -> int:
+        st = torch.load(path, map_location=self.device)
+        self.pipeline.load_state_dict(st["pipeline"])
+        self.optimizers.load_optimizers(st["optimizers"])
+        self._start_step = st["step"] + 1
+        return self._start_step

@@ -1,0 +1,142 @@
+"""Drop-in stand-ins for the tiny-cuda-nn torch modules the reference instantiates
+(`tcnn.Encoding`, `tcnn.Network`, `tcnn.NetworkWithInputEncoding`; call sites samnerf/sam_field.py:51-109,
+nerfstudio/fields/nerfacto_field.py:144-240, nerfstudio/fields/density_fields.py:73-100).
+
+Same constructor arguments, `n_input_dims` / `n_output_dims` attributes and one flat fp32 `params` tensor per
+module; the arithmetic is the reference's torch semantics (encodings.py:289-349, mlp.py:80-99) on the gfx950
+kernels.  Networks are bias-free like tcnn's.  Parameters are created directly in HBM and initialised by the
+counter-based fill kernel (tables U(-1,1)*1e-3 as encodings.py:257-258; layers U(+-1/sqrt(fan_in))).
+"""
+from __future__ import annotations
+
+import itertools
+import math
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import ops
+from .arena import fill_uniform_reference
+
+_seed_counter = itertools.count(1)
+_base_seed = 0
+
+
+def manual_seed(seed: int) -> None:
+    """Reset the deterministic parameter-initialisation stream."""
+    global _seed_counter, _base_seed
+    _base_seed = int(seed)
+    _seed_counter = itertools.count(1)
+
+
+def _next_seed() -> int:
+    return (_base_seed << 20) + next(_seed_counter)
+
+
+def _fill(t: torch.Tensor, lo: float, hi: float) -> None:
+    seed = _next_seed()
+    if t.is_cuda:
+        ops.fill_uniform_(t, seed, lo, hi)
+    else:  # host-side construction (shape / config tests): the identical numpy stream
+        t.copy_(torch.from_numpy(fill_uniform_reference(t.numel(), seed, lo, hi)).view(t.shape))
+
+
+def hash_scalings(n_levels: int, base_resolution: int, per_level_scale: float) -> torch.Tensor:
+    """floor(base * g^l) evaluated as the reference's torch path does (encodings.py:252-254): fp32."""
+    levels = torch.arange(n_levels)
+    return torch.floor(base_resolution * np.float64(per_level_scale) ** levels)
+
+
+def default_device() -> torch.device:
+    return torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu")
+
+
+class Encoding(nn.Module):
+    """tcnn.Encoding(n_input_dims=3, encoding_config={"otype": "HashGrid", ...})."""
+
+    def __init__(self, n_input_dims: int, encoding_config: Dict, device=None, hash_init_scale: float = 1e-3):
+        super().__init__()
+        if encoding_config.get("otype") != "HashGrid" or n_input_dims != 3:
+            raise ValueError("only the 3-D HashGrid encoding is on the hot path")
+        self.n_input_dims = 3
+        self.n_levels = int(encoding_config["n_levels"])
+        self.n_features_per_level = int(encoding_config["n_features_per_level"])
+        self.log2_hashmap_size = int(encoding_config["log2_hashmap_size"])
+        self.base_resolution = int(encoding_config["base_resolution"])
+        self.per_level_scale = float(encoding_config["per_level_scale"])
+        if self.n_features_per_level not in (2, 8):
+            raise ValueError("n_features_per_level must be 2 or 8")
+        self.n_output_dims = self.n_levels * self.n_features_per_level
+        device = device or default_device()
+        rows = self.n_levels << self.log2_hashmap_size
+        p = torch.empty((rows * self.n_features_per_level,), device=device, dtype=torch.float32)
+        _fill(p, -hash_init_scale, hash_init_scale)
+        self.params = nn.Parameter(p)
+        self.register_buffer("scalings", hash_scalings(self.n_levels, self.base_resolution,
+                                                       self.per_level_scale).to(device), persistent=False)
+
+    @property
+    def spec(self) -> Tuple[torch.Tensor, int, int, int]:
+        return (self.scalings, self.n_levels, self.n_features_per_level, self.log2_hashmap_size)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return ops.hashgrid(x.reshape(-1, 3), [self.params], (self.spec,))
+
+
+class Network(nn.Module):
+    """tcnn.Network(n_input_dims, n_output_dims, network_config) -- FullyFusedMLP / CutlassMLP, bias-free."""
+
+    def __init__(self, n_input_dims: int, n_output_dims: int, network_config: Dict, device=None):
+        super().__init__()
+        self.n_input_dims, self.n_output_dims = int(n_input_dims), int(n_output_dims)
+        self.n_neurons = int(network_config["n_neurons"])
+        self.n_hidden_layers = int(network_config["n_hidden_layers"])
+        if network_config.get("activation", "ReLU") != "ReLU":
+            raise ValueError("hidden activation must be ReLU")
+        self.output_activation = ops.ACT_BY_NAME[network_config.get("output_activation", "None")]
+        dims = [self.n_input_dims] + [self.n_neurons] * self.n_hidden_layers + [self.n_output_dims]
+        self.layer_shapes: List[Tuple[int, int]] = [(dims[i + 1], dims[i]) for i in range(len(dims) - 1)]
+        total = sum(o * i for o, i in self.layer_shapes)
+        device = device or default_device()
+        p = torch.empty((total,), device=device, dtype=torch.float32)
+        off = 0
+        for o, i in self.layer_shapes:
+            bound = 1.0 / math.sqrt(i)
+            _fill(p[off:off + o * i], -bound, bound)
+            off += o * i
+        self.params = nn.Parameter(p)
+
+    def weights(self) -> List[torch.Tensor]:
+        """Per-layer [out,in] views of the flat parameter (and of its gradient arena, if attached)."""
+        out, off = [], 0
+        mg = getattr(self.params, "main_grad", None)
+        for o, i in self.layer_shapes:
+            w = self.params[off:off + o * i].view(o, i)
+            if mg is not None:
+                w.main_grad = mg[off:off + o * i].view(o, i)
+            out.append(w)
+            off += o * i
+        return out
+
+    def load_weights(self, ws) -> None:
+        with torch.no_grad():
+            for dst, src in zip(self.weights(), ws):
+                dst.copy_(src)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return ops.mlp(x.reshape(-1, self.n_input_dims), self.weights(), None, self.output_activation)
+
+
+class NetworkWithInputEncoding(nn.Module):
+    """tcnn.NetworkWithInputEncoding(n_input_dims, n_output_dims, encoding_config, network_config)."""
+
+    def __init__(self, n_input_dims: int, n_output_dims: int, encoding_config: Dict, network_config: Dict, device=None):
+        super().__init__()
+        self.encoding = Encoding(n_input_dims, encoding_config, device=device)
+        self.network = Network(self.encoding.n_output_dims, n_output_dims, network_config, device=device)
+        self.n_input_dims, self.n_output_dims = n_input_dims, n_output_dims
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return self.network(self.encoding(x))
