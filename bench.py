@@ -43,9 +43,9 @@ def algorithmic_model(key: str, w: dict):
     (8 corners x F floats x 4 B per level per sample; backward = read-modify-write)."""
     R, P, S, K = w["R"], w["P"], w["S"], w["K"]
     name, _, tag = key.partition("/")
-    if name in ("snf_hashgrid_fwd", "snf_hashgrid_bwd"):
+    if name in ("snf_hashgrid_fwd", "snf_hashgrid_bwd", "snf_hashgrid_bwd_sorted"):
         F = int(tag[1:])
-        rw = 2 if name.endswith("bwd") else 1
+        rw = 1 if name.endswith("fwd") else 2
         if F == 8:
             n, L = R * K, 12
         else:

@@ -73,6 +73,15 @@ int snf_hashgrid_fwd(const float* u, const float* table, const float* scalings, 
 int snf_hashgrid_bwd(const float* u, const float* grad_out, const float* scalings, int N, int L, int F,
                      int log2_T, int ld_out, int col_off, float* grad_table, snf_stream_t stream);
 
+/* Atomic-free variant of snf_hashgrid_bwd (the default in the product path): contributions are counting-sorted by
+ * destination bucket and reduced per bucket in LDS; same result up to fp32 summation order.  `workspace` is a
+ * caller-allocated scratch buffer of at least snf_hashgrid_bwd_workspace_bytes(N, L, log2_T) bytes (16-B aligned),
+ * free for reuse as soon as the call's kernels have run on `stream`. */
+int64_t snf_hashgrid_bwd_workspace_bytes(int N, int L, int log2_T);
+int snf_hashgrid_bwd_sorted(const float* u, const float* grad_out, const float* scalings, int N, int L, int F,
+                            int log2_T, int ld_out, int col_off, float* grad_table, void* workspace,
+                            int64_t workspace_bytes, snf_stream_t stream);
+
 /* ---- a7: one layer of tcnn.Network (FullyFusedMLP / CutlassMLP) == nerfstudio MLP layer
  *      (field_components/mlp.py:80-99): Y[N,O] = act(X[N,I] W[O,I]^T + bias).  bias may be NULL. */
 int snf_linear_fwd(const float* X, const float* W, const float* bias, int N, int I, int O, int ldx,

@@ -86,6 +86,7 @@ SIGNATURES = {
     "snf_positions": [P, P, P, P, I, I, I, I, I, P, P, P],
     "snf_hashgrid_fwd": [P, P, P, I, I, I, I, P, I, I, P],
     "snf_hashgrid_bwd": [P, P, P, I, I, I, I, I, I, P, P],
+    "snf_hashgrid_bwd_sorted": [P, P, P, I, I, I, I, I, I, P, P, c_int64, P],
     "snf_linear_fwd": [P, P, P, I, I, I, I, I, I, P, P],
     "snf_linear_bwd_data": [P, P, P, I, I, I, I, I, I, I, P, P],
     "snf_linear_bwd_weight": [P, P, P, I, I, I, I, I, I, I, P, P, P],
@@ -126,6 +127,8 @@ def load(auto_build: bool = True) -> ctypes.CDLL:
     lib.snf_version.argtypes = []
     lib.snf_last_error.restype = c_char_p
     lib.snf_last_error.argtypes = []
+    lib.snf_hashgrid_bwd_workspace_bytes.restype = c_int64
+    lib.snf_hashgrid_bwd_workspace_bytes.argtypes = [c_int, c_int, c_int]
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
         fn.restype = c_int

@@ -18,6 +18,7 @@ import torch
 from . import _lib
 
 CONTRACT_NONE, CONTRACT_LINF, CONTRACT_L2 = 0, 1, 2
+HASHGRID_BWD_MODE = "sorted"  # "sorted": bucketed, atomic-free (default) | "atomic": global fp32 atomics
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 ACT_BY_NAME = {None: ACT_NONE, "None": ACT_NONE, "none": ACT_NONE, "ReLU": ACT_RELU, "relu": ACT_RELU,
                "Sigmoid": ACT_SIGMOID, "sigmoid": ACT_SIGMOID}
@@ -192,7 +193,14 @@ class _HashGridMulti(torch.autograd.Function):
                 grads.append(None)
             else:
                 buf, fused = _grad_target(tab)
-                _launch("snf_hashgrid_bwd", _p(u), _p(g), _p(sc), N, L, F, T, total, col, _p(buf), _stream(), tag=f"F{F}")
+                if HASHGRID_BWD_MODE == "atomic":
+                    _launch("snf_hashgrid_bwd", _p(u), _p(g), _p(sc), N, L, F, T, total, col, _p(buf), _stream(),
+                            tag=f"F{F}")
+                else:
+                    nbytes = int(_L().snf_hashgrid_bwd_workspace_bytes(N, L, T))
+                    ws = torch.empty(((nbytes + 3) // 4,), device=g.device, dtype=torch.int32)
+                    _launch("snf_hashgrid_bwd_sorted", _p(u), _p(g), _p(sc), N, L, F, T, total, col, _p(buf), _p(ws),
+                            nbytes, _stream(), tag=f"F{F}")
                 grads.append(None if fused else buf)
             col += L * F
         return (None, None, *grads)
