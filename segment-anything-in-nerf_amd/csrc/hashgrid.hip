@@ -10,6 +10,7 @@
 // Launch: grid = (ceil(N/256), L): blockIdx.y is the level, so a workgroup (and its neighbours in x)
 // gather from ONE level slab; a thread owns one (sample, level) pair and keeps all 8 corner loads in flight.
 #include "common.hpp"
+#include <stdlib.h>
 
 namespace snf {
 
@@ -136,37 +137,57 @@ __global__ __launch_bounds__(256) void k_hashgrid_bwd(const float* __restrict__ 
 }
 
 // ==========================================================================================
-// Bucketed backward: scatter-add without global atomics.
+// Bucketed backward: scatter-add without global atomics and without float atomics at all.
 //
-// Device-scope fp32 atomics are executed at the memory side of the fabric (the 8 XCD L2s are not coherent), one
-// 4-byte request each: ~13 G atomics/s measured, i.e. 3.8 ms for one L12/F8 grid at 65k samples.  Instead the
-// (sample, level, corner) contributions are counting-sorted by destination: a level's 2^T rows are cut into B = 256
-// buckets of rpb = 2^T/256 consecutive rows; records (4 B: sample<<3 | corner) are partitioned by bucket in three
-// streaming passes, then ONE workgroup per (bucket, level) re-derives index and weight from the record, gathers the
-// upstream gradient, accumulates the bucket's rpb x F slab in LDS (ds_add_f32) and adds the slab to the gradient
-// table with plain coalesced dwordx4 read-modify-writes -- no other workgroup owns those rows.
+// Why: device-scope fp32 atomics execute at the memory side of the fabric (the 8 XCD L2s are not coherent), one
+// 4-byte request each: ~13 G atomics/s measured = 3.8 ms for ONE L12/F8 grid at 65k samples.  LDS float atomics are
+// no way out either: ds_add_f32 retires 0.375 lane-ops/clk/CU on gfx950 against 10.1 for ds_add_u32
+// (tools/ubench/lds_atomic_rate.hip).  So contributions are counting-sorted by destination with INTEGER atomics only:
+//   stage   upstream gradient [N, ld] -> level-major gT[l][n][F] (compact, L2-resident per level)
+//   count   per (tile of samples, level): histogram of the 8 corner rows over B buckets of rpb = 2^T/B consecutive rows
+//   scan    per level: exclusive scan over tiles and buckets -> record offsets
+//   scatter 4-byte records (sample<<3 | corner) written bucket by bucket
+//   reduce  one workgroup per (bucket, level): counting-sort the bucket's records by row inside LDS (rank =
+//           ds_add_rtn_u32), then rows with short segments are summed by their owner thread, rows with long segments
+//           (coarse levels: hundreds of samples per cell) by a whole wave with a shuffle reduction; each row is added
+//           to the gradient table by exactly one lane with a plain read-modify-write (rows are owned, no atomics).
+// B is sized so that a bucket holds ~2048 records (8N/B), i.e. one LDS chunk.
 // ==========================================================================================
-constexpr int HG_TILE = 1024;  // samples per workgroup in the count / scatter passes (4 per thread)
+constexpr int HG_MAX_LOG2B = 12;
+constexpr int HG_RT = 1024;      // threads of the reduce workgroup (16 waves)
+constexpr int HG_CHUNK = 4096;   // records sorted per trip through LDS (4 per thread)
+constexpr int HG_MAX_RPB = 2048; // rows per bucket (two per reduce thread)
+constexpr int HG_LONG = 8;       // segments longer than this are reduced by a wave
 
-__device__ __forceinline__ void bucket_geometry(int log2_T, int& log2B, int& log2rpb) {
-    log2B = log2_T < 8 ? log2_T : 8;
-    log2rpb = log2_T - log2B;
+struct HgGeom {
+    int log2B, log2rpb, spt, nblk;  // buckets, rows per bucket, samples per thread in count/scatter, tiles
+};
+
+inline HgGeom hg_geometry(int N, int log2_T) {
+    HgGeom g;
+    int lb = 8;
+    while (lb < HG_MAX_LOG2B && ((long long)8 * N >> lb) > 2048) ++lb;  // ~2048 records per bucket
+    if (lb > log2_T) lb = log2_T;
+    if (log2_T - lb > 11) lb = log2_T - 11;                             // rpb <= 2048
+    g.log2B = lb;
+    g.log2rpb = log2_T - lb;
+    int spt = (N + 256 * 128 - 1) / (256 * 128);                       // aim for <= 128 tiles
+    g.spt = spt < 4 ? 4 : (spt > 16 ? 16 : spt);
+    g.nblk = (N + 256 * g.spt - 1) / (256 * g.spt);
+    return g;
 }
 
 __global__ __launch_bounds__(256) void k_hg_count(const float* __restrict__ u, const float* __restrict__ scalings, int N,
-                                                  int log2_T, uint32_t* __restrict__ g_hist) {
-    __shared__ uint32_t hist[256];
-    int log2B, log2rpb;
-    bucket_geometry(log2_T, log2B, log2rpb);
-    const int B = 1 << log2B;
+                                                  int log2_T, int log2B, int spt, uint32_t* __restrict__ g_hist) {
+    __shared__ uint32_t hist[1 << HG_MAX_LOG2B];
+    const int B = 1 << log2B, log2rpb = log2_T - log2B;
     const int tid = threadIdx.x, blk = blockIdx.x, l = blockIdx.y, nblk = gridDim.x;
-    hist[tid] = 0;
+    for (int i = tid; i < B; i += 256) hist[i] = 0;
     __syncthreads();
     const uint32_t mask = (1u << log2_T) - 1u;
     const float s = scalings[l];
-#pragma unroll
-    for (int j = 0; j < HG_TILE / 256; ++j) {
-        const int n = blk * HG_TILE + j * 256 + tid;
+    for (int j = 0; j < spt; ++j) {
+        const int n = (blk * spt + j) * 256 + tid;
         if (n < N) {
             const Corners c = corners_of(u, n, s, mask);
 #pragma unroll
@@ -174,58 +195,68 @@ __global__ __launch_bounds__(256) void k_hg_count(const float* __restrict__ u, c
         }
     }
     __syncthreads();
-    if (tid < B) g_hist[((size_t)l * nblk + blk) * B + tid] = hist[tid];
+    for (int i = tid; i < B; i += 256) g_hist[((size_t)l * nblk + blk) * B + i] = hist[i];
 }
 
-// one workgroup per level: per-bucket exclusive scan over the tile histograms, then bucket bases
-__global__ __launch_bounds__(256) void k_hg_scan(int N, int log2_T, int nblk, uint32_t* __restrict__ g_hist,
-                                                 uint32_t* __restrict__ bucket_start) {
+// one workgroup per level: exclusive scan over tiles and buckets (hist -> offs) and the bucket bases.
+// Thread t owns the B/256 consecutive buckets [t*bpt, (t+1)*bpt); input and output arrays are distinct so the tile
+// loads of a thread are independent and stay in flight together.
+__global__ __launch_bounds__(256) void k_hg_scan(int N, int log2B, int nblk, const uint32_t* __restrict__ g_hist,
+                                                 uint32_t* __restrict__ g_offs, uint32_t* __restrict__ bucket_start) {
     __shared__ uint32_t tot[256];
-    int log2B, log2rpb;
-    bucket_geometry(log2_T, log2B, log2rpb);
     const int B = 1 << log2B;
-    const int b = threadIdx.x, l = blockIdx.x;
-    uint32_t total = 0;
-    if (b < B) {
-        for (int blk = 0; blk < nblk; ++blk) {
-            uint32_t* p = &g_hist[((size_t)l * nblk + blk) * B + b];
-            const uint32_t v = *p;
-            *p = total;
-            total += v;
+    const int t = threadIdx.x, l = blockIdx.x;
+    const int bpt = (B + 255) / 256;  // 1 (B <= 256) .. 16
+    uint32_t btot[16];
+    uint32_t mine = 0;
+    for (int q = 0; q < bpt; ++q) {
+        const int b = t * bpt + q;
+        uint32_t total = 0;
+        if (b < B) {
+#pragma unroll 8
+            for (int blk = 0; blk < nblk; ++blk) total += g_hist[((size_t)l * nblk + blk) * B + b];
         }
+        btot[q] = total;
+        mine += total;
     }
-    tot[b] = (b < B) ? total : 0u;
+    tot[t] = mine;
     __syncthreads();
-    // Hillis-Steele inclusive scan over 256 entries
-    for (int d = 1; d < 256; d <<= 1) {
-        const uint32_t v = (b >= d) ? tot[b - d] : 0u;
+    for (int d = 1; d < 256; d <<= 1) {  // Hillis-Steele inclusive scan over the 256 threads
+        const uint32_t v = (t >= d) ? tot[t - d] : 0u;
         __syncthreads();
-        tot[b] += v;
+        tot[t] += v;
         __syncthreads();
     }
-    if (b < B) {
-        const uint32_t base = (uint32_t)((size_t)l * 8u * (uint32_t)N) + (tot[b] - total);
-        bucket_start[l * (B + 1) + b] = base;
-        if (b == B - 1) bucket_start[l * (B + 1) + B] = base + total;
-        for (int blk = 0; blk < nblk; ++blk) g_hist[((size_t)l * nblk + blk) * B + b] += base;
+    uint32_t base = (uint32_t)((size_t)l * 8u * (uint32_t)N) + (tot[t] - mine);
+    for (int q = 0; q < bpt; ++q) {
+        const int b = t * bpt + q;
+        if (b < B) {
+            bucket_start[l * (B + 1) + b] = base;
+            if (b == B - 1) bucket_start[l * (B + 1) + B] = base + btot[q];
+            uint32_t run = base;
+#pragma unroll 8
+            for (int blk = 0; blk < nblk; ++blk) {
+                const size_t idx = ((size_t)l * nblk + blk) * B + b;
+                g_offs[idx] = run;
+                run += g_hist[idx];
+            }
+            base += btot[q];
+        }
     }
 }
 
 __global__ __launch_bounds__(256) void k_hg_scatter(const float* __restrict__ u, const float* __restrict__ scalings, int N,
-                                                    int log2_T, const uint32_t* __restrict__ g_hist,
+                                                    int log2_T, int log2B, int spt, const uint32_t* __restrict__ g_offs,
                                                     uint32_t* __restrict__ records) {
-    __shared__ uint32_t cursor[256];
-    int log2B, log2rpb;
-    bucket_geometry(log2_T, log2B, log2rpb);
-    const int B = 1 << log2B;
+    __shared__ uint32_t cursor[1 << HG_MAX_LOG2B];
+    const int B = 1 << log2B, log2rpb = log2_T - log2B;
     const int tid = threadIdx.x, blk = blockIdx.x, l = blockIdx.y, nblk = gridDim.x;
-    if (tid < B) cursor[tid] = g_hist[((size_t)l * nblk + blk) * B + tid];
+    for (int i = tid; i < B; i += 256) cursor[i] = g_offs[((size_t)l * nblk + blk) * B + i];
     __syncthreads();
     const uint32_t mask = (1u << log2_T) - 1u;
     const float s = scalings[l];
-#pragma unroll
-    for (int j = 0; j < HG_TILE / 256; ++j) {
-        const int n = blk * HG_TILE + j * 256 + tid;
+    for (int j = 0; j < spt; ++j) {
+        const int n = (blk * spt + j) * 256 + tid;
         if (n < N) {
             const Corners c = corners_of(u, n, s, mask);
 #pragma unroll
@@ -237,72 +268,184 @@ __global__ __launch_bounds__(256) void k_hg_scatter(const float* __restrict__ u,
     }
 }
 
+// upstream gradient [N, ld] (this grid's L*F columns) -> level-major staging gT[l][n][F]
 template <int F>
-__global__ __launch_bounds__(256) void k_hg_reduce(const float* __restrict__ u, const float* __restrict__ grad_out,
-                                                   const float* __restrict__ scalings, int log2_T, int ld_out, int col_off,
-                                                   const uint32_t* __restrict__ bucket_start,
-                                                   const uint32_t* __restrict__ records, float* __restrict__ grad_table) {
-    extern __shared__ __attribute__((aligned(16))) float acc[];
-    int log2B, log2rpb;
-    bucket_geometry(log2_T, log2B, log2rpb);
-    const int B = 1 << log2B;
+__global__ __launch_bounds__(256) void k_hg_stage_grad(const float* __restrict__ grad_out, int N, int L, int ld_out,
+                                                       int col_off, float* __restrict__ gT) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long long)N * L) return;
+    const int n = (int)(t / L), l = (int)(t - (long long)n * L);
+    float g[F];
+    load_row<F>(grad_out + (size_t)n * ld_out + col_off + l * F, g);
+    float* o = gT + ((size_t)l * N + n) * F;
+    if constexpr (F == 2) {
+        *reinterpret_cast<float2*>(o) = make_float2(g[0], g[1]);
+    } else {
+        *reinterpret_cast<float4*>(o) = make_float4(g[0], g[1], g[2], g[3]);
+        *reinterpret_cast<float4*>(o + 4) = make_float4(g[4], g[5], g[6], g[7]);
+    }
+}
+
+template <int F>
+__device__ __forceinline__ void row_rmw(float* __restrict__ dst, const float (&a)[F]) {
+    if constexpr (F == 8) {
+        float4 t0 = reinterpret_cast<float4*>(dst)[0], t1 = reinterpret_cast<float4*>(dst)[1];
+        t0.x += a[0]; t0.y += a[1]; t0.z += a[2]; t0.w += a[3];
+        t1.x += a[4]; t1.y += a[5]; t1.z += a[6]; t1.w += a[7];
+        reinterpret_cast<float4*>(dst)[0] = t0;
+        reinterpret_cast<float4*>(dst)[1] = t1;
+    } else {
+        float2 t0 = *reinterpret_cast<float2*>(dst);
+        t0.x += a[0]; t0.y += a[1];
+        *reinterpret_cast<float2*>(dst) = t0;
+    }
+}
+
+template <int F>
+__global__ __launch_bounds__(HG_RT) void k_hg_reduce(const float* __restrict__ u, const float* __restrict__ gT,
+                                                     const float* __restrict__ scalings, int N, int log2_T, int log2B,
+                                                     const uint32_t* __restrict__ bucket_start,
+                                                     const uint32_t* __restrict__ records, float* __restrict__ grad_table) {
+    __shared__ uint32_t cnt[HG_MAX_RPB + 1];  // per-row counts, then exclusive offsets
+    __shared__ uint32_t pay_n[HG_CHUNK];
+    __shared__ float pay_w[HG_CHUNK];
+    __shared__ uint32_t wave_tot[HG_RT / 64];
+    __shared__ uint32_t long_rows[HG_CHUNK / HG_LONG + 1];
+    __shared__ uint32_t n_long;
+    const int B = 1 << log2B, log2rpb = log2_T - log2B;
     const int rpb = 1 << log2rpb;
     const int tid = threadIdx.x, b = blockIdx.x, l = blockIdx.y;
-    const int lane = tid & 63;
+    const int lane = tid & 63, wave = tid >> 6;
     const uint32_t start = bucket_start[l * (B + 1) + b], end = bucket_start[l * (B + 1) + b + 1];
     if (start == end) return;  // nothing lands in this bucket: leave the slab untouched
-    const int nacc = rpb * F;
-    for (int i = tid; i < nacc; i += 256) acc[i] = 0.f;
-    __syncthreads();
     const uint32_t mask = (1u << log2_T) - 1u;
     const float s = scalings[l];
-    for (uint32_t i = start + tid; i < end; i += 256) {
-        const uint32_t rec = records[i];
-        const int n = (int)(rec >> 3);
-        const int k = (int)(rec & 7u);
-        // corner naming of encodings.py:318-325: x takes ceil for k in {0,1,4,5}, y for {0,3,4,7}, z for {0,1,2,3}
-        const bool xc = (0x33u >> k) & 1u, yc = (0x99u >> k) & 1u, zc = (0x0Fu >> k) & 1u;
-        float px, py, pz;
-        {
-#pragma clang fp contract(off)
-            px = u[(size_t)n * 3 + 0] * s;
-            py = u[(size_t)n * 3 + 1] * s;
-            pz = u[(size_t)n * 3 + 2] * s;
-        }
-        const float fxf = floorf(px), fyf = floorf(py), fzf = floorf(pz);
-        const float ox = px - fxf, oy = py - fyf, oz = pz - fzf;
-        const uint32_t ix = (uint32_t)(int)(xc ? ceilf(px) : fxf);
-        const uint32_t iy = (uint32_t)(int)(yc ? ceilf(py) : fyf) * PRIME_Y;
-        const uint32_t iz = (uint32_t)(int)(zc ? ceilf(pz) : fzf) * PRIME_Z;
-        const uint32_t row = (ix ^ iy ^ iz) & mask;
-        const float wx = xc ? ox : 1.f - ox, wy = yc ? oy : 1.f - oy, wz = zc ? oz : 1.f - oz;
-        const float w = wz * wy * wx;
-        if (w != 0.f) {
-            float g[F];
-            load_row<F>(grad_out + (size_t)n * ld_out + col_off + l * F, g);
-            float* dst = acc + (size_t)(row & (uint32_t)(rpb - 1)) * F;
-            // feature order rotated by lane: spreads the 64 lanes of a ds_add over all LDS banks
-#pragma unroll
-            for (int j = 0; j < F; ++j) {
-                const int f = (j + lane) & (F - 1);
-                atomicAdd(dst + f, w * g[f]);
-            }
-        }
-    }
-    __syncthreads();
+    const float* __restrict__ gl = gT + (size_t)l * N * F;
     float* __restrict__ slab = grad_table + (((size_t)l << log2_T) + ((size_t)b << log2rpb)) * F;
-    if ((nacc & 3) == 0) {
-        for (int i = tid; i < nacc / 4; i += 256) {
-            const float4 a = reinterpret_cast<const float4*>(acc)[i];
-            if (a.x != 0.f || a.y != 0.f || a.z != 0.f || a.w != 0.f) {
-                float4 t = reinterpret_cast<float4*>(slab)[i];
-                t.x += a.x; t.y += a.y; t.z += a.z; t.w += a.w;
-                reinterpret_cast<float4*>(slab)[i] = t;
+
+    for (uint32_t c0 = start; c0 < end; c0 += HG_CHUNK) {
+        for (int i = tid; i <= rpb; i += HG_RT) cnt[i] = 0u;
+        if (tid == 0) n_long = 0u;
+        __syncthreads();  // also orders the previous chunk's table updates before this chunk's
+        // ---- phase 1: decode 4 records per thread, rank them within their row (integer atomics only)
+        uint32_t rec[4], row[4], pos[4];
+        float wgt[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t i = c0 + tid + (uint32_t)HG_RT * j;
+            rec[j] = (i < end) ? records[i] : 0xFFFFFFFFu;
+        }
+        float ux[4], uy[4], uz[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const size_t n = (rec[j] == 0xFFFFFFFFu) ? 0 : (rec[j] >> 3);
+            ux[j] = u[n * 3 + 0];
+            uy[j] = u[n * 3 + 1];
+            uz[j] = u[n * 3 + 2];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = (int)(rec[j] & 7u);
+            // corner naming of encodings.py:318-325: x takes ceil for k in {0,1,4,5}, y for {0,3,4,7}, z for {0,1,2,3}
+            const bool xc = (0x33u >> k) & 1u, yc = (0x99u >> k) & 1u, zc = (0x0Fu >> k) & 1u;
+            float px, py, pz;
+            {
+#pragma clang fp contract(off)
+                px = ux[j] * s;
+                py = uy[j] * s;
+                pz = uz[j] * s;
+            }
+            const float fxf = floorf(px), fyf = floorf(py), fzf = floorf(pz);
+            const float ox = px - fxf, oy = py - fyf, oz = pz - fzf;
+            const uint32_t ix = (uint32_t)(int)(xc ? ceilf(px) : fxf);
+            const uint32_t iy = (uint32_t)(int)(yc ? ceilf(py) : fyf) * PRIME_Y;
+            const uint32_t iz = (uint32_t)(int)(zc ? ceilf(pz) : fzf) * PRIME_Z;
+            const float wx = xc ? ox : 1.f - ox, wy = yc ? oy : 1.f - oy, wz = zc ? oz : 1.f - oz;
+            wgt[j] = wz * wy * wx;
+            row[j] = ((ix ^ iy ^ iz) & mask) & (uint32_t)(rpb - 1);
+            const bool live = (rec[j] != 0xFFFFFFFFu) && (wgt[j] != 0.f);
+            pos[j] = live ? atomicAdd(&cnt[row[j]], 1u) : 0xFFFFFFFFu;
+        }
+        __syncthreads();
+        // ---- phase 2: exclusive scan of cnt[0..rpb) in place (thread t scans entries 2t, 2t+1); cnt[rpb] = total.
+        //      Long rows are queued for the wave-cooperative pass.
+        {
+            const int i0 = tid * 2;
+            const uint32_t v0 = (i0 < rpb) ? cnt[i0] : 0u;
+            const uint32_t v1 = (i0 + 1 < rpb) ? cnt[i0 + 1] : 0u;
+            if (v0 > HG_LONG) long_rows[atomicAdd(&n_long, 1u)] = (uint32_t)i0;
+            if (v1 > HG_LONG) long_rows[atomicAdd(&n_long, 1u)] = (uint32_t)i0 + 1u;
+            const uint32_t sum = v0 + v1;
+            uint32_t inc = sum;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t t = __shfl_up(inc, d, 64);
+                if (lane >= d) inc += t;
+            }
+            if (lane == 63) wave_tot[wave] = inc;
+            __syncthreads();
+            uint32_t base = 0;
+            for (int w2 = 0; w2 < wave; ++w2) base += wave_tot[w2];
+            const uint32_t excl = base + inc - sum;
+            if (i0 < rpb) cnt[i0] = excl;
+            if (i0 + 1 < rpb) cnt[i0 + 1] = excl + v0;
+            if (tid == HG_RT - 1) cnt[rpb] = base + inc;
+        }
+        __syncthreads();
+        // ---- phase 3: scatter (sample, weight) to the row-sorted order
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (pos[j] != 0xFFFFFFFFu) {
+                const uint32_t e = cnt[row[j]] + pos[j];
+                pay_n[e] = rec[j] >> 3;
+                pay_w[e] = wgt[j];
             }
         }
-    } else {
-        for (int i = tid; i < nacc; i += 256)
-            if (acc[i] != 0.f) slab[i] += acc[i];
+        __syncthreads();
+        // ---- phase 4a: short segments, one owner thread per row (rows tid and tid + 1024)
+#pragma unroll
+        for (int sidx = 0; sidx < 2; ++sidx) {
+            const int r = tid + sidx * HG_RT;
+            if (r < rpb) {
+                const uint32_t e0 = cnt[r], e1 = cnt[r + 1];
+                if (e1 > e0 && e1 - e0 <= HG_LONG) {
+                    float a[F];
+#pragma unroll
+                    for (int f = 0; f < F; ++f) a[f] = 0.f;
+                    for (uint32_t e = e0; e < e1; ++e) {
+                        float g[F];
+                        load_row<F>(gl + (size_t)pay_n[e] * F, g);
+                        const float w = pay_w[e];
+#pragma unroll
+                        for (int f = 0; f < F; ++f) a[f] += w * g[f];
+                    }
+                    row_rmw<F>(slab + (size_t)r * F, a);
+                }
+            }
+        }
+        // ---- phase 4b: long segments, one wave per row
+        const uint32_t nl = n_long;
+        for (uint32_t q = wave; q < nl; q += HG_RT / 64) {
+            const uint32_t r = long_rows[q];
+            const uint32_t e0 = cnt[r], e1 = cnt[r + 1];
+            float a[F];
+#pragma unroll
+            for (int f = 0; f < F; ++f) a[f] = 0.f;
+            for (uint32_t e = e0 + lane; e < e1; e += 64) {
+                float g[F];
+                load_row<F>(gl + (size_t)pay_n[e] * F, g);
+                const float w = pay_w[e];
+#pragma unroll
+                for (int f = 0; f < F; ++f) a[f] += w * g[f];
+            }
+#pragma unroll
+            for (int f = 0; f < F; ++f) {
+#pragma unroll
+                for (int d = 32; d > 0; d >>= 1) a[f] += __shfl_xor(a[f], d, 64);
+            }
+            if (lane == 0) row_rmw<F>(slab + (size_t)r * F, a);
+        }
+        __syncthreads();
     }
 }
 
@@ -357,10 +500,11 @@ extern "C" int snf_hashgrid_bwd(const float* u, const float* grad_out, const flo
 
 // ---- bucketed (atomic-free) backward ---------------------------------------------------------------------
 static size_t hg_ws_words(int N, int L, int log2_T) {
-    const int log2B = log2_T < 8 ? log2_T : 8;
-    const size_t B = (size_t)1 << log2B;
-    const size_t nblk = (size_t)ceil_div(N, HG_TILE);
-    return (size_t)L * 8 * (size_t)N + (size_t)L * nblk * B + (size_t)L * (B + 1);
+    const HgGeom g = hg_geometry(N, log2_T);
+    const size_t B = (size_t)1 << g.log2B;
+    // records | tile histograms | tile offsets | bucket starts (padded to 4 words) | staged gradients (F <= 8 floats)
+    return (size_t)L * 8 * (size_t)N + 2 * (size_t)L * g.nblk * B + (((size_t)L * (B + 1) + 3) & ~(size_t)3) +
+           (size_t)L * (size_t)N * 8;
 }
 
 extern "C" int64_t snf_hashgrid_bwd_workspace_bytes(int N, int L, int log2_T) {
@@ -375,35 +519,40 @@ extern "C" int snf_hashgrid_bwd_sorted(const float* u, const float* grad_out, co
     if (rc) return rc;
     SNF_REQUIRE(((uintptr_t)grad_out % 16) == 0 && ((uintptr_t)grad_table % 16) == 0,
                 "snf_hashgrid_bwd_sorted: unaligned pointer");
-    const int log2B = log2_T < 8 ? log2_T : 8;
-    const int log2rpb = log2_T - log2B;
-    const size_t lds = ((size_t)F << log2rpb) * sizeof(float);
-    SNF_REQUIRE((long long)N * 8 < (1LL << 31) / (L > 0 ? 1 : 1) && (long long)L * 8 * N < (1LL << 32),
+    SNF_REQUIRE((long long)L * 8 * N < (1LL << 32) && N < (1 << 29),
                 "snf_hashgrid_bwd_sorted: too many records for 32-bit offsets (N=%d L=%d)", N, L);
-    SNF_REQUIRE(N < (1 << 29), "snf_hashgrid_bwd_sorted: N too large for the record packing");
-    if (lds > 64 * 1024) {
-        // slab does not fit LDS (log2_T > 19 at F=8): fall back to the atomic kernel
+    const HgGeom g = hg_geometry(N, log2_T);
+    if ((1 << g.log2rpb) > HG_MAX_RPB) {
+        // more than 2048 rows per bucket even at 4096 buckets (log2_T > 23): fall back to the atomic kernel
         return snf_hashgrid_bwd(u, grad_out, scalings, N, L, F, log2_T, ld_out, col_off, grad_table, stream);
     }
     SNF_REQUIRE(workspace && workspace_bytes >= (int64_t)(hg_ws_words(N, L, log2_T) * sizeof(uint32_t)),
                 "snf_hashgrid_bwd_sorted: workspace too small (need %lld bytes)",
                 (long long)(hg_ws_words(N, L, log2_T) * sizeof(uint32_t)));
     SNF_REQUIRE(((uintptr_t)workspace % 16) == 0, "snf_hashgrid_bwd_sorted: unaligned workspace");
-    const int B = 1 << log2B;
-    const int nblk = ceil_div(N, HG_TILE);
+    const int B = 1 << g.log2B;
+    const int nblk = g.nblk;
     uint32_t* records = (uint32_t*)workspace;
     uint32_t* hist = records + (size_t)L * 8 * (size_t)N;
-    uint32_t* bstart = hist + (size_t)L * nblk * B;
+    uint32_t* offs = hist + (size_t)L * nblk * B;
+    uint32_t* bstart = offs + (size_t)L * nblk * B;
+    float* gT = (float*)(bstart + (((size_t)L * (B + 1) + 3) & ~(size_t)3));
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_hg_count, dim3(nblk, L), dim3(256), 0, st, u, scalings, N, log2_T, hist);
-    hipLaunchKernelGGL(k_hg_scan, dim3(L), dim3(256), 0, st, N, log2_T, nblk, hist, bstart);
-    hipLaunchKernelGGL(k_hg_scatter, dim3(nblk, L), dim3(256), 0, st, u, scalings, N, log2_T, hist, records);
+    const int tblocks = ceil_div((long long)N * L, 256);
     if (F == 2)
-        hipLaunchKernelGGL(k_hg_reduce<2>, dim3(B, L), dim3(256), lds, st, u, grad_out, scalings, log2_T, ld_out, col_off,
-                           bstart, records, grad_table);
+        hipLaunchKernelGGL(k_hg_stage_grad<2>, dim3(tblocks), dim3(256), 0, st, grad_out, N, L, ld_out, col_off, gT);
     else
-        hipLaunchKernelGGL(k_hg_reduce<8>, dim3(B, L), dim3(256), lds, st, u, grad_out, scalings, log2_T, ld_out, col_off,
-                           bstart, records, grad_table);
+        hipLaunchKernelGGL(k_hg_stage_grad<8>, dim3(tblocks), dim3(256), 0, st, grad_out, N, L, ld_out, col_off, gT);
+    hipLaunchKernelGGL(k_hg_count, dim3(nblk, L), dim3(256), 0, st, u, scalings, N, log2_T, g.log2B, g.spt, hist);
+    hipLaunchKernelGGL(k_hg_scan, dim3(L), dim3(256), 0, st, N, g.log2B, nblk, hist, offs, bstart);
+    hipLaunchKernelGGL(k_hg_scatter, dim3(nblk, L), dim3(256), 0, st, u, scalings, N, log2_T, g.log2B, g.spt, offs,
+                       records);
+    if (F == 2)
+        hipLaunchKernelGGL(k_hg_reduce<2>, dim3(B, L), dim3(HG_RT), 0, st, u, gT, scalings, N, log2_T, g.log2B, bstart,
+                           records, grad_table);
+    else
+        hipLaunchKernelGGL(k_hg_reduce<8>, dim3(B, L), dim3(HG_RT), 0, st, u, gT, scalings, N, log2_T, g.log2B, bstart,
+                           records, grad_table);
     SNF_LAUNCH_CHECK("snf_hashgrid_bwd_sorted");
     return SNF_OK;
 }
