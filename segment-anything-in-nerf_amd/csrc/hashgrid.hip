@@ -155,9 +155,10 @@ __global__ __launch_bounds__(256) void k_hashgrid_bwd(const float* __restrict__ 
 // ==========================================================================================
 constexpr int HG_MAX_LOG2B = 12;
 constexpr int HG_RT = 1024;      // threads of the reduce workgroup (16 waves)
-constexpr int HG_CHUNK = 4096;   // records sorted per trip through LDS (4 per thread)
+constexpr int HG_CHUNK = 4096;   // records sorted per trip through LDS (HG_RPT per thread)
+constexpr int HG_RPT = HG_CHUNK / HG_RT;
 constexpr int HG_MAX_RPB = 2048; // rows per bucket (two per reduce thread)
-constexpr int HG_LONG = 8;       // segments longer than this are reduced by a wave
+constexpr int HG_LONG = 16;      // segments longer than this are reduced by a wave
 
 struct HgGeom {
     int log2B, log2rpb, spt, nblk;  // buckets, rows per bucket, samples per thread in count/scatter, tiles
@@ -165,8 +166,9 @@ struct HgGeom {
 
 inline HgGeom hg_geometry(int N, int log2_T) {
     HgGeom g;
+    // 256 buckets per level: a tile then emits long runs per bucket (coalescing record writes) and big-N grids simply
+    // take several LDS chunks per bucket; more buckets only when a bucket would exceed 2048 rows.
     int lb = 8;
-    while (lb < HG_MAX_LOG2B && ((long long)8 * N >> lb) > 2048) ++lb;  // ~2048 records per bucket
     if (lb > log2_T) lb = log2_T;
     if (log2_T - lb > 11) lb = log2_T - 11;                             // rpb <= 2048
     g.log2B = lb;
@@ -199,49 +201,63 @@ __global__ __launch_bounds__(256) void k_hg_count(const float* __restrict__ u, c
 }
 
 // one workgroup per level: exclusive scan over tiles and buckets (hist -> offs) and the bucket bases.
-// Thread t owns the B/256 consecutive buckets [t*bpt, (t+1)*bpt); input and output arrays are distinct so the tile
-// loads of a thread are independent and stay in flight together.
-__global__ __launch_bounds__(256) void k_hg_scan(int N, int log2B, int nblk, const uint32_t* __restrict__ g_hist,
-                                                 uint32_t* __restrict__ g_offs, uint32_t* __restrict__ bucket_start) {
+// 1024 threads = 4 tile-partitions x 256 bucket columns; column c owns the B/256 consecutive buckets [c*bpt, (c+1)*bpt).
+// Input and output arrays are distinct so a thread's tile loads are independent and stay in flight together.
+__global__ __launch_bounds__(1024) void k_hg_scan(int N, int log2B, int nblk, const uint32_t* __restrict__ g_hist,
+                                                  uint32_t* __restrict__ g_offs, uint32_t* __restrict__ bucket_start) {
+    __shared__ uint32_t part_tot[4][256][16];  // [tile partition][column][bucket within column]
     __shared__ uint32_t tot[256];
     const int B = 1 << log2B;
-    const int t = threadIdx.x, l = blockIdx.x;
+    const int c = threadIdx.x & 255, part = threadIdx.x >> 8, l = blockIdx.x;
     const int bpt = (B + 255) / 256;  // 1 (B <= 256) .. 16
-    uint32_t btot[16];
-    uint32_t mine = 0;
+    const int t0 = (int)((long long)nblk * part / 4), t1 = (int)((long long)nblk * (part + 1) / 4);
     for (int q = 0; q < bpt; ++q) {
-        const int b = t * bpt + q;
+        const int b = c * bpt + q;
         uint32_t total = 0;
         if (b < B) {
 #pragma unroll 8
-            for (int blk = 0; blk < nblk; ++blk) total += g_hist[((size_t)l * nblk + blk) * B + b];
+            for (int blk = t0; blk < t1; ++blk) total += g_hist[((size_t)l * nblk + blk) * B + b];
         }
-        btot[q] = total;
-        mine += total;
+        part_tot[part][c][q] = total;
     }
-    tot[t] = mine;
     __syncthreads();
-    for (int d = 1; d < 256; d <<= 1) {  // Hillis-Steele inclusive scan over the 256 threads
-        const uint32_t v = (t >= d) ? tot[t - d] : 0u;
+    uint32_t mine = 0;
+    if (part == 0) {
+        for (int q = 0; q < bpt; ++q)
+            mine += part_tot[0][c][q] + part_tot[1][c][q] + part_tot[2][c][q] + part_tot[3][c][q];
+        tot[c] = mine;
+    }
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {  // Hillis-Steele inclusive scan over the 256 columns
+        uint32_t v = 0;
+        if (part == 0 && c >= d) v = tot[c - d];
         __syncthreads();
-        tot[t] += v;
+        if (part == 0) tot[c] += v;
         __syncthreads();
     }
-    uint32_t base = (uint32_t)((size_t)l * 8u * (uint32_t)N) + (tot[t] - mine);
+    // column base = exclusive prefix of column totals; within the column, buckets and tile partitions in order
+    uint32_t colsum = 0;
+    for (int q = 0; q < bpt; ++q)
+        colsum += part_tot[0][c][q] + part_tot[1][c][q] + part_tot[2][c][q] + part_tot[3][c][q];
+    uint32_t base = (uint32_t)((size_t)l * 8u * (uint32_t)N) + (tot[c] - colsum);
     for (int q = 0; q < bpt; ++q) {
-        const int b = t * bpt + q;
+        const int b = c * bpt + q;
+        const uint32_t btot = part_tot[0][c][q] + part_tot[1][c][q] + part_tot[2][c][q] + part_tot[3][c][q];
         if (b < B) {
-            bucket_start[l * (B + 1) + b] = base;
-            if (b == B - 1) bucket_start[l * (B + 1) + B] = base + btot[q];
+            if (part == 0) {
+                bucket_start[l * (B + 1) + b] = base;
+                if (b == B - 1) bucket_start[l * (B + 1) + B] = base + btot;
+            }
             uint32_t run = base;
+            for (int pp = 0; pp < part; ++pp) run += part_tot[pp][c][q];
 #pragma unroll 8
-            for (int blk = 0; blk < nblk; ++blk) {
+            for (int blk = t0; blk < t1; ++blk) {
                 const size_t idx = ((size_t)l * nblk + blk) * B + b;
                 g_offs[idx] = run;
                 run += g_hist[idx];
             }
-            base += btot[q];
         }
+        base += btot;
     }
 }
 
@@ -305,7 +321,8 @@ template <int F>
 __global__ __launch_bounds__(HG_RT) void k_hg_reduce(const float* __restrict__ u, const float* __restrict__ gT,
                                                      const float* __restrict__ scalings, int N, int log2_T, int log2B,
                                                      const uint32_t* __restrict__ bucket_start,
-                                                     const uint32_t* __restrict__ records, float* __restrict__ grad_table) {
+                                                     const uint32_t* __restrict__ records, float* __restrict__ grad_table,
+                                                     uint32_t hg_long) {
     __shared__ uint32_t cnt[HG_MAX_RPB + 1];  // per-row counts, then exclusive offsets
     __shared__ uint32_t pay_n[HG_CHUNK];
     __shared__ float pay_w[HG_CHUNK];
@@ -327,24 +344,24 @@ __global__ __launch_bounds__(HG_RT) void k_hg_reduce(const float* __restrict__ u
         for (int i = tid; i <= rpb; i += HG_RT) cnt[i] = 0u;
         if (tid == 0) n_long = 0u;
         __syncthreads();  // also orders the previous chunk's table updates before this chunk's
-        // ---- phase 1: decode 4 records per thread, rank them within their row (integer atomics only)
-        uint32_t rec[4], row[4], pos[4];
-        float wgt[4];
+        // ---- phase 1: decode HG_RPT records per thread, rank them within their row (integer atomics only)
+        uint32_t rec[HG_RPT], row[HG_RPT], pos[HG_RPT];
+        float wgt[HG_RPT];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < HG_RPT; ++j) {
             const uint32_t i = c0 + tid + (uint32_t)HG_RT * j;
             rec[j] = (i < end) ? records[i] : 0xFFFFFFFFu;
         }
-        float ux[4], uy[4], uz[4];
+        float ux[HG_RPT], uy[HG_RPT], uz[HG_RPT];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < HG_RPT; ++j) {
             const size_t n = (rec[j] == 0xFFFFFFFFu) ? 0 : (rec[j] >> 3);
             ux[j] = u[n * 3 + 0];
             uy[j] = u[n * 3 + 1];
             uz[j] = u[n * 3 + 2];
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < HG_RPT; ++j) {
             const int k = (int)(rec[j] & 7u);
             // corner naming of encodings.py:318-325: x takes ceil for k in {0,1,4,5}, y for {0,3,4,7}, z for {0,1,2,3}
             const bool xc = (0x33u >> k) & 1u, yc = (0x99u >> k) & 1u, zc = (0x0Fu >> k) & 1u;
@@ -373,8 +390,8 @@ __global__ __launch_bounds__(HG_RT) void k_hg_reduce(const float* __restrict__ u
             const int i0 = tid * 2;
             const uint32_t v0 = (i0 < rpb) ? cnt[i0] : 0u;
             const uint32_t v1 = (i0 + 1 < rpb) ? cnt[i0 + 1] : 0u;
-            if (v0 > HG_LONG) long_rows[atomicAdd(&n_long, 1u)] = (uint32_t)i0;
-            if (v1 > HG_LONG) long_rows[atomicAdd(&n_long, 1u)] = (uint32_t)i0 + 1u;
+            if (v0 > hg_long) long_rows[atomicAdd(&n_long, 1u)] = (uint32_t)i0;
+            if (v1 > hg_long) long_rows[atomicAdd(&n_long, 1u)] = (uint32_t)i0 + 1u;
             const uint32_t sum = v0 + v1;
             uint32_t inc = sum;
 #pragma unroll
@@ -394,7 +411,7 @@ __global__ __launch_bounds__(HG_RT) void k_hg_reduce(const float* __restrict__ u
         __syncthreads();
         // ---- phase 3: scatter (sample, weight) to the row-sorted order
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < HG_RPT; ++j) {
             if (pos[j] != 0xFFFFFFFFu) {
                 const uint32_t e = cnt[row[j]] + pos[j];
                 pay_n[e] = rec[j] >> 3;
@@ -408,7 +425,7 @@ __global__ __launch_bounds__(HG_RT) void k_hg_reduce(const float* __restrict__ u
             const int r = tid + sidx * HG_RT;
             if (r < rpb) {
                 const uint32_t e0 = cnt[r], e1 = cnt[r + 1];
-                if (e1 > e0 && e1 - e0 <= HG_LONG) {
+                if (e1 > e0 && e1 - e0 <= hg_long) {
                     float a[F];
 #pragma unroll
                     for (int f = 0; f < F; ++f) a[f] = 0.f;
@@ -538,21 +555,23 @@ extern "C" int snf_hashgrid_bwd_sorted(const float* u, const float* grad_out, co
     uint32_t* bstart = offs + (size_t)L * nblk * B;
     float* gT = (float*)(bstart + (((size_t)L * (B + 1) + 3) & ~(size_t)3));
     hipStream_t st = (hipStream_t)stream;
+    const char* e_long = getenv("SNF_HG_LONG");
+    const uint32_t hg_long = e_long ? (uint32_t)atoi(e_long) : (uint32_t)HG_LONG;
     const int tblocks = ceil_div((long long)N * L, 256);
     if (F == 2)
         hipLaunchKernelGGL(k_hg_stage_grad<2>, dim3(tblocks), dim3(256), 0, st, grad_out, N, L, ld_out, col_off, gT);
     else
         hipLaunchKernelGGL(k_hg_stage_grad<8>, dim3(tblocks), dim3(256), 0, st, grad_out, N, L, ld_out, col_off, gT);
     hipLaunchKernelGGL(k_hg_count, dim3(nblk, L), dim3(256), 0, st, u, scalings, N, log2_T, g.log2B, g.spt, hist);
-    hipLaunchKernelGGL(k_hg_scan, dim3(L), dim3(256), 0, st, N, g.log2B, nblk, hist, offs, bstart);
+    hipLaunchKernelGGL(k_hg_scan, dim3(L), dim3(1024), 0, st, N, g.log2B, nblk, hist, offs, bstart);
     hipLaunchKernelGGL(k_hg_scatter, dim3(nblk, L), dim3(256), 0, st, u, scalings, N, log2_T, g.log2B, g.spt, offs,
                        records);
     if (F == 2)
         hipLaunchKernelGGL(k_hg_reduce<2>, dim3(B, L), dim3(HG_RT), 0, st, u, gT, scalings, N, log2_T, g.log2B, bstart,
-                           records, grad_table);
+                           records, grad_table, hg_long);
     else
         hipLaunchKernelGGL(k_hg_reduce<8>, dim3(B, L), dim3(HG_RT), 0, st, u, gT, scalings, N, log2_T, g.log2B, bstart,
-                           records, grad_table);
+                           records, grad_table, hg_long);
     SNF_LAUNCH_CHECK("snf_hashgrid_bwd_sorted");
     return SNF_OK;
 }

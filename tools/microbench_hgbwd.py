@@ -26,7 +26,7 @@ def run(N, L, F, T, mn, mx, ld, clustered):
     return {k: round(v["avg_ms"], 4) for k, v in s.items()}
 
 for dbg in os.environ.get("DBGS", "0").split(","):
-    os.environ["SNF_HG_DEBUG"] = dbg
+    os.environ["SNF_HG_LONG"] = dbg
     print("dbg", dbg, "F8 uniform  ", run(65536, 12, 8, 19, 128, 512, 96, False))
     print("dbg", dbg, "F8 clustered", run(65536, 12, 8, 19, 16, 128, 96, True))
     print("dbg", dbg, "F2 field    ", run(524288, 16, 2, 19, 16, 2048, 32, True))
