@@ -44,13 +44,10 @@ def algorithmic_model(key: str, w: dict):
     R, P, S, K = w["R"], w["P"], w["S"], w["K"]
     name, _, tag = key.partition("/")
     if name in ("snf_hashgrid_fwd", "snf_hashgrid_bwd", "snf_hashgrid_bwd_sorted"):
-        F = int(tag[1:])
+        F, L = (int(x) for x in tag[1:].split("L"))
         rw = 1 if name.endswith("fwd") else 2
-        if F == 8:
-            n, L = R * K, 12
-        else:
-            # F=2 launches: proposal (R*P samples, 5 levels) and field (R*S, 16 levels); report the field grid
-            n, L = R * S, 16
+        # F=8: feature grids on the R*K top-K samples; F=2: proposal grid (L=5, R*P samples) or field grid (L=16, R*S)
+        n = R * K if F == 8 else (R * P if L == 5 else R * S)
         return "hbm", float(n * L * 8 * F * 4 * rw), "GB/s"
     if name.startswith("snf_linear"):
         i, o = (int(x) for x in tag.split("x"))

@@ -154,10 +154,11 @@ __global__ __launch_bounds__(256) void k_hashgrid_bwd(const float* __restrict__ 
 // B is sized so that a bucket holds ~2048 records (8N/B), i.e. one LDS chunk.
 // ==========================================================================================
 constexpr int HG_MAX_LOG2B = 12;
-constexpr int HG_RT = 1024;      // threads of the reduce workgroup (16 waves)
-constexpr int HG_CHUNK = 4096;   // records sorted per trip through LDS (HG_RPT per thread)
+constexpr int HG_RT = 512;       // threads of the reduce workgroup (8 waves; 4 workgroups per CU)
+constexpr int HG_CHUNK = 2048;   // records sorted per trip through LDS (HG_RPT per thread)
 constexpr int HG_RPT = HG_CHUNK / HG_RT;
-constexpr int HG_MAX_RPB = 2048; // rows per bucket (two per reduce thread)
+constexpr int HG_MAX_RPB = 2048; // rows per bucket (HG_ROWS_PT per reduce thread)
+constexpr int HG_ROWS_PT = HG_MAX_RPB / HG_RT;
 constexpr int HG_LONG = 16;      // segments longer than this are reduced by a wave
 
 struct HgGeom {
@@ -261,24 +262,34 @@ __global__ __launch_bounds__(1024) void k_hg_scan(int N, int log2B, int nblk, co
     }
 }
 
+// record = 8 bytes { key = sample | (row_in_bucket << 21), corner weight w }: one aligned dwordx2 store per record in
+// the scatter pass; the reduce pass needs no position gather and no index math, only the staged-gradient gather.
+// (Payload-carrying 12/36-byte records were measured: the scatter's store-transaction count made them slower.)
+constexpr int HG_SAMPLE_BITS = 21;  // N <= 2^21 per launch (row_in_bucket needs 11 bits)
+
 __global__ __launch_bounds__(256) void k_hg_scatter(const float* __restrict__ u, const float* __restrict__ scalings, int N,
                                                     int log2_T, int log2B, int spt, const uint32_t* __restrict__ g_offs,
-                                                    uint32_t* __restrict__ records) {
+                                                    uint2* __restrict__ records) {
     __shared__ uint32_t cursor[1 << HG_MAX_LOG2B];
     const int B = 1 << log2B, log2rpb = log2_T - log2B;
     const int tid = threadIdx.x, blk = blockIdx.x, l = blockIdx.y, nblk = gridDim.x;
     for (int i = tid; i < B; i += 256) cursor[i] = g_offs[((size_t)l * nblk + blk) * B + i];
     __syncthreads();
-    const uint32_t mask = (1u << log2_T) - 1u;
+    const uint32_t mask = (1u << log2_T) - 1u, rmask = (1u << log2rpb) - 1u;
     const float s = scalings[l];
     for (int j = 0; j < spt; ++j) {
         const int n = (blk * spt + j) * 256 + tid;
         if (n < N) {
             const Corners c = corners_of(u, n, s, mask);
+            const float ox = c.ox, oy = c.oy, oz = c.oz;
+            const float mx = 1.f - ox, my = 1.f - oy, mz = 1.f - oz;
+            float w[8];  // chain-rule weights in autograd's order: ((g*z)*y)*x
+            w[0] = oz * oy * ox; w[3] = oz * oy * mx; w[1] = oz * my * ox; w[2] = oz * my * mx;
+            w[4] = mz * oy * ox; w[7] = mz * oy * mx; w[5] = mz * my * ox; w[6] = mz * my * mx;
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const uint32_t slot = atomicAdd(&cursor[c.idx[k] >> log2rpb], 1u);
-                records[slot] = ((uint32_t)n << 3) | (uint32_t)k;
+                records[slot] = make_uint2((uint32_t)n | ((c.idx[k] & rmask) << HG_SAMPLE_BITS), __float_as_uint(w[k]));
             }
         }
     }
@@ -317,17 +328,23 @@ __device__ __forceinline__ void row_rmw(float* __restrict__ dst, const float (&a
     }
 }
 
+// Reduce pass, one workgroup per (bucket, level); integer LDS atomics only (see the header of this section).
+// Per chunk of HG_CHUNK records (streamed, coalesced; no index math):
+//   1. every thread loads HG_RPT records {sample|row, w}, gathers the staged gradient of its samples (independent
+//      loads) and ranks each record within its row (pos = ds_add_rtn_u32 on the row counter);
+//   2. exclusive scan of the row counters -> segment offsets; rows with long segments are queued;
+//   3. the record payloads w*g are written to their row-sorted slots of an LDS staging array;
+//   4. owner threads sum their rows' (short) segments from LDS into registers, waves sum the long ones with a shuffle
+//      reduction; each row is added to the gradient table by exactly one lane with a plain read-modify-write.
 template <int F>
-__global__ __launch_bounds__(HG_RT) void k_hg_reduce(const float* __restrict__ u, const float* __restrict__ gT,
-                                                     const float* __restrict__ scalings, int N, int log2_T, int log2B,
+__global__ __launch_bounds__(HG_RT) void k_hg_reduce(const float* __restrict__ gT, int N, int log2_T, int log2B,
                                                      const uint32_t* __restrict__ bucket_start,
-                                                     const uint32_t* __restrict__ records, float* __restrict__ grad_table,
+                                                     const uint2* __restrict__ records, float* __restrict__ grad_table,
                                                      uint32_t hg_long) {
     __shared__ uint32_t cnt[HG_MAX_RPB + 1];  // per-row counts, then exclusive offsets
-    __shared__ uint32_t pay_n[HG_CHUNK];
-    __shared__ float pay_w[HG_CHUNK];
+    __shared__ __attribute__((aligned(16))) float val[HG_CHUNK * F];  // w*g per record, row-sorted
     __shared__ uint32_t wave_tot[HG_RT / 64];
-    __shared__ uint32_t long_rows[HG_CHUNK / HG_LONG + 1];
+    __shared__ uint32_t long_rows[HG_CHUNK / 8 + 1];
     __shared__ uint32_t n_long;
     const int B = 1 << log2B, log2rpb = log2_T - log2B;
     const int rpb = 1 << log2rpb;
@@ -335,64 +352,54 @@ __global__ __launch_bounds__(HG_RT) void k_hg_reduce(const float* __restrict__ u
     const int lane = tid & 63, wave = tid >> 6;
     const uint32_t start = bucket_start[l * (B + 1) + b], end = bucket_start[l * (B + 1) + b + 1];
     if (start == end) return;  // nothing lands in this bucket: leave the slab untouched
-    const uint32_t mask = (1u << log2_T) - 1u;
-    const float s = scalings[l];
-    const float* __restrict__ gl = gT + (size_t)l * N * F;
     float* __restrict__ slab = grad_table + (((size_t)l << log2_T) + ((size_t)b << log2rpb)) * F;
+    const float* __restrict__ gl = gT + (size_t)l * N * F;
+    if (hg_long < 8u) hg_long = 8u;  // capacity of long_rows
+    float racc[HG_ROWS_PT][F];       // running sums of the owned rows over all chunks (short segments)
+#pragma unroll
+    for (int q = 0; q < HG_ROWS_PT; ++q)
+#pragma unroll
+        for (int f = 0; f < F; ++f) racc[q][f] = 0.f;
 
     for (uint32_t c0 = start; c0 < end; c0 += HG_CHUNK) {
         for (int i = tid; i <= rpb; i += HG_RT) cnt[i] = 0u;
         if (tid == 0) n_long = 0u;
         __syncthreads();  // also orders the previous chunk's table updates before this chunk's
-        // ---- phase 1: decode HG_RPT records per thread, rank them within their row (integer atomics only)
-        uint32_t rec[HG_RPT], row[HG_RPT], pos[HG_RPT];
-        float wgt[HG_RPT];
+        // ---- phase 1: stream the records in, rank within row
+        uint32_t row[HG_RPT], pos[HG_RPT];
+        float v[HG_RPT][F];
+        uint2 rec[HG_RPT];
 #pragma unroll
         for (int j = 0; j < HG_RPT; ++j) {
             const uint32_t i = c0 + tid + (uint32_t)HG_RT * j;
-            rec[j] = (i < end) ? records[i] : 0xFFFFFFFFu;
-        }
-        float ux[HG_RPT], uy[HG_RPT], uz[HG_RPT];
-#pragma unroll
-        for (int j = 0; j < HG_RPT; ++j) {
-            const size_t n = (rec[j] == 0xFFFFFFFFu) ? 0 : (rec[j] >> 3);
-            ux[j] = u[n * 3 + 0];
-            uy[j] = u[n * 3 + 1];
-            uz[j] = u[n * 3 + 2];
+            const bool live = i < end;
+            rec[j] = records[live ? i : start];
+            pos[j] = live ? 0u : 0xFFFFFFFFu;
         }
 #pragma unroll
         for (int j = 0; j < HG_RPT; ++j) {
-            const int k = (int)(rec[j] & 7u);
-            // corner naming of encodings.py:318-325: x takes ceil for k in {0,1,4,5}, y for {0,3,4,7}, z for {0,1,2,3}
-            const bool xc = (0x33u >> k) & 1u, yc = (0x99u >> k) & 1u, zc = (0x0Fu >> k) & 1u;
-            float px, py, pz;
-            {
-#pragma clang fp contract(off)
-                px = ux[j] * s;
-                py = uy[j] * s;
-                pz = uz[j] * s;
-            }
-            const float fxf = floorf(px), fyf = floorf(py), fzf = floorf(pz);
-            const float ox = px - fxf, oy = py - fyf, oz = pz - fzf;
-            const uint32_t ix = (uint32_t)(int)(xc ? ceilf(px) : fxf);
-            const uint32_t iy = (uint32_t)(int)(yc ? ceilf(py) : fyf) * PRIME_Y;
-            const uint32_t iz = (uint32_t)(int)(zc ? ceilf(pz) : fzf) * PRIME_Z;
-            const float wx = xc ? ox : 1.f - ox, wy = yc ? oy : 1.f - oy, wz = zc ? oz : 1.f - oz;
-            wgt[j] = wz * wy * wx;
-            row[j] = ((ix ^ iy ^ iz) & mask) & (uint32_t)(rpb - 1);
-            const bool live = (rec[j] != 0xFFFFFFFFu) && (wgt[j] != 0.f);
-            pos[j] = live ? atomicAdd(&cnt[row[j]], 1u) : 0xFFFFFFFFu;
+            row[j] = rec[j].x >> HG_SAMPLE_BITS;
+            const float w = __uint_as_float(rec[j].y);
+            float g[F];
+            load_row<F>(gl + (size_t)(rec[j].x & ((1u << HG_SAMPLE_BITS) - 1u)) * F, g);
+#pragma unroll
+            for (int f = 0; f < F; ++f) v[j][f] = w * g[f];
         }
+#pragma unroll
+        for (int j = 0; j < HG_RPT; ++j)
+            if (pos[j] != 0xFFFFFFFFu) pos[j] = atomicAdd(&cnt[row[j]], 1u);
         __syncthreads();
-        // ---- phase 2: exclusive scan of cnt[0..rpb) in place (thread t scans entries 2t, 2t+1); cnt[rpb] = total.
-        //      Long rows are queued for the wave-cooperative pass.
+        // ---- phase 2: exclusive scan of cnt[0..rpb) in place (thread t scans HG_ROWS_PT consecutive entries)
         {
-            const int i0 = tid * 2;
-            const uint32_t v0 = (i0 < rpb) ? cnt[i0] : 0u;
-            const uint32_t v1 = (i0 + 1 < rpb) ? cnt[i0 + 1] : 0u;
-            if (v0 > hg_long) long_rows[atomicAdd(&n_long, 1u)] = (uint32_t)i0;
-            if (v1 > hg_long) long_rows[atomicAdd(&n_long, 1u)] = (uint32_t)i0 + 1u;
-            const uint32_t sum = v0 + v1;
+            const int i0 = tid * HG_ROWS_PT;
+            uint32_t c[HG_ROWS_PT];
+            uint32_t sum = 0;
+#pragma unroll
+            for (int q = 0; q < HG_ROWS_PT; ++q) {
+                c[q] = (i0 + q < rpb) ? cnt[i0 + q] : 0u;
+                if (c[q] > hg_long) long_rows[atomicAdd(&n_long, 1u)] = (uint32_t)(i0 + q);
+                sum += c[q];
+            }
             uint32_t inc = sum;
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) {
@@ -403,40 +410,40 @@ __global__ __launch_bounds__(HG_RT) void k_hg_reduce(const float* __restrict__ u
             __syncthreads();
             uint32_t base = 0;
             for (int w2 = 0; w2 < wave; ++w2) base += wave_tot[w2];
-            const uint32_t excl = base + inc - sum;
-            if (i0 < rpb) cnt[i0] = excl;
-            if (i0 + 1 < rpb) cnt[i0 + 1] = excl + v0;
+            uint32_t run = base + inc - sum;
+#pragma unroll
+            for (int q = 0; q < HG_ROWS_PT; ++q) {
+                if (i0 + q < rpb) cnt[i0 + q] = run;
+                run += c[q];
+            }
             if (tid == HG_RT - 1) cnt[rpb] = base + inc;
         }
         __syncthreads();
-        // ---- phase 3: scatter (sample, weight) to the row-sorted order
+        // ---- phase 3: payloads to their row-sorted slots
 #pragma unroll
         for (int j = 0; j < HG_RPT; ++j) {
             if (pos[j] != 0xFFFFFFFFu) {
-                const uint32_t e = cnt[row[j]] + pos[j];
-                pay_n[e] = rec[j] >> 3;
-                pay_w[e] = wgt[j];
+                float* d = &val[(size_t)(cnt[row[j]] + pos[j]) * F];
+                if constexpr (F == 8) {
+                    reinterpret_cast<float4*>(d)[0] = make_float4(v[j][0], v[j][1], v[j][2], v[j][3]);
+                    reinterpret_cast<float4*>(d)[1] = make_float4(v[j][4], v[j][5], v[j][6], v[j][7]);
+                } else {
+                    *reinterpret_cast<float2*>(d) = make_float2(v[j][0], v[j][1]);
+                }
             }
         }
         __syncthreads();
-        // ---- phase 4a: short segments, one owner thread per row (rows tid and tid + 1024)
+        // ---- phase 4a: short segments, one owner thread per row (rows tid, tid + HG_RT, ...), summed from LDS
 #pragma unroll
-        for (int sidx = 0; sidx < 2; ++sidx) {
+        for (int sidx = 0; sidx < HG_ROWS_PT; ++sidx) {
             const int r = tid + sidx * HG_RT;
             if (r < rpb) {
                 const uint32_t e0 = cnt[r], e1 = cnt[r + 1];
-                if (e1 > e0 && e1 - e0 <= hg_long) {
-                    float a[F];
-#pragma unroll
-                    for (int f = 0; f < F; ++f) a[f] = 0.f;
+                if (e1 - e0 <= hg_long) {
                     for (uint32_t e = e0; e < e1; ++e) {
-                        float g[F];
-                        load_row<F>(gl + (size_t)pay_n[e] * F, g);
-                        const float w = pay_w[e];
 #pragma unroll
-                        for (int f = 0; f < F; ++f) a[f] += w * g[f];
+                        for (int f = 0; f < F; ++f) racc[sidx][f] += val[(size_t)e * F + f];
                     }
-                    row_rmw<F>(slab + (size_t)r * F, a);
                 }
             }
         }
@@ -449,11 +456,8 @@ __global__ __launch_bounds__(HG_RT) void k_hg_reduce(const float* __restrict__ u
 #pragma unroll
             for (int f = 0; f < F; ++f) a[f] = 0.f;
             for (uint32_t e = e0 + lane; e < e1; e += 64) {
-                float g[F];
-                load_row<F>(gl + (size_t)pay_n[e] * F, g);
-                const float w = pay_w[e];
 #pragma unroll
-                for (int f = 0; f < F; ++f) a[f] += w * g[f];
+                for (int f = 0; f < F; ++f) a[f] += val[(size_t)e * F + f];
             }
 #pragma unroll
             for (int f = 0; f < F; ++f) {
@@ -463,6 +467,32 @@ __global__ __launch_bounds__(HG_RT) void k_hg_reduce(const float* __restrict__ u
             if (lane == 0) row_rmw<F>(slab + (size_t)r * F, a);
         }
         __syncthreads();
+    }
+    // ---- epilogue: one read-modify-write per owned row that received something; the loads issue together
+    float cur[HG_ROWS_PT][F];
+    bool nz[HG_ROWS_PT];
+#pragma unroll
+    for (int q = 0; q < HG_ROWS_PT; ++q) {
+        const int r = tid + q * HG_RT;
+        nz[q] = false;
+#pragma unroll
+        for (int f = 0; f < F; ++f) nz[q] |= racc[q][f] != 0.f;
+        nz[q] = nz[q] && (r < rpb);
+        if (nz[q]) load_row<F>(slab + (size_t)r * F, cur[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < HG_ROWS_PT; ++q) {
+        if (nz[q]) {
+            float* dst = slab + (size_t)(tid + q * HG_RT) * F;
+            if constexpr (F == 8) {
+                reinterpret_cast<float4*>(dst)[0] = make_float4(cur[q][0] + racc[q][0], cur[q][1] + racc[q][1],
+                                                                cur[q][2] + racc[q][2], cur[q][3] + racc[q][3]);
+                reinterpret_cast<float4*>(dst)[1] = make_float4(cur[q][4] + racc[q][4], cur[q][5] + racc[q][5],
+                                                                cur[q][6] + racc[q][6], cur[q][7] + racc[q][7]);
+            } else {
+                *reinterpret_cast<float2*>(dst) = make_float2(cur[q][0] + racc[q][0], cur[q][1] + racc[q][1]);
+            }
+        }
     }
 }
 
@@ -519,8 +549,8 @@ extern "C" int snf_hashgrid_bwd(const float* u, const float* grad_out, const flo
 static size_t hg_ws_words(int N, int L, int log2_T) {
     const HgGeom g = hg_geometry(N, log2_T);
     const size_t B = (size_t)1 << g.log2B;
-    // records | tile histograms | tile offsets | bucket starts (padded to 4 words) | staged gradients (F <= 8 floats)
-    return (size_t)L * 8 * (size_t)N + 2 * (size_t)L * g.nblk * B + (((size_t)L * (B + 1) + 3) & ~(size_t)3) +
+    // records (8 B each) | tile histograms | tile offsets | bucket starts (padded to 4 words) | staged gradients
+    return (size_t)L * 8 * (size_t)N * 2 + 2 * (size_t)L * g.nblk * B + (((size_t)L * (B + 1) + 3) & ~(size_t)3) +
            (size_t)L * (size_t)N * 8;
 }
 
@@ -536,8 +566,8 @@ extern "C" int snf_hashgrid_bwd_sorted(const float* u, const float* grad_out, co
     if (rc) return rc;
     SNF_REQUIRE(((uintptr_t)grad_out % 16) == 0 && ((uintptr_t)grad_table % 16) == 0,
                 "snf_hashgrid_bwd_sorted: unaligned pointer");
-    SNF_REQUIRE((long long)L * 8 * N < (1LL << 32) && N < (1 << 29),
-                "snf_hashgrid_bwd_sorted: too many records for 32-bit offsets (N=%d L=%d)", N, L);
+    SNF_REQUIRE((long long)L * 8 * N < (1LL << 32) && N <= (1 << HG_SAMPLE_BITS),
+                "snf_hashgrid_bwd_sorted: at most 2^21 samples per call (N=%d L=%d); split the batch", N, L);
     const HgGeom g = hg_geometry(N, log2_T);
     if ((1 << g.log2rpb) > HG_MAX_RPB) {
         // more than 2048 rows per bucket even at 4096 buckets (log2_T > 23): fall back to the atomic kernel
@@ -550,7 +580,7 @@ extern "C" int snf_hashgrid_bwd_sorted(const float* u, const float* grad_out, co
     const int B = 1 << g.log2B;
     const int nblk = g.nblk;
     uint32_t* records = (uint32_t*)workspace;
-    uint32_t* hist = records + (size_t)L * 8 * (size_t)N;
+    uint32_t* hist = records + (size_t)L * 8 * (size_t)N * 2;
     uint32_t* offs = hist + (size_t)L * nblk * B;
     uint32_t* bstart = offs + (size_t)L * nblk * B;
     float* gT = (float*)(bstart + (((size_t)L * (B + 1) + 3) & ~(size_t)3));
@@ -565,13 +595,13 @@ extern "C" int snf_hashgrid_bwd_sorted(const float* u, const float* grad_out, co
     hipLaunchKernelGGL(k_hg_count, dim3(nblk, L), dim3(256), 0, st, u, scalings, N, log2_T, g.log2B, g.spt, hist);
     hipLaunchKernelGGL(k_hg_scan, dim3(L), dim3(1024), 0, st, N, g.log2B, nblk, hist, offs, bstart);
     hipLaunchKernelGGL(k_hg_scatter, dim3(nblk, L), dim3(256), 0, st, u, scalings, N, log2_T, g.log2B, g.spt, offs,
-                       records);
+                       (uint2*)records);
     if (F == 2)
-        hipLaunchKernelGGL(k_hg_reduce<2>, dim3(B, L), dim3(HG_RT), 0, st, u, gT, scalings, N, log2_T, g.log2B, bstart,
-                           records, grad_table, hg_long);
+        hipLaunchKernelGGL(k_hg_reduce<2>, dim3(B, L), dim3(HG_RT), 0, st, gT, N, log2_T, g.log2B, bstart,
+                           (const uint2*)records, grad_table, hg_long);
     else
-        hipLaunchKernelGGL(k_hg_reduce<8>, dim3(B, L), dim3(HG_RT), 0, st, u, gT, scalings, N, log2_T, g.log2B, bstart,
-                           records, grad_table, hg_long);
+        hipLaunchKernelGGL(k_hg_reduce<8>, dim3(B, L), dim3(HG_RT), 0, st, gT, N, log2_T, g.log2B, bstart,
+                           (const uint2*)records, grad_table, hg_long);
     SNF_LAUNCH_CHECK("snf_hashgrid_bwd_sorted");
     return SNF_OK;
 }

@@ -70,6 +70,38 @@ __device__ __forceinline__ float4 load_a4(const float* __restrict__ A, const flo
     return v;
 }
 
+// Branch-free 16-byte variants (VEC kernels: every leading dimension and K / Nc a multiple of 4, 16-B aligned bases):
+// out-of-range rows / k-quads are clamped to a valid address and zeroed by a select, so all loads of a tile issue
+// back to back without exec-mask branches in between.
+template <bool DERIV>
+__device__ __forceinline__ float4 load_a4_vec(const float* __restrict__ A, const float* __restrict__ Aux, int row, int k,
+                                              int M, int K, int lda, int ldaux, int act) {
+    const bool ok = (row < M) && (k < K);
+    const int rc = row < M ? row : M - 1;
+    const int kc = k < K ? k : K - 4;
+    float4 v = *reinterpret_cast<const float4*>(A + (size_t)rc * lda + kc);
+    if constexpr (DERIV) {
+        if (act != SNF_ACT_NONE) {
+            const float4 y = *reinterpret_cast<const float4*>(Aux + (size_t)rc * ldaux + kc);
+            v.x *= act_deriv(y.x, act);
+            v.y *= act_deriv(y.y, act);
+            v.z *= act_deriv(y.z, act);
+            v.w *= act_deriv(y.w, act);
+        }
+    }
+    if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+    return v;
+}
+
+__device__ __forceinline__ float4 load_b4_vec(const float* __restrict__ B, int r, int c, int Rn, int Cn, int ldb) {
+    const bool ok = (r < Rn) && (c < Cn);
+    const int rc = r < Rn ? r : Rn - 1;
+    const int cc = c < Cn ? c : Cn - 4;
+    float4 v = *reinterpret_cast<const float4*>(B + (size_t)rc * ldb + cc);
+    if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+    return v;
+}
+
 // generic 4-wide load along the contiguous dimension of a row-major matrix [R, C] at (r, c)
 __device__ __forceinline__ float4 load_b4(const float* __restrict__ B, int r, int c, int Rn, int Cn, int ldb, bool vec) {
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -86,7 +118,7 @@ __device__ __forceinline__ float4 load_b4(const float* __restrict__ B, int r, in
     return v;
 }
 
-template <bool BT, bool DERIV>
+template <bool BT, bool DERIV, bool VEC>
 __global__ __launch_bounds__(256) void k_gemm_rows(const float* __restrict__ A, const float* __restrict__ Aux,
                                                    const float* __restrict__ B, const float* __restrict__ bias, int M,
                                                    int K, int Nc, int lda, int ldaux, int ldb, int ldc, int act_in,
@@ -104,24 +136,38 @@ __global__ __launch_bounds__(256) void k_gemm_rows(const float* __restrict__ A, 
     for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
 
     const int a_kq = tid & 7, a_r = tid >> 3;  // A staging: 8 k-quads x 32 rows, 4 passes
-    for (int k0 = 0; k0 < K; k0 += BK) {
-        // ---- stage A (transposed into [k][row])
-        float4 av[4];
+    const int b_jq = tid & 15, b_k = tid >> 4;  // B staging when B is [K, Nc]: 16 col-quads x 16 k, 2 passes
+    float4 av[4], bv[2];
+    // global -> registers for the tile starting at k0 (software pipeline: issued one tile ahead of its use)
+    auto fetch = [&](int k0) {
+        if constexpr (VEC) {
 #pragma unroll
-        for (int p = 0; p < 4; ++p)
-            av[p] = load_a4<DERIV>(A, Aux, row0 + a_r + 32 * p, k0 + a_kq * 4, M, K, lda, ldaux, act_in, vecA);
-        float4 bv[2];
-        if constexpr (BT) {
-            // B = W[Nc, K] row-major: 8 k-quads x 32 cols, 2 passes
+            for (int p = 0; p < 4; ++p)
+                av[p] = load_a4_vec<DERIV>(A, Aux, row0 + a_r + 32 * p, k0 + a_kq * 4, M, K, lda, ldaux, act_in);
+            if constexpr (BT) {
 #pragma unroll
-            for (int p = 0; p < 2; ++p) bv[p] = load_b4(B, col0 + a_r + 32 * p, k0 + a_kq * 4, Nc, K, ldb, vecB);
+                for (int p = 0; p < 2; ++p) bv[p] = load_b4_vec(B, col0 + a_r + 32 * p, k0 + a_kq * 4, Nc, K, ldb);
+            } else {
+#pragma unroll
+                for (int p = 0; p < 2; ++p) bv[p] = load_b4_vec(B, k0 + b_k + 16 * p, col0 + b_jq * 4, K, Nc, ldb);
+            }
         } else {
-            // B = W[K, Nc] row-major: 16 col-quads x 16 k, 2 passes
-            const int b_jq = tid & 15, b_k = tid >> 4;
 #pragma unroll
-            for (int p = 0; p < 2; ++p) bv[p] = load_b4(B, k0 + b_k + 16 * p, col0 + b_jq * 4, K, Nc, ldb, vecB);
+            for (int p = 0; p < 4; ++p)
+                av[p] = load_a4<DERIV>(A, Aux, row0 + a_r + 32 * p, k0 + a_kq * 4, M, K, lda, ldaux, act_in, vecA);
+            if constexpr (BT) {
+#pragma unroll
+                for (int p = 0; p < 2; ++p) bv[p] = load_b4(B, col0 + a_r + 32 * p, k0 + a_kq * 4, Nc, K, ldb, vecB);
+            } else {
+#pragma unroll
+                for (int p = 0; p < 2; ++p) bv[p] = load_b4(B, k0 + b_k + 16 * p, col0 + b_jq * 4, K, Nc, ldb, vecB);
+            }
         }
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < K; k0 += BK) {
         __syncthreads();  // previous tile fully consumed
+        // ---- registers -> LDS (A transposed into [k][row])
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const int r = a_r + 32 * p;
@@ -140,7 +186,6 @@ __global__ __launch_bounds__(256) void k_gemm_rows(const float* __restrict__ A, 
                 Bs[(a_kq * 4 + 3) * LDB_S + j] = bv[p].w;
             }
         } else {
-            const int b_jq = tid & 15, b_k = tid >> 4;
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
                 float* d = &Bs[(b_k + 16 * p) * LDB_S + b_jq * 4];
@@ -148,6 +193,7 @@ __global__ __launch_bounds__(256) void k_gemm_rows(const float* __restrict__ A, 
             }
         }
         __syncthreads();
+        if (k0 + BK < K) fetch(k0 + BK);  // next tile's HBM/L2 latency hides under this tile's MFMAs
         // ---- 16 k-pairs on the matrix core
         const int kh = lane >> 5, li = lane & 31;
         const float* ap = &As[kh * LDA_S + wave * 32 + li];
@@ -194,6 +240,7 @@ __global__ __launch_bounds__(256) void k_gemm_rows(const float* __restrict__ A, 
 
 // dW[O,I] += sum over this block's rows of dZ[n,o] * X[n,i];   tile 64(o) x 64(i), waves 2x2.
 constexpr int WG_LD = 65;
+template <bool VEC>
 __global__ __launch_bounds__(256) void k_gemm_wgrad(const float* __restrict__ dY, const float* __restrict__ Y,
                                                     const float* __restrict__ X, int N, int I, int O, int lddy, int ldy,
                                                     int ldx, int act, int rows_per_block, int vecA, int vecB,
@@ -210,16 +257,24 @@ __global__ __launch_bounds__(256) void k_gemm_wgrad(const float* __restrict__ dY
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
     float bsum = 0.f;
     const int q = tid & 15, kr = tid >> 4;  // 16 quads x 16 rows, 2 passes
-    for (int n0 = n_begin; n0 < n_end; n0 += BK) {
-        float4 av[2], bv[2];
+    float4 av[2], bv[2];
+    auto fetch = [&](int n0) {
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             const int n = n0 + kr + 16 * p;
             const bool ok = n < n_end;
             // A: dZ[n][o0 + q*4 ..]  (activation derivative folded in)
-            av[p] = ok ? load_a4<true>(dY, Y, n, o0 + q * 4, N, O, lddy, ldy, act, vecA) : make_float4(0, 0, 0, 0);
-            bv[p] = ok ? load_b4(X, n, i0 + q * 4, N, I, ldx, vecB) : make_float4(0, 0, 0, 0);
+            if constexpr (VEC) {
+                av[p] = load_a4_vec<true>(dY, Y, n, o0 + q * 4, n_end, O, lddy, ldy, act);
+                bv[p] = load_b4_vec(X, n, i0 + q * 4, n_end, I, ldx);
+            } else {
+                av[p] = ok ? load_a4<true>(dY, Y, n, o0 + q * 4, N, O, lddy, ldy, act, vecA) : make_float4(0, 0, 0, 0);
+                bv[p] = ok ? load_b4(X, n, i0 + q * 4, N, I, ldx, vecB) : make_float4(0, 0, 0, 0);
+            }
         }
+    };
+    fetch(n_begin);
+    for (int n0 = n_begin; n0 < n_end; n0 += BK) {
         __syncthreads();
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
@@ -229,6 +284,7 @@ __global__ __launch_bounds__(256) void k_gemm_wgrad(const float* __restrict__ dY
             db[0] = bv[p].x; db[1] = bv[p].y; db[2] = bv[p].z; db[3] = bv[p].w;
         }
         __syncthreads();
+        if (n0 + BK < n_end) fetch(n0 + BK);
         const int kh = lane >> 5, li = lane & 31;
         const float* ap = &As[kh * WG_LD + wm * 32 + li];
         const float* bp = &Bs[kh * WG_LD + wn * 32 + li];
@@ -264,8 +320,12 @@ extern "C" int snf_linear_fwd(const float* X, const float* W, const float* bias,
     const int vecA = aligned16(X) && (ldx % 4 == 0) && (I % 4 == 0);
     const int vecB = aligned16(W) && (I % 4 == 0);
     dim3 grid(ceil_div(N, BM), ceil_div(O, BN));
-    hipLaunchKernelGGL((k_gemm_rows<true, false>), grid, dim3(256), 0, (hipStream_t)stream, X, (const float*)nullptr, W,
-                       bias, N, I, O, ldx, 0, I, ldy, SNF_ACT_NONE, act, vecA, vecB, Y);
+    if (vecA && vecB && N >= 1)
+        hipLaunchKernelGGL((k_gemm_rows<true, false, true>), grid, dim3(256), 0, (hipStream_t)stream, X,
+                           (const float*)nullptr, W, bias, N, I, O, ldx, 0, I, ldy, SNF_ACT_NONE, act, vecA, vecB, Y);
+    else
+        hipLaunchKernelGGL((k_gemm_rows<true, false, false>), grid, dim3(256), 0, (hipStream_t)stream, X,
+                           (const float*)nullptr, W, bias, N, I, O, ldx, 0, I, ldy, SNF_ACT_NONE, act, vecA, vecB, Y);
     SNF_LAUNCH_CHECK("snf_linear_fwd");
     return SNF_OK;
 }
@@ -279,8 +339,12 @@ extern "C" int snf_linear_bwd_data(const float* dY, const float* Y, const float*
                      (act == SNF_ACT_NONE || (aligned16(Y) && ldy % 4 == 0));
     const int vecB = aligned16(W) && (I % 4 == 0);
     dim3 grid(ceil_div(N, BM), ceil_div(I, BN));
-    hipLaunchKernelGGL((k_gemm_rows<false, true>), grid, dim3(256), 0, (hipStream_t)stream, dY, Y, W,
-                       (const float*)nullptr, N, O, I, lddy, ldy, I, lddx, act, SNF_ACT_NONE, vecA, vecB, dX);
+    if (vecA && vecB)
+        hipLaunchKernelGGL((k_gemm_rows<false, true, true>), grid, dim3(256), 0, (hipStream_t)stream, dY, Y, W,
+                           (const float*)nullptr, N, O, I, lddy, ldy, I, lddx, act, SNF_ACT_NONE, vecA, vecB, dX);
+    else
+        hipLaunchKernelGGL((k_gemm_rows<false, true, false>), grid, dim3(256), 0, (hipStream_t)stream, dY, Y, W,
+                           (const float*)nullptr, N, O, I, lddy, ldy, I, lddx, act, SNF_ACT_NONE, vecA, vecB, dX);
     SNF_LAUNCH_CHECK("snf_linear_bwd_data");
     return SNF_OK;
 }
@@ -302,8 +366,12 @@ extern "C" int snf_linear_bwd_weight(const float* dY, const float* Y, const floa
     if (rows < 4 * BK) rows = 4 * BK;
     chunks = ceil_div(N, rows);
     dim3 grid(to, ti, chunks);
-    hipLaunchKernelGGL(k_gemm_wgrad, grid, dim3(256), 0, (hipStream_t)stream, dY, Y, X, N, I, O, lddy, ldy, ldx, act,
-                       rows, vecA, vecB, dW, dbias);
+    if (vecA && vecB)
+        hipLaunchKernelGGL(k_gemm_wgrad<true>, grid, dim3(256), 0, (hipStream_t)stream, dY, Y, X, N, I, O, lddy, ldy, ldx,
+                           act, rows, vecA, vecB, dW, dbias);
+    else
+        hipLaunchKernelGGL(k_gemm_wgrad<false>, grid, dim3(256), 0, (hipStream_t)stream, dY, Y, X, N, I, O, lddy, ldy, ldx,
+                           act, rows, vecA, vecB, dW, dbias);
     SNF_LAUNCH_CHECK("snf_linear_bwd_weight");
     return SNF_OK;
 }

@@ -67,12 +67,16 @@ class Optimizers:
         for a in self.arenas.values():
             a.grad.zero_()
 
+    def optimizer_step(self, k: str, grad_scale: float = 1.0, zero_grad: bool = True) -> None:
+        """One fused Adam launch over the whole arena of group `k` (on the current stream)."""
+        a, oc = self.arenas[k], self.config[k]["optimizer"]
+        self.step_count[k] += 1
+        ops.adam_step_(a.param, a.grad, a.exp_avg, a.exp_avg_sq, self.lr(k), oc.betas[0], oc.betas[1], oc.eps,
+                       self.step_count[k], grad_scale, zero_grad)
+
     def optimizer_step_all(self, grad_scale: float = 1.0, zero_grad: bool = True) -> None:
-        for k, a in self.arenas.items():
-            oc = self.config[k]["optimizer"]
-            self.step_count[k] += 1
-            ops.adam_step_(a.param, a.grad, a.exp_avg, a.exp_avg_sq, self.lr(k), oc.betas[0], oc.betas[1], oc.eps,
-                           self.step_count[k], grad_scale, zero_grad)
+        for k in self.arenas:
+            self.optimizer_step(k, grad_scale, zero_grad)
 
     def scheduler_step_all(self, step: int) -> None:
         for k in self.sched_step:

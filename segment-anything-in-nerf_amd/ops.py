@@ -174,7 +174,7 @@ class _HashGridMulti(torch.autograd.Function):
         for (sc, L, F, T), tab in zip(specs, tables):
             tab = _chk(tab, "table")
             assert tab.numel() == (L << T) * F, "table size does not match (levels, log2_T, features)"
-            _launch("snf_hashgrid_fwd", _p(u), _p(tab), _p(sc), N, L, F, T, _p(out), total, col, _stream(), tag=f"F{F}")
+            _launch("snf_hashgrid_fwd", _p(u), _p(tab), _p(sc), N, L, F, T, _p(out), total, col, _stream(), tag=f"F{F}L{L}")
             col += L * F
         ctx.specs = specs
         ctx.tables = tables
@@ -195,12 +195,12 @@ class _HashGridMulti(torch.autograd.Function):
                 buf, fused = _grad_target(tab)
                 if HASHGRID_BWD_MODE == "atomic":
                     _launch("snf_hashgrid_bwd", _p(u), _p(g), _p(sc), N, L, F, T, total, col, _p(buf), _stream(),
-                            tag=f"F{F}")
+                            tag=f"F{F}L{L}")
                 else:
                     nbytes = int(_L().snf_hashgrid_bwd_workspace_bytes(N, L, T))
                     ws = torch.empty(((nbytes + 3) // 4,), device=g.device, dtype=torch.int32)
                     _launch("snf_hashgrid_bwd_sorted", _p(u), _p(g), _p(sc), N, L, F, T, total, col, _p(buf), _p(ws),
-                            nbytes, _stream(), tag=f"F{F}")
+                            nbytes, _stream(), tag=f"F{F}L{L}")
                 grads.append(None if fused else buf)
             col += L * F
         return (None, None, *grads)

@@ -139,6 +139,8 @@ class Trainer:
         self.local_rank, self.world_size = local_rank, world_size
         self.device = device
         self._start_step = 0
+        self.overlap = True  # feature-group exchange + Adam on a side stream under the nerf backward
+        self._side = None
 
     def setup(self, test_mode="val") -> None:
         self.pipeline = self.config.pipeline.setup(device=self.device, test_mode=test_mode, world_size=self.world_size,
@@ -149,17 +151,47 @@ class Trainer:
         D.broadcast_parameters([a.param for a in arenas.values()])
         self.callbacks = self.pipeline.get_training_callbacks()
 
+    # The feature branch sees the nerfacto branch only through DETACHED quantities (sample positions sam_field.py:116,
+    # sam_weights.detach() sam_model.py:260-277), so the loss splits into two disjoint autograd graphs:
+    #   feature losses -> {sam_field, conv}           nerf losses -> {fields, proposal_networks}
+    # The feature graph is back-propagated first; its gradient exchange (RCCL) and its Adam pass (the 0.8 GB arena, an
+    # HBM-streaming kernel) then run on a side stream underneath the nerf backward, which is latency- not bandwidth-bound.
+    FEATURE_LOSSES = ("sam_loss", "clipseg_loss", "dino_loss")
+    FEATURE_GROUPS = ("sam_field", "conv")
+
     def train_iteration(self, step: int):
         for cb in self.callbacks:
             cb.run_callback_at_location(step, BEFORE_TRAIN_ITERATION)
         _, loss_dict, metrics_dict = self.pipeline.get_train_loss_dict(step=step)
-        loss = sum(loss_dict.values())
-        loss.backward()
-        D.allreduce_gradients([a.grad for a in self.optimizers.arenas.values()])
-        self.optimizers.optimizer_step_all(grad_scale=1.0 / D.world_size(), zero_grad=True)
-        self.optimizers.scheduler_step_all(step)
+        opt, scale = self.optimizers, 1.0 / D.world_size()
+        feat = [v for k, v in loss_dict.items() if k in self.FEATURE_LOSSES]
+        rest = [v for k, v in loss_dict.items() if k not in self.FEATURE_LOSSES]
+        feat_groups = [g for g in self.FEATURE_GROUPS if g in opt.arenas]
+        rest_groups = [g for g in opt.arenas if g not in feat_groups]
+        use_side = self.overlap and torch.cuda.is_available() and len(feat) > 0 and len(feat_groups) > 0
+        if use_side:
+            main = torch.cuda.current_stream()
+            if self._side is None:
+                self._side = torch.cuda.Stream()
+            sum(feat).backward()
+            self._side.wait_stream(main)
+            with torch.cuda.stream(self._side):
+                D.allreduce_gradients([opt.arenas[g].grad for g in feat_groups])
+                for g in feat_groups:
+                    opt.optimizer_step(g, scale, True)
+            sum(rest).backward()
+            D.allreduce_gradients([opt.arenas[g].grad for g in rest_groups])
+            for g in rest_groups:
+                opt.optimizer_step(g, scale, True)
+            main.wait_stream(self._side)
+        else:
+            sum(loss_dict.values()).backward()
+            D.allreduce_gradients([a.grad for a in opt.arenas.values()])
+            opt.optimizer_step_all(grad_scale=scale, zero_grad=True)
+        opt.scheduler_step_all(step)
         for cb in self.callbacks:
             cb.run_callback_at_location(step, AFTER_TRAIN_ITERATION)
+        loss = sum(v.detach() for v in loss_dict.values())
         return loss, loss_dict, metrics_dict
 
     def save_checkpoint(self, path: str, step: int) -> None:
