@@ -94,6 +94,23 @@ int snf_linear_bwd_data(const float* dY, const float* Y, const float* W, int N, 
 int snf_linear_bwd_weight(const float* dY, const float* Y, const float* X, int N, int I, int O, int lddy,
                           int ldy, int ldx, int act, float* dW, float* dbias, snf_stream_t stream);
 
+/* ---- a7, fused: a whole 64-wide tiny MLP (tcnn FullyFusedMLP: nerfstudio/fields/nerfacto_field.py:157-175,228-240)
+ *      in one launch, activations in registers.  Layers: W0 [64, in_real] (in_real <= 32), W1 [64,64] (n_hidden == 2
+ *      only), Wout [out, 64] (out <= 32); ReLU between layers, out_act on the output (NONE or SIGMOID); no biases.
+ * X is [N, ldx] with ldx >= 32, ldx % 4 == 0 (columns in_real..31 are ignored but must be readable).
+ * H1, H2 ([N,64], may be NULL at inference) receive the hidden activations needed by the backward. */
+int snf_mlp64_fwd(const float* X, int ldx, const float* W0, int in_real, const float* W1, const float* Wout,
+                  int n_hidden, int out, int out_act, int64_t N, float* H1, float* H2, float* Y, int ldy,
+                  snf_stream_t stream);
+/* data-gradient chain of the same net: dZ[s][o] = dY[s*lddy + dy_col_off + o] (column 0 taken from dY0[s] when dY0 !=
+ * NULL), times the sigmoid derivative of Y when out_act == SIGMOID.  Writes the ReLU-masked hidden gradients dH2, dH1
+ * ([N,64]), the pre-activation output gradient dZ ([N, lddz >= out], may be NULL) and dX ([N, lddx >= 32], may be NULL).  The
+ * weight gradients are then snf_linear_bwd_weight(dZ, Hlast), (dH2, H1), (dH1, X) with act = NONE. */
+int snf_mlp64_bwd_data(const float* dY, int lddy, int dy_col_off, const float* dY0, const float* Y, int ldy,
+                       const float* W0, int in_real, const float* W1, const float* Wout, int n_hidden, int out,
+                       int out_act, int64_t N, const float* H1, const float* H2, float* dH1, float* dH2, float* dZ,
+                       int lddz, float* dX, int lddx, snf_stream_t stream);
+
 /* ---- a13: SH degree-4 basis of the raw unit direction (nerfstudio/utils/math.py:27-73) written to
  *      the first 16 columns of the colour-MLP input, with the geo features copied behind it
  *      (torch.cat of fields/nerfacto_field.py:336-343).  dirs [R,3]; geo points at h[:,1] of the
@@ -115,11 +132,11 @@ int snf_weights_bwd(const float* raw, int raw_stride, int is_density, const uint
 
 /* ---- a8 alone: density = trunc_exp(raw) * selector, the tail of Field.get_density
  *      (fields/nerfacto_field.py:260-265, fields/density_fields.py:120-124, activations.py:24-40).
- * raw[t*raw_stride], selector [N] uint8 or NULL -> density [N]; backward writes grad_raw[t*raw_stride]. */
+ * raw[t*raw_stride], selector [N] uint8 or NULL -> density [N]; backward writes grad_raw[t*grad_stride]. */
 int snf_trunc_exp_fwd(const float* raw, int raw_stride, const uint8_t* selector, int64_t N, float* density,
                       snf_stream_t stream);
 int snf_trunc_exp_bwd(const float* raw, int raw_stride, const uint8_t* selector, const float* grad_density,
-                      int64_t N, float* grad_raw, snf_stream_t stream);
+                      int64_t N, float* grad_raw, int grad_stride, snf_stream_t stream);
 
 /* ---- a10: PDFSampler.generate_ray_samples, include_original=False, single jitter
  *      (model_components/ray_samplers.py:298-367), preceded by the anneal pow of :583.

@@ -20,7 +20,7 @@ INCLUDE = os.path.join(ROOT, "include")
 LIB_DIR = os.path.join(PKG_DIR, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libsamnerf_hip.so")
 HASH_PATH = LIB_PATH + ".srchash"
-SOURCES = ["sampling.hip", "hashgrid.hip", "linear.hip", "render.hip", "losses.hip", "optim.hip"]
+SOURCES = ["sampling.hip", "hashgrid.hip", "linear.hip", "mlp_chain.hip", "render.hip", "losses.hip", "optim.hip"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics"]
 
 
@@ -90,11 +90,13 @@ SIGNATURES = {
     "snf_linear_fwd": [P, P, P, I, I, I, I, I, I, P, P],
     "snf_linear_bwd_data": [P, P, P, I, I, I, I, I, I, I, P, P],
     "snf_linear_bwd_weight": [P, P, P, I, I, I, I, I, I, I, P, P, P],
+    "snf_mlp64_fwd": [P, I, P, I, P, P, I, I, I, c_int64, P, P, P, I, P],
+    "snf_mlp64_bwd_data": [P, I, I, P, P, I, P, I, P, P, I, I, I, c_int64, P, P, P, P, P, I, P, I, P],
     "snf_head_input": [P, P, I, I, I, I, P, I, P],
     "snf_weights_fwd": [P, I, I, P, P, I, I, P, P, P],
     "snf_weights_bwd": [P, I, I, P, P, P, I, I, P, P],
     "snf_trunc_exp_fwd": [P, I, P, c_int64, P, P],
-    "snf_trunc_exp_bwd": [P, I, P, P, c_int64, P, P],
+    "snf_trunc_exp_bwd": [P, I, P, P, c_int64, P, I, P],
     "snf_pdf_resample": [P, P, P, P, P, I, I, I, F, F, P, P, P],
     "snf_composite_fwd": [P, P, P, I, I, I, P, P, P, P],
     "snf_composite_bwd": [P, P, P, I, I, P, P, P],

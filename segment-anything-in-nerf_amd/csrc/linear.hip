@@ -78,7 +78,7 @@ __device__ __forceinline__ float4 load_a4_vec(const float* __restrict__ A, const
                                               int M, int K, int lda, int ldaux, int act) {
     const bool ok = (row < M) && (k < K);
     const int rc = row < M ? row : M - 1;
-    const int kc = k < K ? k : K - 4;
+    const int kc = k < K ? k : 0;  // k is a multiple of 4 and lda % 4 == 0: kc + 3 stays inside the (padded) row
     float4 v = *reinterpret_cast<const float4*>(A + (size_t)rc * lda + kc);
     if constexpr (DERIV) {
         if (act != SNF_ACT_NONE) {
@@ -89,16 +89,23 @@ __device__ __forceinline__ float4 load_a4_vec(const float* __restrict__ A, const
             v.w *= act_deriv(y.w, act);
         }
     }
-    if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+    // pad columns (k+i >= K) of a padded row hold arbitrary bytes: select, never multiply
+    v.x = ok ? v.x : 0.f;
+    v.y = (ok && k + 1 < K) ? v.y : 0.f;
+    v.z = (ok && k + 2 < K) ? v.z : 0.f;
+    v.w = (ok && k + 3 < K) ? v.w : 0.f;
     return v;
 }
 
 __device__ __forceinline__ float4 load_b4_vec(const float* __restrict__ B, int r, int c, int Rn, int Cn, int ldb) {
     const bool ok = (r < Rn) && (c < Cn);
     const int rc = r < Rn ? r : Rn - 1;
-    const int cc = c < Cn ? c : Cn - 4;
+    const int cc = c < Cn ? c : 0;
     float4 v = *reinterpret_cast<const float4*>(B + (size_t)rc * ldb + cc);
-    if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+    v.x = ok ? v.x : 0.f;
+    v.y = (ok && c + 1 < Cn) ? v.y : 0.f;
+    v.z = (ok && c + 2 < Cn) ? v.z : 0.f;
+    v.w = (ok && c + 3 < Cn) ? v.w : 0.f;
     return v;
 }
 
@@ -354,9 +361,9 @@ extern "C" int snf_linear_bwd_weight(const float* dY, const float* Y, const floa
     SNF_REQUIRE(dY && X && dW, "snf_linear_bwd_weight: null pointer");
     SNF_REQUIRE(act == SNF_ACT_NONE || Y, "snf_linear_bwd_weight: Y required for activation derivative");
     SNF_REQUIRE(N > 0 && I > 0 && O > 0 && lddy >= O && ldx >= I, "snf_linear_bwd_weight: bad shape");
-    const int vecA = aligned16(dY) && (lddy % 4 == 0) && (O % 4 == 0) &&
-                     (act == SNF_ACT_NONE || (aligned16(Y) && ldy % 4 == 0));
-    const int vecB = aligned16(X) && (ldx % 4 == 0) && (I % 4 == 0);
+    // activations may be stored with padded leading dimensions (multiple of 4): the vector loaders mask pad columns
+    const int vecA = aligned16(dY) && (lddy % 4 == 0) && (act == SNF_ACT_NONE || (aligned16(Y) && ldy % 4 == 0));
+    const int vecB = aligned16(X) && (ldx % 4 == 0);
     const int to = ceil_div(O, 64), ti = ceil_div(I, 64);
     // aim for ~2048 workgroups; every chunk is a multiple of BK rows
     int chunks = 2048 / (to * ti);

@@ -1,0 +1,326 @@
+// mlp_chain.hip -- the 64-wide "fully fused" tiny MLPs (tcnn FullyFusedMLP role) on the fp32 matrix cores (gfx950).
+//
+// Nets: base  32 -> 64 -> 16          (nerfstudio/fields/nerfacto_field.py:157-175, density + 15 geo features)
+//       head  31 -> 64 -> 64 -> 3     (nerfacto_field.py:228-240, SH16 ++ geo15 -> rgb, sigmoid)
+// Layer-by-layer GEMMs move every hidden activation through HBM several times (4.6 GB per step for these two nets at
+// 524k samples).  Here a wavefront carries 32 samples through the WHOLE net with activations in registers:
+//
+//   the product is formed transposed, H^T[neuron][sample] = W * X^T, with the weights as the MFMA A operand (read from
+//   LDS, where all layers live) and the activations as the B operand.  v_mfma_f32_32x32x2_f32 leaves D[row][col] in
+//   lane (col, half) / register r with row = (r&3) + 8*(r>>2) + 4*half -- and a B operand wants, per k-step, one k from
+//   the lower half-wave and one from the upper.  Since the k order of a dot product is free, step r of the next layer
+//   simply uses register r as its B operand and reads the weight column k = row(r, half): no transposes, no LDS
+//   round trip for activations, no workgroup barriers in the tile loop (waves are independent).
+//
+//   forward : X -> [H1] -> [H2] -> Y          (hidden activations are stored once, for the backward)
+//   backward: dY -> dH2 -> dH1 -> dX          (data-gradient chain; ReLU masks from the stored activations)
+// Weight gradients are three tall-skinny GEMMs over the (pre-masked) dH / H pairs (linear.hip).
+#include "common.hpp"
+
+namespace snf {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int MC_H = 64;        // hidden width
+constexpr int MC_IN = 32;       // (padded) input width
+constexpr int MC_P0 = 33;       // LDS pitch of W0 [64][32]
+constexpr int MC_P1 = 65;       // LDS pitch of W1 [64][64] and Wout [32][64]
+
+__device__ __forceinline__ int krow(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+
+__device__ __forceinline__ f32x16 zero16() {
+    f32x16 z;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) z[i] = 0.f;
+    return z;
+}
+
+struct ChainWeights {
+    float* w0;    // [64][MC_P0]   W0[o][i], columns >= in_real zero
+    float* w1;    // [64][MC_P1]   W1[o][k]           (NH == 2 only)
+    float* wo;    // [32][MC_P1]   Wout[o][k], rows >= out zero
+};
+
+template <int NH>
+__device__ __forceinline__ void load_chain_weights(float* lds, ChainWeights& cw, const float* __restrict__ W0, int in_real,
+                                                   const float* __restrict__ W1, const float* __restrict__ Wout,
+                                                   int out) {
+    cw.w0 = lds;
+    cw.w1 = lds + MC_H * MC_P0;
+    cw.wo = cw.w1 + (NH == 2 ? MC_H * MC_P1 : 0);
+    for (int i = threadIdx.x; i < MC_H * MC_IN; i += blockDim.x) {
+        const int o = i / MC_IN, c = i % MC_IN;
+        cw.w0[o * MC_P0 + c] = (c < in_real) ? W0[o * in_real + c] : 0.f;
+    }
+    if constexpr (NH == 2) {
+        for (int i = threadIdx.x; i < MC_H * MC_H; i += blockDim.x) cw.w1[(i / MC_H) * MC_P1 + (i % MC_H)] = W1[i];
+    }
+    for (int i = threadIdx.x; i < 32 * MC_H; i += blockDim.x) {
+        const int o = i / MC_H, c = i % MC_H;
+        cw.wo[o * MC_P1 + c] = (o < out) ? Wout[o * MC_H + c] : 0.f;
+    }
+    __syncthreads();
+}
+
+constexpr int chain_lds_floats(int NH) { return MC_H * MC_P0 + (NH == 2 ? MC_H * MC_P1 : 0) + 32 * MC_P1; }
+
+// next layer (64 wide) from a 64-wide activation held as two D tiles: out[u] = sum_t sum_r A(W[u*32+li][t*32+krow]) * act[t][r]
+__device__ __forceinline__ void layer_64x64(const float* __restrict__ w, int pitch, const f32x16 (&act)[2], f32x16 (&out)[2],
+                                            int li, int half) {
+    out[0] = zero16();
+    out[1] = zero16();
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int k = t * 32 + krow(r, half);
+            const float b = act[t][r];
+            out[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[li * pitch + k], b, out[0], 0, 0, 0);
+            out[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[(32 + li) * pitch + k], b, out[1], 0, 0, 0);
+        }
+    }
+}
+
+// store a 64-wide D-tile pair as rows of a [N,64] row-major matrix (lane (s,half) owns columns t*32 + 8q + 4half + 0..3)
+__device__ __forceinline__ void store_h64(float* __restrict__ H, long long s, const f32x16 (&a)[2], int half) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<float4*>(H + s * MC_H + t * 32 + 8 * q + 4 * half) =
+                make_float4(a[t][4 * q], a[t][4 * q + 1], a[t][4 * q + 2], a[t][4 * q + 3]);
+}
+
+__device__ __forceinline__ void load_h64(const float* __restrict__ H, long long s, f32x16 (&a)[2], int half) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 v = *reinterpret_cast<const float4*>(H + s * MC_H + t * 32 + 8 * q + 4 * half);
+            a[t][4 * q] = v.x; a[t][4 * q + 1] = v.y; a[t][4 * q + 2] = v.z; a[t][4 * q + 3] = v.w;
+        }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+template <int NH>
+__global__ __launch_bounds__(256) void k_mlp_chain_fwd(const float* __restrict__ X, int ldx, const float* __restrict__ W0,
+                                                       int in_real, const float* __restrict__ W1,
+                                                       const float* __restrict__ Wout, int out, int out_act, long long N,
+                                                       float* __restrict__ H1, float* __restrict__ H2,
+                                                       float* __restrict__ Y, int ldy) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    ChainWeights cw;
+    load_chain_weights<NH>(lds, cw, W0, in_real, W1, Wout, out);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 31, half = lane >> 5;
+    const long long ntiles = (N + 31) / 32;
+    for (long long tile = (long long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long long)gridDim.x * 4) {
+        const long long s = tile * 32 + li;
+        const bool ok = s < N;
+        const long long sc = ok ? s : N - 1;
+        // this lane's half of the input row: X[s][half*16 .. half*16+15]
+        float x[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 v = *reinterpret_cast<const float4*>(X + sc * ldx + half * 16 + 4 * q);
+            x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (half * 16 + i >= in_real) x[i] = 0.f;  // pad columns may hold anything (select, not multiply)
+        // layer 0: H1^T[o][s], k pairing (step, 16 + step)
+        f32x16 h1[2] = {zero16(), zero16()};
+#pragma unroll
+        for (int st = 0; st < 16; ++st) {
+            const int k = half * 16 + st;
+            h1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(cw.w0[li * MC_P0 + k], x[st], h1[0], 0, 0, 0);
+            h1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(cw.w0[(32 + li) * MC_P0 + k], x[st], h1[1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) h1[t][r] = fmaxf(h1[t][r], 0.f);
+        if (H1 != nullptr && ok) store_h64(H1, s, h1, half);
+        f32x16 last[2];
+        if constexpr (NH == 2) {
+            layer_64x64(cw.w1, MC_P1, h1, last, li, half);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) last[t][r] = fmaxf(last[t][r], 0.f);
+            if (H2 != nullptr && ok) store_h64(H2, s, last, half);
+        } else {
+            last[0] = h1[0];
+            last[1] = h1[1];
+        }
+        // output layer (<= 32 neurons): Y^T[o][s]
+        f32x16 y = zero16();
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                y = __builtin_amdgcn_mfma_f32_32x32x2f32(cw.wo[li * MC_P1 + t * 32 + krow(r, half)], last[t][r], y, 0, 0, 0);
+        if (ok) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = krow(r, half);
+                if (o < out) {
+                    float v = y[r];
+                    if (out_act == SNF_ACT_SIGMOID) v = 1.f / (1.f + expf(-v));
+                    else if (out_act == SNF_ACT_RELU) v = fmaxf(v, 0.f);
+                    Y[s * ldy + o] = v;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// dZ[s][o] = dY[s*lddy + dy_col_off + o]  (o >= 1, or all o when dY0 == NULL) ; dZ[s][0] = dY0[s] when dY0 != NULL.
+// With out_act == SIGMOID the derivative y(1-y) of the stored output Y is applied.
+template <int NH>
+__global__ __launch_bounds__(256) void k_mlp_chain_bwd(const float* __restrict__ dY, int lddy, int dy_col_off,
+                                                       const float* __restrict__ dY0, const float* __restrict__ Yout,
+                                                       int ldy, const float* __restrict__ W0, int in_real,
+                                                       const float* __restrict__ W1, const float* __restrict__ Wout,
+                                                       int out, int out_act, long long N, const float* __restrict__ H1,
+                                                       const float* __restrict__ H2, float* __restrict__ dH1,
+                                                       float* __restrict__ dH2, float* __restrict__ dZout, int lddz,
+                                                       float* __restrict__ dX, int lddx) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    ChainWeights cw;
+    load_chain_weights<NH>(lds, cw, W0, in_real, W1, Wout, out);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 31, half = lane >> 5;
+    const int outp = (out + 1) & ~1;  // padded to even: k pairing (step, outp/2 + step)
+    const int hsteps = outp >> 1;
+    const long long ntiles = (N + 31) / 32;
+    for (long long tile = (long long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long long)gridDim.x * 4) {
+        const long long s = tile * 32 + li;
+        const bool ok = s < N;
+        const long long sc = ok ? s : N - 1;
+        // ---- dLast^T[k][s] = sum_o Wout[o][k] dZ^T[o][s]
+        f32x16 dl[2] = {zero16(), zero16()};
+        for (int st = 0; st < hsteps; ++st) {
+            const int o = half * hsteps + st;
+            float dz = 0.f;
+            if (o < out) {
+                dz = (o == 0 && dY0 != nullptr) ? dY0[sc] : dY[sc * lddy + dy_col_off + o];
+                if (out_act == SNF_ACT_SIGMOID) {
+                    const float yv = Yout[sc * ldy + o];
+                    dz *= yv * (1.f - yv);
+                }
+                if (dZout != nullptr && ok) dZout[s * lddz + o] = dz;  // pre-activation output gradient, for the wgrad GEMM
+            }
+            const int oc = o < 32 ? o : 31;
+            dl[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(cw.wo[oc * MC_P1 + li], dz, dl[0], 0, 0, 0);
+            dl[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(cw.wo[oc * MC_P1 + 32 + li], dz, dl[1], 0, 0, 0);
+        }
+        f32x16 hh[2];
+        if constexpr (NH == 2) {
+            load_h64(H2, sc, hh, half);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dl[t][r] = hh[t][r] > 0.f ? dl[t][r] : 0.f;
+            if (ok) store_h64(dH2, s, dl, half);
+            // dH1^T[k1][s] = sum_k2 W1[k2][k1] dH2^T[k2][s]
+            f32x16 d1[2] = {zero16(), zero16()};
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int k2 = u * 32 + krow(r, half);
+                    const float b = dl[u][r];
+                    d1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(cw.w1[k2 * MC_P1 + li], b, d1[0], 0, 0, 0);
+                    d1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(cw.w1[k2 * MC_P1 + 32 + li], b, d1[1], 0, 0, 0);
+                }
+            dl[0] = d1[0];
+            dl[1] = d1[1];
+        }
+        load_h64(H1, sc, hh, half);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dl[t][r] = hh[t][r] > 0.f ? dl[t][r] : 0.f;
+        if (ok) store_h64(dH1, s, dl, half);
+        // ---- dX^T[i][s] = sum_k1 W0[k1][i] dH1^T[k1][s]
+        if (dX != nullptr) {
+            f32x16 dx = zero16();
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    dx = __builtin_amdgcn_mfma_f32_32x32x2f32(cw.w0[(t * 32 + krow(r, half)) * MC_P0 + li], dl[t][r], dx, 0,
+                                                              0, 0);
+            if (ok) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<float4*>(dX + s * lddx + 8 * q + 4 * half) =
+                        make_float4(dx[4 * q], dx[4 * q + 1], dx[4 * q + 2], dx[4 * q + 3]);
+            }
+        }
+    }
+}
+
+}  // namespace snf
+
+using namespace snf;
+
+static int chain_common_checks(const char* who, int in_real, int n_hidden, int out, long long N) {
+    SNF_REQUIRE(in_real >= 1 && in_real <= MC_IN, "%s: input width %d not in [1,32]", who, in_real);
+    SNF_REQUIRE(n_hidden == 1 || n_hidden == 2, "%s: 1 or 2 hidden layers of width 64 (got %d)", who, n_hidden);
+    SNF_REQUIRE(out >= 1 && out <= 32, "%s: output width %d not in [1,32]", who, out);
+    SNF_REQUIRE(N > 0, "%s: empty batch", who);
+    return SNF_OK;
+}
+
+extern "C" int snf_mlp64_fwd(const float* X, int ldx, const float* W0, int in_real, const float* W1, const float* Wout,
+                             int n_hidden, int out, int out_act, int64_t N, float* H1, float* H2, float* Y, int ldy,
+                             snf_stream_t stream) {
+    int rc = chain_common_checks("snf_mlp64_fwd", in_real, n_hidden, out, N);
+    if (rc) return rc;
+    SNF_REQUIRE(X && W0 && Wout && Y && (n_hidden == 1 || W1), "snf_mlp64_fwd: null pointer");
+    SNF_REQUIRE(ldx >= MC_IN && ldx % 4 == 0 && ((uintptr_t)X % 16) == 0,
+                "snf_mlp64_fwd: X must be [N, ldx>=32] with ldx %% 4 == 0 and 16-byte aligned rows (pad columns readable)");
+    SNF_REQUIRE(ldy >= out, "snf_mlp64_fwd: ldy < out");
+    SNF_REQUIRE((!H1 || ((uintptr_t)H1 % 16) == 0) && (!H2 || ((uintptr_t)H2 % 16) == 0), "snf_mlp64_fwd: unaligned H");
+    const long long ntiles = (N + 31) / 32;
+    long long blocks = (ntiles + 3) / 4;
+    if (blocks > 256 * 4) blocks = 256 * 4;  // persistent: <= 4 workgroups per CU
+    if (n_hidden == 2)
+        hipLaunchKernelGGL(k_mlp_chain_fwd<2>, dim3((unsigned)blocks), dim3(256), chain_lds_floats(2) * sizeof(float),
+                           (hipStream_t)stream, X, ldx, W0, in_real, W1, Wout, out, out_act, (long long)N, H1, H2, Y, ldy);
+    else
+        hipLaunchKernelGGL(k_mlp_chain_fwd<1>, dim3((unsigned)blocks), dim3(256), chain_lds_floats(1) * sizeof(float),
+                           (hipStream_t)stream, X, ldx, W0, in_real, W1, Wout, out, out_act, (long long)N, H1, H2, Y, ldy);
+    SNF_LAUNCH_CHECK("snf_mlp64_fwd");
+    return SNF_OK;
+}
+
+extern "C" int snf_mlp64_bwd_data(const float* dY, int lddy, int dy_col_off, const float* dY0, const float* Y, int ldy,
+                                  const float* W0, int in_real, const float* W1, const float* Wout, int n_hidden, int out,
+                                  int out_act, int64_t N, const float* H1, const float* H2, float* dH1, float* dH2,
+                                  float* dZ, int lddz, float* dX, int lddx, snf_stream_t stream) {
+    int rc = chain_common_checks("snf_mlp64_bwd_data", in_real, n_hidden, out, N);
+    if (rc) return rc;
+    SNF_REQUIRE(dY && W0 && Wout && H1 && dH1 && (n_hidden == 1 || (W1 && H2 && dH2)), "snf_mlp64_bwd_data: null pointer");
+    SNF_REQUIRE(out_act != SNF_ACT_SIGMOID || Y, "snf_mlp64_bwd_data: Y required for the sigmoid derivative");
+    SNF_REQUIRE(out_act != SNF_ACT_RELU, "snf_mlp64_bwd_data: ReLU output activation is not supported");
+    SNF_REQUIRE(!dZ || lddz >= out, "snf_mlp64_bwd_data: lddz < out");
+    SNF_REQUIRE(!dX || (lddx >= MC_IN && lddx % 4 == 0 && ((uintptr_t)dX % 16) == 0), "snf_mlp64_bwd_data: bad dX layout");
+    SNF_REQUIRE(((uintptr_t)H1 % 16) == 0 && ((uintptr_t)dH1 % 16) == 0, "snf_mlp64_bwd_data: unaligned H1/dH1");
+    const long long ntiles = (N + 31) / 32;
+    long long blocks = (ntiles + 3) / 4;
+    if (blocks > 256 * 4) blocks = 256 * 4;
+    if (n_hidden == 2)
+        hipLaunchKernelGGL(k_mlp_chain_bwd<2>, dim3((unsigned)blocks), dim3(256), chain_lds_floats(2) * sizeof(float),
+                           (hipStream_t)stream, dY, lddy, dy_col_off, dY0, Y, ldy, W0, in_real, W1, Wout, out, out_act,
+                           (long long)N, H1, H2, dH1, dH2, dZ, lddz, dX, lddx);
+    else
+        hipLaunchKernelGGL(k_mlp_chain_bwd<1>, dim3((unsigned)blocks), dim3(256), chain_lds_floats(1) * sizeof(float),
+                           (hipStream_t)stream, dY, lddy, dy_col_off, dY0, Y, ldy, W0, in_real, W1, Wout, out, out_act,
+                           (long long)N, H1, H2, dH1, dH2, dZ, lddz, dX, lddx);
+    SNF_LAUNCH_CHECK("snf_mlp64_bwd_data");
+    return SNF_OK;
+}

@@ -38,6 +38,7 @@ __global__ __launch_bounds__(256) void k_head_input(const float* __restrict__ di
     o[15] = 0.5900435899266435f * x * (xx - 3.f * yy);
     const float* g = geo + (size_t)t * ld_geo;
     for (int j = 0; j < n_geo; ++j) o[16 + j] = g[j];
+    for (int j = 16 + n_geo; j < ld_out; ++j) o[j] = 0.f;  // pad columns (e.g. 31 -> 32 for the fused MLP)
 }
 
 // ------------------------------------------------------------------------------------------
@@ -144,13 +145,13 @@ __global__ __launch_bounds__(256) void k_trunc_exp_fwd(const float* __restrict__
 __global__ __launch_bounds__(256) void k_trunc_exp_bwd(const float* __restrict__ raw, int raw_stride,
                                                        const uint8_t* __restrict__ selector,
                                                        const float* __restrict__ gd, long long N,
-                                                       float* __restrict__ grad_raw) {
+                                                       float* __restrict__ grad_raw, int grad_stride) {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= N) return;
     const float x = fminf(fmaxf(raw[t * raw_stride], -15.f), 15.f);
     float g = gd[t] * expf(x);
     if (selector) g *= (float)selector[t];
-    grad_raw[t * raw_stride] = g;
+    grad_raw[t * grad_stride] = g;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -303,10 +304,11 @@ extern "C" int snf_trunc_exp_fwd(const float* raw, int raw_stride, const uint8_t
 }
 
 extern "C" int snf_trunc_exp_bwd(const float* raw, int raw_stride, const uint8_t* selector, const float* grad_density,
-                                 int64_t N, float* grad_raw, snf_stream_t stream) {
-    SNF_REQUIRE(raw && grad_density && grad_raw && N > 0 && raw_stride >= 1, "snf_trunc_exp_bwd: bad argument");
+                                 int64_t N, float* grad_raw, int grad_stride, snf_stream_t stream) {
+    SNF_REQUIRE(raw && grad_density && grad_raw && N > 0 && raw_stride >= 1 && grad_stride >= 1,
+                "snf_trunc_exp_bwd: bad argument");
     hipLaunchKernelGGL(k_trunc_exp_bwd, dim3(ceil_div(N, 256)), dim3(256), 0, (hipStream_t)stream, raw, raw_stride,
-                       selector, grad_density, (long long)N, grad_raw);
+                       selector, grad_density, (long long)N, grad_raw, grad_stride);
     SNF_LAUNCH_CHECK("snf_trunc_exp_bwd");
     return SNF_OK;
 }

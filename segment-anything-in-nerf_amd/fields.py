@@ -133,6 +133,27 @@ class TCNNNerfactoField(Field):
                             "n_neurons": hidden_dim_color, "n_hidden_layers": num_layers_color - 1}, device=device)
         self._h_full = None
 
+    def _fusable(self) -> bool:
+        enc, base, head = self.mlp_base.encoding, self.mlp_base.network, self.mlp_head
+        return (enc.n_output_dims == 32 and base.n_neurons == 64 and base.n_hidden_layers == 1
+                and head.n_neurons == 64 and head.n_hidden_layers == 2 and head.n_input_dims <= 32
+                and base.n_output_dims <= 32)
+
+    def forward(self, ray_samples: RaySamples, compute_normals: bool = False) -> Dict:
+        """Field.forward (base_field.py:99-118) as one fused autograd node when the net has the nerfacto shape."""
+        if compute_normals:
+            raise NotImplementedError("predict_normals is disabled in the samnerf configs")
+        if not (isinstance(ray_samples, RaySamples) and self._fusable()):
+            return super().forward(ray_samples, compute_normals)
+        if ray_samples.camera_indices is None:
+            raise AttributeError("Camera indices are not provided.")
+        u, sel, shape = _positions_of(ray_samples, self.spatial_distortion, True)
+        R, S = shape
+        enc = self.mlp_base.encoding
+        density, rgb = ops.nerfacto_field(u, sel, ray_samples.ray_bundle.directions, R, S, enc.spec, enc.params,
+                                          self.mlp_base.network.weights(), self.mlp_head.weights())
+        return {FieldHeadNames.RGB: rgb.view(R, S, 3), FieldHeadNames.DENSITY: density.view(R, S, 1)}
+
     def get_density(self, ray_samples):
         u, sel, shape = _positions_of(ray_samples, self.spatial_distortion, True)
         h = self.mlp_base(u)  # [N, 1+geo]: column 0 = pre-activation density

@@ -160,6 +160,16 @@ def render_depth_acc(weights, ebins, want_acc: bool = True):
 # ---------------------------------------------------------------------------------------------
 # hash grid
 # ---------------------------------------------------------------------------------------------
+def _hashgrid_bwd_launch(u, g, sc, N, L, F, T, ld, col, buf) -> None:
+    if HASHGRID_BWD_MODE == "atomic":
+        _launch("snf_hashgrid_bwd", _p(u), _p(g), _p(sc), N, L, F, T, ld, col, _p(buf), _stream(), tag=f"F{F}L{L}")
+    else:
+        nbytes = int(_L().snf_hashgrid_bwd_workspace_bytes(N, L, T))
+        ws = torch.empty(((nbytes + 3) // 4,), device=g.device, dtype=torch.int32)
+        _launch("snf_hashgrid_bwd_sorted", _p(u), _p(g), _p(sc), N, L, F, T, ld, col, _p(buf), _p(ws), nbytes, _stream(),
+                tag=f"F{F}L{L}")
+
+
 class _HashGridMulti(torch.autograd.Function):
     """One or more hash grids evaluated at the same points, outputs concatenated along the feature axis."""
 
@@ -193,14 +203,7 @@ class _HashGridMulti(torch.autograd.Function):
                 grads.append(None)
             else:
                 buf, fused = _grad_target(tab)
-                if HASHGRID_BWD_MODE == "atomic":
-                    _launch("snf_hashgrid_bwd", _p(u), _p(g), _p(sc), N, L, F, T, total, col, _p(buf), _stream(),
-                            tag=f"F{F}L{L}")
-                else:
-                    nbytes = int(_L().snf_hashgrid_bwd_workspace_bytes(N, L, T))
-                    ws = torch.empty(((nbytes + 3) // 4,), device=g.device, dtype=torch.int32)
-                    _launch("snf_hashgrid_bwd_sorted", _p(u), _p(g), _p(sc), N, L, F, T, total, col, _p(buf), _p(ws),
-                            nbytes, _stream(), tag=f"F{F}L{L}")
+                _hashgrid_bwd_launch(u, g, sc, N, L, F, T, total, col, buf)
                 grads.append(None if fused else buf)
             col += L * F
         return (None, None, *grads)
@@ -258,6 +261,151 @@ def mlp(x, weights: Sequence[torch.Tensor], biases=None, out_act: int = ACT_NONE
         b = None if biases is None else biases[i]
         x = linear(x, w, b, ACT_RELU if i < n - 1 else out_act)
     return x
+
+
+# ---------------------------------------------------------------------------------------------
+# fused 64-wide MLP (activations in registers; see csrc/mlp_chain.hip)
+# ---------------------------------------------------------------------------------------------
+def mlp64_supported(in_dim: int, weights: Sequence[torch.Tensor]) -> bool:
+    n = len(weights)
+    return (n in (2, 3) and in_dim <= 32 and all(w.shape[1] == 64 for w in weights[1:])
+            and all(w.shape[0] == 64 for w in weights[:-1]) and weights[-1].shape[0] <= 32)
+
+
+def _mlp64_fwd_launch(x, in_real, ws, out_act, save: bool):
+    N, ldx = x.shape
+    nh = len(ws) - 1
+    out = ws[-1].shape[0]
+    dev = x.device
+    h1 = torch.empty((N, 64), device=dev, dtype=torch.float32) if save else None
+    h2 = torch.empty((N, 64), device=dev, dtype=torch.float32) if (save and nh == 2) else None
+    y = torch.empty((N, out), device=dev, dtype=torch.float32)
+    _launch("snf_mlp64_fwd", _p(x), ldx, _p(ws[0]), in_real, _p(ws[1] if nh == 2 else None), _p(ws[-1]), nh, out,
+            out_act, N, _p(h1), _p(h2), _p(y), out, _stream(), tag=f"{in_real}x{'x'.join(['64'] * nh)}x{out}")
+    return y, h1, h2
+
+
+def _mlp64_bwd_launch(x, in_real, ws, out_act, y, h1, h2, dy, lddy, dy_col_off, dy0, need_dx: bool):
+    """-> dX [N,32] (or None).  Weight gradients are accumulated into the weights' grad targets; returns them too."""
+    N, ldx = x.shape
+    nh = len(ws) - 1
+    out = ws[-1].shape[0]
+    dev = x.device
+    ldz = (out + 3) // 4 * 4
+    dh1 = torch.empty((N, 64), device=dev, dtype=torch.float32)
+    dh2 = torch.empty((N, 64), device=dev, dtype=torch.float32) if nh == 2 else None
+    dz = torch.empty((N, ldz), device=dev, dtype=torch.float32)
+    dx = torch.empty((N, 32), device=dev, dtype=torch.float32) if need_dx else None
+    tag = f"{in_real}x{'x'.join(['64'] * nh)}x{out}"
+    _launch("snf_mlp64_bwd_data", _p(dy), lddy, dy_col_off, _p(dy0), _p(y), out, _p(ws[0]), in_real,
+            _p(ws[1] if nh == 2 else None), _p(ws[-1]), nh, out, out_act, N, _p(h1), _p(h2), _p(dh1), _p(dh2), _p(dz),
+            ldz, _p(dx), 32, _stream(), tag=tag)
+    grads = []
+    # (dZ, Hlast) -> dWout ; (dH2, H1) -> dW1 ; (dH1, X) -> dW0      [all pre-masked: act = NONE]
+    pairs = [(dh1, 64, x, ldx, in_real, ws[0])]
+    if nh == 2:
+        pairs.append((dh2, 64, h1, 64, 64, ws[1]))
+    pairs.append((dz, ldz, h2 if nh == 2 else h1, 64, 64, ws[-1]))
+    for (g, ldg, a, lda, I, w) in pairs:
+        if not w.requires_grad:
+            grads.append(None)
+            continue
+        O = w.shape[0]
+        buf, fused = _grad_target(w)
+        _launch("snf_linear_bwd_weight", _p(g), _p(None), _p(a), N, I, O, ldg, 0, lda, ACT_NONE, _p(buf), _p(None),
+                _stream(), tag=f"{I}x{O}")
+        grads.append(None if fused else buf)
+    return dx, grads
+
+
+class _MLP64(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, in_real: int, out_act: int, *ws):
+        x = _chk(x, "x")
+        assert x.shape[1] >= 32 and x.shape[1] % 4 == 0, "mlp64 input must be padded to >= 32 columns (multiple of 4)"
+        y, h1, h2 = _mlp64_fwd_launch(x, in_real, ws, out_act, True)
+        ctx.save_for_backward(x, y, h1, *((h2,) if h2 is not None else ()))
+        ctx.ws, ctx.in_real, ctx.out_act = ws, in_real, out_act
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        saved = ctx.saved_tensors
+        x, y, h1 = saved[0], saved[1], saved[2]
+        h2 = saved[3] if len(saved) > 3 else None
+        gy = _chk(gy, "grad_y")
+        dx, grads = _mlp64_bwd_launch(x, ctx.in_real, ctx.ws, ctx.out_act, y, h1, h2, gy, gy.shape[1], 0, None,
+                                      ctx.needs_input_grad[0])
+        if dx is not None and x.shape[1] != 32:
+            full = torch.zeros_like(x)
+            full[:, :32] = dx
+            dx = full
+        return (dx, None, None, *grads)
+
+
+def mlp64(x, weights: Sequence[torch.Tensor], in_real: int, out_act: int = ACT_NONE) -> torch.Tensor:
+    """Fused 64-wide MLP: x [N, >=32 (padded)] -> [N, out].  weights: [64,in_real], ([64,64]), [out,64]."""
+    return _MLP64.apply(x, in_real, out_act, *weights)
+
+
+# ---------------------------------------------------------------------------------------------
+# the whole nerfacto field as ONE autograd node: hash grid -> base MLP -> {trunc_exp density, SH ++ geo -> colour MLP}
+# (TCNNNerfactoField.get_density + get_outputs, nerfstudio/fields/nerfacto_field.py:242-351), fused MLP kernels,
+# no glue tensors (cat / split / zero-filled slice gradients) in between.
+# ---------------------------------------------------------------------------------------------
+class _NerfactoField(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, u, sel, dirs, R: int, S: int, spec, table, bw0, bw1, hw0, hw1, hw2):
+        u, dirs, table = _chk(u, "u"), _chk(dirs, "dirs"), _chk(table, "table")
+        sc, L, F, T = spec
+        N = R * S
+        dev = u.device
+        need = any(ctx.needs_input_grad)  # (grad mode is off inside forward; autograd tells us what it will ask for)
+        enc = torch.empty((N, L * F), device=dev, dtype=torch.float32)
+        _launch("snf_hashgrid_fwd", _p(u), _p(table), _p(sc), N, L, F, T, _p(enc), L * F, 0, _stream(), tag=f"F{F}L{L}")
+        h, hb1, _ = _mlp64_fwd_launch(enc, L * F, (bw0, bw1), ACT_NONE, need)
+        C = h.shape[1]
+        density = torch.empty((N,), device=dev, dtype=torch.float32)
+        _launch("snf_trunc_exp_fwd", _p(h), C, _p(sel), N, _p(density), _stream())
+        n_geo = C - 1
+        x2 = torch.empty((N, 32), device=dev, dtype=torch.float32)
+        geo = ctypes.c_void_p(h.data_ptr() + 4)
+        _launch("snf_head_input", _p(dirs), geo, R, S, n_geo, C, _p(x2), 32, _stream())
+        rgb, hh1, hh2 = _mlp64_fwd_launch(x2, 16 + n_geo, (hw0, hw1, hw2), ACT_SIGMOID, need)
+        if need:
+            ctx.save_for_backward(u, enc, h, hb1, x2, hh1, hh2, rgb)
+            ctx.sel, ctx.spec = sel, spec
+            ctx.params = (table, bw0, bw1, hw0, hw1, hw2)
+        return density, rgb
+
+    @staticmethod
+    def backward(ctx, g_density, g_rgb):
+        u, enc, h, hb1, x2, hh1, hh2, rgb = ctx.saved_tensors
+        table, bw0, bw1, hw0, hw1, hw2 = ctx.params
+        sc, L, F, T = ctx.spec
+        N, C = h.shape
+        dev = h.device
+        # colour MLP: d rgb -> d(SH ++ geo)
+        g_rgb = _chk(g_rgb, "grad_rgb") if g_rgb is not None else torch.zeros_like(rgb)
+        dx2, gh = _mlp64_bwd_launch(x2, x2.shape[1] - 1, (hw0, hw1, hw2), ACT_SIGMOID, rgb, hh1, hh2, g_rgb, 3, 0, None, True)
+        # density column: through trunc_exp * selector
+        graw = torch.empty((N,), device=dev, dtype=torch.float32)
+        gd = _chk(g_density, "grad_density") if g_density is not None else torch.zeros((N,), device=dev)
+        _launch("snf_trunc_exp_bwd", _p(h), C, _p(ctx.sel), _p(gd), N, _p(graw), 1, _stream())
+        # base MLP: dZ[:,0] = graw, dZ[:,1:] = dx2[:, 16:31]  (read in place: column offset 15 of the [N,32] buffer)
+        denc, gb = _mlp64_bwd_launch(enc, L * F, (bw0, bw1), ACT_NONE, None, hb1, None, dx2, 32, 15, graw,
+                                     table.requires_grad)
+        gt = None
+        if table.requires_grad:
+            buf, fused = _grad_target(table)
+            _hashgrid_bwd_launch(u, denc, sc, N, L, F, T, 32, 0, buf)
+            gt = None if fused else buf
+        return (None, None, None, None, None, None, gt, gb[0], gb[1], gh[0], gh[1], gh[2])
+
+
+def nerfacto_field(u, sel, dirs, R: int, S: int, spec, table, base_ws, head_ws):
+    """-> (density [R*S], rgb [R*S,3]); base_ws = (W0 [64,32], W1 [16,64]), head_ws = (W0 [64,31], W1 [64,64], W2 [3,64])."""
+    return _NerfactoField.apply(u, sel, dirs, R, S, spec, table, *base_ws, *head_ws)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -352,7 +500,7 @@ class _TruncExpSel(torch.autograd.Function):
         N, C = h.shape
         gd = _chk(gd, "grad_density")
         gh = torch.zeros_like(h) if C > 1 else torch.empty_like(h)
-        _launch("snf_trunc_exp_bwd", _p(h), C, _p(ctx.selector), _p(gd), N, _p(gh), _stream())
+        _launch("snf_trunc_exp_bwd", _p(h), C, _p(ctx.selector), _p(gd), N, _p(gh), C, _stream())
         return gh, None
 
 

@@ -140,6 +140,32 @@ def test_linear_large_ragged():
         assert maxdiff(wg.grad, wc.grad) <= 1e-4 * max(1.0, float(wc.grad.abs().max())), (N, I, Oo)
 
 
+@pytest.mark.parametrize("cfg", [(32, 1, 16, None), (31, 2, 3, "sigmoid"), (10, 1, 1, None), (32, 2, 32, None)])
+@pytest.mark.parametrize("N", [1, 1000, 4133])
+def test_mlp64_fused_vs_torch(cfg, N):
+    """fused 64-wide MLP (activations in registers) against torch autograd, incl. ragged N and padded inputs."""
+    in_real, nh, out, act = cfg
+    gen = torch.Generator().manual_seed(11 + N + in_real)
+    dims = [in_real] + [64] * nh + [out]
+    ws = [O._linear_init(dims[i + 1], dims[i], gen) for i in range(len(dims) - 1)]
+    x = torch.randn((N, in_real), generator=gen) * 0.7
+    gy = torch.randn((N, out), generator=gen)
+    xc = x.clone().requires_grad_(True)
+    wc = [w.clone().requires_grad_(True) for w in ws]
+    yc = O.mlp_fwd(xc, wc, None, act)
+    (yc * gy).sum().backward()
+    xp = torch.full((N, 32), float("nan"))  # pad columns hold garbage on purpose
+    xp[:, :in_real] = x
+    xg = xp.to(DEV).requires_grad_(True)
+    wg = [w.to(DEV).requires_grad_(True) for w in ws]
+    yg = ops().mlp64(xg, wg, in_real, ops().ACT_BY_NAME[act])
+    assert maxdiff(yg, yc) <= 5e-6
+    (yg * gy.to(DEV)).sum().backward()
+    assert maxdiff(xg.grad[:, :in_real], xc.grad) <= 2e-5
+    for a, b in zip(wg, wc):
+        assert maxdiff(a.grad, b.grad) <= 1e-4 * max(1.0, float(b.grad.abs().max()))
+
+
 def test_head_input(golden):
     g = golden("sh16")
     d = G(g["directions"])
