@@ -29,24 +29,53 @@ __device__ __forceinline__ void adam1(float& p, float& g, float& m, float& v, fl
     p = p - step_size * (m / denom);
 }
 
+// Streaming pass: every thread keeps two independent 16-byte groups of p,g,m,v in flight (8 loads) and writes with
+// non-temporal stores (the arenas are far larger than the caches and are not re-read before the next step).
+template <typename T>
+__device__ __forceinline__ T ldnt(const T* p) { return __builtin_nontemporal_load(p); }
+template <typename T>
+__device__ __forceinline__ void stnt(T* p, T v) { __builtin_nontemporal_store(v, p); }
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
 __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                               float* __restrict__ v, long long n, float b1, float b2, float step_size,
                                               float inv_sqrt_bc2, float eps, float gs, int zero_grad) {
     const long long n4 = n >> 2;
     const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-        float4 P = reinterpret_cast<float4*>(p)[i];
-        float4 G = reinterpret_cast<float4*>(g)[i];
-        float4 M = reinterpret_cast<float4*>(m)[i];
-        float4 V = reinterpret_cast<float4*>(v)[i];
-        adam1(P.x, G.x, M.x, V.x, gs, b1, b2, step_size, inv_sqrt_bc2, eps);
-        adam1(P.y, G.y, M.y, V.y, gs, b1, b2, step_size, inv_sqrt_bc2, eps);
-        adam1(P.z, G.z, M.z, V.z, gs, b1, b2, step_size, inv_sqrt_bc2, eps);
-        adam1(P.w, G.w, M.w, V.w, gs, b1, b2, step_size, inv_sqrt_bc2, eps);
-        reinterpret_cast<float4*>(p)[i] = P;
-        reinterpret_cast<float4*>(m)[i] = M;
-        reinterpret_cast<float4*>(v)[i] = V;
-        if (zero_grad) reinterpret_cast<float4*>(g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    f4* p4 = reinterpret_cast<f4*>(p);
+    f4* g4 = reinterpret_cast<f4*>(g);
+    f4* m4 = reinterpret_cast<f4*>(m);
+    f4* v4 = reinterpret_cast<f4*>(v);
+    const f4 zero = {0.f, 0.f, 0.f, 0.f};
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + stride < n4; i += 2 * stride) {
+        const long long j = i + stride;
+        f4 P0 = ldnt(p4 + i), G0 = ldnt(g4 + i), M0 = ldnt(m4 + i), V0 = ldnt(v4 + i);
+        f4 P1 = ldnt(p4 + j), G1 = ldnt(g4 + j), M1 = ldnt(m4 + j), V1 = ldnt(v4 + j);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float a = P0[c], bg = G0[c], cm = M0[c], dv = V0[c];
+            adam1(a, bg, cm, dv, gs, b1, b2, step_size, inv_sqrt_bc2, eps);
+            P0[c] = a; M0[c] = cm; V0[c] = dv;
+            a = P1[c]; bg = G1[c]; cm = M1[c]; dv = V1[c];
+            adam1(a, bg, cm, dv, gs, b1, b2, step_size, inv_sqrt_bc2, eps);
+            P1[c] = a; M1[c] = cm; V1[c] = dv;
+        }
+        stnt(p4 + i, P0); stnt(m4 + i, M0); stnt(v4 + i, V0);
+        stnt(p4 + j, P1); stnt(m4 + j, M1); stnt(v4 + j, V1);
+        if (zero_grad) { stnt(g4 + i, zero); stnt(g4 + j, zero); }
+    }
+    for (; i < n4; i += stride) {
+        f4 P0 = ldnt(p4 + i), G0 = ldnt(g4 + i), M0 = ldnt(m4 + i), V0 = ldnt(v4 + i);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float a = P0[c], bg = G0[c], cm = M0[c], dv = V0[c];
+            adam1(a, bg, cm, dv, gs, b1, b2, step_size, inv_sqrt_bc2, eps);
+            P0[c] = a; M0[c] = cm; V0[c] = dv;
+        }
+        stnt(p4 + i, P0); stnt(m4 + i, M0); stnt(v4 + i, V0);
+        if (zero_grad) stnt(g4 + i, zero);
     }
     // tail (n not a multiple of 4)
     const long long t = (n4 << 2) + (long long)blockIdx.x * blockDim.x + threadIdx.x;

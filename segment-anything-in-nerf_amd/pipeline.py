@@ -152,46 +152,56 @@ class Trainer:
         self.callbacks = self.pipeline.get_training_callbacks()
 
     # The feature branch sees the nerfacto branch only through DETACHED quantities (sample positions sam_field.py:116,
-    # sam_weights.detach() sam_model.py:260-277), so the loss splits into two disjoint autograd graphs:
-    #   feature losses -> {sam_field, conv}           nerf losses -> {fields, proposal_networks}
-    # The feature graph is back-propagated first; its gradient exchange (RCCL) and its Adam pass (the 0.8 GB arena, an
-    # HBM-streaming kernel) then run on a side stream underneath the nerf backward, which is latency- not bandwidth-bound.
+    # sam_weights.detach() sam_model.py:260-277), so a train step is two independent tasks after the nerfacto forward:
+    #   main stream : nerf losses -> backward {fields, proposal_networks} -> gradient exchange -> Adam
+    #   side stream : feature forward -> feature losses -> backward {sam_field, conv} -> gradient exchange -> Adam (0.8 GB)
+    # Both are enqueued back to back and run concurrently on the GPU (autograd executes a node's backward on the stream of
+    # its forward); the streams are joined at the end of the step.
     FEATURE_LOSSES = ("sam_loss", "clipseg_loss", "dino_loss")
     FEATURE_GROUPS = ("sam_field", "conv")
 
     def train_iteration(self, step: int):
         for cb in self.callbacks:
             cb.run_callback_at_location(step, BEFORE_TRAIN_ITERATION)
-        _, loss_dict, metrics_dict = self.pipeline.get_train_loss_dict(step=step)
         opt, scale = self.optimizers, 1.0 / D.world_size()
+        feat_groups = [g for g in self.FEATURE_GROUPS if g in opt.arenas]
+        use_side = self.overlap and torch.cuda.is_available() and len(feat_groups) > 0
+        model = self.pipeline.model
+        if use_side and self._side is None:
+            self._side = torch.cuda.Stream()
+        model.feature_stream = self._side if use_side else None
+        _, loss_dict, metrics_dict = self.pipeline.get_train_loss_dict(step=step)
         feat = [v for k, v in loss_dict.items() if k in self.FEATURE_LOSSES]
         rest = [v for k, v in loss_dict.items() if k not in self.FEATURE_LOSSES]
-        feat_groups = [g for g in self.FEATURE_GROUPS if g in opt.arenas]
         rest_groups = [g for g in opt.arenas if g not in feat_groups]
-        use_side = self.overlap and torch.cuda.is_available() and len(feat) > 0 and len(feat_groups) > 0
-        if use_side:
-            main = torch.cuda.current_stream()
-            if self._side is None:
-                self._side = torch.cuda.Stream()
-            sum(feat).backward()
-            self._side.wait_stream(main)
-            with torch.cuda.stream(self._side):
-                D.allreduce_gradients([opt.arenas[g].grad for g in feat_groups])
-                for g in feat_groups:
-                    opt.optimizer_step(g, scale, True)
-            sum(rest).backward()
+        if use_side and len(feat) > 0:
+            main, side = torch.cuda.current_stream(), self._side
+            loss_rest = sum(rest)
+            with torch.cuda.stream(side):
+                loss_feat = sum(feat)
+            # nerf task on the main stream
+            loss_rest.backward()
             D.allreduce_gradients([opt.arenas[g].grad for g in rest_groups])
             for g in rest_groups:
                 opt.optimizer_step(g, scale, True)
-            main.wait_stream(self._side)
+            # feature task on the side stream
+            with torch.cuda.stream(side):
+                loss_feat.backward()
+                D.allreduce_gradients([opt.arenas[g].grad for g in feat_groups])
+                for g in feat_groups:
+                    opt.optimizer_step(g, scale, True)
+                loss = loss_feat.detach()
+            main.wait_stream(side)
+            loss = loss + loss_rest.detach()
         else:
-            sum(loss_dict.values()).backward()
+            loss = sum(loss_dict.values())
+            loss.backward()
             D.allreduce_gradients([a.grad for a in opt.arenas.values()])
             opt.optimizer_step_all(grad_scale=scale, zero_grad=True)
+            loss = loss.detach()
         opt.scheduler_step_all(step)
         for cb in self.callbacks:
             cb.run_callback_at_location(step, AFTER_TRAIN_ITERATION)
-        loss = sum(v.detach() for v in loss_dict.values())
         return loss, loss_dict, metrics_dict
 
     def save_checkpoint(self, path: str, step: int) -> None:
