@@ -82,6 +82,12 @@ int snf_hashgrid_bwd_sorted(const float* u, const float* grad_out, const float* 
                             int log2_T, int ld_out, int col_off, float* grad_table, void* workspace,
                             int64_t workspace_bytes, snf_stream_t stream);
 
+/* Arithmetic of the wide (>= 128 input) dense layers: 1 (default) = bf16 3-term split on the bf16 matrix cores with fp32
+ * accumulate (max abs error ~1e-6 on head-shaped data, 1/5 of the matrix cycles), 0 = exact fp32 matrix cores.
+ * Process-wide; narrow layers always run exact fp32. */
+int snf_set_gemm_mode(int mode);
+int snf_get_gemm_mode(void);
+
 /* ---- a7: one layer of tcnn.Network (FullyFusedMLP / CutlassMLP) == nerfstudio MLP layer
  *      (field_components/mlp.py:80-99): Y[N,O] = act(X[N,I] W[O,I]^T + bias).  bias may be NULL. */
 int snf_linear_fwd(const float* X, const float* W, const float* bias, int N, int I, int O, int ldx,

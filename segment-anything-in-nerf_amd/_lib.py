@@ -20,7 +20,7 @@ INCLUDE = os.path.join(ROOT, "include")
 LIB_DIR = os.path.join(PKG_DIR, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libsamnerf_hip.so")
 HASH_PATH = LIB_PATH + ".srchash"
-SOURCES = ["sampling.hip", "hashgrid.hip", "linear.hip", "mlp_chain.hip", "render.hip", "losses.hip", "optim.hip"]
+SOURCES = ["sampling.hip", "hashgrid.hip", "linear.hip", "linear_b3.hip", "mlp_chain.hip", "render.hip", "losses.hip", "optim.hip"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics"]
 
 
@@ -129,6 +129,10 @@ def load(auto_build: bool = True) -> ctypes.CDLL:
     lib.snf_version.argtypes = []
     lib.snf_last_error.restype = c_char_p
     lib.snf_last_error.argtypes = []
+    lib.snf_set_gemm_mode.restype = c_int
+    lib.snf_set_gemm_mode.argtypes = [c_int]
+    lib.snf_get_gemm_mode.restype = c_int
+    lib.snf_get_gemm_mode.argtypes = []
     lib.snf_hashgrid_bwd_workspace_bytes.restype = c_int64
     lib.snf_hashgrid_bwd_workspace_bytes.argtypes = [c_int, c_int, c_int]
     for name, argtypes in SIGNATURES.items():

@@ -324,6 +324,10 @@ extern "C" int snf_linear_fwd(const float* X, const float* W, const float* bias,
     SNF_REQUIRE(X && W && Y, "snf_linear_fwd: null pointer");
     SNF_REQUIRE(N > 0 && I > 0 && O > 0 && ldx >= I && ldy >= O, "snf_linear_fwd: bad shape N=%d I=%d O=%d", N, I, O);
     SNF_REQUIRE(act >= 0 && act <= 2, "snf_linear_fwd: bad activation %d", act);
+    if (b3_try_fwd(X, W, bias, N, I, O, ldx, ldy, act, Y, stream)) {
+        SNF_LAUNCH_CHECK("snf_linear_fwd(bf16x3)");
+        return SNF_OK;
+    }
     const int vecA = aligned16(X) && (ldx % 4 == 0) && (I % 4 == 0);
     const int vecB = aligned16(W) && (I % 4 == 0);
     dim3 grid(ceil_div(N, BM), ceil_div(O, BN));
@@ -342,6 +346,10 @@ extern "C" int snf_linear_bwd_data(const float* dY, const float* Y, const float*
     SNF_REQUIRE(dY && W && dX, "snf_linear_bwd_data: null pointer");
     SNF_REQUIRE(act == SNF_ACT_NONE || Y, "snf_linear_bwd_data: Y required for activation derivative");
     SNF_REQUIRE(N > 0 && I > 0 && O > 0 && lddy >= O && lddx >= I, "snf_linear_bwd_data: bad shape");
+    if (b3_try_bwd_data(dY, Y, W, N, I, O, lddy, ldy, lddx, act, dX, stream)) {
+        SNF_LAUNCH_CHECK("snf_linear_bwd_data(bf16x3)");
+        return SNF_OK;
+    }
     const int vecA = aligned16(dY) && (lddy % 4 == 0) && (O % 4 == 0) &&
                      (act == SNF_ACT_NONE || (aligned16(Y) && ldy % 4 == 0));
     const int vecB = aligned16(W) && (I % 4 == 0);

@@ -1,0 +1,234 @@
+// linear_b3.hip -- the 192/256-wide feature-head layers (tcnn CutlassMLP role: samnerf/sam_field.py:51-61,84-94) on the
+// bf16 matrix cores with a 3-term split, fp32 accumulate (gfx950).
+//
+// fp32 operands are split on the fly into bf16 hi + bf16 lo (x = hi + lo + O(2^-17 |x|)); a product is accumulated as
+// hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 (the lo*lo term is below fp32 round-off of the sum).  Measured
+// against an fp64 reference on head-shaped data (K = 192..256): max abs error 8e-7 at |y| ~ 0.15, i.e. 10x the error of
+// the exact-fp32 MFMA path and 100x inside the 1e-4 parity bar -- at 1/5 of the matrix-core cycles
+// (3 x 32 cycles per 16 k against 8 x 64 cycles).  snf_set_gemm_mode(0) switches the library back to exact fp32.
+//
+// Tile: 128 rows x 64 cols x 32 k per workgroup (4 waves x 32 rows x two 32x32 accumulators), operands in LDS as
+// row-major bf16 planes [row][k] with an 80-byte pitch: one conflict-free ds_read_b128 per operand fragment.
+#include "common.hpp"
+
+namespace snf {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int B3_BM = 128, B3_BN = 64, B3_BK = 32;
+constexpr int B3_PITCH = 40;  // bf16 elements per LDS row (80 B: 16-lane groups of a ds_read_b128 hit 16 distinct slots)
+
+__device__ __forceinline__ float b3_act_deriv(float y, int act) {
+    if (act == SNF_ACT_RELU) return y > 0.f ? 1.f : 0.f;
+    if (act == SNF_ACT_SIGMOID) return y * (1.f - y);
+    return 1.f;
+}
+
+__device__ __forceinline__ float b3_act_apply(float x, int act) {
+    if (act == SNF_ACT_RELU) return fmaxf(x, 0.f);
+    if (act == SNF_ACT_SIGMOID) return 1.f / (1.f + expf(-x));
+    return x;
+}
+
+// round-to-nearest-even fp32 -> bf16 bits (NaN stays NaN)
+__device__ __forceinline__ uint32_t bf16_bits(float x) {
+    uint32_t u = __float_as_uint(x);
+    if (x != x) return 0x7FC0u;
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+
+__device__ __forceinline__ void split_bf16(float x, uint32_t& hi, uint32_t& lo) {
+    hi = bf16_bits(x);
+    const float r = x - __uint_as_float(hi << 16);
+    lo = (r == r) ? bf16_bits(r) : 0u;  // inf - inf: keep the value in hi only
+}
+
+// four consecutive fp32 -> 8 bytes of hi bf16 and 8 bytes of lo bf16
+__device__ __forceinline__ void split4(const float4 v, uint2& hi, uint2& lo) {
+    uint32_t h0, h1, h2, h3, l0, l1, l2, l3;
+    split_bf16(v.x, h0, l0);
+    split_bf16(v.y, h1, l1);
+    split_bf16(v.z, h2, l2);
+    split_bf16(v.w, h3, l3);
+    hi = make_uint2(h0 | (h1 << 16), h2 | (h3 << 16));
+    lo = make_uint2(l0 | (l1 << 16), l2 | (l3 << 16));
+}
+
+template <bool DERIV>
+__device__ __forceinline__ float4 b3_load_a(const float* __restrict__ A, const float* __restrict__ Aux, int row, int k, int M,
+                                            int K, int lda, int ldaux, int act) {
+    const bool ok = (row < M) && (k < K);
+    const int rc = row < M ? row : M - 1;
+    const int kc = k < K ? k : 0;
+    float4 v = *reinterpret_cast<const float4*>(A + (size_t)rc * lda + kc);
+    if constexpr (DERIV) {
+        if (act != SNF_ACT_NONE) {
+            const float4 y = *reinterpret_cast<const float4*>(Aux + (size_t)rc * ldaux + kc);
+            v.x *= b3_act_deriv(y.x, act);
+            v.y *= b3_act_deriv(y.y, act);
+            v.z *= b3_act_deriv(y.z, act);
+            v.w *= b3_act_deriv(y.w, act);
+        }
+    }
+    if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+    return v;
+}
+
+__device__ __forceinline__ float4 b3_load_b(const float* __restrict__ B, int r, int c, int Rn, int Cn, int ldb) {
+    const bool ok = (r < Rn) && (c < Cn);
+    const int rc = r < Rn ? r : Rn - 1;
+    const int cc = c < Cn ? c : 0;
+    float4 v = *reinterpret_cast<const float4*>(B + (size_t)rc * ldb + cc);
+    if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+    return v;
+}
+
+// C[M,Nc] = op(A)[M,K] * B   (BT: B = W[Nc,K] row-major, i.e. forward;  !BT: B = W[K,Nc] row-major, i.e. data gradient)
+// Requirements (checked by the host wrapper): K % 4 == 0, Nc % 4 == 0, leading dimensions % 4 == 0, 16-byte aligned bases.
+template <bool BT, bool DERIV>
+__global__ __launch_bounds__(256) void k_gemm_rows_b3(const float* __restrict__ A, const float* __restrict__ Aux,
+                                                      const float* __restrict__ B, const float* __restrict__ bias, int M,
+                                                      int K, int Nc, int lda, int ldaux, int ldb, int ldc, int act_in,
+                                                      int act_out, float* __restrict__ C) {
+    __shared__ __attribute__((aligned(16))) uint16_t Ah[B3_BM * B3_PITCH];
+    __shared__ __attribute__((aligned(16))) uint16_t Al[B3_BM * B3_PITCH];
+    __shared__ __attribute__((aligned(16))) uint16_t Bh[B3_BN * B3_PITCH];
+    __shared__ __attribute__((aligned(16))) uint16_t Bl[B3_BN * B3_PITCH];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, half = lane >> 5;
+    const int row0 = blockIdx.x * B3_BM, col0 = blockIdx.y * B3_BN;
+    const bool two = (col0 + 32) < Nc;
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+    const int a_kq = tid & 7, a_r = tid >> 3;   // 8 k-quads x 32 rows (A: 4 passes, B^T: 2 passes)
+    const int b_jq = tid & 15, b_k = tid >> 4;  // B as [K, Nc]: 16 col-quads x 16 k, 2 passes
+    float4 av[4], bv[2];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+            av[p] = b3_load_a<DERIV>(A, Aux, row0 + a_r + 32 * p, k0 + a_kq * 4, M, K, lda, ldaux, act_in);
+        if constexpr (BT) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p) bv[p] = b3_load_b(B, col0 + a_r + 32 * p, k0 + a_kq * 4, Nc, K, ldb);
+        } else {
+#pragma unroll
+            for (int p = 0; p < 2; ++p) bv[p] = b3_load_b(B, k0 + b_k + 16 * p, col0 + b_jq * 4, K, Nc, ldb);
+        }
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < K; k0 += B3_BK) {
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            uint2 hi, lo;
+            split4(av[p], hi, lo);
+            const int off = (a_r + 32 * p) * B3_PITCH + a_kq * 4;
+            *reinterpret_cast<uint2*>(&Ah[off]) = hi;
+            *reinterpret_cast<uint2*>(&Al[off]) = lo;
+        }
+        if constexpr (BT) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                uint2 hi, lo;
+                split4(bv[p], hi, lo);
+                const int off = (a_r + 32 * p) * B3_PITCH + a_kq * 4;
+                *reinterpret_cast<uint2*>(&Bh[off]) = hi;
+                *reinterpret_cast<uint2*>(&Bl[off]) = lo;
+            }
+        } else {
+            // transpose while staging: W[k][j..j+3] -> B planes [j][k]
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int kk = b_k + 16 * p;
+                const float e[4] = {bv[p].x, bv[p].y, bv[p].z, bv[p].w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    uint32_t h, l;
+                    split_bf16(e[q], h, l);
+                    Bh[(b_jq * 4 + q) * B3_PITCH + kk] = (uint16_t)h;
+                    Bl[(b_jq * 4 + q) * B3_PITCH + kk] = (uint16_t)l;
+                }
+            }
+        }
+        __syncthreads();
+        if (k0 + B3_BK < K) fetch(k0 + B3_BK);
+#pragma unroll
+        for (int ks = 0; ks < B3_BK / 16; ++ks) {
+            const int ko = ks * 16 + half * 8;
+            const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&Ah[(wave * 32 + li) * B3_PITCH + ko]);
+            const bf16x8 al = *reinterpret_cast<const bf16x8*>(&Al[(wave * 32 + li) * B3_PITCH + ko]);
+            const bf16x8 bh0 = *reinterpret_cast<const bf16x8*>(&Bh[li * B3_PITCH + ko]);
+            const bf16x8 bl0 = *reinterpret_cast<const bf16x8*>(&Bl[li * B3_PITCH + ko]);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh0, acc0, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl0, acc0, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh0, acc0, 0, 0, 0);
+            if (two) {
+                const bf16x8 bh1 = *reinterpret_cast<const bf16x8*>(&Bh[(32 + li) * B3_PITCH + ko]);
+                const bf16x8 bl1 = *reinterpret_cast<const bf16x8*>(&Bl[(32 + li) * B3_PITCH + ko]);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh1, acc1, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl1, acc1, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh1, acc1, 0, 0, 0);
+            }
+        }
+    }
+    // epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int row = row0 + wave * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half;
+        if (row < M) {
+            const int c0 = col0 + li;
+            if (c0 < Nc) {
+                float v = acc0[reg];
+                if (bias) v += bias[c0];
+                C[(size_t)row * ldc + c0] = b3_act_apply(v, act_out);
+            }
+            const int c1 = c0 + 32;
+            if (two && c1 < Nc) {
+                float v = acc1[reg];
+                if (bias) v += bias[c1];
+                C[(size_t)row * ldc + c1] = b3_act_apply(v, act_out);
+            }
+        }
+    }
+}
+
+static int g_gemm_mode = 1;  // 1: bf16x3 for the wide layers (default), 0: exact fp32 everywhere
+
+bool b3_enabled() { return g_gemm_mode == 1; }
+
+}  // namespace snf
+
+using namespace snf;
+
+extern "C" int snf_set_gemm_mode(int mode) {
+    SNF_REQUIRE(mode == 0 || mode == 1, "snf_set_gemm_mode: mode must be 0 (fp32) or 1 (bf16x3 on wide layers)");
+    g_gemm_mode = mode;
+    return SNF_OK;
+}
+
+extern "C" int snf_get_gemm_mode(void) { return g_gemm_mode; }
+
+// called by snf_linear_fwd / snf_linear_bwd_data for wide, aligned layers; returns 1 if it took the launch
+int snf::b3_try_fwd(const float* X, const float* W, const float* bias, int N, int I, int O, int ldx, int ldy,
+                              int act, float* Y, snf_stream_t stream) {
+    if (!b3_enabled() || I < 128 || O < 64 || (I % 4) || (O % 4) || (ldx % 4) || ((uintptr_t)X & 15) || ((uintptr_t)W & 15))
+        return 0;
+    dim3 grid(ceil_div(N, B3_BM), ceil_div(O, B3_BN));
+    hipLaunchKernelGGL((k_gemm_rows_b3<true, false>), grid, dim3(256), 0, (hipStream_t)stream, X, (const float*)nullptr, W,
+                       bias, N, I, O, ldx, 0, I, ldy, SNF_ACT_NONE, act, Y);
+    return 1;
+}
+
+int snf::b3_try_bwd_data(const float* dY, const float* Y, const float* W, int N, int I, int O, int lddy, int ldy,
+                                   int lddx, int act, float* dX, snf_stream_t stream) {
+    if (!b3_enabled() || O < 128 || I < 64 || (I % 4) || (O % 4) || (lddy % 4) || ((uintptr_t)dY & 15) ||
+        ((uintptr_t)W & 15) || (act != SNF_ACT_NONE && ((ldy % 4) || ((uintptr_t)Y & 15))))
+        return 0;
+    dim3 grid(ceil_div(N, B3_BM), ceil_div(I, B3_BN));
+    hipLaunchKernelGGL((k_gemm_rows_b3<false, true>), grid, dim3(256), 0, (hipStream_t)stream, dY, Y, W,
+                       (const float*)nullptr, N, O, I, lddy, ldy, I, lddx, act, SNF_ACT_NONE, dX);
+    return 1;
+}

@@ -82,6 +82,11 @@ def _launch(name: str, *args, tag: str = "") -> None:
     _lib.check(rc, name)
 
 
+def set_gemm_mode(mode: str) -> None:
+    """'bf16x3' (default: wide layers on the bf16 matrix cores, 3-term split, fp32 accumulate) or 'fp32' (exact)."""
+    _lib.check(_L().snf_set_gemm_mode({"fp32": 0, "bf16x3": 1}[mode]), "snf_set_gemm_mode")
+
+
 def _grad_target(param: torch.Tensor) -> Tuple[torch.Tensor, bool]:
     """(buffer to accumulate into, whether autograd should get None)."""
     mg = getattr(param, "main_grad", None)

@@ -17,6 +17,15 @@ def ops():
     return m
 
 
+@pytest.fixture(autouse=True)
+def _exact_fp32_gemm():
+    """Kernel unit tests compare against fp32 torch at fp32 round-off: run the wide layers on the exact-fp32 matrix
+    cores here.  The product default (bf16 3-term split) has its own test below and is what test_model_gpu.py runs."""
+    ops().set_gemm_mode("fp32")
+    yield
+    ops().set_gemm_mode("bf16x3")
+
+
 def G(a, dtype=None):
     t = torch.from_numpy(np.ascontiguousarray(a))
     if dtype is not None:
@@ -164,6 +173,36 @@ def test_mlp64_fused_vs_torch(cfg, N):
     assert maxdiff(xg.grad[:, :in_real], xc.grad) <= 2e-5
     for a, b in zip(wg, wc):
         assert maxdiff(a.grad, b.grad) <= 1e-4 * max(1.0, float(b.grad.abs().max()))
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16x3"])
+def test_wide_layers_both_gemm_modes(mode):
+    """192/256-wide head layers: exact-fp32 MFMA vs bf16 3-term split, against an fp64 reference."""
+    gen = torch.Generator().manual_seed(21)
+    ops().set_gemm_mode(mode)
+    try:
+        for (N, I, Oo, act) in [(5000, 192, 256, "relu"), (4099, 256, 256, None), (777, 256, 192, None)]:
+            x = torch.randn((N, I), generator=gen) * 0.05
+            w = O._linear_init(Oo, I, gen)
+            gy = torch.randn((N, Oo), generator=gen)
+            xg, wg = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
+            yg = ops().linear(xg, wg, None, ops().ACT_BY_NAME[act])
+            xc, wc = x.double().requires_grad_(True), w.double().requires_grad_(True)
+            yc = torch.nn.functional.linear(xc, wc)
+            if act == "relu":
+                # pre-activations within round-off of zero may land on either side: take the ReLU mask from the
+                # kernel's own output so that the gradient check measures arithmetic, not mask flips
+                mask = (yg.detach().cpu() > 0).double()
+                assert float(((yc > 0).double() - mask).abs().sum()) <= 1e-4 * mask.numel()
+                yc = yc * mask
+            (yc * gy.double()).sum().backward()
+            tol = 2e-7 if mode == "fp32" else 3e-6
+            assert maxdiff(yg, yc) <= tol * max(1.0, float(yc.abs().max())), (mode, N, I, Oo)
+            (yg * gy.to(DEV)).sum().backward()
+            assert maxdiff(xg.grad, xc.grad) <= (5e-6 if mode == "fp32" else 3e-5), (mode, N, I, Oo)
+            assert maxdiff(wg.grad, wc.grad) <= 1e-4 * max(1.0, float(wc.grad.abs().max()))
+    finally:
+        ops().set_gemm_mode("fp32")
 
 
 def test_head_input(golden):
