@@ -74,6 +74,18 @@ class Optimizers:
         ops.adam_step_(a.param, a.grad, a.exp_avg, a.exp_avg_sq, self.lr(k), oc.betas[0], oc.betas[1], oc.eps,
                        self.step_count[k], grad_scale, zero_grad)
 
+    def optimizer_step_params(self, k: str, first: int, last: int, grad_scale: float = 1.0, zero_grad: bool = True,
+                              count_step: bool = True) -> None:
+        """Adam over the contiguous arena slice holding parameters [first, last) of group `k` (registration order)."""
+        a, oc = self.arenas[k], self.config[k]["optimizer"]
+        names = list(a.offsets)
+        lo = a.offsets[names[first]][0]
+        hi = a.offsets[names[last]][0] if last < len(names) else a.numel
+        if count_step:
+            self.step_count[k] += 1
+        ops.adam_step_(a.param[lo:hi], a.grad[lo:hi], a.exp_avg[lo:hi], a.exp_avg_sq[lo:hi], self.lr(k), oc.betas[0],
+                       oc.betas[1], oc.eps, self.step_count[k], grad_scale, zero_grad)
+
     def optimizer_step_all(self, grad_scale: float = 1.0, zero_grad: bool = True) -> None:
         for k in self.arenas:
             self.optimizer_step(k, grad_scale, zero_grad)

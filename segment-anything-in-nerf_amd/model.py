@@ -356,7 +356,7 @@ class SAMModel(NerfactoModel):
         self.text_prompt_capable = True
         self.prompts = None
         self.renderer_mean = MeanRenderer()
-        self.feature_stream = None  # set by the trainer: HIP stream for the (independent) feature branch
+        self.feature_streams = None  # set by the trainer: {head: HIP stream} for the (independent) feature heads
         c = self.config
         dev = self.kwargs.get("device", None)
         if c.distill_sam:
@@ -390,38 +390,36 @@ class SAMModel(NerfactoModel):
             for i in range(self.config.num_proposal_iterations):
                 outputs[f"prop_depth_{i}"] = self.renderer_depth(weights=weights_list[i], ray_samples=ray_samples_list[i])
         if self.config.distill_sam and len(get_feature) > 0:
-            # The feature branch reads the nerfacto branch only through detached tensors (weights, sample bins), so it is an
-            # independent task: when the trainer hands us a side stream, its forward (and, by autograd's stream rule, its
-            # backward) is enqueued there and runs beside the nerf losses / backward on the main stream.
-            fs = self.feature_stream if (self.training and weights.is_cuda) else None
-            if fs is not None:
-                fs.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(fs):
-                    self._feature_branch(ray_samples, weights, get_feature, outputs)
-            else:
-                self._feature_branch(ray_samples, weights, get_feature, outputs)
+            # The feature heads read the nerfacto branch only through detached tensors (weights, sample bins) and do not
+            # depend on each other, so each head is an independent task: when the trainer hands us side streams, a head's
+            # forward (and, by autograd's stream rule, its backward) is enqueued on its own stream and runs beside the nerf
+            # losses / backward on the main stream.
+            fs = self.feature_streams if (self.training and weights.is_cuda) else None
+            heads = [h for h in ("sam", "clipseg") if h in get_feature and (h == "sam" or self.config.use_clipseg_feature)]
+            for h in heads:
+                st = fs.get(h) if fs else None
+                if st is not None:
+                    st.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(st):
+                        self._feature_head(h, ray_samples, weights, outputs)
+                else:
+                    self._feature_head(h, ray_samples, weights, outputs)
         return outputs
 
-    def _feature_branch(self, ray_samples: RaySamples, weights, get_feature, outputs) -> None:
-        """samnerf/sam_model.py:243-277."""
-        # top-K by weight, sharpen w^T, renormalise (sam_model.py:244-248) -- one kernel
+    def _feature_head(self, head: str, ray_samples: RaySamples, weights, outputs) -> None:
+        """One head of samnerf/sam_model.py:243-277 (top-K select, SAMField head, weighted mean, conv head for 'sam')."""
+        # top-K by weight, sharpen w^T, renormalise (sam_model.py:244-248) -- one kernel (recomputed per head: trivial)
         sam_weights, best_ids = ops.topk_sharpen(weights[..., 0].detach(), self.config.num_sam_samples,
                                                  self.config.sharpening_temperature)
         sam_samples = ray_samples.gather(best_ids)
         sam_weights = sam_weights[..., None]
-        sam_field_outputs = None
-        if "sam" in get_feature:
-            sam_field_outputs = self.sam_field.get_outputs(sam_samples, get_feautre=get_feature)
-            feat_out = self.renderer_mean(embeds=sam_field_outputs["sam"], weights=sam_weights.detach())
-            if self.config.patch_size > 1:
-                p = self.config.patch_size
-                feat_out = feat_out.reshape(-1, p, p, feat_out.shape[-1]).permute(0, 3, 1, 2)
-                feat_out = self.conv_head(feat_out).mean(dim=[2, 3])
-            outputs["sam"] = feat_out
-        if "clipseg" in get_feature and self.config.use_clipseg_feature:
-            if sam_field_outputs is None:
-                sam_field_outputs = self.sam_field.get_outputs(sam_samples, get_feautre=get_feature)
-            outputs["clipseg"] = self.renderer_mean(embeds=sam_field_outputs["clipseg"], weights=sam_weights.detach())
+        field_out = self.sam_field.get_outputs(sam_samples, get_feautre=[head])
+        feat_out = self.renderer_mean(embeds=field_out[head], weights=sam_weights.detach())
+        if head == "sam" and self.config.patch_size > 1:
+            p = self.config.patch_size
+            feat_out = feat_out.reshape(-1, p, p, feat_out.shape[-1]).permute(0, 3, 1, 2)
+            feat_out = self.conv_head(feat_out).mean(dim=[2, 3])
+        outputs[head] = feat_out
 
     def _get_outputs_nerfacto(self, ray_samples: RaySamples, fast=False):
         field_outputs = self.field(ray_samples, compute_normals=self.config.predict_normals)
@@ -437,20 +435,20 @@ class SAMModel(NerfactoModel):
     def get_loss_dict(self, outputs, batch, metrics_dict=None):
         loss_dict = super().get_loss_dict(outputs, batch, metrics_dict)
         if self.training and self.config.distill_sam:
-            fs = self.feature_stream if outputs["sam"].is_cuda else None
-            if fs is not None:
-                with torch.cuda.stream(fs):  # stays on the feature branch's stream
-                    self._feature_losses(outputs, batch, loss_dict)
-            else:
-                self._feature_losses(outputs, batch, loss_dict)
+            fs = self.feature_streams if outputs["sam"].is_cuda else None
+            for head, key, wgt in (("sam", "sam_loss", self.config.sam_loss_weight),
+                                   ("clipseg", "clipseg_loss", self.config.clipseg_loss_weight)):
+                if head == "clipseg" and not self.config.use_clipseg_feature:
+                    continue
+                st = fs.get(head) if fs else None
+                if st is not None:
+                    with torch.cuda.stream(st):  # stays on the head's stream
+                        unreduced = torch.nn.functional.mse_loss(outputs[head], batch[head], reduction="none")
+                        loss_dict[key] = wgt * unreduced.mean(dim=-1).nanmean()
+                else:
+                    unreduced = torch.nn.functional.mse_loss(outputs[head], batch[head], reduction="none")
+                    loss_dict[key] = wgt * unreduced.mean(dim=-1).nanmean()
         return loss_dict
-
-    def _feature_losses(self, outputs, batch, loss_dict) -> None:
-        unreduced_sam = torch.nn.functional.mse_loss(outputs["sam"], batch["sam"], reduction="none")
-        loss_dict["sam_loss"] = self.config.sam_loss_weight * unreduced_sam.mean(dim=-1).nanmean()
-        if self.config.use_clipseg_feature:
-            unreduced = torch.nn.functional.mse_loss(outputs["clipseg"], batch["clipseg"], reduction="none")
-            loss_dict["clipseg_loss"] = self.config.clipseg_loss_weight * unreduced.mean(dim=-1).nanmean()
 
     def get_param_groups(self) -> Dict[str, List[Parameter]]:
         param_groups = super().get_param_groups()

@@ -151,48 +151,69 @@ class Trainer:
         D.broadcast_parameters([a.param for a in arenas.values()])
         self.callbacks = self.pipeline.get_training_callbacks()
 
-    # The feature branch sees the nerfacto branch only through DETACHED quantities (sample positions sam_field.py:116,
-    # sam_weights.detach() sam_model.py:260-277), so a train step is two independent tasks after the nerfacto forward:
-    #   main stream : nerf losses -> backward {fields, proposal_networks} -> gradient exchange -> Adam
-    #   side stream : feature forward -> feature losses -> backward {sam_field, conv} -> gradient exchange -> Adam (0.8 GB)
-    # Both are enqueued back to back and run concurrently on the GPU (autograd executes a node's backward on the stream of
-    # its forward); the streams are joined at the end of the step.
-    FEATURE_LOSSES = ("sam_loss", "clipseg_loss", "dino_loss")
-    FEATURE_GROUPS = ("sam_field", "conv")
+    # The feature heads see the nerfacto branch only through DETACHED quantities (sample positions sam_field.py:116,
+    # sam_weights.detach() sam_model.py:260-277) and do not see each other, so a train step is three independent tasks
+    # after the nerfacto forward:
+    #   main stream     : nerf losses -> backward {fields, proposal_networks} -> gradient exchange -> Adam
+    #   'sam' stream    : SAM head forward -> loss -> backward {sam grids, sam MLP, conv} -> exchange -> Adam (0.4 GB)
+    #   'clipseg' stream: ClipSeg head forward -> loss -> backward {clipseg grids, MLP} -> exchange -> Adam (0.4 GB)
+    # They are enqueued back to back and run concurrently on the GPU (autograd executes a node's backward on the stream
+    # of its forward); the streams are joined at the end of the step.
+    HEAD_LOSS = {"sam": "sam_loss", "clipseg": "clipseg_loss"}
+
+    def _head_param_ranges(self):
+        """{head: (first, last)} parameter index ranges inside the 'sam_field' arena (module registration order:
+        clip_encs.*, sam_net, clipseg_encs.*, clipseg_net -- samnerf/sam_field.py:38-94)."""
+        sf = self.pipeline.model.sam_field
+        n_sam = len(list(sf.clip_encs.parameters())) + len(list(sf.sam_net.parameters()))
+        n_all = len(list(sf.parameters()))
+        return {"sam": (0, n_sam), "clipseg": (n_sam, n_all)}
 
     def train_iteration(self, step: int):
         for cb in self.callbacks:
             cb.run_callback_at_location(step, BEFORE_TRAIN_ITERATION)
         opt, scale = self.optimizers, 1.0 / D.world_size()
-        feat_groups = [g for g in self.FEATURE_GROUPS if g in opt.arenas]
-        use_side = self.overlap and torch.cuda.is_available() and len(feat_groups) > 0
         model = self.pipeline.model
+        use_side = self.overlap and torch.cuda.is_available() and "sam_field" in opt.arenas
         if use_side and self._side is None:
-            self._side = torch.cuda.Stream()
-        model.feature_stream = self._side if use_side else None
+            self._side = {"sam": torch.cuda.Stream(), "clipseg": torch.cuda.Stream()}
+        if hasattr(model, "feature_streams"):
+            model.feature_streams = self._side if use_side else None
         _, loss_dict, metrics_dict = self.pipeline.get_train_loss_dict(step=step)
-        feat = [v for k, v in loss_dict.items() if k in self.FEATURE_LOSSES]
-        rest = [v for k, v in loss_dict.items() if k not in self.FEATURE_LOSSES]
-        rest_groups = [g for g in opt.arenas if g not in feat_groups]
-        if use_side and len(feat) > 0:
-            main, side = torch.cuda.current_stream(), self._side
-            loss_rest = sum(rest)
-            with torch.cuda.stream(side):
-                loss_feat = sum(feat)
+        head_losses = {h: loss_dict[k] for h, k in self.HEAD_LOSS.items() if k in loss_dict}
+        rest = [v for k, v in loss_dict.items() if k not in self.HEAD_LOSS.values()]
+        if use_side and len(head_losses) > 0:
+            main = torch.cuda.current_stream()
+            ranges = self._head_param_ranges()
+            arena = opt.arenas["sam_field"]
+            names = list(arena.offsets)
+            rest_groups = [g for g in opt.arenas if g not in ("sam_field", "conv")]
             # nerf task on the main stream
+            loss_rest = sum(rest)
             loss_rest.backward()
             D.allreduce_gradients([opt.arenas[g].grad for g in rest_groups])
             for g in rest_groups:
                 opt.optimizer_step(g, scale, True)
-            # feature task on the side stream
-            with torch.cuda.stream(side):
-                loss_feat.backward()
-                D.allreduce_gradients([opt.arenas[g].grad for g in feat_groups])
-                for g in feat_groups:
-                    opt.optimizer_step(g, scale, True)
-                loss = loss_feat.detach()
-            main.wait_stream(side)
-            loss = loss + loss_rest.detach()
+            loss = loss_rest.detach()
+            # one task per feature head on its own stream
+            first_head = True
+            for h, lv in head_losses.items():
+                st = self._side[h]
+                lo_i, hi_i = ranges[h]
+                lo = arena.offsets[names[lo_i]][0]
+                hi = arena.offsets[names[hi_i]][0] if hi_i < len(names) else arena.numel
+                with torch.cuda.stream(st):
+                    lv.backward()
+                    bufs = [arena.grad[lo:hi]] + ([opt.arenas["conv"].grad] if (h == "sam" and "conv" in opt.arenas) else [])
+                    D.allreduce_gradients(bufs)
+                    opt.optimizer_step_params("sam_field", lo_i, hi_i, scale, True, count_step=first_head)
+                    if h == "sam" and "conv" in opt.arenas:
+                        opt.optimizer_step("conv", scale, True)
+                first_head = False
+            for h in head_losses:
+                main.wait_stream(self._side[h])
+            for lv in head_losses.values():
+                loss = loss + lv.detach()
         else:
             loss = sum(loss_dict.values())
             loss.backward()
