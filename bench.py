@@ -165,8 +165,10 @@ def main():
     launches = {k: v["launches"] / n_break for k, v in breakdown.items()}
 
     def model_of(key):
-        if key == "snf_adam_step":  # all arenas of a step together
-            return "hbm", adam_bytes(trainer) / max(launches.get(key, 1.0), 1.0), "GB/s"
+        """(bound, algorithmic units per launch or None, unit).  Adam is modelled per STEP (its launches cover the
+        arenas in pieces whose number differs between the serial and the concurrent schedule)."""
+        if key == "snf_adam_step":
+            return "hbm", adam_bytes(trainer), "GB/s"
         return algorithmic_model(key, w)
 
     dom = args.roofline_kernel
@@ -196,25 +198,27 @@ def main():
     if rank == 0:
         R, S, K = w["R"], w["S"], w["K"]
         ms = elapsed / args.steps * 1e3
-        def roof(key, avg_ms, nl, where):
+        def roof(key, stat, nsteps, where):
+            """achieved = algorithmic units of all timed launches / their summed HIP-event duration."""
             bound, units, unit = model_of(key)
-            achieved = units / (avg_ms * 1e-3) / (1e9 if bound == "hbm" else 1e12)
+            nl, total_ms = stat["launches"], stat["total_ms"]
+            total_units = units * nsteps if key == "snf_adam_step" else units * nl
+            achieved = total_units / (total_ms * 1e-3) / (1e9 if bound == "hbm" else 1e12)
             peak = HBM_PEAK_GBPS if bound == "hbm" else FP32_MATRIX_PEAK_TFLOPS
             return {"kernel": key, "bound": bound, "achieved": round(achieved, 2), "peak": peak, "unit": unit,
-                    "frac": round(achieved / peak, 4), "traffic": None, "avg_launch_ms": round(avg_ms, 4),
-                    "launches_timed": nl, "algorithmic_units_per_launch": units, "measured": where}
+                    "frac": round(achieved / peak, 4), "traffic": None, "avg_launch_ms": round(total_ms / max(nl, 1), 4),
+                    "launches_timed": nl, "algorithmic_units_per_launch": total_units / max(nl, 1), "measured": where}
 
         roofline = None
         if dom is not None and dom in live:
             # contract: the dominant kernel timed live over the timed region.  The step runs three streams concurrently,
             # so this duration includes whatever shared the GPU with the kernel (a lower bound on its own roofline).
-            roofline = roof(dom, live[dom]["avg_ms"], live[dom]["launches"], "HIP events, timed region (3 concurrent streams)")
-            roofline["serial"] = roof(dom, breakdown[dom]["avg_ms"], breakdown[dom]["launches"],
-                                      "HIP events, serial replay (kernel alone on the GPU)")
+            roofline = roof(dom, live[dom], args.steps, "HIP events, timed region (3 concurrent streams)")
+            roofline["serial"] = roof(dom, breakdown[dom], n_break, "HIP events, serial replay (kernel alone on the GPU)")
         others = []
         for k in sorted(per_step, key=lambda kk: -per_step[kk]):
             if k != dom and model_of(k)[1] and len(others) < 7:
-                others.append(roof(k, breakdown[k]["avg_ms"], breakdown[k]["launches"], "HIP events, serial replay"))
+                others.append(roof(k, breakdown[k], n_break, "HIP events, serial replay"))
         # algorithmic bytes of the whole step (SURVEY.md 8d), for the step-level fraction
         feat = K * 12288 if w["method"] == "samnerf_distill" else 0
         b_step = 3 * (w["P"] * 320 + S * 1024 + feat) * R
