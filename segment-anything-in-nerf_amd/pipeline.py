@@ -5,6 +5,7 @@ The datamanager here is the SYNTHETIC one of SURVEY.md 8(d): seeded random rays 
 device.  Disk formats (transforms.json, SAM .npy, ClipSeg .pt) are a 'next' row."""
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass, field
 from typing import Any, Dict, List, Optional, Tuple, Type
 
@@ -139,7 +140,8 @@ class Trainer:
         self.local_rank, self.world_size = local_rank, world_size
         self.device = device
         self._start_step = 0
-        self.overlap = True  # feature-group exchange + Adam on a side stream under the nerf backward
+        self.overlap = True  # run the nerf / SAM-head / ClipSeg-head tasks on separate HIP streams
+        self.enqueue_order = os.environ.get("SNF_ENQUEUE_ORDER", "heads_first")
         self._side = None
 
     def setup(self, test_mode="val") -> None:
@@ -188,13 +190,19 @@ class Trainer:
             arena = opt.arenas["sam_field"]
             names = list(arena.offsets)
             rest_groups = [g for g in opt.arenas if g not in ("sam_field", "conv")]
-            # nerf task on the main stream
             loss_rest = sum(rest)
-            loss_rest.backward()
-            D.allreduce_gradients([opt.arenas[g].grad for g in rest_groups])
-            for g in rest_groups:
-                opt.optimizer_step(g, scale, True)
             loss = loss_rest.detach()
+
+            def nerf_task():  # on the main stream
+                loss_rest.backward()
+                D.allreduce_gradients([opt.arenas[g].grad for g in rest_groups])
+                for g in rest_groups:
+                    opt.optimizer_step(g, scale, True)
+
+            # host enqueue order (the GPU runs the three tasks concurrently; a task cannot start before the host has
+            # issued it): "heads_first" gets the two Adam-heavy head tasks going before the nerf backward is issued
+            if self.enqueue_order != "heads_first":
+                nerf_task()
             # one task per feature head on its own stream
             first_head = True
             for h, lv in head_losses.items():
@@ -210,6 +218,8 @@ class Trainer:
                     if h == "sam" and "conv" in opt.arenas:
                         opt.optimizer_step("conv", scale, True)
                 first_head = False
+            if self.enqueue_order == "heads_first":
+                nerf_task()
             for h in head_losses:
                 main.wait_stream(self._side[h])
             for lv in head_losses.values():
