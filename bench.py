@@ -78,6 +78,7 @@ def build_trainer(w: dict, local_rank: int, world: int, seed: int = 0):
     tcnn_compat.manual_seed(seed)
     trainer = tc.setup(local_rank=local_rank, world_size=world, device=f"cuda:{local_rank}")
     trainer.setup()
+    trainer.pipeline_steps = os.environ.get("SNF_PIPELINE_STEPS", "1") == "1"
     return trainer
 
 

@@ -400,6 +400,13 @@ class SAMModel(NerfactoModel):
                 st = fs.get(h) if fs else None
                 if st is not None:
                     st.wait_stream(torch.cuda.current_stream())
+                    # tensors produced on the main stream and read on the head's stream: tell the caching allocator, so
+                    # their memory is not recycled for main-stream work while the head task is still running (the
+                    # trainer may already be enqueueing the next step's forward)
+                    for t in (weights, ray_samples.euclid_bins, ray_samples.spacing_bins, ray_samples.ray_bundle.origins,
+                              ray_samples.ray_bundle.directions):
+                        if t is not None:
+                            t.record_stream(st)
                     with torch.cuda.stream(st):
                         self._feature_head(h, ray_samples, weights, outputs)
                 else:
@@ -442,6 +449,7 @@ class SAMModel(NerfactoModel):
                     continue
                 st = fs.get(head) if fs else None
                 if st is not None:
+                    batch[head].record_stream(st)
                     with torch.cuda.stream(st):  # stays on the head's stream
                         unreduced = torch.nn.functional.mse_loss(outputs[head], batch[head], reduction="none")
                         loss_dict[key] = wgt * unreduced.mean(dim=-1).nanmean()

@@ -142,6 +142,7 @@ class Trainer:
         self._start_step = 0
         self.overlap = True  # run the nerf / SAM-head / ClipSeg-head tasks on separate HIP streams
         self.enqueue_order = os.environ.get("SNF_ENQUEUE_ORDER", "heads_first")
+        self.pipeline_steps = False  # True: do not join the head streams at the end of a step (see train_iteration)
         self._side = None
 
     def setup(self, test_mode="val") -> None:
@@ -220,10 +221,17 @@ class Trainer:
                 first_head = False
             if self.enqueue_order == "heads_first":
                 nerf_task()
-            for h in head_losses:
-                main.wait_stream(self._side[h])
-            for lv in head_losses.values():
-                loss = loss + lv.detach()
+            if self.pipeline_steps:
+                # no join: the next step's nerfacto forward/backward (main stream) may run under the tails of this step's
+                # head tasks.  Nothing is stale -- every parameter group is read and updated on one stream only -- it just
+                # removes a false dependency.  `loss` then covers the main-stream terms; call synchronize() before
+                # reading head losses on the host.
+                pass
+            else:
+                for h in head_losses:
+                    main.wait_stream(self._side[h])
+                for lv in head_losses.values():
+                    loss = loss + lv.detach()
         else:
             loss = sum(loss_dict.values())
             loss.backward()
@@ -235,8 +243,16 @@ class Trainer:
             cb.run_callback_at_location(step, AFTER_TRAIN_ITERATION)
         return loss, loss_dict, metrics_dict
 
+    def synchronize(self) -> None:
+        """Join the task streams (needed before reading results of the head tasks when pipeline_steps is on)."""
+        if self._side is not None and torch.cuda.is_available():
+            main = torch.cuda.current_stream()
+            for st in self._side.values():
+                main.wait_stream(st)
+
     def save_checkpoint(self, path: str, step: int) -> None:
         """trainer.py:379-406: {step, pipeline state_dict, optimizers}."""
+        self.synchronize()
         torch.save({"step": step, "pipeline": self.pipeline.state_dict(), "optimizers": self.optimizers.state_dict()}, path)
 
     def load_checkpoint(self, path: str) -> int:
