@@ -608,3 +608,48 @@ def synthetic_batch(cfg: PathConfig, num_rays: int, seed: int = 1) -> Dict[str, 
         if cfg.use_clipseg:
             b["clipseg"] = torch.randn((num_rays, cfg.clipseg_dim), generator=gen)
     return b
+
+
+# --------------------------------------------------------------------------------------------
+# patch-render eval path   samnerf/sam_model.py:337-419, samnerf/sam_utils.py:7-14
+# --------------------------------------------------------------------------------------------
+def get_feature_size(h: int, w: int, largesize: int = 64):
+    """samnerf/sam_utils.py:7-14 (the reference leaves h == w undefined; square images map to largesize x largesize)."""
+    if h < w:
+        return int(math.ceil((h / w) * largesize)), largesize
+    if h > w:
+        return largesize, int(math.ceil((w / h) * largesize))
+    return largesize, largesize
+
+
+def render_camera(params, cfg: PathConfig, origins: torch.Tensor, directions: torch.Tensor, chunk: int = 1 << 15):
+    """get_outputs_for_camera_ray_bundle passes 1-3 (eval mode, no grad): origins/directions [H,W,3] ->
+    rgb/depth/accumulation [H,W,*], sam [fh,fw,256], clipseg [32,32,192]."""
+    H, W = origins.shape[:2]
+    out: Dict[str, torch.Tensor] = {}
+    with torch.no_grad():
+        o, d = origins.reshape(-1, 3), directions.reshape(-1, 3)
+        parts = [forward(params, cfg, o[i:i + chunk], d[i:i + chunk], False, get_feature=()) for i in range(0, H * W, chunk)]
+        for k in ("rgb", "depth", "accumulation", "prop_depth_0"):
+            out[k] = torch.cat([p[k] for p in parts]).view(H, W, -1)
+        if cfg.distill_sam:
+            fh, fw = get_feature_size(H, W)
+            p = cfg.patch_size
+            chunk = max(p * p, chunk - chunk % (p * p))  # whole patches per chunk (the reference's 1<<15 already is)
+            hi = torch.linspace(0, H - 1, fh * p, dtype=torch.long)
+            wi = torch.linspace(0, W - 1, fw * p, dtype=torch.long)
+            hind, wind = torch.meshgrid(hi, wi, indexing="ij")
+            fo = origins[hind.flatten(), wind.flatten()].reshape(fh, p, fw, p, 3).transpose(1, 2).reshape(-1, 3)
+            fd = directions[hind.flatten(), wind.flatten()].reshape(fh, p, fw, p, 3).transpose(1, 2).reshape(-1, 3)
+            parts = [forward(params, cfg, fo[i:i + chunk], fd[i:i + chunk], False, get_feature=("sam",))["sam"]
+                     for i in range(0, fo.shape[0], chunk)]
+            out["sam"] = torch.cat(parts).view(fh, fw, -1)
+            if cfg.use_clipseg:
+                hi = torch.linspace(0, H - 1, 32, dtype=torch.long)
+                wi = torch.linspace(0, W - 1, 32, dtype=torch.long)
+                hind, wind = torch.meshgrid(hi, wi, indexing="ij")
+                co, cd = origins[hind.flatten(), wind.flatten()], directions[hind.flatten(), wind.flatten()]
+                parts = [forward(params, cfg, co[i:i + chunk], cd[i:i + chunk], False, get_feature=("clipseg",))["clipseg"]
+                         for i in range(0, co.shape[0], chunk)]
+                out["clipseg"] = torch.cat(parts).view(32, 32, -1)
+    return out

@@ -458,6 +458,68 @@ class SAMModel(NerfactoModel):
                     loss_dict[key] = wgt * unreduced.mean(dim=-1).nanmean()
         return loss_dict
 
+    @torch.no_grad()
+    def get_outputs_for_camera_ray_bundle(self, camera_ray_bundle: RayBundle, points=None, intrin=None, c2w=None,
+                                          text_prompt=None, topk=5, thresh=0.5, fast=False) -> Dict[str, torch.Tensor]:
+        """samnerf/sam_model.py:337-419, passes 1-3: full-image render in chunks, the SAM feature map from a
+        linspace-subsampled [fh*p, fw*p] ray grid regrouped into p x p patches, the 32 x 32 ClipSeg map.  Prompt encoding and
+        mask decoding (sam_model.py:420-548) belong to the perception models outside this path: `points` / `text_prompt`
+        are accepted and ignored here; the caller feeds outputs['sam'] to SamPredictor.set_feature."""
+        num_rays_per_chunk = self.config.eval_num_rays_per_chunk
+        image_height, image_width = camera_ray_bundle.origins.shape[:2]
+        num_rays = len(camera_ray_bundle)
+        outputs_lists: Dict[str, List[torch.Tensor]] = {}
+
+        def run(bundle, **kw):
+            n = len(bundle)
+            for i in range(0, n, num_rays_per_chunk):
+                rb = bundle.get_row_major_sliced_ray_bundle(i, i + num_rays_per_chunk)
+                rb.nears, rb.fars = None, None
+                for name, out in self.forward(ray_bundle=rb, **kw).items():
+                    if torch.is_tensor(out):
+                        outputs_lists.setdefault(name, []).append(out)
+
+        run(camera_ray_bundle, get_feature=[], fast=fast)
+        sz = camera_ray_bundle.shape
+        feature_h = feature_w = feature_h_clipseg = feature_w_clipseg = None
+        if self.config.distill_sam:
+            from .sam_utils import get_feature_size
+            feature_h, feature_w = get_feature_size(image_height, image_width)
+            p = self.config.patch_size
+            dev = camera_ray_bundle.origins.device
+            h_indices = torch.linspace(0, sz[0] - 1, feature_h * p, dtype=torch.long, device=dev)
+            w_indices = torch.linspace(0, sz[1] - 1, feature_w * p, dtype=torch.long, device=dev)
+            hind, wind = torch.meshgrid(h_indices, w_indices, indexing="ij")
+            fb = camera_ray_bundle[hind.flatten(), wind.flatten()]
+            fb = fb.reshape((feature_h, p, feature_w, p))._apply_fn_to_fields(lambda x: x.transpose(1, 2))
+            saved = {k: outputs_lists.pop(k) for k in list(outputs_lists)}
+            run(fb, get_feature=["sam"])
+            sam_list = outputs_lists.get("sam", [])
+            outputs_lists.clear()
+            outputs_lists.update(saved)
+            outputs_lists["sam"] = sam_list
+            if self.config.use_clipseg_feature:
+                feature_h_clipseg, feature_w_clipseg = 32, 32
+                h_indices = torch.linspace(0, sz[0] - 1, feature_h_clipseg, dtype=torch.long, device=dev)
+                w_indices = torch.linspace(0, sz[1] - 1, feature_w_clipseg, dtype=torch.long, device=dev)
+                hind, wind = torch.meshgrid(h_indices, w_indices, indexing="ij")
+                cb = camera_ray_bundle[hind.flatten(), wind.flatten()].reshape((feature_h_clipseg, feature_w_clipseg))
+                saved = {k: outputs_lists.pop(k) for k in list(outputs_lists)}
+                run(cb, get_feature=["clipseg"])
+                clip_list = outputs_lists.get("clipseg", [])
+                outputs_lists.clear()
+                outputs_lists.update(saved)
+                outputs_lists["clipseg"] = clip_list
+        outputs = {}
+        for name, lst in outputs_lists.items():
+            if name == "sam":
+                outputs[name] = torch.cat(lst).view(feature_h, feature_w, -1)
+            elif name == "clipseg":
+                outputs[name] = torch.cat(lst).view(feature_h_clipseg, feature_w_clipseg, -1)
+            else:
+                outputs[name] = torch.cat(lst).view(image_height, image_width, -1)
+        return outputs
+
     def get_param_groups(self) -> Dict[str, List[Parameter]]:
         param_groups = super().get_param_groups()
         if self.config.distill_sam:

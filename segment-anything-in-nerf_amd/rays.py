@@ -48,6 +48,13 @@ class RayBundle:
     def __getitem__(self, idx) -> "RayBundle":
         return self._map(lambda t: t[idx])
 
+    def reshape(self, new_shape) -> "RayBundle":
+        return self._map(lambda t: t.reshape(*new_shape, t.shape[-1]))
+
+    def _apply_fn_to_fields(self, fn, dataclass_fn=None) -> "RayBundle":
+        """tensor_dataclass._apply_fn_to_fields (nerfstudio/utils/tensor_dataclass.py:259-320) for the tensor fields."""
+        return self._map(fn)
+
     def get_row_major_sliced_ray_bundle(self, start_idx: int, end_idx: int) -> "RayBundle":
         return self.flatten()[start_idx:end_idx]
 

@@ -153,3 +153,30 @@ def test_train_iterations_reduce_loss():
     assert last < first
     for a in trainer.optimizers.arenas.values():
         assert float(a.grad.abs().max()) == 0.0  # re-zeroed by the fused Adam pass
+
+
+def test_patch_render_eval_path_vs_oracle():
+    """SURVEY 8f rank 1 (samnerf/sam_model.py:337-419): full-image render + SAM / ClipSeg feature maps, eval mode."""
+    from samnerf_amd.interop import load_named_params
+    from samnerf_amd.rays import RayBundle
+    H, W, P, S, K, patch, T = 24, 40, 64, 32, 16, 4, 12
+    cfg = O.PathConfig(num_proposal_samples=P, num_nerf_samples=S, num_sam_samples=K, patch_size=patch).small(T)
+    params = O.init_params(cfg, seed=5, table_scale=0.05)
+    o, d = O.synthetic_rays(H * W, 9)
+    o, d = o.view(H, W, 3), d.view(H, W, 3)
+    ref = O.render_camera(params, cfg, o, d, chunk=512)
+    model = build_model(P, S, K, patch, T)
+    model.config.eval_num_rays_per_chunk = 512
+    load_named_params(model, params)
+    model.eval()
+    cam = RayBundle(origins=o.cuda(), directions=d.cuda(), pixel_area=torch.full((H, W, 1), 1e-6, device="cuda"),
+                    camera_indices=torch.zeros((H, W, 1), dtype=torch.long, device="cuda"))
+    out = model.get_outputs_for_camera_ray_bundle(cam)
+    fh, fw = O.get_feature_size(H, W)
+    assert out["rgb"].shape == (H, W, 3) and out["sam"].shape == (fh, fw, 256) and out["clipseg"].shape == (32, 32, 192)
+    assert md(out["rgb"], ref["rgb"]) <= TOL
+    assert md(out["accumulation"], ref["accumulation"]) <= TOL
+    assert md(out["sam"], ref["sam"]) <= TOL
+    assert md(out["clipseg"], ref["clipseg"]) <= TOL
+    rel = (out["depth"].cpu() - ref["depth"]).abs() / ref["depth"].abs()
+    assert float(rel.max()) <= 1e-4
