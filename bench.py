@@ -137,6 +137,9 @@ def main():
     rank, local_rank, world = D.init_distributed()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local_rank)
+    if os.environ.get("SNF_ADAM_LAUNCH"):  # tuning: "max_blocks,threads,unroll"
+        from samnerf_amd import _lib
+        assert _lib.load().snf_set_adam_launch(*(int(x) for x in os.environ["SNF_ADAM_LAUNCH"].split(","))) == 0
     trainer = build_trainer(w, local_rank, world)
 
     def barrier():
@@ -210,11 +213,22 @@ def main():
                     "frac": round(achieved / peak, 4), "traffic": None, "avg_launch_ms": round(total_ms / max(nl, 1), 4),
                     "launches_timed": nl, "algorithmic_units_per_launch": total_units / max(nl, 1), "measured": where}
 
+        def pmc_traffic(key):
+            """HBM bytes per launch from the committed PMC passes (profiles/pmc_traffic.json, made by tools/gpu_record.sh +
+            tools/pmc_traffic.py from `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this same command)."""
+            try:
+                t = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            except OSError:
+                return None
+            return t["traffic_bytes_per_launch"] if t["workload"] == args.workload and t["kernel"] == key and world == 1 else None
+
         roofline = None
         if dom is not None and dom in live:
             # contract: the dominant kernel timed live over the timed region.  The step runs three streams concurrently,
             # so this duration includes whatever shared the GPU with the kernel (a lower bound on its own roofline).
             roofline = roof(dom, live[dom], args.steps, "HIP events, timed region (3 concurrent streams)")
+            roofline["traffic"] = pmc_traffic(dom)
+            roofline["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 PMC passes, per launch)" if roofline["traffic"] else None
             roofline["serial"] = roof(dom, breakdown[dom], n_break, "HIP events, serial replay (kernel alone on the GPU)")
         others = []
         for k in sorted(per_step, key=lambda kk: -per_step[kk]):

@@ -192,6 +192,10 @@ int snf_distortion(const float* sbins, const float* w, int R, int S, float grad_
 int snf_adam_step(float* p, float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                   float eps, int step, float grad_scale, int zero_grad, snf_stream_t stream);
 
+/* Tuning hook: launch shape of the Adam kernel (grid cap, threads per block in {64,128,256}, independent 16-byte groups
+ * per thread in {1,2,4}).  Process-wide; the default is the measured best for MI355X. */
+int snf_set_adam_launch(int max_blocks, int threads, int unroll);
+
 /* Counter-based deterministic fill: x[i] = lo + (hi-lo)*U(seed,i); identical to the CPU restatement in
  * the package (used to initialise full-size tables without shipping them). */
 int snf_fill_uniform(float* x, int64_t n, uint64_t seed, float lo, float hi, snf_stream_t stream);

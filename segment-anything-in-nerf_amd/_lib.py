@@ -106,6 +106,7 @@ SIGNATURES = {
     "snf_interlevel": [P, P, P, P, I, I, I, F, P, P, P],
     "snf_distortion": [P, P, I, I, F, P, P, P],
     "snf_adam_step": [P, P, P, P, c_int64, F, F, F, F, I, F, I, P],
+    "snf_set_adam_launch": [I, I, I],
     "snf_fill_uniform": [P, c_int64, c_uint64, F, F, P],
 }
 

@@ -38,6 +38,7 @@ __device__ __forceinline__ void stnt(T* p, T v) { __builtin_nontemporal_store(v,
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 
+template <int U>
 __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                               float* __restrict__ v, long long n, float b1, float b2, float step_size,
                                               float inv_sqrt_bc2, float eps, float gs, int zero_grad) {
@@ -49,22 +50,28 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, float* __re
     f4* v4 = reinterpret_cast<f4*>(v);
     const f4 zero = {0.f, 0.f, 0.f, 0.f};
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    for (; i + stride < n4; i += 2 * stride) {
-        const long long j = i + stride;
-        f4 P0 = ldnt(p4 + i), G0 = ldnt(g4 + i), M0 = ldnt(m4 + i), V0 = ldnt(v4 + i);
-        f4 P1 = ldnt(p4 + j), G1 = ldnt(g4 + j), M1 = ldnt(m4 + j), V1 = ldnt(v4 + j);
+    for (; i + (U - 1) * stride < n4; i += U * stride) {
+        f4 P[U], G[U], M[U], V[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long long j = i + u * stride;
+            P[u] = ldnt(p4 + j); G[u] = ldnt(g4 + j); M[u] = ldnt(m4 + j); V[u] = ldnt(v4 + j);
+        }
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            float a = P0[c], bg = G0[c], cm = M0[c], dv = V0[c];
-            adam1(a, bg, cm, dv, gs, b1, b2, step_size, inv_sqrt_bc2, eps);
-            P0[c] = a; M0[c] = cm; V0[c] = dv;
-            a = P1[c]; bg = G1[c]; cm = M1[c]; dv = V1[c];
-            adam1(a, bg, cm, dv, gs, b1, b2, step_size, inv_sqrt_bc2, eps);
-            P1[c] = a; M1[c] = cm; V1[c] = dv;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                float a = P[u][c], bg = G[u][c], cm = M[u][c], dv = V[u][c];
+                adam1(a, bg, cm, dv, gs, b1, b2, step_size, inv_sqrt_bc2, eps);
+                P[u][c] = a; M[u][c] = cm; V[u][c] = dv;
+            }
         }
-        stnt(p4 + i, P0); stnt(m4 + i, M0); stnt(v4 + i, V0);
-        stnt(p4 + j, P1); stnt(m4 + j, M1); stnt(v4 + j, V1);
-        if (zero_grad) { stnt(g4 + i, zero); stnt(g4 + j, zero); }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long long j = i + u * stride;
+            stnt(p4 + j, P[u]); stnt(m4 + j, M[u]); stnt(v4 + j, V[u]);
+            if (zero_grad) stnt(g4 + j, zero);
+        }
     }
     for (; i < n4; i += stride) {
         f4 P0 = ldnt(p4 + i), G0 = ldnt(g4 + i), M0 = ldnt(m4 + i), V0 = ldnt(v4 + i);
@@ -84,6 +91,9 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, float* __re
         if (zero_grad) g[t] = 0.f;
     }
 }
+
+// launch shape of k_adam: {max blocks, threads per block, unroll}; snf_set_adam_launch overrides (tuning hook)
+static int g_adam_launch[3] = {2048, 256, 2};
 
 __global__ __launch_bounds__(256) void k_fill_uniform(float* __restrict__ x, long long n, unsigned long long seed, float lo,
                                                       float hi) {
@@ -116,12 +126,23 @@ extern "C" int snf_adam_step(float* p, float* g, float* m, float* v, int64_t n, 
     const double bc2 = 1.0 - pow((double)beta2, (double)step);
     const float step_size = (float)((double)lr / bc1);
     const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
-    long long blocks = (n / 4 + 255) / 256;
-    if (blocks > 256 * 8) blocks = 256 * 8;
+    const int threads = g_adam_launch[1], U = g_adam_launch[2];
+    long long blocks = (n / 4 + threads - 1) / threads;
+    if (blocks > g_adam_launch[0]) blocks = g_adam_launch[0];
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(k_adam, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long long)n, beta1,
-                       beta2, step_size, inv_sqrt_bc2, eps, grad_scale, zero_grad);
+#define SNF_ADAM_LAUNCH(UU)                                                                                             \
+    hipLaunchKernelGGL(k_adam<UU>, dim3((unsigned)blocks), dim3(threads), 0, (hipStream_t)stream, p, g, m, v, (long long)n, \
+                       beta1, beta2, step_size, inv_sqrt_bc2, eps, grad_scale, zero_grad)
+    if (U == 1) SNF_ADAM_LAUNCH(1); else if (U == 4) SNF_ADAM_LAUNCH(4); else SNF_ADAM_LAUNCH(2);
+#undef SNF_ADAM_LAUNCH
     SNF_LAUNCH_CHECK("snf_adam_step");
+    return SNF_OK;
+}
+
+extern "C" int snf_set_adam_launch(int max_blocks, int threads, int unroll) {
+    SNF_REQUIRE(max_blocks >= 1 && (threads == 64 || threads == 128 || threads == 256) && (unroll == 1 || unroll == 2 || unroll == 4),
+                "snf_set_adam_launch: max_blocks >= 1, threads in {64,128,256}, unroll in {1,2,4}");
+    g_adam_launch[0] = max_blocks; g_adam_launch[1] = threads; g_adam_launch[2] = unroll;
     return SNF_OK;
 }
 

@@ -62,9 +62,19 @@ def kernel_timing_summary() -> dict:
     torch.cuda.synchronize()
     out = {}
     for name, evs in _TIMING["events"].items():
-        tot = sum(a.elapsed_time(b) for a, b in evs)
+        tot = sum(e[0].elapsed_time(e[1]) for e in evs)
         out[name] = {"launches": len(evs), "total_ms": tot, "avg_ms": tot / max(len(evs), 1)}
     return out
+
+
+def kernel_timeline(base_event) -> list:
+    """-> [(start_ms, end_ms, stream_id, key)] relative to `base_event` for every timed launch (synchronises)."""
+    torch.cuda.synchronize()
+    out = []
+    for key, evs in _TIMING["events"].items():
+        for a, b, sid in evs:
+            out.append((base_event.elapsed_time(a), base_event.elapsed_time(b), sid, key))
+    return sorted(out)
 
 
 def _launch(name: str, *args, tag: str = "") -> None:
@@ -76,7 +86,7 @@ def _launch(name: str, *args, tag: str = "") -> None:
         a.record()
         rc = fn(*args)
         b.record()
-        _TIMING["events"].setdefault(key, []).append((a, b))
+        _TIMING["events"].setdefault(key, []).append((a, b, torch.cuda.current_stream().stream_id))
     else:
         rc = fn(*args)
     _lib.check(rc, name)

@@ -1,5 +1,6 @@
 import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+src=open(sys.argv[1]).read() if len(sys.argv)>1 else sys.stdin.read()
+d=json.loads(src.strip().splitlines()[-1])
 print("ms/step", round(d["ms_per_step"],3), "value %.3e"%d["value"], "serial C-ABI kernel sum", d.get("serial_step_ms"))
 print("  roofline:", {k:v for k,v in d["roofline"].items() if k!="serial"})
 print("  serial  :", d["roofline"].get("serial"))

@@ -25,8 +25,13 @@ def run(N, L, F, T, mn, mx, ld, clustered):
     s = ops.kernel_timing_summary()
     return {k: round(v["avg_ms"], 4) for k, v in s.items()}
 
-for dbg in os.environ.get("DBGS", "0").split(","):
-    os.environ["SNF_HG_LONG"] = dbg
-    print("dbg", dbg, "F8 uniform  ", run(65536, 12, 8, 19, 128, 512, 96, False))
-    print("dbg", dbg, "F8 clustered", run(65536, 12, 8, 19, 16, 128, 96, True))
-    print("dbg", dbg, "F2 field    ", run(524288, 16, 2, 19, 16, 2048, 32, True))
+CASES = {"f8u": ("F8 uniform  ", (65536, 12, 8, 19, 128, 512, 96, False)),
+         "f8c": ("F8 clustered", (65536, 12, 8, 19, 16, 128, 96, True)),
+         "f2": ("F2 field    ", (524288, 16, 2, 19, 16, 2048, 32, True)),
+         "f2p": ("F2 proposal ", (262144, 5, 2, 17, 16, 128, 10, True))}
+for r in (16, 32, 64, 128, 256, 512, 1024, 2048):
+    CASES[f"f2r{r}"] = (f"F2 L2 res {r}", (524288, 2, 2, 19, r, r, 4, True))
+    CASES[f"f8r{r}"] = (f"F8 L2 res {r}", (65536, 2, 8, 19, r, r, 16, True))
+if True:
+  for c in os.environ.get("CASES", "f8u,f8c,f2").split(","):
+    print("  ", CASES[c][0], run(*CASES[c][1]))
