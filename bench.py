@@ -50,8 +50,12 @@ def algorithmic_model(key: str, w: dict):
         n = R * K if F == 8 else (R * P if L == 5 else R * S)
         return "hbm", float(n * L * 8 * F * 4 * rw), "GB/s"
     if name.startswith("snf_linear"):
-        i, o = (int(x) for x in tag.split("x"))
-        n = R * K if max(i, o) >= 192 else R * S
+        pm = tag.endswith("pm")  # conv head: second convolution, on the patch means
+        i, o = (int(x) for x in tag.rstrip("pm").split("x"))
+        if i >= 1024:  # conv head as GEMMs: first convolution on every ray row, second on the patch means
+            n = R // (w["patch"] ** 2) if pm else R
+        else:
+            n = R * K if max(i, o) >= 192 else R * S
         return "mfma", 2.0 * n * i * o, "TFLOP/s"
     if name.startswith("snf_mlp64"):
         dims = [int(x) for x in tag.split("x")]

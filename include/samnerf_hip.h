@@ -92,6 +92,13 @@ int snf_get_gemm_mode(void);
  *      (field_components/mlp.py:80-99): Y[N,O] = act(X[N,I] W[O,I]^T + bias).  bias may be NULL. */
 int snf_linear_fwd(const float* X, const float* W, const float* bias, int N, int I, int O, int ldx,
                    int ldy, int act, float* Y, snf_stream_t stream);
+/* The same layer with a caller-provided scratch buffer: when the 128 x 64 output tiles of a long-K layer do not fill the
+ * chip (the conv head's [4096 | 256, 2304] x [2304, 256] GEMMs) the k range is split over workgroups and the partial
+ * products are summed, biased and activated by a second small kernel.  snf_linear_fwd_workspace_bytes returns the scratch
+ * size this shape wants (0: no split; workspace may then be NULL and the call equals snf_linear_fwd). */
+int64_t snf_linear_fwd_workspace_bytes(int N, int I, int O);
+int snf_linear_fwd_ws(const float* X, const float* W, const float* bias, int N, int I, int O, int ldx, int ldy, int act,
+                      float* Y, void* workspace, int64_t workspace_bytes, snf_stream_t stream);
 /* dX[N,I] = (dY * act'(Y)) W ;  Y is the layer OUTPUT (post-activation), may be NULL when act == NONE. */
 int snf_linear_bwd_data(const float* dY, const float* Y, const float* W, int N, int I, int O, int lddy,
                         int ldy, int lddx, int act, float* dX, snf_stream_t stream);
@@ -99,6 +106,20 @@ int snf_linear_bwd_data(const float* dY, const float* Y, const float* W, int N, 
  * into caller-zeroed (or running) buffers. */
 int snf_linear_bwd_weight(const float* dY, const float* Y, const float* X, int N, int I, int O, int lddy,
                           int ldy, int ldx, int act, float* dW, float* dbias, snf_stream_t stream);
+
+/* ---- a16: the SAM conv head (samnerf/sam_model.py:196-200,259-264: Conv2d(C,C,k,padding=k/2) -> ReLU -> Conv2d -> mean over
+ *      the p x p patch) as GEMMs.  Features stay channel-last [R, C], row = patch*p*p + y*p + x (MeanRenderer's layout).
+ *   unfold      : col[row, c*k*k + t] = x[patch, y+dy_t, x+dx_t, c] (0 outside the patch), t = ky*k + kx -- the column
+ *                 order of Conv2d.weight [O, C, k, k] viewed as [O, C*k*k], so  conv(x) = snf_linear_fwd(col, W, bias).
+ *   fold        : adjoint of unfold (dcol [R, C*k*k] -> dx [R, C]).
+ *   unfold_mean : cm[patch, c*k*k + t] = mean over the patch rows of unfold(h): the patch mean moved in front of the
+ *                 second convolution's GEMM (both linear), so that GEMM runs on R/p^2 rows.
+ *   fold_mean   : adjoint of unfold_mean (dcm [R/p^2, C*k*k] -> dh [R, C]).
+ * R must be a multiple of p*p; p <= 8, k odd <= 5. */
+int snf_patch_unfold(const float* x, int R, int p, int C, int k, float* col, snf_stream_t stream);
+int snf_patch_fold(const float* dcol, int R, int p, int C, int k, float* dx, snf_stream_t stream);
+int snf_patch_unfold_mean(const float* h, int R, int p, int C, int k, float* cm, snf_stream_t stream);
+int snf_patch_fold_mean(const float* dcm, int R, int p, int C, int k, float* dh, snf_stream_t stream);
 
 /* ---- a7, fused: a whole 64-wide tiny MLP (tcnn FullyFusedMLP: nerfstudio/fields/nerfacto_field.py:157-175,228-240)
  *      in one launch, activations in registers.  Layers: W0 [64, in_real] (in_real <= 32), W1 [64,64] (n_hidden == 2

@@ -20,7 +20,7 @@ INCLUDE = os.path.join(ROOT, "include")
 LIB_DIR = os.path.join(PKG_DIR, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libsamnerf_hip.so")
 HASH_PATH = LIB_PATH + ".srchash"
-SOURCES = ["sampling.hip", "hashgrid.hip", "linear.hip", "linear_b3.hip", "mlp_chain.hip", "render.hip", "losses.hip", "optim.hip"]
+SOURCES = ["sampling.hip", "hashgrid.hip", "linear.hip", "linear_b3.hip", "mlp_chain.hip", "patchconv.hip", "render.hip", "losses.hip", "optim.hip"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics"]
 
 
@@ -88,6 +88,7 @@ SIGNATURES = {
     "snf_hashgrid_bwd": [P, P, P, I, I, I, I, I, I, P, P],
     "snf_hashgrid_bwd_sorted": [P, P, P, I, I, I, I, I, I, P, P, c_int64, P],
     "snf_linear_fwd": [P, P, P, I, I, I, I, I, I, P, P],
+    "snf_linear_fwd_ws": [P, P, P, I, I, I, I, I, I, P, P, c_int64, P],
     "snf_linear_bwd_data": [P, P, P, I, I, I, I, I, I, I, P, P],
     "snf_linear_bwd_weight": [P, P, P, I, I, I, I, I, I, I, P, P, P],
     "snf_mlp64_fwd": [P, I, P, I, P, P, I, I, I, c_int64, P, P, P, I, P],
@@ -107,6 +108,10 @@ SIGNATURES = {
     "snf_distortion": [P, P, I, I, F, P, P, P],
     "snf_adam_step": [P, P, P, P, c_int64, F, F, F, F, I, F, I, P],
     "snf_set_adam_launch": [I, I, I],
+    "snf_patch_unfold": [P, I, I, I, I, P, P],
+    "snf_patch_fold": [P, I, I, I, I, P, P],
+    "snf_patch_unfold_mean": [P, I, I, I, I, P, P],
+    "snf_patch_fold_mean": [P, I, I, I, I, P, P],
     "snf_fill_uniform": [P, c_int64, c_uint64, F, F, P],
 }
 
@@ -136,6 +141,8 @@ def load(auto_build: bool = True) -> ctypes.CDLL:
     lib.snf_get_gemm_mode.argtypes = []
     lib.snf_hashgrid_bwd_workspace_bytes.restype = c_int64
     lib.snf_hashgrid_bwd_workspace_bytes.argtypes = [c_int, c_int, c_int]
+    lib.snf_linear_fwd_workspace_bytes.restype = c_int64
+    lib.snf_linear_fwd_workspace_bytes.argtypes = [c_int, c_int, c_int]
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
         fn.restype = c_int

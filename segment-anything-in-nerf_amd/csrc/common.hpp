@@ -91,6 +91,8 @@ inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
 // linear_b3.hip: bf16x3 path of the wide layers; return 1 when they launched the layer
 int b3_try_fwd(const float* X, const float* W, const float* bias, int N, int I, int O, int ldx, int ldy, int act, float* Y,
                snf_stream_t stream);
+int b3_try_fwd_splitk(const float* X, const float* W, int N, int I, int O, int ldx, int ksplit, int splits, float* P,
+                      snf_stream_t stream);
 int b3_try_bwd_data(const float* dY, const float* Y, const float* W, int N, int I, int O, int lddy, int ldy, int lddx,
                     int act, float* dX, snf_stream_t stream);
 

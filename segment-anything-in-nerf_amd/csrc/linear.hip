@@ -129,9 +129,17 @@ template <bool BT, bool DERIV, bool VEC>
 __global__ __launch_bounds__(256) void k_gemm_rows(const float* __restrict__ A, const float* __restrict__ Aux,
                                                    const float* __restrict__ B, const float* __restrict__ bias, int M,
                                                    int K, int Nc, int lda, int ldaux, int ldb, int ldc, int act_in,
-                                                   int act_out, int vecA, int vecB, float* __restrict__ C) {
+                                                   int act_out, int vecA, int vecB, float* __restrict__ C, int ksplit = 0,
+                                                   long long c_split_stride = 0) {
     __shared__ float As[BK * LDA_S];
     __shared__ float Bs[BK * LDB_S];
+    if constexpr (BT && !DERIV) {
+        if (ksplit > 0) {  // split-K slice z: a GEMM on the k-range [z*ksplit, ...) into the z-th partial buffer
+            const int kb = blockIdx.z * ksplit;
+            A += kb; B += kb; K = min(ksplit, K - kb);
+            C += (size_t)blockIdx.z * c_split_stride;
+        }
+    }
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -338,6 +346,64 @@ extern "C" int snf_linear_fwd(const float* X, const float* W, const float* bias,
         hipLaunchKernelGGL((k_gemm_rows<true, false, false>), grid, dim3(256), 0, (hipStream_t)stream, X,
                            (const float*)nullptr, W, bias, N, I, O, ldx, 0, I, ldy, SNF_ACT_NONE, act, vecA, vecB, Y);
     SNF_LAUNCH_CHECK("snf_linear_fwd");
+    return SNF_OK;
+}
+
+namespace snf {
+// Y[n,o] = act(sum_z P[z][n][o] + bias[o])
+__global__ __launch_bounds__(256) void k_splitk_epilogue(const float* __restrict__ P, int splits, long long stride, int M,
+                                                         int Nc, const float* __restrict__ bias, int act, float* __restrict__ Y,
+                                                         int ldy) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long long)M * Nc) return;
+    const int n = (int)(t / Nc), o = (int)(t - (long long)n * Nc);
+    float v = 0.f;
+    for (int z = 0; z < splits; ++z) v += P[(size_t)z * stride + t];
+    if (bias) v += bias[o];
+    Y[(size_t)n * ldy + o] = act_apply(v, act);
+}
+
+// split-K plan for a forward GEMM whose 128 x 64 output tiles do not fill the chip: number of k-slices (1 = no split)
+static int splitk_plan(int N, int I, int O, int* ksplit) {
+    const int tiles = ceil_div(N, BM) * ceil_div(O, BN);
+    *ksplit = I;
+    if (tiles >= 256 || I < 512 || (I % 4)) return 1;
+    int splits = ceil_div(512, tiles);
+    if (splits > I / 128) splits = I / 128;
+    if (splits < 2) return 1;
+    int ks = ceil_div(I, splits);
+    ks = ((ks + 31) / 32) * 32;
+    *ksplit = ks;
+    return ceil_div(I, ks);
+}
+}  // namespace snf
+
+extern "C" int64_t snf_linear_fwd_workspace_bytes(int N, int I, int O) {
+    int ks;
+    const int splits = splitk_plan(N, I, O, &ks);
+    return splits > 1 ? (int64_t)splits * N * O * (int64_t)sizeof(float) : 0;
+}
+
+extern "C" int snf_linear_fwd_ws(const float* X, const float* W, const float* bias, int N, int I, int O, int ldx, int ldy,
+                                 int act, float* Y, void* workspace, int64_t workspace_bytes, snf_stream_t stream) {
+    int ks;
+    const int splits = (X && W && Y && N > 0 && I > 0 && O > 0) ? splitk_plan(N, I, O, &ks) : 1;
+    if (splits <= 1 || workspace == nullptr) return snf_linear_fwd(X, W, bias, N, I, O, ldx, ldy, act, Y, stream);
+    SNF_REQUIRE(ldx >= I && ldy >= O && act >= 0 && act <= 2, "snf_linear_fwd_ws: bad shape / activation");
+    SNF_REQUIRE(workspace_bytes >= snf_linear_fwd_workspace_bytes(N, I, O), "snf_linear_fwd_ws: workspace too small");
+    SNF_REQUIRE(aligned16(X) && aligned16(W) && aligned16(workspace) && (ldx % 4 == 0),
+                "snf_linear_fwd_ws: X, W, workspace must be 16-byte aligned and ldx a multiple of 4");
+    float* P = (float*)workspace;
+    const long long stride = (long long)N * O;
+    dim3 grid(ceil_div(N, BM), ceil_div(O, BN), splits);
+    if (!b3_try_fwd_splitk(X, W, N, I, O, ldx, ks, splits, P, stream))
+        hipLaunchKernelGGL((k_gemm_rows<true, false, true>), grid, dim3(256), 0, (hipStream_t)stream, X,
+                           (const float*)nullptr, W, (const float*)nullptr, N, I, O, ldx, 0, I, O, SNF_ACT_NONE, SNF_ACT_NONE,
+                           1, 1, P, ks, stride);
+    const long long total = (long long)N * O;
+    hipLaunchKernelGGL(k_splitk_epilogue, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, P, splits,
+                       stride, N, O, bias, act, Y, ldy);
+    SNF_LAUNCH_CHECK("snf_linear_fwd_ws");
     return SNF_OK;
 }
 

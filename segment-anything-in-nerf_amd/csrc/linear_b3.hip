@@ -91,7 +91,15 @@ template <bool BT, bool DERIV>
 __global__ __launch_bounds__(256) void k_gemm_rows_b3(const float* __restrict__ A, const float* __restrict__ Aux,
                                                       const float* __restrict__ B, const float* __restrict__ bias, int M,
                                                       int K, int Nc, int lda, int ldaux, int ldb, int ldc, int act_in,
-                                                      int act_out, float* __restrict__ C) {
+                                                      int act_out, float* __restrict__ C, int ksplit = 0,
+                                                      long long c_split_stride = 0) {
+    if constexpr (BT && !DERIV) {
+        if (ksplit > 0) {  // split-K slice z (see k_gemm_rows)
+            const int kb = blockIdx.z * ksplit;
+            A += kb; B += kb; K = min(ksplit, K - kb);
+            C += (size_t)blockIdx.z * c_split_stride;
+        }
+    }
     __shared__ __attribute__((aligned(16))) uint16_t Ah[B3_BM * B3_PITCH];
     __shared__ __attribute__((aligned(16))) uint16_t Al[B3_BM * B3_PITCH];
     __shared__ __attribute__((aligned(16))) uint16_t Bh[B3_BN * B3_PITCH];
@@ -219,6 +227,17 @@ int snf::b3_try_fwd(const float* X, const float* W, const float* bias, int N, in
     dim3 grid(ceil_div(N, B3_BM), ceil_div(O, B3_BN));
     hipLaunchKernelGGL((k_gemm_rows_b3<true, false>), grid, dim3(256), 0, (hipStream_t)stream, X, (const float*)nullptr, W,
                        bias, N, I, O, ldx, 0, I, ldy, SNF_ACT_NONE, act, Y);
+    return 1;
+}
+
+int snf::b3_try_fwd_splitk(const float* X, const float* W, int N, int I, int O, int ldx, int ksplit, int splits, float* P,
+                           snf_stream_t stream) {
+    if (!b3_enabled() || I < 128 || O < 64 || (I % 4) || (O % 4) || (ldx % 4) || ((uintptr_t)X & 15) || ((uintptr_t)W & 15))
+        return 0;
+    dim3 grid(ceil_div(N, B3_BM), ceil_div(O, B3_BN), splits);
+    hipLaunchKernelGGL((k_gemm_rows_b3<true, false>), grid, dim3(256), 0, (hipStream_t)stream, X, (const float*)nullptr, W,
+                       (const float*)nullptr, N, I, O, ldx, 0, I, O, SNF_ACT_NONE, SNF_ACT_NONE, P, ksplit,
+                       (long long)N * O);
     return 1;
 }
 

@@ -1,0 +1,158 @@
+// patchconv.hip -- the SAM conv head (samnerf/sam_model.py:196-200,259-264: Conv2d(C,C,k,pad) -> ReLU -> Conv2d -> mean over
+// the p x p patch) as GEMMs on the library's own matrix-core kernels (gfx950).
+//
+// The head sees R/p^2 independent p x p "images" (p = 4).  Features stay CHANNEL-LAST, exactly as MeanRenderer leaves them:
+// x[row, c], row = patch*p*p + y*p + x.  With zero padding a k x k convolution of such a patch is one GEMM over the
+// unfolded rows,
+//     col[row, c*k*k + t] = x[patch, y + dy_t, x + dx_t, c]   (0 outside the patch),   t = ky*k + kx, dy = ky - k/2,
+//     conv(x)[row, o] = sum_j col[row, j] * W[o, j] + b[o],    W = Conv2d.weight viewed [O, C*k*k]  (no copy: the torch
+// weight layout [O, C, k, k] flattens to exactly this column order).
+// The second convolution is followed by the mean over the patch, and both are linear, so the mean moves in front of the
+// GEMM: mean_rows(col) is a [R/p^2, C*k*k] matrix whose entry (c, t) is 1/p^2 times the sum of h over the sub-rectangle of
+// the patch that tap t can see -- the second GEMM runs on p^2 = 16x fewer rows.
+//
+//   snf_patch_unfold        x [R, C]            -> col  [R, C*k*k]
+//   snf_patch_fold          dcol [R, C*k*k]     -> dx   [R, C]            (adjoint of unfold)
+//   snf_patch_unfold_mean   h [R, C]            -> cm   [R/p^2, C*k*k]
+//   snf_patch_fold_mean     dcm [R/p^2, C*k*k]  -> dh   [R, C]            (adjoint of unfold_mean)
+// All four are pure data movement (HBM/LDS bound); the arithmetic is snf_linear_fwd / _bwd_data / _bwd_weight.
+#include "common.hpp"
+
+namespace snf {
+
+constexpr int PC_MAX_KK = 25;  // k <= 5
+
+// One workgroup per output row (pixel): the k*k neighbour rows are read coalesced into LDS, the C*k*k outputs leave as
+// one contiguous stream.
+__global__ __launch_bounds__(256) void k_patch_unfold(const float* __restrict__ x, int p, int C, int k, float* __restrict__ col) {
+    extern __shared__ float nb[];  // [k*k][C]
+    const int row = blockIdx.x, pp = p * p, kk = k * k, h = k / 2;
+    const int patch = row / pp, y = (row % pp) / p, xx = row % p;
+    for (int e = threadIdx.x; e < kk * C; e += 256) {
+        const int t = e / C, c = e - t * C;
+        const int iy = y + t / k - h, ix = xx + t % k - h;
+        nb[e] = (iy >= 0 && iy < p && ix >= 0 && ix < p) ? x[((size_t)patch * pp + iy * p + ix) * C + c] : 0.f;
+    }
+    __syncthreads();
+    float* __restrict__ o = col + (size_t)row * C * kk;
+    for (int e = threadIdx.x; e < kk * C; e += 256) {
+        const int c = e / kk, t = e - c * kk;
+        o[e] = nb[t * C + c];
+    }
+}
+
+// One workgroup per (patch, chunk of CC channels): the chunk's columns of all p*p rows of dcol are read as contiguous
+// runs into LDS; each thread then sums the <= k*k taps of its outputs.
+constexpr int PC_CC = 32;
+__global__ __launch_bounds__(256) void k_patch_fold(const float* __restrict__ dcol, int p, int C, int k, float* __restrict__ dx) {
+    extern __shared__ float sm[];  // [p*p][CC*k*k]
+    const int patch = blockIdx.x, c0 = blockIdx.y * PC_CC, pp = p * p, kk = k * k, h = k / 2;
+    const int cc = min(PC_CC, C - c0), run = cc * kk;
+    for (int e = threadIdx.x; e < pp * run; e += 256) {
+        const int r = e / run, j = e - r * run;
+        sm[r * (PC_CC * kk) + j] = dcol[((size_t)patch * pp + r) * C * kk + (size_t)c0 * kk + j];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < pp * cc; e += 256) {
+        const int r = e / cc, c = e - r * cc;
+        const int y = r / p, xx = r % p;
+        float acc = 0.f;
+        for (int t = 0; t < kk; ++t) {
+            // output pixel (oy, ox) read input (y, xx) through tap t  <=>  oy = y - dy_t, ox = xx - dx_t
+            const int oy = y - (t / k - h), ox = xx - (t % k - h);
+            if (oy >= 0 && oy < p && ox >= 0 && ox < p) acc += sm[(oy * p + ox) * (PC_CC * kk) + c * kk + t];
+        }
+        dx[((size_t)patch * pp + r) * C + c0 + c] = acc;
+    }
+}
+
+// One workgroup per patch: h[p*p][C] into LDS, then cm[c*k*k + t] = 1/p^2 * sum of h over the rectangle tap t can see.
+__global__ __launch_bounds__(256) void k_patch_unfold_mean(const float* __restrict__ hh, int p, int C, int k,
+                                                           float* __restrict__ cm) {
+    extern __shared__ float sm[];  // [p*p][C]
+    const int patch = blockIdx.x, pp = p * p, kk = k * k, h = k / 2;
+    for (int e = threadIdx.x; e < pp * C; e += 256) sm[e] = hh[(size_t)patch * pp * C + e];
+    __syncthreads();
+    const float inv = 1.f / (float)pp;
+    float* __restrict__ o = cm + (size_t)patch * C * kk;
+    for (int e = threadIdx.x; e < C * kk; e += 256) {
+        const int c = e / kk, t = e - c * kk;
+        const int dy = t / k - h, dx = t % k - h;
+        // output pixel (y, x) reads input (y + dy, x + dx): inputs iy in [max(0,dy), min(p, p+dy))
+        float acc = 0.f;
+        for (int iy = max(0, dy); iy < min(p, p + dy); ++iy)
+            for (int ix = max(0, dx); ix < min(p, p + dx); ++ix) acc += sm[(iy * p + ix) * C + c];
+        o[e] = acc * inv;
+    }
+}
+
+// One workgroup per patch: dcm[C*k*k] into LDS, then dh[(y,x), c] = 1/p^2 * sum over the taps whose rectangle holds (y,x).
+__global__ __launch_bounds__(256) void k_patch_fold_mean(const float* __restrict__ dcm, int p, int C, int k,
+                                                         float* __restrict__ dh) {
+    extern __shared__ float sm[];  // [C*k*k]
+    const int patch = blockIdx.x, pp = p * p, kk = k * k, h = k / 2;
+    for (int e = threadIdx.x; e < C * kk; e += 256) sm[e] = dcm[(size_t)patch * C * kk + e];
+    __syncthreads();
+    const float inv = 1.f / (float)pp;
+    for (int e = threadIdx.x; e < pp * C; e += 256) {
+        const int r = e / C, c = e - r * C;
+        const int iy = r / p, ix = r % p;
+        float acc = 0.f;
+        for (int t = 0; t < kk; ++t) {
+            const int dy = t / k - h, dx = t % k - h;
+            if (iy >= max(0, dy) && iy < min(p, p + dy) && ix >= max(0, dx) && ix < min(p, p + dx)) acc += sm[c * kk + t];
+        }
+        dh[(size_t)patch * pp * C + e] = acc * inv;
+    }
+}
+
+}  // namespace snf
+
+using namespace snf;
+
+static int check_patch(const char* who, const void* a, const void* b, int R, int p, int C, int k) {
+    SNF_REQUIRE(a && b, "%s: null pointer", who);
+    SNF_REQUIRE(p >= 1 && p <= 8 && k >= 1 && k <= 5 && (k & 1) && C >= 1, "%s: bad patch=%d kernel=%d C=%d", who, p, k, C);
+    SNF_REQUIRE(R > 0 && R % (p * p) == 0, "%s: R=%d is not a multiple of patch^2=%d", who, R, p * p);
+    return SNF_OK;
+}
+
+extern "C" int snf_patch_unfold(const float* x, int R, int p, int C, int k, float* col, snf_stream_t stream) {
+    int rc = check_patch("snf_patch_unfold", x, col, R, p, C, k);
+    if (rc) return rc;
+    const size_t lds = (size_t)k * k * C * sizeof(float);
+    SNF_REQUIRE(lds <= 64 * 1024, "snf_patch_unfold: C*k*k too large");
+    hipLaunchKernelGGL(k_patch_unfold, dim3(R), dim3(256), lds, (hipStream_t)stream, x, p, C, k, col);
+    SNF_LAUNCH_CHECK("snf_patch_unfold");
+    return SNF_OK;
+}
+
+extern "C" int snf_patch_fold(const float* dcol, int R, int p, int C, int k, float* dx, snf_stream_t stream) {
+    int rc = check_patch("snf_patch_fold", dcol, dx, R, p, C, k);
+    if (rc) return rc;
+    const size_t lds = (size_t)p * p * PC_CC * k * k * sizeof(float);
+    hipLaunchKernelGGL(k_patch_fold, dim3(R / (p * p), (C + PC_CC - 1) / PC_CC), dim3(256), lds, (hipStream_t)stream, dcol, p,
+                       C, k, dx);
+    SNF_LAUNCH_CHECK("snf_patch_fold");
+    return SNF_OK;
+}
+
+extern "C" int snf_patch_unfold_mean(const float* h, int R, int p, int C, int k, float* cm, snf_stream_t stream) {
+    int rc = check_patch("snf_patch_unfold_mean", h, cm, R, p, C, k);
+    if (rc) return rc;
+    const size_t lds = (size_t)p * p * C * sizeof(float);
+    SNF_REQUIRE(lds <= 64 * 1024, "snf_patch_unfold_mean: patch^2*C too large");
+    hipLaunchKernelGGL(k_patch_unfold_mean, dim3(R / (p * p)), dim3(256), lds, (hipStream_t)stream, h, p, C, k, cm);
+    SNF_LAUNCH_CHECK("snf_patch_unfold_mean");
+    return SNF_OK;
+}
+
+extern "C" int snf_patch_fold_mean(const float* dcm, int R, int p, int C, int k, float* dh, snf_stream_t stream) {
+    int rc = check_patch("snf_patch_fold_mean", dcm, dh, R, p, C, k);
+    if (rc) return rc;
+    const size_t lds = (size_t)C * k * k * sizeof(float);
+    SNF_REQUIRE(lds <= 64 * 1024, "snf_patch_fold_mean: C*k*k too large");
+    hipLaunchKernelGGL(k_patch_fold_mean, dim3(R / (p * p)), dim3(256), lds, (hipStream_t)stream, dcm, p, C, k, dh);
+    SNF_LAUNCH_CHECK("snf_patch_fold_mean");
+    return SNF_OK;
+}

@@ -423,9 +423,12 @@ class SAMModel(NerfactoModel):
         field_out = self.sam_field.get_outputs(sam_samples, get_feautre=[head])
         feat_out = self.renderer_mean(embeds=field_out[head], weights=sam_weights.detach())
         if head == "sam" and self.config.patch_size > 1:
-            p = self.config.patch_size
-            feat_out = feat_out.reshape(-1, p, p, feat_out.shape[-1]).permute(0, 3, 1, 2)
-            feat_out = self.conv_head(feat_out).mean(dim=[2, 3])
+            c0, c1 = self.conv_head[0], self.conv_head[2]
+            if feat_out.is_cuda:
+                # Conv2d -> ReLU -> Conv2d -> patch mean as GEMMs on channel-last rows (csrc/patchconv.hip)
+                feat_out = ops.conv_head(feat_out, c0.weight, c0.bias, c1.weight, c1.bias, self.config.patch_size)
+            else:
+                raise RuntimeError("SAMModel: the conv head runs on the HIP kernels only (no CPU path)")
         outputs[head] = feat_out
 
     def _get_outputs_nerfacto(self, ray_samples: RaySamples, fast=False):

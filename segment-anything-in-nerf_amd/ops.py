@@ -279,6 +279,88 @@ def mlp(x, weights: Sequence[torch.Tensor], biases=None, out_act: int = ACT_NONE
 
 
 # ---------------------------------------------------------------------------------------------
+# SAM conv head as GEMMs (csrc/patchconv.hip)
+# ---------------------------------------------------------------------------------------------
+def _linear_fwd_ws(x, w, b, N: int, I: int, O: int, act: int, y, st, tag: str) -> None:
+    """snf_linear_fwd with the split-K scratch buffer the shape asks for (long-K layers with few output tiles)."""
+    nbytes = int(_L().snf_linear_fwd_workspace_bytes(N, I, O))
+    ws = torch.empty((max(nbytes, 16) // 4,), device=x.device, dtype=torch.float32)
+    _launch("snf_linear_fwd_ws", _p(x), _p(w), _p(b), N, I, O, I, O, act, _p(y), _p(ws), nbytes, st, tag=tag)
+
+
+class _ConvHead(torch.autograd.Function):
+    """Conv2d(C,C,k,pad) -> ReLU -> Conv2d(C,C,k,pad) -> mean over the p x p patch (samnerf/sam_model.py:196-200,259-264)
+    on channel-last rows x [R, C] -> [R/p^2, C]: unfold + GEMM + ReLU, then patch-mean of the unfolded rows + GEMM."""
+
+    @staticmethod
+    def forward(ctx, x, w0, b0, w1, b1, p: int):
+        x = _chk(x, "x")
+        R, C = x.shape
+        O0, O1, k = w0.shape[0], w1.shape[0], w0.shape[-1]
+        kk = k * k
+        assert w0.is_contiguous() and w1.is_contiguous() and w0.shape[1] == C and w1.shape[1] == O0 and w1.shape[-1] == k
+        dev, st = x.device, _stream()
+        col = torch.empty((R, C * kk), device=dev, dtype=torch.float32)
+        _launch("snf_patch_unfold", _p(x), R, p, C, k, _p(col), st)
+        h = torch.empty((R, O0), device=dev, dtype=torch.float32)
+        _linear_fwd_ws(col, w0, b0, R, C * kk, O0, ACT_RELU, h, st, f"{C * kk}x{O0}")
+        npatch = R // (p * p)
+        cm = torch.empty((npatch, O0 * kk), device=dev, dtype=torch.float32)
+        _launch("snf_patch_unfold_mean", _p(h), R, p, O0, k, _p(cm), st)
+        y = torch.empty((npatch, O1), device=dev, dtype=torch.float32)
+        _linear_fwd_ws(cm, w1, b1, npatch, O0 * kk, O1, ACT_NONE, y, st, f"{O0 * kk}x{O1}pm")
+        ctx.p, ctx.k = p, k
+        ctx.refs = (w0, b0, w1, b1)
+        if any(ctx.needs_input_grad):
+            ctx.save_for_backward(col, h, cm)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        col, h, cm = ctx.saved_tensors
+        w0, b0, w1, b1 = ctx.refs
+        p, k = ctx.p, ctx.k
+        kk = k * k
+        gy = _chk(gy, "grad_y")
+        R, npatch = h.shape[0], cm.shape[0]
+        C, O0, O1 = col.shape[1] // kk, w0.shape[0], w1.shape[0]
+        dev, st = h.device, _stream()
+        grads = [None] * 6
+        # second convolution (+ mean): dW1, db1, d(cm)
+        w1buf, w1f = _grad_target(w1)
+        b1buf, b1f = (None, True) if b1 is None else _grad_target(b1)
+        _launch("snf_linear_bwd_weight", _p(gy), None, _p(cm), npatch, O0 * kk, O1, O1, O1, O0 * kk, ACT_NONE, _p(w1buf),
+                _p(b1buf), st, tag=f"{O0 * kk}x{O1}pm")
+        dcm = torch.empty((npatch, O0 * kk), device=dev, dtype=torch.float32)
+        _launch("snf_linear_bwd_data", _p(gy), None, _p(w1), npatch, O0 * kk, O1, O1, O1, O0 * kk, ACT_NONE, _p(dcm), st,
+                tag=f"{O0 * kk}x{O1}pm")
+        dh = torch.empty((R, O0), device=dev, dtype=torch.float32)
+        _launch("snf_patch_fold_mean", _p(dcm), R, p, O0, k, _p(dh), st)
+        # first convolution (ReLU derivative taken from h inside the GEMM loaders): dW0, db0, d(col) -> dx
+        w0buf, w0f = _grad_target(w0)
+        b0buf, b0f = (None, True) if b0 is None else _grad_target(b0)
+        _launch("snf_linear_bwd_weight", _p(dh), _p(h), _p(col), R, C * kk, O0, O0, O0, C * kk, ACT_RELU, _p(w0buf), _p(b0buf),
+                st, tag=f"{C * kk}x{O0}")
+        if ctx.needs_input_grad[0]:
+            dcol = torch.empty((R, C * kk), device=dev, dtype=torch.float32)
+            _launch("snf_linear_bwd_data", _p(dh), _p(h), _p(w0), R, C * kk, O0, O0, O0, C * kk, ACT_RELU, _p(dcol), st,
+                    tag=f"{C * kk}x{O0}")
+            dx = torch.empty((R, C), device=dev, dtype=torch.float32)
+            _launch("snf_patch_fold", _p(dcol), R, p, C, k, _p(dx), st)
+            grads[0] = dx
+        grads[1] = None if w0f else w0buf
+        grads[2] = None if b0f else b0buf
+        grads[3] = None if w1f else w1buf
+        grads[4] = None if b1f else b1buf
+        return tuple(grads)
+
+
+def conv_head(x, w0, b0, w1, b1, patch: int) -> torch.Tensor:
+    """x [R, C] channel-last patch rows -> [R/patch^2, O]."""
+    return _ConvHead.apply(x, w0, b0, w1, b1, patch)
+
+
+# ---------------------------------------------------------------------------------------------
 # fused 64-wide MLP (activations in registers; see csrc/mlp_chain.hip)
 # ---------------------------------------------------------------------------------------------
 def mlp64_supported(in_dim: int, weights: Sequence[torch.Tensor]) -> bool:

@@ -378,3 +378,48 @@ def test_bad_arguments_raise():
         ops().topk_sharpen(w, 16)  # S > 256
     with pytest.raises(RuntimeError):
         ops().sample_spacing(torch.zeros(4), torch.ones(4), 8)  # CPU tensors: no fallback
+
+
+@pytest.mark.parametrize("npatch,p,C,k", [(256, 4, 256, 3), (7, 2, 8, 3), (5, 3, 12, 1), (3, 4, 16, 5)])
+def test_conv_head_vs_torch_conv2d(npatch, p, C, k):
+    """csrc/patchconv.hip + the GEMM kernels against F.conv2d -> ReLU -> F.conv2d -> mean (samnerf/sam_model.py:259-264),
+    forward and every gradient."""
+    g = torch.Generator().manual_seed(3)
+    R = npatch * p * p
+    x = torch.randn((R, C), generator=g)
+    w0 = torch.randn((C, C, k, k), generator=g) / (C * k * k) ** 0.5
+    w1 = torch.randn((C, C, k, k), generator=g) / (C * k * k) ** 0.5
+    b0, b1 = torch.randn((C,), generator=g) * 0.1, torch.randn((C,), generator=g) * 0.1
+    gy = torch.randn((npatch, C), generator=g)
+    ref_in = [t.clone().double().requires_grad_(True) for t in (x, w0, b0, w1, b1)]
+    xr = ref_in[0].reshape(-1, p, p, C).permute(0, 3, 1, 2)
+    hr = torch.relu(torch.nn.functional.conv2d(xr, ref_in[1], ref_in[2], padding=k // 2))
+    yr = torch.nn.functional.conv2d(hr, ref_in[3], ref_in[4], padding=k // 2).mean(dim=[2, 3])
+    yr.backward(gy.double())
+    dev_in = [t.clone().cuda().requires_grad_(True) for t in (x, w0, b0, w1, b1)]
+    y = ops().conv_head(*dev_in, p)
+    y.backward(gy.cuda())
+    scale = float(yr.abs().max())
+    assert float((y.detach().cpu().double() - yr.detach()).abs().max()) <= 2e-5 * max(scale, 1.0)
+    for a, b, name in zip(dev_in, ref_in, ("x", "w0", "b0", "w1", "b1")):
+        err = float((a.grad.cpu().double() - b.grad).abs().max())
+        assert err <= 2e-5 * max(float(b.grad.abs().max()), 1.0), (name, err)
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("N,I,O", [(4096, 2304, 256), (256, 2304, 256), (100, 1000, 72)])
+def test_linear_fwd_splitk(N, I, O, mode):
+    """snf_linear_fwd_ws: split-K forward (partials + bias/activation epilogue) against fp64 torch."""
+    m = ops()
+    m.set_gemm_mode(mode)
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn((N, I), generator=g).cuda()
+    w = (torch.randn((O, I), generator=g) / I ** 0.5).cuda()
+    b = torch.randn((O,), generator=g).cuda()
+    assert int(m._L().snf_linear_fwd_workspace_bytes(N, I, O)) > 0
+    for act, fn in ((m.ACT_RELU, torch.relu), (m.ACT_NONE, lambda t: t)):
+        y = torch.empty((N, O), device="cuda")
+        m._linear_fwd_ws(x, w, b, N, I, O, act, y, m._stream(), f"{I}x{O}")
+        ref = fn(x.double() @ w.double().T + b.double())
+        tol = 5e-6 if mode == "fp32" else 2e-5
+        assert float((y.double() - ref).abs().max()) <= tol * max(1.0, float(ref.abs().max()))
