@@ -155,8 +155,8 @@ __global__ __launch_bounds__(256) void k_hashgrid_bwd(const float* __restrict__ 
 // ==========================================================================================
 constexpr int HG_MAX_LOG2B = 12;
 constexpr int HG_RT = 512;       // threads of the reduce workgroup (8 waves; 4 workgroups per CU)
-constexpr int HG_CHUNK = 2048;   // records sorted per trip through LDS (HG_RPT per thread)
-constexpr int HG_RPT = HG_CHUNK / HG_RT;
+// records sorted per trip through LDS (16 KB of payload at F = 2, 64 KB at F = 8; a 1024-record chunk for F = 8 measured slower)
+template <int F> constexpr int hg_chunk() { return 2048; }
 constexpr int HG_MAX_RPB = 2048; // rows per bucket (HG_ROWS_PT per reduce thread)
 constexpr int HG_ROWS_PT = HG_MAX_RPB / HG_RT;
 constexpr int HG_LONG = 16;      // segments longer than this are reduced by a wave
@@ -267,31 +267,119 @@ __global__ __launch_bounds__(1024) void k_hg_scan(int N, int log2B, int nblk, co
 // (Payload-carrying 12/36-byte records were measured: the scatter's store-transaction count made them slower.)
 constexpr int HG_SAMPLE_BITS = 21;  // N <= 2^21 per launch (row_in_bucket needs 11 bits)
 
+// The scatter pass stages records through LDS: a batch of HG_SB_SAMPLES samples per thread-block trip (x 8 corners) is
+// counting-sorted by bucket in LDS and leaves as one contiguous run per bucket (~128 B at 256 buckets) instead of 8-byte
+// stores to 256 different cache lines -- the store-transaction count, not the byte count, bounded the direct version
+// (rocprofv3: 84 % of its wave cycles were issue stalls behind the store queue).
+constexpr int HG_SB_SPT = 2;                      // samples per thread per batch
+constexpr int HG_SB_REC = 256 * HG_SB_SPT * 8;    // 4096 staged records (32 KB)
+
+inline size_t hg_scatter_lds_bytes(int log2B) {
+    return ((size_t)3 << log2B) * sizeof(uint32_t) + (size_t)HG_SB_REC * (sizeof(uint2) + sizeof(uint16_t));
+}
+
 __global__ __launch_bounds__(256) void k_hg_scatter(const float* __restrict__ u, const float* __restrict__ scalings, int N,
                                                     int log2_T, int log2B, int spt, const uint32_t* __restrict__ g_offs,
                                                     uint2* __restrict__ records) {
-    __shared__ uint32_t cursor[1 << HG_MAX_LOG2B];
+    extern __shared__ __attribute__((aligned(16))) uint32_t hs_lds[];
     const int B = 1 << log2B, log2rpb = log2_T - log2B;
-    const int tid = threadIdx.x, blk = blockIdx.x, l = blockIdx.y, nblk = gridDim.x;
-    for (int i = tid; i < B; i += 256) cursor[i] = g_offs[((size_t)l * nblk + blk) * B + i];
+    uint2* stage = reinterpret_cast<uint2*>(hs_lds);                        // [HG_SB_REC]
+    uint32_t* cursor = hs_lds + 2 * HG_SB_REC;                               // [B] global write cursor of this tile
+    uint32_t* lcnt = cursor + B;                                             // [B] batch-local count -> exclusive offset
+    uint32_t* delta = lcnt + B;                                              // [B] cursor - local offset
+    uint16_t* sbkt = reinterpret_cast<uint16_t*>(delta + B);                 // [HG_SB_REC] bucket of a staged record
+    __shared__ uint32_t wave_tot[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int blk = blockIdx.x, l = blockIdx.y, nblk = gridDim.x;
+    for (int i = tid; i < B; i += 256) {
+        cursor[i] = g_offs[((size_t)l * nblk + blk) * B + i];
+        lcnt[i] = 0u;
+    }
     __syncthreads();
     const uint32_t mask = (1u << log2_T) - 1u, rmask = (1u << log2rpb) - 1u;
     const float s = scalings[l];
-    for (int j = 0; j < spt; ++j) {
-        const int n = (blk * spt + j) * 256 + tid;
-        if (n < N) {
-            const Corners c = corners_of(u, n, s, mask);
-            const float ox = c.ox, oy = c.oy, oz = c.oz;
-            const float mx = 1.f - ox, my = 1.f - oy, mz = 1.f - oz;
-            float w[8];  // chain-rule weights in autograd's order: ((g*z)*y)*x
-            w[0] = oz * oy * ox; w[3] = oz * oy * mx; w[1] = oz * my * ox; w[2] = oz * my * mx;
-            w[4] = mz * oy * ox; w[7] = mz * oy * mx; w[5] = mz * my * ox; w[6] = mz * my * mx;
+    const int bpt = (B + 255) >> 8;  // buckets per thread in the scan (1 .. 16)
+    for (int j0 = 0; j0 < spt; j0 += HG_SB_SPT) {
+        // ---- 1: records of this batch, ranked within their bucket
+        uint2 rec[HG_SB_SPT * 8];
+        uint32_t bk[HG_SB_SPT * 8], rk[HG_SB_SPT * 8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const uint32_t slot = atomicAdd(&cursor[c.idx[k] >> log2rpb], 1u);
-                records[slot] = make_uint2((uint32_t)n | ((c.idx[k] & rmask) << HG_SAMPLE_BITS), __float_as_uint(w[k]));
+        for (int jj = 0; jj < HG_SB_SPT; ++jj) {
+            const int j = j0 + jj;
+            const int n = (blk * spt + j) * 256 + tid;
+            const bool live = (j < spt) && (n < N);
+            if (live) {
+                const Corners c = corners_of(u, n, s, mask);
+                const float ox = c.ox, oy = c.oy, oz = c.oz;
+                const float mx = 1.f - ox, my = 1.f - oy, mz = 1.f - oz;
+                float w[8];  // chain-rule weights in autograd's order: ((g*z)*y)*x
+                w[0] = oz * oy * ox; w[3] = oz * oy * mx; w[1] = oz * my * ox; w[2] = oz * my * mx;
+                w[4] = mz * oy * ox; w[7] = mz * oy * mx; w[5] = mz * my * ox; w[6] = mz * my * mx;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int q = jj * 8 + k;
+                    bk[q] = c.idx[k] >> log2rpb;
+                    rec[q] = make_uint2((uint32_t)n | ((c.idx[k] & rmask) << HG_SAMPLE_BITS), __float_as_uint(w[k]));
+                    rk[q] = atomicAdd(&lcnt[bk[q]], 1u);
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) bk[jj * 8 + k] = 0xFFFFFFFFu;
             }
         }
+        __syncthreads();
+        // ---- 2: exclusive scan of the bucket counts (thread t owns buckets [t*bpt, (t+1)*bpt))
+        uint32_t cq[16];
+        uint32_t sum = 0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int bb = tid * bpt + q;
+            cq[q] = (q < bpt && bb < B) ? lcnt[bb] : 0u;
+            sum += cq[q];
+        }
+        uint32_t inc = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t t = __shfl_up(inc, d, 64);
+            if (lane >= d) inc += t;
+        }
+        if (lane == 63) wave_tot[wave] = inc;
+        __syncthreads();
+        uint32_t run = inc - sum;
+        for (int w2 = 0; w2 < wave; ++w2) run += wave_tot[w2];
+        const uint32_t total = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int bb = tid * bpt + q;
+            if (q < bpt && bb < B) {
+                lcnt[bb] = run;
+                delta[bb] = cursor[bb] - run;
+            }
+            run += cq[q];
+        }
+        __syncthreads();
+        // ---- 3: records to their bucket-sorted slots
+#pragma unroll
+        for (int q = 0; q < HG_SB_SPT * 8; ++q) {
+            if (bk[q] != 0xFFFFFFFFu) {
+                const uint32_t slot = lcnt[bk[q]] + rk[q];
+                stage[slot] = rec[q];
+                sbkt[slot] = (uint16_t)bk[q];
+            }
+        }
+        __syncthreads();
+        // ---- 4: contiguous runs out; advance the cursors
+        for (uint32_t i = tid; i < total; i += 256) records[delta[sbkt[i]] + i] = stage[i];
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int bb = tid * bpt + q;
+            if (q < bpt && bb < B) {
+                cursor[bb] += cq[q];
+                lcnt[bb] = 0u;
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -329,8 +417,8 @@ __device__ __forceinline__ void row_rmw(float* __restrict__ dst, const float (&a
 }
 
 // Reduce pass, one workgroup per (bucket, level); integer LDS atomics only (see the header of this section).
-// Per chunk of HG_CHUNK records (streamed, coalesced; no index math):
-//   1. every thread loads HG_RPT records {sample|row, w}, gathers the staged gradient of its samples (independent
+// Per chunk of hg_chunk<F>() records (streamed, coalesced; no index math):
+//   1. every thread loads its records {sample|row, w}, gathers the staged gradient of its samples (independent
 //      loads) and ranks each record within its row (pos = ds_add_rtn_u32 on the row counter);
 //   2. exclusive scan of the row counters -> segment offsets; rows with long segments are queued;
 //   3. the record payloads w*g are written to their row-sorted slots of an LDS staging array;
@@ -341,10 +429,12 @@ __global__ __launch_bounds__(HG_RT) void k_hg_reduce(const float* __restrict__ g
                                                      const uint32_t* __restrict__ bucket_start,
                                                      const uint2* __restrict__ records, float* __restrict__ grad_table,
                                                      uint32_t hg_long) {
+    constexpr int CHUNK = hg_chunk<F>();
+    constexpr int RPT = CHUNK / HG_RT;
     __shared__ uint32_t cnt[HG_MAX_RPB + 1];  // per-row counts, then exclusive offsets
-    __shared__ __attribute__((aligned(16))) float val[HG_CHUNK * F];  // w*g per record, row-sorted
+    __shared__ __attribute__((aligned(16))) float val[CHUNK * F];  // w*g per record, row-sorted
     __shared__ uint32_t wave_tot[HG_RT / 64];
-    __shared__ uint32_t long_rows[HG_CHUNK / 8 + 1];
+    __shared__ uint32_t long_rows[CHUNK / 8 + 1];
     __shared__ uint32_t n_long;
     const int B = 1 << log2B, log2rpb = log2_T - log2B;
     const int rpb = 1 << log2rpb;
@@ -361,33 +451,44 @@ __global__ __launch_bounds__(HG_RT) void k_hg_reduce(const float* __restrict__ g
 #pragma unroll
         for (int f = 0; f < F; ++f) racc[q][f] = 0.f;
 
-    for (uint32_t c0 = start; c0 < end; c0 += HG_CHUNK) {
-        for (int i = tid; i <= rpb; i += HG_RT) cnt[i] = 0u;
-        if (tid == 0) n_long = 0u;
-        __syncthreads();  // also orders the previous chunk's table updates before this chunk's
-        // ---- phase 1: stream the records in, rank within row
-        uint32_t row[HG_RPT], pos[HG_RPT];
-        float v[HG_RPT][F];
-        uint2 rec[HG_RPT];
+    // Software pipeline over chunks: the records of chunk c+1 are requested at the top of chunk c and their staged
+    // gradients gathered half-way through it, so both global latencies of a chunk hide under the LDS work of the previous
+    // one (workgroup barriers do not wait for outstanding global loads on gfx950).
+    // (F = 2 only: at F = 8 the second register set of 4 x 8 gradients costs more occupancy than the overlap returns.)
+    constexpr bool PIPE = (F == 2);
+    constexpr int NRPT = PIPE ? RPT : 1;
+    uint2 rec[RPT], recn[NRPT];
+    float g[RPT][F], gn[NRPT][F];
+    auto load_recs = [&](uint32_t c0, auto& r) {
 #pragma unroll
-        for (int j = 0; j < HG_RPT; ++j) {
+        for (int j = 0; j < RPT; ++j) {
             const uint32_t i = c0 + tid + (uint32_t)HG_RT * j;
-            const bool live = i < end;
-            rec[j] = records[live ? i : start];
-            pos[j] = live ? 0u : 0xFFFFFFFFu;
+            r[j] = records[i < end ? i : start];
         }
+    };
+    auto gather = [&](const auto& r, auto& gg) {
 #pragma unroll
-        for (int j = 0; j < HG_RPT; ++j) {
+        for (int j = 0; j < RPT; ++j) load_row<F>(gl + (size_t)(r[j].x & ((1u << HG_SAMPLE_BITS) - 1u)) * F, gg[j]);
+    };
+    load_recs(start, rec);
+    for (int i = tid; i <= rpb; i += HG_RT) cnt[i] = 0u;
+    if (tid == 0) n_long = 0u;
+    gather(rec, g);
+    __syncthreads();
+
+    for (uint32_t c0 = start; c0 < end; c0 += CHUNK) {
+        const bool has_next = c0 + CHUNK < end;
+        if constexpr (PIPE) {
+            if (has_next) load_recs(c0 + CHUNK, recn);
+        }
+        // ---- phase 1: rank within row
+        uint32_t row[RPT], pos[RPT];
+#pragma unroll
+        for (int j = 0; j < RPT; ++j) {
+            const bool live = c0 + tid + (uint32_t)HG_RT * j < end;
             row[j] = rec[j].x >> HG_SAMPLE_BITS;
-            const float w = __uint_as_float(rec[j].y);
-            float g[F];
-            load_row<F>(gl + (size_t)(rec[j].x & ((1u << HG_SAMPLE_BITS) - 1u)) * F, g);
-#pragma unroll
-            for (int f = 0; f < F; ++f) v[j][f] = w * g[f];
+            pos[j] = live ? atomicAdd(&cnt[row[j]], 1u) : 0xFFFFFFFFu;
         }
-#pragma unroll
-        for (int j = 0; j < HG_RPT; ++j)
-            if (pos[j] != 0xFFFFFFFFu) pos[j] = atomicAdd(&cnt[row[j]], 1u);
         __syncthreads();
         // ---- phase 2: exclusive scan of cnt[0..rpb) in place (thread t scans HG_ROWS_PT consecutive entries)
         {
@@ -419,16 +520,20 @@ __global__ __launch_bounds__(HG_RT) void k_hg_reduce(const float* __restrict__ g
             if (tid == HG_RT - 1) cnt[rpb] = base + inc;
         }
         __syncthreads();
-        // ---- phase 3: payloads to their row-sorted slots
+        if constexpr (PIPE) {
+            if (has_next) gather(recn, gn);  // the next chunk's records have landed by now
+        }
+        // ---- phase 3: payloads w*g to their row-sorted slots
 #pragma unroll
-        for (int j = 0; j < HG_RPT; ++j) {
+        for (int j = 0; j < RPT; ++j) {
             if (pos[j] != 0xFFFFFFFFu) {
+                const float w = __uint_as_float(rec[j].y);
                 float* d = &val[(size_t)(cnt[row[j]] + pos[j]) * F];
                 if constexpr (F == 8) {
-                    reinterpret_cast<float4*>(d)[0] = make_float4(v[j][0], v[j][1], v[j][2], v[j][3]);
-                    reinterpret_cast<float4*>(d)[1] = make_float4(v[j][4], v[j][5], v[j][6], v[j][7]);
+                    reinterpret_cast<float4*>(d)[0] = make_float4(w * g[j][0], w * g[j][1], w * g[j][2], w * g[j][3]);
+                    reinterpret_cast<float4*>(d)[1] = make_float4(w * g[j][4], w * g[j][5], w * g[j][6], w * g[j][7]);
                 } else {
-                    *reinterpret_cast<float2*>(d) = make_float2(v[j][0], v[j][1]);
+                    *reinterpret_cast<float2*>(d) = make_float2(w * g[j][0], w * g[j][1]);
                 }
             }
         }
@@ -466,7 +571,23 @@ __global__ __launch_bounds__(HG_RT) void k_hg_reduce(const float* __restrict__ g
             }
             if (lane == 0) row_rmw<F>(slab + (size_t)r * F, a);
         }
-        __syncthreads();
+        __syncthreads();  // also orders this chunk's table updates before the next chunk's
+        if (has_next) {
+            for (int i = tid; i <= rpb; i += HG_RT) cnt[i] = 0u;
+            if (tid == 0) n_long = 0u;
+            if constexpr (PIPE) {
+#pragma unroll
+                for (int j = 0; j < RPT; ++j) {
+                    rec[j] = recn[j];
+#pragma unroll
+                    for (int f = 0; f < F; ++f) g[j][f] = gn[j][f];
+                }
+            } else {
+                load_recs(c0 + CHUNK, rec);
+                gather(rec, g);
+            }
+            __syncthreads();
+        }
     }
     // ---- epilogue: one read-modify-write per owned row that received something; the loads issue together
     float cur[HG_ROWS_PT][F];
@@ -594,7 +715,10 @@ extern "C" int snf_hashgrid_bwd_sorted(const float* u, const float* grad_out, co
         hipLaunchKernelGGL(k_hg_stage_grad<8>, dim3(tblocks), dim3(256), 0, st, grad_out, N, L, ld_out, col_off, gT);
     hipLaunchKernelGGL(k_hg_count, dim3(nblk, L), dim3(256), 0, st, u, scalings, N, log2_T, g.log2B, g.spt, hist);
     hipLaunchKernelGGL(k_hg_scan, dim3(L), dim3(1024), 0, st, N, g.log2B, nblk, hist, offs, bstart);
-    hipLaunchKernelGGL(k_hg_scatter, dim3(nblk, L), dim3(256), 0, st, u, scalings, N, log2_T, g.log2B, g.spt, offs,
+    if (hg_scatter_lds_bytes(g.log2B) > 48 * 1024)
+        hipFuncSetAttribute((const void*)k_hg_scatter, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)hg_scatter_lds_bytes(g.log2B));
+    hipLaunchKernelGGL(k_hg_scatter, dim3(nblk, L), dim3(256), hg_scatter_lds_bytes(g.log2B), st, u, scalings, N, log2_T, g.log2B, g.spt, offs,
                        (uint2*)records);
     if (F == 2)
         hipLaunchKernelGGL(k_hg_reduce<2>, dim3(B, L), dim3(HG_RT), 0, st, gT, N, log2_T, g.log2B, bstart,
