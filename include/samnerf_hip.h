@@ -107,6 +107,16 @@ int snf_linear_bwd_data(const float* dY, const float* Y, const float* W, int N, 
 int snf_linear_bwd_weight(const float* dY, const float* Y, const float* X, int N, int I, int O, int lddy,
                           int ldy, int ldx, int act, float* dW, float* dbias, snf_stream_t stream);
 
+/* ---- a7, tiny: the proposal networks' density MLP (nerfstudio/fields/density_fields.py:80-97 with hidden_dim 16:
+ *      I -> H (ReLU) -> 1, bias-free) in one launch per direction, one thread per sample.  Built for I = 10, H = 16
+ *      (snf_mlp_tiny_supported).  Hid [N,H] receives the hidden activations (may be NULL at inference); the backward
+ *      writes dX [N, lddx] (may be NULL) and ACCUMULATES dW0 [H,I], dW1 [H] (one set of atomics per workgroup). */
+int snf_mlp_tiny_supported(int I, int H, int O);
+int snf_mlp_tiny_fwd(const float* X, int ldx, const float* W0, const float* W1, int I, int H, int64_t N, float* Hid,
+                     float* Y, snf_stream_t stream);
+int snf_mlp_tiny_bwd(const float* dY, const float* X, int ldx, const float* Hid, const float* W0, const float* W1, int I,
+                     int H, int64_t N, float* dX, int lddx, float* dW0, float* dW1, snf_stream_t stream);
+
 /* ---- a16: the SAM conv head (samnerf/sam_model.py:196-200,259-264: Conv2d(C,C,k,padding=k/2) -> ReLU -> Conv2d -> mean over
  *      the p x p patch) as GEMMs.  Features stay channel-last [R, C], row = patch*p*p + y*p + x (MeanRenderer's layout).
  *   unfold      : col[row, c*k*k + t] = x[patch, y+dy_t, x+dx_t, c] (0 outside the patch), t = ky*k + kx -- the column

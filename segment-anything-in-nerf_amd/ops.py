@@ -279,6 +279,48 @@ def mlp(x, weights: Sequence[torch.Tensor], biases=None, out_act: int = ACT_NONE
 
 
 # ---------------------------------------------------------------------------------------------
+# the proposal networks' tiny density MLP (csrc/mlp_tiny.hip)
+# ---------------------------------------------------------------------------------------------
+def mlp_tiny_supported(in_dim: int, weights: Sequence[torch.Tensor], out_act: int) -> bool:
+    return (len(weights) == 2 and out_act == ACT_NONE
+            and bool(_L().snf_mlp_tiny_supported(in_dim, weights[0].shape[0], weights[1].shape[0])))
+
+
+class _MLPTiny(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w0, w1):
+        x = _chk(x, "x")
+        N, I = x.shape
+        H = w0.shape[0]
+        need = any(ctx.needs_input_grad)
+        hid = torch.empty((N, H), device=x.device, dtype=torch.float32) if need else None
+        y = torch.empty((N, 1), device=x.device, dtype=torch.float32)
+        _launch("snf_mlp_tiny_fwd", _p(x), I, _p(w0), _p(w1), I, H, N, _p(hid), _p(y), _stream(), tag=f"{I}x{H}x1")
+        ctx.refs = (w0, w1)
+        if need:
+            ctx.save_for_backward(x, hid)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, hid = ctx.saved_tensors
+        w0, w1 = ctx.refs
+        gy = _chk(gy, "grad_y")
+        N, I = x.shape
+        H = w0.shape[0]
+        gx = torch.empty((N, I), device=x.device, dtype=torch.float32) if ctx.needs_input_grad[0] else None
+        w0buf, f0 = _grad_target(w0)
+        w1buf, f1 = _grad_target(w1)
+        _launch("snf_mlp_tiny_bwd", _p(gy), _p(x), I, _p(hid), _p(w0), _p(w1), I, H, N, _p(gx), I, _p(w0buf), _p(w1buf),
+                _stream(), tag=f"{I}x{H}x1")
+        return gx, (None if f0 else w0buf), (None if f1 else w1buf)
+
+
+def mlp_tiny(x, w0, w1) -> torch.Tensor:
+    return _MLPTiny.apply(x, w0, w1)
+
+
+# ---------------------------------------------------------------------------------------------
 # SAM conv head as GEMMs (csrc/patchconv.hip)
 # ---------------------------------------------------------------------------------------------
 def _linear_fwd_ws(x, w, b, N: int, I: int, O: int, act: int, y, st, tag: str) -> None:

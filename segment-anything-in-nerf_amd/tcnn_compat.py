@@ -126,7 +126,10 @@ class Network(nn.Module):
                 dst.copy_(src)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        return ops.mlp(x.reshape(-1, self.n_input_dims), self.weights(), None, self.output_activation)
+        x, ws = x.reshape(-1, self.n_input_dims), self.weights()
+        if x.is_cuda and ops.mlp_tiny_supported(self.n_input_dims, ws, self.output_activation):
+            return ops.mlp_tiny(x, ws[0], ws[1])  # proposal-network shape: one launch per direction
+        return ops.mlp(x, ws, None, self.output_activation)
 
 
 class NetworkWithInputEncoding(nn.Module):

@@ -423,3 +423,25 @@ def test_linear_fwd_splitk(N, I, O, mode):
         ref = fn(x.double() @ w.double().T + b.double())
         tol = 5e-6 if mode == "fp32" else 2e-5
         assert float((y.double() - ref).abs().max()) <= tol * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("N", [1, 1000, 262144])
+def test_mlp_tiny_vs_torch(N):
+    """csrc/mlp_tiny.hip (proposal density MLP 10 -> 16 -> 1) against fp64 torch: forward, dX, dW0, dW1."""
+    m = ops()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn((N, 10), generator=g)
+    w0 = torch.randn((16, 10), generator=g) * 0.4
+    w1 = torch.randn((1, 16), generator=g) * 0.4
+    gy = torch.randn((N, 1), generator=g)
+    ref = [t.clone().double().requires_grad_(True) for t in (x, w0, w1)]
+    yr = torch.relu(ref[0] @ ref[1].T) @ ref[2].T
+    yr.backward(gy.double())
+    dev = [t.clone().cuda().requires_grad_(True) for t in (x, w0, w1)]
+    assert m.mlp_tiny_supported(10, dev[1:], m.ACT_NONE)
+    y = m.mlp_tiny(*dev)
+    y.backward(gy.cuda())
+    assert float((y.detach().cpu().double() - yr.detach()).abs().max()) <= 2e-6 * max(1.0, float(yr.abs().max()))
+    for a, b, name in zip(dev, ref, ("x", "w0", "w1")):
+        err = float((a.grad.cpu().double() - b.grad).abs().max())
+        assert err <= 1e-5 * max(float(b.grad.abs().max()), 1.0), (name, err)
