@@ -13,6 +13,7 @@
 // operand read is one conflict-free ds_read_b32 per lane; the row pitch (129 / 65 floats) makes the
 // transposing ds_write_b32 pattern conflict-free as well.
 #include "common.hpp"
+#include <stdlib.h>
 
 namespace snf {
 
@@ -439,8 +440,10 @@ extern "C" int snf_linear_bwd_weight(const float* dY, const float* Y, const floa
     const int vecA = aligned16(dY) && (lddy % 4 == 0) && (act == SNF_ACT_NONE || (aligned16(Y) && ldy % 4 == 0));
     const int vecB = aligned16(X) && (ldx % 4 == 0);
     const int to = ceil_div(O, 64), ti = ceil_div(I, 64);
-    // aim for ~2048 workgroups; every chunk is a multiple of BK rows
-    int chunks = 2048 / (to * ti);
+    // aim for ~1024 workgroups (measured best for the 64-wide nets: 2048 doubles the atomics of the final accumulation, 512
+    // leaves the CUs short of loads in flight); every chunk is a multiple of BK rows
+    static const int target = getenv("SNF_WGRAD_BLOCKS") ? atoi(getenv("SNF_WGRAD_BLOCKS")) : 1024;
+    int chunks = target / (to * ti);
     if (chunks < 1) chunks = 1;
     int rows = ceil_div(N, chunks);
     rows = ((rows + BK - 1) / BK) * BK;

@@ -6,10 +6,10 @@ import samnerf_amd
 from samnerf_amd import ops
 
 N = int(os.environ.get("N", 65536))
-shapes = [(192, 256), (256, 256), (256, 192), (64, 64), (32, 64)]
+shapes = [(192, 256), (256, 256), (256, 192), (64, 64), (32, 64), (64, 16), (2304, 256)]
 ops.enable_kernel_timing("all")
 for (I, O) in shapes:
-    n = N if max(I, O) >= 192 else N * 8
+    n = (4096 if I > 1024 else N) if max(I, O) >= 192 else N * 8
     x = torch.randn((n, I), device="cuda", requires_grad=True)
     w = (torch.randn((O, I), device="cuda") / I ** 0.5).requires_grad_(True)
     gy = torch.randn((n, O), device="cuda")
@@ -20,6 +20,6 @@ s = ops.kernel_timing_summary()
 for k, v in s.items():
     name, _, tag = k.partition("/")
     I, O = (int(t) for t in tag.split("x"))
-    n = N if max(I, O) >= 192 else N * 8
+    n = (4096 if I > 1024 else N) if max(I, O) >= 192 else N * 8
     fl = 2.0 * n * I * O
     print(f"{k:36s} {v['avg_ms']*1e3:8.1f} us  {fl / (v['avg_ms']*1e-3) / 1e12:6.1f} TFLOP/s")
