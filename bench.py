@@ -146,8 +146,10 @@ def main():
         assert _lib.load().snf_set_adam_launch(*(int(x) for x in os.environ["SNF_ADAM_LAUNCH"].split(","))) == 0
     trainer = build_trainer(w, local_rank, world)
 
+    multi = dist.is_initialized()  # world > 1 (or SNF_FORCE_COLLECTIVES=1 under torchrun: RCCL paths on one GPU)
+
     def barrier():
-        if world > 1:
+        if multi:
             dist.barrier()
 
     # ---- warm-up (untimed).  Afterwards a short SERIAL replay (one stream, every C-ABI launch bracketed by HIP events)
@@ -196,12 +198,31 @@ def main():
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     live = ops.kernel_timing_summary() if dom is not None else {}
     ops.enable_kernel_timing(None)
+
+    # ---- the same step WITHOUT the exchange + optimizer (report both): gradients just accumulate
+    n_fb = min(args.steps, 20)
+    trainer.optimizers.enabled = False
+    trainer.train_iteration(step)
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n_fb):
+        trainer.train_iteration(step)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed_fb = time.perf_counter() - t0
+    trainer.optimizers.enabled = True
+    trainer.optimizers.zero_grad_all()
+    if multi:
+        t = torch.tensor([elapsed_fb], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed_fb = float(t.item())
 
     if rank == 0:
         R, S, K = w["R"], w["S"], w["K"]
@@ -210,7 +231,7 @@ def main():
             """achieved = algorithmic units of all timed launches / their summed HIP-event duration."""
             bound, units, unit = model_of(key)
             nl, total_ms = stat["launches"], stat["total_ms"]
-            total_units = units * nsteps if key == "snf_adam_step" else units * nl
+            total_units = stat["units"] if key == "snf_adam_step" else units * nl  # Adam: bytes of the actual launches
             achieved = total_units / (total_ms * 1e-3) / (1e9 if bound == "hbm" else 1e12)
             peak = HBM_PEAK_GBPS if bound == "hbm" else FP32_MATRIX_PEAK_TFLOPS
             return {"kernel": key, "bound": bound, "achieved": round(achieved, 2), "peak": peak, "unit": unit,
@@ -252,6 +273,10 @@ def main():
                                    + ", full-size fp32 tables (T=19), fwd+bwd+RCCL grad mean+fused Adam",
                        "name": args.workload, "rays_per_gpu": R, "parallelism": f"ray-dp{world}"},
             "rays_per_s": world * R * args.steps / elapsed,
+            "feature_samples_per_s": world * R * K * args.steps / elapsed,
+            "fwd_bwd_only": {"value": world * R * S * n_fb / elapsed_fb, "unit": "ray-samples/s",
+                             "ms_per_step": elapsed_fb / n_fb * 1e3, "steps": n_fb,
+                             "note": "same step without the gradient exchange and the Adam pass"},
             "step_algorithmic_GBps": b_step / (ms * 1e-3) / 1e9,
             "step_frac_of_hbm_peak": b_step / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
             "roofline": roofline,
@@ -264,7 +289,7 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

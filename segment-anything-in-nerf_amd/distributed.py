@@ -4,7 +4,9 @@ own rays (seed + rank, samnerf/train.py:87), ONE exchange per step -- the gradie
 The reference wraps the model in DDP but calls the unwrapped module, so its all-reduce never runs
 (SURVEY.md fact 9); here the mean is real: `dist.all_reduce(SUM)` over each flat gradient arena (backend
 "nccl" == RCCL over xGMI on ROCm; "gloo" on CPU for tests) and the 1/world factor folded into the fused Adam
-pass.  Four collectives per step (one per parameter group), the largest being the ~0.8 GB `sam_field` arena.
+pass.  By default the exchange is sharded (`sharded_step`: reduce-scatter -> Adam on 1/world of the arena -> all-gather
+of the parameters), which moves the same bytes over xGMI but divides the HBM-bound optimizer pass by the world size;
+`allreduce_gradients` + a replicated Adam remains available (SNF_SHARDED_OPTIMIZER=0).
 """
 from __future__ import annotations
 
@@ -15,6 +17,15 @@ import torch
 import torch.distributed as dist
 
 
+def _force() -> bool:
+    """SNF_FORCE_COLLECTIVES=1: take the collective code paths even at world size 1 (exercises RCCL on a 1-GPU box)."""
+    return os.environ.get("SNF_FORCE_COLLECTIVES", "0") == "1"
+
+
+def _collectives_on() -> bool:
+    return dist.is_initialized() and (dist.get_world_size() > 1 or _force())
+
+
 def env_world() -> tuple:
     return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 
@@ -22,7 +33,7 @@ def env_world() -> tuple:
 def init_distributed(backend: Optional[str] = None) -> tuple:
     """Initialise torch.distributed from the torchrun environment; returns (rank, local_rank, world_size)."""
     rank, local_rank, world = env_world()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or (_force() and "RANK" in os.environ)) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -35,7 +46,7 @@ def init_distributed(backend: Optional[str] = None) -> tuple:
 
 def allreduce_gradients(grad_buffers: Iterable[torch.Tensor], async_op: bool = False):
     """SUM-all-reduce every flat gradient buffer in place; the caller divides by world size in the Adam pass."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not _collectives_on():
         return []
     handles = []
     for g in grad_buffers:
@@ -45,9 +56,63 @@ def allreduce_gradients(grad_buffers: Iterable[torch.Tensor], async_op: bool = F
     return handles
 
 
+SHARD_ALIGN = 64  # floats: shard boundaries stay on 256-B lines
+
+
+def shard_bounds(n: int, world: int, rank: int) -> tuple:
+    """Split [0, n) into `world` equal 256-B-aligned shards plus a remainder: -> (chunk, bulk, lo, hi) with
+    bulk = world * chunk <= n, this rank's shard [lo, hi) = [rank*chunk, (rank+1)*chunk); [bulk, n) is the remainder
+    every rank keeps replicated (fewer than world * 64 elements)."""
+    chunk = (n // world) // SHARD_ALIGN * SHARD_ALIGN
+    return chunk, chunk * world, rank * chunk, (rank + 1) * chunk
+
+
+def sharded_step(param: torch.Tensor, grad: torch.Tensor, step_fn) -> None:
+    """The exchange step of ray data-parallel training, ZeRO-1 style, on one flat (param, grad) slice pair:
+
+        reduce-scatter(SUM) the gradient -> each rank runs the optimizer on its 1/world shard only
+        (`step_fn(lo, hi)`, which must also re-zero grad[lo:hi]) -> all-gather the updated parameters.
+
+    Same bytes on the xGMI links as the all-reduce it replaces (an all-reduce IS reduce-scatter + all-gather), but the
+    HBM-bound Adam pass and its state traffic shrink by the world size.  The small unaligned remainder is all-reduced
+    and stepped redundantly on every rank.  Gradients outside the own shard are zeroed here.  With world size 1 this is
+    just step_fn(0, n).  The caller folds 1/world into step_fn (gradients arrive SUMMED)."""
+    n = param.numel()
+    if not _collectives_on():
+        step_fn(0, n)
+        return
+    world, rank = dist.get_world_size(), dist.get_rank()
+    chunk, bulk, lo, hi = shard_bounds(n, world, rank)
+    if chunk > 0:
+        if dist.get_backend() == "gloo":  # no reduce_scatter in gloo (CPU tests): all-reduce, then use the own shard
+            dist.all_reduce(grad[:bulk], op=dist.ReduceOp.SUM)
+        else:
+            dist.reduce_scatter_tensor(grad[lo:hi], grad[:bulk], op=dist.ReduceOp.SUM)
+        step_fn(lo, hi)
+        if lo > 0:
+            grad[:lo].zero_()
+        if hi < bulk:
+            grad[hi:bulk].zero_()
+        # in place (input = this rank's slot of the output) on RCCL; gloo needs a separate input buffer
+        dist.all_gather_into_tensor(param[:bulk], param[lo:hi].clone() if dist.get_backend() == "gloo" else param[lo:hi])
+    if bulk < n:
+        dist.all_reduce(grad[bulk:], op=dist.ReduceOp.SUM)
+        step_fn(bulk, n)
+
+
+def gather_sharded_state(buf: torch.Tensor) -> None:
+    """Make a sharded optimizer-state buffer whole on every rank (before a checkpoint)."""
+    if not _collectives_on():
+        return
+    world, rank = dist.get_world_size(), dist.get_rank()
+    chunk, bulk, lo, hi = shard_bounds(buf.numel(), world, rank)
+    if chunk > 0:
+        dist.all_gather_into_tensor(buf[:bulk], buf[lo:hi].clone())
+
+
 def broadcast_parameters(param_buffers: Iterable[torch.Tensor], src: int = 0) -> None:
     """Make every replica start from rank 0's parameters (DDP's constructor-time broadcast)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not _collectives_on():
         return
     for p in param_buffers:
         dist.broadcast(p, src=src)

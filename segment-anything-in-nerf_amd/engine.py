@@ -51,6 +51,10 @@ class Optimizers:
             raise KeyError(f"no optimizer configured for parameter groups {missing}")
         self.config = config
         self.arenas = arenas
+        import os
+        self.sharded = os.environ.get("SNF_SHARDED_OPTIMIZER", "1") == "1"
+        self.enabled = True
+        self.shard_slices: Dict[str, List] = {}  # group -> [(lo, hi)] arena slices stepped separately (set by the trainer)
         self.step_count = {k: 0 for k in arenas}
         self.sched_step = {k: 0 for k in arenas}
         for k, a in arenas.items():
@@ -85,6 +89,48 @@ class Optimizers:
             self.step_count[k] += 1
         ops.adam_step_(a.param[lo:hi], a.grad[lo:hi], a.exp_avg[lo:hi], a.exp_avg_sq[lo:hi], self.lr(k), oc.betas[0],
                        oc.betas[1], oc.eps, self.step_count[k], grad_scale, zero_grad)
+
+    # -- data-parallel exchange + step (distributed.sharded_step) ---------------------------------------------------
+    def exchange_and_step(self, k: str, first: Optional[int] = None, last: Optional[int] = None, count_step: bool = True,
+                          extra: Optional[List[str]] = None) -> None:
+        """Gradient mean over the ranks + Adam for group `k` (or its parameters [first, last)), on the current stream.
+        world == 1: plain fused Adam.  world > 1: reduce-scatter, Adam on this rank's shard, all-gather of the parameters
+        (or all-reduce + replicated Adam when `self.sharded` is off)."""
+        from . import distributed as D
+        if not self.enabled:  # measurement of the forward+backward alone (bench.py): gradients keep accumulating
+            return
+        a, oc = self.arenas[k], self.config[k]["optimizer"]
+        if first is None:
+            lo, hi = 0, a.numel
+        else:
+            names = list(a.offsets)
+            lo = a.offsets[names[first]][0]
+            hi = a.offsets[names[last]][0] if last < len(names) else a.numel
+        if count_step:
+            self.step_count[k] += 1
+        scale, lr, t = 1.0 / D.world_size(), self.lr(k), self.step_count[k]
+        p, g, m, v = a.param[lo:hi], a.grad[lo:hi], a.exp_avg[lo:hi], a.exp_avg_sq[lo:hi]
+
+        def step_fn(s0: int, s1: int) -> None:
+            if s1 > s0:
+                ops.adam_step_(p[s0:s1], g[s0:s1], m[s0:s1], v[s0:s1], lr, oc.betas[0], oc.betas[1], oc.eps, t, scale, True)
+
+        if self.sharded:
+            D.sharded_step(p, g, step_fn)
+        else:
+            D.allreduce_gradients([g])
+            step_fn(0, hi - lo)
+
+    def consolidate_state(self) -> None:
+        """Sharded runs keep each rank's Adam moments only for its shards: gather them before saving a checkpoint.
+        (Slices stepped through `exchange_and_step(first, last)` are sharded per slice; the trainer passes the same slices.)"""
+        from . import distributed as D
+        if not self.sharded or D.world_size() == 1:
+            return
+        for k, a in self.arenas.items():
+            for lo, hi in self.shard_slices.get(k, [(0, a.numel)]):
+                D.gather_sharded_state(a.exp_avg[lo:hi])
+                D.gather_sharded_state(a.exp_avg_sq[lo:hi])
 
     def optimizer_step_all(self, grad_scale: float = 1.0, zero_grad: bool = True) -> None:
         for k in self.arenas:

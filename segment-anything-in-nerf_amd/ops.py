@@ -63,7 +63,8 @@ def kernel_timing_summary() -> dict:
     out = {}
     for name, evs in _TIMING["events"].items():
         tot = sum(e[0].elapsed_time(e[1]) for e in evs)
-        out[name] = {"launches": len(evs), "total_ms": tot, "avg_ms": tot / max(len(evs), 1)}
+        out[name] = {"launches": len(evs), "total_ms": tot, "avg_ms": tot / max(len(evs), 1),
+                     "units": sum(e[3] for e in evs)}
     return out
 
 
@@ -72,12 +73,13 @@ def kernel_timeline(base_event) -> list:
     torch.cuda.synchronize()
     out = []
     for key, evs in _TIMING["events"].items():
-        for a, b, sid in evs:
+        for a, b, sid, _ in evs:
             out.append((base_event.elapsed_time(a), base_event.elapsed_time(b), sid, key))
     return sorted(out)
 
 
-def _launch(name: str, *args, tag: str = "") -> None:
+def _launch(name: str, *args, tag: str = "", units: float = 0.0) -> None:
+    """`units`: algorithmic bytes / flops of this launch when the caller knows them (summed by kernel_timing_summary)."""
     fn = getattr(_L(), name)
     sel = _TIMING["names"]
     key = name + ("/" + tag if tag else "")
@@ -86,7 +88,7 @@ def _launch(name: str, *args, tag: str = "") -> None:
         a.record()
         rc = fn(*args)
         b.record()
-        _TIMING["events"].setdefault(key, []).append((a, b, torch.cuda.current_stream().stream_id))
+        _TIMING["events"].setdefault(key, []).append((a, b, torch.cuda.current_stream().stream_id, units))
     else:
         rc = fn(*args)
     _lib.check(rc, name)
@@ -768,7 +770,8 @@ def adam_step_(p, g, m, v, lr: float, beta1: float, beta2: float, eps: float, st
     for t in (p, g, m, v):
         assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
     _launch("snf_adam_step", _p(p), _p(g), _p(m), _p(v), p.numel(), float(lr), float(beta1), float(beta2),
-                                  float(eps), int(step), float(grad_scale), int(zero_grad), _stream())
+                                  float(eps), int(step), float(grad_scale), int(zero_grad), _stream(),
+            units=32.0 * p.numel())  # p, g, m, v read + p, m, v, g(zero) written
 
 
 @torch.no_grad()

@@ -151,6 +151,12 @@ class Trainer:
         self.pipeline.model.train()
         arenas = self.pipeline.model.build_arenas(with_optimizer_state=True)
         self.optimizers = Optimizers(self.config.optimizers, arenas)
+        if "sam_field" in arenas:  # the two feature heads are stepped (and sharded) as separate slices of one arena
+            a = arenas["sam_field"]
+            names = list(a.offsets)
+            self.optimizers.shard_slices["sam_field"] = [
+                (a.offsets[names[lo_i]][0], a.offsets[names[hi_i]][0] if hi_i < len(names) else a.numel)
+                for lo_i, hi_i in self._head_param_ranges().values() if hi_i > lo_i]
         D.broadcast_parameters([a.param for a in arenas.values()])
         self.callbacks = self.pipeline.get_training_callbacks()
 
@@ -196,9 +202,8 @@ class Trainer:
 
             def nerf_task():  # on the main stream
                 loss_rest.backward()
-                D.allreduce_gradients([opt.arenas[g].grad for g in rest_groups])
                 for g in rest_groups:
-                    opt.optimizer_step(g, scale, True)
+                    opt.exchange_and_step(g)
 
             # host enqueue order (the GPU runs the three tasks concurrently; a task cannot start before the host has
             # issued it): "heads_first" gets the two Adam-heavy head tasks going before the nerf backward is issued
@@ -213,11 +218,9 @@ class Trainer:
                 hi = arena.offsets[names[hi_i]][0] if hi_i < len(names) else arena.numel
                 with torch.cuda.stream(st):
                     lv.backward()
-                    bufs = [arena.grad[lo:hi]] + ([opt.arenas["conv"].grad] if (h == "sam" and "conv" in opt.arenas) else [])
-                    D.allreduce_gradients(bufs)
-                    opt.optimizer_step_params("sam_field", lo_i, hi_i, scale, True, count_step=first_head)
+                    opt.exchange_and_step("sam_field", lo_i, hi_i, count_step=first_head)
                     if h == "sam" and "conv" in opt.arenas:
-                        opt.optimizer_step("conv", scale, True)
+                        opt.exchange_and_step("conv")
                 first_head = False
             if self.enqueue_order == "heads_first":
                 nerf_task()
@@ -235,8 +238,16 @@ class Trainer:
         else:
             loss = sum(loss_dict.values())
             loss.backward()
-            D.allreduce_gradients([a.grad for a in opt.arenas.values()])
-            opt.optimizer_step_all(grad_scale=scale, zero_grad=True)
+            # same arena slices as the three-task schedule (the sharded optimizer's layout must not depend on the schedule)
+            for g in opt.arenas:
+                if g == "sam_field":
+                    first = True
+                    for lo_i, hi_i in self._head_param_ranges().values():
+                        if hi_i > lo_i:
+                            opt.exchange_and_step(g, lo_i, hi_i, count_step=first)
+                            first = False
+                else:
+                    opt.exchange_and_step(g)
             loss = loss.detach()
         opt.scheduler_step_all(step)
         for cb in self.callbacks:
@@ -253,6 +264,7 @@ class Trainer:
     def save_checkpoint(self, path: str, step: int) -> None:
         """trainer.py:379-406: {step, pipeline state_dict, optimizers}."""
         self.synchronize()
+        self.optimizers.consolidate_state()
         torch.save({"step": step, "pipeline": self.pipeline.state_dict(), "optimizers": self.optimizers.state_dict()}, path)
 
     def load_checkpoint(self, path: str) -> int:

@@ -171,3 +171,71 @@ def test_data_parallel_gradient_mean_gloo_world2():
     for p in procs:
         p.join(timeout=60)
     assert res == [(0, True), (1, True)]
+
+
+def _adam_ref(p, g, m, v, lr, b1, b2, eps, t, scale):
+    """torch.optim.Adam's update on flat tensors (the fused kernel's contract), gradient pre-scaled by `scale`."""
+    g = g * scale
+    m.mul_(b1).add_(g, alpha=1 - b1)
+    v.mul_(b2).addcmul_(g, g, value=1 - b2)
+    denom = (v.sqrt() / np.sqrt(1 - b2 ** t)).add_(eps)
+    p.addcdiv_(m, denom, value=-lr / (1 - b1 ** t))
+
+
+def _sharded_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    import samnerf_amd  # noqa: F401
+    from samnerf_amd import distributed as D
+    D.init_distributed(backend="gloo")
+    ok = True
+    for n in (1000, 64 * world, 64 * world * 5 + 17, 30):  # bulk + remainder, exact multiple, remainder only
+        gen = torch.Generator().manual_seed(n)
+        p0 = torch.randn(n, generator=gen)
+        grads = [torch.randn(n, generator=gen) for _ in range(world)]  # what each rank's backward produced
+        # reference: replicated Adam on the mean gradient, three steps
+        pr, mr, vr = p0.clone(), torch.zeros(n), torch.zeros(n)
+        p, g, m, v = p0.clone(), torch.zeros(n), torch.zeros(n), torch.zeros(n)
+        for t in (1, 2, 3):
+            _adam_ref(pr, sum(grads) * (0.5 + t), mr, vr, 1e-2, 0.9, 0.999, 1e-15, t, 1.0 / world)
+            g += grads[rank] * (0.5 + t)  # backward accumulates into the (zeroed) gradient slice
+
+            def step_fn(lo, hi, t=t):
+                _adam_ref(p[lo:hi], g[lo:hi], m[lo:hi], v[lo:hi], 1e-2, 0.9, 0.999, 1e-15, t, 1.0 / world)
+                g[lo:hi].zero_()
+
+            D.sharded_step(p, g, step_fn)
+            ok = ok and bool(torch.count_nonzero(g) == 0)          # the whole gradient slice is re-zeroed
+            ok = ok and torch.allclose(p, pr, rtol=1e-5, atol=1e-6)  # every rank holds the full updated parameters
+        # moments live only in the own shard (+ remainder) until gathered
+        D.gather_sharded_state(m)
+        D.gather_sharded_state(v)
+        ok = ok and torch.allclose(m, mr, rtol=1e-5, atol=1e-6) and torch.allclose(v, vr, rtol=1e-5, atol=1e-6)
+    q.put((rank, bool(ok)))
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_optimizer_exchange_gloo(world):
+    """distributed.sharded_step (reduce-scatter -> Adam on 1/world -> all-gather) equals replicated Adam on the mean."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31000 + (os.getpid() % 2000) + world
+    procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(r, True) for r in range(world)]
+
+
+def test_shard_bounds_cover_the_slice():
+    from samnerf_amd.distributed import shard_bounds
+    for n in (0, 63, 64, 1000, 201_326_592 + 640):
+        for world in (1, 2, 8):
+            chunk, bulk, lo, hi = shard_bounds(n, world, world - 1)
+            assert chunk % 64 == 0 and bulk == chunk * world <= n and n - bulk < world * 64 + 64
+            assert hi == bulk and lo == bulk - chunk

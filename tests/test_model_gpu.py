@@ -180,3 +180,61 @@ def test_patch_render_eval_path_vs_oracle():
     assert md(out["clipseg"], ref["clipseg"]) <= TOL
     rel = (out["depth"].cpu() - ref["depth"]).abs() / ref["depth"].abs()
     assert float(rel.max()) <= 1e-4
+
+
+_RCCL_SCRIPT = r"""
+import copy, json, os, sys
+sys.path.insert(0, os.environ["SNF_ROOT"])
+import torch
+import samnerf_amd
+from samnerf_amd import configs, distributed as D
+rank, local_rank, world = D.init_distributed()
+torch.manual_seed(0)  # the samplers draw their jitter from the default generator
+tc = copy.deepcopy(configs.method_configs["samnerf_distill"])
+tc.pipeline.datamanager.train_num_rays_per_batch = 256
+mc = tc.pipeline.model
+mc.log2_hashmap_size, mc.hashgrid_sizes = 12, (12, 12)
+mc.proposal_net_args_list = [dict(a, log2_hashmap_size=11) for a in mc.proposal_net_args_list]
+trainer = tc.setup(device="cuda")
+trainer.setup()
+dm = trainer.pipeline.datamanager
+fixed = dm.next_train(0)
+dm.next_train = lambda step: (copy.copy(fixed[0]), fixed[1])
+losses = []
+for step in range(6):
+    loss, ld, _ = trainer.train_iteration(step)
+    trainer.synchronize()
+    losses.append(float(sum(v.detach() for v in ld.values())))
+trainer.optimizers.consolidate_state()
+gmax = max(float(a.grad.abs().max()) for a in trainer.optimizers.arenas.values())
+print("RESULT " + json.dumps({"losses": losses, "gmax": gmax, "dist": torch.distributed.is_initialized()}))
+if torch.distributed.is_initialized():
+    torch.distributed.destroy_process_group()
+"""
+
+
+def _run_rccl_script(force: bool):
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SNF_ROOT=root, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29600 + os.getpid() % 300),
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if force:
+        env.update(SNF_FORCE_COLLECTIVES="1", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    else:
+        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "SNF_FORCE_COLLECTIVES"):
+            env.pop(k, None)
+    out = subprocess.run([sys.executable, "-c", _RCCL_SCRIPT], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("RESULT ")][-1]
+    return json.loads(line[len("RESULT "):])
+
+
+def test_sharded_exchange_runs_on_rccl_single_rank():
+    """The data-parallel exchange (in-place reduce_scatter_tensor -> Adam on the shard -> in-place all_gather_into_tensor,
+    all_reduce of the remainder, barrier) on the real RCCL backend: a one-rank process group must reproduce the plain run."""
+    plain = _run_rccl_script(False)
+    forced = _run_rccl_script(True)
+    assert forced["dist"] and not plain["dist"]
+    assert forced["gmax"] == 0.0 and plain["gmax"] == 0.0
+    assert np.allclose(forced["losses"], plain["losses"], rtol=2e-4, atol=1e-6), (forced["losses"], plain["losses"])
+    assert forced["losses"][-1] < forced["losses"][0]
