@@ -238,3 +238,76 @@ def test_sharded_exchange_runs_on_rccl_single_rank():
     assert forced["gmax"] == 0.0 and plain["gmax"] == 0.0
     assert np.allclose(forced["losses"], plain["losses"], rtol=2e-4, atol=1e-6), (forced["losses"], plain["losses"])
     assert forced["losses"][-1] < forced["losses"][0]
+
+
+def test_training_trajectory_and_psnr_match_oracle():
+    """SURVEY 8(d) 'PSNR vs ref': the oracle (CPU autograd + torch.optim.Adam, eps 1e-15, the configs' learning rates) and
+    the HIP trainer start from identical parameters and see identical rays / jitter / targets for N steps; per-step
+    losses must agree to 1e-4 relative and the final eval PSNR to 0.01 dB."""
+    from samnerf_amd import configs
+    from samnerf_amd.interop import load_named_params
+    from samnerf_amd.rays import RayBundle
+    P, S, K, patch, T, R, NSTEP = 32, 32, 8, 4, 12, 256, 8
+    cfg = O.PathConfig(num_proposal_samples=P, num_nerf_samples=S, num_sam_samples=K, patch_size=patch).small(T)
+    params = O.init_params(cfg, seed=11, table_scale=0.05)
+    tc = copy.deepcopy(configs.method_configs["samnerf_distill"])
+    tc.pipeline.datamanager.train_num_rays_per_batch = R
+    mc = tc.pipeline.model
+    mc.num_proposal_samples_per_ray, mc.num_nerf_samples_per_ray, mc.num_sam_samples = (P,), S, K
+    mc.log2_hashmap_size, mc.hashgrid_sizes = min(19, T), (min(19, T),) * 2
+    mc.proposal_net_args_list = [dict(a, log2_hashmap_size=min(17, T)) for a in mc.proposal_net_args_list]
+    trainer = tc.setup(device="cuda")
+    trainer.setup()
+    model = trainer.pipeline.model
+    load_named_params(model, params)
+    # fixed data: analytic colours (so PSNR means something), random feature targets
+    o, d = O.synthetic_rays(R, 21)
+    batch = O.synthetic_batch(cfg, R, 22)
+    batch["image"] = 0.5 + 0.5 * torch.sin(3.0 * d + torch.tensor([0.0, 1.0, 2.0]))
+    gen = torch.Generator().manual_seed(23)
+    jit = [(torch.rand((R, 1), generator=gen), torch.rand((R, 1), generator=gen)) for _ in range(NSTEP)]
+    rb = RayBundle(origins=o.cuda(), directions=d.cuda(), pixel_area=torch.full((R, 1), 1e-6, device="cuda"),
+                   camera_indices=torch.zeros((R, 1), dtype=torch.long, device="cuda"))
+    dev_batch = {k: v.cuda() for k, v in batch.items()}
+    trainer.pipeline.datamanager.next_train = lambda step: (copy.copy(rb), dev_batch)
+    # ---- oracle side
+    ref = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    group_of = lambda n: ("proposal_networks" if n.startswith("prop") else "conv" if n.startswith("conv") else
+                          "sam_field" if n.startswith(("sam", "clipseg")) else "fields")
+    ocfg = trainer.config.optimizers
+    opts = {g: torch.optim.Adam([v for n, v in ref.items() if group_of(n) == g], lr=ocfg[g]["optimizer"].lr,
+                                eps=ocfg[g]["optimizer"].eps, betas=ocfg[g]["optimizer"].betas)
+            for g in trainer.optimizers.arenas}
+    ref_losses, hip_losses = [], []
+    for step in range(NSTEP):
+        t_rand, u_rand = jit[step]
+        for g, opt in opts.items():
+            for pg in opt.param_groups:
+                pg["lr"] = trainer.optimizers.lr(g)
+            opt.zero_grad(set_to_none=True)
+        out = O.forward(ref, cfg, o, d, True, t_rand, u_rand, O.proposal_anneal(step))
+        loss = sum(O.loss_dict(out, batch, cfg).values())
+        loss.backward()
+        for opt in opts.values():
+            opt.step()
+        ref_losses.append(float(loss))
+        model.proposal_sampler.initial_sampler.jitter_override = t_rand.cuda()
+        model.proposal_sampler.pdf_sampler.jitter_override = u_rand.cuda()
+        _, ld, _ = trainer.train_iteration(step)
+        trainer.synchronize()
+        hip_losses.append(float(sum(v.detach() for v in ld.values())))
+    rel = [abs(a - b) / abs(b) for a, b in zip(hip_losses, ref_losses)]
+    assert max(rel) <= 1e-4, (hip_losses, ref_losses)
+    assert ref_losses[-1] < ref_losses[0]
+    # ---- eval PSNR on the training rays (eval mode: deterministic sampling)
+    model.proposal_sampler.initial_sampler.jitter_override = None
+    model.proposal_sampler.pdf_sampler.jitter_override = None
+    model.eval()
+    with torch.no_grad():
+        rgb_hip = model(copy.copy(rb), get_feature=[])["rgb"].cpu()
+        rgb_ref = O.forward({k: v.detach() for k, v in ref.items()}, cfg, o, d, False, get_feature=())["rgb"]
+    psnr = lambda x: float(-10.0 * torch.log10(torch.mean((x - batch["image"]) ** 2)))
+    assert abs(psnr(rgb_hip) - psnr(rgb_ref)) <= 0.01, (psnr(rgb_hip), psnr(rgb_ref))
+    # per-pixel agreement after 8 Adam steps: with eps = 1e-15 an update is ~lr*sign(g) wherever a gradient is tiny, so
+    # fp32 summation-order differences move individual table rows by O(lr); measured 6e-3 max on one pixel
+    assert md(rgb_hip, rgb_ref) <= 2e-2
