@@ -216,6 +216,15 @@ int snf_interlevel(const float* sbins_fine, const float* w_fine, const float* sb
 int snf_distortion(const float* sbins, const float* w, int R, int S, float grad_scale, float* loss_rows,
                    float* grad_w, snf_stream_t stream);
 
+/* ---- a19: L2 losses.  loss = weight * mean over rows r of mean_c (pred - target)^2 ; with nan_skip the mean runs over the
+ * rows whose own mean is not NaN ( = mse_loss(.., 'none').mean(-1).nanmean(), samnerf/sam_model.py:316-328; without it
+ * nn.MSELoss(), nerfstudio/models/nerfacto.py:326 ).  acc: 4 zeroed scratch words (left zeroed); out: {loss, counted rows}.
+ * bwd: dpred = gout * weight * 2 (pred - target) / (C * out[1]), zero for skipped rows; gout, out are device scalars. */
+int snf_rowmse_loss_fwd(const float* pred, const float* target, int R, int C, float weight, int nan_skip, float* acc,
+                        float* out, snf_stream_t stream);
+int snf_rowmse_loss_bwd(const float* pred, const float* target, int R, int C, float weight, int nan_skip,
+                        const float* gout, const float* out, float* dpred, snf_stream_t stream);
+
 /* ---- optimiser side (nerfstudio/engine/optimizers.py:100-147; torch.optim.Adam, eps 1e-15,
  *      samnerf/samconfigs.py:144-161): fused Adam over one contiguous parameter-arena slice.
  * grads are multiplied by grad_scale first (1/world_size for the data-parallel mean) and are

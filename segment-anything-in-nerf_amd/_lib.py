@@ -108,6 +108,8 @@ SIGNATURES = {
     "snf_distortion": [P, P, I, I, F, P, P, P],
     "snf_adam_step": [P, P, P, P, c_int64, F, F, F, F, I, F, I, P],
     "snf_set_adam_launch": [I, I, I],
+    "snf_rowmse_loss_fwd": [P, P, I, I, F, I, P, P, P],
+    "snf_rowmse_loss_bwd": [P, P, I, I, F, I, P, P, P, P],
     "snf_mlp_tiny_supported": [I, I, I],
     "snf_mlp_tiny_fwd": [P, I, P, P, I, I, c_int64, P, P, P],
     "snf_mlp_tiny_bwd": [P, P, I, P, P, P, I, I, c_int64, P, I, P, P, P],

@@ -1,4 +1,5 @@
-// losses.hip -- the two per-ray regularisers of the nerfacto loss, forward + gradient in one pass (gfx950).
+// losses.hip -- the losses of the path (gfx950): the two per-ray regularisers of the nerfacto loss, forward + gradient in one
+// pass, and the L2 rendering / distillation losses (snf_rowmse_loss_*).
 //   snf_interlevel : interlevel_loss / lossfun_outer / outer   (model_components/losses.py:46-120)
 //   snf_distortion : distortion_loss / lossfun_distortion      (model_components/losses.py:124-143)
 // One wavefront per ray; bins, weights and the difference array live in LDS.
@@ -109,6 +110,72 @@ __global__ __launch_bounds__(256) void k_distortion(const float* __restrict__ sb
     if (active && lane == 0) loss_rows[r] = part;
 }
 
+// ---- a19: the L2 (distillation) losses.  nn.MSELoss()(image, rgb)              = mean over all elements
+//           w * mse_loss(pred, target, 'none').mean(-1).nanmean()      = mean over the rows whose own mean is not NaN
+// (samnerf/sam_model.py:316-328, nerfstudio/models/nerfacto.py:326-333).  One wavefront per row; workgroup partials are
+// added to two device scalars, and the LAST workgroup to arrive (atomic ticket) turns them into {loss, row count} -- one
+// launch, no host involvement.  `acc` is 4 caller-zeroed words {sum, count, ticket, -}; they are left zeroed again.
+__global__ __launch_bounds__(256) void k_rowmse_fwd(const float* __restrict__ pred, const float* __restrict__ target, int R,
+                                                    int C, float weight, int nan_skip, float* __restrict__ acc,
+                                                    float* __restrict__ out) {
+    __shared__ float s_sum[4], s_cnt[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float wsum = 0.f, wcnt = 0.f;
+    for (int r = blockIdx.x * 4 + wave; r < R; r += gridDim.x * 4) {
+        const float* p = pred + (size_t)r * C;
+        const float* t = target + (size_t)r * C;
+        float a = 0.f;
+        for (int c = lane; c < C; c += 64) {
+            const float d = p[c] - t[c];
+            a += d * d;
+        }
+        a = wave_sum(a) / (float)C;  // the row's mean squared error
+        const bool skip = nan_skip && (a != a);
+        wsum += skip ? 0.f : a;
+        wcnt += skip ? 0.f : 1.f;
+    }
+    if (lane == 0) { s_sum[wave] = wsum; s_cnt[wave] = wcnt; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(&acc[0], s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3]);
+        atomicAdd(&acc[1], s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3]);
+        __threadfence();
+        const unsigned ticket = atomicAdd(reinterpret_cast<unsigned*>(&acc[2]), 1u);
+        if (ticket == gridDim.x - 1) {  // every partial is in: finish and leave the scratch words zeroed
+            __threadfence();
+            const float total = atomicExch(&acc[0], 0.f), count = atomicExch(&acc[1], 0.f);
+            atomicExch(reinterpret_cast<unsigned*>(&acc[2]), 0u);
+            out[0] = weight * (total / count);  // 0/0 = NaN when every row is skipped, as torch.nanmean does
+            out[1] = count;
+        }
+    }
+}
+
+// dpred[r][c] = gout * weight * 2 (pred - target) / (C * count), zero for the rows nanmean skipped (0 * NaN stays NaN, as in
+// autograd).  `gout` and `count` are device scalars.
+__global__ __launch_bounds__(256) void k_rowmse_bwd(const float* __restrict__ pred, const float* __restrict__ target, int R,
+                                                    int C, float weight, int nan_skip, const float* __restrict__ gout,
+                                                    const float* __restrict__ out, float* __restrict__ dpred) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float k = gout[0] * weight * 2.f / ((float)C * out[1]);
+    for (int r = blockIdx.x * 4 + wave; r < R; r += gridDim.x * 4) {
+        const float* p = pred + (size_t)r * C;
+        const float* t = target + (size_t)r * C;
+        float* d = dpred + (size_t)r * C;
+        float kk = k;
+        if (nan_skip) {  // the forward's row test, recomputed
+            float a = 0.f;
+            for (int c = lane; c < C; c += 64) {
+                const float e = p[c] - t[c];
+                a += e * e;
+            }
+            a = wave_sum(a);
+            if (a != a) kk = 0.f;
+        }
+        for (int c = lane; c < C; c += 64) d[c] = kk * (p[c] - t[c]);
+    }
+}
+
 }  // namespace snf
 
 using namespace snf;
@@ -131,5 +198,27 @@ extern "C" int snf_distortion(const float* sbins, const float* w, int R, int S, 
     hipLaunchKernelGGL(k_distortion, dim3(ceil_div(R, RAYS_PER_BLOCK)), dim3(256), 0, (hipStream_t)stream, sbins, w, R,
                        S, grad_scale, loss_rows, grad_w);
     SNF_LAUNCH_CHECK("snf_distortion");
+    return SNF_OK;
+}
+
+extern "C" int snf_rowmse_loss_fwd(const float* pred, const float* target, int R, int C, float weight, int nan_skip,
+                                   float* acc, float* out, snf_stream_t stream) {
+    SNF_REQUIRE(pred && target && acc && out && R > 0 && C > 0, "snf_rowmse_loss_fwd: bad argument");
+    int blocks = ceil_div(R, 4);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(k_rowmse_fwd, dim3(blocks), dim3(256), 0, (hipStream_t)stream, pred, target, R, C, weight, nan_skip, acc,
+                       out);
+    SNF_LAUNCH_CHECK("snf_rowmse_loss_fwd");
+    return SNF_OK;
+}
+
+extern "C" int snf_rowmse_loss_bwd(const float* pred, const float* target, int R, int C, float weight, int nan_skip,
+                                   const float* gout, const float* out, float* dpred, snf_stream_t stream) {
+    SNF_REQUIRE(pred && target && gout && out && dpred && R > 0 && C > 0, "snf_rowmse_loss_bwd: bad argument");
+    int blocks = ceil_div(R, 4);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_rowmse_bwd, dim3(blocks), dim3(256), 0, (hipStream_t)stream, pred, target, R, C, weight, nan_skip, gout,
+                       out, dpred);
+    SNF_LAUNCH_CHECK("snf_rowmse_loss_bwd");
     return SNF_OK;
 }

@@ -231,7 +231,8 @@ class NerfactoModel(Model):
     @staticmethod
     def psnr(pred: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
         """torchmetrics PeakSignalNoiseRatio(data_range=1.0) (nerfacto.py:232,319)."""
-        return -10.0 * torch.log10(torch.mean((pred - target) ** 2))
+        mse = ops.mse_loss(pred, target) if pred.is_cuda else torch.mean((pred - target) ** 2)
+        return -10.0 * torch.log10(mse)
 
     def get_param_groups(self) -> Dict[str, List[Parameter]]:
         return {"proposal_networks": list(self.proposal_networks.parameters()),
@@ -278,7 +279,7 @@ class NerfactoModel(Model):
     def get_loss_dict(self, outputs, batch, metrics_dict=None):
         loss_dict = {}
         image = batch["image"].to(self.device)
-        loss_dict["rgb_loss"] = self.rgb_loss(image, outputs["rgb"])
+        loss_dict["rgb_loss"] = self.rgb_loss(image, outputs["rgb"])  # ops.mse_loss on the GPU (losses.MSELoss)
         if self.training:
             loss_dict["interlevel_loss"] = self.config.interlevel_loss_mult * interlevel_loss(
                 outputs["weights_list"], outputs["ray_samples_list"])
@@ -454,11 +455,9 @@ class SAMModel(NerfactoModel):
                 if st is not None:
                     batch[head].record_stream(st)
                     with torch.cuda.stream(st):  # stays on the head's stream
-                        unreduced = torch.nn.functional.mse_loss(outputs[head], batch[head], reduction="none")
-                        loss_dict[key] = wgt * unreduced.mean(dim=-1).nanmean()
+                        loss_dict[key] = ops.rowmse_nanmean_loss(outputs[head], batch[head], wgt)
                 else:
-                    unreduced = torch.nn.functional.mse_loss(outputs[head], batch[head], reduction="none")
-                    loss_dict[key] = wgt * unreduced.mean(dim=-1).nanmean()
+                    loss_dict[key] = ops.rowmse_nanmean_loss(outputs[head], batch[head], wgt)
         return loss_dict
 
     @torch.no_grad()

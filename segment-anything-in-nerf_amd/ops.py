@@ -715,6 +715,42 @@ def feature_mean(embeds, w, R: int, K: int) -> torch.Tensor:
 # ---------------------------------------------------------------------------------------------
 # regularisers: value + gradient in one kernel pass each
 # ---------------------------------------------------------------------------------------------
+class _RowMSELoss(torch.autograd.Function):
+    """weight * mean_r mean_c (pred - target)^2, optionally skipping NaN rows (nanmean); one launch per direction."""
+
+    @staticmethod
+    def forward(ctx, pred, target, weight: float, nan_skip: bool):
+        pred, target = _chk(pred, "pred"), _chk(target, "target")
+        assert pred.shape == target.shape
+        C = pred.shape[-1]
+        R = pred.numel() // C
+        acc = torch.zeros((4,), device=pred.device, dtype=torch.float32)
+        out = torch.empty((2,), device=pred.device, dtype=torch.float32)
+        _launch("snf_rowmse_loss_fwd", _p(pred), _p(target), R, C, float(weight), int(nan_skip), _p(acc), _p(out), _stream())
+        ctx.args = (R, C, float(weight), int(nan_skip))
+        ctx.save_for_backward(pred, target, out)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        pred, target, out = ctx.saved_tensors
+        R, C, weight, nan_skip = ctx.args
+        g = g.contiguous()
+        dpred = torch.empty_like(pred)
+        _launch("snf_rowmse_loss_bwd", _p(pred), _p(target), R, C, weight, nan_skip, _p(g), _p(out), _p(dpred), _stream())
+        return dpred, None, None, None
+
+
+def mse_loss(pred, target, weight: float = 1.0) -> torch.Tensor:
+    """weight * nn.MSELoss()(pred, target) (mean over all elements; NaN propagates)."""
+    return _RowMSELoss.apply(pred, target.detach(), weight, False)
+
+
+def rowmse_nanmean_loss(pred, target, weight: float = 1.0) -> torch.Tensor:
+    """weight * mse_loss(pred, target, reduction='none').mean(-1).nanmean() (samnerf/sam_model.py:316-328)."""
+    return _RowMSELoss.apply(pred, target.detach(), weight, True)
+
+
 class _Interlevel(torch.autograd.Function):
     @staticmethod
     def forward(ctx, w_prop, sbins_prop, sbins_fine, w_fine):

@@ -445,3 +445,35 @@ def test_mlp_tiny_vs_torch(N):
     for a, b, name in zip(dev, ref, ("x", "w0", "w1")):
         err = float((a.grad.cpu().double() - b.grad).abs().max())
         assert err <= 1e-5 * max(float(b.grad.abs().max()), 1.0), (name, err)
+
+
+@pytest.mark.parametrize("R,C", [(4096, 3), (256, 256), (4096, 192), (5, 7)])
+def test_rowmse_losses_vs_torch(R, C):
+    """a19 (csrc/losses.hip): nn.MSELoss and mse_loss('none').mean(-1).nanmean() incl. NaN target rows, value + gradient."""
+    m = ops()
+    g = torch.Generator().manual_seed(R + C)
+    pred = torch.randn((R, C), generator=g)
+    target = torch.randn((R, C), generator=g)
+    for nan_rows in (False, True):
+        t = target.clone()
+        if nan_rows:
+            t[1] = float("nan")
+            t[R - 1, C - 1] = float("nan")
+        pr = pred.clone().double().requires_grad_(True)
+        ref = 0.7 * torch.nn.functional.mse_loss(pr, t.double(), reduction="none").mean(dim=-1).nanmean()
+        (ref * 1.5).backward()
+        pd = pred.clone().cuda().requires_grad_(True)
+        out = m.rowmse_nanmean_loss(pd, t.cuda(), 0.7)
+        (out * 1.5).backward()
+        assert abs(float(out) - float(ref)) <= 2e-6 * max(1.0, abs(float(ref)))
+        gd, gr = pd.grad.cpu().double(), pr.grad
+        assert torch.equal(torch.isnan(gd), torch.isnan(gr))  # 0 * NaN rows stay NaN, exactly as in autograd
+        assert float((torch.nan_to_num(gd) - torch.nan_to_num(gr)).abs().max()) <= 1e-7
+    pr = pred.clone().double().requires_grad_(True)
+    ref = torch.nn.functional.mse_loss(pr, target.double())
+    ref.backward()
+    pd = pred.clone().cuda().requires_grad_(True)
+    out = m.mse_loss(pd, target.cuda())
+    out.backward()
+    assert abs(float(out) - float(ref)) <= 2e-6 * max(1.0, abs(float(ref)))
+    assert float((pd.grad.cpu().double() - pr.grad).abs().max()) <= 1e-7
