@@ -121,18 +121,24 @@ __global__ __launch_bounds__(256) void k_rowmse_fwd(const float* __restrict__ pr
     __shared__ float s_sum[4], s_cnt[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float wsum = 0.f, wcnt = 0.f;
-    for (int r = blockIdx.x * 4 + wave; r < R; r += gridDim.x * 4) {
-        const float* p = pred + (size_t)r * C;
-        const float* t = target + (size_t)r * C;
-        float a = 0.f;
+    // four rows per wave and trip: their loads are independent, so one memory latency covers all four
+    for (int r0 = (blockIdx.x * 4 + wave) * 4; r0 < R; r0 += gridDim.x * 16) {
+        float a[4] = {0.f, 0.f, 0.f, 0.f};
         for (int c = lane; c < C; c += 64) {
-            const float d = p[c] - t[c];
-            a += d * d;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = min(r0 + q, R - 1);
+                const float d = pred[(size_t)r * C + c] - target[(size_t)r * C + c];
+                a[q] += d * d;
+            }
         }
-        a = wave_sum(a) / (float)C;  // the row's mean squared error
-        const bool skip = nan_skip && (a != a);
-        wsum += skip ? 0.f : a;
-        wcnt += skip ? 0.f : 1.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float m = wave_sum(a[q]) / (float)C;  // the row's mean squared error
+            const bool skip = (r0 + q >= R) || (nan_skip && (m != m));
+            wsum += skip ? 0.f : m;
+            wcnt += skip ? 0.f : 1.f;
+        }
     }
     if (lane == 0) { s_sum[wave] = wsum; s_cnt[wave] = wcnt; }
     __syncthreads();
@@ -204,8 +210,9 @@ extern "C" int snf_distortion(const float* sbins, const float* w, int R, int S, 
 extern "C" int snf_rowmse_loss_fwd(const float* pred, const float* target, int R, int C, float weight, int nan_skip,
                                    float* acc, float* out, snf_stream_t stream) {
     SNF_REQUIRE(pred && target && acc && out && R > 0 && C > 0, "snf_rowmse_loss_fwd: bad argument");
-    int blocks = ceil_div(R, 4);
-    if (blocks > 1024) blocks = 1024;
+    // few workgroups: every one of them ends with three same-address device atomics, which serialise (~10 ns each)
+    int blocks = ceil_div(R, 16);
+    if (blocks > 64) blocks = 64;
     hipLaunchKernelGGL(k_rowmse_fwd, dim3(blocks), dim3(256), 0, (hipStream_t)stream, pred, target, R, C, weight, nan_skip, acc,
                        out);
     SNF_LAUNCH_CHECK("snf_rowmse_loss_fwd");
