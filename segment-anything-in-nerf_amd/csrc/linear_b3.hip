@@ -10,6 +10,7 @@
 // Tile: 128 rows x 64 cols x 32 k per workgroup (4 waves x 32 rows x two 32x32 accumulators), operands in LDS as
 // row-major bf16 planes [row][k] with an 80-byte pitch: one conflict-free ds_read_b128 per operand fragment.
 #include "common.hpp"
+#include <stdlib.h>
 
 namespace snf {
 
@@ -87,12 +88,16 @@ __device__ __forceinline__ float4 b3_load_b(const float* __restrict__ B, int r, 
 
 // C[M,Nc] = op(A)[M,K] * B   (BT: B = W[Nc,K] row-major, i.e. forward;  !BT: B = W[K,Nc] row-major, i.e. data gradient)
 // Requirements (checked by the host wrapper): K % 4 == 0, Nc % 4 == 0, leading dimensions % 4 == 0, 16-byte aligned bases.
-template <bool BT, bool DERIV>
+// BN = columns per workgroup (64 / 128 / 192 / 256): a wave owns 32 rows x BN columns = BN/32 accumulators.  Wider tiles
+// split every A element fewer times and run more MFMAs per staged k-tile; measured on the head shapes 128 is the best
+// (+10 % over 64), 192 / 256 lose it again to register pressure and two-workgroup occupancy (SNF_B3_BN overrides the cap).
+template <bool BT, bool DERIV, int BN>
 __global__ __launch_bounds__(256) void k_gemm_rows_b3(const float* __restrict__ A, const float* __restrict__ Aux,
                                                       const float* __restrict__ B, const float* __restrict__ bias, int M,
                                                       int K, int Nc, int lda, int ldaux, int ldb, int ldc, int act_in,
                                                       int act_out, float* __restrict__ C, int ksplit = 0,
                                                       long long c_split_stride = 0) {
+    constexpr int NB = BN / 32;  // accumulators per wave; also B-staging passes per thread
     if constexpr (BT && !DERIV) {
         if (ksplit > 0) {  // split-K slice z (see k_gemm_rows)
             const int kb = blockIdx.z * ksplit;
@@ -102,28 +107,30 @@ __global__ __launch_bounds__(256) void k_gemm_rows_b3(const float* __restrict__ 
     }
     __shared__ __attribute__((aligned(16))) uint16_t Ah[B3_BM * B3_PITCH];
     __shared__ __attribute__((aligned(16))) uint16_t Al[B3_BM * B3_PITCH];
-    __shared__ __attribute__((aligned(16))) uint16_t Bh[B3_BN * B3_PITCH];
-    __shared__ __attribute__((aligned(16))) uint16_t Bl[B3_BN * B3_PITCH];
+    __shared__ __attribute__((aligned(16))) uint16_t Bh[BN * B3_PITCH];
+    __shared__ __attribute__((aligned(16))) uint16_t Bl[BN * B3_PITCH];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, half = lane >> 5;
-    const int row0 = blockIdx.x * B3_BM, col0 = blockIdx.y * B3_BN;
-    const bool two = (col0 + 32) < Nc;
-    f32x16 acc0, acc1;
+    const int row0 = blockIdx.x * B3_BM, col0 = blockIdx.y * BN;
+    f32x16 acc[NB];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
-    const int a_kq = tid & 7, a_r = tid >> 3;   // 8 k-quads x 32 rows (A: 4 passes, B^T: 2 passes)
-    const int b_jq = tid & 15, b_k = tid >> 4;  // B as [K, Nc]: 16 col-quads x 16 k, 2 passes
-    float4 av[4], bv[2];
+    for (int t = 0; t < NB; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+    const int a_kq = tid & 7, a_r = tid >> 3;  // 8 k-quads x 32 rows (A: 4 passes, B^T: NB passes)
+    constexpr int BQ = BN / 4;                  // B as [K, Nc]: BQ col-quads x (256 / BQ) k rows per pass, NB passes
+    const int b_jq = tid % BQ, b_k = tid / BQ;
+    float4 av[4], bv[NB];
     auto fetch = [&](int k0) {
 #pragma unroll
         for (int p = 0; p < 4; ++p)
             av[p] = b3_load_a<DERIV>(A, Aux, row0 + a_r + 32 * p, k0 + a_kq * 4, M, K, lda, ldaux, act_in);
         if constexpr (BT) {
 #pragma unroll
-            for (int p = 0; p < 2; ++p) bv[p] = b3_load_b(B, col0 + a_r + 32 * p, k0 + a_kq * 4, Nc, K, ldb);
+            for (int p = 0; p < NB; ++p) bv[p] = b3_load_b(B, col0 + a_r + 32 * p, k0 + a_kq * 4, Nc, K, ldb);
         } else {
 #pragma unroll
-            for (int p = 0; p < 2; ++p) bv[p] = b3_load_b(B, k0 + b_k + 16 * p, col0 + b_jq * 4, K, Nc, ldb);
+            for (int p = 0; p < NB; ++p) bv[p] = b3_load_b(B, k0 + b_k + (256 / BQ) * p, col0 + b_jq * 4, K, Nc, ldb);
         }
     };
     fetch(0);
@@ -139,7 +146,7 @@ __global__ __launch_bounds__(256) void k_gemm_rows_b3(const float* __restrict__ 
         }
         if constexpr (BT) {
 #pragma unroll
-            for (int p = 0; p < 2; ++p) {
+            for (int p = 0; p < NB; ++p) {
                 uint2 hi, lo;
                 split4(bv[p], hi, lo);
                 const int off = (a_r + 32 * p) * B3_PITCH + a_kq * 4;
@@ -149,8 +156,8 @@ __global__ __launch_bounds__(256) void k_gemm_rows_b3(const float* __restrict__ 
         } else {
             // transpose while staging: W[k][j..j+3] -> B planes [j][k]
 #pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                const int kk = b_k + 16 * p;
+            for (int p = 0; p < NB; ++p) {
+                const int kk = b_k + (256 / BQ) * p;
                 const float e[4] = {bv[p].x, bv[p].y, bv[p].z, bv[p].w};
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -168,40 +175,47 @@ __global__ __launch_bounds__(256) void k_gemm_rows_b3(const float* __restrict__ 
             const int ko = ks * 16 + half * 8;
             const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&Ah[(wave * 32 + li) * B3_PITCH + ko]);
             const bf16x8 al = *reinterpret_cast<const bf16x8*>(&Al[(wave * 32 + li) * B3_PITCH + ko]);
-            const bf16x8 bh0 = *reinterpret_cast<const bf16x8*>(&Bh[li * B3_PITCH + ko]);
-            const bf16x8 bl0 = *reinterpret_cast<const bf16x8*>(&Bl[li * B3_PITCH + ko]);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh0, acc0, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl0, acc0, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh0, acc0, 0, 0, 0);
-            if (two) {
-                const bf16x8 bh1 = *reinterpret_cast<const bf16x8*>(&Bh[(32 + li) * B3_PITCH + ko]);
-                const bf16x8 bl1 = *reinterpret_cast<const bf16x8*>(&Bl[(32 + li) * B3_PITCH + ko]);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh1, acc1, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl1, acc1, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh1, acc1, 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NB; ++t) {
+                if (col0 + 32 * t < Nc) {  // workgroup-uniform
+                    const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&Bh[(32 * t + li) * B3_PITCH + ko]);
+                    const bf16x8 bl = *reinterpret_cast<const bf16x8*>(&Bl[(32 * t + li) * B3_PITCH + ko]);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[t], 0, 0, 0);
+                }
             }
         }
     }
     // epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
 #pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-        const int row = row0 + wave * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half;
-        if (row < M) {
-            const int c0 = col0 + li;
-            if (c0 < Nc) {
-                float v = acc0[reg];
-                if (bias) v += bias[c0];
-                C[(size_t)row * ldc + c0] = b3_act_apply(v, act_out);
-            }
-            const int c1 = c0 + 32;
-            if (two && c1 < Nc) {
-                float v = acc1[reg];
-                if (bias) v += bias[c1];
-                C[(size_t)row * ldc + c1] = b3_act_apply(v, act_out);
+    for (int t = 0; t < NB; ++t) {
+        const int c = col0 + 32 * t + li;
+        if (c < Nc) {
+            const float bb = bias ? bias[c] : 0.f;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int row = row0 + wave * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half;
+                if (row < M) C[(size_t)row * ldc + c] = b3_act_apply(acc[t][reg] + bb, act_out);
             }
         }
     }
 }
+
+// widest column tile that still leaves >= 256 workgroups (one per CU); 64 otherwise
+static int b3_pick_bn(int M, int Nc) {
+    const int row_tiles = ceil_div(M, B3_BM);
+    static const int cap = getenv("SNF_B3_BN") ? atoi(getenv("SNF_B3_BN")) : 128;
+    if (row_tiles >= 256) {
+        if (Nc > 192 && cap >= 256) return 256;
+        if (Nc > 128 && cap >= 192) return 192;
+        if (Nc > 64 && cap >= 128) return 128;
+    }
+    return 64;
+}
+
+#define B3_LAUNCH(BT_, DERIV_, BN_, grid, st, ...) \
+    hipLaunchKernelGGL((k_gemm_rows_b3<BT_, DERIV_, BN_>), grid, dim3(256), 0, (hipStream_t)st, __VA_ARGS__)
 
 static int g_gemm_mode = 1;  // 1: bf16x3 for the wide layers (default), 0: exact fp32 everywhere
 
@@ -224,9 +238,13 @@ int snf::b3_try_fwd(const float* X, const float* W, const float* bias, int N, in
                               int act, float* Y, snf_stream_t stream) {
     if (!b3_enabled() || I < 128 || O < 64 || (I % 4) || (O % 4) || (ldx % 4) || ((uintptr_t)X & 15) || ((uintptr_t)W & 15))
         return 0;
-    dim3 grid(ceil_div(N, B3_BM), ceil_div(O, B3_BN));
-    hipLaunchKernelGGL((k_gemm_rows_b3<true, false>), grid, dim3(256), 0, (hipStream_t)stream, X, (const float*)nullptr, W,
-                       bias, N, I, O, ldx, 0, I, ldy, SNF_ACT_NONE, act, Y);
+    const int bn = b3_pick_bn(N, O);
+    dim3 grid(ceil_div(N, B3_BM), ceil_div(O, bn));
+    const float* none = nullptr;
+    if (bn == 256) B3_LAUNCH(true, false, 256, grid, stream, X, none, W, bias, N, I, O, ldx, 0, I, ldy, SNF_ACT_NONE, act, Y);
+    else if (bn == 192) B3_LAUNCH(true, false, 192, grid, stream, X, none, W, bias, N, I, O, ldx, 0, I, ldy, SNF_ACT_NONE, act, Y);
+    else if (bn == 128) B3_LAUNCH(true, false, 128, grid, stream, X, none, W, bias, N, I, O, ldx, 0, I, ldy, SNF_ACT_NONE, act, Y);
+    else B3_LAUNCH(true, false, 64, grid, stream, X, none, W, bias, N, I, O, ldx, 0, I, ldy, SNF_ACT_NONE, act, Y);
     return 1;
 }
 
@@ -235,9 +253,9 @@ int snf::b3_try_fwd_splitk(const float* X, const float* W, int N, int I, int O, 
     if (!b3_enabled() || I < 128 || O < 64 || (I % 4) || (O % 4) || (ldx % 4) || ((uintptr_t)X & 15) || ((uintptr_t)W & 15))
         return 0;
     dim3 grid(ceil_div(N, B3_BM), ceil_div(O, B3_BN), splits);
-    hipLaunchKernelGGL((k_gemm_rows_b3<true, false>), grid, dim3(256), 0, (hipStream_t)stream, X, (const float*)nullptr, W,
-                       (const float*)nullptr, N, I, O, ldx, 0, I, O, SNF_ACT_NONE, SNF_ACT_NONE, P, ksplit,
-                       (long long)N * O);
+    const float* none = nullptr;
+    B3_LAUNCH(true, false, 64, grid, stream, X, none, W, none, N, I, O, ldx, 0, I, O, SNF_ACT_NONE, SNF_ACT_NONE, P, ksplit,
+              (long long)N * O);
     return 1;
 }
 
@@ -246,8 +264,12 @@ int snf::b3_try_bwd_data(const float* dY, const float* Y, const float* W, int N,
     if (!b3_enabled() || O < 128 || I < 64 || (I % 4) || (O % 4) || (lddy % 4) || ((uintptr_t)dY & 15) ||
         ((uintptr_t)W & 15) || (act != SNF_ACT_NONE && ((ldy % 4) || ((uintptr_t)Y & 15))))
         return 0;
-    dim3 grid(ceil_div(N, B3_BM), ceil_div(I, B3_BN));
-    hipLaunchKernelGGL((k_gemm_rows_b3<false, true>), grid, dim3(256), 0, (hipStream_t)stream, dY, Y, W,
-                       (const float*)nullptr, N, O, I, lddy, ldy, I, lddx, act, SNF_ACT_NONE, dX);
+    const int bn = b3_pick_bn(N, I);
+    dim3 grid(ceil_div(N, B3_BM), ceil_div(I, bn));
+    const float* none = nullptr;
+    if (bn == 256) B3_LAUNCH(false, true, 256, grid, stream, dY, Y, W, none, N, O, I, lddy, ldy, I, lddx, act, SNF_ACT_NONE, dX);
+    else if (bn == 192) B3_LAUNCH(false, true, 192, grid, stream, dY, Y, W, none, N, O, I, lddy, ldy, I, lddx, act, SNF_ACT_NONE, dX);
+    else if (bn == 128) B3_LAUNCH(false, true, 128, grid, stream, dY, Y, W, none, N, O, I, lddy, ldy, I, lddx, act, SNF_ACT_NONE, dX);
+    else B3_LAUNCH(false, true, 64, grid, stream, dY, Y, W, none, N, O, I, lddy, ldy, I, lddx, act, SNF_ACT_NONE, dX);
     return 1;
 }
