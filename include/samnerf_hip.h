@@ -225,6 +225,23 @@ int snf_rowmse_loss_fwd(const float* pred, const float* target, int R, int C, fl
 int snf_rowmse_loss_bwd(const float* pred, const float* target, int R, int C, float weight, int nan_skip,
                         const float* gout, const float* out, float* dpred, snf_stream_t stream);
 
+/* ---- the batch builder in front of the path (images, feature maps and cameras resident in HBM).
+ * snf_pixel_indices: PixelSampler (patch == 1: u [B,3]) / PatchPixelSampler (u [B/patch^2,3]) .sample_method without a
+ *   mask (nerfstudio/data/pixel_samplers.py:50-75,246-300): u ~ U[0,1) -> indices [B,3] int64 (camera, row, col).
+ * snf_generate_rays: RayGenerator.forward + pinhole Cameras._generate_rays_from_coords, camera optimizer off, no
+ *   distortion (model_components/ray_generators.py:44-63, cameras/cameras.py:576-722): c2w [N,3,4], intrinsics [N,4] =
+ *   fx, fy, cx, cy -> origins/directions [R,3], pixel_area [R], camera_indices [R] int64.
+ * snf_gather_nearest: FeatureDataloader.__call__ (samnerf/data/feature_loader.py:49-56): out[b] = features[cam,
+ *   long(row * fh/H), long(col * fw/W)] for the points b*point_stride + point_offset of `points` [.,3]
+ *   (stride p^2, offset (p/2)*p + p/2 = the patch centres of samnerf/datamanager.py:106-110; fh = H, fw = W gathers the
+ *   image pixels themselves).  features [N, fh, fw, C] fp32. */
+int snf_pixel_indices(const float* u, int B, int patch, int num_images, int H, int W, int64_t* indices,
+                      snf_stream_t stream);
+int snf_generate_rays(const int64_t* indices, int R, const float* c2w, const float* intrinsics, int num_cameras,
+                      float* origins, float* directions, float* pixel_area, int64_t* camera_indices, snf_stream_t stream);
+int snf_gather_nearest(const int64_t* points, int B, int point_stride, int point_offset, const float* features,
+                       int num_images, int fh, int fw, int C, int H, int W, float* out, snf_stream_t stream);
+
 /* ---- optimiser side (nerfstudio/engine/optimizers.py:100-147; torch.optim.Adam, eps 1e-15,
  *      samnerf/samconfigs.py:144-161): fused Adam over one contiguous parameter-arena slice.
  * grads are multiplied by grad_scale first (1/world_size for the data-parallel mean) and are

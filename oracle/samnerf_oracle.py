@@ -653,3 +653,68 @@ def render_camera(params, cfg: PathConfig, origins: torch.Tensor, directions: to
                          for i in range(0, co.shape[0], chunk)]
                 out["clipseg"] = torch.cat(parts).view(32, 32, -1)
     return out
+
+
+# --------------------------------------------------------------------------------------------
+# the batch builder in front of the hot path
+#   nerfstudio/data/pixel_samplers.py:50-75,246-300 ; nerfstudio/model_components/ray_generators.py:44-63 ;
+#   nerfstudio/cameras/cameras.py:284-311,576-722 (pinhole branch) ; samnerf/data/feature_loader.py:49-56 ;
+#   samnerf/datamanager.py:97-117
+# --------------------------------------------------------------------------------------------
+def pixel_indices(u: torch.Tensor, num_images: int, H: int, W: int) -> torch.Tensor:
+    """PixelSampler.sample_method without a mask: u [B,3] ~ U[0,1) -> (camera, row, col) int64."""
+    return torch.floor(u * torch.tensor([num_images, H, W])).long()
+
+
+def patch_pixel_indices(u: torch.Tensor, num_images: int, H: int, W: int, p: int) -> torch.Tensor:
+    """PatchPixelSampler.sample_method: u [B/p^2,3] -> top-left corners U * (n, H-p, W-p), + (yy, xx), floor."""
+    n = u.shape[0]
+    ind = u * torch.tensor([num_images, H - p, W - p])
+    ind = ind.view(n, 1, 1, 3).broadcast_to(n, p, p, 3).clone()
+    yys, xxs = torch.meshgrid(torch.arange(p), torch.arange(p), indexing="ij")
+    ind[:, ..., 1] += yys
+    ind[:, ..., 2] += xxs
+    return torch.floor(ind).long().flatten(0, 2)
+
+
+def generate_rays(indices: torch.Tensor, c2w: torch.Tensor, fx, fy, cx, cy):
+    """RayGenerator.forward + the PERSPECTIVE branch of Cameras._generate_rays_from_coords (no distortion, no camera
+    optimizer).  indices [R,3] (camera, row, col); c2w [N,3,4]; fx, fy, cx, cy [N].
+    -> origins [R,3], directions [R,3] (unit), pixel_area [R,1], camera_indices [R,1]."""
+    c, yi, xi = indices[:, 0], indices[:, 1], indices[:, 2]
+    y, x = yi + 0.5, xi + 0.5  # image_coords: pixel centres (cameras.py:303-304)
+    fx_, fy_, cx_, cy_ = fx[c], fy[c], cx[c], cy[c]
+    coord = torch.stack([(x - cx_) / fx_, -(y - cy_) / fy_], -1)
+    coord_x = torch.stack([(x - cx_ + 1) / fx_, -(y - cy_) / fy_], -1)
+    coord_y = torch.stack([(x - cx_) / fx_, -(y - cy_ + 1) / fy_], -1)
+    cs = torch.stack([coord, coord_x, coord_y], 0)  # [3,R,2]
+    d = torch.empty(cs.shape[:-1] + (3,))
+    d[..., 0], d[..., 1], d[..., 2] = cs[..., 0], cs[..., 1], -1.0
+    rot = c2w[c][..., :3, :3]
+    d = torch.sum(d[..., None, :] * rot, dim=-1)
+    eps = torch.tensor([np.finfo(float).eps * 4.0]).to(d)
+    d = d / torch.maximum(torch.linalg.vector_norm(d, dim=-1, keepdims=True), eps)  # normalize_with_norm
+    dx = torch.sqrt(torch.sum((d[0] - d[1]) ** 2, dim=-1))
+    dy = torch.sqrt(torch.sum((d[0] - d[2]) ** 2, dim=-1))
+    return c2w[c][..., :3, 3], d[0], (dx * dy)[..., None], c[:, None]
+
+
+def gather_features(features: torch.Tensor, img_points: torch.Tensor, image_shape) -> torch.Tensor:
+    """FeatureDataloader.__call__: nearest lookup features[cam, long(row * fh/H), long(col * fw/W)]."""
+    scale = (features.shape[1] / image_shape[0], features.shape[2] / image_shape[1])
+    xi, yi = (img_points[:, 1] * scale[0]).long(), (img_points[:, 2] * scale[1]).long()
+    return features[img_points[:, 0].long(), xi, yi]
+
+
+def build_batch(u, images, c2w, fx, fy, cx, cy, patch: int, sam_features=None, clipseg_features=None):
+    """SAMDataManager.next_train (samnerf/datamanager.py:97-117) from the random draws `u`:
+    images [N,H,W,3]; returns (origins, directions, pixel_area, camera_indices), batch{image, indices, sam, clipseg}."""
+    N, H, W = images.shape[:3]
+    ind = patch_pixel_indices(u, N, H, W, patch) if patch > 1 else pixel_indices(u, N, H, W)
+    batch = {"image": images[ind[:, 0], ind[:, 1], ind[:, 2]], "indices": ind}
+    if sam_features is not None:
+        centers = ind.reshape(-1, patch, patch, 3)[:, patch // 2, patch // 2, :]
+        batch["sam"] = gather_features(sam_features, centers, (H, W))
+    if clipseg_features is not None:
+        batch["clipseg"] = gather_features(clipseg_features, ind, (H, W))
+    return generate_rays(ind, c2w, fx, fy, cx, cy), batch

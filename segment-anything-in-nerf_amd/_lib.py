@@ -20,7 +20,7 @@ INCLUDE = os.path.join(ROOT, "include")
 LIB_DIR = os.path.join(PKG_DIR, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libsamnerf_hip.so")
 HASH_PATH = LIB_PATH + ".srchash"
-SOURCES = ["sampling.hip", "hashgrid.hip", "linear.hip", "linear_b3.hip", "mlp_chain.hip", "mlp_tiny.hip", "patchconv.hip", "render.hip", "losses.hip", "optim.hip"]
+SOURCES = ["batch.hip", "sampling.hip", "hashgrid.hip", "linear.hip", "linear_b3.hip", "mlp_chain.hip", "mlp_tiny.hip", "patchconv.hip", "render.hip", "losses.hip", "optim.hip"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics"]
 
 
@@ -108,6 +108,9 @@ SIGNATURES = {
     "snf_distortion": [P, P, I, I, F, P, P, P],
     "snf_adam_step": [P, P, P, P, c_int64, F, F, F, F, I, F, I, P],
     "snf_set_adam_launch": [I, I, I],
+    "snf_pixel_indices": [P, I, I, I, I, I, P, P],
+    "snf_generate_rays": [P, I, P, P, I, P, P, P, P, P],
+    "snf_gather_nearest": [P, I, I, I, P, I, I, I, I, I, I, P, P],
     "snf_rowmse_loss_fwd": [P, P, I, I, F, I, P, P, P],
     "snf_rowmse_loss_bwd": [P, P, I, I, F, I, P, P, P, P],
     "snf_mlp_tiny_supported": [I, I, I],

@@ -10,7 +10,8 @@ script aborts on a mismatch), which is how the oracle is pinned.  The reference 
 travels: fixtures contain only numeric arrays and scalar hyper-parameters.
 
 The two packages under tests/golden/_stubs (torchtyping, nerfacc) only satisfy import statements
-of names the reference never executes on this path.
+of names the reference never executes on this path (fx_batch_builder adds empty cv2 / torchvision modules likewise).
+`python tests/golden/make_golden.py fx_batch_builder` regenerates a single fixture.
 """
 import os
 import sys
@@ -492,9 +493,97 @@ def fx_ministep():
         loss=loss, **arrays)
 
 
+# ---------------------------------------------------------------------------------------------
+def fx_batch_builder():
+    """PatchPixelSampler / PixelSampler, RayGenerator + Cameras (pinhole), FeatureDataloader.
+    cameras.py imports cv2 / torchvision at module level only: empty stand-in modules satisfy the import."""
+    import types
+    for name in ("cv2", "torchvision", "torchvision.transforms", "torchvision.transforms.functional"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    from nerfstudio.cameras.cameras import Cameras, CameraType
+    from nerfstudio.data.pixel_samplers import PatchPixelSampler, PixelSampler
+    from samnerf.data.feature_loader import FeatureDataloader
+
+    N, H, W, p, R = 3, 42, 65, 4, 256
+    g = torch.Generator().manual_seed(3)
+    # LLFF-style forward-facing poses: small rotations about x/y, translations in a 0.5 box, random intrinsics per camera
+    ang = (torch.rand((N, 2), generator=g) - 0.5) * 0.6
+    c2w = torch.zeros((N, 3, 4))
+    for i in range(N):
+        ca, sa, cb, sb = torch.cos(ang[i, 0]), torch.sin(ang[i, 0]), torch.cos(ang[i, 1]), torch.sin(ang[i, 1])
+        rx = torch.tensor([[1, 0, 0], [0, ca, -sa], [0, sa, ca]])
+        ry = torch.tensor([[cb, 0, sb], [0, 1, 0], [-sb, 0, cb]])
+        c2w[i, :, :3] = ry @ rx
+        c2w[i, :, 3] = (torch.rand((3,), generator=g) - 0.5)
+    fx = 50.0 + 20.0 * torch.rand((N,), generator=g)
+    fy = 50.0 + 20.0 * torch.rand((N,), generator=g)
+    cx = W / 2 + torch.rand((N,), generator=g)
+    cy = H / 2 + torch.rand((N,), generator=g)
+    cams = Cameras(camera_to_worlds=c2w, fx=fx, fy=fy, cx=cx, cy=cy, width=W, height=H,
+                   camera_type=CameraType.PERSPECTIVE)
+    images = torch.rand((N, H, W, 3), generator=g)
+    fh, fw = 42, 64  # SAM map of a 42x65-ish image (get_feature_size)
+    sam = torch.randn((N, fh, fw, 8), generator=g)       # 8 channels stand in for 256: the index math is what is pinned
+    clip = torch.randn((N, 32, 32, 6), generator=g)
+
+    # --- samplers: seed, draw u ourselves, re-seed, let the reference draw the same numbers
+    torch.manual_seed(11)
+    u_patch = torch.rand((R // (p * p), 3))
+    torch.manual_seed(11)
+    ref_patch = PatchPixelSampler(R, patch_size=p).sample_method(R, N, H, W)
+    check("patch_pixel_indices", O.patch_pixel_indices(u_patch, N, H, W, p), ref_patch)
+    torch.manual_seed(12)
+    u_pix = torch.rand((R, 3))
+    torch.manual_seed(12)
+    ref_pix = PixelSampler(R).sample_method(R, N, H, W)
+    check("pixel_indices", O.pixel_indices(u_pix, N, H, W), ref_pix)
+    # full collate path (image gather + absolute camera indices)
+    torch.manual_seed(11)
+    pb = PatchPixelSampler(R, patch_size=p).sample({"image": images, "image_idx": torch.arange(N)})
+    check("collate indices", pb["indices"], ref_patch)
+    # --- rays
+    # RayGenerator.forward (ray_generators.py:44-63) spelled out -- the class itself imports the tyro-based config
+    # stack; with camera_optimizer mode "off" (samconfigs.py:74,128) its pose correction is the identity
+    coords = cams.get_image_coords()[ref_patch[:, 1], ref_patch[:, 2]]
+    rb = cams.generate_rays(camera_indices=ref_patch[:, 0].unsqueeze(-1), coords=coords)
+    o_o, o_d, o_pa, o_ci = O.generate_rays(ref_patch, c2w, fx, fy, cx, cy)
+    check("ray origins", o_o, rb.origins)
+    check("ray directions", o_d, rb.directions)
+    check("ray pixel_area", o_pa, rb.pixel_area)
+    check("ray camera_indices", o_ci, rb.camera_indices)
+    # --- feature loaders (constructed without files: the loaded tensors are set directly)
+    def loader(feat, patch):
+        fl = FeatureDataloader.__new__(FeatureDataloader)
+        fl.device, fl.features, fl.image_shape, fl.patch_size = "cpu", feat, [H, W], patch
+        return fl
+    centers = ref_patch.reshape(-1, p, p, 3)[:, p // 2, p // 2, :]
+    ref_sam = loader(sam, p)(centers)
+    ref_clip = loader(clip, 1)(ref_patch)
+    check("sam gather", O.gather_features(sam, centers, (H, W)), ref_sam)
+    check("clipseg gather", O.gather_features(clip, ref_patch, (H, W)), ref_clip)
+    (bo, bd, bpa, bci), batch = O.build_batch(u_patch, images, c2w, fx, fy, cx, cy, p, sam, clip)
+    check("batch image", batch["image"], pb["image"])
+    check("batch sam", batch["sam"], ref_sam)
+    check("batch clipseg", batch["clipseg"], ref_clip)
+    check("batch dirs", bd, rb.directions)
+    # --- dataparser pose normalisation (camera_utils.auto_orient_and_center_poses "up" / "none" + auto-scale)
+    from nerfstudio.cameras import camera_utils
+    poses4 = torch.cat([c2w, torch.tensor([0.0, 0.0, 0.0, 1.0]).expand(N, 1, 4)], dim=1)
+    poses4[:, :3, 3] += torch.tensor([3.0, -2.0, 5.0])
+    up_poses, up_tf = camera_utils.auto_orient_and_center_poses(poses4.clone(), method="up", center_poses=True)
+    none_poses, none_tf = camera_utils.auto_orient_and_center_poses(poses4.clone(), method="none", center_poses=True)
+    npz("batch_builder", poses4=poses4, up_poses=up_poses, up_tf=up_tf, none_poses=none_poses, none_tf=none_tf, N=N, H=H, W=W, p=p, R=R, c2w=c2w, fx=fx, fy=fy, cx=cx, cy=cy, images=images, sam=sam, clip=clip,
+        u_patch=u_patch, u_pix=u_pix, patch_indices=ref_patch, pix_indices=ref_pix, origins=rb.origins,
+        directions=rb.directions, pixel_area=rb.pixel_area, camera_indices=rb.camera_indices, batch_image=pb["image"],
+        batch_sam=ref_sam, batch_clipseg=ref_clip)
+
+
 if __name__ == "__main__":
+    only = set(sys.argv[1:])
     for fn in (fx_spacing, fx_contraction, fx_hashgrid, fx_mlp, fx_sh, fx_weights, fx_pdf, fx_render, fx_topk,
-               fx_losses, fx_ministep):
+               fx_losses, fx_ministep, fx_batch_builder):
+        if only and fn.__name__ not in only:
+            continue
         print(fn.__name__)
         fn()
     print("all reference outputs matched the oracle restatement; fixtures written.")

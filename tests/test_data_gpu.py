@@ -1,0 +1,149 @@
+"""GPU tests of the batch builder: the three kernels against the reference-generated fixture and the
+oracle at full size, the on-disk formats round trip, and a train step fed by the disk datamanager."""
+import copy
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import samnerf_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def T(g, k):
+    return torch.from_numpy(np.ascontiguousarray(g[k]))
+
+
+def test_batch_kernels_vs_golden(golden):
+    from samnerf_amd import ops
+    from samnerf_amd.data import Cameras, FeatureDataloader, PatchPixelSampler, PixelSampler, RayGenerator
+    g = golden("batch_builder")
+    N, H, W, p, R = (int(g[k]) for k in ("N", "H", "W", "p", "R"))
+    ind = ops.pixel_indices(T(g, "u_patch").cuda(), R, p, N, H, W)
+    assert torch.equal(ind.cpu(), T(g, "patch_indices"))                       # bit-exact index arithmetic
+    assert torch.equal(ops.pixel_indices(T(g, "u_pix").cuda(), R, 1, N, H, W).cpu(), T(g, "pix_indices"))
+    cams = Cameras(T(g, "c2w"), T(g, "fx"), T(g, "fy"), T(g, "cx"), T(g, "cy"), W, H).to("cuda")
+    rb = RayGenerator(cams)(ind)
+    assert torch.equal(rb.origins.cpu(), T(g, "origins"))
+    assert float((rb.directions.cpu() - T(g, "directions")).abs().max()) <= 2e-7  # 1-2 ulp (rsqrt / division order)
+    rel = (rb.pixel_area.cpu() - T(g, "pixel_area")).abs() / T(g, "pixel_area")
+    assert float(rel.max()) <= 1e-3  # |dir - dir_offset| cancels ~3 digits: ulp noise of the unit vectors is amplified
+    assert torch.equal(rb.camera_indices.cpu(), T(g, "camera_indices"))
+    images = T(g, "images").cuda()
+    assert torch.equal(ops.gather_nearest(ind, images, (H, W)).cpu(), T(g, "batch_image"))
+    sam = FeatureDataloader("cuda", T(g, "sam"), [H, W], patch_size=p)
+    clip = FeatureDataloader("cuda", T(g, "clip"), [H, W])
+    assert torch.equal(sam(ind, point_stride=p * p, point_offset=(p // 2) * p + p // 2).cpu(), T(g, "batch_sam"))
+    centers = ind.reshape(-1, p, p, 3)[:, p // 2, p // 2, :].contiguous()
+    assert torch.equal(sam(centers).cpu(), T(g, "batch_sam"))                  # the reference's own call form
+    assert torch.equal(clip(ind).cpu(), T(g, "batch_clipseg"))
+    # sampler classes draw on the device: same u -> same indices
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    ps = PatchPixelSampler(R, patch_size=p, generator=gen)
+    u = torch.rand((R // (p * p), 3), device="cuda", generator=torch.Generator(device="cuda").manual_seed(5))
+    b = ps.sample({"image": images})
+    assert torch.equal(b["indices"].cpu(), O.patch_pixel_indices(u.cpu(), N, H, W, p))
+    assert torch.equal(b["image"].cpu(), T(g, "images")[b["indices"][:, 0].cpu(), b["indices"][:, 1].cpu(), b["indices"][:, 2].cpu()])
+    assert PixelSampler(100).sample({"image": images})["indices"].shape == (100, 3)
+
+
+def test_batch_builder_full_size_vs_oracle():
+    """BASELINE sizes: 4096 rays (256 patches of 4x4) from 840x1297 images with a [42,64,256] SAM map."""
+    from samnerf_amd import ops
+    N, H, W, p, R = 2, 840, 1297, 4, 4096
+    g = torch.Generator().manual_seed(0)
+    u = torch.rand((R // 16, 3), generator=g)
+    u[0] = torch.tensor([0.0, 0.0, 0.0])
+    u[1] = torch.tensor([0.999999, 0.999999, 0.999999])  # last camera, bottom-right patch
+    c2w = torch.eye(4)[None, :3].repeat(N, 1, 1) + 0.01 * torch.randn((N, 3, 4), generator=g)
+    intr = torch.tensor([[1100.0, 1110.0, W / 2, H / 2]] * N)
+    sam = torch.randn((N, 42, 64, 256), generator=g)
+    clip = torch.randn((N, 32, 32, 192), generator=g)
+    images = torch.rand((N, H, W, 3), generator=g)
+    (o, d, pa, ci), batch = O.build_batch(u, images, c2w, intr[:, 0], intr[:, 1], intr[:, 2], intr[:, 3], p, sam, clip)
+    ind = ops.pixel_indices(u.cuda(), R, p, N, H, W)
+    assert torch.equal(ind.cpu(), batch["indices"])
+    assert int(ind[:, 1].max()) <= H - 1 and int(ind[:, 2].max()) <= W - 1 and int(ind[:, 0].max()) == N - 1
+    go, gd, gpa, gci = ops.generate_rays(ind, c2w.cuda(), intr.cuda())
+    assert torch.equal(go.cpu(), o) and float((gd.cpu() - d).abs().max()) <= 2e-7
+    assert float(((gpa.cpu() - pa).abs() / pa).max()) <= 2e-2  # 1100-px focal length: |dir - dir_offset| ~ 1e-3
+    assert torch.equal(ops.gather_nearest(ind, images.cuda(), (H, W)).cpu(), batch["image"])
+    assert torch.equal(ops.gather_nearest(ind, sam.cuda(), (H, W), 16, 10).cpu(), batch["sam"])
+    assert torch.equal(ops.gather_nearest(ind, clip.cuda(), (H, W)).cpu(), batch["clipseg"])
+
+
+def _write_scene(root, N=3, H=24, W=40):
+    from PIL import Image
+    os.makedirs(os.path.join(root, "images"))
+    os.makedirs(os.path.join(root, "sam_features"))
+    os.makedirs(os.path.join(root, "clipseg_features"))
+    g = torch.Generator().manual_seed(1)
+    frames, imgs, sams, clips = [], [], [], []
+    fh, fw = O.get_feature_size(H, W)
+    for i in range(N):
+        img = (torch.rand((H, W, 3), generator=g) * 255).to(torch.uint8).numpy()
+        Image.fromarray(img).save(os.path.join(root, "images", f"frame_{i:03d}.png"))
+        imgs.append(torch.from_numpy(img.astype(np.float32) / 255.0))
+        sam = torch.randn((256, fh, fw), generator=g)
+        np.save(os.path.join(root, "sam_features", f"frame_{i:03d}.npy"), sam.numpy())
+        sams.append(sam.permute(1, 2, 0))
+        acts = [torch.randn((1025, 1, 64), generator=g) for _ in range(3)]
+        torch.save({"activations": acts}, os.path.join(root, "clipseg_features", f"frame_{i:03d}.pt"))
+        clips.append(torch.cat(acts, -1).squeeze()[1:].reshape(32, 32, -1))
+        m = torch.eye(4)
+        m[:3, 3] = torch.tensor([0.3 * i, 0.1, 2.0 + 0.2 * i])
+        frames.append({"file_path": f"images/frame_{i:03d}.png", "transform_matrix": m.tolist()})
+    meta = {"w": W, "h": H, "fl_x": 50.0, "fl_y": 52.0, "cx": W / 2, "cy": H / 2, "aabb_scale": 4, "frames": frames}
+    json.dump(meta, open(os.path.join(root, "transforms_train.json"), "w"))
+    return torch.stack(imgs), torch.stack(sams), torch.stack(clips)
+
+
+def test_disk_formats_and_datamanager(tmp_path):
+    """transforms_train.json + PNG images + SAM .npy [256,fh,fw] + ClipSeg .pt {activations: 3 x [1025,1,64]} -> batches."""
+    from samnerf_amd.data import DiskSAMDataManagerConfig, NerfstudioDataParserConfig
+    root = str(tmp_path)
+    imgs, sams, clips = _write_scene(root)
+    cfg = DiskSAMDataManagerConfig(dataparser=NerfstudioDataParserConfig(data=root, train_val_json_split=True),
+                                   train_num_rays_per_batch=256, patch_size=4, distill_sam=True, use_clipseg_feature=True)
+    dm = cfg.setup(device="cuda")
+    assert torch.equal(dm.images.cpu(), imgs) and torch.equal(dm.sam_loader.features.cpu(), sams)
+    assert torch.equal(dm.clipseg_loader.features.cpu(), clips)
+    t = dm.cameras.camera_to_worlds[:, :, 3].cpu()
+    assert float(t.abs().max()) == pytest.approx(1.0, abs=1e-6)      # auto-scaled: max |translation| = 1
+    assert float(t.mean(dim=0).abs().max()) < 1e-6                    # centred
+    rb, batch = dm.next_train(0)
+    ind = batch["indices"].cpu()
+    assert rb.origins.shape == (256, 3) and batch["sam"].shape == (16, 256) and batch["clipseg"].shape == (256, 192)
+    assert torch.equal(batch["image"].cpu(), imgs[ind[:, 0], ind[:, 1], ind[:, 2]])
+    centers = ind.reshape(-1, 4, 4, 3)[:, 2, 2, :]
+    assert torch.equal(batch["sam"].cpu(), O.gather_features(sams, centers, imgs.shape[1:3]))
+    assert torch.equal(batch["clipseg"].cpu(), O.gather_features(clips, ind, imgs.shape[1:3]))
+    patches = ind.reshape(-1, 4, 4, 3)
+    assert torch.equal(patches[:, :, :, 1] - patches[:, :1, :1, 1], torch.arange(4)[None, :, None].expand(16, 4, 4))
+    assert float((rb.directions.norm(dim=-1) - 1).abs().max()) < 1e-6
+
+
+def test_train_step_from_disk_datamanager(tmp_path):
+    """The hot path fed by the disk datamanager: a few trainer iterations run and lower the loss."""
+    from samnerf_amd import configs
+    from samnerf_amd.data import DiskSAMDataManagerConfig, NerfstudioDataParserConfig
+    root = str(tmp_path)
+    _write_scene(root)
+    tc = copy.deepcopy(configs.method_configs["samnerf_distill"])
+    tc.pipeline.datamanager = DiskSAMDataManagerConfig(
+        dataparser=NerfstudioDataParserConfig(data=root, train_val_json_split=True), train_num_rays_per_batch=256,
+        patch_size=4, distill_sam=True, use_clipseg_feature=True)
+    mc = tc.pipeline.model
+    mc.log2_hashmap_size, mc.hashgrid_sizes = 12, (12, 12)
+    mc.proposal_net_args_list = [dict(a, log2_hashmap_size=11) for a in mc.proposal_net_args_list]
+    trainer = tc.setup(device="cuda")
+    trainer.setup()
+    losses = []
+    for step in range(12):
+        loss, ld, _ = trainer.train_iteration(step)
+        trainer.synchronize()
+        losses.append(float(sum(v.detach() for v in ld.values())))
+    assert all(np.isfinite(losses)) and min(losses[-3:]) < losses[0]

@@ -239,3 +239,18 @@ def test_shard_bounds_cover_the_slice():
             chunk, bulk, lo, hi = shard_bounds(n, world, world - 1)
             assert chunk % 64 == 0 and bulk == chunk * world <= n and n - bulk < world * 64 + 64
             assert hi == bulk and lo == bulk - chunk
+
+
+def test_dataparser_pose_normalisation_vs_reference(golden):
+    """data.auto_orient_and_center_poses ('up' / 'none', centred) against camera_utils.py:432-487 outputs."""
+    import samnerf_amd  # noqa: F401
+    from samnerf_amd.data import Cameras, auto_orient_and_center_poses
+    g = golden("batch_builder")
+    poses4 = torch.from_numpy(g["poses4"])
+    for m in ("up", "none"):
+        poses, tf = auto_orient_and_center_poses(poses4.clone(), m, True)
+        assert float((poses - torch.from_numpy(g[f"{m}_poses"])).abs().max()) <= 1e-6
+        assert float((tf - torch.from_numpy(g[f"{m}_tf"])).abs().max()) <= 1e-6
+    cams = Cameras(poses, 50.0, 52.0, 20.0, 12.0, 40, 24)
+    assert len(cams) == poses4.shape[0] and cams.intrinsics().shape == (len(cams), 4)
+    assert cams.get_image_coords().shape == (24, 40, 2) and float(cams.get_image_coords()[0, 0, 0]) == 0.5

@@ -162,3 +162,21 @@ def test_ministep(golden):
     sum(ld.values()).backward()
     for k, p in params.items():
         close(p.grad, T(g["grad_" + k]), 2e-6)
+
+
+def test_batch_builder(golden):
+    """pixel samplers, pinhole ray generation, nearest feature gather vs the reference's outputs."""
+    g = golden("batch_builder")
+    T = lambda k: torch.from_numpy(np.ascontiguousarray(g[k]))
+    N, H, W, p = int(g["N"]), int(g["H"]), int(g["W"]), int(g["p"])
+    ind = O.patch_pixel_indices(T("u_patch"), N, H, W, p)
+    assert torch.equal(ind, T("patch_indices"))
+    assert torch.equal(O.pixel_indices(T("u_pix"), N, H, W), T("pix_indices"))
+    o, d, pa, ci = O.generate_rays(ind, T("c2w"), T("fx"), T("fy"), T("cx"), T("cy"))
+    assert torch.equal(o, T("origins")) and torch.equal(d, T("directions")) and torch.equal(pa, T("pixel_area"))
+    assert torch.equal(ci, T("camera_indices"))
+    (bo, bd, bpa, bci), batch = O.build_batch(T("u_patch"), T("images"), T("c2w"), T("fx"), T("fy"), T("cx"), T("cy"), p,
+                                              T("sam"), T("clip"))
+    assert torch.equal(batch["image"], T("batch_image")) and torch.equal(batch["sam"], T("batch_sam"))
+    assert torch.equal(batch["clipseg"], T("batch_clipseg")) and torch.equal(bd, T("directions"))
+    assert float((d.norm(dim=-1) - 1).abs().max()) < 1e-6
