@@ -249,6 +249,13 @@ int snf_gather_nearest(const int64_t* points, int B, int point_stride, int point
 int snf_adam_step(float* p, float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                   float eps, int step, float grad_scale, int zero_grad, snf_stream_t stream);
 
+/* The same update on a LIST of table rows: rows[i] = element offset (from the bases p, g, m, v) of a row of F = 2 or 8
+ * floats.  For the coarse levels of a hash grid only the rows the level's lattice hashes to can ever receive a gradient;
+ * every other row keeps g = m = v = 0, for which the Adam update is exactly the identity, so the optimizer visits the
+ * reachable rows only (host side: tcnn_compat.Encoding.active_rows, engine.Optimizers). */
+int snf_adam_step_rows(float* p, float* g, float* m, float* v, const int32_t* rows, int64_t nrows, int F, float lr,
+                       float beta1, float beta2, float eps, int step, float grad_scale, int zero_grad, snf_stream_t stream);
+
 /* Tuning hook: launch shape of the Adam kernel (grid cap, threads per block in {64,128,256}, independent 16-byte groups
  * per thread in {1,2,4}).  Process-wide; the default is the measured best for MI355X. */
 int snf_set_adam_launch(int max_blocks, int threads, int unroll);

@@ -107,6 +107,7 @@ SIGNATURES = {
     "snf_interlevel": [P, P, P, P, I, I, I, F, P, P, P],
     "snf_distortion": [P, P, I, I, F, P, P, P],
     "snf_adam_step": [P, P, P, P, c_int64, F, F, F, F, I, F, I, P],
+    "snf_adam_step_rows": [P, P, P, P, P, c_int64, I, F, F, F, F, I, F, I, P],
     "snf_set_adam_launch": [I, I, I],
     "snf_pixel_indices": [P, I, I, I, I, I, P, P],
     "snf_generate_rays": [P, I, P, P, I, P, P, P, P, P],

@@ -47,6 +47,7 @@ class ParamGroupArena:
         self.grad = torch.zeros_like(self.param)
         self.exp_avg = torch.zeros_like(self.param) if with_optimizer_state else None
         self.exp_avg_sq = torch.zeros_like(self.param) if with_optimizer_state else None
+        self.tables: Dict[str, object] = {}  # pname -> hash-grid Encoding owning that slice (see engine.Optimizers._plan)
 
     def view(self, buf: torch.Tensor, pname: str) -> torch.Tensor:
         off, shape = self.offsets[pname]

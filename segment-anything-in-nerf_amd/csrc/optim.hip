@@ -92,6 +92,39 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, float* __re
     }
 }
 
+// Adam over a list of table rows (F = 2 or 8 consecutive floats each, `rows[i]` = element offset of row i from the arena
+// base).  Used for the coarse hash-grid levels, where only the rows the (res+1)^3 lattice hashes to can ever receive a
+// gradient: all other rows keep g = m = v = 0 forever, so skipping them is exact (p - lr * 0 / (0 + eps) = p).
+template <int F>
+__global__ __launch_bounds__(256) void k_adam_rows(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, const int* __restrict__ rows, long long nrows,
+                                                   float b1, float b2, float step_size, float inv_sqrt_bc2, float eps,
+                                                   float gs, int zero_grad) {
+    constexpr int VPR = F == 8 ? 2 : 1;  // vector accesses per row (float4 x 2 or float2 x 1)
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= nrows * VPR) return;
+    const long long r = t / VPR;
+    const size_t off = (size_t)rows[r] + (size_t)(t - r * VPR) * 4;
+    if constexpr (F == 8) {
+        f4 P = *reinterpret_cast<f4*>(p + off), G = *reinterpret_cast<f4*>(g + off);
+        f4 M = *reinterpret_cast<f4*>(m + off), V = *reinterpret_cast<f4*>(v + off);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float a = P[c], bg = G[c], cm = M[c], dv = V[c];
+            adam1(a, bg, cm, dv, gs, b1, b2, step_size, inv_sqrt_bc2, eps);
+            P[c] = a; M[c] = cm; V[c] = dv;
+        }
+        *reinterpret_cast<f4*>(p + off) = P; *reinterpret_cast<f4*>(m + off) = M; *reinterpret_cast<f4*>(v + off) = V;
+        if (zero_grad) *reinterpret_cast<f4*>(g + off) = f4{0.f, 0.f, 0.f, 0.f};
+    } else {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            adam1(p[off + c], g[off + c], m[off + c], v[off + c], gs, b1, b2, step_size, inv_sqrt_bc2, eps);
+            if (zero_grad) g[off + c] = 0.f;
+        }
+    }
+}
+
 // launch shape of k_adam: {max blocks, threads per block, unroll}; snf_set_adam_launch overrides (tuning hook)
 static int g_adam_launch[3] = {2048, 256, 2};
 
@@ -136,6 +169,30 @@ extern "C" int snf_adam_step(float* p, float* g, float* m, float* v, int64_t n, 
     if (U == 1) SNF_ADAM_LAUNCH(1); else if (U == 4) SNF_ADAM_LAUNCH(4); else SNF_ADAM_LAUNCH(2);
 #undef SNF_ADAM_LAUNCH
     SNF_LAUNCH_CHECK("snf_adam_step");
+    return SNF_OK;
+}
+
+extern "C" int snf_adam_step_rows(float* p, float* g, float* m, float* v, const int32_t* rows, int64_t nrows, int F, float lr,
+                                  float beta1, float beta2, float eps, int step, float grad_scale, int zero_grad,
+                                  snf_stream_t stream) {
+    SNF_REQUIRE(p && g && m && v && rows, "snf_adam_step_rows: null pointer");
+    SNF_REQUIRE(nrows > 0 && step >= 1 && (F == 2 || F == 8), "snf_adam_step_rows: bad nrows=%lld step=%d F=%d", (long long)nrows,
+                step, F);
+    SNF_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0,
+                "snf_adam_step_rows: arena bases must be 16-byte aligned");
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    const float step_size = (float)((double)lr / bc1);
+    const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+    const long long threads = (long long)nrows * (F == 8 ? 2 : 1);
+    const unsigned blocks = (unsigned)((threads + 255) / 256);
+    if (F == 8)
+        hipLaunchKernelGGL(k_adam_rows<8>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (const int*)rows,
+                           (long long)nrows, beta1, beta2, step_size, inv_sqrt_bc2, eps, grad_scale, zero_grad);
+    else
+        hipLaunchKernelGGL(k_adam_rows<2>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (const int*)rows,
+                           (long long)nrows, beta1, beta2, step_size, inv_sqrt_bc2, eps, grad_scale, zero_grad);
+    SNF_LAUNCH_CHECK("snf_adam_step_rows");
     return SNF_OK;
 }
 

@@ -100,6 +100,20 @@ def sharded_step(param: torch.Tensor, grad: torch.Tensor, step_fn) -> None:
         step_fn(bulk, n)
 
 
+def collectives_on() -> bool:
+    return _collectives_on()
+
+
+def exchange_rows(grad_rows: torch.Tensor, row_index: torch.Tensor) -> None:
+    """SUM-all-reduce the listed rows of a [n_rows, F] gradient view only (the reachable rows of a coarse hash level:
+    every other row of that level is zero on every rank and stays zero): pack -> all_reduce -> unpack."""
+    if not _collectives_on() or row_index.numel() == 0:
+        return
+    packed = grad_rows.index_select(0, row_index)
+    dist.all_reduce(packed, op=dist.ReduceOp.SUM)
+    grad_rows.index_copy_(0, row_index, packed)
+
+
 def gather_sharded_state(buf: torch.Tensor) -> None:
     """Make a sharded optimizer-state buffer whole on every rank (before a checkpoint)."""
     if not _collectives_on():

@@ -54,6 +54,10 @@ class Optimizers:
         import os
         self.sharded = os.environ.get("SNF_SHARDED_OPTIMIZER", "1") == "1"
         self.enabled = True
+        # Adam skips hash-table rows no input can ever address (exact: their g = m = v stay 0); SNF_ADAM_ALL_ROWS=1 disables
+        self.skip_unreachable_rows = os.environ.get("SNF_ADAM_ALL_ROWS", "0") != "1"
+        self._plans: Dict[str, list] = {}
+        self._row_cuts: Dict[tuple, tuple] = {}
         self.shard_slices: Dict[str, List] = {}  # group -> [(lo, hi)] arena slices stepped separately (set by the trainer)
         self.step_count = {k: 0 for k in arenas}
         self.sched_step = {k: 0 for k in arenas}
@@ -75,8 +79,11 @@ class Optimizers:
         """One fused Adam launch over the whole arena of group `k` (on the current stream)."""
         a, oc = self.arenas[k], self.config[k]["optimizer"]
         self.step_count[k] += 1
-        ops.adam_step_(a.param, a.grad, a.exp_avg, a.exp_avg_sq, self.lr(k), oc.betas[0], oc.betas[1], oc.eps,
-                       self.step_count[k], grad_scale, zero_grad)
+        if zero_grad:
+            self._adam_range(k, 0, a.numel, self.lr(k), oc.betas[0], oc.betas[1], oc.eps, self.step_count[k], grad_scale)
+        else:
+            ops.adam_step_(a.param, a.grad, a.exp_avg, a.exp_avg_sq, self.lr(k), oc.betas[0], oc.betas[1], oc.eps,
+                           self.step_count[k], grad_scale, zero_grad)
 
     def optimizer_step_params(self, k: str, first: int, last: int, grad_scale: float = 1.0, zero_grad: bool = True,
                               count_step: bool = True) -> None:
@@ -109,28 +116,102 @@ class Optimizers:
         if count_step:
             self.step_count[k] += 1
         scale, lr, t = 1.0 / D.world_size(), self.lr(k), self.step_count[k]
-        p, g, m, v = a.param[lo:hi], a.grad[lo:hi], a.exp_avg[lo:hi], a.exp_avg_sq[lo:hi]
+        b1, b2, eps = oc.betas[0], oc.betas[1], oc.eps
+        if not D.collectives_on():
+            self._adam_range(k, lo, hi, lr, b1, b2, eps, t, scale)
+            return
+        # data-parallel: walk the plan.  Dense segments: sharded exchange + step (or all-reduce + replicated step);
+        # row segments (reachable rows of coarse hash levels): only those rows travel, and every rank steps them.
+        for seg in self._plan(k):
+            s0, s1 = max(lo, seg[1]), min(hi, seg[2])
+            if s1 <= s0:
+                continue
+            if seg[0] == "dense":
+                def step_fn(x0: int, x1: int, s0=s0) -> None:
+                    if x1 > x0:
+                        self._adam_range(k, s0 + x0, s0 + x1, lr, b1, b2, eps, t, scale)
+                if self.sharded:
+                    D.sharded_step(a.param[s0:s1], a.grad[s0:s1], step_fn)
+                else:
+                    D.allreduce_gradients([a.grad[s0:s1]])
+                    step_fn(0, s1 - s0)
+            else:
+                F = seg[4]
+                i0, i1 = self._cut(k, seg, s0, s1)
+                if i1 > i0:
+                    key = ("rowidx", k, seg[1], i0, i1)
+                    if key not in self._row_cuts:
+                        self._row_cuts[key] = torch.div(seg[3][i0:i1].long(), F, rounding_mode="floor")
+                    D.exchange_rows(a.grad.view(-1, F), self._row_cuts[key])
+                    self._adam_range(k, s0, s1, lr, b1, b2, eps, t, scale)
 
-        def step_fn(s0: int, s1: int) -> None:
-            if s1 > s0:
-                ops.adam_step_(p[s0:s1], g[s0:s1], m[s0:s1], v[s0:s1], lr, oc.betas[0], oc.betas[1], oc.eps, t, scale, True)
+    def _cut(self, k: str, seg, s0: int, s1: int):
+        """Index range of a row segment's sorted offset list that falls inside the arena elements [s0, s1)."""
+        key = (k, seg[1], s0, s1)
+        if key not in self._row_cuts:
+            host = seg[5]
+            self._row_cuts[key] = (int(np.searchsorted(host, s0, "left")), int(np.searchsorted(host, s1, "left")))
+        return self._row_cuts[key]
 
-        if self.sharded:
-            D.sharded_step(p, g, step_fn)
-        else:
-            D.allreduce_gradients([g])
-            step_fn(0, hi - lo)
+    # -- reachable-row plan -------------------------------------------------------------------------------------------
+    def _plan(self, k: str):
+        """Arena `k` as an ordered list of segments: ("rows", start, end, offsets int32, F) for the coarse levels of a
+        hash table (only the rows their lattice can reach are ever updated -- exact, see Encoding.active_rows) and
+        ("dense", start, end) for everything else.  Built once."""
+        if k in self._plans:
+            return self._plans[k]
+        a = self.arenas[k]
+        segs, cur = [], 0
+        if self.skip_unreachable_rows:
+            for pname, (off, shape) in a.offsets.items():
+                enc = a.tables.get(pname)
+                if enc is None:
+                    continue
+                n_sparse, rows = enc.active_rows()
+                if n_sparse == 0:
+                    continue
+                F = enc.n_features_per_level
+                sparse_end = off + (n_sparse << enc.log2_hashmap_size) * F
+                if off > cur:
+                    segs.append(("dense", cur, off))
+                offsets = (rows * F + off).to(torch.int32).contiguous()
+                segs.append(("rows", off, sparse_end, offsets, F, (rows * F + off).cpu().numpy()))
+                cur = sparse_end
+        if cur < a.numel:
+            segs.append(("dense", cur, a.numel))
+        self._plans[k] = segs
+        return segs
+
+    def _adam_range(self, k: str, lo: int, hi: int, lr, b1, b2, eps, t, scale) -> None:
+        """Fused Adam (+ gradient re-zeroing) on the arena elements [lo, hi) of group `k`, following the plan."""
+        a = self.arenas[k]
+        for seg in self._plan(k):
+            s0, s1 = max(lo, seg[1]), min(hi, seg[2])
+            if s1 <= s0:
+                continue
+            if seg[0] == "dense":
+                ops.adam_step_(a.param[s0:s1], a.grad[s0:s1], a.exp_avg[s0:s1], a.exp_avg_sq[s0:s1], lr, b1, b2, eps, t,
+                               scale, True)
+            else:
+                offsets, F = seg[3], seg[4]
+                i0, i1 = self._cut(k, seg, s0, s1)  # rows are sorted: the slice of the list inside [s0, s1)
+                if i1 > i0:
+                    ops.adam_step_rows_(a.param, a.grad, a.exp_avg, a.exp_avg_sq, offsets[i0:i1], F, lr, b1, b2, eps, t,
+                                        scale, True)
 
     def consolidate_state(self) -> None:
-        """Sharded runs keep each rank's Adam moments only for its shards: gather them before saving a checkpoint.
-        (Slices stepped through `exchange_and_step(first, last)` are sharded per slice; the trainer passes the same slices.)"""
+        """Sharded runs keep each rank's Adam moments only for its shards of the dense segments: gather them before saving
+        a checkpoint (the layout is the one exchange_and_step uses: trainer slices x dense plan segments)."""
         from . import distributed as D
-        if not self.sharded or D.world_size() == 1:
+        if not self.sharded or not D.collectives_on():
             return
         for k, a in self.arenas.items():
             for lo, hi in self.shard_slices.get(k, [(0, a.numel)]):
-                D.gather_sharded_state(a.exp_avg[lo:hi])
-                D.gather_sharded_state(a.exp_avg_sq[lo:hi])
+                for seg in self._plan(k):
+                    s0, s1 = max(lo, seg[1]), min(hi, seg[2])
+                    if seg[0] == "dense" and s1 > s0:
+                        D.gather_sharded_state(a.exp_avg[s0:s1])
+                        D.gather_sharded_state(a.exp_avg_sq[s0:s1])
 
     def optimizer_step_all(self, grad_scale: float = 1.0, zero_grad: bool = True) -> None:
         for k in self.arenas:

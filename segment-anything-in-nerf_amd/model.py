@@ -302,6 +302,8 @@ class NerfactoModel(Model):
                 view.copy_(p.data)
                 p.data = view
                 p.main_grad = arena.view(arena.grad, str(i))
+                if getattr(p, "hash_table_of", None) is not None:
+                    arena.tables[str(i)] = p.hash_table_of
                 # autograd-produced gradients (conv head) accumulate in place into the same arena slice
                 p.grad = p.main_grad
             self.arenas[gname] = arena

@@ -74,8 +74,41 @@ class Encoding(nn.Module):
         p = torch.empty((rows * self.n_features_per_level,), device=device, dtype=torch.float32)
         _fill(p, -hash_init_scale, hash_init_scale)
         self.params = nn.Parameter(p)
+        self.params.hash_table_of = self  # lets the optimizer ask for the reachable rows of the coarse levels
         self.register_buffer("scalings", hash_scalings(self.n_levels, self.base_resolution,
                                                        self.per_level_scale).to(device), persistent=False)
+
+    PRIME_Y, PRIME_Z = 2654435761, 805459861
+
+    @torch.no_grad()
+    def active_rows(self, max_fraction: float = 0.4) -> Tuple[int, torch.Tensor]:
+        """Rows of the coarse levels that can EVER be addressed.
+
+        A level of resolution s hashes lattice points (x, y, z) in [0, s]^3 (inputs in [0, 1]; one cell of slack on either
+        side is added here for rounding at the borders), so at most (s + 3)^3 of its 2^T rows are reachable; the others
+        never receive a gradient and Adam leaves them untouched forever.  Returns (n, rows): the first n levels are
+        sparse (fewer than max_fraction * 2^T reachable rows -- the reachable count grows with the level, so they form
+        a prefix) and `rows` is the sorted int64 list of their reachable row indices (l * 2^T + hash); levels >= n are
+        treated as dense."""
+        T, dev = self.log2_hashmap_size, self.params.device
+        mask32, maskT = 0xFFFFFFFF, (1 << T) - 1
+        rows, n_sparse = [], 0
+        for l in range(self.n_levels):
+            s = int(self.scalings[l].item())
+            if (s + 3) ** 3 >= max_fraction * (1 << T) * 4:  # cannot be sparse enough even before de-duplication
+                break
+            c = torch.arange(-1, s + 2, device=dev, dtype=torch.int64)
+            x = (c & mask32)[:, None, None]
+            y = ((c * self.PRIME_Y) & mask32)[None, :, None]
+            z = ((c * self.PRIME_Z) & mask32)[None, None, :]
+            idx = torch.unique(((x ^ y ^ z) & maskT).reshape(-1))
+            if idx.numel() >= max_fraction * (1 << T):
+                break
+            rows.append(idx + (l << T))
+            n_sparse = l + 1
+        if n_sparse == 0:
+            return 0, torch.empty((0,), device=dev, dtype=torch.int64)
+        return n_sparse, torch.cat(rows)
 
     @property
     def spec(self) -> Tuple[torch.Tensor, int, int, int]:

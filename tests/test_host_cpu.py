@@ -212,6 +212,14 @@ def _sharded_worker(rank, world, port, q):
         D.gather_sharded_state(m)
         D.gather_sharded_state(v)
         ok = ok and torch.allclose(m, mr, rtol=1e-5, atol=1e-6) and torch.allclose(v, vr, rtol=1e-5, atol=1e-6)
+    # reachable-row exchange: only the listed rows of a [rows, F] gradient view are summed, the rest is left alone
+    g2 = torch.arange(40 * 8, dtype=torch.float32).view(40, 8) * (rank + 1)
+    idx = torch.tensor([1, 5, 6, 39])
+    before = g2.clone()
+    D.exchange_rows(g2, idx)
+    expect = before.clone()
+    expect[idx] = torch.arange(40 * 8, dtype=torch.float32).view(40, 8)[idx] * sum(range(1, world + 1))
+    ok = ok and torch.equal(g2, expect)
     q.put((rank, bool(ok)))
     torch.distributed.destroy_process_group()
 
@@ -254,3 +262,40 @@ def test_dataparser_pose_normalisation_vs_reference(golden):
     cams = Cameras(poses, 50.0, 52.0, 20.0, 12.0, 40, 24)
     assert len(cams) == poses4.shape[0] and cams.intrinsics().shape == (len(cams), 4)
     assert cams.get_image_coords().shape == (24, 40, 2) and float(cams.get_image_coords()[0, 0, 0]) == 0.5
+
+
+def test_reachable_rows_cover_every_addressable_row():
+    """Encoding.active_rows: the sparse levels' row lists contain every row any input in [0,1]^3 (plus border slack) can
+    address -- the invariant that makes skipping the other rows in Adam exact."""
+    import samnerf_amd  # noqa: F401
+    from samnerf_amd.tcnn_compat import Encoding
+    from oracle import samnerf_oracle as O
+    for (L, F, T, lo, hi) in ((12, 8, 17, 16, 128), (16, 2, 19, 16, 2048), (5, 2, 17, 16, 128)):
+        growth = float(np.exp((np.log(hi) - np.log(lo)) / (L - 1)))
+        enc = Encoding(3, {"otype": "HashGrid", "n_levels": L, "n_features_per_level": F, "log2_hashmap_size": T,
+                           "base_resolution": lo, "per_level_scale": growth}, device="cpu")
+        n_sparse, rows = enc.active_rows()
+        assert 1 <= n_sparse < L and torch.equal(rows, torch.unique(rows))  # sorted, unique
+        active = set(rows.tolist())
+        g = torch.Generator().manual_seed(L)
+        u = torch.cat([torch.rand((20000, 3), generator=g), torch.zeros((1, 3)), torch.ones((1, 3)),
+                       torch.tensor([[1.0 + 1e-7, -1e-8, 0.5]]), torch.randint(0, 2, (64, 3)).float()])
+        s = enc.scalings.view(-1, 1)
+        scaled = u[:, None, :] * s
+        c, f = torch.ceil(scaled).to(torch.int32), torch.floor(scaled).to(torch.int32)
+        off = (torch.arange(L) * (1 << T)).to(torch.int64)
+        touched = set()
+        for a in (c[..., 0], f[..., 0]):
+            for b in (c[..., 1], f[..., 1]):
+                for cc in (c[..., 2], f[..., 2]):
+                    idx = O.hash_index(a, b, cc, T, off)[:, :n_sparse]
+                    touched |= set(idx.reshape(-1).tolist())
+        assert touched <= active
+        # the list is a real saving: fewer than 40 % of the rows of every sparse level
+        per_level = torch.bincount((rows >> T), minlength=n_sparse)
+        assert int(per_level.max()) < 0.4 * (1 << T)
+    # full-size SAM grid (T = 19, 16 -> 128): 8 sparse levels, ~1.0 M of 4.2 M rows
+    enc = Encoding(3, {"otype": "HashGrid", "n_levels": 12, "n_features_per_level": 8, "log2_hashmap_size": 19,
+                       "base_resolution": 16, "per_level_scale": float(np.exp(np.log(128 / 16) / 11))}, device="cpu")
+    n_sparse, rows = enc.active_rows()
+    assert n_sparse == 8 and rows.numel() < 0.3 * (n_sparse << 19)
