@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """HBM traffic of the dominant kernel from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE -- separate runs).
 
-    python tools/pmc_traffic.py gpurun_out/r01g --regex k_adam --out profiles/pmc_traffic.json
+    python tools/pmc_traffic.py gpurun_out/r01g --out profiles/pmc_traffic.json
 
 Reads <dir>/pmc_FETCH_SIZE/pmc_counter_collection.csv, <dir>/pmc_WRITE_SIZE/... and the bench line the PMC run printed
 (<dir>/pmc_FETCH_SIZE.json: `roofline.launches_timed` = launches in the timed region, which are the LAST dispatches of
@@ -25,7 +25,7 @@ def counter(path, rx):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("dir")
-    ap.add_argument("--regex", default="k_adam")
+    ap.add_argument("--regex", default="k_adam<")
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
     bench = json.loads(open(os.path.join(a.dir, "pmc_FETCH_SIZE.json")).read().strip().splitlines()[-1])
