@@ -43,7 +43,7 @@ def algorithmic_model(key: str, w: dict):
     (8 corners x F floats x 4 B per level per sample; backward = read-modify-write)."""
     R, P, S, K = w["R"], w["P"], w["S"], w["K"]
     name, _, tag = key.partition("/")
-    if name in ("snf_hashgrid_fwd", "snf_hashgrid_bwd", "snf_hashgrid_bwd_sorted"):
+    if name in ("snf_hashgrid_fwd", "snf_hashgrid_bwd", "snf_hashgrid_bwd_sorted", "snf_hashgrid_bwd_sorted_ex"):
         F, L = (int(x) for x in tag[1:].split("L"))
         rw = 1 if name.endswith("fwd") else 2
         # F=8: feature grids on the R*K top-K samples; F=2: proposal grid (L=5, R*P samples) or field grid (L=16, R*S)

@@ -82,6 +82,13 @@ int snf_hashgrid_bwd_sorted(const float* u, const float* grad_out, const float* 
                             int log2_T, int ld_out, int col_off, float* grad_table, void* workspace,
                             int64_t workspace_bytes, snf_stream_t stream);
 
+/* The same with run aggregation in the reduce pass for the first n_run_levels levels: at a coarse level neighbouring
+ * records of a bucket carry the same row (consecutive samples of a ray inside one cell); they are summed across adjacent
+ * lanes before ranking.  Any n_run_levels in [0, L] gives the same sums up to fp32 summation order. */
+int snf_hashgrid_bwd_sorted_ex(const float* u, const float* grad_out, const float* scalings, int N, int L, int F,
+                               int log2_T, int ld_out, int col_off, int n_run_levels, float* grad_table, void* workspace,
+                               int64_t workspace_bytes, snf_stream_t stream);
+
 /* Arithmetic of the wide (>= 128 input) dense layers: 1 (default) = bf16 3-term split on the bf16 matrix cores with fp32
  * accumulate (max abs error ~1e-6 on head-shaped data, 1/5 of the matrix cycles), 0 = exact fp32 matrix cores.
  * Process-wide; narrow layers always run exact fp32. */

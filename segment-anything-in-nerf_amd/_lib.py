@@ -87,6 +87,7 @@ SIGNATURES = {
     "snf_hashgrid_fwd": [P, P, P, I, I, I, I, P, I, I, P],
     "snf_hashgrid_bwd": [P, P, P, I, I, I, I, I, I, P, P],
     "snf_hashgrid_bwd_sorted": [P, P, P, I, I, I, I, I, I, P, P, c_int64, P],
+    "snf_hashgrid_bwd_sorted_ex": [P, P, P, I, I, I, I, I, I, I, P, P, c_int64, P],
     "snf_linear_fwd": [P, P, P, I, I, I, I, I, I, P, P],
     "snf_linear_fwd_ws": [P, P, P, I, I, I, I, I, I, P, P, c_int64, P],
     "snf_linear_bwd_data": [P, P, P, I, I, I, I, I, I, I, P, P],

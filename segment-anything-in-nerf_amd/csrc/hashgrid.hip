@@ -428,7 +428,7 @@ template <int F>
 __global__ __launch_bounds__(HG_RT) void k_hg_reduce(const float* __restrict__ gT, int N, int log2_T, int log2B,
                                                      const uint32_t* __restrict__ bucket_start,
                                                      const uint2* __restrict__ records, float* __restrict__ grad_table,
-                                                     uint32_t hg_long) {
+                                                     uint32_t hg_long, int n_run_levels) {
     constexpr int CHUNK = hg_chunk<F>();
     constexpr int RPT = CHUNK / HG_RT;
     __shared__ uint32_t cnt[HG_MAX_RPB + 1];  // per-row counts, then exclusive offsets
@@ -445,6 +445,7 @@ __global__ __launch_bounds__(HG_RT) void k_hg_reduce(const float* __restrict__ g
     float* __restrict__ slab = grad_table + (((size_t)l << log2_T) + ((size_t)b << log2rpb)) * F;
     const float* __restrict__ gl = gT + (size_t)l * N * F;
     if (hg_long < 8u) hg_long = 8u;  // capacity of long_rows
+    const bool coarse = l < n_run_levels;
     float racc[HG_ROWS_PT][F];       // running sums of the owned rows over all chunks (short segments)
 #pragma unroll
     for (int q = 0; q < HG_ROWS_PT; ++q)
@@ -481,12 +482,36 @@ __global__ __launch_bounds__(HG_RT) void k_hg_reduce(const float* __restrict__ g
         if constexpr (PIPE) {
             if (has_next) load_recs(c0 + CHUNK, recn);
         }
-        // ---- phase 1: rank within row
+        // ---- phase 1: rank within row.  At a coarse level neighbouring records of the bucket stream mostly come from
+        // neighbouring samples of one ray inside one cell, i.e. carry the same row: such runs are summed across adjacent
+        // lanes first (segmented shuffle scan) and only the run tail is ranked, sorted and summed -- it removes the
+        // same-address rank atomics and the thousand-record segments that made a coarse level 5-8x dearer than a fine one.
         uint32_t row[RPT], pos[RPT];
+        float v[RPT][F];
 #pragma unroll
         for (int j = 0; j < RPT; ++j) {
-            const bool live = c0 + tid + (uint32_t)HG_RT * j < end;
+            bool live = c0 + tid + (uint32_t)HG_RT * j < end;
             row[j] = rec[j].x >> HG_SAMPLE_BITS;
+            const float w = __uint_as_float(rec[j].y);
+#pragma unroll
+            for (int f = 0; f < F; ++f) v[j][f] = w * g[j][f];
+            if (coarse) {
+                const uint32_t key = live ? row[j] : (0xFFFFFF00u + (uint32_t)lane);  // dead lanes: singleton runs
+                const uint32_t prev = __shfl_up(key, 1, 64);
+                const unsigned long long heads = __ballot((lane == 0) || (prev != key));
+                const int h = 63 - __builtin_clzll(heads & ((2ull << lane) - 1ull));  // first lane of this lane's run
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const bool take = (lane - d) >= h;
+#pragma unroll
+                    for (int f = 0; f < F; ++f) {
+                        const float t = __shfl_up(v[j][f], d, 64);
+                        if (take) v[j][f] += t;
+                    }
+                }
+                const uint32_t next = __shfl_down(key, 1, 64);
+                live = live && ((lane == 63) || (next != key));  // the run tail carries the run's sum
+            }
             pos[j] = live ? atomicAdd(&cnt[row[j]], 1u) : 0xFFFFFFFFu;
         }
         __syncthreads();
@@ -527,13 +552,12 @@ __global__ __launch_bounds__(HG_RT) void k_hg_reduce(const float* __restrict__ g
 #pragma unroll
         for (int j = 0; j < RPT; ++j) {
             if (pos[j] != 0xFFFFFFFFu) {
-                const float w = __uint_as_float(rec[j].y);
                 float* d = &val[(size_t)(cnt[row[j]] + pos[j]) * F];
                 if constexpr (F == 8) {
-                    reinterpret_cast<float4*>(d)[0] = make_float4(w * g[j][0], w * g[j][1], w * g[j][2], w * g[j][3]);
-                    reinterpret_cast<float4*>(d)[1] = make_float4(w * g[j][4], w * g[j][5], w * g[j][6], w * g[j][7]);
+                    reinterpret_cast<float4*>(d)[0] = make_float4(v[j][0], v[j][1], v[j][2], v[j][3]);
+                    reinterpret_cast<float4*>(d)[1] = make_float4(v[j][4], v[j][5], v[j][6], v[j][7]);
                 } else {
-                    *reinterpret_cast<float2*>(d) = make_float2(w * g[j][0], w * g[j][1]);
+                    *reinterpret_cast<float2*>(d) = make_float2(v[j][0], v[j][1]);
                 }
             }
         }
@@ -683,6 +707,13 @@ extern "C" int64_t snf_hashgrid_bwd_workspace_bytes(int N, int L, int log2_T) {
 extern "C" int snf_hashgrid_bwd_sorted(const float* u, const float* grad_out, const float* scalings, int N, int L, int F,
                                        int log2_T, int ld_out, int col_off, float* grad_table, void* workspace,
                                        int64_t workspace_bytes, snf_stream_t stream) {
+    return snf_hashgrid_bwd_sorted_ex(u, grad_out, scalings, N, L, F, log2_T, ld_out, col_off, 0, grad_table, workspace,
+                                      workspace_bytes, stream);
+}
+
+extern "C" int snf_hashgrid_bwd_sorted_ex(const float* u, const float* grad_out, const float* scalings, int N, int L, int F,
+                                          int log2_T, int ld_out, int col_off, int n_run_levels, float* grad_table,
+                                          void* workspace, int64_t workspace_bytes, snf_stream_t stream) {
     int rc = check_common("snf_hashgrid_bwd_sorted", u, grad_out, scalings, grad_table, N, L, F, log2_T, ld_out, col_off);
     if (rc) return rc;
     SNF_REQUIRE(((uintptr_t)grad_out % 16) == 0 && ((uintptr_t)grad_table % 16) == 0,
@@ -722,10 +753,10 @@ extern "C" int snf_hashgrid_bwd_sorted(const float* u, const float* grad_out, co
                        (uint2*)records);
     if (F == 2)
         hipLaunchKernelGGL(k_hg_reduce<2>, dim3(B, L), dim3(HG_RT), 0, st, gT, N, log2_T, g.log2B, bstart,
-                           (const uint2*)records, grad_table, hg_long);
+                           (const uint2*)records, grad_table, hg_long, n_run_levels);
     else
         hipLaunchKernelGGL(k_hg_reduce<8>, dim3(B, L), dim3(HG_RT), 0, st, gT, N, log2_T, g.log2B, bstart,
-                           (const uint2*)records, grad_table, hg_long);
+                           (const uint2*)records, grad_table, hg_long, n_run_levels);
     SNF_LAUNCH_CHECK("snf_hashgrid_bwd_sorted");
     return SNF_OK;
 }
