@@ -35,6 +35,7 @@ extern "C" {
 #define SNF_ACT_NONE 0
 #define SNF_ACT_RELU 1
 #define SNF_ACT_SIGMOID 2
+#define SNF_ACT_GELU 3 /* forward only (nn.GELU, erf form): the image encoder's MLP blocks */
 
 typedef void* snf_stream_t;
 
@@ -132,7 +133,7 @@ int snf_mlp_tiny_bwd(const float* dY, const float* X, int ldx, const float* Hid,
  *   unfold_mean : cm[patch, c*k*k + t] = mean over the patch rows of unfold(h): the patch mean moved in front of the
  *                 second convolution's GEMM (both linear), so that GEMM runs on R/p^2 rows.
  *   fold_mean   : adjoint of unfold_mean (dcm [R/p^2, C*k*k] -> dh [R, C]).
- * R must be a multiple of p*p; p <= 8, k odd <= 5. */
+ * R must be a multiple of p*p; k odd <= 5; p <= 64 for unfold (the image encoder's 64 x 64 neck), p <= 8 for the others. */
 int snf_patch_unfold(const float* x, int R, int p, int C, int k, float* col, snf_stream_t stream);
 int snf_patch_fold(const float* dcol, int R, int p, int C, int k, float* dx, snf_stream_t stream);
 int snf_patch_unfold_mean(const float* h, int R, int p, int C, int k, float* cm, snf_stream_t stream);
@@ -231,6 +232,28 @@ int snf_rowmse_loss_fwd(const float* pred, const float* target, int R, int C, fl
                         float* out, snf_stream_t stream);
 int snf_rowmse_loss_bwd(const float* pred, const float* target, int R, int C, float weight, int nan_skip,
                         const float* gout, const float* out, float* dpred, snf_stream_t stream);
+
+/* ---- the SAM image encoder forward (samnerf/segment_anything/modeling/image_encoder.py, common.py).
+ * Dense layers are snf_linear_fwd (SNF_ACT_GELU for the MLP); these are the pieces around them.  Tokens are rows [B*T, C].
+ * snf_patchify: image [B,Cin,S,S] -> rows [B*(S/P)^2, Cin*P*P] in Conv2d.weight.view(E, Cin*P*P) column order (PatchEmbed).
+ * snf_layernorm: y = LayerNorm(x + residual) (residual may be NULL; sum_out, if given, receives x + residual); also
+ *   LayerNorm2d on channel-last rows.
+ * snf_window_partition / snf_window_merge_add: window_partition with zero padding; window_unpartition fused with the
+ *   block's `shortcut + x` (ws == 0: plain add).
+ * snf_relpos: rel[bh][i][0..n) = q_i . rel_pos_h[ih-kh+n-1], rel[bh][i][n..2n) = q_i . rel_pos_w[iw-kw+n-1] from the qkv rows
+ *   [Bw*T, 3*C] (add_decomposed_rel_pos; tables must have 2n-1 rows).
+ * snf_attention: out[b*T+i, h*hd..] = softmax(scale * q k^T + rel_h + rel_w) v for every (window b, head h), q/k/v read in
+ *   place from the qkv rows; rel may be NULL; head_dim <= 96. */
+int snf_patchify(const float* img, int B, int Cin, int S, int P, float* rows, snf_stream_t stream);
+int snf_layernorm(const float* x, const float* residual, int N, int C, const float* weight, const float* bias, float eps,
+                  float* sum_out, float* y, snf_stream_t stream);
+int snf_window_partition(const float* x, int B, int H, int W, int C, int ws, float* out, snf_stream_t stream);
+int snf_window_merge_add(const float* windows, const float* shortcut, int B, int H, int W, int C, int ws, float* out,
+                         snf_stream_t stream);
+int snf_relpos(const float* qkv, int Bw, int T, int heads, int head_dim, int n, const float* rel_pos_h,
+               const float* rel_pos_w, float* rel, snf_stream_t stream);
+int snf_attention(const float* qkv, const float* rel, int Bw, int T, int heads, int head_dim, int n, float scale, float* out,
+                  snf_stream_t stream);
 
 /* ---- the batch builder in front of the path (images, feature maps and cameras resident in HBM).
  * snf_pixel_indices: PixelSampler (patch == 1: u [B,3]) / PatchPixelSampler (u [B/patch^2,3]) .sample_method without a

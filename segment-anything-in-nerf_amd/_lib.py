@@ -20,7 +20,7 @@ INCLUDE = os.path.join(ROOT, "include")
 LIB_DIR = os.path.join(PKG_DIR, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libsamnerf_hip.so")
 HASH_PATH = LIB_PATH + ".srchash"
-SOURCES = ["batch.hip", "sampling.hip", "hashgrid.hip", "linear.hip", "linear_b3.hip", "mlp_chain.hip", "mlp_tiny.hip", "patchconv.hip", "render.hip", "losses.hip", "optim.hip"]
+SOURCES = ["vit.hip", "batch.hip", "sampling.hip", "hashgrid.hip", "linear.hip", "linear_b3.hip", "mlp_chain.hip", "mlp_tiny.hip", "patchconv.hip", "render.hip", "losses.hip", "optim.hip"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics"]
 
 
@@ -110,6 +110,12 @@ SIGNATURES = {
     "snf_adam_step": [P, P, P, P, c_int64, F, F, F, F, I, F, I, P],
     "snf_adam_step_rows": [P, P, P, P, P, c_int64, I, F, F, F, F, I, F, I, P],
     "snf_set_adam_launch": [I, I, I],
+    "snf_patchify": [P, I, I, I, I, P, P],
+    "snf_layernorm": [P, P, I, I, P, P, F, P, P, P],
+    "snf_window_partition": [P, I, I, I, I, I, P, P],
+    "snf_window_merge_add": [P, P, I, I, I, I, I, P, P],
+    "snf_relpos": [P, I, I, I, I, I, P, P, P, P],
+    "snf_attention": [P, P, I, I, I, I, I, F, P, P],
     "snf_pixel_indices": [P, I, I, I, I, I, P, P],
     "snf_generate_rays": [P, I, P, P, I, P, P, P, P, P],
     "snf_gather_nearest": [P, I, I, I, P, I, I, I, I, I, I, P, P],

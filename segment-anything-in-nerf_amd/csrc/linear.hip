@@ -32,6 +32,7 @@ __device__ __forceinline__ float act_deriv(float y, int act) {
 __device__ __forceinline__ float act_apply(float x, int act) {
     if (act == SNF_ACT_RELU) return fmaxf(x, 0.f);
     if (act == SNF_ACT_SIGMOID) return 1.f / (1.f + expf(-x));
+    if (act == SNF_ACT_GELU) return 0.5f * x * (1.f + erff(x * 0.70710678118654752f));  // nn.GELU() (erf form)
     return x;
 }
 
@@ -332,7 +333,7 @@ extern "C" int snf_linear_fwd(const float* X, const float* W, const float* bias,
                               int act, float* Y, snf_stream_t stream) {
     SNF_REQUIRE(X && W && Y, "snf_linear_fwd: null pointer");
     SNF_REQUIRE(N > 0 && I > 0 && O > 0 && ldx >= I && ldy >= O, "snf_linear_fwd: bad shape N=%d I=%d O=%d", N, I, O);
-    SNF_REQUIRE(act >= 0 && act <= 2, "snf_linear_fwd: bad activation %d", act);
+    SNF_REQUIRE(act >= 0 && act <= 3, "snf_linear_fwd: bad activation %d", act);
     if (b3_try_fwd(X, W, bias, N, I, O, ldx, ldy, act, Y, stream)) {
         SNF_LAUNCH_CHECK("snf_linear_fwd(bf16x3)");
         return SNF_OK;
@@ -390,7 +391,7 @@ extern "C" int snf_linear_fwd_ws(const float* X, const float* W, const float* bi
     int ks;
     const int splits = (X && W && Y && N > 0 && I > 0 && O > 0) ? splitk_plan(N, I, O, &ks) : 1;
     if (splits <= 1 || workspace == nullptr) return snf_linear_fwd(X, W, bias, N, I, O, ldx, ldy, act, Y, stream);
-    SNF_REQUIRE(ldx >= I && ldy >= O && act >= 0 && act <= 2, "snf_linear_fwd_ws: bad shape / activation");
+    SNF_REQUIRE(ldx >= I && ldy >= O && act >= 0 && act <= 3, "snf_linear_fwd_ws: bad shape / activation");
     SNF_REQUIRE(workspace_bytes >= snf_linear_fwd_workspace_bytes(N, I, O), "snf_linear_fwd_ws: workspace too small");
     SNF_REQUIRE(aligned16(X) && aligned16(W) && aligned16(workspace) && (ldx % 4 == 0),
                 "snf_linear_fwd_ws: X, W, workspace must be 16-byte aligned and ldx a multiple of 4");
@@ -412,6 +413,7 @@ extern "C" int snf_linear_bwd_data(const float* dY, const float* Y, const float*
                                    int ldy, int lddx, int act, float* dX, snf_stream_t stream) {
     SNF_REQUIRE(dY && W && dX, "snf_linear_bwd_data: null pointer");
     SNF_REQUIRE(act == SNF_ACT_NONE || Y, "snf_linear_bwd_data: Y required for activation derivative");
+    SNF_REQUIRE(act != SNF_ACT_GELU, "snf_linear_bwd_data: GELU is forward-only (image encoder inference)");
     SNF_REQUIRE(N > 0 && I > 0 && O > 0 && lddy >= O && lddx >= I, "snf_linear_bwd_data: bad shape");
     if (b3_try_bwd_data(dY, Y, W, N, I, O, lddy, ldy, lddx, act, dX, stream)) {
         SNF_LAUNCH_CHECK("snf_linear_bwd_data(bf16x3)");
@@ -435,6 +437,7 @@ extern "C" int snf_linear_bwd_weight(const float* dY, const float* Y, const floa
                                      int ldy, int ldx, int act, float* dW, float* dbias, snf_stream_t stream) {
     SNF_REQUIRE(dY && X && dW, "snf_linear_bwd_weight: null pointer");
     SNF_REQUIRE(act == SNF_ACT_NONE || Y, "snf_linear_bwd_weight: Y required for activation derivative");
+    SNF_REQUIRE(act != SNF_ACT_GELU, "snf_linear_bwd_weight: GELU is forward-only (image encoder inference)");
     SNF_REQUIRE(N > 0 && I > 0 && O > 0 && lddy >= O && ldx >= I, "snf_linear_bwd_weight: bad shape");
     // activations may be stored with padded leading dimensions (multiple of 4): the vector loaders mask pad columns
     const int vecA = aligned16(dY) && (lddy % 4 == 0) && (act == SNF_ACT_NONE || (aligned16(Y) && ldy % 4 == 0));

@@ -29,6 +29,7 @@ __device__ __forceinline__ float b3_act_deriv(float y, int act) {
 __device__ __forceinline__ float b3_act_apply(float x, int act) {
     if (act == SNF_ACT_RELU) return fmaxf(x, 0.f);
     if (act == SNF_ACT_SIGMOID) return 1.f / (1.f + expf(-x));
+    if (act == SNF_ACT_GELU) return 0.5f * x * (1.f + erff(x * 0.70710678118654752f));  // nn.GELU() (erf form)
     return x;
 }
 

@@ -112,7 +112,7 @@ using namespace snf;
 
 static int check_patch(const char* who, const void* a, const void* b, int R, int p, int C, int k) {
     SNF_REQUIRE(a && b, "%s: null pointer", who);
-    SNF_REQUIRE(p >= 1 && p <= 8 && k >= 1 && k <= 5 && (k & 1) && C >= 1, "%s: bad patch=%d kernel=%d C=%d", who, p, k, C);
+    SNF_REQUIRE(p >= 1 && p <= 64 && k >= 1 && k <= 5 && (k & 1) && C >= 1, "%s: bad patch=%d kernel=%d C=%d", who, p, k, C);
     SNF_REQUIRE(R > 0 && R % (p * p) == 0, "%s: R=%d is not a multiple of patch^2=%d", who, R, p * p);
     return SNF_OK;
 }
@@ -131,6 +131,7 @@ extern "C" int snf_patch_fold(const float* dcol, int R, int p, int C, int k, flo
     int rc = check_patch("snf_patch_fold", dcol, dx, R, p, C, k);
     if (rc) return rc;
     const size_t lds = (size_t)p * p * PC_CC * k * k * sizeof(float);
+    SNF_REQUIRE(lds <= 64 * 1024, "snf_patch_fold: patch too large for the fold kernel (p <= 8 at k = 3)");
     hipLaunchKernelGGL(k_patch_fold, dim3(R / (p * p), (C + PC_CC - 1) / PC_CC), dim3(256), lds, (hipStream_t)stream, dcol, p,
                        C, k, dx);
     SNF_LAUNCH_CHECK("snf_patch_fold");

@@ -1,0 +1,327 @@
+// vit.hip -- the non-GEMM pieces of the SAM image encoder forward (reference
+// samnerf/segment_anything/modeling/image_encoder.py, common.py) for gfx950.  The dense layers (patch embedding, qkv, proj,
+// MLP, neck) are snf_linear_fwd GEMMs; here:
+//   snf_patchify          : image [B,3,S,S] -> rows [B*G*G, 3*P*P] in the column order of Conv2d.weight.view(E, 3*P*P)
+//   snf_layernorm         : nn.LayerNorm over the last axis (also LayerNorm2d on channel-last rows), optional residual add
+//   snf_window_partition  : window_partition with zero padding (image_encoder.py:239-261)
+//   snf_window_merge_add  : window_unpartition + the block's `shortcut + x` (image_encoder.py:264-287,178-180)
+//   snf_relpos            : the two decomposed relative-position terms rel_h, rel_w (image_encoder.py:323-361)
+//   snf_attention         : softmax((q*scale) k^T + rel_h + rel_w) v on the fp32 matrix cores, flash style
+// Attention layout: tokens stay in the qkv GEMM's output [B*T, 3*C] (q | k | v, each heads x head_dim) -- no permutes; the
+// output goes straight into [B*T, C] at column head*hd, which is what the proj GEMM reads.
+//
+// snf_attention: one wave = 32 queries of one (batch-window, head); four waves share staged K / V tiles of 32 keys.
+// The score tile is formed TRANSPOSED, S^T[key][query] = K Q^T (A = K rows from LDS, B = the lane's own query row held in
+// registers), so that in the MFMA accumulator layout a lane owns ONE query column: the online-softmax statistics are
+// per-lane scalars (max / sum over the lane's 16 registers + one cross-half shuffle), rescaling the output accumulators is a
+// per-lane multiply, and P^T is already the B operand of O^T = V^T P^T -- the same transposed chaining as mlp_chain.hip.
+#include "common.hpp"
+#include <math.h>
+
+namespace snf {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ int vrow(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }  // C/D row of reg r
+
+__global__ __launch_bounds__(256) void k_patchify(const float* __restrict__ img, int B, int Cin, int S, int P,
+                                                  float* __restrict__ rows) {
+    const int G = S / P, K = Cin * P * P;
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long long)B * G * G * K) return;
+    const int col = (int)(t % K);
+    const long long tok = t / K;
+    const int c = col / (P * P), ky = (col / P) % P, kx = col % P;
+    const int b = (int)(tok / (G * G)), gy = (int)((tok / G) % G), gx = (int)(tok % G);
+    rows[t] = img[(((size_t)b * Cin + c) * S + gy * P + ky) * S + gx * P + kx];
+}
+
+// y = LN(x') * w + b with x' = x + res (res optional; biased variance, eps inside the sqrt); x' is also written to `sum_out`
+// when given -- a block's second residual `x + mlp(..)` folds into the next block's norm1 this way.  One wave per row.
+__global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ x, const float* __restrict__ res, int N, int C,
+                                                   const float* __restrict__ w, const float* __restrict__ b, float eps,
+                                                   float* __restrict__ sum_out, float* __restrict__ y) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= N) return;
+    const float* xr = x + (size_t)row * C;
+    const float* rr = res ? res + (size_t)row * C : nullptr;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += xr[c] + (rr ? rr[c] : 0.f);
+    const float mean = wave_sum(s) / (float)C;
+    float v = 0.f;
+    for (int c = lane; c < C; c += 64) {
+        const float d = xr[c] + (rr ? rr[c] : 0.f) - mean;
+        v += d * d;
+    }
+    const float inv = 1.f / sqrtf(wave_sum(v) / (float)C + eps);
+    for (int c = lane; c < C; c += 64) {
+        const float xv = xr[c] + (rr ? rr[c] : 0.f);
+        if (sum_out) sum_out[(size_t)row * C + c] = xv;
+        y[(size_t)row * C + c] = (xv - mean) * inv * w[c] + b[c];
+    }
+}
+
+// x [B,H,W,C] -> windows [B * nWh * nWw, ws, ws, C], zero padded to multiples of ws
+__global__ __launch_bounds__(256) void k_window_partition(const float* __restrict__ x, int B, int H, int W, int C, int ws,
+                                                          float* __restrict__ out) {
+    const int nWh = (H + ws - 1) / ws, nWw = (W + ws - 1) / ws;
+    const int tok = blockIdx.x;  // output token
+    const int per = ws * ws;
+    const int win = tok / per, q = tok % per;
+    const int b = win / (nWh * nWw), wy = (win / nWw) % nWh, wx = win % nWw;
+    const int y = wy * ws + q / ws, xx = wx * ws + q % ws;
+    const bool in = y < H && xx < W;
+    const float* src = x + (((size_t)b * H + y) * W + xx) * C;
+    float* dst = out + (size_t)tok * C;
+    for (int c = threadIdx.x; c < C; c += 256) dst[c] = in ? src[c] : 0.f;
+}
+
+// out[b,y,x,:] = shortcut[b,y,x,:] + windows[window(y,x), pos(y,x), :]   (ws == 0: windows is already [B,H,W,C])
+__global__ __launch_bounds__(256) void k_window_merge_add(const float* __restrict__ win, const float* __restrict__ shortcut,
+                                                          int B, int H, int W, int C, int ws, float* __restrict__ out) {
+    const int tok = blockIdx.x;  // b*H*W + y*W + x
+    size_t src_tok = tok;
+    if (ws > 0) {
+        const int nWh = (H + ws - 1) / ws, nWw = (W + ws - 1) / ws;
+        const int b = tok / (H * W), y = (tok / W) % H, x = tok % W;
+        src_tok = ((size_t)(b * nWh + y / ws) * nWw + x / ws) * (ws * ws) + (y % ws) * ws + x % ws;
+    }
+    const float* s = win + src_tok * C;
+    const float* sc = shortcut + (size_t)tok * C;
+    float* d = out + (size_t)tok * C;
+    for (int c = threadIdx.x; c < C; c += 256) d[c] = sc[c] + s[c];
+}
+
+// rel[bh][i][0..n) = q_i . rel_pos_h[ih - kh + n - 1],  rel[bh][i][n..2n) = q_i . rel_pos_w[iw - kw + n - 1]   (q unscaled)
+// qkv [Bw*T, 3*C].  One workgroup per (bh, query row ih): the n queries of that row, the n table rows rel_pos_h[ih - kh + n-1]
+// and the whole rel_pos_w table are staged in LDS (pitch hd+1), then every thread forms its (iw, j) dot products from LDS.
+__global__ __launch_bounds__(256) void k_relpos(const float* __restrict__ qkv, int Bw, int T, int heads, int hd, int n,
+                                                const float* __restrict__ rph, const float* __restrict__ rpw,
+                                                float* __restrict__ rel) {
+    extern __shared__ float rp_lds[];
+    const int P = hd + 1;
+    float* qs = rp_lds;                 // [n][P]
+    float* hs = qs + n * P;             // [n][P]      rel_pos_h rows for kh = 0..n-1
+    float* ws = hs + n * P;             // [2n-1][P]   rel_pos_w
+    const int ih = blockIdx.x, bh = blockIdx.y, b = bh / heads, h = bh % heads, C = heads * hd;
+    for (int e = threadIdx.x; e < n * hd; e += 256) {
+        const int r = e / hd, c = e - r * hd;
+        qs[r * P + c] = qkv[((size_t)b * T + ih * n + r) * 3 * C + h * hd + c];
+        hs[r * P + c] = rph[(size_t)(ih - r + n - 1) * hd + c];
+    }
+    for (int e = threadIdx.x; e < (2 * n - 1) * hd; e += 256) {
+        const int r = e / hd, c = e - r * hd;
+        ws[r * P + c] = rpw[e];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < n * 2 * n; e += 256) {
+        const int iw = e / (2 * n), j = e - iw * 2 * n;
+        const float* q = qs + iw * P;
+        const float* r = j < n ? hs + j * P : ws + (iw - (j - n) + n - 1) * P;
+        float a = 0.f;
+        for (int c = 0; c < hd; ++c) a += q[c] * r[c];
+        rel[(((size_t)bh * T) + ih * n + iw) * 2 * n + j] = a;
+    }
+}
+
+// DB = ceil(hd / 32) output blocks of 32 head dims
+template <int DB>
+__global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv, const float* __restrict__ rel, int T,
+                                                   int heads, int hd, int n, float scale, float* __restrict__ out) {
+    constexpr int DP = DB * 32;          // padded head dim
+    constexpr int KP = DP + 1;           // K tile pitch (odd: the A-operand reads walk rows)
+    __shared__ float Ks[32 * KP];
+    __shared__ float Vs[32 * DP];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, half = lane >> 5;
+    const int bh = blockIdx.y, b = bh / heads, h = bh % heads, C = heads * hd;
+    const int q0 = (blockIdx.x * 4 + wave) * 32;
+    const int qi = q0 + li;              // this lane's query (both halves hold the same one)
+    const bool qlive = qi < T;
+    const float* base = qkv + (size_t)b * T * 3 * C + h * hd;
+    // the lane's query row, B operand of S^T = K Q^T: element d = 2j + half for step j
+    float qreg[DP / 2];
+    {
+        const float* qp = base + (size_t)(qlive ? qi : T - 1) * 3 * C;
+#pragma unroll
+        for (int j = 0; j < DP / 2; ++j) {
+            const int d = 2 * j + half;
+            qreg[j] = (d < hd) ? qp[d] : 0.f;
+        }
+    }
+    // the 32 queries' relative-position rows of this wave, staged once (read every key tile: from global memory that was 64
+    // cache lines per load instruction and bounded the kernel)
+    extern __shared__ float rel_lds[];
+    const int RP = 2 * n + 1;
+    float* relw = rel_lds + (size_t)wave * 32 * RP;
+    if (rel) {
+        for (int e = lane; e < 32 * 2 * n; e += 64) {
+            const int r = e / (2 * n), j = e - r * 2 * n;
+            const int qq = q0 + r < T ? q0 + r : T - 1;
+            relw[r * RP + j] = rel[((size_t)bh * T + qq) * 2 * n + j];
+        }
+    }
+    const float* relq = rel ? relw + li * RP : nullptr;
+    f32x16 o[DB];
+#pragma unroll
+    for (int t = 0; t < DB; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    // K / V tiles: global -> registers one tile ahead (the loads fly under the current tile's MFMAs), registers -> LDS
+    constexpr int EPT = (32 * DP) / 256;  // staged elements per thread and matrix
+    float kreg[EPT], vreg[EPT];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int q = 0; q < EPT; ++q) {
+            const int e = threadIdx.x + 256 * q;
+            const int kr = e / DP, d = e - kr * DP;
+            const int key = k0 + kr;
+            const bool ok = key < T && d < hd;
+            const float* kp = base + (size_t)(key < T ? key : T - 1) * 3 * C + C + (d < hd ? d : 0);
+            kreg[q] = ok ? kp[0] : 0.f;
+            vreg[q] = ok ? kp[C] : 0.f;
+        }
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < T; k0 += 32) {
+        __syncthreads();  // previous tile consumed
+#pragma unroll
+        for (int q = 0; q < EPT; ++q) {
+            const int e = threadIdx.x + 256 * q;
+            const int kr = e / DP, d = e - kr * DP;
+            Ks[kr * KP + d] = kreg[q];
+            Vs[kr * DP + d] = vreg[q];
+        }
+        __syncthreads();
+        if (k0 + 32 < T) fetch(k0 + 32);
+        // ---- S^T[key][query]
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+        for (int j = 0; j < DP / 2; ++j) s = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[li * KP + 2 * j + half], qreg[j], s, 0, 0, 0);
+        // ---- scale, relative-position bias, mask, online softmax (everything per lane = per query)
+        float m_tile = -INFINITY;
+        const int kh0 = relq ? k0 / n : 0, kw0 = relq ? k0 - kh0 * n : 0;  // one division per tile, not per register
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = k0 + vrow(r, half);
+            float v = s[r] * scale;
+            if (relq) {
+                int kh = kh0, kw = kw0 + vrow(r, half);
+                while (kw >= n) { kw -= n; ++kh; }
+                if (key < T) v += relq[kh] + relq[n + kw];
+            }
+            v = key < T ? v : -INFINITY;
+            s[r] = v;
+            m_tile = fmaxf(m_tile, v);
+        }
+        m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 32, 64));
+        const float m_new = fmaxf(m_run, m_tile);
+        const float alpha = expf(m_run - m_new);  // exp(-inf) = 0 on the first tile
+        float l_tile = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float p = expf(s[r] - m_new);
+            s[r] = p;
+            l_tile += p;
+        }
+        l_tile += __shfl_xor(l_tile, 32, 64);
+        l_run = l_run * alpha + l_tile;
+        m_run = m_new;
+        // ---- O^T[d][query] = alpha * O^T + V^T P^T
+#pragma unroll
+        for (int t = 0; t < DB; ++t) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                o[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[vrow(r, half) * DP + t * 32 + li], s[r], o[t], 0, 0, 0);
+        }
+    }
+    if (qlive) {
+        const float inv = 1.f / l_run;
+        float* op = out + ((size_t)b * T + qi) * C + h * hd;
+#pragma unroll
+        for (int t = 0; t < DB; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int d = t * 32 + vrow(r, half);
+                if (d < hd) op[d] = o[t][r] * inv;
+            }
+    }
+}
+
+}  // namespace snf
+
+using namespace snf;
+
+extern "C" int snf_patchify(const float* img, int B, int Cin, int S, int P, float* rows, snf_stream_t stream) {
+    SNF_REQUIRE(img && rows && B > 0 && Cin > 0 && P > 0 && S > 0 && S % P == 0, "snf_patchify: bad argument");
+    const long long total = (long long)B * (S / P) * (S / P) * Cin * P * P;
+    hipLaunchKernelGGL(k_patchify, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, img, B, Cin, S, P,
+                       rows);
+    SNF_LAUNCH_CHECK("snf_patchify");
+    return SNF_OK;
+}
+
+extern "C" int snf_layernorm(const float* x, const float* residual, int N, int C, const float* weight, const float* bias,
+                             float eps, float* sum_out, float* y, snf_stream_t stream) {
+    SNF_REQUIRE(x && weight && bias && y && N > 0 && C > 0, "snf_layernorm: bad argument");
+    hipLaunchKernelGGL(k_layernorm, dim3(ceil_div(N, 4)), dim3(256), 0, (hipStream_t)stream, x, residual, N, C, weight, bias,
+                       eps, sum_out, y);
+    SNF_LAUNCH_CHECK("snf_layernorm");
+    return SNF_OK;
+}
+
+extern "C" int snf_window_partition(const float* x, int B, int H, int W, int C, int ws, float* out, snf_stream_t stream) {
+    SNF_REQUIRE(x && out && B > 0 && H > 0 && W > 0 && C > 0 && ws > 0, "snf_window_partition: bad argument");
+    const int nW = ((H + ws - 1) / ws) * ((W + ws - 1) / ws);
+    hipLaunchKernelGGL(k_window_partition, dim3(B * nW * ws * ws), dim3(256), 0, (hipStream_t)stream, x, B, H, W, C, ws, out);
+    SNF_LAUNCH_CHECK("snf_window_partition");
+    return SNF_OK;
+}
+
+extern "C" int snf_window_merge_add(const float* windows, const float* shortcut, int B, int H, int W, int C, int ws,
+                                    float* out, snf_stream_t stream) {
+    SNF_REQUIRE(windows && shortcut && out && B > 0 && H > 0 && W > 0 && C > 0 && ws >= 0, "snf_window_merge_add: bad argument");
+    hipLaunchKernelGGL(k_window_merge_add, dim3(B * H * W), dim3(256), 0, (hipStream_t)stream, windows, shortcut, B, H, W, C, ws,
+                       out);
+    SNF_LAUNCH_CHECK("snf_window_merge_add");
+    return SNF_OK;
+}
+
+extern "C" int snf_relpos(const float* qkv, int Bw, int T, int heads, int head_dim, int n, const float* rel_pos_h,
+                          const float* rel_pos_w, float* rel, snf_stream_t stream) {
+    SNF_REQUIRE(qkv && rel_pos_h && rel_pos_w && rel && Bw > 0 && heads > 0 && head_dim > 0 && n > 0 && T == n * n,
+                "snf_relpos: bad argument (T must be n*n)");
+    const size_t lds = (size_t)(4 * n - 1) * (head_dim + 1) * sizeof(float);
+    SNF_REQUIRE(lds <= 160 * 1024, "snf_relpos: n * head_dim too large for the LDS staging");
+    if (lds > 48 * 1024) hipFuncSetAttribute((const void*)k_relpos, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_relpos, dim3(n, Bw * heads), dim3(256), lds, (hipStream_t)stream, qkv, Bw, T, heads, head_dim, n,
+                       rel_pos_h, rel_pos_w, rel);
+    SNF_LAUNCH_CHECK("snf_relpos");
+    return SNF_OK;
+}
+
+extern "C" int snf_attention(const float* qkv, const float* rel, int Bw, int T, int heads, int head_dim, int n, float scale,
+                             float* out, snf_stream_t stream) {
+    SNF_REQUIRE(qkv && out && Bw > 0 && T > 0 && heads > 0 && head_dim > 0 && head_dim <= 96,
+                "snf_attention: bad argument (head_dim <= 96)");
+    SNF_REQUIRE(!rel || (n > 0 && T == n * n), "snf_attention: relative positions need T == n*n");
+    dim3 grid(ceil_div(T, 128), Bw * heads);
+    const int DB = (head_dim + 31) / 32;
+    const size_t lds = rel ? (size_t)4 * 32 * (2 * n + 1) * sizeof(float) : 0;
+    SNF_REQUIRE(lds <= 100 * 1024, "snf_attention: grid side n=%d too large for the relative-position staging", n);
+#define SNF_ATT(DB_)                                                                                                        \
+    do {                                                                                                                    \
+        if (lds > 32 * 1024)                                                                                                \
+            hipFuncSetAttribute((const void*)k_attention<DB_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);       \
+        hipLaunchKernelGGL(k_attention<DB_>, grid, dim3(256), lds, (hipStream_t)stream, qkv, rel, T, heads, head_dim, n, scale, \
+                           out);                                                                                            \
+    } while (0)
+    if (DB == 1) SNF_ATT(1); else if (DB == 2) SNF_ATT(2); else SNF_ATT(3);
+#undef SNF_ATT
+    SNF_LAUNCH_CHECK("snf_attention");
+    return SNF_OK;
+}

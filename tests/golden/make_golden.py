@@ -578,10 +578,51 @@ def fx_batch_builder():
         batch_sam=ref_sam, batch_clipseg=ref_clip)
 
 
+# ---------------------------------------------------------------------------------------------
+def fx_vit():
+    """the SAM image encoder.  The reference's two model files are loaded as a synthetic package (its
+    own package __init__ pulls in the predictor / torchvision stack); small configuration with one windowed block (window 5
+    on a 14 x 14 grid: padded to 15) and one global block, random rel-pos tables."""
+    import importlib.util
+    import types
+    from functools import partial
+    from oracle import vit_oracle as V
+    pkg = types.ModuleType("ref_sa_modeling")
+    pkg.__path__ = [os.path.join(REF, "samnerf/segment_anything/modeling")]
+    sys.modules["ref_sa_modeling"] = pkg
+    for m in ("common", "image_encoder"):
+        spec = importlib.util.spec_from_file_location(f"ref_sa_modeling.{m}", os.path.join(pkg.__path__[0], m + ".py"))
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules[f"ref_sa_modeling.{m}"] = mod
+        spec.loader.exec_module(mod)
+    Ref = sys.modules["ref_sa_modeling.image_encoder"].ImageEncoderViT
+    cfg = V.ViTConfig(img_size=224, patch_size=16, embed_dim=32, depth=2, num_heads=2, mlp_ratio=2.0, out_chans=16,
+                      window_size=5, global_attn_indexes=(1,))
+    ref = Ref(img_size=cfg.img_size, patch_size=cfg.patch_size, embed_dim=cfg.embed_dim, depth=cfg.depth,
+              num_heads=cfg.num_heads, mlp_ratio=cfg.mlp_ratio, out_chans=cfg.out_chans, qkv_bias=True,
+              norm_layer=partial(torch.nn.LayerNorm, eps=1e-6), use_rel_pos=True, window_size=cfg.window_size,
+              global_attn_indexes=cfg.global_attn_indexes)
+    sd = V.init_weights(cfg, seed=4)
+    missing = ref.load_state_dict(sd, strict=True)
+    ref.eval()
+    x = torch.randn((2, 3, 224, 224), generator=torch.Generator().manual_seed(5))
+    with torch.no_grad():
+        y_ref = ref(x)
+        t0 = ref.patch_embed(x) + ref.pos_embed
+        t1 = ref.blocks[0](t0)
+        t2 = ref.blocks[1](t1)
+        y, trace = V.forward(sd, x, cfg, return_tokens=True)
+    check("vit tokens after patch embed", trace[0], t0, 1e-6)
+    check("vit block 0 (windowed, padded)", trace[1], t1, 2e-6)
+    check("vit block 1 (global)", trace[2], t2, 2e-6)
+    check("vit output", y, y_ref, 2e-6)
+    npz("vit_small", x=x, y=y_ref, t0=t0, t1=t1, t2=t2, **{"w:" + k: v for k, v in sd.items()})
+
+
 if __name__ == "__main__":
     only = set(sys.argv[1:])
     for fn in (fx_spacing, fx_contraction, fx_hashgrid, fx_mlp, fx_sh, fx_weights, fx_pdf, fx_render, fx_topk,
-               fx_losses, fx_ministep, fx_batch_builder):
+               fx_losses, fx_ministep, fx_batch_builder, fx_vit):
         if only and fn.__name__ not in only:
             continue
         print(fn.__name__)

@@ -180,3 +180,19 @@ def test_batch_builder(golden):
     assert torch.equal(batch["image"], T("batch_image")) and torch.equal(batch["sam"], T("batch_sam"))
     assert torch.equal(batch["clipseg"], T("batch_clipseg")) and torch.equal(bd, T("directions"))
     assert float((d.norm(dim=-1) - 1).abs().max()) < 1e-6
+
+
+def test_vit_oracle_vs_reference_fixture(golden):
+    """oracle/vit_oracle.py against the outputs of the reference's ImageEncoderViT (small configuration:
+    one padded windowed block, one global block, random rel-pos tables)."""
+    from oracle import vit_oracle as V
+    g = golden("vit_small")
+    cfg = V.ViTConfig(img_size=224, patch_size=16, embed_dim=32, depth=2, num_heads=2, mlp_ratio=2.0, out_chans=16,
+                      window_size=5, global_attn_indexes=(1,))
+    sd = {k[2:]: torch.from_numpy(np.ascontiguousarray(g[k])) for k in g.keys() if k.startswith("w:")}
+    assert set(sd) == set(V.init_weights(cfg).keys())
+    y, trace = V.forward(sd, torch.from_numpy(g["x"]), cfg, return_tokens=True)
+    close(trace[0], T(g["t0"]), 1e-6)
+    close(trace[1], T(g["t1"]), 2e-6)
+    close(trace[2], T(g["t2"]), 2e-6)
+    close(y, T(g["y"]), 2e-6)

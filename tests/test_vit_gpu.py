@@ -1,0 +1,106 @@
+"""GPU tests of the SAM image encoder forward: the reference-generated fixture (small configuration with a
+padded windowed block and a global block), per-kernel checks against torch, and ViT-H-shaped layers against the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import vit_oracle as V
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _fp32_gemm():
+    from samnerf_amd import ops
+    ops.set_gemm_mode("fp32")
+    yield
+    ops.set_gemm_mode("bf16x3")
+
+
+def _build(cfg, sd):
+    from functools import partial
+    from samnerf_amd.image_encoder import ImageEncoderViT
+    enc = ImageEncoderViT(img_size=cfg.img_size, patch_size=cfg.patch_size, embed_dim=cfg.embed_dim, depth=cfg.depth,
+                          num_heads=cfg.num_heads, mlp_ratio=cfg.mlp_ratio, out_chans=cfg.out_chans, qkv_bias=True,
+                          norm_layer=partial(torch.nn.LayerNorm, eps=1e-6), use_rel_pos=cfg.use_rel_pos,
+                          window_size=cfg.window_size, global_attn_indexes=cfg.global_attn_indexes)
+    enc.load_state_dict(sd, strict=True)
+    return enc.cuda().eval()
+
+
+def test_encoder_vs_reference_fixture(golden):
+    g = golden("vit_small")
+    cfg = V.ViTConfig(img_size=224, patch_size=16, embed_dim=32, depth=2, num_heads=2, mlp_ratio=2.0, out_chans=16,
+                      window_size=5, global_attn_indexes=(1,))
+    sd = {k[2:]: torch.from_numpy(np.ascontiguousarray(g[k])) for k in g.keys() if k.startswith("w:")}
+    enc = _build(cfg, sd)
+    x = torch.from_numpy(g["x"])
+    y = enc(x.cuda()).cpu()
+    ref = torch.from_numpy(g["y"])
+    assert y.shape == ref.shape
+    assert float((y - ref).abs().max()) <= 1e-4 * max(1.0, float(ref.abs().max()))
+    from samnerf_amd import ops
+    ops.set_gemm_mode("bf16x3")  # the product default
+    y3 = enc(x.cuda()).cpu()
+    assert float((y3 - ref).abs().max()) <= 1e-4 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("Bw,n,heads,hd,rel", [(3, 14, 2, 80, True), (1, 9, 1, 16, False), (2, 5, 3, 40, True)])
+def test_attention_kernel_vs_torch(Bw, n, heads, hd, rel):
+    from samnerf_amd import ops
+    g = torch.Generator().manual_seed(n + hd)
+    T, C = n * n, heads * hd
+    qkv = torch.randn((Bw * T, 3 * C), generator=g)
+    rph, rpw = torch.randn((2 * n - 1, hd), generator=g) * 0.3, torch.randn((2 * n - 1, hd), generator=g) * 0.3
+    sd = {"qkv.weight": torch.eye(3 * C), "qkv.bias": torch.zeros(3 * C), "proj.weight": torch.eye(C), "proj.bias": torch.zeros(C),
+          "rel_pos_h": rph, "rel_pos_w": rpw}
+    # the oracle's attention() with identity qkv / proj layers: x = the qkv rows' "input" is qkv itself only if C_in = 3C;
+    # compute the expected result directly instead
+    q4 = qkv.view(Bw, T, 3, heads, hd).permute(2, 0, 3, 1, 4).reshape(3, Bw * heads, T, hd).double()
+    q, k, v = q4.unbind(0)
+    attn = (q * hd ** -0.5) @ k.transpose(-2, -1)
+    if rel:
+        Rh, Rw = V.get_rel_pos(n, n, rph.double()), V.get_rel_pos(n, n, rpw.double())
+        rq = q.reshape(-1, n, n, hd)
+        attn = (attn.view(-1, n, n, n, n) + torch.einsum("bhwc,hkc->bhwk", rq, Rh)[:, :, :, :, None]
+                + torch.einsum("bhwc,wkc->bhwk", rq, Rw)[:, :, :, None, :]).view(-1, T, T)
+    ref = (attn.softmax(-1) @ v).view(Bw, heads, T, hd).permute(0, 2, 1, 3).reshape(Bw * T, C)
+    out = ops.attention(qkv.cuda(), Bw, T, heads, n, rph.cuda() if rel else None, rpw.cuda() if rel else None).cpu().double()
+    assert float((out - ref).abs().max()) <= 2e-5
+
+
+def test_layernorm_window_kernels_vs_torch():
+    from samnerf_amd import ops
+    g = torch.Generator().manual_seed(0)
+    x, r = torch.randn((300, 96), generator=g), torch.randn((300, 96), generator=g)
+    w, b = torch.randn((96,), generator=g), torch.randn((96,), generator=g)
+    y, s = ops.layernorm(x.cuda(), w.cuda(), b.cuda(), 1e-6, residual=r.cuda(), want_sum=True)
+    ref = torch.nn.functional.layer_norm((x + r).double(), (96,), w.double(), b.double(), 1e-6)
+    assert float((y.cpu().double() - ref).abs().max()) <= 1e-5 and torch.equal(s.cpu(), x + r)
+    B, H, W, C, ws = 2, 14, 14, 8, 5
+    t = torch.randn((B, H, W, C), generator=g)
+    win, pad_hw = V.window_partition(t, ws)
+    got = ops.window_partition(t.view(-1, C).cuda(), B, H, W, ws).cpu()
+    assert torch.equal(got, win.reshape(-1, C))
+    sc = torch.randn((B * H * W, C), generator=g)
+    merged = ops.window_merge_add(got.cuda(), sc.cuda(), B, H, W, ws).cpu()
+    assert torch.equal(merged, sc + V.window_unpartition(win, ws, pad_hw, (H, W)).reshape(-1, C))
+    img = torch.randn((2, 3, 64, 64), generator=g)
+    rows = ops.patchify(img.cuda(), 16).cpu()
+    ref_rows = torch.nn.functional.unfold(img, 16, stride=16).transpose(1, 2).reshape(-1, 3 * 256)
+    assert torch.equal(rows, ref_rows)
+
+
+def test_vit_h_shaped_block_vs_oracle():
+    """One windowed and one global block at ViT-H width (1280, 16 heads of 80, window 14, 64 x 64 tokens): oracle on the GPU
+    (torch fp32) against the HIP forward."""
+    cfg = V.ViTConfig(depth=2, global_attn_indexes=(1,))
+    sd = V.init_weights(cfg, seed=1)
+    enc = _build(cfg, sd)
+    x = torch.randn((1, 3, 1024, 1024), generator=torch.Generator().manual_seed(2))
+    y = enc(x.cuda())
+    with torch.no_grad():
+        ref = V.forward({k: v.cuda() for k, v in sd.items()}, x.cuda(), cfg)
+    assert y.shape == (1, 256, 64, 64)
+    err = float((y - ref).abs().max())
+    assert err <= 2e-4 * max(1.0, float(ref.abs().max())), err
