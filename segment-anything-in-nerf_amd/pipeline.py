@@ -189,6 +189,7 @@ class Trainer:
         if hasattr(model, "feature_streams"):
             model.feature_streams = self._side if use_side else None
         _, loss_dict, metrics_dict = self.pipeline.get_train_loss_dict(step=step)
+        prop_updated = getattr(getattr(model, "proposal_sampler", None), "last_updated", True)
         head_losses = {h: loss_dict[k] for h, k in self.HEAD_LOSS.items() if k in loss_dict}
         rest = [v for k, v in loss_dict.items() if k not in self.HEAD_LOSS.values()]
         if use_side and len(head_losses) > 0:
@@ -203,6 +204,8 @@ class Trainer:
             def nerf_task():  # on the main stream
                 loss_rest.backward()
                 for g in rest_groups:
+                    if g == "proposal_networks" and not prop_updated:
+                        continue  # no gradient this step (ray_samplers.py:569-579): Adam skips the group, as torch does
                     opt.exchange_and_step(g)
 
             # host enqueue order (the GPU runs the three tasks concurrently; a task cannot start before the host has
@@ -240,6 +243,8 @@ class Trainer:
             loss.backward()
             # same arena slices as the three-task schedule (the sharded optimizer's layout must not depend on the schedule)
             for g in opt.arenas:
+                if g == "proposal_networks" and not prop_updated:
+                    continue
                 if g == "sam_field":
                     first = True
                     for lo_i, hi_i in self._head_param_ranges().values():

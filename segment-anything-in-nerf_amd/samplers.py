@@ -99,6 +99,7 @@ class ProposalNetworkSampler(Sampler):
         self._anneal = 1.0
         self._steps_since_update = 0
         self._step = 0
+        self.last_updated = True
 
     def set_anneal(self, anneal: float) -> None:
         self._anneal = anneal
@@ -114,6 +115,10 @@ class ProposalNetworkSampler(Sampler):
         n = self.num_proposal_network_iterations
         weights, ray_samples = None, None
         updated = self._steps_since_update > self.update_sched(self._step) or self._step < 10
+        if torch.is_grad_enabled():
+            # remembered for the trainer: on a non-update step the proposal parameters have NO gradient in the reference
+            # (grad is None), so torch.optim.Adam skips them entirely -- no moment decay, no step count
+            self.last_updated = bool(updated)
         for i_level in range(n + 1):
             is_prop = i_level < n
             num_samples = self.num_proposal_samples_per_ray[i_level] if is_prop else self.num_nerf_samples_per_ray
