@@ -93,6 +93,8 @@ int b3_try_fwd(const float* X, const float* W, const float* bias, int N, int I, 
                snf_stream_t stream);
 int b3_try_fwd_splitk(const float* X, const float* W, int N, int I, int O, int ldx, int ksplit, int splits, float* P,
                       snf_stream_t stream);
+int b3_try_bwd_weight(const float* dY, const float* Y, const float* X, int N, int I, int O, int lddy, int ldy, int ldx,
+                      int act, float* dW, float* dbias, snf_stream_t stream);
 int b3_try_bwd_data(const float* dY, const float* Y, const float* W, int N, int I, int O, int lddy, int ldy, int lddx,
                     int act, float* dX, snf_stream_t stream);
 

@@ -439,6 +439,10 @@ extern "C" int snf_linear_bwd_weight(const float* dY, const float* Y, const floa
     SNF_REQUIRE(act == SNF_ACT_NONE || Y, "snf_linear_bwd_weight: Y required for activation derivative");
     SNF_REQUIRE(act != SNF_ACT_GELU, "snf_linear_bwd_weight: GELU is forward-only (image encoder inference)");
     SNF_REQUIRE(N > 0 && I > 0 && O > 0 && lddy >= O && ldx >= I, "snf_linear_bwd_weight: bad shape");
+    if (b3_try_bwd_weight(dY, Y, X, N, I, O, lddy, ldy, ldx, act, dW, dbias, stream)) {
+        SNF_LAUNCH_CHECK("snf_linear_bwd_weight(bf16x3)");
+        return SNF_OK;
+    }
     // activations may be stored with padded leading dimensions (multiple of 4): the vector loaders mask pad columns
     const int vecA = aligned16(dY) && (lddy % 4 == 0) && (act == SNF_ACT_NONE || (aligned16(Y) && ldy % 4 == 0));
     const int vecB = aligned16(X) && (ldx % 4 == 0);

@@ -214,6 +214,84 @@ __global__ __launch_bounds__(256) void k_gemm_rows_b3(const float* __restrict__ 
     }
 }
 
+// Weight gradient on the bf16 matrix cores: dW[O,I] += sum_n dZ[n][o] X[n][i], dZ = dY * act'(Y).  The contraction runs over
+// the ROWS, so both operands are staged transposed ([o][k = row] and [i][k = row] bf16 planes): a thread loads two consecutive
+// rows of four columns and writes four packed (k, k+1) pairs per plane.  64 x 64 output tile, waves 2 x 2, 32 rows per trip;
+// partial sums of a row chunk are added to dW with fp32 atomics (as the fp32 kernel does).
+__global__ __launch_bounds__(256) void k_gemm_wgrad_b3(const float* __restrict__ dY, const float* __restrict__ Y,
+                                                       const float* __restrict__ X, int N, int I, int O, int lddy, int ldy,
+                                                       int ldx, int act, int rows_per_block, float* __restrict__ dW,
+                                                       float* __restrict__ dbias) {
+    __shared__ __attribute__((aligned(16))) uint16_t Ah[64 * B3_PITCH];
+    __shared__ __attribute__((aligned(16))) uint16_t Al[64 * B3_PITCH];
+    __shared__ __attribute__((aligned(16))) uint16_t Bh[64 * B3_PITCH];
+    __shared__ __attribute__((aligned(16))) uint16_t Bl[64 * B3_PITCH];
+    __shared__ float bs[64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, half = lane >> 5, wm = wave >> 1, wn = wave & 1;
+    const int o0 = blockIdx.x * 64, i0 = blockIdx.y * 64;
+    const int n_begin = blockIdx.z * rows_per_block, n_end = min(N, n_begin + rows_per_block);
+    const int q = tid & 15, kp = tid >> 4;  // 16 column quads x 16 row pairs
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+    if (tid < 64) bs[tid] = 0.f;
+    float4 av[2], bv[2];
+    auto fetch = [&](int n0) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int n = n0 + 2 * kp + p;
+            av[p] = b3_load_a<true>(dY, Y, n, o0 + q * 4, n_end, O, lddy, ldy, act);
+            bv[p] = b3_load_b(X, n, i0 + q * 4, n_end, I, ldx);
+        }
+    };
+    fetch(n_begin);
+    for (int n0 = n_begin; n0 < n_end; n0 += B3_BK) {
+        __syncthreads();
+        {
+            const float a0[4] = {av[0].x, av[0].y, av[0].z, av[0].w}, a1[4] = {av[1].x, av[1].y, av[1].z, av[1].w};
+            const float b0[4] = {bv[0].x, bv[0].y, bv[0].z, bv[0].w}, b1[4] = {bv[1].x, bv[1].y, bv[1].z, bv[1].w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                uint32_t h, l;
+                split2(a0[c], a1[c], h, l);  // rows (2kp, 2kp+1) of column o0 + 4q + c -> k positions (2kp, 2kp+1)
+                *reinterpret_cast<uint32_t*>(&Ah[(q * 4 + c) * B3_PITCH + 2 * kp]) = h;
+                *reinterpret_cast<uint32_t*>(&Al[(q * 4 + c) * B3_PITCH + 2 * kp]) = l;
+                split2(b0[c], b1[c], h, l);
+                *reinterpret_cast<uint32_t*>(&Bh[(q * 4 + c) * B3_PITCH + 2 * kp]) = h;
+                *reinterpret_cast<uint32_t*>(&Bl[(q * 4 + c) * B3_PITCH + 2 * kp]) = l;
+                bsum[c] += a0[c] + a1[c];
+            }
+        }
+        __syncthreads();
+        if (n0 + B3_BK < n_end) fetch(n0 + B3_BK);
+#pragma unroll
+        for (int ks = 0; ks < B3_BK / 16; ++ks) {
+            const int ko = ks * 16 + half * 8;
+            const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&Ah[(wm * 32 + li) * B3_PITCH + ko]);
+            const bf16x8 al = *reinterpret_cast<const bf16x8*>(&Al[(wm * 32 + li) * B3_PITCH + ko]);
+            const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&Bh[(wn * 32 + li) * B3_PITCH + ko]);
+            const bf16x8 bl = *reinterpret_cast<const bf16x8*>(&Bl[(wn * 32 + li) * B3_PITCH + ko]);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int o = o0 + wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half;
+        const int i = i0 + wn * 32 + li;
+        if (o < O && i < I) unsafeAtomicAdd(&dW[(size_t)o * I + i], acc[reg]);
+    }
+    if (dbias != nullptr && blockIdx.y == 0) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) atomicAdd(&bs[q * 4 + c], bsum[c]);
+        __syncthreads();
+        if (tid < 64 && o0 + tid < O) unsafeAtomicAdd(&dbias[o0 + tid], bs[tid]);
+    }
+}
+
 // widest column tile (up to the SNF_B3_BN cap, default 128) that still leaves >= 256 workgroups (one per CU); 64 otherwise
 static int b3_pick_bn(int M, int Nc) {
     static const int cap = getenv("SNF_B3_BN") ? atoi(getenv("SNF_B3_BN")) : 128;
@@ -283,5 +361,22 @@ int snf::b3_try_bwd_data(const float* dY, const float* Y, const float* W, int N,
     else if (bn == 192) B3_LAUNCH(false, true, 192, grid, stream, dY, Y, W, none, N, O, I, lddy, ldy, I, lddx, act, SNF_ACT_NONE, dX);
     else if (bn == 128) B3_LAUNCH(false, true, 128, grid, stream, dY, Y, W, none, N, O, I, lddy, ldy, I, lddx, act, SNF_ACT_NONE, dX);
     else B3_LAUNCH(false, true, 64, grid, stream, dY, Y, W, none, N, O, I, lddy, ldy, I, lddx, act, SNF_ACT_NONE, dX);
+    return 1;
+}
+
+int snf::b3_try_bwd_weight(const float* dY, const float* Y, const float* X, int N, int I, int O, int lddy, int ldy, int ldx,
+                           int act, float* dW, float* dbias, snf_stream_t stream) {
+    if (!b3_enabled() || O < 64 || I < 64 || (I % 4) || (O % 4) || (lddy % 4) || (ldx % 4) || ((uintptr_t)dY & 15) ||
+        ((uintptr_t)X & 15) || (act != SNF_ACT_NONE && ((ldy % 4) || ((uintptr_t)Y & 15))))
+        return 0;
+    const int to = ceil_div(O, 64), ti = ceil_div(I, 64);
+    int chunks = 1024 / (to * ti);
+    if (chunks < 1) chunks = 1;
+    int rows = ceil_div(N, chunks);
+    rows = ((rows + B3_BK - 1) / B3_BK) * B3_BK;
+    if (rows < 4 * B3_BK) rows = 4 * B3_BK;
+    chunks = ceil_div(N, rows);
+    hipLaunchKernelGGL(k_gemm_wgrad_b3, dim3(to, ti, chunks), dim3(256), 0, (hipStream_t)stream, dY, Y, X, N, I, O, lddy, ldy, ldx,
+                       act, rows, dW, dbias);
     return 1;
 }
