@@ -245,15 +245,18 @@ def main():
                 t = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
             except OSError:
                 return None
-            return t["traffic_bytes_per_launch"] if t["workload"] == args.workload and t["kernel"] == key and world == 1 else None
+            return t["traffic_over_algorithmic"] if t["workload"] == args.workload and t["kernel"] == key and world == 1 else None
 
         roofline = None
         if dom is not None and dom in live:
             # contract: the dominant kernel timed live over the timed region.  The step runs three streams concurrently,
             # so this duration includes whatever shared the GPU with the kernel (a lower bound on its own roofline).
             roofline = roof(dom, live[dom], args.steps, "HIP events, timed region (3 concurrent streams)")
-            roofline["traffic"] = pmc_traffic(dom)
-            roofline["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 PMC passes, per launch)" if roofline["traffic"] else None
+            ratio = pmc_traffic(dom)  # measured HBM bytes / algorithmic bytes of the same launches in the PMC passes
+            roofline["traffic"] = ratio * roofline["algorithmic_units_per_launch"] if ratio else None
+            roofline["traffic_source"] = ("profiles/pmc_traffic.json: rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this command, "
+                                          f"HBM bytes = {ratio:.4f} x algorithmic bytes, scaled to this run's launch mix"
+                                          if ratio else None)
             roofline["serial"] = roof(dom, breakdown[dom], n_break, "HIP events, serial replay (kernel alone on the GPU)")
         others = []
         for k in sorted(per_step, key=lambda kk: -per_step[kk]):
