@@ -188,8 +188,8 @@ def main():
     dom = args.roofline_kernel
     if dom is None and per_step:
         modelled = [k for k in per_step if model_of(k)[1]]
-        rank = lambda k: per_step[k] * largest_kernel_share.get(k.partition("/")[0], 1.0)  # noqa: E731
-        dom = max(modelled, key=rank) if modelled else None
+        dom = (max(modelled, key=lambda k: per_step[k] * largest_kernel_share.get(k.partition("/")[0], 1.0))
+               if modelled else None)
     if dom is not None:
         ops.enable_kernel_timing([dom])
 
