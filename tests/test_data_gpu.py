@@ -147,3 +147,88 @@ def test_train_step_from_disk_datamanager(tmp_path):
         trainer.synchronize()
         losses.append(float(sum(v.detach() for v in ld.values())))
     assert all(np.isfinite(losses)) and min(losses[-3:]) < losses[0]
+
+
+def test_config1_no_distill_llff_scene_trajectory_vs_oracle():
+    """BASELINE configs[0]: samnerf_no_distill on a 2-image synthetic forward-facing scene, 1024 rays x 48 samples.  Rays come
+    from the HIP batch builder (pixel sampler + pinhole cameras), the oracle trains on the very same rays / jitter with
+    torch.optim.Adam: per-step losses within 1e-4, eval PSNR within 0.01 dB."""
+    from samnerf_amd import configs
+    from samnerf_amd.data import Cameras, DiskSAMDataManagerConfig
+    from samnerf_amd.interop import load_named_params
+    from samnerf_amd.rays import RayBundle
+    R, P, S, T, NSTEP, H, W = 1024, 64, 48, 12, 6, 64, 64
+    g = torch.Generator().manual_seed(2)
+    yy, xx = torch.meshgrid(torch.linspace(0, 1, H), torch.linspace(0, 1, W), indexing="ij")
+    images = torch.stack([torch.stack([0.5 + 0.5 * torch.sin(6 * xx + i), yy, 0.5 + 0.5 * torch.cos(5 * yy * xx + i)], -1)
+                          for i in range(2)])
+    c2w = torch.eye(4)[None, :3].repeat(2, 1, 1)
+    c2w[0, :, 3] = torch.tensor([-0.2, 0.0, 0.6])
+    c2w[1, :, 3] = torch.tensor([0.2, 0.05, 0.6])
+    cams = Cameras(c2w, 60.0, 60.0, W / 2, H / 2, W, H)
+    tc = copy.deepcopy(configs.method_configs["samnerf_no_distill"])
+    tc.pipeline.datamanager = DiskSAMDataManagerConfig(train_num_rays_per_batch=R, patch_size=1, distill_sam=False)
+    mc = tc.pipeline.model
+    mc.num_proposal_samples_per_ray, mc.num_nerf_samples_per_ray = (P,), S
+    mc.log2_hashmap_size = T
+    mc.proposal_net_args_list = [dict(a, log2_hashmap_size=T) for a in mc.proposal_net_args_list]
+    pipe_cfg = tc.pipeline
+    # the datamanager is built from in-memory images / cameras (the file readers are covered by test_disk_formats_*)
+    orig_setup = pipe_cfg.datamanager.setup
+    pipe_cfg.datamanager.setup = lambda **kw: orig_setup(images=images, cameras=cams, **kw)
+    trainer = tc.setup(device="cuda")
+    trainer.setup()
+    model = trainer.pipeline.model
+    cfg = O.PathConfig(num_proposal_samples=P, num_nerf_samples=S, num_sam_samples=3, patch_size=1, distill_sam=False).small(T)
+    params = O.init_params(cfg, seed=3, table_scale=0.05)
+    load_named_params(model, params)
+    ref = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    ocfg = trainer.config.optimizers
+    group_of = lambda n: "proposal_networks" if n.startswith("prop") else "fields"  # noqa: E731
+    opts = {gname: torch.optim.Adam([v for n, v in ref.items() if group_of(n) == gname], lr=ocfg[gname]["optimizer"].lr,
+                                    eps=ocfg[gname]["optimizer"].eps) for gname in trainer.optimizers.arenas}
+    dm = trainer.pipeline.datamanager
+    real_next = dm.next_train
+    seen = {}
+
+    def recording_next(step):
+        rb, batch = real_next(step)
+        seen["rb"], seen["batch"] = rb, batch
+        return rb, batch
+
+    dm.next_train = recording_next
+    hip_losses, ref_losses = [], []
+    for step in range(NSTEP):
+        t_rand, u_rand = torch.rand((R, 1), generator=g), torch.rand((R, 1), generator=g)
+        model.proposal_sampler.initial_sampler.jitter_override = t_rand.cuda()
+        model.proposal_sampler.pdf_sampler.jitter_override = u_rand.cuda()
+        lrs = {k: trainer.optimizers.lr(k) for k in opts}
+        _, ld, _ = trainer.train_iteration(step)
+        trainer.synchronize()
+        hip_losses.append(float(sum(v.detach() for v in ld.values())))
+        o, d = seen["rb"].origins.cpu(), seen["rb"].directions.cpu()
+        batch = {"image": seen["batch"]["image"].cpu()}
+        for k, opt in opts.items():
+            for pg in opt.param_groups:
+                pg["lr"] = lrs[k]
+            opt.zero_grad(set_to_none=True)
+        out = O.forward(ref, cfg, o, d, True, t_rand, u_rand, O.proposal_anneal(step), get_feature=())
+        loss = sum(O.loss_dict(out, batch, cfg).values())
+        loss.backward()
+        for opt in opts.values():
+            opt.step()
+        ref_losses.append(float(loss))
+    rel = [abs(a - b) / abs(b) for a, b in zip(hip_losses, ref_losses)]
+    assert max(rel) <= 1e-4, (hip_losses, ref_losses)
+    assert ref_losses[-1] < ref_losses[0]
+    # eval: render camera 0 with both and compare PSNR against the image
+    model.proposal_sampler.initial_sampler.jitter_override = None
+    model.proposal_sampler.pdf_sampler.jitter_override = None
+    model.eval()
+    cam_rb = dm.cameras.generate_rays(0)
+    with torch.no_grad():
+        rgb_hip = model.get_outputs_for_camera_ray_bundle(cam_rb)["rgb"].cpu()
+        rgb_ref = O.render_camera({k: v.detach() for k, v in ref.items()}, cfg, cam_rb.origins.cpu(), cam_rb.directions.cpu(),
+                                  chunk=4096)["rgb"]
+    psnr = lambda x: float(-10.0 * torch.log10(torch.mean((x - images[0]) ** 2)))  # noqa: E731
+    assert abs(psnr(rgb_hip) - psnr(rgb_ref)) <= 0.01, (psnr(rgb_hip), psnr(rgb_ref))
