@@ -226,8 +226,10 @@ int snf_distortion(const float* sbins, const float* w, int R, int S, float grad_
 
 /* ---- a19: L2 losses.  loss = weight * mean over rows r of mean_c (pred - target)^2 ; with nan_skip the mean runs over the
  * rows whose own mean is not NaN ( = mse_loss(.., 'none').mean(-1).nanmean(), samnerf/sam_model.py:316-328; without it
- * nn.MSELoss(), nerfstudio/models/nerfacto.py:326 ).  acc: 4 zeroed scratch words (left zeroed); out: {loss, counted rows}.
+ * nn.MSELoss(), nerfstudio/models/nerfacto.py:326 ).  acc: SNF_ROWMSE_SCRATCH_WORDS zeroed scratch words (the ticket word is
+ * left zeroed, so the buffer can be reused by later calls on the same stream); out: {loss, counted rows}.
  * bwd: dpred = gout * weight * 2 (pred - target) / (C * out[1]), zero for skipped rows; gout, out are device scalars. */
+#define SNF_ROWMSE_SCRATCH_WORDS 516
 int snf_rowmse_loss_fwd(const float* pred, const float* target, int R, int C, float weight, int nan_skip, float* acc,
                         float* out, snf_stream_t stream);
 int snf_rowmse_loss_bwd(const float* pred, const float* target, int R, int C, float weight, int nan_skip,

@@ -114,7 +114,10 @@ __global__ __launch_bounds__(256) void k_distortion(const float* __restrict__ sb
 //           w * mse_loss(pred, target, 'none').mean(-1).nanmean()      = mean over the rows whose own mean is not NaN
 // (samnerf/sam_model.py:316-328, nerfstudio/models/nerfacto.py:326-333).  One wavefront per row; workgroup partials are
 // added to two device scalars, and the LAST workgroup to arrive (atomic ticket) turns them into {loss, row count} -- one
-// launch, no host involvement.  `acc` is 4 caller-zeroed words {sum, count, ticket, -}; they are left zeroed again.
+// launch, no host involvement.  `acc` is a scratch buffer of SNF_ROWMSE_SCRATCH_WORDS words whose ticket word (index
+// 2 * 256) must be zero on entry; it is left zeroed again.
+constexpr int RM_MAX_BLOCKS = 256;
+
 __global__ __launch_bounds__(256) void k_rowmse_fwd(const float* __restrict__ pred, const float* __restrict__ target, int R,
                                                     int C, float weight, int nan_skip, float* __restrict__ acc,
                                                     float* __restrict__ out) {
@@ -142,17 +145,29 @@ __global__ __launch_bounds__(256) void k_rowmse_fwd(const float* __restrict__ pr
     }
     if (lane == 0) { s_sum[wave] = wsum; s_cnt[wave] = wcnt; }
     __syncthreads();
+    __shared__ bool last;
     if (threadIdx.x == 0) {
-        atomicAdd(&acc[0], s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3]);
-        atomicAdd(&acc[1], s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3]);
+        // per-workgroup partials in their own slots (no same-address float atomics); only the ticket is shared
+        acc[blockIdx.x] = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
+        acc[RM_MAX_BLOCKS + blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
         __threadfence();
-        const unsigned ticket = atomicAdd(reinterpret_cast<unsigned*>(&acc[2]), 1u);
-        if (ticket == gridDim.x - 1) {  // every partial is in: finish and leave the scratch words zeroed
-            __threadfence();
-            const float total = atomicExch(&acc[0], 0.f), count = atomicExch(&acc[1], 0.f);
-            atomicExch(reinterpret_cast<unsigned*>(&acc[2]), 0u);
-            out[0] = weight * (total / count);  // 0/0 = NaN when every row is skipped, as torch.nanmean does
-            out[1] = count;
+        const unsigned ticket = atomicAdd(reinterpret_cast<unsigned*>(&acc[2 * RM_MAX_BLOCKS]), 1u);
+        last = ticket == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (last && wave == 0) {  // every partial is in: the last workgroup's first wave finishes and re-arms the ticket
+        __threadfence();
+        float t = 0.f, c = 0.f;
+        for (int i = lane; i < (int)gridDim.x; i += 64) {
+            t += __builtin_nontemporal_load(&acc[i]);
+            c += __builtin_nontemporal_load(&acc[RM_MAX_BLOCKS + i]);
+        }
+        t = wave_sum(t);
+        c = wave_sum(c);
+        if (lane == 0) {
+            atomicExch(reinterpret_cast<unsigned*>(&acc[2 * RM_MAX_BLOCKS]), 0u);
+            out[0] = weight * (t / c);  // 0/0 = NaN when every row is skipped, as torch.nanmean does
+            out[1] = c;
         }
     }
 }
@@ -210,9 +225,9 @@ extern "C" int snf_distortion(const float* sbins, const float* w, int R, int S, 
 extern "C" int snf_rowmse_loss_fwd(const float* pred, const float* target, int R, int C, float weight, int nan_skip,
                                    float* acc, float* out, snf_stream_t stream) {
     SNF_REQUIRE(pred && target && acc && out && R > 0 && C > 0, "snf_rowmse_loss_fwd: bad argument");
-    // few workgroups: every one of them ends with three same-address device atomics, which serialise (~10 ns each)
+    // one trip of four rows per wave where possible (the loss sits on the step's critical chain: latency matters, not bytes)
     int blocks = ceil_div(R, 16);
-    if (blocks > 64) blocks = 64;
+    if (blocks > RM_MAX_BLOCKS) blocks = RM_MAX_BLOCKS;
     hipLaunchKernelGGL(k_rowmse_fwd, dim3(blocks), dim3(256), 0, (hipStream_t)stream, pred, target, R, C, weight, nan_skip, acc,
                        out);
     SNF_LAUNCH_CHECK("snf_rowmse_loss_fwd");

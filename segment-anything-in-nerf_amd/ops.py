@@ -742,7 +742,7 @@ class _RowMSELoss(torch.autograd.Function):
         assert pred.shape == target.shape
         C = pred.shape[-1]
         R = pred.numel() // C
-        acc = torch.zeros((4,), device=pred.device, dtype=torch.float32)
+        acc = torch.zeros((516,), device=pred.device, dtype=torch.float32)  # SNF_ROWMSE_SCRATCH_WORDS
         out = torch.empty((2,), device=pred.device, dtype=torch.float32)
         _launch("snf_rowmse_loss_fwd", _p(pred), _p(target), R, C, float(weight), int(nan_skip), _p(acc), _p(out), _stream())
         ctx.args = (R, C, float(weight), int(nan_skip))
@@ -760,7 +760,11 @@ class _RowMSELoss(torch.autograd.Function):
 
 
 def mse_loss(pred, target, weight: float = 1.0) -> torch.Tensor:
-    """weight * nn.MSELoss()(pred, target) (mean over all elements; NaN propagates)."""
+    """weight * nn.MSELoss()(pred, target) (mean over all elements; NaN propagates).  A plain mean does not care about the
+    row shape: [R, 3] colours are viewed as 64-wide rows so that one wave covers 64 elements instead of 3."""
+    if pred.is_contiguous() and target.is_contiguous() and pred.shape[-1] < 64 and pred.numel() % 64 == 0:
+        out = _RowMSELoss.apply(pred.view(-1, 64), target.detach().view(-1, 64), weight, False)
+        return out
     return _RowMSELoss.apply(pred, target.detach(), weight, False)
 
 
