@@ -192,17 +192,26 @@ def hashgrid_run_levels(sc: torch.Tensor) -> int:
     return _RUN_LEVELS[key]
 
 
+HASHGRID_BWD_MAX_SAMPLES = 1 << 21  # per launch of the sorted backward (21 sample bits in a record)
+
+
 def _hashgrid_bwd_launch(u, g, sc, N, L, F, T, ld, col, buf) -> None:
     if HASHGRID_BWD_MODE == "atomic":
         _launch("snf_hashgrid_bwd", _p(u), _p(g), _p(sc), N, L, F, T, ld, col, _p(buf), _stream(), tag=f"F{F}L{L}")
-    else:
-        nbytes = int(_L().snf_hashgrid_bwd_workspace_bytes(N, L, T))
-        ws = torch.empty(((nbytes + 3) // 4,), device=g.device, dtype=torch.int32)
-        # run aggregation pays for the ray-ordered F = 2 grids (field grid -8 %); the top-K-ordered F = 8 feature grids have
-        # shorter runs and 4x the shuffle work per record (+20 % measured), so they keep the plain reduce
-        nrun = hashgrid_run_levels(sc) if F == 2 else 0
-        _launch("snf_hashgrid_bwd_sorted_ex", _p(u), _p(g), _p(sc), N, L, F, T, ld, col, nrun, _p(buf), _p(ws), nbytes,
-                _stream(), tag=f"F{F}L{L}")
+        return
+    # run aggregation pays for the ray-ordered F = 2 grids (field grid -8 %); the top-K-ordered F = 8 feature grids have
+    # shorter runs and 4x the shuffle work per record (+20 % measured), so they keep the plain reduce
+    nrun = hashgrid_run_levels(sc) if F == 2 else 0
+    # batches beyond 2^21 samples (or 2^32 records) go through in slices: the gradient table accumulates
+    per = min(HASHGRID_BWD_MAX_SAMPLES, ((1 << 32) - 1) // (8 * L))
+    ws = None
+    for n0 in range(0, N, per):
+        n = min(per, N - n0)
+        nbytes = int(_L().snf_hashgrid_bwd_workspace_bytes(n, L, T))
+        if ws is None:
+            ws = torch.empty(((nbytes + 3) // 4,), device=g.device, dtype=torch.int32)
+        _launch("snf_hashgrid_bwd_sorted_ex", ctypes.c_void_p(u.data_ptr() + n0 * 3 * 4), ctypes.c_void_p(g.data_ptr() + n0 * ld * 4),
+                _p(sc), n, L, F, T, ld, col, nrun, _p(buf), _p(ws), nbytes, _stream(), tag=f"F{F}L{L}")
 
 
 class _HashGridMulti(torch.autograd.Function):
