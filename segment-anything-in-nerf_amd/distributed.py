@@ -114,6 +114,34 @@ def exchange_rows(grad_rows: torch.Tensor, row_index: torch.Tensor) -> None:
     grad_rows.index_copy_(0, row_index, packed)
 
 
+def split_range(n: int, granule: int = 1) -> tuple:
+    """This rank's contiguous share [lo, hi) of n items, in whole granules (eval: rays of one image, patches kept whole)."""
+    if not _collectives_on():
+        return 0, n
+    world, rank = dist.get_world_size(), dist.get_rank()
+    units = (n + granule - 1) // granule
+    lo_u, hi_u = units * rank // world, units * (rank + 1) // world
+    return min(lo_u * granule, n), min(hi_u * granule, n)
+
+
+def all_gather_rows(local: torch.Tensor) -> torch.Tensor:
+    """Concatenate every rank's [n_r, ...] rows in rank order (n_r may differ): sizes are exchanged, rows padded to the
+    longest share for the collective and trimmed afterwards."""
+    if not _collectives_on():
+        return local
+    world = dist.get_world_size()
+    sizes = torch.zeros((world,), dtype=torch.int64, device=local.device)
+    mine = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
+    dist.all_gather_into_tensor(sizes, mine)
+    sizes = sizes.tolist()
+    m = max(max(sizes), 1)
+    padded = torch.zeros((m,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    padded[:local.shape[0]] = local
+    out = torch.empty((world * m,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, padded)
+    return torch.cat([out[r * m:r * m + sizes[r]] for r in range(world)], dim=0)
+
+
 def gather_sharded_state(buf: torch.Tensor) -> None:
     """Make a sharded optimizer-state buffer whole on every rank (before a checkpoint)."""
     if not _collectives_on():

@@ -474,14 +474,25 @@ class SAMModel(NerfactoModel):
         num_rays = len(camera_ray_bundle)
         outputs_lists: Dict[str, List[torch.Tensor]] = {}
 
-        def run(bundle, **kw):
+        from . import distributed as D
+
+        def run(bundle, granule=1, **kw):
+            """Render `bundle` in chunks.  In a data-parallel run the rays of the image are SHARDED over the ranks (contiguous
+            shares in whole `granule`s, so p x p patches stay on one rank) and the rows gathered (eval)."""
             n = len(bundle)
-            for i in range(0, n, num_rays_per_chunk):
-                rb = bundle.get_row_major_sliced_ray_bundle(i, i + num_rays_per_chunk)
+            # (every rank takes the same decision: with fewer granules than ranks each rank simply renders everything)
+            shard = D.collectives_on() and (n + granule - 1) // granule >= D.world_size()
+            lo, hi = D.split_range(n, granule) if shard else (0, n)
+            local: Dict[str, List[torch.Tensor]] = {}
+            for i in range(lo, hi, num_rays_per_chunk):
+                rb = bundle.get_row_major_sliced_ray_bundle(i, min(i + num_rays_per_chunk, hi))
                 rb.nears, rb.fars = None, None
                 for name, out in self.forward(ray_bundle=rb, **kw).items():
                     if torch.is_tensor(out):
-                        outputs_lists.setdefault(name, []).append(out)
+                        local.setdefault(name, []).append(out)
+            for name, lst in local.items():
+                rows = torch.cat(lst)
+                outputs_lists.setdefault(name, []).append(D.all_gather_rows(rows) if shard else rows)
 
         run(camera_ray_bundle, get_feature=[], fast=fast)
         sz = camera_ray_bundle.shape
@@ -497,7 +508,7 @@ class SAMModel(NerfactoModel):
             fb = camera_ray_bundle[hind.flatten(), wind.flatten()]
             fb = fb.reshape((feature_h, p, feature_w, p))._apply_fn_to_fields(lambda x: x.transpose(1, 2))
             saved = {k: outputs_lists.pop(k) for k in list(outputs_lists)}
-            run(fb, get_feature=["sam"])
+            run(fb, granule=p * p, get_feature=["sam"])
             sam_list = outputs_lists.get("sam", [])
             outputs_lists.clear()
             outputs_lists.update(saved)

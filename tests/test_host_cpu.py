@@ -220,6 +220,13 @@ def _sharded_worker(rank, world, port, q):
     expect = before.clone()
     expect[idx] = torch.arange(40 * 8, dtype=torch.float32).view(40, 8)[idx] * sum(range(1, world + 1))
     ok = ok and torch.equal(g2, expect)
+    # eval sharding helpers: contiguous shares in whole granules; ragged all-gather restores row order
+    for n, gran in ((1000, 1), (160, 16), (16, 16)):
+        lo, hi = D.split_range(n, gran)
+        ok = ok and lo % gran == 0 and (hi % gran == 0 or hi == n) and 0 <= lo <= hi <= n
+        rows = torch.arange(lo, hi, dtype=torch.float32)[:, None] * torch.ones((1, 3))
+        full = D.all_gather_rows(rows)
+        ok = ok and torch.equal(full, torch.arange(n, dtype=torch.float32)[:, None] * torch.ones((1, 3)))
     q.put((rank, bool(ok)))
     torch.distributed.destroy_process_group()
 

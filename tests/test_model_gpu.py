@@ -207,7 +207,19 @@ for step in range(6):
     losses.append(float(sum(v.detach() for v in ld.values())))
 trainer.optimizers.consolidate_state()
 gmax = max(float(a.grad.abs().max()) for a in trainer.optimizers.arenas.values())
-print("RESULT " + json.dumps({"losses": losses, "gmax": gmax, "dist": torch.distributed.is_initialized()}))
+# eval render of a small image: sharded over the ranks + gathered when a process group is up
+from samnerf_amd.rays import RayBundle
+g = torch.Generator().manual_seed(1)
+o = (torch.rand((12, 20, 3), generator=g) - 0.5).cuda()
+d = torch.nn.functional.normalize(torch.randn((12, 20, 3), generator=g), dim=-1).cuda()
+cam = RayBundle(origins=o, directions=d, pixel_area=torch.full((12, 20, 1), 1e-6, device="cuda"),
+                camera_indices=torch.zeros((12, 20, 1), dtype=torch.long, device="cuda"))
+model = trainer.pipeline.model
+model.eval()
+model.config.eval_num_rays_per_chunk = 64
+img = model.get_outputs_for_camera_ray_bundle(cam)
+render = [float(img["rgb"].sum()), float(img["sam"].sum()), float(img["clipseg"].sum())]
+print("RESULT " + json.dumps({"losses": losses, "gmax": gmax, "dist": torch.distributed.is_initialized(), "render": render}))
 if torch.distributed.is_initialized():
     torch.distributed.destroy_process_group()
 """
@@ -237,6 +249,7 @@ def test_sharded_exchange_runs_on_rccl_single_rank():
     assert forced["dist"] and not plain["dist"]
     assert forced["gmax"] == 0.0 and plain["gmax"] == 0.0
     assert np.allclose(forced["losses"], plain["losses"], rtol=2e-4, atol=1e-6), (forced["losses"], plain["losses"])
+    assert np.allclose(forced["render"], plain["render"], rtol=1e-3, atol=1e-4), (forced["render"], plain["render"])
     assert forced["losses"][-1] < forced["losses"][0]
 
 
