@@ -31,7 +31,11 @@ def _positions_of(x, distortion, use_selector: bool):
     """normalised positions [N,3] (+ selector) from a RaySamples or a tensor of world positions."""
     mode = contraction_mode(distortion)
     if isinstance(x, RaySamples):
-        u, sel = ops.positions(x.ray_bundle.origins, x.ray_bundle.directions, x.euclid_bins, x.ids, mode, use_selector)
+        cache = x.__dict__.setdefault("_positions_cache", {})  # the two feature heads ask for the same top-K positions
+        key = (mode, use_selector)
+        if key not in cache:
+            cache[key] = ops.positions(x.ray_bundle.origins, x.ray_bundle.directions, x.euclid_bins, x.ids, mode, use_selector)
+        u, sel = cache[key]
         return u, sel, x.shape
     flat = x.detach().reshape(-1, 3).contiguous()
     zeros = torch.zeros_like(flat)

@@ -399,6 +399,7 @@ class SAMModel(NerfactoModel):
             # losses / backward on the main stream.
             fs = self.feature_streams if (self.training and weights.is_cuda) else None
             heads = [h for h in ("sam", "clipseg") if h in get_feature and (h == "sam" or self.config.use_clipseg_feature)]
+            selected = self._select_feature_samples(ray_samples, weights) if heads else None
             for h in heads:
                 st = fs.get(h) if fs else None
                 if st is not None:
@@ -406,23 +407,32 @@ class SAMModel(NerfactoModel):
                     # tensors produced on the main stream and read on the head's stream: tell the caching allocator, so
                     # their memory is not recycled for main-stream work while the head task is still running (the
                     # trainer may already be enqueueing the next step's forward)
+                    shared = [selected[1], selected[0].ids, *selected[0].__dict__.get("_positions_cache", {}).get(
+                        (ops.CONTRACT_L2, False), ())]
                     for t in (weights, ray_samples.euclid_bins, ray_samples.spacing_bins, ray_samples.ray_bundle.origins,
-                              ray_samples.ray_bundle.directions):
+                              ray_samples.ray_bundle.directions, *shared):
                         if t is not None:
                             t.record_stream(st)
                     with torch.cuda.stream(st):
-                        self._feature_head(h, ray_samples, weights, outputs)
+                        self._feature_head(h, selected, outputs)
                 else:
-                    self._feature_head(h, ray_samples, weights, outputs)
+                    self._feature_head(h, selected, outputs)
         return outputs
 
-    def _feature_head(self, head: str, ray_samples: RaySamples, weights, outputs) -> None:
-        """One head of samnerf/sam_model.py:243-277 (top-K select, SAMField head, weighted mean, conv head for 'sam')."""
-        # top-K by weight, sharpen w^T, renormalise (sam_model.py:244-248) -- one kernel (recomputed per head: trivial)
+    def _select_feature_samples(self, ray_samples: RaySamples, weights):
+        """sam_model.py:244-255: top-K by weight, sharpen w^T, renormalise, gather the samples -- shared by the heads, as are
+        the contracted positions of the selected samples (computed here once, on the caller's stream)."""
         sam_weights, best_ids = ops.topk_sharpen(weights[..., 0].detach(), self.config.num_sam_samples,
                                                  self.config.sharpening_temperature)
         sam_samples = ray_samples.gather(best_ids)
-        sam_weights = sam_weights[..., None]
+        if weights.is_cuda:
+            from .fields import _positions_of
+            _positions_of(sam_samples, self.sam_field.spatial_distortion, False)  # fills sam_samples' position cache
+        return sam_samples, sam_weights[..., None]
+
+    def _feature_head(self, head: str, selected, outputs) -> None:
+        """One head of samnerf/sam_model.py:243-277 (SAMField head, weighted mean, conv head for 'sam')."""
+        sam_samples, sam_weights = selected
         field_out = self.sam_field.get_outputs(sam_samples, get_feautre=[head])
         feat_out = self.renderer_mean(embeds=field_out[head], weights=sam_weights.detach())
         if head == "sam" and self.config.patch_size > 1:
