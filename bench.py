@@ -43,7 +43,8 @@ def algorithmic_model(key: str, w: dict):
     (8 corners x F floats x 4 B per level per sample; backward = read-modify-write)."""
     R, P, S, K = w["R"], w["P"], w["S"], w["K"]
     name, _, tag = key.partition("/")
-    if name in ("snf_hashgrid_fwd", "snf_hashgrid_bwd", "snf_hashgrid_bwd_sorted", "snf_hashgrid_bwd_sorted_ex"):
+    if name in ("snf_hashgrid_fwd", "snf_hashgrid_bwd", "snf_hashgrid_bwd_sorted", "snf_hashgrid_bwd_sorted_ex",
+                "snf_hashgrid_bwd_presorted"):
         F, L = (int(x) for x in tag[1:].split("L"))
         rw = 1 if name.endswith("fwd") else 2
         # F=8: feature grids on the R*K top-K samples; F=2: proposal grid (L=5, R*P samples) or field grid (L=16, R*S)
@@ -184,7 +185,8 @@ def main():
     # "Dominant kernel" is meant at the GPU-kernel level (what rocprofv3 --stats ranks).  A C-ABI entry that is a pipeline of
     # several kernels counts with the share of its largest one: the bucketed hash-grid backward is stage/count/scan/scatter/
     # reduce, k_hg_reduce being ~60 % of it (profiles/*_kernel_stats.csv).
-    largest_kernel_share = {"snf_hashgrid_bwd_sorted": 0.6, "snf_hashgrid_bwd_sorted_ex": 0.6}
+    largest_kernel_share = {"snf_hashgrid_bwd_sorted": 0.6, "snf_hashgrid_bwd_sorted_ex": 0.6,
+                            "snf_hashgrid_bwd_presorted": 0.9}
     dom = args.roofline_kernel
     if dom is None and per_step:
         modelled = [k for k in per_step if model_of(k)[1]]

@@ -90,6 +90,16 @@ int snf_hashgrid_bwd_sorted_ex(const float* u, const float* grad_out, const floa
                                int log2_T, int ld_out, int col_off, int n_run_levels, float* grad_table, void* workspace,
                                int64_t workspace_bytes, snf_stream_t stream);
 
+/* The sorted backward in two halves.  snf_hashgrid_sort (count / scan / scatter) depends on the positions and the level
+ * geometry only, so grids of equal geometry at the same points share it and it can run in the forward pass;
+ * snf_hashgrid_bwd_presorted (stage + reduce) then needs the sorted workspace (read-only: may be shared by concurrent
+ * streams) and a stage buffer of L*N*F floats.  workspace size: snf_hashgrid_bwd_workspace_bytes(N, L, log2_T). */
+int snf_hashgrid_sort(const float* u, const float* scalings, int N, int L, int log2_T, void* workspace,
+                      int64_t workspace_bytes, snf_stream_t stream);
+int snf_hashgrid_bwd_presorted(const float* grad_out, int N, int L, int F, int log2_T, int ld_out, int col_off,
+                               int n_run_levels, float* grad_table, const void* sorted_workspace, float* stage,
+                               snf_stream_t stream);
+
 /* Arithmetic of the wide (>= 128 input) dense layers: 1 (default) = bf16 3-term split on the bf16 matrix cores with fp32
  * accumulate (max abs error ~1e-6 on head-shaped data, 1/5 of the matrix cycles), 0 = exact fp32 matrix cores.
  * Process-wide; narrow layers always run exact fp32. */

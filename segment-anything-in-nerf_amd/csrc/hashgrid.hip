@@ -711,52 +711,97 @@ extern "C" int snf_hashgrid_bwd_sorted(const float* u, const float* grad_out, co
                                       workspace_bytes, stream);
 }
 
+// The sorted backward in two halves.  The sort (count / scan / scatter) depends on the positions and the level geometry only --
+// not on the upstream gradient, the table or F -- so grids of equal geometry evaluated at the same points (the SAM and
+// ClipSeg feature grids) share one sort, and it can run as soon as the positions exist (in the forward pass).
+static int hg_sort_checks(const char* who, int N, int L, int log2_T, const void* workspace, int64_t workspace_bytes) {
+    SNF_REQUIRE(N > 0 && L > 0 && log2_T >= 1 && log2_T <= 26, "%s: bad N=%d L=%d log2_T=%d", who, N, L, log2_T);
+    SNF_REQUIRE((long long)L * 8 * N < (1LL << 32) && N <= (1 << HG_SAMPLE_BITS),
+                "%s: at most 2^21 samples per call (N=%d L=%d); split the batch", who, N, L);
+    SNF_REQUIRE(workspace && workspace_bytes >= (int64_t)(hg_ws_words(N, L, log2_T) * sizeof(uint32_t)),
+                "%s: workspace too small (need %lld bytes)", who, (long long)(hg_ws_words(N, L, log2_T) * sizeof(uint32_t)));
+    SNF_REQUIRE(((uintptr_t)workspace % 16) == 0, "%s: unaligned workspace", who);
+    return SNF_OK;
+}
+
+struct HgWs {
+    uint32_t *records, *hist, *offs, *bstart;
+    float* gT;
+};
+
+static HgWs hg_ws_layout(void* workspace, int N, int L, const HgGeom& g) {
+    const size_t B = (size_t)1 << g.log2B;
+    HgWs w;
+    w.records = (uint32_t*)workspace;
+    w.hist = w.records + (size_t)L * 8 * (size_t)N * 2;
+    w.offs = w.hist + (size_t)L * g.nblk * B;
+    w.bstart = w.offs + (size_t)L * g.nblk * B;
+    w.gT = (float*)(w.bstart + (((size_t)L * (B + 1) + 3) & ~(size_t)3));
+    return w;
+}
+
+extern "C" int snf_hashgrid_sort(const float* u, const float* scalings, int N, int L, int log2_T, void* workspace,
+                                 int64_t workspace_bytes, snf_stream_t stream) {
+    SNF_REQUIRE(u && scalings, "snf_hashgrid_sort: null pointer");
+    int rc = hg_sort_checks("snf_hashgrid_sort", N, L, log2_T, workspace, workspace_bytes);
+    if (rc) return rc;
+    const HgGeom g = hg_geometry(N, log2_T);
+    SNF_REQUIRE((1 << g.log2rpb) <= HG_MAX_RPB, "snf_hashgrid_sort: log2_T=%d too large for the bucketed backward", log2_T);
+    const HgWs w = hg_ws_layout(workspace, N, L, g);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_hg_count, dim3(g.nblk, L), dim3(256), 0, st, u, scalings, N, log2_T, g.log2B, g.spt, w.hist);
+    hipLaunchKernelGGL(k_hg_scan, dim3(L), dim3(1024), 0, st, N, g.log2B, g.nblk, w.hist, w.offs, w.bstart);
+    if (hg_scatter_lds_bytes(g.log2B) > 48 * 1024)
+        hipFuncSetAttribute((const void*)k_hg_scatter, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)hg_scatter_lds_bytes(g.log2B));
+    hipLaunchKernelGGL(k_hg_scatter, dim3(g.nblk, L), dim3(256), hg_scatter_lds_bytes(g.log2B), st, u, scalings, N, log2_T,
+                       g.log2B, g.spt, w.offs, (uint2*)w.records);
+    SNF_LAUNCH_CHECK("snf_hashgrid_sort");
+    return SNF_OK;
+}
+
+extern "C" int snf_hashgrid_bwd_presorted(const float* grad_out, int N, int L, int F, int log2_T, int ld_out, int col_off,
+                                          int n_run_levels, float* grad_table, const void* sorted_workspace, float* stage,
+                                          snf_stream_t stream) {
+    SNF_REQUIRE(grad_out && grad_table && sorted_workspace && stage, "snf_hashgrid_bwd_presorted: null pointer");
+    SNF_REQUIRE(F == 2 || F == 8, "snf_hashgrid_bwd_presorted: features_per_level must be 2 or 8 (got %d)", F);
+    SNF_REQUIRE(N > 0 && L > 0 && N <= (1 << HG_SAMPLE_BITS) && ld_out >= col_off + L * F && col_off >= 0,
+                "snf_hashgrid_bwd_presorted: bad shape N=%d L=%d ld_out=%d col_off=%d", N, L, ld_out, col_off);
+    SNF_REQUIRE(((uintptr_t)grad_out % 16) == 0 && ((uintptr_t)grad_table % 16) == 0 && ((uintptr_t)stage % 16) == 0,
+                "snf_hashgrid_bwd_presorted: unaligned pointer");
+    const HgGeom g = hg_geometry(N, log2_T);
+    const HgWs w = hg_ws_layout(const_cast<void*>(sorted_workspace), N, L, g);
+    const int B = 1 << g.log2B;
+    hipStream_t st = (hipStream_t)stream;
+    const char* e_long = getenv("SNF_HG_LONG");
+    const uint32_t hg_long = e_long ? (uint32_t)atoi(e_long) : (uint32_t)HG_LONG;
+    const int tblocks = ceil_div((long long)N * L, 256);
+    if (F == 2) {
+        hipLaunchKernelGGL(k_hg_stage_grad<2>, dim3(tblocks), dim3(256), 0, st, grad_out, N, L, ld_out, col_off, stage);
+        hipLaunchKernelGGL(k_hg_reduce<2>, dim3(B, L), dim3(HG_RT), 0, st, stage, N, log2_T, g.log2B, w.bstart,
+                           (const uint2*)w.records, grad_table, hg_long, n_run_levels);
+    } else {
+        hipLaunchKernelGGL(k_hg_stage_grad<8>, dim3(tblocks), dim3(256), 0, st, grad_out, N, L, ld_out, col_off, stage);
+        hipLaunchKernelGGL(k_hg_reduce<8>, dim3(B, L), dim3(HG_RT), 0, st, stage, N, log2_T, g.log2B, w.bstart,
+                           (const uint2*)w.records, grad_table, hg_long, n_run_levels);
+    }
+    SNF_LAUNCH_CHECK("snf_hashgrid_bwd_presorted");
+    return SNF_OK;
+}
+
 extern "C" int snf_hashgrid_bwd_sorted_ex(const float* u, const float* grad_out, const float* scalings, int N, int L, int F,
                                           int log2_T, int ld_out, int col_off, int n_run_levels, float* grad_table,
                                           void* workspace, int64_t workspace_bytes, snf_stream_t stream) {
     int rc = check_common("snf_hashgrid_bwd_sorted", u, grad_out, scalings, grad_table, N, L, F, log2_T, ld_out, col_off);
     if (rc) return rc;
-    SNF_REQUIRE(((uintptr_t)grad_out % 16) == 0 && ((uintptr_t)grad_table % 16) == 0,
-                "snf_hashgrid_bwd_sorted: unaligned pointer");
-    SNF_REQUIRE((long long)L * 8 * N < (1LL << 32) && N <= (1 << HG_SAMPLE_BITS),
-                "snf_hashgrid_bwd_sorted: at most 2^21 samples per call (N=%d L=%d); split the batch", N, L);
     const HgGeom g = hg_geometry(N, log2_T);
     if ((1 << g.log2rpb) > HG_MAX_RPB) {
         // more than 2048 rows per bucket even at 4096 buckets (log2_T > 23): fall back to the atomic kernel
         return snf_hashgrid_bwd(u, grad_out, scalings, N, L, F, log2_T, ld_out, col_off, grad_table, stream);
     }
-    SNF_REQUIRE(workspace && workspace_bytes >= (int64_t)(hg_ws_words(N, L, log2_T) * sizeof(uint32_t)),
-                "snf_hashgrid_bwd_sorted: workspace too small (need %lld bytes)",
-                (long long)(hg_ws_words(N, L, log2_T) * sizeof(uint32_t)));
-    SNF_REQUIRE(((uintptr_t)workspace % 16) == 0, "snf_hashgrid_bwd_sorted: unaligned workspace");
-    const int B = 1 << g.log2B;
-    const int nblk = g.nblk;
-    uint32_t* records = (uint32_t*)workspace;
-    uint32_t* hist = records + (size_t)L * 8 * (size_t)N * 2;
-    uint32_t* offs = hist + (size_t)L * nblk * B;
-    uint32_t* bstart = offs + (size_t)L * nblk * B;
-    float* gT = (float*)(bstart + (((size_t)L * (B + 1) + 3) & ~(size_t)3));
-    hipStream_t st = (hipStream_t)stream;
-    const char* e_long = getenv("SNF_HG_LONG");
-    const uint32_t hg_long = e_long ? (uint32_t)atoi(e_long) : (uint32_t)HG_LONG;
-    const int tblocks = ceil_div((long long)N * L, 256);
-    if (F == 2)
-        hipLaunchKernelGGL(k_hg_stage_grad<2>, dim3(tblocks), dim3(256), 0, st, grad_out, N, L, ld_out, col_off, gT);
-    else
-        hipLaunchKernelGGL(k_hg_stage_grad<8>, dim3(tblocks), dim3(256), 0, st, grad_out, N, L, ld_out, col_off, gT);
-    hipLaunchKernelGGL(k_hg_count, dim3(nblk, L), dim3(256), 0, st, u, scalings, N, log2_T, g.log2B, g.spt, hist);
-    hipLaunchKernelGGL(k_hg_scan, dim3(L), dim3(1024), 0, st, N, g.log2B, nblk, hist, offs, bstart);
-    if (hg_scatter_lds_bytes(g.log2B) > 48 * 1024)
-        hipFuncSetAttribute((const void*)k_hg_scatter, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)hg_scatter_lds_bytes(g.log2B));
-    hipLaunchKernelGGL(k_hg_scatter, dim3(nblk, L), dim3(256), hg_scatter_lds_bytes(g.log2B), st, u, scalings, N, log2_T, g.log2B, g.spt, offs,
-                       (uint2*)records);
-    if (F == 2)
-        hipLaunchKernelGGL(k_hg_reduce<2>, dim3(B, L), dim3(HG_RT), 0, st, gT, N, log2_T, g.log2B, bstart,
-                           (const uint2*)records, grad_table, hg_long, n_run_levels);
-    else
-        hipLaunchKernelGGL(k_hg_reduce<8>, dim3(B, L), dim3(HG_RT), 0, st, gT, N, log2_T, g.log2B, bstart,
-                           (const uint2*)records, grad_table, hg_long, n_run_levels);
-    SNF_LAUNCH_CHECK("snf_hashgrid_bwd_sorted");
-    return SNF_OK;
+    rc = snf_hashgrid_sort(u, scalings, N, L, log2_T, workspace, workspace_bytes, stream);
+    if (rc) return rc;
+    const HgWs w = hg_ws_layout(workspace, N, L, g);  // the staged gradients use the tail of the same workspace
+    return snf_hashgrid_bwd_presorted(grad_out, N, L, F, log2_T, ld_out, col_off, n_run_levels, grad_table, workspace, w.gT,
+                                      stream);
 }

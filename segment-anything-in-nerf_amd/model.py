@@ -407,8 +407,10 @@ class SAMModel(NerfactoModel):
                     # tensors produced on the main stream and read on the head's stream: tell the caching allocator, so
                     # their memory is not recycled for main-stream work while the head task is still running (the
                     # trainer may already be enqueueing the next step's forward)
-                    shared = [selected[1], selected[0].ids, *selected[0].__dict__.get("_positions_cache", {}).get(
-                        (ops.CONTRACT_L2, False), ())]
+                    pos = selected[0].__dict__.get("_positions_cache", {}).get((ops.CONTRACT_L2, False), ())
+                    shared = [selected[1], selected[0].ids, *pos]
+                    if pos:
+                        shared += list(pos[0].__dict__.get("_snf_sorted", {}).values())
                     for t in (weights, ray_samples.euclid_bins, ray_samples.spacing_bins, ray_samples.ray_bundle.origins,
                               ray_samples.ray_bundle.directions, *shared):
                         if t is not None:
@@ -427,7 +429,15 @@ class SAMModel(NerfactoModel):
         sam_samples = ray_samples.gather(best_ids)
         if weights.is_cuda:
             from .fields import _positions_of
-            _positions_of(sam_samples, self.sam_field.spatial_distortion, False)  # fills sam_samples' position cache
+            u, _, _ = _positions_of(sam_samples, self.sam_field.spatial_distortion, False)  # fills the position cache
+            if self.training and torch.is_grad_enabled():
+                # the backward sorts of the feature grids depend on these positions and the level geometry only: done
+                # here, once per geometry (the SAM and ClipSeg grids have the same two), while the GPU is still lightly
+                # loaded, instead of four times inside the backward of the heads
+                encs = list(self.sam_field.clip_encs) + (list(self.sam_field.clipseg_encs)
+                                                          if self.config.use_clipseg_feature else [])
+                for enc in encs:
+                    ops.hashgrid_presort(u, enc.scalings, enc.n_levels, enc.log2_hashmap_size)
         return sam_samples, sam_weights[..., None]
 
     def _feature_head(self, head: str, selected, outputs) -> None:

@@ -192,6 +192,35 @@ def hashgrid_run_levels(sc: torch.Tensor) -> int:
     return _RUN_LEVELS[key]
 
 
+_SC_VALUES: dict = {}
+
+
+def _geometry_key(sc: torch.Tensor, L: int, T: int):
+    """(levels, log2_T, resolutions) -- what a backward sort depends on besides the positions.  One host read per tensor."""
+    k = (sc.data_ptr(), int(sc.numel()))
+    if k not in _SC_VALUES:
+        _SC_VALUES[k] = tuple(sc.detach().cpu().tolist())
+    return (L, T, _SC_VALUES[k])
+
+
+@torch.no_grad()
+def hashgrid_presort(u: torch.Tensor, sc: torch.Tensor, L: int, T: int) -> None:
+    """Sort the (sample, level, corner) records of positions `u` for one level geometry NOW (forward pass) and attach the
+    result to `u`: every hash-grid backward at these positions with this geometry then skips its own sort."""
+    u = _chk(u, "u")
+    N = u.shape[0]
+    if HASHGRID_BWD_MODE != "sorted" or N > HASHGRID_BWD_MAX_SAMPLES or 8 * L * N >= (1 << 32) or T > 23:
+        return
+    cache = u.__dict__.setdefault("_snf_sorted", {})
+    key = _geometry_key(sc, L, T)
+    if key in cache:
+        return
+    nbytes = int(_L().snf_hashgrid_bwd_workspace_bytes(N, L, T))
+    ws = torch.empty(((nbytes + 3) // 4,), device=u.device, dtype=torch.int32)
+    _launch("snf_hashgrid_sort", _p(u), _p(sc), N, L, T, _p(ws), nbytes, _stream(), tag=f"L{L}")
+    cache[key] = ws
+
+
 HASHGRID_BWD_MAX_SAMPLES = 1 << 21  # per launch of the sorted backward (21 sample bits in a record)
 
 
@@ -202,6 +231,14 @@ def _hashgrid_bwd_launch(u, g, sc, N, L, F, T, ld, col, buf) -> None:
     # run aggregation pays for the ray-ordered F = 2 grids (field grid -8 %); the top-K-ordered F = 8 feature grids have
     # shorter runs and 4x the shuffle work per record (+20 % measured), so they keep the plain reduce
     nrun = hashgrid_run_levels(sc) if F == 2 else 0
+    presorted = getattr(u, "_snf_sorted", None)
+    if presorted:
+        ws = presorted.get(_geometry_key(sc, L, T))
+        if ws is not None:
+            stage = torch.empty((L * N * F,), device=g.device, dtype=torch.float32)
+            _launch("snf_hashgrid_bwd_presorted", _p(g), N, L, F, T, ld, col, nrun, _p(buf), _p(ws), _p(stage), _stream(),
+                    tag=f"F{F}L{L}")
+            return
     # batches beyond 2^21 samples (or 2^32 records) go through in slices: the gradient table accumulates
     per = min(HASHGRID_BWD_MAX_SAMPLES, ((1 << 32) - 1) // (8 * L))
     ws = None
