@@ -163,6 +163,7 @@ def main():
     n_break = 3
     torch.cuda.synchronize()
     trainer.overlap = False
+    ops.PRESORT_SIDE_STREAM = False  # keep the replay on one stream
     ops.enable_kernel_timing("all")
     for i in range(n_break):
         trainer.train_iteration(step)
@@ -170,6 +171,7 @@ def main():
     breakdown = ops.kernel_timing_summary()
     ops.enable_kernel_timing(None)
     trainer.overlap = True
+    ops.PRESORT_SIDE_STREAM = True
     trainer.train_iteration(step)  # back on the concurrent schedule before timing starts
     step += 1
     per_step = {k: v["total_ms"] / n_break for k, v in breakdown.items()}

@@ -410,7 +410,7 @@ class SAMModel(NerfactoModel):
                     pos = selected[0].__dict__.get("_positions_cache", {}).get((ops.CONTRACT_L2, False), ())
                     shared = [selected[1], selected[0].ids, *pos]
                     if pos:
-                        shared += list(pos[0].__dict__.get("_snf_sorted", {}).values())
+                        shared += [w for w, _ in pos[0].__dict__.get("_snf_sorted", {}).values()]
                     for t in (weights, ray_samples.euclid_bins, ray_samples.spacing_bins, ray_samples.ray_bundle.origins,
                               ray_samples.ray_bundle.directions, *shared):
                         if t is not None:

@@ -21,6 +21,8 @@ CONTRACT_NONE, CONTRACT_LINF, CONTRACT_L2 = 0, 1, 2
 import os as _os
 
 HASHGRID_BWD_MODE = "sorted"  # "sorted": bucketed, atomic-free (default) | "atomic": global fp32 atomics
+PRESORT_FIELD_GRID = _os.environ.get("SNF_PRESORT_FIELD", "1") == "1"
+PRESORT_SIDE_STREAM = True  # False: forward-time sorts stay on the caller's stream (bench.py's serial replay)
 HASHGRID_RUN_MAX_RES = float(_os.environ.get("SNF_HG_RUN_MAX_RES", "64"))  # levels up to this resolution aggregate runs
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_GELU = 0, 1, 2, 3
 ACT_BY_NAME = {None: ACT_NONE, "None": ACT_NONE, "none": ACT_NONE, "ReLU": ACT_RELU, "relu": ACT_RELU,
@@ -203,10 +205,14 @@ def _geometry_key(sc: torch.Tensor, L: int, T: int):
     return (L, T, _SC_VALUES[k])
 
 
+_PRESORT_STREAM = {}
+
+
 @torch.no_grad()
-def hashgrid_presort(u: torch.Tensor, sc: torch.Tensor, L: int, T: int) -> None:
+def hashgrid_presort(u: torch.Tensor, sc: torch.Tensor, L: int, T: int, side_stream: bool = False) -> None:
     """Sort the (sample, level, corner) records of positions `u` for one level geometry NOW (forward pass) and attach the
-    result to `u`: every hash-grid backward at these positions with this geometry then skips its own sort."""
+    result to `u`: every hash-grid backward at these positions with this geometry then skips its own sort.
+    side_stream: run the sort on a dedicated HIP stream beside the caller's forward kernels (the backward waits on its event)."""
     u = _chk(u, "u")
     N = u.shape[0]
     if HASHGRID_BWD_MODE != "sorted" or N > HASHGRID_BWD_MAX_SAMPLES or 8 * L * N >= (1 << 32) or T > 23:
@@ -216,9 +222,23 @@ def hashgrid_presort(u: torch.Tensor, sc: torch.Tensor, L: int, T: int) -> None:
     if key in cache:
         return
     nbytes = int(_L().snf_hashgrid_bwd_workspace_bytes(N, L, T))
-    ws = torch.empty(((nbytes + 3) // 4,), device=u.device, dtype=torch.int32)
-    _launch("snf_hashgrid_sort", _p(u), _p(sc), N, L, T, _p(ws), nbytes, _stream(), tag=f"L{L}")
-    cache[key] = ws
+    if not (side_stream and PRESORT_SIDE_STREAM):
+        ws = torch.empty(((nbytes + 3) // 4,), device=u.device, dtype=torch.int32)
+        _launch("snf_hashgrid_sort", _p(u), _p(sc), N, L, T, _p(ws), nbytes, _stream(), tag=f"L{L}")
+        cache[key] = (ws, None)
+        return
+    cur = torch.cuda.current_stream()
+    st = _PRESORT_STREAM.setdefault(u.device.index, None) or torch.cuda.Stream()
+    _PRESORT_STREAM[u.device.index] = st
+    st.wait_stream(cur)  # the positions are ready
+    with torch.cuda.stream(st):
+        ws = torch.empty(((nbytes + 3) // 4,), device=u.device, dtype=torch.int32)
+        _launch("snf_hashgrid_sort", _p(u), _p(sc), N, L, T, _p(ws), nbytes, _stream(), tag=f"L{L}")
+        ev = torch.cuda.Event()
+        ev.record(st)
+    u.record_stream(st)
+    sc.record_stream(st)
+    cache[key] = (ws, ev)
 
 
 HASHGRID_BWD_MAX_SAMPLES = 1 << 21  # per launch of the sorted backward (21 sample bits in a record)
@@ -233,8 +253,12 @@ def _hashgrid_bwd_launch(u, g, sc, N, L, F, T, ld, col, buf) -> None:
     nrun = hashgrid_run_levels(sc) if F == 2 else 0
     presorted = getattr(u, "_snf_sorted", None)
     if presorted:
-        ws = presorted.get(_geometry_key(sc, L, T))
-        if ws is not None:
+        hit = presorted.get(_geometry_key(sc, L, T))
+        if hit is not None:
+            ws, ev = hit
+            if ev is not None:  # sorted on the side stream: order this stream after it, keep the buffer alive for it
+                torch.cuda.current_stream().wait_event(ev)
+                ws.record_stream(torch.cuda.current_stream())
             stage = torch.empty((L * N * F,), device=g.device, dtype=torch.float32)
             _launch("snf_hashgrid_bwd_presorted", _p(g), N, L, F, T, ld, col, nrun, _p(buf), _p(ws), _p(stage), _stream(),
                     tag=f"F{F}L{L}")
@@ -262,6 +286,11 @@ class _HashGridMulti(torch.autograd.Function):
         total = sum(L * F for (_, L, F, _) in specs)
         out = torch.empty((N, total), device=u.device, dtype=torch.float32)
         col = 0
+        if PRESORT_FIELD_GRID and N >= (1 << 16):
+            # backward sorts that are not attached to `u` yet (the proposal grid) start now, on the side stream
+            for (sc, L, F, T), need in zip(specs, ctx.needs_input_grad[2:]):
+                if need:
+                    hashgrid_presort(u, sc, L, T, side_stream=True)
         for (sc, L, F, T), tab in zip(specs, tables):
             tab = _chk(tab, "table")
             assert tab.numel() == (L << T) * F, "table size does not match (levels, log2_T, features)"
@@ -567,6 +596,10 @@ class _NerfactoField(torch.autograd.Function):
         dev = u.device
         need = any(ctx.needs_input_grad)  # (grad mode is off inside forward; autograd tells us what it will ask for)
         enc = torch.empty((N, L * F), device=dev, dtype=torch.float32)
+        if need and table.requires_grad and PRESORT_FIELD_GRID:
+            # the field grid's backward sort needs only the positions: it runs NOW on a side stream, beside the forward
+            # kernels (the forward phase leaves most of the GPU idle), instead of on the backward's critical chain
+            hashgrid_presort(u, sc, L, T, side_stream=True)
         _launch("snf_hashgrid_fwd", _p(u), _p(table), _p(sc), N, L, F, T, _p(enc), L * F, 0, _stream(), tag=f"F{F}L{L}")
         h, hb1, _ = _mlp64_fwd_launch(enc, L * F, (bw0, bw1), ACT_NONE, need)
         C = h.shape[1]
