@@ -164,6 +164,7 @@ def main():
     torch.cuda.synchronize()
     trainer.overlap = False
     ops.PRESORT_SIDE_STREAM = False  # keep the replay on one stream
+    wgrad_side, ops.WGRAD_SIDE_STREAM = ops.WGRAD_SIDE_STREAM, False
     ops.enable_kernel_timing("all")
     for i in range(n_break):
         trainer.train_iteration(step)
@@ -172,6 +173,7 @@ def main():
     ops.enable_kernel_timing(None)
     trainer.overlap = True
     ops.PRESORT_SIDE_STREAM = True
+    ops.WGRAD_SIDE_STREAM = wgrad_side
     trainer.train_iteration(step)  # back on the concurrent schedule before timing starts
     step += 1
     per_step = {k: v["total_ms"] / n_break for k, v in breakdown.items()}

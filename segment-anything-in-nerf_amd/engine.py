@@ -104,6 +104,7 @@ class Optimizers:
         world == 1: plain fused Adam.  world > 1: reduce-scatter, Adam on this rank's shard, all-gather of the parameters
         (or all-reduce + replicated Adam when `self.sharded` is off)."""
         from . import distributed as D
+        ops.join_wgrad_stream()  # weight gradients of this task may still be running on the companion stream
         if not self.enabled:  # measurement of the forward+backward alone (bench.py): gradients keep accumulating
             return
         a, oc = self.arenas[k], self.config[k]["optimizer"]

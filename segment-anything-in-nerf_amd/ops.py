@@ -104,6 +104,75 @@ def set_gemm_mode(mode: str) -> None:
     _lib.check(_L().snf_set_gemm_mode({"fp32": 0, "bf16x3": 1}[mode]), "snf_set_gemm_mode")
 
 
+# ---------------------------------------------------------------------------------------------
+# weight gradients on a companion stream
+# ---------------------------------------------------------------------------------------------
+# A layer's weight gradient feeds nothing but the optimizer, while its data gradient is on the backward's dependency chain.
+# With WGRAD_SIDE_STREAM on, every snf_linear_bwd_weight launch of a task goes to a companion HIP stream of the task's
+# stream and runs beside the following data-gradient kernels; the optimizer joins the companion before it steps
+# (join_wgrad_stream, called by engine.Optimizers.exchange_and_step).
+WGRAD_SIDE_STREAM = _os.environ.get("SNF_WGRAD_SIDE", "1") == "1"
+_WGRAD_STREAMS: dict = {}
+
+
+_WGRAD_PENDING: list = []  # (task stream, companion) pairs of the running backward pass
+
+
+def _join_pending_wgrads() -> None:
+    """Final callback of the backward pass: every task stream waits for its companion, so that -- as autograd promises --
+    all gradients are ready on the stream that called backward() when it returns."""
+    while _WGRAD_PENDING:
+        cur, side = _WGRAD_PENDING.pop()
+        cur.wait_stream(side)
+
+
+class _wgrad_stream:
+    """Context (used inside autograd backward functions): the current stream becomes the companion of the caller's stream,
+    ordered after the work issued so far; the listed tensors are kept alive for the companion."""
+
+    def __init__(self, *tensors):
+        self.tensors = tensors
+        self.ctx = None
+
+    def __enter__(self):
+        if not (WGRAD_SIDE_STREAM and torch.cuda.is_available()):
+            return self
+        cur = torch.cuda.current_stream()
+        if not any(c.stream_id == cur.stream_id for c, _ in _WGRAD_PENDING):
+            if not _WGRAD_PENDING:
+                try:
+                    torch.autograd.Variable._execution_engine.queue_callback(_join_pending_wgrads)
+                except RuntimeError:  # not inside a backward pass: stay on the caller's stream
+                    return self
+            side = _WGRAD_STREAMS.get(cur.stream_id)
+            if side is None:
+                side = _WGRAD_STREAMS[cur.stream_id] = torch.cuda.Stream()
+            _WGRAD_PENDING.append((cur, side))
+        side = _WGRAD_STREAMS[cur.stream_id]
+        side.wait_stream(cur)
+        for t in self.tensors:
+            if t is not None and t.is_cuda:
+                t.record_stream(side)
+        self.ctx = torch.cuda.stream(side)
+        self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+        return False
+
+
+def join_wgrad_stream() -> None:
+    """Order the current stream after the weight-gradient launches its companion stream has received (normally done by
+    the backward pass's final callback; harmless to repeat)."""
+    if torch.cuda.is_available():
+        cur = torch.cuda.current_stream()
+        side = _WGRAD_STREAMS.get(cur.stream_id)
+        if side is not None:
+            cur.wait_stream(side)
+
+
 def _grad_target(param: torch.Tensor) -> Tuple[torch.Tensor, bool]:
     """(buffer to accumulate into, whether autograd should get None)."""
     mg = getattr(param, "main_grad", None)
@@ -354,8 +423,9 @@ class _Linear(torch.autograd.Function):
         if w.requires_grad or (b is not None and b.requires_grad):
             wbuf, wfused = _grad_target(w)
             bbuf, bfused = (None, True) if b is None else _grad_target(b)
-            _launch("snf_linear_bwd_weight", _p(gy), _p(y), _p(x), N, I, O, O, O, I, act, _p(wbuf), _p(bbuf), _stream(),
-                    tag=f"{I}x{O}")
+            with _wgrad_stream(gy, y, x, wbuf, bbuf):
+                _launch("snf_linear_bwd_weight", _p(gy), _p(y), _p(x), N, I, O, O, O, I, act, _p(wbuf), _p(bbuf), _stream(),
+                        tag=f"{I}x{O}")
             gw = None if wfused else wbuf
             gb = None if bfused else bbuf
         return gx, gw, gb, None
@@ -466,8 +536,9 @@ class _ConvHead(torch.autograd.Function):
         # second convolution (+ mean): dW1, db1, d(cm)
         w1buf, w1f = _grad_target(w1)
         b1buf, b1f = (None, True) if b1 is None else _grad_target(b1)
-        _launch("snf_linear_bwd_weight", _p(gy), None, _p(cm), npatch, O0 * kk, O1, O1, O1, O0 * kk, ACT_NONE, _p(w1buf),
-                _p(b1buf), st, tag=f"{O0 * kk}x{O1}pm")
+        with _wgrad_stream(gy, cm, w1buf, b1buf):
+            _launch("snf_linear_bwd_weight", _p(gy), None, _p(cm), npatch, O0 * kk, O1, O1, O1, O0 * kk, ACT_NONE, _p(w1buf),
+                    _p(b1buf), _stream(), tag=f"{O0 * kk}x{O1}pm")
         dcm = torch.empty((npatch, O0 * kk), device=dev, dtype=torch.float32)
         _launch("snf_linear_bwd_data", _p(gy), None, _p(w1), npatch, O0 * kk, O1, O1, O1, O0 * kk, ACT_NONE, _p(dcm), st,
                 tag=f"{O0 * kk}x{O1}pm")
@@ -476,8 +547,9 @@ class _ConvHead(torch.autograd.Function):
         # first convolution (ReLU derivative taken from h inside the GEMM loaders): dW0, db0, d(col) -> dx
         w0buf, w0f = _grad_target(w0)
         b0buf, b0f = (None, True) if b0 is None else _grad_target(b0)
-        _launch("snf_linear_bwd_weight", _p(dh), _p(h), _p(col), R, C * kk, O0, O0, O0, C * kk, ACT_RELU, _p(w0buf), _p(b0buf),
-                st, tag=f"{C * kk}x{O0}")
+        with _wgrad_stream(dh, h, col, w0buf, b0buf):
+            _launch("snf_linear_bwd_weight", _p(dh), _p(h), _p(col), R, C * kk, O0, O0, O0, C * kk, ACT_RELU, _p(w0buf),
+                    _p(b0buf), _stream(), tag=f"{C * kk}x{O0}")
         if ctx.needs_input_grad[0]:
             dcol = torch.empty((R, C * kk), device=dev, dtype=torch.float32)
             _launch("snf_linear_bwd_data", _p(dh), _p(h), _p(w0), R, C * kk, O0, O0, O0, C * kk, ACT_RELU, _p(dcol), st,
@@ -546,8 +618,9 @@ def _mlp64_bwd_launch(x, in_real, ws, out_act, y, h1, h2, dy, lddy, dy_col_off, 
             continue
         O = w.shape[0]
         buf, fused = _grad_target(w)
-        _launch("snf_linear_bwd_weight", _p(g), _p(None), _p(a), N, I, O, ldg, 0, lda, ACT_NONE, _p(buf), _p(None),
-                _stream(), tag=f"{I}x{O}")
+        with _wgrad_stream(g, a, buf):
+            _launch("snf_linear_bwd_weight", _p(g), _p(None), _p(a), N, I, O, ldg, 0, lda, ACT_NONE, _p(buf), _p(None),
+                    _stream(), tag=f"{I}x{O}")
         grads.append(None if fused else buf)
     return dx, grads
 
