@@ -116,14 +116,43 @@ _WGRAD_STREAMS: dict = {}
 
 
 _WGRAD_PENDING: list = []  # (task stream, companion) pairs of the running backward pass
+_GRAD_STREAMS: list = []   # streams on which gradient-writing nodes of the running backward pass were executed
 
 
 def _join_pending_wgrads() -> None:
-    """Final callback of the backward pass: every task stream waits for its companion, so that -- as autograd promises --
-    all gradients are ready on the stream that called backward() when it returns."""
+    """Final callback of the backward pass (runs on the thread, hence the stream, that called backward()): every task stream
+    waits for its companion, and the caller's stream waits for every stream a gradient-writing node ran on -- what autograd
+    does for AccumulateGrad leaves and cannot know for gradients written in place into the arenas.  So, as autograd
+    promises, all gradients are ready on the stream that called backward() when it returns."""
     while _WGRAD_PENDING:
         cur, side = _WGRAD_PENDING.pop()
         cur.wait_stream(side)
+    caller = torch.cuda.current_stream()
+    while _GRAD_STREAMS:
+        st = _GRAD_STREAMS.pop()
+        if st.stream_id != caller.stream_id:
+            caller.wait_stream(st)
+
+
+def _queue_final_callback() -> bool:
+    if _WGRAD_PENDING or _GRAD_STREAMS:
+        return True  # already queued for this pass
+    try:
+        torch.autograd.Variable._execution_engine.queue_callback(_join_pending_wgrads)
+        return True
+    except RuntimeError:  # not inside a backward pass
+        return False
+
+
+def _note_grad_stream() -> None:
+    """Called by every backward node that writes parameter gradients in place."""
+    if not torch.cuda.is_available():
+        return
+    cur = torch.cuda.current_stream()
+    if any(s.stream_id == cur.stream_id for s in _GRAD_STREAMS):
+        return
+    if _queue_final_callback():
+        _GRAD_STREAMS.append(cur)
 
 
 class _wgrad_stream:
@@ -139,11 +168,8 @@ class _wgrad_stream:
             return self
         cur = torch.cuda.current_stream()
         if not any(c.stream_id == cur.stream_id for c, _ in _WGRAD_PENDING):
-            if not _WGRAD_PENDING:
-                try:
-                    torch.autograd.Variable._execution_engine.queue_callback(_join_pending_wgrads)
-                except RuntimeError:  # not inside a backward pass: stay on the caller's stream
-                    return self
+            if not _queue_final_callback():  # not inside a backward pass: stay on the caller's stream
+                return self
             side = _WGRAD_STREAMS.get(cur.stream_id)
             if side is None:
                 side = _WGRAD_STREAMS[cur.stream_id] = torch.cuda.Stream()
@@ -175,6 +201,7 @@ def join_wgrad_stream() -> None:
 
 def _grad_target(param: torch.Tensor) -> Tuple[torch.Tensor, bool]:
     """(buffer to accumulate into, whether autograd should get None)."""
+    _note_grad_stream()
     mg = getattr(param, "main_grad", None)
     if mg is not None:
         return mg, True
