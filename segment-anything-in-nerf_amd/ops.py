@@ -34,11 +34,28 @@ def _L():
 
 
 def _p(t: Optional[torch.Tensor]):
-    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+    """Raw device pointer for a c_void_p argument (ctypes converts a plain int / None itself: no wrapper object)."""
+    return None if t is None else t.data_ptr()
+
+
+_DEVICE_INDEX: Optional[int] = None
+_HAS_GPU: Optional[bool] = None
+
+
+def _has_gpu() -> bool:
+    global _HAS_GPU
+    if _HAS_GPU is None:
+        _HAS_GPU = torch.cuda.is_available()
+    return _HAS_GPU
 
 
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    """Raw handle of the current HIP stream of this process's device (one process per GPU).  The torch.cuda.Stream object
+    behind torch.cuda.current_stream() costs ~9 us per call on the host -- 0.6 ms per train step at ~60 launches."""
+    global _DEVICE_INDEX
+    if _DEVICE_INDEX is None:
+        _DEVICE_INDEX = torch.cuda.current_device()
+    return torch._C._cuda_getCurrentRawStream(_DEVICE_INDEX)
 
 
 def _chk(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:
@@ -146,7 +163,7 @@ def _queue_final_callback() -> bool:
 
 def _note_grad_stream() -> None:
     """Called by every backward node that writes parameter gradients in place."""
-    if not torch.cuda.is_available():
+    if not _has_gpu():
         return
     cur = torch.cuda.current_stream()
     if any(s.stream_id == cur.stream_id for s in _GRAD_STREAMS):
@@ -164,7 +181,7 @@ class _wgrad_stream:
         self.ctx = None
 
     def __enter__(self):
-        if not (WGRAD_SIDE_STREAM and torch.cuda.is_available()):
+        if not (WGRAD_SIDE_STREAM and _has_gpu()):
             return self
         cur = torch.cuda.current_stream()
         if not any(c.stream_id == cur.stream_id for c, _ in _WGRAD_PENDING):
