@@ -306,3 +306,12 @@ def test_reachable_rows_cover_every_addressable_row():
                        "base_resolution": 16, "per_level_scale": float(np.exp(np.log(128 / 16) / 11))}, device="cpu")
     n_sparse, rows = enc.active_rows()
     assert n_sparse == 8 and rows.numel() < 0.3 * (n_sparse << 19)
+
+
+def test_every_exported_symbol_is_documented():
+    """INTEGRATION.md names the reference interface behind every entry point declared in include/samnerf_hip.h."""
+    hdr = open(os.path.join(ROOT, "include", "samnerf_hip.h")).read()
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    declared = sorted(set(re.findall(r"\b(snf_[a-z0-9_]+)\s*\(", hdr)))
+    missing = [n for n in declared if n not in doc]
+    assert not missing, missing
