@@ -162,3 +162,108 @@ def broadcast_parameters(param_buffers: Iterable[torch.Tensor], src: int = 0) ->
 
 def world_size() -> int:
     return dist.get_world_size() if dist.is_initialized() else 1
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Table parallelism for the feature hash grids
+# ---------------------------------------------------------------------------------------------------------------------
+# The four F=8 feature tables are 805 MB -- 92 % of all parameters -- while a step only reads/writes N*L*8 rows of them.
+# Replicating them (plain ray data-parallelism) puts 2 x 7/8 x 805 MB per GPU on the xGMI links every step; owning them
+# costs N x 768 B per head and direction.  So each rank OWNS a contiguous run of (grid, level) slabs of every head, evaluates
+# those levels for the samples of ALL ranks, and the activations travel instead of the tables:
+#
+#   forward   all-gather positions [N,3] -> own levels at W*N points -> all-to-all -> [N, L_total*F] on the sample's rank
+#   backward  all-to-all of d(features)  -> sorted scatter-add of W*N samples into the OWN slabs only
+#   step      Adam on the own slabs, no gradient exchange and no parameter all-gather for the tables
+#
+# The sums are the ones the all-reduce would have formed (every sample's contribution to every row, then 1/W in Adam), in a
+# different fp32 order.  The dense layers, the field / proposal grids (69 MB) and the conv head stay replicated
+# (`sharded_step`).  Tables are made whole again (`broadcast` of each owner's slabs) before evaluation and checkpoints.
+
+
+class TableParallelLayout:
+    """Slab ownership for one head = a tuple of hash grids evaluated at the same points (each (levels, F, log2_T)).
+
+    Slabs are numbered grid-major / level-minor -- the order of the head's output columns -- and rank r owns slabs
+    [r*per, (r+1)*per).  `runs(r)`: the owned slabs as (grid, first_level, n_levels, local_column) runs, one kernel launch
+    each; a rank's levels inside one grid are always contiguous."""
+
+    def __init__(self, grids, world: int):
+        self.grids = [(int(L), int(F), int(T)) for (L, F, T) in grids]
+        self.world = int(world)
+        self.F = self.grids[0][1]
+        self.n_slabs = sum(L for L, _, _ in self.grids)
+        self.per = self.n_slabs // self.world
+        self.width = self.per * self.F            # columns a rank produces
+        self.total = self.n_slabs * self.F        # columns of the head
+
+    @staticmethod
+    def supported(grids, world: int) -> bool:
+        grids = list(grids)
+        return (world >= 1 and len(grids) > 0 and len({F for _, F, _ in grids}) == 1
+                and sum(L for L, _, _ in grids) % world == 0)
+
+    def runs(self, rank: int):
+        lo, hi = rank * self.per, (rank + 1) * self.per
+        out, base = [], 0
+        for gi, (L, _, _) in enumerate(self.grids):
+            a, b = max(lo, base), min(hi, base + L)
+            if b > a:
+                out.append((gi, a - base, b - a, (a - lo) * self.F))
+            base += L
+        return out
+
+    def owned_levels(self, rank: int, grid: int):
+        """(first_level, end_level) of `grid` owned by `rank` ((0, 0) if none)."""
+        for gi, l0, nl, _ in self.runs(rank):
+            if gi == grid:
+                return l0, l0 + nl
+        return 0, 0
+
+    def owned_elements(self, rank: int, grid: int):
+        """The same as a flat element range of that grid's [L, 2^T, F] table."""
+        l0, l1 = self.owned_levels(rank, grid)
+        _, F, T = self.grids[grid]
+        return (l0 << T) * F, (l1 << T) * F
+
+
+def tp_gather_positions(u: torch.Tensor) -> torch.Tensor:
+    """[N, 3] on every rank -> [W*N, 3] in rank order (N must be the same on every rank: rays x top-K)."""
+    world = dist.get_world_size()
+    out = torch.empty((world * u.shape[0], u.shape[1]), dtype=u.dtype, device=u.device)
+    dist.all_gather_into_tensor(out, u.contiguous())
+    return out
+
+
+def tp_exchange(block: torch.Tensor) -> torch.Tensor:
+    """All-to-all of a [W, N, C] block: slice w goes to rank w; the result's slice w came from rank w."""
+    out = torch.empty_like(block)
+    dist.all_to_all_single(out.view(-1), block.contiguous().view(-1))
+    return out
+
+
+def tp_forward(u_all: torch.Tensor, n_local: int, layout: TableParallelLayout, eval_run) -> torch.Tensor:
+    """Features of this rank's n_local samples from all owners.  eval_run(grid, first_level, n_levels, out, ld, col) writes
+    the levels of one run for every row of u_all into out[:, col : col + n_levels*F]."""
+    world, rank = layout.world, dist.get_rank()
+    mine = torch.empty((world * n_local, layout.width), dtype=torch.float32, device=u_all.device)
+    for gi, l0, nl, col in layout.runs(rank):
+        eval_run(gi, l0, nl, mine, layout.width, col)
+    got = tp_exchange(mine.view(world, n_local, layout.width))          # [owner, n, per*F]
+    return got.permute(1, 0, 2).reshape(n_local, layout.total)          # owner-major == slab order == column order
+
+
+def tp_backward(grad_out: torch.Tensor, layout: TableParallelLayout) -> torch.Tensor:
+    """d(features) [n_local, total] of this rank's samples -> [W*n_local, per*F]: the gradients of the columns this rank owns,
+    for the samples of every rank (rank order, matching tp_gather_positions)."""
+    world, n_local = layout.world, grad_out.shape[0]
+    send = grad_out.view(n_local, world, layout.width).permute(1, 0, 2).contiguous()
+    return tp_exchange(send).view(world * n_local, layout.width)
+
+
+def tp_refresh_table(param_flat: torch.Tensor, layout: TableParallelLayout, grid: int) -> None:
+    """Make one table whole on every rank: each owner broadcasts its levels."""
+    for w in range(layout.world):
+        lo, hi = layout.owned_elements(w, grid)
+        if hi > lo:
+            dist.broadcast(param_flat[lo:hi], src=w)

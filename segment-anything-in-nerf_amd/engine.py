@@ -58,6 +58,7 @@ class Optimizers:
         self.skip_unreachable_rows = os.environ.get("SNF_ADAM_ALL_ROWS", "0") != "1"
         self._plans: Dict[str, list] = {}
         self._row_cuts: Dict[tuple, tuple] = {}
+        self._tp_cache: Dict[str, list] = {}
         self.shard_slices: Dict[str, List] = {}  # group -> [(lo, hi)] arena slices stepped separately (set by the trainer)
         self.step_count = {k: 0 for k in arenas}
         self.sched_step = {k: 0 for k in arenas}
@@ -123,9 +124,18 @@ class Optimizers:
             return
         # data-parallel: walk the plan.  Dense segments: sharded exchange + step (or all-reduce + replicated step);
         # row segments (reachable rows of coarse hash levels): only those rows travel, and every rank steps them.
+        owned = self._tp_tables(k)
         for seg in self._plan(k):
             s0, s1 = max(lo, seg[1]), min(hi, seg[2])
             if s1 <= s0:
+                continue
+            tp = next((t for t in owned if t[0] <= seg[1] < t[1]), None)
+            if tp is not None:
+                # table-parallel hash table: the backward already summed every rank's samples into the levels this rank
+                # owns, nothing else was touched -- step the owned levels, no exchange
+                x0, x1 = max(s0, tp[2]), min(s1, tp[3])
+                if x1 > x0:
+                    self._adam_range(k, x0, x1, lr, b1, b2, eps, t, scale)
                 continue
             if seg[0] == "dense":
                 def step_fn(x0: int, x1: int, s0=s0) -> None:
@@ -163,25 +173,59 @@ class Optimizers:
             return self._plans[k]
         a = self.arenas[k]
         segs, cur = [], 0
-        if self.skip_unreachable_rows:
-            for pname, (off, shape) in a.offsets.items():
-                enc = a.tables.get(pname)
-                if enc is None:
-                    continue
-                n_sparse, rows = enc.active_rows()
-                if n_sparse == 0:
-                    continue
+        tp_offs = {t[0] for t in self._tp_tables(k)}
+        for pname, (off, shape) in a.offsets.items():
+            enc = a.tables.get(pname)
+            if enc is None:
+                continue
+            n_sparse, rows = enc.active_rows() if self.skip_unreachable_rows else (0, None)
+            if n_sparse == 0 and off not in tp_offs:
+                continue
+            if off > cur:
+                segs.append(("dense", cur, off))
+            cur = off
+            if n_sparse:
                 F = enc.n_features_per_level
-                sparse_end = off + (n_sparse << enc.log2_hashmap_size) * F
-                if off > cur:
-                    segs.append(("dense", cur, off))
+                cur = off + (n_sparse << enc.log2_hashmap_size) * F
                 offsets = (rows * F + off).to(torch.int32).contiguous()
-                segs.append(("rows", off, sparse_end, offsets, F, (rows * F + off).cpu().numpy()))
-                cur = sparse_end
+                segs.append(("rows", off, cur, offsets, F, (rows * F + off).cpu().numpy()))
+            if off in tp_offs:  # segments never straddle the end of a table-parallel table
+                end = off + enc.params.numel()
+                if end > cur:
+                    segs.append(("dense", cur, end))
+                cur = end
         if cur < a.numel:
             segs.append(("dense", cur, a.numel))
         self._plans[k] = segs
         return segs
+
+    def _tp_tables(self, k: str):
+        """Hash tables of group `k` that are trained table-parallel (distributed.TableParallelLayout), as arena element
+        ranges (table_start, table_end, owned_start, owned_end); [] on one rank.  Also hands each such parameter the
+        collective that makes it whole again (ops.hashgrid calls it before a replicated evaluation)."""
+        if k in self._tp_cache:
+            return self._tp_cache[k]
+        from . import distributed as D
+        out = []
+        a = self.arenas[k]
+        if D.collectives_on():
+            import torch.distributed as dist
+            for pname, (off, shape) in a.offsets.items():
+                enc = a.tables.get(pname)
+                head = getattr(enc, "tp_head", None)
+                if head is None:
+                    continue
+                encs, gi = head
+                layout = ops.table_parallel_layout(tuple(e.spec for e in encs))
+                if layout is None:
+                    continue
+                lo, hi = layout.owned_elements(dist.get_rank(), gi)
+                n = enc.params.numel()
+                out.append((off, off + n, off + lo, off + hi, layout, gi))
+                enc.params._tp_refresh = (lambda flat=a.param[off:off + n], layout=layout, gi=gi:
+                                          D.tp_refresh_table(flat, layout, gi))
+        self._tp_cache[k] = out
+        return out
 
     def _adam_range(self, k: str, lo: int, hi: int, lr, b1, b2, eps, t, scale) -> None:
         """Fused Adam (+ gradient re-zeroing) on the arena elements [lo, hi) of group `k`, following the plan."""
@@ -204,13 +248,23 @@ class Optimizers:
         """Sharded runs keep each rank's Adam moments only for its shards of the dense segments: gather them before saving
         a checkpoint (the layout is the one exchange_and_step uses: trainer slices x dense plan segments)."""
         from . import distributed as D
-        if not self.sharded or not D.collectives_on():
+        if not D.collectives_on():
             return
         for k, a in self.arenas.items():
+            owned = self._tp_tables(k)
+            for toff, tend, _, _, layout, gi in owned:  # table-parallel tables: every owner broadcasts its levels
+                for buf in (a.param, a.exp_avg, a.exp_avg_sq):
+                    D.tp_refresh_table(buf[toff:tend], layout, gi)
+            for pname in a.offsets:
+                enc = a.tables.get(pname)
+                if enc is not None and getattr(enc.params, "_tp_stale", False):
+                    enc.params._tp_stale = False
+            if not self.sharded:
+                continue
             for lo, hi in self.shard_slices.get(k, [(0, a.numel)]):
                 for seg in self._plan(k):
                     s0, s1 = max(lo, seg[1]), min(hi, seg[2])
-                    if seg[0] == "dense" and s1 > s0:
+                    if seg[0] == "dense" and s1 > s0 and not any(t[0] <= seg[1] < t[1] for t in owned):
                         D.gather_sharded_state(a.exp_avg[s0:s1])
                         D.gather_sharded_state(a.exp_avg_sq[s0:s1])
 

@@ -206,6 +206,12 @@ class SAMField(Field):
             self.clipseg_encs = mk()
             self.clipseg_net = cut(sum(e.n_output_dims for e in self.clipseg_encs), 192, 1)
 
+        # the grids of one head are evaluated at the same points: under multi-GPU training their levels are sharded over
+        # the ranks as one group (distributed.TableParallelLayout)
+        for encs in (self.clip_encs, getattr(self, "clipseg_encs", ())):
+            for i, e in enumerate(encs):
+                e.tp_head = (tuple(encs), i)
+
     @staticmethod
     def _get_encoding(start_res, end_res, levels, indim=3, hash_size=19, device=None):
         growth = np.exp((np.log(end_res) - np.log(start_res)) / (levels - 1))

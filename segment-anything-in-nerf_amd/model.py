@@ -411,6 +411,9 @@ class SAMModel(NerfactoModel):
                     shared = [selected[1], selected[0].ids, *pos]
                     if pos:
                         shared += [w for w, _ in pos[0].__dict__.get("_snf_sorted", {}).values()]
+                        gathered = pos[0].__dict__.get("_snf_tp_gathered")
+                        if gathered is not None:
+                            shared += [gathered] + [w for w, _ in gathered.__dict__.get("_snf_sorted", {}).values()]
                     for t in (weights, ray_samples.euclid_bins, ray_samples.spacing_bins, ray_samples.ray_bundle.origins,
                               ray_samples.ray_bundle.directions, *shared):
                         if t is not None:
@@ -434,10 +437,16 @@ class SAMModel(NerfactoModel):
                 # the backward sorts of the feature grids depend on these positions and the level geometry only: done
                 # here, once per geometry (the SAM and ClipSeg grids have the same two), while the GPU is still lightly
                 # loaded, instead of four times inside the backward of the heads
-                encs = list(self.sam_field.clip_encs) + (list(self.sam_field.clipseg_encs)
-                                                          if self.config.use_clipseg_feature else [])
-                for enc in encs:
-                    ops.hashgrid_presort(u, enc.scalings, enc.n_levels, enc.log2_hashmap_size)
+                heads = [list(self.sam_field.clip_encs)] + ([list(self.sam_field.clipseg_encs)]
+                                                           if self.config.use_clipseg_feature else [])
+                layouts = [ops.table_parallel_layout(tuple(e.spec for e in h)) for h in heads]
+                for h, layout in zip(heads, layouts):
+                    if layout is not None:
+                        # table-parallel head: positions of all ranks gathered once, sorted for the levels owned here
+                        ops.tp_presort(u, tuple(e.spec for e in h), layout)
+                    else:
+                        for enc in h:
+                            ops.hashgrid_presort(u, enc.scalings, enc.n_levels, enc.log2_hashmap_size)
         return sam_samples, sam_weights[..., None]
 
     def _feature_head(self, head: str, selected, outputs) -> None:

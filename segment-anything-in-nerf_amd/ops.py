@@ -432,8 +432,128 @@ class _HashGridMulti(torch.autograd.Function):
         return (None, None, *grads)
 
 
+# -- table parallelism (distributed.py: TableParallelLayout) ------------------------------------------------------------
+TABLE_PARALLEL = _os.environ.get("SNF_TABLE_PARALLEL", "1") == "1"
+_SC_RUNS: dict = {}
+
+
+def table_parallel_layout(specs):
+    """The slab-ownership layout of a head whose grids are `specs`, or None when the head stays replicated (one rank, the
+    switch is off, F != 8, or the slab count does not divide by the world size)."""
+    from . import distributed as D
+    if not (TABLE_PARALLEL and D.collectives_on()):
+        return None
+    grids = [(L, F, T) for (_, L, F, T) in specs]
+    world = D.world_size()
+    if grids[0][1] != 8 or not D.TableParallelLayout.supported(grids, world):
+        return None
+    return D.TableParallelLayout(grids, world)
+
+
+def _sc_run(sc: torch.Tensor, l0: int, nl: int) -> torch.Tensor:
+    """scalings[l0 : l0+nl] as a tensor object that lives as long as `sc` (the geometry caches key on data_ptr)."""
+    k = (sc.data_ptr(), l0, nl)
+    if k not in _SC_RUNS:
+        _SC_RUNS[k] = (sc, sc[l0:l0 + nl])
+    return _SC_RUNS[k][1]
+
+
+def tp_gathered_positions(u: torch.Tensor) -> torch.Tensor:
+    """Positions of every rank's samples, gathered once per `u` (the heads share it, and the backward sorts attach to it)."""
+    from . import distributed as D
+    U = u.__dict__.get("_snf_tp_gathered")
+    if U is None:
+        U = D.tp_gather_positions(_chk(u, "u"))
+        u.__dict__["_snf_tp_gathered"] = U
+    return U
+
+
+def tp_presort(u: torch.Tensor, specs, layout) -> None:
+    """Forward-time sorts of the gathered positions for the level runs this rank owns."""
+    from . import distributed as D
+    import torch.distributed as dist
+    U = tp_gathered_positions(u)
+    for gi, l0, nl, _ in layout.runs(dist.get_rank()):
+        sc, _, _, T = specs[gi]
+        hashgrid_presort(U, _sc_run(sc, l0, nl), nl, T)
+
+
+def tp_eval_run(U: torch.Tensor, specs, tables):
+    """eval_run(grid, first_level, n_levels, out, ld, col) for distributed.tp_forward: the levels of one owned run at every
+    row of U, written to out[:, col : col + n_levels*F]."""
+    M = U.shape[0]
+
+    def eval_run(gi, l0, nl, out, ld, col):
+        sc, L, F, T = specs[gi]
+        tab = _chk(tables[gi], "table")
+        assert tab.numel() == (L << T) * F, "table size does not match (levels, log2_T, features)"
+        _launch("snf_hashgrid_fwd", _p(U), ctypes.c_void_p(tab.data_ptr() + ((l0 << T) * F) * 4), _p(_sc_run(sc, l0, nl)),
+                M, nl, F, T, _p(out), ld, col, _stream(), tag=f"F{F}L{nl}tp")
+
+    return eval_run
+
+
+def tp_accumulate(U: torch.Tensor, G: torch.Tensor, specs, tables, layout, rank: int) -> List[Optional[torch.Tensor]]:
+    """Scatter-add the gradients G [rows of U, per*F] of the columns `rank` owns into the owned levels of the tables'
+    gradient buffers.  Returns, per table, None (arena gradient written in place) or the full-size gradient tensor."""
+    grads: List[Optional[torch.Tensor]] = [None] * len(tables)
+    for gi, l0, nl, col in layout.runs(rank):
+        sc, L, F, T = specs[gi]
+        tab = tables[gi]
+        if not tab.requires_grad:
+            continue
+        buf, fused = _grad_target(tab)
+        _hashgrid_bwd_launch(U, G, _sc_run(sc, l0, nl), U.shape[0], nl, F, T, layout.width, col,
+                             buf.view(-1)[(l0 << T) * F:((l0 + nl) << T) * F])
+        tab._tp_stale = True  # the other ranks' copies of these levels are behind once Adam has run
+        if not fused:
+            grads[gi] = buf  # no arena: autograd gets the full-size gradient (zero outside the owned levels)
+    return grads
+
+
+class _HashGridTableParallel(torch.autograd.Function):
+    """_HashGridMulti with the tables sharded by level over the ranks: this rank evaluates (and accumulates gradients for)
+    its own levels at the samples of all ranks; features and their gradients cross the links, the tables never do."""
+
+    @staticmethod
+    def forward(ctx, u, specs, layout, *tables):
+        from . import distributed as D
+        u = _chk(u, "u")
+        U = tp_gathered_positions(u)
+        out = D.tp_forward(U, u.shape[0], layout, tp_eval_run(U, specs, tables))
+        ctx.specs, ctx.layout, ctx.tables, ctx.U = specs, layout, tables, U
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import distributed as D
+        import torch.distributed as dist
+        g = _chk(g, "grad_out")
+        G = D.tp_backward(g, ctx.layout)  # [W*N, per*F]
+        grads = tp_accumulate(ctx.U, G, ctx.specs, ctx.tables, ctx.layout, dist.get_rank())
+        return (None, None, None, *grads)
+
+
+def _tp_refresh(tables) -> None:
+    """Replicated evaluation of tables that were trained table-parallel: make them whole first (collective)."""
+    for tab in tables:
+        if getattr(tab, "_tp_stale", False):
+            refresh = getattr(tab, "_tp_refresh", None)
+            if refresh is None:
+                raise RuntimeError("hash table was trained table-parallel but has no owner map to consolidate it "
+                                   "(engine.Optimizers attaches one)")
+            refresh()
+            tab._tp_stale = False
+
+
 def hashgrid(u, tables: Sequence[torch.Tensor], specs) -> torch.Tensor:
-    return _HashGridMulti.apply(u, tuple(specs), *tables)
+    specs = tuple(specs)
+    if torch.is_grad_enabled() and any(t.requires_grad for t in tables):
+        layout = table_parallel_layout(specs)
+        if layout is not None:
+            return _HashGridTableParallel.apply(u, specs, layout, *tables)
+    _tp_refresh(tables)
+    return _HashGridMulti.apply(u, specs, *tables)
 
 
 # ---------------------------------------------------------------------------------------------

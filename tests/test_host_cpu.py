@@ -247,6 +247,105 @@ def test_sharded_optimizer_exchange_gloo(world):
     assert res == [(r, True) for r in range(world)]
 
 
+def _table_parallel_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    import samnerf_amd  # noqa: F401
+    from samnerf_amd import distributed as D
+    from oracle import samnerf_oracle as O
+    D.init_distributed(backend="gloo")
+    T, F, N = 10, 8, 96
+    grids = [(6, F, T), (6, F, T)]
+    layout = D.TableParallelLayout(grids, world)
+    gen = torch.Generator().manual_seed(5)
+    tables = [torch.randn((L << T, F), generator=gen) for L, _, _ in grids]
+    scal = [O.hash_scalings(6, 16, 128), O.hash_scalings(6, 128, 512)]
+    us = [torch.rand((N, 3), generator=gen) for _ in range(world)]          # every rank's samples ...
+    gs = [torch.randn((N, layout.total), generator=gen) for _ in range(world)]  # ... and upstream gradients
+    ok = True
+
+    # forward: features of the own samples, assembled from the owners, equal the replicated evaluation
+    U = D.tp_gather_positions(us[rank])
+    ok = ok and torch.equal(U, torch.cat(us))
+
+    def eval_run(gi, l0, nl, out, ld, col):
+        out[:, col:col + nl * F] = O.hashgrid_fwd(U, tables[gi][l0 << T:(l0 + nl) << T], scal[gi][l0:l0 + nl], T)
+
+    out = D.tp_forward(U, N, layout, eval_run)
+    full = torch.cat([O.hashgrid_fwd(us[rank], tables[g], scal[g], T) for g in range(2)], dim=1)
+    ok = ok and torch.equal(out, full)
+
+    # backward: the owned levels receive the sum over every rank's samples, exactly what the all-reduce would have formed
+    G = D.tp_backward(gs[rank], layout)
+    ref = [torch.zeros_like(t) for t in tables]
+    for w in range(world):
+        leaves = [t.clone().requires_grad_(True) for t in tables]
+        y = torch.cat([O.hashgrid_fwd(us[w], leaves[g], scal[g], T) for g in range(2)], dim=1)
+        y.backward(gs[w])
+        for g in range(2):
+            ref[g] += leaves[g].grad
+    for gi, l0, nl, col in layout.runs(rank):
+        slab = tables[gi][l0 << T:(l0 + nl) << T].clone().requires_grad_(True)
+        O.hashgrid_fwd(U, slab, scal[gi][l0:l0 + nl], T).backward(G[:, col:col + nl * F])
+        ok = ok and torch.allclose(slab.grad, ref[gi][l0 << T:(l0 + nl) << T], rtol=1e-5, atol=1e-6)
+        lo, hi = layout.owned_elements(rank, gi)
+        ok = ok and (lo, hi) == ((l0 << T) * F, ((l0 + nl) << T) * F)
+
+    # consolidation: every owner's levels reach every rank
+    for gi in range(2):
+        flat = tables[gi].clone().view(-1)
+        lo, hi = layout.owned_elements(rank, gi)
+        flat[lo:hi] += rank + 1
+        D.tp_refresh_table(flat, layout, gi)
+        expect = tables[gi].clone().view(-1)
+        for w in range(world):
+            lo, hi = layout.owned_elements(w, gi)
+            expect[lo:hi] += w + 1
+        ok = ok and torch.equal(flat, expect)
+    q.put((rank, bool(ok)))
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_table_parallel_hash_grids_gloo(world):
+    """distributed.tp_forward / tp_backward (levels sharded over the ranks, activations exchanged) against the replicated
+    evaluation and the all-reduced gradient, with the oracle's hash grid as the per-level arithmetic."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33000 + (os.getpid() % 2000) + world
+    procs = [ctx.Process(target=_table_parallel_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(r, True) for r in range(world)]
+
+
+def test_table_parallel_layout_covers_every_slab_once():
+    from samnerf_amd.distributed import TableParallelLayout as TPL
+    for grids in ([(12, 8, 19), (12, 8, 19)], [(6, 8, 10), (6, 8, 10)], [(5, 8, 4), (7, 8, 6), (12, 8, 5)]):
+        n = sum(L for L, _, _ in grids)
+        for world in range(1, 13):
+            if n % world:
+                assert not TPL.supported(grids, world)
+                continue
+            lay = TPL(grids, world)
+            seen = []
+            for r in range(world):
+                col = 0
+                for gi, l0, nl, c in lay.runs(r):
+                    assert c == col and nl > 0
+                    col += nl * lay.F
+                    seen += [(gi, l) for l in range(l0, l0 + nl)]
+                    assert lay.owned_levels(r, gi) == (l0, l0 + nl)
+                assert col == lay.width
+            assert seen == [(gi, l) for gi, (L, _, _) in enumerate(grids) for l in range(L)]
+    assert not TPL.supported([(12, 8, 19), (12, 2, 19)], 2)
+
+
 def test_shard_bounds_cover_the_slice():
     from samnerf_amd.distributed import shard_bounds
     for n in (0, 63, 64, 1000, 201_326_592 + 640):

@@ -497,3 +497,44 @@ def test_hashgrid_backward_slices_large_batches():
     m.HASHGRID_BWD_MODE = "sorted"
     scale = float(res["atomic"].abs().max())
     assert float((res["sorted"] - res["atomic"]).abs().max()) <= 2e-4 * scale
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_table_parallel_level_runs_match_the_replicated_grids(world):
+    """The per-rank halves of the table-parallel hash grids (ops.tp_eval_run / tp_accumulate: level sub-ranges of a table,
+    strided output columns) for every rank of a virtual world, against the replicated evaluation / backward of the same
+    points: the ownership arithmetic on the real kernels, without a process group."""
+    m = ops()
+    from samnerf_amd.distributed import TableParallelLayout
+    T, F, n = 14, 8, 3000
+    specs, tables = [], []
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    for lo, hi in ((16, 128), (128, 512)):
+        sc = O.hash_scalings(12, lo, hi).cuda()
+        specs.append((sc, 12, F, T))
+        tables.append((torch.rand(((12 << T) * F,), device="cuda", generator=gen) - 0.5).requires_grad_(True))
+    specs = tuple(specs)
+    layout = TableParallelLayout([(12, F, T)] * 2, world)
+    U = torch.rand((world * n, 3), device="cuda", generator=gen)   # the gathered positions of `world` ranks
+    Gfull = torch.randn((world * n, layout.total), device="cuda", generator=gen)
+    full = m.hashgrid(U, tables, specs)
+    full.backward(Gfull)
+    ref = [t.grad.clone() for t in tables]
+    got = [torch.zeros_like(t) for t in tables]
+    for t in tables:
+        t.grad = None
+    m.hashgrid_presort(U, m._sc_run(specs[0][0], 0, 12 if world == 2 else layout.per), 12 if world == 2 else layout.per, T)
+    for r in range(world):
+        mine = torch.empty((world * n, layout.width), device="cuda")
+        ev = m.tp_eval_run(U, specs, tables)
+        for gi, l0, nl, col in layout.runs(r):
+            ev(gi, l0, nl, mine, layout.width, col)
+        assert torch.equal(mine, full[:, r * layout.width:(r + 1) * layout.width])
+        G = Gfull[:, r * layout.width:(r + 1) * layout.width].contiguous()
+        grads = m.tp_accumulate(U, G, specs, tables, layout, r)
+        for gi, g in enumerate(grads):
+            if g is not None:
+                got[gi] += g
+    for gi in range(2):
+        scale = float(ref[gi].abs().max())
+        assert float((got[gi] - ref[gi]).abs().max()) <= 1e-5 * scale
