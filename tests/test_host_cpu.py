@@ -346,6 +346,92 @@ def test_table_parallel_layout_covers_every_slab_once():
     assert not TPL.supported([(12, 8, 19), (12, 2, 19)], 2)
 
 
+def _engine_worker(rank, world, port, q, table_parallel):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), SNF_TABLE_PARALLEL="1" if table_parallel else "0")
+    sys.path.insert(0, ROOT)
+    import samnerf_amd  # noqa: F401
+    from samnerf_amd import configs, distributed as D, engine, model, ops
+    D.init_distributed(backend="gloo")
+
+    # the two Adam launches as plain torch (the C-ABI kernels need a GPU); everything around them is the product code
+    def adam_step_(p, g, m, v, lr, b1, b2, eps, t, scale=1.0, zero=True):
+        _adam_ref(p, g, m, v, lr, b1, b2, eps, t, scale)
+        if zero:
+            g.zero_()
+
+    def adam_step_rows_(p, g, m, v, rows, F, lr, b1, b2, eps, t, scale=1.0, zero=True):
+        idx = (rows.long()[:, None] + torch.arange(F)[None, :]).reshape(-1)
+        pp, gg, mm, vv = p[idx], g[idx], m[idx], v[idx]
+        _adam_ref(pp, gg, mm, vv, lr, b1, b2, eps, t, scale)
+        p[idx], m[idx], v[idx] = pp, mm, vv
+        if zero:
+            g[idx] = 0
+
+    ops.adam_step_, ops.adam_step_rows_ = adam_step_, adam_step_rows_
+    mc = copy.deepcopy(configs.method_configs["samnerf_distill"].pipeline.model)
+    mc.log2_hashmap_size, mc.hashgrid_sizes = 8, (14, 14)  # T=14: the coarsest feature level is a reachable-row segment
+    mc.proposal_net_args_list = [dict(a, log2_hashmap_size=8) for a in mc.proposal_net_args_list]
+    samnerf_amd.tcnn_compat.manual_seed(3)
+    m = mc.setup(scene_box=model.SceneBox(), num_train_data=2, device="cpu")
+    arenas = m.build_arenas()
+    opt = engine.Optimizers(copy.deepcopy(configs.method_configs["samnerf_distill"].optimizers), arenas)
+    a = arenas["sam_field"]
+    names = list(a.offsets)
+    n_sam = len(list(m.sam_field.clip_encs.parameters())) + len(list(m.sam_field.sam_net.parameters()))
+    slices = [(0, n_sam), (n_sam, len(names))]  # the trainer steps the two heads separately (pipeline.py)
+    opt.shard_slices["sam_field"] = [(a.offsets[names[lo]][0], a.offsets[names[hi]][0] if hi < len(names) else a.numel)
+                                     for lo, hi in slices]
+    owned = opt._tp_tables("sam_field")
+    plan = opt._plan("sam_field")
+    ok = (len(owned) == 4) == table_parallel and any(s[0] == "rows" for s in plan)
+    # gradients can only be non-zero on rows some input can address
+    live = torch.ones(a.numel)
+    for seg in plan:
+        if seg[0] == "rows":
+            live[seg[1]:seg[2]] = 0
+            live[(seg[3].long()[:, None] + torch.arange(seg[4])[None, :]).reshape(-1)] = 1
+    pr, mr, vr = a.param.clone(), torch.zeros(a.numel), torch.zeros(a.numel)
+    oc = opt.config["sam_field"]["optimizer"]
+    for t in (1, 2, 3):
+        gen = torch.Generator().manual_seed(100 + t)
+        local = [torch.randn(a.numel, generator=gen) * live for _ in range(world)]  # each rank's backward, replicated tables
+        total = sum(local)
+        _adam_ref(pr, total.clone(), mr, vr, opt.lr("sam_field"), oc.betas[0], oc.betas[1], oc.eps, t, 1.0 / world)
+        a.grad.copy_(local[rank])
+        for toff, tend, lo, hi, _, _ in owned:  # table-parallel backward: all ranks' samples, owned levels only
+            a.grad[toff:tend] = 0
+            a.grad[lo:hi] = total[lo:hi]
+        first = True
+        for lo_i, hi_i in slices:
+            opt.exchange_and_step("sam_field", lo_i, hi_i, count_step=first)
+            first = False
+        ok = ok and bool(torch.count_nonzero(a.grad) == 0)
+    opt.consolidate_state()
+    for got, ref in ((a.param, pr), (a.exp_avg, mr), (a.exp_avg_sq, vr)):
+        ok = ok and torch.allclose(got, ref, rtol=1e-5, atol=1e-7)
+    q.put((rank, bool(ok)))
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,table_parallel", [(2, True), (3, True), (2, False)])
+def test_engine_exchange_and_step_gloo(world, table_parallel):
+    """engine.Optimizers.exchange_and_step on the 'sam_field' arena of a small model, per head slice as the trainer calls it
+    (plan segments x table-parallel ownership x sharded dense exchange x reachable-row segments), against replicated Adam
+    on the mean gradient; then consolidate_state makes parameters and moments whole on every rank."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 35000 + (os.getpid() % 2000) + world + 10 * table_parallel
+    procs = [ctx.Process(target=_engine_worker, args=(r, world, port, q, table_parallel)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(r, True) for r in range(world)]
+
+
 def test_shard_bounds_cover_the_slice():
     from samnerf_amd.distributed import shard_bounds
     for n in (0, 63, 64, 1000, 201_326_592 + 640):
