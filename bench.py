@@ -20,6 +20,7 @@ import argparse
 import copy
 import json
 import os
+import re
 import sys
 import time
 
@@ -45,10 +46,14 @@ def algorithmic_model(key: str, w: dict):
     name, _, tag = key.partition("/")
     if name in ("snf_hashgrid_fwd", "snf_hashgrid_bwd", "snf_hashgrid_bwd_sorted", "snf_hashgrid_bwd_sorted_ex",
                 "snf_hashgrid_bwd_presorted"):
-        F, L = (int(x) for x in tag[1:].split("L"))
+        m = re.fullmatch(r"F(\d+)L(\d+)(tp)?", tag)
+        if m is None:
+            return None, None, None
+        F, L = int(m.group(1)), int(m.group(2))
         rw = 1 if name.endswith("fwd") else 2
-        # F=8: feature grids on the R*K top-K samples; F=2: proposal grid (L=5, R*P samples) or field grid (L=16, R*S)
-        n = R * K if F == 8 else (R * P if L == 5 else R * S)
+        # F=8: feature grids on the R*K top-K samples; F=2: proposal grid (L=5, R*P samples) or field grid (L=16, R*S).
+        # Table-parallel feature grids (multi-GPU): a launch covers the L levels this rank owns at the samples of all ranks.
+        n = R * K * w.get("world", 1) if F == 8 else (R * P if L == 5 else R * S)
         return "hbm", float(n * L * 8 * F * 4 * rw), "GB/s"
     if name.startswith("snf_linear"):
         pm = tag.endswith("pm")  # conv head: second convolution, on the patch means
@@ -145,6 +150,7 @@ def main():
     if os.environ.get("SNF_ADAM_LAUNCH"):  # tuning: "max_blocks,threads,unroll"
         from samnerf_amd import _lib
         assert _lib.load().snf_set_adam_launch(*(int(x) for x in os.environ["SNF_ADAM_LAUNCH"].split(","))) == 0
+    w["world"] = world
     trainer = build_trainer(w, local_rank, world)
 
     multi = dist.is_initialized()  # world > 1 (or SNF_FORCE_COLLECTIVES=1 under torchrun: RCCL paths on one GPU)

@@ -394,3 +394,24 @@ def test_bench_prints_the_contract_line():
     assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["unit"] in ("GB/s", "TFLOP/s")
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+
+
+def test_bench_under_the_multi_gpu_launcher_single_rank():
+    """bench.py the way the driver starts it for N > 1 (python -m torch.distributed.run ... bench.py --gpus N), with one rank
+    and SNF_FORCE_COLLECTIVES=1: process group on RCCL, table-parallel feature grids (all-gather / all-to-all in forward and
+    backward), sharded exchange, max-over-ranks timing -- and still exactly one JSON line."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env.update(SNF_FORCE_COLLECTIVES="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    port = str(29900 + os.getpid() % 90)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                          "--master-addr", "127.0.0.1", "--master-port", port, os.path.join(root, "bench.py"),
+                          "--gpus", "1", "--steps", "3", "--warmup", "1", "--cpu-baseline-seconds", "0"],
+                         env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-500:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["roofline"] is not None
+    assert any(k.endswith("tp") for k in d["kernel_ms_per_step_serial"]), "the table-parallel path did not run"
