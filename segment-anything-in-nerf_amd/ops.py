@@ -295,27 +295,25 @@ def render_depth_acc(weights, ebins, want_acc: bool = True):
 # ---------------------------------------------------------------------------------------------
 # hash grid
 # ---------------------------------------------------------------------------------------------
-_RUN_LEVELS: dict = {}
+def _sc_values(sc: torch.Tensor) -> tuple:
+    """The level resolutions as a host tuple: one device read per tensor OBJECT, cached on the object itself (a cache keyed
+    by data_ptr would hand a dead tensor's values to whatever is allocated at its address next)."""
+    v = sc.__dict__.get("_snf_values")
+    if v is None:
+        v = tuple(sc.detach().cpu().tolist())
+        sc.__dict__["_snf_values"] = v
+    return v
 
 
 def hashgrid_run_levels(sc: torch.Tensor) -> int:
     """Leading levels whose backward sums runs of equal rows before sorting (resolution <= HASHGRID_RUN_MAX_RES: cells wide
-    enough that consecutive samples of a ray share them).  Cached per scalings tensor (one host read)."""
-    key = (sc.data_ptr(), int(sc.numel()), HASHGRID_RUN_MAX_RES)
-    if key not in _RUN_LEVELS:
-        _RUN_LEVELS[key] = sum(1 for s in sc.detach().cpu().tolist() if s <= HASHGRID_RUN_MAX_RES)
-    return _RUN_LEVELS[key]
-
-
-_SC_VALUES: dict = {}
+    enough that consecutive samples of a ray share them)."""
+    return sum(1 for s in _sc_values(sc) if s <= HASHGRID_RUN_MAX_RES)
 
 
 def _geometry_key(sc: torch.Tensor, L: int, T: int):
-    """(levels, log2_T, resolutions) -- what a backward sort depends on besides the positions.  One host read per tensor."""
-    k = (sc.data_ptr(), int(sc.numel()))
-    if k not in _SC_VALUES:
-        _SC_VALUES[k] = tuple(sc.detach().cpu().tolist())
-    return (L, T, _SC_VALUES[k])
+    """(levels, log2_T, resolutions) -- what a backward sort depends on besides the positions."""
+    return (L, T, _sc_values(sc))
 
 
 _PRESORT_STREAM = {}
@@ -434,7 +432,6 @@ class _HashGridMulti(torch.autograd.Function):
 
 # -- table parallelism (distributed.py: TableParallelLayout) ------------------------------------------------------------
 TABLE_PARALLEL = _os.environ.get("SNF_TABLE_PARALLEL", "1") == "1"
-_SC_RUNS: dict = {}
 
 
 def table_parallel_layout(specs):
@@ -451,11 +448,12 @@ def table_parallel_layout(specs):
 
 
 def _sc_run(sc: torch.Tensor, l0: int, nl: int) -> torch.Tensor:
-    """scalings[l0 : l0+nl] as a tensor object that lives as long as `sc` (the geometry caches key on data_ptr)."""
-    k = (sc.data_ptr(), l0, nl)
-    if k not in _SC_RUNS:
-        _SC_RUNS[k] = (sc, sc[l0:l0 + nl])
-    return _SC_RUNS[k][1]
+    """scalings[l0 : l0+nl] as ONE tensor object per run (kept on `sc`), so its cached host values are read once."""
+    runs = sc.__dict__.setdefault("_snf_runs", {})
+    r = runs.get((l0, nl))
+    if r is None:
+        r = runs[(l0, nl)] = sc[l0:l0 + nl]
+    return r
 
 
 def tp_gathered_positions(u: torch.Tensor) -> torch.Tensor:
