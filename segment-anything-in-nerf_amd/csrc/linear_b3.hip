@@ -292,6 +292,245 @@ __global__ __launch_bounds__(256) void k_gemm_wgrad_b3(const float* __restrict__
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Weight-stationary variant for the feature-head shapes (K <= 256, tens of thousands of rows): C[M,Nc] = op(A)[M,K] * B.
+// A head layer is 3x-5x above its HBM floor in the tiled kernel above: every 128-row tile re-stages and re-splits the
+// weights, pays two workgroup barriers per 32 k, and every A element is split once per column tile.  Here a workgroup
+// keeps its BN-column slice of the weights in LDS for its whole life (bf16 hi/lo planes [n][k], split once), and the
+// activations never touch LDS: a wave owns 32*RB rows, loads its A fragments straight from global memory in MFMA operand
+// layout (lane (m, half) holds A[m][16s + 8*half .. +8], two dwordx4), splits them in registers and runs 3 MFMAs per
+// (row block, column tile, k-step) against B fragments read with one ds_read_b128 per plane.  No barrier after the
+// prologue; the loop over row tiles is persistent.  The split is the VALU cost that matters (a wave64 VALU instruction
+// occupies its SIMD for 4 cycles): ~6 instructions per pair of elements here, once per BN columns.
+//   BT  : B[k][n] = W[n][k]  (W [Nc,K] row-major: forward)         !BT : B[k][n] = W[k][n]  (W [K,Nc] row-major: data gradient)
+// LDS: 2 planes x BN x (K + 8) bf16 (pitch K + 8 keeps the b128 fragment reads of 16 lanes on distinct banks for K = 192, 256).
+// +-inf inputs give NaN here (lo = inf - inf), where fp32 arithmetic gives +-inf or NaN; NaN inputs propagate as NaN.
+__device__ __forceinline__ void ws_split2(float x0, float x1, uint32_t& hi, uint32_t& lo) {
+    hi = cvt_pk_bf16(x0, x1);
+    lo = cvt_pk_bf16(x0 - __uint_as_float(hi << 16), x1 - __uint_as_float(hi & 0xFFFF0000u));
+}
+
+template <bool BT, bool DERIV, int BN, int RB, int THREADS, int DEPTH>
+__global__ __launch_bounds__(THREADS) void k_gemm_ws_b3(const float* __restrict__ A, const float* __restrict__ Aux,
+                                                        const float* __restrict__ W, const float* __restrict__ bias, int M,
+                                                        int K, int Nc, int lda, int ldaux, int ldw, int ldc, int act_in,
+                                                        int act_out, float* __restrict__ C) {
+    constexpr int NB = BN / 32;
+    constexpr int TILE_ROWS = (THREADS / 64) * 32 * RB;
+    extern __shared__ __attribute__((aligned(16))) uint16_t ws_lds[];
+    const int pitch = K + 8;
+    uint16_t* __restrict__ Bh = ws_lds;
+    uint16_t* __restrict__ Bl = ws_lds + (size_t)BN * pitch;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, half = lane >> 5;
+    const int col0 = blockIdx.y * BN;
+    // ---- prologue: this workgroup's weight slice, split once; loads go out in batches of independent float4 per thread
+    constexpr int PB = 8;
+    if constexpr (BT) {
+        const int kq = K >> 2;  // float4 per row
+        const int total = BN * kq;
+        for (int e0 = tid; e0 < total; e0 += THREADS * PB) {
+            float4 v[PB];
+#pragma unroll
+            for (int u = 0; u < PB; ++u) {
+                const int e = e0 + THREADS * u;
+                const int n = e / kq, k = (e - n * kq) * 4;
+                v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (e < total && col0 + n < Nc) v[u] = *reinterpret_cast<const float4*>(W + (size_t)(col0 + n) * ldw + k);
+            }
+#pragma unroll
+            for (int u = 0; u < PB; ++u) {
+                const int e = e0 + THREADS * u;
+                if (e < total) {
+                    const int n = e / kq, k = (e - n * kq) * 4;
+                    uint2 hi, lo;
+                    split4(v[u], hi, lo);
+                    *reinterpret_cast<uint2*>(&Bh[(size_t)n * pitch + k]) = hi;
+                    *reinterpret_cast<uint2*>(&Bl[(size_t)n * pitch + k]) = lo;
+                }
+            }
+        }
+    } else {
+        constexpr int NQ = BN / 4;  // column quads
+        const int kp = K >> 1;      // k pairs
+        const int total = NQ * kp;
+        for (int e0 = tid; e0 < total; e0 += THREADS * (PB / 2)) {
+            float4 v0[PB / 2], v1[PB / 2];
+#pragma unroll
+            for (int u = 0; u < PB / 2; ++u) {
+                const int e = e0 + THREADS * u;
+                const int q = e % NQ, k = (e / NQ) * 2;
+                v0[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                v1[u] = v0[u];
+                if (e < total && col0 + q * 4 < Nc) {  // Nc % 4 == 0
+                    v0[u] = *reinterpret_cast<const float4*>(W + (size_t)k * ldw + col0 + q * 4);
+                    v1[u] = *reinterpret_cast<const float4*>(W + (size_t)(k + 1) * ldw + col0 + q * 4);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < PB / 2; ++u) {
+                const int e = e0 + THREADS * u;
+                if (e < total) {
+                    const int q = e % NQ, k = (e / NQ) * 2;
+                    const float a0[4] = {v0[u].x, v0[u].y, v0[u].z, v0[u].w}, a1[4] = {v1[u].x, v1[u].y, v1[u].z, v1[u].w};
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        uint32_t h, l;
+                        split2(a0[c], a1[c], h, l);  // (k, k+1) of column n = 4q + c
+                        *reinterpret_cast<uint32_t*>(&Bh[(size_t)(q * 4 + c) * pitch + k]) = h;
+                        *reinterpret_cast<uint32_t*>(&Bl[(size_t)(q * 4 + c) * pitch + k]) = l;
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    float bcol[NB];
+#pragma unroll
+    for (int t = 0; t < NB; ++t) bcol[t] = (bias != nullptr && col0 + 32 * t + li < Nc) ? bias[col0 + 32 * t + li] : 0.f;
+    const int ksteps = K >> 4;
+    const int tiles = (M + TILE_ROWS - 1) / TILE_ROWS;
+    for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const int r0 = tile * TILE_ROWS + wave * 32 * RB;
+        if (r0 >= M) continue;  // wave-uniform; nothing below synchronises
+        // rows of this lane in its row blocks (clamped: out-of-range rows are computed and dropped)
+        const float* __restrict__ pa[RB];
+        const float* __restrict__ ya[RB];
+#pragma unroll
+        for (int b = 0; b < RB; ++b) {
+            const int r = min(r0 + 32 * b + li, M - 1);
+            pa[b] = A + (size_t)r * lda + half * 8;
+            ya[b] = DERIV ? Aux + (size_t)r * ldaux + half * 8 : nullptr;
+        }
+        f32x16 acc[RB][NB];
+#pragma unroll
+        for (int b = 0; b < RB; ++b)
+#pragma unroll
+            for (int t = 0; t < NB; ++t)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[b][t][i] = 0.f;
+        // raw A (and, for the data gradient, the activations whose derivative masks it) of the next D k-steps in flight;
+        // the mask is applied when a fragment is built, so nothing waits on a load before its k-step comes up
+        constexpr int D = DEPTH;
+        float4 raw[D][RB][2], rawy[DERIV ? D : 1][RB][2];
+        const bool masked = DERIV && act_in != SNF_ACT_NONE;
+        auto load8 = [&](int b, int s, int u) {
+            raw[u][b][0] = *reinterpret_cast<const float4*>(pa[b] + s * 16);
+            raw[u][b][1] = *reinterpret_cast<const float4*>(pa[b] + s * 16 + 4);
+            if constexpr (DERIV) {
+                if (masked) {
+                    rawy[u][b][0] = *reinterpret_cast<const float4*>(ya[b] + s * 16);
+                    rawy[u][b][1] = *reinterpret_cast<const float4*>(ya[b] + s * 16 + 4);
+                }
+            }
+        };
+        auto frag = [&](int b, int u, bf16x8& hi, bf16x8& lo) {
+            float4 v0 = raw[u][b][0], v1 = raw[u][b][1];
+            if constexpr (DERIV) {
+                if (masked) {
+                    const float4 y0 = rawy[u][b][0], y1 = rawy[u][b][1];
+                    v0.x *= b3_act_deriv(y0.x, act_in); v0.y *= b3_act_deriv(y0.y, act_in);
+                    v0.z *= b3_act_deriv(y0.z, act_in); v0.w *= b3_act_deriv(y0.w, act_in);
+                    v1.x *= b3_act_deriv(y1.x, act_in); v1.y *= b3_act_deriv(y1.y, act_in);
+                    v1.z *= b3_act_deriv(y1.z, act_in); v1.w *= b3_act_deriv(y1.w, act_in);
+                }
+            }
+            uint32_t h[4], l[4];
+            ws_split2(v0.x, v0.y, h[0], l[0]);
+            ws_split2(v0.z, v0.w, h[1], l[1]);
+            ws_split2(v1.x, v1.y, h[2], l[2]);
+            ws_split2(v1.z, v1.w, h[3], l[3]);
+            hi = __builtin_bit_cast(bf16x8, make_uint4(h[0], h[1], h[2], h[3]));
+            lo = __builtin_bit_cast(bf16x8, make_uint4(l[0], l[1], l[2], l[3]));
+        };
+#pragma unroll
+        for (int u = 0; u < D; ++u) {
+            if (u < ksteps) {
+#pragma unroll
+                for (int b = 0; b < RB; ++b) load8(b, u, u);
+            }
+        }
+        for (int s = 0; s < ksteps; s += D) {
+#pragma unroll
+            for (int u = 0; u < D; ++u) {
+                if (s + u < ksteps) {
+                    bf16x8 ah[RB], al[RB];
+#pragma unroll
+                    for (int b = 0; b < RB; ++b) frag(b, u, ah[b], al[b]);
+                    if (s + u + D < ksteps) {  // refill this buffer D k-steps ahead
+#pragma unroll
+                        for (int b = 0; b < RB; ++b) load8(b, s + u + D, u);
+                    }
+                    const int ko = (s + u) * 16 + half * 8;
+#pragma unroll
+                    for (int t = 0; t < NB; ++t) {
+                        const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&Bh[(size_t)(32 * t + li) * pitch + ko]);
+                        const bf16x8 bl = *reinterpret_cast<const bf16x8*>(&Bl[(size_t)(32 * t + li) * pitch + ko]);
+#pragma unroll
+                        for (int b = 0; b < RB; ++b) acc[b][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[b], bh, acc[b][t], 0, 0, 0);
+#pragma unroll
+                        for (int b = 0; b < RB; ++b) acc[b][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[b], bl, acc[b][t], 0, 0, 0);
+#pragma unroll
+                        for (int b = 0; b < RB; ++b) acc[b][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[b], bh, acc[b][t], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        // epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+        for (int b = 0; b < RB; ++b)
+#pragma unroll
+            for (int t = 0; t < NB; ++t) {
+                const int c = col0 + 32 * t + li;
+                if (c < Nc) {
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        const int row = r0 + 32 * b + (reg & 3) + 8 * (reg >> 2) + 4 * half;
+                        if (row < M) C[(size_t)row * ldc + c] = b3_act_apply(acc[b][t][reg] + bcol[t], act_out);
+                    }
+                }
+            }
+    }
+}
+
+template <bool BT, bool DERIV, int BN, int RB, int THREADS, int DEPTH>
+static void ws_launch(dim3 grid, size_t lds, snf_stream_t stream, const float* A, const float* Aux, const float* W,
+                      const float* bias, int M, int K, int Nc, int lda, int ldaux, int ldw, int ldc, int act_in, int act_out,
+                      float* C) {
+    auto kern = k_gemm_ws_b3<BT, DERIV, BN, RB, THREADS, DEPTH>;
+    static bool attr = false;
+    if (!attr) {
+        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(THREADS), lds, (hipStream_t)stream, A, Aux, W, bias, M, K, Nc, lda, ldaux, ldw, ldc,
+                       act_in, act_out, C);
+}
+
+// takes the launch when the shape fits the weight-stationary kernel (K % 16 == 0, K <= 256, many rows); SNF_GEMM_WS=0 disables
+template <bool BT, bool DERIV>
+static int ws_try(const float* A, const float* Aux, const float* W, const float* bias, int M, int K, int Nc, int lda, int ldaux,
+                  int ldw, int ldc, int act_in, int act_out, float* C, snf_stream_t stream) {
+    static const int on = getenv("SNF_GEMM_WS") ? atoi(getenv("SNF_GEMM_WS")) : 1;
+    if (!on || (K % 16) || K > 256 || K < 64 || M < 4096 || Nc < 64 || (Nc % 4) || (lda % 4)) return 0;
+    // variants: 0 = BN 128, 8 waves x 32 rows, 4 k-steps of loads in flight (default); 1 = BN 64, 4 waves x 64 rows; 2 / 3 = as 0 with 8 / 2 k-steps in flight
+    static const int variant = getenv("SNF_GEMM_WS_VARIANT") ? atoi(getenv("SNF_GEMM_WS_VARIANT")) : 0;
+    const int v = (Nc <= 64) ? 1 : variant;
+    const int bn = v == 1 ? 64 : 128, tile_rows = 256;
+    const size_t lds = (size_t)2 * bn * (K + 8) * sizeof(uint16_t);
+    const int gy = ceil_div(Nc, bn), tiles = ceil_div(M, tile_rows);
+    const int per_cu = lds > 80 * 1024 ? 1 : 2;
+    int gx = (256 * per_cu) / gy;
+    if (gx < 1) gx = 1;
+    if (gx > tiles) gx = tiles;
+    dim3 grid(gx, gy);
+    if (v == 0) ws_launch<BT, DERIV, 128, 1, 512, 4>(grid, lds, stream, A, Aux, W, bias, M, K, Nc, lda, ldaux, ldw, ldc, act_in, act_out, C);
+    else if (v == 1) ws_launch<BT, DERIV, 64, 2, 256, 2>(grid, lds, stream, A, Aux, W, bias, M, K, Nc, lda, ldaux, ldw, ldc, act_in, act_out, C);
+    else if (v == 3) ws_launch<BT, DERIV, 128, 1, 512, 2>(grid, lds, stream, A, Aux, W, bias, M, K, Nc, lda, ldaux, ldw, ldc, act_in, act_out, C);
+    else ws_launch<BT, DERIV, 128, 1, 512, 8>(grid, lds, stream, A, Aux, W, bias, M, K, Nc, lda, ldaux, ldw, ldc, act_in, act_out, C);
+    return 1;
+}
+
 // widest column tile (up to the SNF_B3_BN cap, default 128) that still leaves >= 256 workgroups (one per CU); 64 otherwise
 static int b3_pick_bn(int M, int Nc) {
     static const int cap = getenv("SNF_B3_BN") ? atoi(getenv("SNF_B3_BN")) : 128;
@@ -328,6 +567,7 @@ int snf::b3_try_fwd(const float* X, const float* W, const float* bias, int N, in
                               int act, float* Y, snf_stream_t stream) {
     if (!b3_enabled() || I < 128 || O < 64 || (I % 4) || (O % 4) || (ldx % 4) || ((uintptr_t)X & 15) || ((uintptr_t)W & 15))
         return 0;
+    if (ws_try<true, false>(X, nullptr, W, bias, N, I, O, ldx, 0, I, ldy, SNF_ACT_NONE, act, Y, stream)) return 1;
     const int bn = b3_pick_bn(N, O);
     dim3 grid(ceil_div(N, B3_BM), ceil_div(O, bn));
     const float* none = nullptr;
@@ -354,6 +594,7 @@ int snf::b3_try_bwd_data(const float* dY, const float* Y, const float* W, int N,
     if (!b3_enabled() || O < 128 || I < 64 || (I % 4) || (O % 4) || (lddy % 4) || ((uintptr_t)dY & 15) ||
         ((uintptr_t)W & 15) || (act != SNF_ACT_NONE && ((ldy % 4) || ((uintptr_t)Y & 15))))
         return 0;
+    if (ws_try<false, true>(dY, Y, W, nullptr, N, O, I, lddy, ldy, I, lddx, act, SNF_ACT_NONE, dX, stream)) return 1;
     const int bn = b3_pick_bn(N, I);
     dim3 grid(ceil_div(N, B3_BM), ceil_div(I, bn));
     const float* none = nullptr;

@@ -181,14 +181,17 @@ def test_wide_layers_both_gemm_modes(mode):
     gen = torch.Generator().manual_seed(21)
     ops().set_gemm_mode(mode)
     try:
-        for (N, I, Oo, act) in [(5000, 192, 256, "relu"), (4099, 256, 256, None), (777, 256, 192, None)]:
+        # rows >= 4096 with K <= 256 take the weight-stationary kernel (ragged row tile, 192 = 1.5 column slices, bias)
+        for (N, I, Oo, act, has_b) in [(5000, 192, 256, "relu", False), (4099, 256, 256, None, False),
+                                       (4500, 256, 192, "relu", True), (777, 256, 192, None, False)]:
             x = torch.randn((N, I), generator=gen) * 0.05
             w = O._linear_init(Oo, I, gen)
+            b = torch.randn((Oo,), generator=gen) * 0.1 if has_b else None
             gy = torch.randn((N, Oo), generator=gen)
             xg, wg = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
-            yg = ops().linear(xg, wg, None, ops().ACT_BY_NAME[act])
+            yg = ops().linear(xg, wg, None if b is None else b.to(DEV), ops().ACT_BY_NAME[act])
             xc, wc = x.double().requires_grad_(True), w.double().requires_grad_(True)
-            yc = torch.nn.functional.linear(xc, wc)
+            yc = torch.nn.functional.linear(xc, wc, None if b is None else b.double())
             if act == "relu":
                 # pre-activations within round-off of zero may land on either side: take the ReLU mask from the
                 # kernel's own output so that the gradient check measures arithmetic, not mask flips
