@@ -100,6 +100,19 @@ int snf_hashgrid_bwd_presorted(const float* grad_out, int N, int L, int F, int l
                                int n_run_levels, float* grad_table, const void* sorted_workspace, float* stage,
                                snf_stream_t stream);
 
+/* snf_hashgrid_bwd_presorted with the optimizer step folded into its reduce pass for the levels >= fuse_from_level: the
+ * workgroup that owns a bucket of rows holds their complete gradient after its last chunk and applies
+ * torch.optim.Adam's update (the arithmetic of snf_adam_step: eps outside the bias-corrected sqrt, gradient pre-scaled by
+ * grad_scale) to param / exp_avg / exp_avg_sq of those rows -- 24 B per parameter instead of 8 B (gradient
+ * read-modify-write) + 32 B (snf_adam_step).  grad_table is left all-zero on those levels.  Replaces, for the hash tables,
+ * torch.optim.Adam.step of nerfstudio/engine/optimizers.py:131-147.  Only valid when this call carries the table's whole
+ * gradient of the step (one backward per step; one rank, or levels owned by this rank).  Levels < fuse_from_level behave as
+ * in snf_hashgrid_bwd_presorted (the caller steps them, e.g. with snf_adam_step_rows). */
+int snf_hashgrid_bwd_presorted_adam(const float* grad_out, int N, int L, int F, int log2_T, int ld_out, int col_off,
+                                    int n_run_levels, float* grad_table, const void* sorted_workspace, float* stage,
+                                    int fuse_from_level, float* param, float* exp_avg, float* exp_avg_sq, float lr,
+                                    float beta1, float beta2, float eps, int step, float grad_scale, snf_stream_t stream);
+
 /* Arithmetic of the wide (>= 128 input) dense layers: 1 (default) = bf16 3-term split on the bf16 matrix cores with fp32
  * accumulate (max abs error ~1e-6 on head-shaped data, 1/5 of the matrix cycles), 0 = exact fp32 matrix cores.
  * Process-wide; narrow layers always run exact fp32. */

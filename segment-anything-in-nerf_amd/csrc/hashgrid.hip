@@ -10,6 +10,7 @@
 // Launch: grid = (ceil(N/256), L): blockIdx.y is the level, so a workgroup (and its neighbours in x)
 // gather from ONE level slab; a thread owns one (sample, level) pair and keeps all 8 corner loads in flight.
 #include "common.hpp"
+#include <math.h>
 #include <stdlib.h>
 
 namespace snf {
@@ -424,11 +425,31 @@ __device__ __forceinline__ void row_rmw(float* __restrict__ dst, const float (&a
 //   3. the record payloads w*g are written to their row-sorted slots of an LDS staging array;
 //   4. owner threads sum their rows' (short) segments from LDS into registers, waves sum the long ones with a shuffle
 //      reduction; each row is added to the gradient table by exactly one lane with a plain read-modify-write.
-template <int F>
+// ADAM = true: for the levels >= adam.from_level the reduce pass IS the optimizer step.  A workgroup owns its bucket's rows
+// and, after the last chunk, holds their complete gradient in registers, so it reads p / exp_avg / exp_avg_sq of those
+// rows, applies torch.optim.Adam's update (optim.hip: adam1) and writes them back: 24 B per parameter instead of the
+// 8 B gradient read-modify-write here plus the 32 B of the separate Adam pass (which also re-zeroes the gradient).
+// Valid when this launch sees the whole gradient of the table: one backward per step, gradients not exchanged between
+// ranks (one rank, or table-parallel levels).  Buckets nothing landed in are still visited (m and v decay, p moves).
+struct HgAdam {
+    float *p, *m, *v;
+    float b1, b2, step_size, inv_sqrt_bc2, eps, gs;
+    int from_level;
+};
+
+__device__ __forceinline__ void hg_adam1(float& p, float g, float& m, float& v, const HgAdam& a) {  // == optim.hip adam1
+    const float gg = g * a.gs;
+    m = m + (gg - m) * (1.f - a.b1);
+    v = v * a.b2 + (1.f - a.b2) * gg * gg;
+    const float denom = sqrtf(v) * a.inv_sqrt_bc2 + a.eps;
+    p = p - a.step_size * (m / denom);
+}
+
+template <int F, bool ADAM>
 __global__ __launch_bounds__(HG_RT) void k_hg_reduce(const float* __restrict__ gT, int N, int log2_T, int log2B,
                                                      const uint32_t* __restrict__ bucket_start,
                                                      const uint2* __restrict__ records, float* __restrict__ grad_table,
-                                                     uint32_t hg_long, int n_run_levels) {
+                                                     uint32_t hg_long, int n_run_levels, HgAdam adam) {
     constexpr int CHUNK = hg_chunk<F>();
     constexpr int RPT = CHUNK / HG_RT;
     __shared__ uint32_t cnt[HG_MAX_RPB + 1];  // per-row counts, then exclusive offsets
@@ -441,7 +462,9 @@ __global__ __launch_bounds__(HG_RT) void k_hg_reduce(const float* __restrict__ g
     const int tid = threadIdx.x, b = blockIdx.x, l = blockIdx.y;
     const int lane = tid & 63, wave = tid >> 6;
     const uint32_t start = bucket_start[l * (B + 1) + b], end = bucket_start[l * (B + 1) + b + 1];
-    if (start == end) return;  // nothing lands in this bucket: leave the slab untouched
+    const bool fuse = ADAM && l >= adam.from_level;
+    if (start == end && !fuse) return;  // nothing lands in this bucket: leave the slab untouched
+    bool any_long = false;
     float* __restrict__ slab = grad_table + (((size_t)l << log2_T) + ((size_t)b << log2rpb)) * F;
     const float* __restrict__ gl = gT + (size_t)l * N * F;
     if (hg_long < 8u) hg_long = 8u;  // capacity of long_rows
@@ -578,6 +601,7 @@ __global__ __launch_bounds__(HG_RT) void k_hg_reduce(const float* __restrict__ g
         }
         // ---- phase 4b: long segments, one wave per row
         const uint32_t nl = n_long;
+        any_long |= nl > 0u;
         for (uint32_t q = wave; q < nl; q += HG_RT / 64) {
             const uint32_t r = long_rows[q];
             const uint32_t e0 = cnt[r], e1 = cnt[r + 1];
@@ -611,6 +635,64 @@ __global__ __launch_bounds__(HG_RT) void k_hg_reduce(const float* __restrict__ g
                 gather(rec, g);
             }
             __syncthreads();
+        }
+    }
+    if constexpr (ADAM) {
+        if (fuse) {
+            // ---- fused optimizer epilogue: every owned row, two rows (6 row loads) in flight per thread
+            const size_t base = (((size_t)l << log2_T) + ((size_t)b << log2rpb)) * F;
+#pragma unroll
+            for (int q0 = 0; q0 < HG_ROWS_PT; q0 += 2) {
+                float pp[2][F], mm[2][F], vv[2][F], gg[2][F];
+                bool on[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int r = tid + (q0 + j) * HG_RT;
+                    on[j] = r < rpb;
+                    if (on[j]) {
+                        const size_t o = base + (size_t)r * F;
+                        load_row<F>(adam.p + o, pp[j]);
+                        load_row<F>(adam.m + o, mm[j]);
+                        load_row<F>(adam.v + o, vv[j]);
+                        if (any_long) load_row<F>(slab + (size_t)r * F, gg[j]);  // wave sums of long segments went there
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if (on[j]) {
+                        const int r = tid + (q0 + j) * HG_RT;
+                        const size_t o = base + (size_t)r * F;
+                        bool had = false;
+#pragma unroll
+                        for (int f = 0; f < F; ++f) {
+                            float g = racc[q0 + j][f];
+                            if (any_long) {
+                                had |= gg[j][f] != 0.f;
+                                g = gg[j][f] + g;
+                            }
+                            hg_adam1(pp[j][f], g, mm[j][f], vv[j][f], adam);
+                        }
+                        if constexpr (F == 8) {
+                            reinterpret_cast<float4*>(adam.p + o)[0] = make_float4(pp[j][0], pp[j][1], pp[j][2], pp[j][3]);
+                            reinterpret_cast<float4*>(adam.p + o)[1] = make_float4(pp[j][4], pp[j][5], pp[j][6], pp[j][7]);
+                            reinterpret_cast<float4*>(adam.m + o)[0] = make_float4(mm[j][0], mm[j][1], mm[j][2], mm[j][3]);
+                            reinterpret_cast<float4*>(adam.m + o)[1] = make_float4(mm[j][4], mm[j][5], mm[j][6], mm[j][7]);
+                            reinterpret_cast<float4*>(adam.v + o)[0] = make_float4(vv[j][0], vv[j][1], vv[j][2], vv[j][3]);
+                            reinterpret_cast<float4*>(adam.v + o)[1] = make_float4(vv[j][4], vv[j][5], vv[j][6], vv[j][7]);
+                            if (had) {
+                                reinterpret_cast<float4*>(slab + (size_t)r * F)[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+                                reinterpret_cast<float4*>(slab + (size_t)r * F)[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+                            }
+                        } else {
+                            *reinterpret_cast<float2*>(adam.p + o) = make_float2(pp[j][0], pp[j][1]);
+                            *reinterpret_cast<float2*>(adam.m + o) = make_float2(mm[j][0], mm[j][1]);
+                            *reinterpret_cast<float2*>(adam.v + o) = make_float2(vv[j][0], vv[j][1]);
+                            if (had) *reinterpret_cast<float2*>(slab + (size_t)r * F) = make_float2(0.f, 0.f);
+                        }
+                    }
+                }
+            }
+            return;
         }
     }
     // ---- epilogue: one read-modify-write per owned row that received something; the loads issue together
@@ -778,14 +860,53 @@ extern "C" int snf_hashgrid_bwd_presorted(const float* grad_out, int N, int L, i
     const int tblocks = ceil_div((long long)N * L, 256);
     if (F == 2) {
         hipLaunchKernelGGL(k_hg_stage_grad<2>, dim3(tblocks), dim3(256), 0, st, grad_out, N, L, ld_out, col_off, stage);
-        hipLaunchKernelGGL(k_hg_reduce<2>, dim3(B, L), dim3(HG_RT), 0, st, stage, N, log2_T, g.log2B, w.bstart,
-                           (const uint2*)w.records, grad_table, hg_long, n_run_levels);
+        hipLaunchKernelGGL((k_hg_reduce<2, false>), dim3(B, L), dim3(HG_RT), 0, st, stage, N, log2_T, g.log2B, w.bstart,
+                           (const uint2*)w.records, grad_table, hg_long, n_run_levels, HgAdam{});
     } else {
         hipLaunchKernelGGL(k_hg_stage_grad<8>, dim3(tblocks), dim3(256), 0, st, grad_out, N, L, ld_out, col_off, stage);
-        hipLaunchKernelGGL(k_hg_reduce<8>, dim3(B, L), dim3(HG_RT), 0, st, stage, N, log2_T, g.log2B, w.bstart,
-                           (const uint2*)w.records, grad_table, hg_long, n_run_levels);
+        hipLaunchKernelGGL((k_hg_reduce<8, false>), dim3(B, L), dim3(HG_RT), 0, st, stage, N, log2_T, g.log2B, w.bstart,
+                           (const uint2*)w.records, grad_table, hg_long, n_run_levels, HgAdam{});
     }
     SNF_LAUNCH_CHECK("snf_hashgrid_bwd_presorted");
+    return SNF_OK;
+}
+
+extern "C" int snf_hashgrid_bwd_presorted_adam(const float* grad_out, int N, int L, int F, int log2_T, int ld_out, int col_off,
+                                               int n_run_levels, float* grad_table, const void* sorted_workspace, float* stage,
+                                               int fuse_from_level, float* param, float* exp_avg, float* exp_avg_sq, float lr,
+                                               float beta1, float beta2, float eps, int step, float grad_scale,
+                                               snf_stream_t stream) {
+    SNF_REQUIRE(grad_out && grad_table && sorted_workspace && stage && param && exp_avg && exp_avg_sq,
+                "snf_hashgrid_bwd_presorted_adam: null pointer");
+    SNF_REQUIRE(F == 2 || F == 8, "snf_hashgrid_bwd_presorted_adam: features_per_level must be 2 or 8 (got %d)", F);
+    SNF_REQUIRE(N > 0 && L > 0 && N <= (1 << HG_SAMPLE_BITS) && ld_out >= col_off + L * F && col_off >= 0,
+                "snf_hashgrid_bwd_presorted_adam: bad shape N=%d L=%d ld_out=%d col_off=%d", N, L, ld_out, col_off);
+    SNF_REQUIRE(fuse_from_level >= 0 && fuse_from_level <= L && step >= 1,
+                "snf_hashgrid_bwd_presorted_adam: bad fuse_from_level=%d (L=%d) or step=%d", fuse_from_level, L, step);
+    SNF_REQUIRE((((uintptr_t)grad_out | (uintptr_t)grad_table | (uintptr_t)stage | (uintptr_t)param | (uintptr_t)exp_avg |
+                  (uintptr_t)exp_avg_sq) & 15) == 0, "snf_hashgrid_bwd_presorted_adam: unaligned pointer");
+    const HgGeom g = hg_geometry(N, log2_T);
+    const HgWs w = hg_ws_layout(const_cast<void*>(sorted_workspace), N, L, g);
+    const int B = 1 << g.log2B;
+    hipStream_t st = (hipStream_t)stream;
+    const char* e_long = getenv("SNF_HG_LONG");
+    const uint32_t hg_long = e_long ? (uint32_t)atoi(e_long) : (uint32_t)HG_LONG;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    HgAdam a;
+    a.p = param; a.m = exp_avg; a.v = exp_avg_sq;
+    a.b1 = beta1; a.b2 = beta2; a.step_size = (float)((double)lr / bc1); a.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+    a.eps = eps; a.gs = grad_scale; a.from_level = fuse_from_level;
+    const int tblocks = ceil_div((long long)N * L, 256);
+    if (F == 2) {
+        hipLaunchKernelGGL(k_hg_stage_grad<2>, dim3(tblocks), dim3(256), 0, st, grad_out, N, L, ld_out, col_off, stage);
+        hipLaunchKernelGGL((k_hg_reduce<2, true>), dim3(B, L), dim3(HG_RT), 0, st, stage, N, log2_T, g.log2B, w.bstart,
+                           (const uint2*)w.records, grad_table, hg_long, n_run_levels, a);
+    } else {
+        hipLaunchKernelGGL(k_hg_stage_grad<8>, dim3(tblocks), dim3(256), 0, st, grad_out, N, L, ld_out, col_off, stage);
+        hipLaunchKernelGGL((k_hg_reduce<8, true>), dim3(B, L), dim3(HG_RT), 0, st, stage, N, log2_T, g.log2B, w.bstart,
+                           (const uint2*)w.records, grad_table, hg_long, n_run_levels, a);
+    }
+    SNF_LAUNCH_CHECK("snf_hashgrid_bwd_presorted_adam");
     return SNF_OK;
 }
 

@@ -56,6 +56,8 @@ class Optimizers:
         self.enabled = True
         # Adam skips hash-table rows no input can ever address (exact: their g = m = v stay 0); SNF_ADAM_ALL_ROWS=1 disables
         self.skip_unreachable_rows = os.environ.get("SNF_ADAM_ALL_ROWS", "0") != "1"
+        # the hash-grid backward of a table IS its Adam step where it sees the table's whole gradient (see arm_fused_adam)
+        self.fuse_table_adam = os.environ.get("SNF_FUSED_TABLE_ADAM", "1") == "1"
         self._plans: Dict[str, list] = {}
         self._row_cuts: Dict[tuple, tuple] = {}
         self._tp_cache: Dict[str, list] = {}
@@ -98,6 +100,47 @@ class Optimizers:
         ops.adam_step_(a.param[lo:hi], a.grad[lo:hi], a.exp_avg[lo:hi], a.exp_avg_sq[lo:hi], self.lr(k), oc.betas[0],
                        oc.betas[1], oc.eps, self.step_count[k], grad_scale, zero_grad)
 
+    # -- optimizer step folded into the hash-grid backward ---------------------------------------------------------------
+    def arm_fused_adam(self) -> None:
+        """Start of a train step: hand every hash table whose backward will see its WHOLE gradient (one rank, or
+        table-parallel levels owned by this rank) Adam's hyper-parameters of this step.  ops._hashgrid_bwd_launch then
+        applies the update inside the reduce pass of the backward for the dense levels (24 B per parameter instead of the
+        gradient read-modify-write + the 32 B Adam pass) and reports the stepped levels; exchange_and_step skips them.
+        The coarse reachable-row levels keep their own small launch."""
+        from . import distributed as D
+        for k, a in self.arenas.items():
+            oc = self.config[k]["optimizer"]
+            owned = {t[0] for t in self._tp_tables(k)}
+            for pname, (off, shape) in a.offsets.items():
+                enc = a.tables.get(pname)
+                if enc is None:
+                    continue
+                ok = (self.enabled and self.fuse_table_adam and a.param.is_cuda
+                      and (not D.collectives_on() or off in owned))
+                if not ok:
+                    enc.params._fused_adam = None
+                    continue
+                n, stride = enc.params.numel(), (1 << enc.log2_hashmap_size) * enc.n_features_per_level
+                n_sparse = next(((seg[2] - off) // stride for seg in self._plan(k) if seg[0] == "rows" and seg[1] == off), 0)
+                enc.params._fused_adam = ops.FusedAdam(
+                    a.param[off:off + n], a.exp_avg[off:off + n], a.exp_avg_sq[off:off + n], self.lr(k), oc.betas[0],
+                    oc.betas[1], oc.eps, self.step_count[k] + 1, 1.0 / D.world_size(), n_sparse)
+
+    def _take_fused(self, k: str, lo: int, hi: int, t: int) -> list:
+        """Arena element ranges of group `k` inside [lo, hi) that this step's backward has already stepped."""
+        a, out = self.arenas[k], []
+        for pname, (off, shape) in a.offsets.items():
+            enc = a.tables.get(pname)
+            fa = getattr(enc.params, "_fused_adam", None) if enc is not None else None
+            if fa is None or fa.done is None or off >= hi or off + enc.params.numel() <= lo:
+                continue
+            if fa.step != t:
+                raise RuntimeError(f"hash table {k}/{pname} was stepped by its backward for step {fa.step}, optimizer is at {t}")
+            stride = (1 << enc.log2_hashmap_size) * enc.n_features_per_level
+            out.append((off + fa.done[0] * stride, off + fa.done[1] * stride))
+            fa.done = None
+        return out
+
     # -- data-parallel exchange + step (distributed.sharded_step) ---------------------------------------------------
     def exchange_and_step(self, k: str, first: Optional[int] = None, last: Optional[int] = None, count_step: bool = True,
                           extra: Optional[List[str]] = None) -> None:
@@ -119,8 +162,9 @@ class Optimizers:
             self.step_count[k] += 1
         scale, lr, t = 1.0 / D.world_size(), self.lr(k), self.step_count[k]
         b1, b2, eps = oc.betas[0], oc.betas[1], oc.eps
+        done = self._take_fused(k, lo, hi, t)
         if not D.collectives_on():
-            self._adam_range(k, lo, hi, lr, b1, b2, eps, t, scale)
+            self._adam_range(k, lo, hi, lr, b1, b2, eps, t, scale, done)
             return
         # data-parallel: walk the plan.  Dense segments: sharded exchange + step (or all-reduce + replicated step);
         # row segments (reachable rows of coarse hash levels): only those rows travel, and every rank steps them.
@@ -135,7 +179,7 @@ class Optimizers:
                 # owns, nothing else was touched -- step the owned levels, no exchange
                 x0, x1 = max(s0, tp[2]), min(s1, tp[3])
                 if x1 > x0:
-                    self._adam_range(k, x0, x1, lr, b1, b2, eps, t, scale)
+                    self._adam_range(k, x0, x1, lr, b1, b2, eps, t, scale, done)
                 continue
             if seg[0] == "dense":
                 def step_fn(x0: int, x1: int, s0=s0) -> None:
@@ -227,16 +271,21 @@ class Optimizers:
         self._tp_cache[k] = out
         return out
 
-    def _adam_range(self, k: str, lo: int, hi: int, lr, b1, b2, eps, t, scale) -> None:
-        """Fused Adam (+ gradient re-zeroing) on the arena elements [lo, hi) of group `k`, following the plan."""
+    def _adam_range(self, k: str, lo: int, hi: int, lr, b1, b2, eps, t, scale, done=()) -> None:
+        """Fused Adam (+ gradient re-zeroing) on the arena elements [lo, hi) of group `k`, following the plan and leaving out
+        the ranges in `done` (already stepped by the hash-grid backward)."""
         a = self.arenas[k]
         for seg in self._plan(k):
             s0, s1 = max(lo, seg[1]), min(hi, seg[2])
             if s1 <= s0:
                 continue
             if seg[0] == "dense":
-                ops.adam_step_(a.param[s0:s1], a.grad[s0:s1], a.exp_avg[s0:s1], a.exp_avg_sq[s0:s1], lr, b1, b2, eps, t,
-                               scale, True)
+                pieces = [(s0, s1)]
+                for d0, d1 in done:
+                    pieces = [q for x0, x1 in pieces for q in ((x0, min(x1, d0)), (max(x0, d1), x1)) if q[1] > q[0]]
+                for x0, x1 in pieces:
+                    ops.adam_step_(a.param[x0:x1], a.grad[x0:x1], a.exp_avg[x0:x1], a.exp_avg_sq[x0:x1], lr, b1, b2, eps, t,
+                                   scale, True)
             else:
                 offsets, F = seg[3], seg[4]
                 i0, i1 = self._cut(k, seg, s0, s1)  # rows are sorted: the slice of the list inside [s0, s1)

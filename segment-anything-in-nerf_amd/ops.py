@@ -355,10 +355,33 @@ def hashgrid_presort(u: torch.Tensor, sc: torch.Tensor, L: int, T: int, side_str
 HASHGRID_BWD_MAX_SAMPLES = 1 << 21  # per launch of the sorted backward (21 sample bits in a record)
 
 
-def _hashgrid_bwd_launch(u, g, sc, N, L, F, T, ld, col, buf) -> None:
+class FusedAdam:
+    """What the hash-grid backward needs to BE the optimizer step of a table (snf_hashgrid_bwd_presorted_adam): the flat
+    param / exp_avg / exp_avg_sq views of the table, Adam's hyper-parameters for this step and the first level to fuse (the
+    coarse levels before it keep the reachable-row Adam launch).  engine.Optimizers arms a table with one of these per step;
+    `done` reports back which levels the backward has stepped."""
+    __slots__ = ("p", "m", "v", "lr", "b1", "b2", "eps", "step", "scale", "from_level", "done")
+
+    def __init__(self, p, m, v, lr, b1, b2, eps, step, scale, from_level):
+        self.p, self.m, self.v = p, m, v
+        self.lr, self.b1, self.b2, self.eps, self.step, self.scale = lr, b1, b2, eps, step, scale
+        self.from_level = from_level
+        self.done = None  # (first level, end level) stepped by the backward
+
+    def levels(self, l0: int, nl: int, T: int, F: int):
+        """The same for the level sub-range [l0, l0+nl) of the table (table-parallel runs)."""
+        a, b = (l0 << T) * F, ((l0 + nl) << T) * F
+        sub = FusedAdam(self.p[a:b], self.m[a:b], self.v[a:b], self.lr, self.b1, self.b2, self.eps, self.step, self.scale,
+                        min(max(self.from_level - l0, 0), nl))
+        return sub
+
+
+def _hashgrid_bwd_launch(u, g, sc, N, L, F, T, ld, col, buf, adam: Optional[FusedAdam] = None) -> bool:
+    """Table-gradient backward of one grid (or level run).  Returns True when `adam` was given and the launch stepped the
+    levels >= adam.from_level itself (only the presorted single-launch path can)."""
     if HASHGRID_BWD_MODE == "atomic":
         _launch("snf_hashgrid_bwd", _p(u), _p(g), _p(sc), N, L, F, T, ld, col, _p(buf), _stream(), tag=f"F{F}L{L}")
-        return
+        return False
     # run aggregation pays for the ray-ordered F = 2 grids (field grid -8 %); the top-K-ordered F = 8 feature grids have
     # shorter runs and 4x the shuffle work per record (+20 % measured), so they keep the plain reduce
     nrun = hashgrid_run_levels(sc) if F == 2 else 0
@@ -371,9 +394,16 @@ def _hashgrid_bwd_launch(u, g, sc, N, L, F, T, ld, col, buf) -> None:
                 torch.cuda.current_stream().wait_event(ev)
                 ws.record_stream(torch.cuda.current_stream())
             stage = torch.empty((L * N * F,), device=g.device, dtype=torch.float32)
+            if adam is not None and adam.from_level < L:
+                fused = ((L - adam.from_level) << T) * F
+                _launch("snf_hashgrid_bwd_presorted_adam", _p(g), N, L, F, T, ld, col, nrun, _p(buf), _p(ws), _p(stage),
+                        adam.from_level, _p(adam.p), _p(adam.m), _p(adam.v), float(adam.lr), float(adam.b1), float(adam.b2),
+                        float(adam.eps), int(adam.step), float(adam.scale), _stream(), tag=f"F{F}L{L}",
+                        units=float(N) * L * 8 * F * 4 * 2 + 24.0 * fused)
+                return True
             _launch("snf_hashgrid_bwd_presorted", _p(g), N, L, F, T, ld, col, nrun, _p(buf), _p(ws), _p(stage), _stream(),
                     tag=f"F{F}L{L}")
-            return
+            return False
     # batches beyond 2^21 samples (or 2^32 records) go through in slices: the gradient table accumulates
     per = min(HASHGRID_BWD_MAX_SAMPLES, ((1 << 32) - 1) // (8 * L))
     ws = None
@@ -384,6 +414,7 @@ def _hashgrid_bwd_launch(u, g, sc, N, L, F, T, ld, col, buf) -> None:
             ws = torch.empty(((nbytes + 3) // 4,), device=g.device, dtype=torch.int32)
         _launch("snf_hashgrid_bwd_sorted_ex", ctypes.c_void_p(u.data_ptr() + n0 * 3 * 4), ctypes.c_void_p(g.data_ptr() + n0 * ld * 4),
                 _p(sc), n, L, F, T, ld, col, nrun, _p(buf), _p(ws), nbytes, _stream(), tag=f"F{F}L{L}")
+    return False
 
 
 class _HashGridMulti(torch.autograd.Function):
@@ -424,7 +455,9 @@ class _HashGridMulti(torch.autograd.Function):
                 grads.append(None)
             else:
                 buf, fused = _grad_target(tab)
-                _hashgrid_bwd_launch(u, g, sc, N, L, F, T, total, col, buf)
+                adam = getattr(tab, "_fused_adam", None) if fused else None
+                if _hashgrid_bwd_launch(u, g, sc, N, L, F, T, total, col, buf, adam):
+                    adam.done = (adam.from_level, L)
                 grads.append(None if fused else buf)
             col += L * F
         return (None, None, *grads)
@@ -501,8 +534,11 @@ def tp_accumulate(U: torch.Tensor, G: torch.Tensor, specs, tables, layout, rank:
         if not tab.requires_grad:
             continue
         buf, fused = _grad_target(tab)
-        _hashgrid_bwd_launch(U, G, _sc_run(sc, l0, nl), U.shape[0], nl, F, T, layout.width, col,
-                             buf.view(-1)[(l0 << T) * F:((l0 + nl) << T) * F])
+        adam = getattr(tab, "_fused_adam", None) if fused else None
+        sub = adam.levels(l0, nl, T, F) if adam is not None else None
+        if _hashgrid_bwd_launch(U, G, _sc_run(sc, l0, nl), U.shape[0], nl, F, T, layout.width, col,
+                                buf.view(-1)[(l0 << T) * F:((l0 + nl) << T) * F], sub):
+            adam.done = (l0 + sub.from_level, l0 + nl)
         tab._tp_stale = True  # the other ranks' copies of these levels are behind once Adam has run
         if not fused:
             grads[gi] = buf  # no arena: autograd gets the full-size gradient (zero outside the owned levels)

@@ -182,6 +182,7 @@ class Trainer:
         for cb in self.callbacks:
             cb.run_callback_at_location(step, BEFORE_TRAIN_ITERATION)
         opt, scale = self.optimizers, 1.0 / D.world_size()
+        opt.arm_fused_adam()
         model = self.pipeline.model
         use_side = self.overlap and torch.cuda.is_available() and "sam_field" in opt.arenas
         if use_side and self._side is None:

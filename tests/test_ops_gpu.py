@@ -541,3 +541,51 @@ def test_table_parallel_level_runs_match_the_replicated_grids(world):
     for gi in range(2):
         scale = float(ref[gi].abs().max())
         assert float((got[gi] - ref[gi]).abs().max()) <= 1e-5 * scale
+
+
+@pytest.mark.parametrize("from_level,N", [(0, 70000), (2, 70000), (3, 5000)])
+def test_hashgrid_backward_with_fused_adam_matches_backward_then_adam(from_level, N):
+    """snf_hashgrid_bwd_presorted_adam (the reduce pass applies Adam to the levels >= from_level) against the plain sorted
+    backward followed by snf_adam_step on the same levels: parameters, both moments, and the gradient buffer (zero on the
+    fused levels, the gradient itself below).  N = 70000 at resolution 16 gives long same-row segments (wave-summed rows)."""
+    m = ops()
+    T, F, L = 14, 8, 6
+    sc = O.hash_scalings(L, 16, 256).cuda()
+    specs = ((sc, L, F, T),)
+    gen = torch.Generator(device="cuda").manual_seed(7)
+    n = (L << T) * F
+    p0 = torch.rand((n,), device="cuda", generator=gen) - 0.5
+    m0 = (torch.rand((n,), device="cuda", generator=gen) - 0.5) * 1e-3
+    v0 = torch.rand((n,), device="cuda", generator=gen) * 1e-6
+    u = torch.rand((N, 3), device="cuda", generator=gen)
+    gy = torch.randn((N, L * F), device="cuda", generator=gen) * 1e-2
+    hyper = dict(lr=1e-2, b1=0.9, b2=0.999, eps=1e-15, step=3, scale=0.5)
+    out = {}
+    for fused in (False, True):
+        p, mm, vv = p0.clone(), m0.clone(), v0.clone()
+        tab = p.requires_grad_(True)
+        tab.main_grad = torch.zeros_like(p0)
+        uu = u.clone()
+        m.hashgrid_presort(uu, sc, L, T)
+        if fused:
+            tab._fused_adam = m.FusedAdam(p.detach(), mm, vv, hyper["lr"], hyper["b1"], hyper["b2"], hyper["eps"], hyper["step"],
+                                          hyper["scale"], from_level)
+        m.hashgrid(uu, [tab], specs).backward(gy)
+        a = (from_level << T) * F
+        if fused:
+            assert tab._fused_adam.done == (from_level, L)
+        else:
+            with torch.no_grad():
+                m.adam_step_(p.detach()[a:], tab.main_grad[a:], mm[a:], vv[a:], hyper["lr"], hyper["b1"], hyper["b2"], hyper["eps"],
+                             hyper["step"], hyper["scale"], True)
+        out[fused] = (p.detach().clone(), mm.clone(), vv.clone(), tab.main_grad.clone())
+    a = (from_level << T) * F
+    assert float(out[True][3][a:].abs().max()) == 0.0 and float(out[False][3][a:].abs().max()) == 0.0
+    if a:  # unfused levels: the gradient is left for the caller (fp32 summation order differs from run to run)
+        scale = float(out[False][3][:a].abs().max())
+        assert scale > 0 and float((out[True][3][:a] - out[False][3][:a]).abs().max()) <= 1e-5 * scale
+    assert torch.equal(out[True][0][:a], p0[:a])                      # ... and their parameters are untouched
+    assert float((out[False][0] - p0).abs().max()) > 1e-3             # the step moved something
+    for i, tol in ((0, 2e-6), (1, 1e-6), (2, 1e-6)):
+        ref, got = out[False][i], out[True][i]
+        assert float((got - ref).abs().max()) <= tol * max(1e-3, float(ref.abs().max())), i
