@@ -45,7 +45,9 @@ def algorithmic_model(key: str, w: dict):
     R, P, S, K = w["R"], w["P"], w["S"], w["K"]
     name, _, tag = key.partition("/")
     if name in ("snf_hashgrid_fwd", "snf_hashgrid_bwd", "snf_hashgrid_bwd_sorted", "snf_hashgrid_bwd_sorted_ex",
-                "snf_hashgrid_bwd_presorted"):
+                "snf_hashgrid_bwd_presorted", "snf_hashgrid_bwd_presorted_adam"):
+        # (the fused backward + Adam reports its own bytes per launch -- ops._hashgrid_bwd_launch: the corner
+        # contributions as below plus 24 B per parameter of the fused levels -- and roof() prefers those)
         m = re.fullmatch(r"F(\d+)L(\d+)(tp)?", tag)
         if m is None:
             return None, None, None
@@ -196,7 +198,7 @@ def main():
     # several kernels counts with the share of its largest one: the bucketed hash-grid backward is stage/count/scan/scatter/
     # reduce, k_hg_reduce being ~60 % of it (profiles/*_kernel_stats.csv).
     largest_kernel_share = {"snf_hashgrid_bwd_sorted": 0.6, "snf_hashgrid_bwd_sorted_ex": 0.6,
-                            "snf_hashgrid_bwd_presorted": 0.9}
+                            "snf_hashgrid_bwd_presorted": 0.9, "snf_hashgrid_bwd_presorted_adam": 0.95}
     dom = args.roofline_kernel
     if dom is None and per_step:
         modelled = [k for k in per_step if model_of(k)[1]]
@@ -248,7 +250,8 @@ def main():
             """achieved = algorithmic units of all timed launches / their summed HIP-event duration."""
             bound, units, unit = model_of(key)
             nl, total_ms = stat["launches"], stat["total_ms"]
-            total_units = stat["units"] if key == "snf_adam_step" else units * nl  # Adam: bytes of the actual launches
+            # Adam and the fused backward + Adam: bytes of the actual launches (reported by the launch sites)
+            total_units = stat["units"] if stat.get("units", 0) > 0 else units * nl
             achieved = total_units / (total_ms * 1e-3) / (1e9 if bound == "hbm" else 1e12)
             peak = HBM_PEAK_GBPS if bound == "hbm" else FP32_MATRIX_PEAK_TFLOPS
             return {"kernel": key, "bound": bound, "achieved": round(achieved, 2), "peak": peak, "unit": unit,

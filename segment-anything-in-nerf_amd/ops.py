@@ -399,7 +399,9 @@ def _hashgrid_bwd_launch(u, g, sc, N, L, F, T, ld, col, buf, adam: Optional[Fuse
                 _launch("snf_hashgrid_bwd_presorted_adam", _p(g), N, L, F, T, ld, col, nrun, _p(buf), _p(ws), _p(stage),
                         adam.from_level, _p(adam.p), _p(adam.m), _p(adam.v), float(adam.lr), float(adam.b1), float(adam.b2),
                         float(adam.eps), int(adam.step), float(adam.scale), _stream(), tag=f"F{F}L{L}",
-                        units=float(N) * L * 8 * F * 4 * 2 + 24.0 * fused)
+                        # algorithmic bytes: every corner contribution (F floats) read once, written back as a gradient
+                        # only on the levels left to the caller; p, exp_avg, exp_avg_sq read + written on the fused ones
+                        units=float(N) * 8 * F * 4 * (L + adam.from_level) + 24.0 * fused)
                 return True
             _launch("snf_hashgrid_bwd_presorted", _p(g), N, L, F, T, ld, col, nrun, _p(buf), _p(ws), _p(stage), _stream(),
                     tag=f"F{F}L{L}")
@@ -907,7 +909,9 @@ class _NerfactoField(torch.autograd.Function):
         gt = None
         if table.requires_grad:
             buf, fused = _grad_target(table)
-            _hashgrid_bwd_launch(u, denc, sc, N, L, F, T, 32, 0, buf)
+            adam = getattr(table, "_fused_adam", None) if fused else None
+            if _hashgrid_bwd_launch(u, denc, sc, N, L, F, T, 32, 0, buf, adam):
+                adam.done = (adam.from_level, L)
             gt = None if fused else buf
         return (None, None, None, None, None, None, gt, gb[0], gb[1], gh[0], gh[1], gh[2])
 

@@ -25,7 +25,7 @@ def counter(path, rx):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("dir")
-    ap.add_argument("--regex", default="k_adam<")
+    ap.add_argument("--regex", default=r"k_hg_reduce<8, ?true>")
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
     bench = json.loads(open(os.path.join(a.dir, "pmc_FETCH_SIZE.json")).read().strip().splitlines()[-1])
