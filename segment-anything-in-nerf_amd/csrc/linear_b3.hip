@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256) void k_gemm_rows_b3(const float* __restrict__ 
 __global__ __launch_bounds__(256) void k_gemm_wgrad_b3(const float* __restrict__ dY, const float* __restrict__ Y,
                                                        const float* __restrict__ X, int N, int I, int O, int lddy, int ldy,
                                                        int ldx, int act, int rows_per_block, float* __restrict__ dW,
-                                                       float* __restrict__ dbias) {
+                                                       float* __restrict__ dbias, int to, int ti, int chunks) {
     __shared__ __attribute__((aligned(16))) uint16_t Ah[64 * B3_PITCH];
     __shared__ __attribute__((aligned(16))) uint16_t Al[64 * B3_PITCH];
     __shared__ __attribute__((aligned(16))) uint16_t Bh[64 * B3_PITCH];
@@ -229,8 +229,17 @@ __global__ __launch_bounds__(256) void k_gemm_wgrad_b3(const float* __restrict__
     __shared__ float bs[64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, half = lane >> 5, wm = wave >> 1, wn = wave & 1;
-    const int o0 = blockIdx.x * 64, i0 = blockIdx.y * 64;
-    const int n_begin = blockIdx.z * rows_per_block, n_end = min(N, n_begin + rows_per_block);
+    // XCD-aware block order.  The to x ti output tiles of one row chunk read the same rows of dY / Y / X; workgroups go to
+    // the 8 XCDs round-robin in linear order, so with a plain (tile, chunk) grid the 12 tiles of a chunk land on 8 different
+    // L2s and every one of them pulls its own copy of the chunk (rocprofv3 FETCH_SIZE: 1.65x the algorithmic bytes).  Here
+    // the tiles of a chunk are consecutive in ONE XCD's queue: chunk = 8 * (seq / tiles) + xcd, tile = seq % tiles.
+    const int tiles = to * ti;
+    const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+    const int tile = seq % tiles, chunk = (seq / tiles) * 8 + xcd;
+    if (chunk >= chunks) return;
+    const int o0 = (tile % to) * 64, i0 = (tile / to) * 64;
+    const bool first_i_tile = tile / to == 0;
+    const int n_begin = chunk * rows_per_block, n_end = min(N, n_begin + rows_per_block);
     const int q = tid & 15, kp = tid >> 4;  // 16 column quads x 16 row pairs
     f32x16 acc;
 #pragma unroll
@@ -284,7 +293,7 @@ __global__ __launch_bounds__(256) void k_gemm_wgrad_b3(const float* __restrict__
         const int i = i0 + wn * 32 + li;
         if (o < O && i < I) unsafeAtomicAdd(&dW[(size_t)o * I + i], acc[reg]);
     }
-    if (dbias != nullptr && blockIdx.y == 0) {
+    if (dbias != nullptr && first_i_tile) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) atomicAdd(&bs[q * 4 + c], bsum[c]);
         __syncthreads();
@@ -617,7 +626,8 @@ int snf::b3_try_bwd_weight(const float* dY, const float* Y, const float* X, int 
     rows = ((rows + B3_BK - 1) / B3_BK) * B3_BK;
     if (rows < 4 * B3_BK) rows = 4 * B3_BK;
     chunks = ceil_div(N, rows);
-    hipLaunchKernelGGL(k_gemm_wgrad_b3, dim3(to, ti, chunks), dim3(256), 0, (hipStream_t)stream, dY, Y, X, N, I, O, lddy, ldy, ldx,
-                       act, rows, dW, dbias);
+    const int chunks8 = (chunks + 7) / 8 * 8;  // whole rounds of the 8 XCDs (surplus workgroups exit at once)
+    hipLaunchKernelGGL(k_gemm_wgrad_b3, dim3(to * ti * chunks8), dim3(256), 0, (hipStream_t)stream, dY, Y, X, N, I, O, lddy, ldy,
+                       ldx, act, rows, dW, dbias, to, ti, chunks);
     return 1;
 }

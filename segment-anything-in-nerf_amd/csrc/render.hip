@@ -41,6 +41,42 @@ __global__ __launch_bounds__(256) void k_head_input(const float* __restrict__ di
     for (int j = 16 + n_geo; j < ld_out; ++j) o[j] = 0.f;  // pad columns (e.g. 31 -> 32 for the fused MLP)
 }
 
+// The same for the fused colour net's input width (ld_out == 32): 8 lanes per sample, lane c writes columns 4c .. 4c+3 as one
+// dwordx4, so a wave stores 8 whole 128-byte rows per instruction.  (One thread per sample writes 16 bytes into 64 different
+// lines per instruction: rocprofv3 WRITE_SIZE showed 3x the algorithmic bytes for it.)
+__global__ __launch_bounds__(256) void k_head_input32(const float* __restrict__ dirs, const float* __restrict__ geo, int R,
+                                                      int S, int n_geo, int ld_geo, float* __restrict__ out) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long s = t >> 3;
+    const int c = (int)(t & 7);
+    if (s >= (long long)R * S) return;
+    float4 v;
+    if (c < 4) {
+        const int r = (int)(s / S);
+        const float x = dirs[r * 3 + 0], y = dirs[r * 3 + 1], z = dirs[r * 3 + 2];
+        const float xx = x * x, yy = y * y, zz = z * z;
+        if (c == 0)
+            v = make_float4(0.28209479177387814f, 0.4886025119029199f * y, 0.4886025119029199f * z, 0.4886025119029199f * x);
+        else if (c == 1)
+            v = make_float4(1.0925484305920792f * x * y, 1.0925484305920792f * y * z,
+                            0.9461746957575601f * zz - 0.31539156525251999f, 1.0925484305920792f * x * z);
+        else if (c == 2)
+            v = make_float4(0.5462742152960396f * (xx - yy), 0.5900435899266435f * y * (3.f * xx - yy),
+                            2.890611442640554f * x * y * z, 0.4570457994644658f * y * (5.f * zz - 1.f));
+        else
+            v = make_float4(0.3731763325901154f * z * (5.f * zz - 3.f), 0.4570457994644658f * x * (5.f * zz - 1.f),
+                            1.445305721320277f * z * (xx - yy), 0.5900435899266435f * x * (xx - 3.f * yy));
+    } else {
+        const float* g = geo + (size_t)s * ld_geo;
+        const int j = (c - 4) * 4;
+        v.x = j + 0 < n_geo ? g[j + 0] : 0.f;
+        v.y = j + 1 < n_geo ? g[j + 1] : 0.f;
+        v.z = j + 2 < n_geo ? g[j + 2] : 0.f;
+        v.w = j + 3 < n_geo ? g[j + 3] : 0.f;
+    }
+    *reinterpret_cast<float4*>(out + (size_t)s * 32 + c * 4) = v;
+}
+
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_weights_fwd(const float* __restrict__ raw, int raw_stride, int is_density,
                                                      const uint8_t* __restrict__ selector,
@@ -267,8 +303,12 @@ extern "C" int snf_head_input(const float* dirs, const float* geo, int R, int S,
                               int ld_out, snf_stream_t stream) {
     SNF_REQUIRE(dirs && geo && out, "snf_head_input: null pointer");
     SNF_REQUIRE(R > 0 && S > 0 && n_geo >= 0 && ld_out >= 16 + n_geo && ld_geo >= n_geo, "snf_head_input: bad shape");
-    hipLaunchKernelGGL(k_head_input, dim3(ceil_div((long long)R * S, 256)), dim3(256), 0, (hipStream_t)stream, dirs, geo,
-                       R, S, n_geo, ld_geo, out, ld_out);
+    if (ld_out == 32 && n_geo <= 16 && ((uintptr_t)out & 15) == 0)
+        hipLaunchKernelGGL(k_head_input32, dim3(ceil_div((long long)R * S * 8, 256)), dim3(256), 0, (hipStream_t)stream, dirs,
+                           geo, R, S, n_geo, ld_geo, out);
+    else
+        hipLaunchKernelGGL(k_head_input, dim3(ceil_div((long long)R * S, 256)), dim3(256), 0, (hipStream_t)stream, dirs, geo,
+                           R, S, n_geo, ld_geo, out, ld_out);
     SNF_LAUNCH_CHECK("snf_head_input");
     return SNF_OK;
 }
