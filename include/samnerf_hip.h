@@ -64,7 +64,9 @@ int snf_positions(const float* origins, const float* dirs, const float* ebins, c
  *      samnerf/sam_field.py:99-109, fields/nerfacto_field.py:157-167, fields/density_fields.py:73-99).
  * u [N,3] in [0,1]; table [L*2^log2_T, F] (level-major rows, feature-minor); scalings [L] (the
  * reference's floor(min_res*g^l) vector, supplied by the caller).  F in {2,8}.
- * Out: out[n*ld_out + col_off + l*F + f]. */
+ * Out: out[n*ld_out + col_off + l*F + f]; ld_out = 0 (col_off = 0) selects the level-major layout out[(l*N + n)*F + f],
+ * which snf_mlp64_fwd (ldx = 0), snf_linear_bwd_weight (ldx = 0) and, for gradients, snf_mlp64_bwd_data (lddx = 0) and
+ * snf_hashgrid_bwd_presorted[_adam] (ld_out = 0: no staging pass) read and write directly. */
 int snf_hashgrid_fwd(const float* u, const float* table, const float* scalings, int N, int L, int F,
                      int log2_T, float* out, int ld_out, int col_off, snf_stream_t stream);
 

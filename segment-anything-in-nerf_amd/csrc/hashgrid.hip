@@ -94,7 +94,10 @@ __global__ __launch_bounds__(256) void k_hashgrid_fwd(const float* __restrict__ 
         const float f4756 = f47 * oy + f56 * my;
         r[j] = f0312 * oz + f4756 * mz;
     }
-    float* __restrict__ o = out + (size_t)n * ld_out + col_off + l * F;
+    // ld_out == 0: level-major ("planar") output [L][N][F] -- consecutive samples of a level are contiguous, so a wave
+    // writes whole lines (row-major [N, L*F] output is 8 / 32 bytes per 128-byte row from a level-at-a-time kernel:
+    // rocprofv3 WRITE_SIZE showed 4x the algorithmic bytes for the F=2 field grid)
+    float* __restrict__ o = ld_out ? out + (size_t)n * ld_out + col_off + l * F : out + ((size_t)l * N + n) * F;
     if constexpr (F == 2) {
         *reinterpret_cast<float2*>(o) = make_float2(r[0], r[1]);
     } else {
@@ -733,7 +736,8 @@ static int check_common(const char* who, const void* u, const void* a, const voi
     SNF_REQUIRE(N > 0 && L > 0 && L <= 65535, "%s: bad N=%d L=%d", who, N, L);
     SNF_REQUIRE(F == 2 || F == 8, "%s: features_per_level must be 2 or 8 (got %d)", who, F);
     SNF_REQUIRE(log2_T >= 1 && log2_T <= 26, "%s: bad log2_T=%d", who, log2_T);
-    SNF_REQUIRE(ld_out >= col_off + L * F && col_off >= 0, "%s: ld_out=%d too small for col_off=%d + L*F=%d", who,
+    SNF_REQUIRE((ld_out == 0 && col_off == 0) || (ld_out >= col_off + L * F && col_off >= 0),
+                "%s: ld_out=%d too small for col_off=%d + L*F=%d (ld_out = 0: level-major [L][N][F], col_off must be 0)", who,
                 ld_out, col_off, L * F);
     const int al = (F == 2) ? 2 : 4;
     SNF_REQUIRE(ld_out % al == 0 && col_off % al == 0, "%s: ld_out/col_off must be multiples of %d", who, al);
@@ -845,12 +849,15 @@ extern "C" int snf_hashgrid_sort(const float* u, const float* scalings, int N, i
 extern "C" int snf_hashgrid_bwd_presorted(const float* grad_out, int N, int L, int F, int log2_T, int ld_out, int col_off,
                                           int n_run_levels, float* grad_table, const void* sorted_workspace, float* stage,
                                           snf_stream_t stream) {
-    SNF_REQUIRE(grad_out && grad_table && sorted_workspace && stage, "snf_hashgrid_bwd_presorted: null pointer");
+    const bool planar = ld_out == 0;  // grad_out is already level-major [L][N][F]: it IS the staged gradient
+    SNF_REQUIRE(grad_out && grad_table && sorted_workspace && (stage || planar), "snf_hashgrid_bwd_presorted: null pointer");
     SNF_REQUIRE(F == 2 || F == 8, "snf_hashgrid_bwd_presorted: features_per_level must be 2 or 8 (got %d)", F);
-    SNF_REQUIRE(N > 0 && L > 0 && N <= (1 << HG_SAMPLE_BITS) && ld_out >= col_off + L * F && col_off >= 0,
+    SNF_REQUIRE(N > 0 && L > 0 && N <= (1 << HG_SAMPLE_BITS) && ((planar && col_off == 0) || ld_out >= col_off + L * F) &&
+                    col_off >= 0,
                 "snf_hashgrid_bwd_presorted: bad shape N=%d L=%d ld_out=%d col_off=%d", N, L, ld_out, col_off);
     SNF_REQUIRE(((uintptr_t)grad_out % 16) == 0 && ((uintptr_t)grad_table % 16) == 0 && ((uintptr_t)stage % 16) == 0,
                 "snf_hashgrid_bwd_presorted: unaligned pointer");
+    if (planar) stage = const_cast<float*>(grad_out);
     const HgGeom g = hg_geometry(N, log2_T);
     const HgWs w = hg_ws_layout(const_cast<void*>(sorted_workspace), N, L, g);
     const int B = 1 << g.log2B;
@@ -859,11 +866,11 @@ extern "C" int snf_hashgrid_bwd_presorted(const float* grad_out, int N, int L, i
     const uint32_t hg_long = e_long ? (uint32_t)atoi(e_long) : (uint32_t)HG_LONG;
     const int tblocks = ceil_div((long long)N * L, 256);
     if (F == 2) {
-        hipLaunchKernelGGL(k_hg_stage_grad<2>, dim3(tblocks), dim3(256), 0, st, grad_out, N, L, ld_out, col_off, stage);
+        if (!planar) hipLaunchKernelGGL(k_hg_stage_grad<2>, dim3(tblocks), dim3(256), 0, st, grad_out, N, L, ld_out, col_off, stage);
         hipLaunchKernelGGL((k_hg_reduce<2, false>), dim3(B, L), dim3(HG_RT), 0, st, stage, N, log2_T, g.log2B, w.bstart,
                            (const uint2*)w.records, grad_table, hg_long, n_run_levels, HgAdam{});
     } else {
-        hipLaunchKernelGGL(k_hg_stage_grad<8>, dim3(tblocks), dim3(256), 0, st, grad_out, N, L, ld_out, col_off, stage);
+        if (!planar) hipLaunchKernelGGL(k_hg_stage_grad<8>, dim3(tblocks), dim3(256), 0, st, grad_out, N, L, ld_out, col_off, stage);
         hipLaunchKernelGGL((k_hg_reduce<8, false>), dim3(B, L), dim3(HG_RT), 0, st, stage, N, log2_T, g.log2B, w.bstart,
                            (const uint2*)w.records, grad_table, hg_long, n_run_levels, HgAdam{});
     }
@@ -876,11 +883,14 @@ extern "C" int snf_hashgrid_bwd_presorted_adam(const float* grad_out, int N, int
                                                int fuse_from_level, float* param, float* exp_avg, float* exp_avg_sq, float lr,
                                                float beta1, float beta2, float eps, int step, float grad_scale,
                                                snf_stream_t stream) {
-    SNF_REQUIRE(grad_out && grad_table && sorted_workspace && stage && param && exp_avg && exp_avg_sq,
+    const bool planar = ld_out == 0;  // grad_out is already level-major [L][N][F]: it IS the staged gradient
+    SNF_REQUIRE(grad_out && grad_table && sorted_workspace && (stage || planar) && param && exp_avg && exp_avg_sq,
                 "snf_hashgrid_bwd_presorted_adam: null pointer");
     SNF_REQUIRE(F == 2 || F == 8, "snf_hashgrid_bwd_presorted_adam: features_per_level must be 2 or 8 (got %d)", F);
-    SNF_REQUIRE(N > 0 && L > 0 && N <= (1 << HG_SAMPLE_BITS) && ld_out >= col_off + L * F && col_off >= 0,
+    SNF_REQUIRE(N > 0 && L > 0 && N <= (1 << HG_SAMPLE_BITS) && ((planar && col_off == 0) || ld_out >= col_off + L * F) &&
+                    col_off >= 0,
                 "snf_hashgrid_bwd_presorted_adam: bad shape N=%d L=%d ld_out=%d col_off=%d", N, L, ld_out, col_off);
+    if (planar) stage = const_cast<float*>(grad_out);
     SNF_REQUIRE(fuse_from_level >= 0 && fuse_from_level <= L && step >= 1,
                 "snf_hashgrid_bwd_presorted_adam: bad fuse_from_level=%d (L=%d) or step=%d", fuse_from_level, L, step);
     SNF_REQUIRE((((uintptr_t)grad_out | (uintptr_t)grad_table | (uintptr_t)stage | (uintptr_t)param | (uintptr_t)exp_avg |
@@ -898,11 +908,11 @@ extern "C" int snf_hashgrid_bwd_presorted_adam(const float* grad_out, int N, int
     a.eps = eps; a.gs = grad_scale; a.from_level = fuse_from_level;
     const int tblocks = ceil_div((long long)N * L, 256);
     if (F == 2) {
-        hipLaunchKernelGGL(k_hg_stage_grad<2>, dim3(tblocks), dim3(256), 0, st, grad_out, N, L, ld_out, col_off, stage);
+        if (!planar) hipLaunchKernelGGL(k_hg_stage_grad<2>, dim3(tblocks), dim3(256), 0, st, grad_out, N, L, ld_out, col_off, stage);
         hipLaunchKernelGGL((k_hg_reduce<2, true>), dim3(B, L), dim3(HG_RT), 0, st, stage, N, log2_T, g.log2B, w.bstart,
                            (const uint2*)w.records, grad_table, hg_long, n_run_levels, a);
     } else {
-        hipLaunchKernelGGL(k_hg_stage_grad<8>, dim3(tblocks), dim3(256), 0, st, grad_out, N, L, ld_out, col_off, stage);
+        if (!planar) hipLaunchKernelGGL(k_hg_stage_grad<8>, dim3(tblocks), dim3(256), 0, st, grad_out, N, L, ld_out, col_off, stage);
         hipLaunchKernelGGL((k_hg_reduce<8, true>), dim3(B, L), dim3(HG_RT), 0, st, stage, N, log2_T, g.log2B, w.bstart,
                            (const uint2*)w.records, grad_table, hg_long, n_run_levels, a);
     }

@@ -99,11 +99,19 @@ __device__ __forceinline__ float4 load_a4_vec(const float* __restrict__ A, const
     return v;
 }
 
-__device__ __forceinline__ float4 load_b4_vec(const float* __restrict__ B, int r, int c, int Rn, int Cn, int ldb) {
+// level-major ("planar") matrix [C/2 levels][R_total][2] read as if it were row-major [R_total, C] at (r, c), c % 4 == 0
+__device__ __forceinline__ float4 load_b4_planar(const float* __restrict__ B, int r, int c, long long r_total) {
+    const float2 a = *reinterpret_cast<const float2*>(B + ((long long)(c >> 1) * r_total + r) * 2);
+    const float2 b = *reinterpret_cast<const float2*>(B + ((long long)((c >> 1) + 1) * r_total + r) * 2);
+    return make_float4(a.x, a.y, b.x, b.y);
+}
+
+__device__ __forceinline__ float4 load_b4_vec(const float* __restrict__ B, int r, int c, int Rn, int Cn, int ldb,
+                                              long long r_total = 0) {
     const bool ok = (r < Rn) && (c < Cn);
     const int rc = r < Rn ? r : Rn - 1;
     const int cc = c < Cn ? c : 0;
-    float4 v = *reinterpret_cast<const float4*>(B + (size_t)rc * ldb + cc);
+    float4 v = ldb ? *reinterpret_cast<const float4*>(B + (size_t)rc * ldb + cc) : load_b4_planar(B, rc, cc, r_total);
     v.x = ok ? v.x : 0.f;
     v.y = (ok && c + 1 < Cn) ? v.y : 0.f;
     v.z = (ok && c + 2 < Cn) ? v.z : 0.f;
@@ -283,7 +291,7 @@ __global__ __launch_bounds__(256) void k_gemm_wgrad(const float* __restrict__ dY
             // A: dZ[n][o0 + q*4 ..]  (activation derivative folded in)
             if constexpr (VEC) {
                 av[p] = load_a4_vec<true>(dY, Y, n, o0 + q * 4, n_end, O, lddy, ldy, act);
-                bv[p] = load_b4_vec(X, n, i0 + q * 4, n_end, I, ldx);
+                bv[p] = load_b4_vec(X, n, i0 + q * 4, n_end, I, ldx, N);
             } else {
                 av[p] = ok ? load_a4<true>(dY, Y, n, o0 + q * 4, N, O, lddy, ldy, act, vecA) : make_float4(0, 0, 0, 0);
                 bv[p] = ok ? load_b4(X, n, i0 + q * 4, N, I, ldx, vecB) : make_float4(0, 0, 0, 0);
@@ -438,7 +446,8 @@ extern "C" int snf_linear_bwd_weight(const float* dY, const float* Y, const floa
     SNF_REQUIRE(dY && X && dW, "snf_linear_bwd_weight: null pointer");
     SNF_REQUIRE(act == SNF_ACT_NONE || Y, "snf_linear_bwd_weight: Y required for activation derivative");
     SNF_REQUIRE(act != SNF_ACT_GELU, "snf_linear_bwd_weight: GELU is forward-only (image encoder inference)");
-    SNF_REQUIRE(N > 0 && I > 0 && O > 0 && lddy >= O && ldx >= I, "snf_linear_bwd_weight: bad shape");
+    // ldx == 0: X is level-major [I/2][N][2] (the hash-grid forward's planar output); needs the vector path
+    SNF_REQUIRE(N > 0 && I > 0 && O > 0 && lddy >= O && (ldx >= I || (ldx == 0 && I % 4 == 0)), "snf_linear_bwd_weight: bad shape");
     if (b3_try_bwd_weight(dY, Y, X, N, I, O, lddy, ldy, ldx, act, dW, dbias, stream)) {
         SNF_LAUNCH_CHECK("snf_linear_bwd_weight(bf16x3)");
         return SNF_OK;
@@ -457,6 +466,7 @@ extern "C" int snf_linear_bwd_weight(const float* dY, const float* Y, const floa
     if (rows < 4 * BK) rows = 4 * BK;
     chunks = ceil_div(N, rows);
     dim3 grid(to, ti, chunks);
+    SNF_REQUIRE(ldx != 0 || (vecA && vecB), "snf_linear_bwd_weight: a level-major X needs 16-byte aligned dY / X");
     if (vecA && vecB)
         hipLaunchKernelGGL(k_gemm_wgrad<true>, grid, dim3(256), 0, (hipStream_t)stream, dY, Y, X, N, I, O, lddy, ldy, ldx,
                            act, rows, vecA, vecB, dW, dbias);

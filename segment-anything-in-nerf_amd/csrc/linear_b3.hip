@@ -616,7 +616,7 @@ int snf::b3_try_bwd_data(const float* dY, const float* Y, const float* W, int N,
 
 int snf::b3_try_bwd_weight(const float* dY, const float* Y, const float* X, int N, int I, int O, int lddy, int ldy, int ldx,
                            int act, float* dW, float* dbias, snf_stream_t stream) {
-    if (!b3_enabled() || O < 64 || I < 64 || (I % 4) || (O % 4) || (lddy % 4) || (ldx % 4) || ((uintptr_t)dY & 15) ||
+    if (!b3_enabled() || O < 64 || I < 64 || (I % 4) || (O % 4) || (lddy % 4) || (ldx % 4) || ldx == 0 || ((uintptr_t)dY & 15) ||
         ((uintptr_t)X & 15) || (act != SNF_ACT_NONE && ((ldy % 4) || ((uintptr_t)Y & 15))))
         return 0;
     const int to = ceil_div(O, 64), ti = ceil_div(I, 64);

@@ -120,10 +120,20 @@ __global__ __launch_bounds__(256) void k_mlp_chain_fwd(const float* __restrict__
         const long long sc = ok ? s : N - 1;
         // this lane's half of the input row: X[s][half*16 .. half*16+15]
         float x[16];
+        if (ldx == 0) {
+            // level-major ("planar") input [16 levels][N][2] (the hash-grid forward's ld_out = 0 layout): feature k lives at
+            // ((k >> 1) * N + s) * 2 + (k & 1); a half-wave reads 32 consecutive samples of a level = 256 contiguous bytes
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float4 v = *reinterpret_cast<const float4*>(X + sc * ldx + half * 16 + 4 * q);
-            x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
+            for (int q = 0; q < 8; ++q) {
+                const float2 v = *reinterpret_cast<const float2*>(X + ((long long)(half * 8 + q) * N + sc) * 2);
+                x[2 * q] = v.x; x[2 * q + 1] = v.y;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 v = *reinterpret_cast<const float4*>(X + sc * ldx + half * 16 + 4 * q);
+                x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
+            }
         }
 #pragma unroll
         for (int i = 0; i < 16; ++i)
@@ -254,10 +264,21 @@ __global__ __launch_bounds__(256) void k_mlp_chain_bwd(const float* __restrict__
                     dx = __builtin_amdgcn_mfma_f32_32x32x2f32(cw.w0[(t * 32 + krow(r, half)) * MC_P0 + li], dl[t][r], dx, 0,
                                                               0, 0);
             if (ok) {
+                if (lddx == 0) {
+                    // level-major dX [16][N][2]: registers 4q .. 4q+3 are features 8q + 4*half + {0..3} = two levels; this is
+                    // the staged-gradient layout of the hash-grid backward (snf_hashgrid_bwd_presorted with ld_out = 0)
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    *reinterpret_cast<float4*>(dX + s * lddx + 8 * q + 4 * half) =
-                        make_float4(dx[4 * q], dx[4 * q + 1], dx[4 * q + 2], dx[4 * q + 3]);
+                    for (int q = 0; q < 4; ++q) {
+                        const long long lv = 4 * q + 2 * half;
+                        *reinterpret_cast<float2*>(dX + (lv * N + s) * 2) = make_float2(dx[4 * q], dx[4 * q + 1]);
+                        *reinterpret_cast<float2*>(dX + ((lv + 1) * N + s) * 2) = make_float2(dx[4 * q + 2], dx[4 * q + 3]);
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        *reinterpret_cast<float4*>(dX + s * lddx + 8 * q + 4 * half) =
+                            make_float4(dx[4 * q], dx[4 * q + 1], dx[4 * q + 2], dx[4 * q + 3]);
+                }
             }
         }
     }
@@ -281,7 +302,7 @@ extern "C" int snf_mlp64_fwd(const float* X, int ldx, const float* W0, int in_re
     int rc = chain_common_checks("snf_mlp64_fwd", in_real, n_hidden, out, N);
     if (rc) return rc;
     SNF_REQUIRE(X && W0 && Wout && Y && (n_hidden == 1 || W1), "snf_mlp64_fwd: null pointer");
-    SNF_REQUIRE(ldx >= MC_IN && ldx % 4 == 0 && ((uintptr_t)X % 16) == 0,
+    SNF_REQUIRE((ldx == 0 || (ldx >= MC_IN && ldx % 4 == 0)) && ((uintptr_t)X % 16) == 0,
                 "snf_mlp64_fwd: X must be [N, ldx>=32] with ldx %% 4 == 0 and 16-byte aligned rows (pad columns readable)");
     SNF_REQUIRE(ldy >= out, "snf_mlp64_fwd: ldy < out");
     SNF_REQUIRE((!H1 || ((uintptr_t)H1 % 16) == 0) && (!H2 || ((uintptr_t)H2 % 16) == 0), "snf_mlp64_fwd: unaligned H");
@@ -308,7 +329,8 @@ extern "C" int snf_mlp64_bwd_data(const float* dY, int lddy, int dy_col_off, con
     SNF_REQUIRE(out_act != SNF_ACT_SIGMOID || Y, "snf_mlp64_bwd_data: Y required for the sigmoid derivative");
     SNF_REQUIRE(out_act != SNF_ACT_RELU, "snf_mlp64_bwd_data: ReLU output activation is not supported");
     SNF_REQUIRE(!dZ || lddz >= out, "snf_mlp64_bwd_data: lddz < out");
-    SNF_REQUIRE(!dX || (lddx >= MC_IN && lddx % 4 == 0 && ((uintptr_t)dX % 16) == 0), "snf_mlp64_bwd_data: bad dX layout");
+    SNF_REQUIRE(!dX || ((lddx == 0 || (lddx >= MC_IN && lddx % 4 == 0)) && ((uintptr_t)dX % 16) == 0),
+                "snf_mlp64_bwd_data: bad dX layout");
     SNF_REQUIRE(((uintptr_t)H1 % 16) == 0 && ((uintptr_t)dH1 % 16) == 0, "snf_mlp64_bwd_data: unaligned H1/dH1");
     const long long ntiles = (N + 31) / 32;
     long long blocks = (ntiles + 3) / 4;

@@ -22,6 +22,7 @@ import os as _os
 
 HASHGRID_BWD_MODE = "sorted"  # "sorted": bucketed, atomic-free (default) | "atomic": global fp32 atomics
 PRESORT_FIELD_GRID = _os.environ.get("SNF_PRESORT_FIELD", "1") == "1"
+PLANAR_FIELD_ENCODING = _os.environ.get("SNF_PLANAR_FIELD", "1") == "1"
 PRESORT_SIDE_STREAM = True  # False: forward-time sorts stay on the caller's stream (bench.py's serial replay)
 HASHGRID_RUN_MAX_RES = float(_os.environ.get("SNF_HG_RUN_MAX_RES", "64"))  # levels up to this resolution aggregate runs
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_GELU = 0, 1, 2, 3
@@ -393,7 +394,7 @@ def _hashgrid_bwd_launch(u, g, sc, N, L, F, T, ld, col, buf, adam: Optional[Fuse
             if ev is not None:  # sorted on the side stream: order this stream after it, keep the buffer alive for it
                 torch.cuda.current_stream().wait_event(ev)
                 ws.record_stream(torch.cuda.current_stream())
-            stage = torch.empty((L * N * F,), device=g.device, dtype=torch.float32)
+            stage = None if ld == 0 else torch.empty((L * N * F,), device=g.device, dtype=torch.float32)
             if adam is not None and adam.from_level < L:
                 fused = ((L - adam.from_level) << T) * F
                 _launch("snf_hashgrid_bwd_presorted_adam", _p(g), N, L, F, T, ld, col, nrun, _p(buf), _p(ws), _p(stage),
@@ -778,8 +779,9 @@ def mlp64_supported(in_dim: int, weights: Sequence[torch.Tensor]) -> bool:
             and all(w.shape[0] == 64 for w in weights[:-1]) and weights[-1].shape[0] <= 32)
 
 
-def _mlp64_fwd_launch(x, in_real, ws, out_act, save: bool):
-    N, ldx = x.shape
+def _mlp64_fwd_launch(x, in_real, ws, out_act, save: bool, planar_rows: int = 0):
+    """planar_rows = N: `x` is the flat level-major encoding [in_real/2][N][2] (ldx = 0 in the C-ABI)."""
+    N, ldx = (planar_rows, 0) if planar_rows else x.shape
     nh = len(ws) - 1
     out = ws[-1].shape[0]
     dev = x.device
@@ -791,9 +793,10 @@ def _mlp64_fwd_launch(x, in_real, ws, out_act, save: bool):
     return y, h1, h2
 
 
-def _mlp64_bwd_launch(x, in_real, ws, out_act, y, h1, h2, dy, lddy, dy_col_off, dy0, need_dx: bool):
-    """-> dX [N,32] (or None).  Weight gradients are accumulated into the weights' grad targets; returns them too."""
-    N, ldx = x.shape
+def _mlp64_bwd_launch(x, in_real, ws, out_act, y, h1, h2, dy, lddy, dy_col_off, dy0, need_dx: bool, planar_rows: int = 0):
+    """-> dX [N,32] (or None).  Weight gradients are accumulated into the weights' grad targets; returns them too.
+    planar_rows = N: `x` is level-major [16][N][2] and dX is produced in the same layout (flat, 32*N)."""
+    N, ldx = (planar_rows, 0) if planar_rows else x.shape
     nh = len(ws) - 1
     out = ws[-1].shape[0]
     dev = x.device
@@ -801,11 +804,11 @@ def _mlp64_bwd_launch(x, in_real, ws, out_act, y, h1, h2, dy, lddy, dy_col_off, 
     dh1 = torch.empty((N, 64), device=dev, dtype=torch.float32)
     dh2 = torch.empty((N, 64), device=dev, dtype=torch.float32) if nh == 2 else None
     dz = torch.empty((N, ldz), device=dev, dtype=torch.float32)
-    dx = torch.empty((N, 32), device=dev, dtype=torch.float32) if need_dx else None
+    dx = (torch.empty((32 * N,) if planar_rows else (N, 32), device=dev, dtype=torch.float32)) if need_dx else None
     tag = f"{in_real}x{'x'.join(['64'] * nh)}x{out}"
     _launch("snf_mlp64_bwd_data", _p(dy), lddy, dy_col_off, _p(dy0), _p(y), out, _p(ws[0]), in_real,
             _p(ws[1] if nh == 2 else None), _p(ws[-1]), nh, out, out_act, N, _p(h1), _p(h2), _p(dh1), _p(dh2), _p(dz),
-            ldz, _p(dx), 32, _stream(), tag=tag)
+            ldz, _p(dx), 0 if planar_rows else 32, _stream(), tag=tag)
     grads = []
     # (dZ, Hlast) -> dWout ; (dH2, H1) -> dW1 ; (dH1, X) -> dW0      [all pre-masked: act = NONE]
     pairs = [(dh1, 64, x, ldx, in_real, ws[0])]
@@ -868,13 +871,18 @@ class _NerfactoField(torch.autograd.Function):
         N = R * S
         dev = u.device
         need = any(ctx.needs_input_grad)  # (grad mode is off inside forward; autograd tells us what it will ask for)
-        enc = torch.empty((N, L * F), device=dev, dtype=torch.float32)
+        # the encoding travels level-major ([L][N][F]) between the grid and the base MLP when the sorted backward can take it:
+        # whole-line stores in the level-at-a-time grid kernels, and the MLP's d(encoding) IS the backward's staged gradient
+        planar = (PLANAR_FIELD_ENCODING and L * F == 32 and F == 2 and HASHGRID_BWD_MODE == "sorted"
+                  and N <= HASHGRID_BWD_MAX_SAMPLES and 8 * L * N < (1 << 32) and T <= 23)
+        enc = torch.empty((L * F * N,) if planar else (N, L * F), device=dev, dtype=torch.float32)
         if need and table.requires_grad and PRESORT_FIELD_GRID:
             # the field grid's backward sort needs only the positions: it runs NOW on a side stream, beside the forward
             # kernels (the forward phase leaves most of the GPU idle), instead of on the backward's critical chain
             hashgrid_presort(u, sc, L, T, side_stream=True)
-        _launch("snf_hashgrid_fwd", _p(u), _p(table), _p(sc), N, L, F, T, _p(enc), L * F, 0, _stream(), tag=f"F{F}L{L}")
-        h, hb1, _ = _mlp64_fwd_launch(enc, L * F, (bw0, bw1), ACT_NONE, need)
+        _launch("snf_hashgrid_fwd", _p(u), _p(table), _p(sc), N, L, F, T, _p(enc), 0 if planar else L * F, 0, _stream(),
+                tag=f"F{F}L{L}")
+        h, hb1, _ = _mlp64_fwd_launch(enc, L * F, (bw0, bw1), ACT_NONE, need, N if planar else 0)
         C = h.shape[1]
         density = torch.empty((N,), device=dev, dtype=torch.float32)
         _launch("snf_trunc_exp_fwd", _p(h), C, _p(sel), N, _p(density), _stream())
@@ -885,7 +893,7 @@ class _NerfactoField(torch.autograd.Function):
         rgb, hh1, hh2 = _mlp64_fwd_launch(x2, 16 + n_geo, (hw0, hw1, hw2), ACT_SIGMOID, need)
         if need:
             ctx.save_for_backward(u, enc, h, hb1, x2, hh1, hh2, rgb)
-            ctx.sel, ctx.spec = sel, spec
+            ctx.sel, ctx.spec, ctx.planar = sel, spec, planar
             ctx.params = (table, bw0, bw1, hw0, hw1, hw2)
         return density, rgb
 
@@ -905,12 +913,12 @@ class _NerfactoField(torch.autograd.Function):
         _launch("snf_trunc_exp_bwd", _p(h), C, _p(ctx.sel), _p(gd), N, _p(graw), 1, _stream())
         # base MLP: dZ[:,0] = graw, dZ[:,1:] = dx2[:, 16:31]  (read in place: column offset 15 of the [N,32] buffer)
         denc, gb = _mlp64_bwd_launch(enc, L * F, (bw0, bw1), ACT_NONE, None, hb1, None, dx2, 32, 15, graw,
-                                     table.requires_grad)
+                                     table.requires_grad, N if ctx.planar else 0)
         gt = None
         if table.requires_grad:
             buf, fused = _grad_target(table)
             adam = getattr(table, "_fused_adam", None) if fused else None
-            if _hashgrid_bwd_launch(u, denc, sc, N, L, F, T, 32, 0, buf, adam):
+            if _hashgrid_bwd_launch(u, denc, sc, N, L, F, T, 0 if ctx.planar else 32, 0, buf, adam):
                 adam.done = (adam.from_level, L)
             gt = None if fused else buf
         return (None, None, None, None, None, None, gt, gb[0], gb[1], gh[0], gh[1], gh[2])
