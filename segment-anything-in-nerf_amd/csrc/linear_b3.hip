@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256) void k_gemm_rows_b3(const float* __restrict__ 
 __global__ __launch_bounds__(256) void k_gemm_wgrad_b3(const float* __restrict__ dY, const float* __restrict__ Y,
                                                        const float* __restrict__ X, int N, int I, int O, int lddy, int ldy,
                                                        int ldx, int act, int rows_per_block, float* __restrict__ dW,
-                                                       float* __restrict__ dbias, int to, int ti, int chunks) {
+                                                       float* __restrict__ dbias, int to, int ti, int chunks, int xcd_order) {
     __shared__ __attribute__((aligned(16))) uint16_t Ah[64 * B3_PITCH];
     __shared__ __attribute__((aligned(16))) uint16_t Al[64 * B3_PITCH];
     __shared__ __attribute__((aligned(16))) uint16_t Bh[64 * B3_PITCH];
@@ -229,13 +229,22 @@ __global__ __launch_bounds__(256) void k_gemm_wgrad_b3(const float* __restrict__
     __shared__ float bs[64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, half = lane >> 5, wm = wave >> 1, wn = wave & 1;
-    // XCD-aware block order.  The to x ti output tiles of one row chunk read the same rows of dY / Y / X; workgroups go to
-    // the 8 XCDs round-robin in linear order, so with a plain (tile, chunk) grid the 12 tiles of a chunk land on 8 different
-    // L2s and every one of them pulls its own copy of the chunk (rocprofv3 FETCH_SIZE: 1.65x the algorithmic bytes).  Here
-    // the tiles of a chunk are consecutive in ONE XCD's queue: chunk = 8 * (seq / tiles) + xcd, tile = seq % tiles.
+    // Block order.  The to x ti output tiles of one row chunk read the same rows of dY / Y / X; workgroups go to the 8 XCDs
+    // round-robin in linear order, so with the plain (tile, chunk) order the 12 tiles of a chunk land on 8 different L2s and
+    // each pulls its own copy of the chunk (rocprofv3 FETCH_SIZE: 2.3 GB per step for the seven launches, 1.65x algorithmic).
+    // xcd_order = 1 makes the tiles of a chunk consecutive in ONE XCD's queue (chunk = 8 * (seq / tiles) + xcd): measured
+    // 1.05 GB per step -- but the kernel alone gets slower (192x256: 0.175 -> 0.25 ms; the twelve tiles now hit the same L2
+    // lines at the same time) and the step time does not move, so the plain order stays the default (SNF_WGRAD_XCD=1).
     const int tiles = to * ti;
-    const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
-    const int tile = seq % tiles, chunk = (seq / tiles) * 8 + xcd;
+    int tile, chunk;
+    if (xcd_order) {
+        const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+        tile = seq % tiles;
+        chunk = (seq / tiles) * 8 + xcd;
+    } else {
+        tile = blockIdx.x % tiles;
+        chunk = blockIdx.x / tiles;
+    }
     if (chunk >= chunks) return;
     const int o0 = (tile % to) * 64, i0 = (tile / to) * 64;
     const bool first_i_tile = tile / to == 0;
@@ -626,8 +635,9 @@ int snf::b3_try_bwd_weight(const float* dY, const float* Y, const float* X, int 
     rows = ((rows + B3_BK - 1) / B3_BK) * B3_BK;
     if (rows < 4 * B3_BK) rows = 4 * B3_BK;
     chunks = ceil_div(N, rows);
+    static const int xcd_order = getenv("SNF_WGRAD_XCD") ? atoi(getenv("SNF_WGRAD_XCD")) : 0;
     const int chunks8 = (chunks + 7) / 8 * 8;  // whole rounds of the 8 XCDs (surplus workgroups exit at once)
     hipLaunchKernelGGL(k_gemm_wgrad_b3, dim3(to * ti * chunks8), dim3(256), 0, (hipStream_t)stream, dY, Y, X, N, I, O, lddy, ldy,
-                       ldx, act, rows, dW, dbias, to, ti, chunks);
+                       ldx, act, rows, dW, dbias, to, ti, chunks, xcd_order);
     return 1;
 }
