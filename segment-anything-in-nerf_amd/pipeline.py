@@ -140,7 +140,8 @@ class Trainer:
         self.local_rank, self.world_size = local_rank, world_size
         self.device = device
         self._start_step = 0
-        self.overlap = True  # run the nerf / SAM-head / ClipSeg-head tasks on separate HIP streams
+        # run the nerf / SAM-head / ClipSeg-head tasks on separate HIP streams (SNF_OVERLAP=0: one stream, for A/B runs)
+        self.overlap = os.environ.get("SNF_OVERLAP", "1") == "1"
         self.enqueue_order = os.environ.get("SNF_ENQUEUE_ORDER", "heads_first")
         self.pipeline_steps = False  # True: do not join the head streams at the end of a step (see train_iteration)
         self._side = None

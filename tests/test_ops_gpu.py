@@ -543,13 +543,13 @@ def test_table_parallel_level_runs_match_the_replicated_grids(world):
         assert float((got[gi] - ref[gi]).abs().max()) <= 1e-5 * scale
 
 
-@pytest.mark.parametrize("from_level,N", [(0, 70000), (2, 70000), (3, 5000)])
-def test_hashgrid_backward_with_fused_adam_matches_backward_then_adam(from_level, N):
+@pytest.mark.parametrize("from_level,N,F", [(0, 70000, 8), (2, 70000, 8), (3, 5000, 8), (0, 300000, 2), (1, 70000, 2)])
+def test_hashgrid_backward_with_fused_adam_matches_backward_then_adam(from_level, N, F):
     """snf_hashgrid_bwd_presorted_adam (the reduce pass applies Adam to the levels >= from_level) against the plain sorted
     backward followed by snf_adam_step on the same levels: parameters, both moments, and the gradient buffer (zero on the
     fused levels, the gradient itself below).  N = 70000 at resolution 16 gives long same-row segments (wave-summed rows)."""
     m = ops()
-    T, F, L = 14, 8, 6
+    T, L = 14, 6
     sc = O.hash_scalings(L, 16, 256).cuda()
     specs = ((sc, L, F, T),)
     gen = torch.Generator(device="cuda").manual_seed(7)
