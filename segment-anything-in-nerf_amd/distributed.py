@@ -36,12 +36,54 @@ def init_distributed(backend: Optional[str] = None) -> tuple:
     if (world > 1 or (_force() and "RANK" in os.environ)) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend is None:  # SNF_DIST_BACKEND=gloo: CPU collectives with device tensors staged through the host (tests)
+            backend = os.environ.get("SNF_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local_rank, world
+
+
+# -- collectives.  backend "nccl" (= RCCL): straight through.  backend "gloo" with device tensors (tests: two ranks sharing
+# one GPU, which RCCL refuses) is staged through host memory, so the same code paths run with the real kernels.
+def _staged(t: torch.Tensor) -> bool:
+    return t.is_cuda and dist.get_backend() == "gloo"
+
+
+def _all_reduce(t: torch.Tensor) -> None:
+    if _staged(t):
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+
+
+def _broadcast(t: torch.Tensor, src: int) -> None:
+    if _staged(t):
+        h = t.cpu()
+        dist.broadcast(h, src=src)
+        t.copy_(h)
+    else:
+        dist.broadcast(t, src=src)
+
+
+def _all_gather_into(out: torch.Tensor, inp: torch.Tensor) -> None:
+    if _staged(out):
+        h = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(h, inp.cpu())
+        out.copy_(h)
+    else:
+        dist.all_gather_into_tensor(out, inp)
+
+
+def _all_to_all(out: torch.Tensor, inp: torch.Tensor) -> None:
+    if _staged(out):
+        h = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_to_all_single(h, inp.cpu())
+        out.copy_(h)
+    else:
+        dist.all_to_all_single(out, inp)
 
 
 def allreduce_gradients(grad_buffers: Iterable[torch.Tensor], async_op: bool = False):
@@ -50,9 +92,10 @@ def allreduce_gradients(grad_buffers: Iterable[torch.Tensor], async_op: bool = F
         return []
     handles = []
     for g in grad_buffers:
-        h = dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=async_op)
         if async_op:
-            handles.append(h)
+            handles.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=True))
+        else:
+            _all_reduce(g)
     return handles
 
 
@@ -85,7 +128,7 @@ def sharded_step(param: torch.Tensor, grad: torch.Tensor, step_fn) -> None:
     chunk, bulk, lo, hi = shard_bounds(n, world, rank)
     if chunk > 0:
         if dist.get_backend() == "gloo":  # no reduce_scatter in gloo (CPU tests): all-reduce, then use the own shard
-            dist.all_reduce(grad[:bulk], op=dist.ReduceOp.SUM)
+            _all_reduce(grad[:bulk])
         else:
             dist.reduce_scatter_tensor(grad[lo:hi], grad[:bulk], op=dist.ReduceOp.SUM)
         step_fn(lo, hi)
@@ -94,9 +137,9 @@ def sharded_step(param: torch.Tensor, grad: torch.Tensor, step_fn) -> None:
         if hi < bulk:
             grad[hi:bulk].zero_()
         # in place (input = this rank's slot of the output) on RCCL; gloo needs a separate input buffer
-        dist.all_gather_into_tensor(param[:bulk], param[lo:hi].clone() if dist.get_backend() == "gloo" else param[lo:hi])
+        _all_gather_into(param[:bulk], param[lo:hi].clone() if dist.get_backend() == "gloo" else param[lo:hi])
     if bulk < n:
-        dist.all_reduce(grad[bulk:], op=dist.ReduceOp.SUM)
+        _all_reduce(grad[bulk:])
         step_fn(bulk, n)
 
 
@@ -110,7 +153,7 @@ def exchange_rows(grad_rows: torch.Tensor, row_index: torch.Tensor) -> None:
     if not _collectives_on() or row_index.numel() == 0:
         return
     packed = grad_rows.index_select(0, row_index)
-    dist.all_reduce(packed, op=dist.ReduceOp.SUM)
+    _all_reduce(packed)
     grad_rows.index_copy_(0, row_index, packed)
 
 
@@ -132,13 +175,13 @@ def all_gather_rows(local: torch.Tensor) -> torch.Tensor:
     world = dist.get_world_size()
     sizes = torch.zeros((world,), dtype=torch.int64, device=local.device)
     mine = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
-    dist.all_gather_into_tensor(sizes, mine)
+    _all_gather_into(sizes, mine)
     sizes = sizes.tolist()
     m = max(max(sizes), 1)
     padded = torch.zeros((m,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     padded[:local.shape[0]] = local
     out = torch.empty((world * m,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(out, padded)
+    _all_gather_into(out, padded)
     return torch.cat([out[r * m:r * m + sizes[r]] for r in range(world)], dim=0)
 
 
@@ -149,7 +192,7 @@ def gather_sharded_state(buf: torch.Tensor) -> None:
     world, rank = dist.get_world_size(), dist.get_rank()
     chunk, bulk, lo, hi = shard_bounds(buf.numel(), world, rank)
     if chunk > 0:
-        dist.all_gather_into_tensor(buf[:bulk], buf[lo:hi].clone())
+        _all_gather_into(buf[:bulk], buf[lo:hi].clone())
 
 
 def broadcast_parameters(param_buffers: Iterable[torch.Tensor], src: int = 0) -> None:
@@ -157,7 +200,7 @@ def broadcast_parameters(param_buffers: Iterable[torch.Tensor], src: int = 0) ->
     if not _collectives_on():
         return
     for p in param_buffers:
-        dist.broadcast(p, src=src)
+        _broadcast(p, src)
 
 
 def world_size() -> int:
@@ -231,14 +274,14 @@ def tp_gather_positions(u: torch.Tensor) -> torch.Tensor:
     """[N, 3] on every rank -> [W*N, 3] in rank order (N must be the same on every rank: rays x top-K)."""
     world = dist.get_world_size()
     out = torch.empty((world * u.shape[0], u.shape[1]), dtype=u.dtype, device=u.device)
-    dist.all_gather_into_tensor(out, u.contiguous())
+    _all_gather_into(out, u.contiguous())
     return out
 
 
 def tp_exchange(block: torch.Tensor) -> torch.Tensor:
     """All-to-all of a [W, N, C] block: slice w goes to rank w; the result's slice w came from rank w."""
     out = torch.empty_like(block)
-    dist.all_to_all_single(out.view(-1), block.contiguous().view(-1))
+    _all_to_all(out.view(-1), block.contiguous().view(-1))
     return out
 
 
@@ -266,4 +309,4 @@ def tp_refresh_table(param_flat: torch.Tensor, layout: TableParallelLayout, grid
     for w in range(layout.world):
         lo, hi = layout.owned_elements(w, grid)
         if hi > lo:
-            dist.broadcast(param_flat[lo:hi], src=w)
+            _broadcast(param_flat[lo:hi], w)

@@ -415,3 +415,134 @@ def test_bench_under_the_multi_gpu_launcher_single_rank():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["roofline"] is not None
     assert any(k.endswith("tp") for k in d["kernel_ms_per_step_serial"]), "the table-parallel path did not run"
+
+
+_TWO_RANK_SCRIPT = r"""
+import copy, json, os, sys
+sys.path.insert(0, os.environ["SNF_ROOT"])
+import torch
+import samnerf_amd
+from samnerf_amd import configs, distributed as D
+from samnerf_amd.rays import RayBundle
+MODE, OUT, R, NSTEP = os.environ["SNF_MODE"], os.environ["SNF_OUT"], 256, int(os.environ.get("SNF_NSTEP", "3"))
+rank, local_rank, world = D.init_distributed() if MODE == "ranks" else (0, 0, 1)
+torch.manual_seed(0)  # the conv head's nn.Conv2d initialisation draws from the default generator
+tc = copy.deepcopy(configs.method_configs["samnerf_distill"])
+tc.pipeline.datamanager.train_num_rays_per_batch = R
+mc = tc.pipeline.model
+mc.log2_hashmap_size, mc.hashgrid_sizes = 12, (14, 14)   # T = 14: the coarsest feature level is a reachable-row segment
+mc.proposal_net_args_list = [dict(a, log2_hashmap_size=11) for a in mc.proposal_net_args_list]
+trainer = tc.setup(device="cuda")
+trainer.setup()
+model, opt = trainer.pipeline.model, trainer.optimizers
+
+
+def data(r):
+    g = torch.Generator(device="cuda").manual_seed(1000 + r)
+    rnd = lambda *s: torch.rand(s, device="cuda", generator=g)
+    d = torch.nn.functional.normalize(torch.randn((R, 3), device="cuda", generator=g), dim=-1)
+    rb = RayBundle(origins=rnd(R, 3) - 0.5, directions=d, pixel_area=torch.full((R, 1), 1e-6, device="cuda"),
+                   camera_indices=torch.zeros((R, 1), dtype=torch.long, device="cuda"))
+    batch = {"image": rnd(R, 3), "indices": torch.zeros((R, 3), dtype=torch.long, device="cuda"),
+             "sam": torch.randn((R // 16, 256), device="cuda", generator=g),
+             "clipseg": torch.randn((R, 192), device="cuda", generator=g)}
+    return rb, batch, rnd(NSTEP, R, 1), rnd(NSTEP, R, 1)
+
+
+def use(r, step, cache={}):
+    if r not in cache:
+        cache[r] = data(r)
+    rb, batch, tj, uj = cache[r]
+    trainer.pipeline.datamanager.next_train = lambda s: (copy.copy(rb), batch)
+    model.proposal_sampler.initial_sampler.jitter_override = tj[step]
+    model.proposal_sampler.pdf_sampler.jitter_override = uj[step]
+    torch.manual_seed(4321 + 10 * step + r)  # the random training background comes from the default generator
+
+
+losses = []
+if MODE == "ranks":
+    for step in range(NSTEP):
+        use(rank, step)
+        _, ld, _ = trainer.train_iteration(step)
+        trainer.synchronize()
+        losses.append(float(sum(v.detach() for v in ld.values())))
+    opt.consolidate_state()
+else:
+    # one process, both ranks' rays per step: gradients accumulate in the arenas, Adam on their mean
+    from samnerf_amd.pipeline import BEFORE_TRAIN_ITERATION, AFTER_TRAIN_ITERATION
+    for step in range(NSTEP):
+        for cb in trainer.callbacks:
+            cb.run_callback_at_location(step, BEFORE_TRAIN_ITERATION)
+        for r in (0, 1):
+            use(r, step)
+            _, ld, _ = trainer.pipeline.get_train_loss_dict(step=step)
+            sum(ld.values()).backward()
+            losses.append(float(sum(v.detach() for v in ld.values())))
+        for g in opt.arenas:
+            opt.optimizer_step(g, grad_scale=0.5)
+        opt.scheduler_step_all(step)
+        for cb in trainer.callbacks:
+            cb.run_callback_at_location(step, AFTER_TRAIN_ITERATION)
+    torch.cuda.synchronize()
+if rank == 0:
+    torch.save({"losses": losses, **{f"{k}.{n}": getattr(a, n).cpu() for k, a in opt.arenas.items()
+                                     for n in ("param", "exp_avg", "exp_avg_sq", "grad")}}, OUT)
+if MODE == "ranks":
+    torch.save({"losses": losses}, OUT + f".rank{rank}")
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+"""
+
+
+def _run_two_rank(tmp_path, nstep: int):
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "SNF_FORCE_COLLECTIVES")}
+    base.update(SNF_ROOT=root, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29300 + (os.getpid() + nstep) % 300), SNF_NSTEP=str(nstep))
+    ref_out, rk_out = str(tmp_path / f"ref{nstep}.pt"), str(tmp_path / f"ranks{nstep}.pt")
+    ref = subprocess.run([sys.executable, "-c", _TWO_RANK_SCRIPT], env=dict(base, SNF_MODE="ref", SNF_OUT=ref_out),
+                         capture_output=True, text=True, timeout=600)
+    assert ref.returncode == 0, ref.stderr[-3000:]
+    procs = [subprocess.Popen([sys.executable, "-c", _TWO_RANK_SCRIPT], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                              env=dict(base, SNF_MODE="ranks", SNF_OUT=rk_out, SNF_DIST_BACKEND="gloo", RANK=str(r),
+                                       LOCAL_RANK=str(r), WORLD_SIZE="2")) for r in range(2)]
+    outs = [p.communicate(timeout=900) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-3000:]
+    a, b = torch.load(ref_out), torch.load(rk_out)
+    l0, l1 = torch.load(rk_out + ".rank0")["losses"], torch.load(rk_out + ".rank1")["losses"]
+    for step in range(nstep):  # the reference interleaves (step, rank)
+        assert abs(l0[step] - a["losses"][2 * step]) <= 2e-4 * abs(a["losses"][2 * step]), (step, l0, a["losses"])
+        assert abs(l1[step] - a["losses"][2 * step + 1]) <= 2e-4 * abs(a["losses"][2 * step + 1]), (step, l1, a["losses"])
+    return a, b
+
+
+def test_two_ranks_on_one_gpu_match_accumulated_single_process(tmp_path):
+    """The whole multi-GPU train step with the real kernels and two ranks: ray data-parallelism, table-parallel feature grids
+    (all-gather / all-to-all in forward and backward), fused backward + Adam on the owned levels, sharded exchange of the
+    replicated groups, consolidation.  RCCL refuses two ranks on one device, so the ranks share cuda:0 and the collectives go
+    through gloo with host staging (distributed._staged); the arithmetic and the schedule are the product's.  Reference: one
+    process that runs both ranks' rays per step, accumulates the gradients and applies Adam to their mean.
+
+    One step pins the GRADIENT: after it exp_avg = 0.1 * mean gradient, and the two sides may differ by fp32 summation order
+    only (measured 1e-7 of the largest entry).  Three steps check the schedule (step counts, re-zeroing, owned levels,
+    consolidation); there Adam (eps 1e-15, scale-free) turns the rounding noise of near-zero gradients into lr-sized
+    differences on a vanishing fraction of the entries, so parameters are compared where the first moment is significant."""
+    a, b = _run_two_rank(tmp_path, 1)
+    for k in [k for k in a if k.endswith(".exp_avg")]:
+        scale = float(a[k].abs().max())
+        assert scale > 0 and float((a[k] - b[k]).abs().max()) <= 1e-5 * scale, (k, scale, float((a[k] - b[k]).abs().max()))
+    a, b = _run_two_rank(tmp_path, 3)
+    for k in a:
+        if k == "losses":
+            continue
+        d = (a[k] - b[k]).abs()
+        if k.endswith(".grad"):
+            assert float(b[k].abs().max()) == 0.0, k          # every gradient slot re-zeroed on the multi-rank side
+        elif k.endswith(".param"):
+            ea = a[k.replace("param", "exp_avg")].abs()
+            sig = ea > 1e-2 * float(ea.max())
+            info = (k, float(d[sig].max()), float(d.max()), int((d > 1e-5).sum()), d.numel())
+            assert float(d[sig].max()) <= 6e-5 and float(d.max()) <= 1.5e-3 and int((d > 1e-5).sum()) <= 2e-3 * d.numel(), info
+        else:
+            assert float(d.max()) <= 2e-3 * max(float(a[k].abs().max()), 1e-30), (k, float(d.max()))
