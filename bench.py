@@ -148,6 +148,8 @@ def main():
 
     rank, local_rank, world = D.init_distributed()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    # SNF_BENCH_DEVICE: ranks sharing one device (tests/test_model_gpu.py runs two gloo ranks on a 1-GPU box)
+    local_rank = int(os.environ.get("SNF_BENCH_DEVICE", local_rank))
     torch.cuda.set_device(local_rank)
     if os.environ.get("SNF_ADAM_LAUNCH"):  # tuning: "max_blocks,threads,unroll"
         from samnerf_amd import _lib

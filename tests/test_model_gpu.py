@@ -546,3 +546,25 @@ def test_two_ranks_on_one_gpu_match_accumulated_single_process(tmp_path):
             assert float(d[sig].max()) <= 6e-5 and float(d.max()) <= 1.5e-3 and int((d > 1e-5).sum()) <= 2e-3 * d.numel(), info
         else:
             assert float(d.max()) <= 2e-3 * max(float(a[k].abs().max()), 1e-30), (k, float(d.max()))
+
+
+def test_bench_with_two_ranks_sharing_the_gpu():
+    """bench.py --gpus 2 under the driver's launcher, both ranks on the one device of the box (gloo collectives with host staging):
+    the N > 1 flow end to end -- table-parallel grids, sharded exchange, barriers, max-over-ranks timing -- prints one JSON line
+    from rank 0 with the whole-job value (2 x rays per step)."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "SNF_FORCE_COLLECTIVES")}
+    env.update(SNF_DIST_BACKEND="gloo", SNF_BENCH_DEVICE="0")
+    port = str(29500 + os.getpid() % 90)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", port, os.path.join(root, "bench.py"),
+                          "--gpus", "2", "--steps", "3", "--warmup", "1", "--cpu-baseline-seconds", "0"],
+                         env=env, capture_output=True, text=True, timeout=1200, cwd=root)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-500:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["parallelism"] == "ray-dp2"
+    assert abs(d["value"] - 2 * 4096 * 128 / (d["ms_per_step"] * 1e-3)) <= 1e-3 * d["value"]
+    assert any(k.endswith("tp") for k in d["kernel_ms_per_step_serial"]), "the table-parallel path did not run"
