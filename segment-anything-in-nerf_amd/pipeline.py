@@ -188,6 +188,8 @@ class Trainer:
         use_side = self.overlap and torch.cuda.is_available() and "sam_field" in opt.arenas
         if use_side and self._side is None:
             self._side = {"sam": torch.cuda.Stream(), "clipseg": torch.cuda.Stream()}
+            if os.environ.get("SNF_HEADS_ONE_STREAM", "0") == "1":  # A/B: both heads on one side stream
+                self._side["clipseg"] = self._side["sam"]
         if hasattr(model, "feature_streams"):
             model.feature_streams = self._side if use_side else None
         _, loss_dict, metrics_dict = self.pipeline.get_train_loss_dict(step=step)
