@@ -531,9 +531,10 @@ static int ws_try(const float* A, const float* Aux, const float* W, const float*
                   int ldw, int ldc, int act_in, int act_out, float* C, snf_stream_t stream) {
     static const int on = getenv("SNF_GEMM_WS") ? atoi(getenv("SNF_GEMM_WS")) : 1;
     if (!on || (K % 16) || K > 256 || K < 64 || M < 4096 || Nc < 64 || (Nc % 4) || (lda % 4)) return 0;
-    // variants: 0 = BN 128, 8 waves x 32 rows, 4 k-steps of loads in flight (default); 1 = BN 64, 4 waves x 64 rows; 2 / 3 = as 0 with 8 / 2 k-steps in flight
+    // BN 128, 8 waves x 32 rows, 4 k-steps of A loads in flight (2 and 8 measured the same: the loads are not latency-bound);
+    // narrow outputs (Nc <= 64) and SNF_GEMM_WS_VARIANT=1 take BN 64 with 4 waves x 64 rows (two workgroups per CU)
     static const int variant = getenv("SNF_GEMM_WS_VARIANT") ? atoi(getenv("SNF_GEMM_WS_VARIANT")) : 0;
-    const int v = (Nc <= 64) ? 1 : variant;
+    const int v = (Nc <= 64 || variant == 1) ? 1 : 0;
     const int bn = v == 1 ? 64 : 128, tile_rows = 256;
     const size_t lds = (size_t)2 * bn * (K + 8) * sizeof(uint16_t);
     const int gy = ceil_div(Nc, bn), tiles = ceil_div(M, tile_rows);
@@ -543,9 +544,7 @@ static int ws_try(const float* A, const float* Aux, const float* W, const float*
     if (gx > tiles) gx = tiles;
     dim3 grid(gx, gy);
     if (v == 0) ws_launch<BT, DERIV, 128, 1, 512, 4>(grid, lds, stream, A, Aux, W, bias, M, K, Nc, lda, ldaux, ldw, ldc, act_in, act_out, C);
-    else if (v == 1) ws_launch<BT, DERIV, 64, 2, 256, 2>(grid, lds, stream, A, Aux, W, bias, M, K, Nc, lda, ldaux, ldw, ldc, act_in, act_out, C);
-    else if (v == 3) ws_launch<BT, DERIV, 128, 1, 512, 2>(grid, lds, stream, A, Aux, W, bias, M, K, Nc, lda, ldaux, ldw, ldc, act_in, act_out, C);
-    else ws_launch<BT, DERIV, 128, 1, 512, 8>(grid, lds, stream, A, Aux, W, bias, M, K, Nc, lda, ldaux, ldw, ldc, act_in, act_out, C);
+    else ws_launch<BT, DERIV, 64, 2, 256, 2>(grid, lds, stream, A, Aux, W, bias, M, K, Nc, lda, ldaux, ldw, ldc, act_in, act_out, C);
     return 1;
 }
 
