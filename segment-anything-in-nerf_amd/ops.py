@@ -101,12 +101,22 @@ def kernel_timeline(base_event) -> list:
     return sorted(out)
 
 
+_FN: dict = {}  # C-ABI entry points by name (one attribute lookup on the ctypes library per name)
+
+
 def _launch(name: str, *args, tag: str = "", units: float = 0.0) -> None:
     """`units`: algorithmic bytes / flops of this launch when the caller knows them (summed by kernel_timing_summary)."""
-    fn = getattr(_L(), name)
+    fn = _FN.get(name)
+    if fn is None:
+        fn = _FN[name] = getattr(_L(), name)
     sel = _TIMING["names"]
+    if sel is None:  # the hot path: no timing bookkeeping, no key formatting
+        rc = fn(*args)
+        if rc:
+            _lib.check(rc, name)
+        return
     key = name + ("/" + tag if tag else "")
-    if sel is not None and (sel == "all" or key in sel or name in sel):
+    if sel == "all" or key in sel or name in sel:
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         rc = fn(*args)

@@ -15,4 +15,4 @@ for i in range(20):
 pr.disable()
 torch.cuda.synchronize()
 st = pstats.Stats(pr)
-st.sort_stats("tottime").print_stats(28)
+st.sort_stats("tottime").print_stats(int(os.environ.get("TOPN", "28")))
