@@ -125,7 +125,12 @@ def cpu_baseline(w: dict, budget_s: float):
         el = time.perf_counter() - t0
         if el + t_w >= budget_s or n >= 10:
             break
+    try:  # core count and CPU model of the box beside the number
+        model = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
+    except (OSError, StopIteration):
+        model = "unknown"
     return {"value": R * w["S"] * n / el, "unit": "ray-samples/s", "cores": torch.get_num_threads(), "kind": "port",
+            "cpu_model": model, "host_cores": os.cpu_count(),
             "sample": f"{n} fwd+bwd steps of {R} rays x {w['S']} samples (P={w['P']}, K={w['K']}), full-size fp32 "
                       f"tables, no optimizer step, {el:.1f} s of CPU work"}
 
