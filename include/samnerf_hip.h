@@ -116,8 +116,9 @@ int snf_hashgrid_bwd_presorted_adam(const float* grad_out, int N, int L, int F, 
                                     float beta1, float beta2, float eps, int step, float grad_scale, snf_stream_t stream);
 
 /* Arithmetic of the wide (>= 128 input) dense layers: 1 (default) = bf16 3-term split on the bf16 matrix cores with fp32
- * accumulate (max abs error ~1e-6 on head-shaped data, 1/5 of the matrix cycles), 0 = exact fp32 matrix cores.
- * Process-wide; narrow layers always run exact fp32. */
+ * accumulate (max abs error ~1e-6 on head-shaped data, 1/5 of the matrix cycles), 0 = exact fp32 matrix cores,
+ * 2 = as 1 and the fused 64-wide chains (snf_mlp64_*) on the same split (opt-in: -9 % on those kernels, 6x their round-off).
+ * Process-wide; other narrow layers always run exact fp32. */
 int snf_set_gemm_mode(int mode);
 int snf_get_gemm_mode(void);
 

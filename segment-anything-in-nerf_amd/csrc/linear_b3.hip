@@ -565,14 +565,15 @@ static int b3_pick_bn(int M, int Nc) {
 
 static int g_gemm_mode = 1;  // 1: bf16x3 for the wide layers (default), 0: exact fp32 everywhere
 
-bool b3_enabled() { return g_gemm_mode == 1; }
+bool b3_enabled() { return g_gemm_mode >= 1; }
 
 }  // namespace snf
 
 using namespace snf;
 
 extern "C" int snf_set_gemm_mode(int mode) {
-    SNF_REQUIRE(mode == 0 || mode == 1, "snf_set_gemm_mode: mode must be 0 (fp32) or 1 (bf16x3 on wide layers)");
+    SNF_REQUIRE(mode >= 0 && mode <= 2,
+                "snf_set_gemm_mode: mode must be 0 (fp32), 1 (bf16x3 on the wide layers) or 2 (1 + bf16x3 64-wide chains)");
     g_gemm_mode = mode;
     return SNF_OK;
 }

@@ -16,6 +16,7 @@
 //   backward: dY -> dH2 -> dH1 -> dX          (data-gradient chain; ReLU masks from the stored activations)
 // Weight gradients are three tall-skinny GEMMs over the (pre-masked) dH / H pairs (linear.hip).
 #include "common.hpp"
+#include <stdlib.h>
 
 namespace snf {
 
@@ -284,6 +285,261 @@ __global__ __launch_bounds__(256) void k_mlp_chain_bwd(const float* __restrict__
     }
 }
 
+// ==================================================================================================================
+// The same chains on the bf16 matrix cores with the 3-term split (hi*hi + hi*lo + lo*hi, fp32 accumulate; linear_b3.hip has
+// the error analysis): a 64 -> 64 layer is 24 v_mfma_f32_32x32x16_bf16 (768 cycles) instead of 64 v_mfma_f32_32x32x2_f32
+// (4096 cycles) -- the fp32 chains ran at 22-31 % of the fp32 matrix peak and were bound by exactly that.
+//
+// The register trick carries over.  A 32x32x16 MFMA wants from lane (n, half) the 8 k-values 8*half .. 8*half+7 of its k-step
+// as one bf16x8 B operand.  The accumulator of the previous layer holds, in lane (n, half), rows
+// row(r, half) = (r&3) + 8*(r>>2) + 4*half for r = 0..15: registers 8s .. 8s+7 are 8 rows, and over the two halves they are
+// 16 DISTINCT rows -- a valid k-step.  So k-step s of the next layer uses registers 8s .. 8s+7 (split to hi / lo in
+// registers) as its B operand, and the weight planes in LDS are stored with their k axis permuted to match
+// (slot (t, s, half, j) <-> input t*32 + row(8s + j, half)): still no transposes, no LDS round trip, no barriers.
+// snf_set_gemm_mode(0) / SNF_MLP64_B3=0 select the exact-fp32 chains above.
+typedef __bf16 mc_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 mc_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float mc_f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t mc_cvt_pk(float a, float b) {
+    const mc_f32x2 v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, mc_bf16x2));
+}
+
+__device__ __forceinline__ void mc_split2(float x0, float x1, uint32_t& hi, uint32_t& lo) {
+    hi = mc_cvt_pk(x0, x1);
+    lo = mc_cvt_pk(x0 - __uint_as_float(hi << 16), x1 - __uint_as_float(hi & 0xFFFF0000u));
+}
+
+constexpr int MC_BP32 = 40;  // bf16 elements per plane row with 32 k-slots (80 B: conflict-free b128 reads)
+constexpr int MC_BP64 = 72;  // ... with 64 k-slots (144 B)
+
+// k-slot -> input index.  LIN: the input is 16 floats per half-wave lane (feature half*16 + i): slot = s*16 + half*8 + j.
+// otherwise the input is an accumulator tile set: slot = t*32 + s*16 + half*8 + j -> t*32 + row(8s + j, half).
+template <bool LIN>
+__device__ __forceinline__ int mc_slot_k(int slot) {
+    const int j = slot & 7, half = (slot >> 3) & 1, s = (slot >> 4) & 1, t = slot >> 5;
+    if constexpr (LIN) return half * 16 + 8 * s + j;
+    return t * 32 + krow(8 * s + j, half);
+}
+
+// planes[m][slot] = split(get(m, k(slot))) for m < rows, slot < slots (slots even)
+template <bool LIN, class G>
+__device__ __forceinline__ void mc_stage(uint16_t* __restrict__ Ph, uint16_t* __restrict__ Pl, int pitch, int rows, int slots,
+                                         G get) {
+    const int pairs = slots >> 1;
+    for (int i = threadIdx.x; i < rows * pairs; i += blockDim.x) {
+        const int m = i / pairs, sl = (i - m * pairs) * 2;
+        uint32_t h, l;
+        mc_split2(get(m, mc_slot_k<LIN>(sl)), get(m, mc_slot_k<LIN>(sl + 1)), h, l);
+        *reinterpret_cast<uint32_t*>(&Ph[m * pitch + sl]) = h;
+        *reinterpret_cast<uint32_t*>(&Pl[m * pitch + sl]) = l;
+    }
+}
+
+// out[u] (u < NU tiles of 32 output rows) = W * act, act = NT tiles of 32 inputs in accumulator layout (or, LIN, one
+// register set of 16 floats per half)
+template <int NT, int NU, bool LIN>
+__device__ __forceinline__ void mc_layer_b3(const uint16_t* __restrict__ Ph, const uint16_t* __restrict__ Pl, int pitch,
+                                            const f32x16 (&act)[NT], f32x16 (&out)[NU], int li, int half) {
+#pragma unroll
+    for (int u = 0; u < NU; ++u) out[u] = zero16();
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            uint32_t h[4], l[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) mc_split2(act[t][8 * s + 2 * p], act[t][8 * s + 2 * p + 1], h[p], l[p]);
+            const mc_bf16x8 bh = __builtin_bit_cast(mc_bf16x8, make_uint4(h[0], h[1], h[2], h[3]));
+            const mc_bf16x8 bl = __builtin_bit_cast(mc_bf16x8, make_uint4(l[0], l[1], l[2], l[3]));
+            const int slot0 = t * 32 + s * 16 + half * 8;
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                const mc_bf16x8 ah = *reinterpret_cast<const mc_bf16x8*>(&Ph[(u * 32 + li) * pitch + slot0]);
+                const mc_bf16x8 al = *reinterpret_cast<const mc_bf16x8*>(&Pl[(u * 32 + li) * pitch + slot0]);
+                out[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, out[u], 0, 0, 0);
+                out[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, out[u], 0, 0, 0);
+                out[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, out[u], 0, 0, 0);
+            }
+        }
+    }
+}
+
+constexpr int chain_b3_lds_elems(int NH) {  // bf16 elements, both planes of every matrix
+    return 2 * (MC_H * MC_BP32 + (NH == 2 ? MC_H * MC_BP64 : 0) + 32 * MC_BP64);
+}
+
+template <int NH>
+__global__ __launch_bounds__(256) void k_mlp_chain_fwd_b3(const float* __restrict__ X, int ldx, const float* __restrict__ W0,
+                                                          int in_real, const float* __restrict__ W1,
+                                                          const float* __restrict__ Wout, int out, int out_act, long long N,
+                                                          float* __restrict__ H1, float* __restrict__ H2,
+                                                          float* __restrict__ Y, int ldy) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t ldsb[];
+    uint16_t* p0h = ldsb;                          // W0  [64][MC_BP32]  LIN slots over the 32 inputs
+    uint16_t* p0l = p0h + MC_H * MC_BP32;
+    uint16_t* p1h = p0l + MC_H * MC_BP32;          // W1  [64][MC_BP64]  (NH == 2)
+    uint16_t* p1l = p1h + (NH == 2 ? MC_H * MC_BP64 : 0);
+    uint16_t* poh = p1l + (NH == 2 ? MC_H * MC_BP64 : 0);  // Wout [32][MC_BP64], rows >= out zero
+    uint16_t* pol = poh + 32 * MC_BP64;
+    mc_stage<true>(p0h, p0l, MC_BP32, MC_H, MC_IN, [&](int m, int k) { return k < in_real ? W0[m * in_real + k] : 0.f; });
+    if constexpr (NH == 2) mc_stage<false>(p1h, p1l, MC_BP64, MC_H, MC_H, [&](int m, int k) { return W1[m * MC_H + k]; });
+    mc_stage<false>(poh, pol, MC_BP64, 32, MC_H, [&](int m, int k) { return m < out ? Wout[m * MC_H + k] : 0.f; });
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 31, half = lane >> 5;
+    const long long ntiles = (N + 31) / 32;
+    for (long long tile = (long long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long long)gridDim.x * 4) {
+        const long long s = tile * 32 + li;
+        const bool ok = s < N;
+        const long long sc = ok ? s : N - 1;
+        f32x16 x[1];
+        if (ldx == 0) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float2 v = *reinterpret_cast<const float2*>(X + ((long long)(half * 8 + q) * N + sc) * 2);
+                x[0][2 * q] = v.x; x[0][2 * q + 1] = v.y;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 v = *reinterpret_cast<const float4*>(X + sc * ldx + half * 16 + 4 * q);
+                x[0][4 * q] = v.x; x[0][4 * q + 1] = v.y; x[0][4 * q + 2] = v.z; x[0][4 * q + 3] = v.w;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (half * 16 + i >= in_real) x[0][i] = 0.f;  // pad columns may hold anything (select, not multiply)
+        f32x16 h1[2];
+        mc_layer_b3<1, 2, true>(p0h, p0l, MC_BP32, x, h1, li, half);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) h1[t][r] = fmaxf(h1[t][r], 0.f);
+        if (H1 != nullptr && ok) store_h64(H1, s, h1, half);
+        f32x16 last[2];
+        if constexpr (NH == 2) {
+            mc_layer_b3<2, 2, false>(p1h, p1l, MC_BP64, h1, last, li, half);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) last[t][r] = fmaxf(last[t][r], 0.f);
+            if (H2 != nullptr && ok) store_h64(H2, s, last, half);
+        } else {
+            last[0] = h1[0];
+            last[1] = h1[1];
+        }
+        f32x16 y[1];
+        mc_layer_b3<2, 1, false>(poh, pol, MC_BP64, last, y, li, half);
+        if (ok) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = krow(r, half);
+                if (o < out) {
+                    float v = y[0][r];
+                    if (out_act == SNF_ACT_SIGMOID) v = 1.f / (1.f + expf(-v));
+                    else if (out_act == SNF_ACT_RELU) v = fmaxf(v, 0.f);
+                    Y[s * ldy + o] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int NH>
+__global__ __launch_bounds__(256) void k_mlp_chain_bwd_b3(const float* __restrict__ dY, int lddy, int dy_col_off,
+                                                          const float* __restrict__ dY0, const float* __restrict__ Yout,
+                                                          int ldy, const float* __restrict__ W0, int in_real,
+                                                          const float* __restrict__ W1, const float* __restrict__ Wout,
+                                                          int out, int out_act, long long N, const float* __restrict__ H1,
+                                                          const float* __restrict__ H2, float* __restrict__ dH1,
+                                                          float* __restrict__ dH2, float* __restrict__ dZout, int lddz,
+                                                          float* __restrict__ dX, int lddx) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t ldsb[];
+    uint16_t* poh = ldsb;                          // Wout^T [64 hidden][MC_BP32]  LIN slots over the (<= 32) outputs
+    uint16_t* pol = poh + MC_H * MC_BP32;
+    uint16_t* p1h = pol + MC_H * MC_BP32;          // W1^T   [64][MC_BP64]  (NH == 2)
+    uint16_t* p1l = p1h + (NH == 2 ? MC_H * MC_BP64 : 0);
+    uint16_t* p0h = p1l + (NH == 2 ? MC_H * MC_BP64 : 0);  // W0^T [32 inputs][MC_BP64], rows >= in_real zero
+    uint16_t* p0l = p0h + 32 * MC_BP64;
+    mc_stage<true>(poh, pol, MC_BP32, MC_H, 32, [&](int k, int o) { return o < out ? Wout[o * MC_H + k] : 0.f; });
+    if constexpr (NH == 2) mc_stage<false>(p1h, p1l, MC_BP64, MC_H, MC_H, [&](int k1, int k2) { return W1[k2 * MC_H + k1]; });
+    mc_stage<false>(p0h, p0l, MC_BP64, 32, MC_H, [&](int i, int k1) { return i < in_real ? W0[k1 * in_real + i] : 0.f; });
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 31, half = lane >> 5;
+    const long long ntiles = (N + 31) / 32;
+    for (long long tile = (long long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long long)gridDim.x * 4) {
+        const long long s = tile * 32 + li;
+        const bool ok = s < N;
+        const long long sc = ok ? s : N - 1;
+        // ---- dZ of this lane's 16 outputs (o = half*16 + i), then dLast^T[k][s] = sum_o Wout[o][k] dZ^T[o][s]
+        f32x16 dzv[1];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int o = half * 16 + i;
+            float dz = 0.f;
+            if (o < out) {
+                dz = (o == 0 && dY0 != nullptr) ? dY0[sc] : dY[sc * lddy + dy_col_off + o];
+                if (out_act == SNF_ACT_SIGMOID) {
+                    const float yv = Yout[sc * ldy + o];
+                    dz *= yv * (1.f - yv);
+                }
+                if (dZout != nullptr && ok) dZout[s * lddz + o] = dz;  // pre-activation output gradient, for the wgrad GEMM
+            }
+            dzv[0][i] = dz;
+        }
+        f32x16 dl[2];
+        mc_layer_b3<1, 2, true>(poh, pol, MC_BP32, dzv, dl, li, half);
+        f32x16 hh[2];
+        if constexpr (NH == 2) {
+            load_h64(H2, sc, hh, half);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dl[t][r] = hh[t][r] > 0.f ? dl[t][r] : 0.f;
+            if (ok) store_h64(dH2, s, dl, half);
+            f32x16 d1[2];
+            mc_layer_b3<2, 2, false>(p1h, p1l, MC_BP64, dl, d1, li, half);
+            dl[0] = d1[0];
+            dl[1] = d1[1];
+        }
+        load_h64(H1, sc, hh, half);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dl[t][r] = hh[t][r] > 0.f ? dl[t][r] : 0.f;
+        if (ok) store_h64(dH1, s, dl, half);
+        if (dX != nullptr) {
+            f32x16 dxv[1];
+            mc_layer_b3<2, 1, false>(p0h, p0l, MC_BP64, dl, dxv, li, half);
+            const f32x16 dx = dxv[0];
+            if (ok) {
+                if (lddx == 0) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const long long lv = 4 * q + 2 * half;
+                        *reinterpret_cast<float2*>(dX + (lv * N + s) * 2) = make_float2(dx[4 * q], dx[4 * q + 1]);
+                        *reinterpret_cast<float2*>(dX + ((lv + 1) * N + s) * 2) = make_float2(dx[4 * q + 2], dx[4 * q + 3]);
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        *reinterpret_cast<float4*>(dX + s * lddx + 8 * q + 4 * half) =
+                            make_float4(dx[4 * q], dx[4 * q + 1], dx[4 * q + 2], dx[4 * q + 3]);
+                }
+            }
+        }
+    }
+}
+
+// opt-in (snf_set_gemm_mode(2)): measured on the train step's two nets against the fp32 chains -- colour net forward
+// 0.131 -> 0.087 ms, base net forward 0.104 -> 0.090, colour net backward 0.189 -> 0.168, base net backward 0.130 -> 0.161
+// (its chain starts from <= 16 output gradients padded to a 32-wide k-step), step time -1 %: with the matrix work cut 5x the
+// chains are bound by their hidden-activation traffic, and the 6x larger round-off is not worth 1 %.
+static bool chain_b3_on() { return snf_get_gemm_mode() == 2; }
+
 }  // namespace snf
 
 using namespace snf;
@@ -309,7 +565,14 @@ extern "C" int snf_mlp64_fwd(const float* X, int ldx, const float* W0, int in_re
     const long long ntiles = (N + 31) / 32;
     long long blocks = (ntiles + 3) / 4;
     if (blocks > 256 * 4) blocks = 256 * 4;  // persistent: <= 4 workgroups per CU
-    if (n_hidden == 2)
+    if (chain_b3_on()) {
+        if (n_hidden == 2)
+            hipLaunchKernelGGL(k_mlp_chain_fwd_b3<2>, dim3((unsigned)blocks), dim3(256), chain_b3_lds_elems(2) * sizeof(uint16_t),
+                               (hipStream_t)stream, X, ldx, W0, in_real, W1, Wout, out, out_act, (long long)N, H1, H2, Y, ldy);
+        else
+            hipLaunchKernelGGL(k_mlp_chain_fwd_b3<1>, dim3((unsigned)blocks), dim3(256), chain_b3_lds_elems(1) * sizeof(uint16_t),
+                               (hipStream_t)stream, X, ldx, W0, in_real, W1, Wout, out, out_act, (long long)N, H1, H2, Y, ldy);
+    } else if (n_hidden == 2)
         hipLaunchKernelGGL(k_mlp_chain_fwd<2>, dim3((unsigned)blocks), dim3(256), chain_lds_floats(2) * sizeof(float),
                            (hipStream_t)stream, X, ldx, W0, in_real, W1, Wout, out, out_act, (long long)N, H1, H2, Y, ldy);
     else
@@ -335,7 +598,16 @@ extern "C" int snf_mlp64_bwd_data(const float* dY, int lddy, int dy_col_off, con
     const long long ntiles = (N + 31) / 32;
     long long blocks = (ntiles + 3) / 4;
     if (blocks > 256 * 4) blocks = 256 * 4;
-    if (n_hidden == 2)
+    if (chain_b3_on()) {
+        if (n_hidden == 2)
+            hipLaunchKernelGGL(k_mlp_chain_bwd_b3<2>, dim3((unsigned)blocks), dim3(256), chain_b3_lds_elems(2) * sizeof(uint16_t),
+                               (hipStream_t)stream, dY, lddy, dy_col_off, dY0, Y, ldy, W0, in_real, W1, Wout, out, out_act,
+                               (long long)N, H1, H2, dH1, dH2, dZ, lddz, dX, lddx);
+        else
+            hipLaunchKernelGGL(k_mlp_chain_bwd_b3<1>, dim3((unsigned)blocks), dim3(256), chain_b3_lds_elems(1) * sizeof(uint16_t),
+                               (hipStream_t)stream, dY, lddy, dy_col_off, dY0, Y, ldy, W0, in_real, W1, Wout, out, out_act,
+                               (long long)N, H1, H2, dH1, dH2, dZ, lddz, dX, lddx);
+    } else if (n_hidden == 2)
         hipLaunchKernelGGL(k_mlp_chain_bwd<2>, dim3((unsigned)blocks), dim3(256), chain_lds_floats(2) * sizeof(float),
                            (hipStream_t)stream, dY, lddy, dy_col_off, dY0, Y, ldy, W0, in_real, W1, Wout, out, out_act,
                            (long long)N, H1, H2, dH1, dH2, dZ, lddz, dX, lddx);

@@ -128,8 +128,9 @@ def _launch(name: str, *args, tag: str = "", units: float = 0.0) -> None:
 
 
 def set_gemm_mode(mode: str) -> None:
-    """'bf16x3' (default: wide layers on the bf16 matrix cores, 3-term split, fp32 accumulate) or 'fp32' (exact)."""
-    _lib.check(_L().snf_set_gemm_mode({"fp32": 0, "bf16x3": 1}[mode]), "snf_set_gemm_mode")
+    """'bf16x3' (default: wide layers on the bf16 matrix cores, 3-term split, fp32 accumulate), 'fp32' (exact) or
+    'bf16x3+chains' (the fused 64-wide MLPs on the split as well)."""
+    _lib.check(_L().snf_set_gemm_mode({"fp32": 0, "bf16x3": 1, "bf16x3+chains": 2}[mode]), "snf_set_gemm_mode")
 
 
 # ---------------------------------------------------------------------------------------------
