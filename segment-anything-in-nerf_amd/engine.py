@@ -126,6 +126,13 @@ class Optimizers:
                     a.param[off:off + n], a.exp_avg[off:off + n], a.exp_avg_sq[off:off + n], self.lr(k), oc.betas[0],
                     oc.betas[1], oc.eps, self.step_count[k] + 1, 1.0 / D.world_size(), n_sparse)
 
+    def disarm_fused_adam(self) -> None:
+        """End of a train step (everything is enqueued): a backward run outside train_iteration must not step the tables
+        with this step's hyper-parameters."""
+        for a in self.arenas.values():
+            for enc in a.tables.values():
+                enc.params._fused_adam = None
+
     def _take_fused(self, k: str, lo: int, hi: int, t: int) -> list:
         """Arena element ranges of group `k` inside [lo, hi) that this step's backward has already stepped."""
         a, out = self.arenas[k], []

@@ -258,6 +258,7 @@ class Trainer:
                 else:
                     opt.exchange_and_step(g)
             loss = loss.detach()
+        opt.disarm_fused_adam()
         opt.scheduler_step_all(step)
         for cb in self.callbacks:
             cb.run_callback_at_location(step, AFTER_TRAIN_ITERATION)
