@@ -134,13 +134,46 @@ def set_gemm_mode(mode: str) -> None:
 
 
 # ---------------------------------------------------------------------------------------------
+# stream factory
+# ---------------------------------------------------------------------------------------------
+# The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES (4) hardware queues, and which streams share a queue changes the
+# step time by up to 15 %.  The step therefore runs on exactly 4 streams by default (main, two heads, the forward-time sort).
+# All streams are made here, by name; STREAM_SLOTS[name] = position modulo 4 in the creation sequence (unused filler streams
+# are created to reach it) is a tuning hook for runs with more streams (SNF_WGRAD_SIDE=1).
+STREAM_SLOTS = {"sam": 0, "clipseg": 1, "presort": 2, "wgrad:sam": 3, "wgrad:clipseg": 0, "wgrad:main": 1}
+if _os.environ.get("SNF_STREAM_SLOTS"):
+    STREAM_SLOTS.update({k: int(v) for k, v in (kv.split("=") for kv in _os.environ["SNF_STREAM_SLOTS"].split(","))})
+_STREAMS_MADE = {"n": 0, "filler": [], "names": {}}
+
+
+def make_stream(name: str) -> "torch.cuda.Stream":
+    slot = STREAM_SLOTS.get(name)
+    if slot is not None:
+        while _STREAMS_MADE["n"] % 4 != slot % 4:
+            _STREAMS_MADE["filler"].append(torch.cuda.Stream())
+            _STREAMS_MADE["n"] += 1
+    st = torch.cuda.Stream()
+    _STREAMS_MADE["n"] += 1
+    _STREAMS_MADE["names"][st.stream_id] = name
+    return st
+
+
+def stream_name(st) -> str:
+    return _STREAMS_MADE["names"].get(st.stream_id, "main")
+
+
+# ---------------------------------------------------------------------------------------------
 # weight gradients on a companion stream
 # ---------------------------------------------------------------------------------------------
 # A layer's weight gradient feeds nothing but the optimizer, while its data gradient is on the backward's dependency chain.
 # With WGRAD_SIDE_STREAM on, every snf_linear_bwd_weight launch of a task goes to a companion HIP stream of the task's
 # stream and runs beside the following data-gradient kernels; the optimizer joins the companion before it steps
 # (join_wgrad_stream, called by engine.Optimizers.exchange_and_step).
-WGRAD_SIDE_STREAM = _os.environ.get("SNF_WGRAD_SIDE", "1") == "1"
+# Off by default since r01p: with the companions the step runs on 7 streams, the runtime multiplexes them onto its 4 hardware
+# queues differently from run to run, and about one run in three lands in a 5-15 % slower mode (8 + 8 interleaved runs on one
+# box: 3.84-3.94 ms without companions, 3.87-4.58 ms with); on exactly 4 streams every run is in the fast mode, and the
+# companions' own gain (-1.5 % when measured in r01m) is gone since the table Adam moved into the backward.
+WGRAD_SIDE_STREAM = _os.environ.get("SNF_WGRAD_SIDE", "0") == "1"
 _WGRAD_STREAMS: dict = {}
 
 
@@ -201,7 +234,7 @@ class _wgrad_stream:
                 return self
             side = _WGRAD_STREAMS.get(cur.stream_id)
             if side is None:
-                side = _WGRAD_STREAMS[cur.stream_id] = torch.cuda.Stream()
+                side = _WGRAD_STREAMS[cur.stream_id] = make_stream("wgrad:" + stream_name(cur))
             _WGRAD_PENDING.append((cur, side))
         side = _WGRAD_STREAMS[cur.stream_id]
         side.wait_stream(cur)
@@ -351,7 +384,7 @@ def hashgrid_presort(u: torch.Tensor, sc: torch.Tensor, L: int, T: int, side_str
         cache[key] = (ws, None)
         return
     cur = torch.cuda.current_stream()
-    st = _PRESORT_STREAM.setdefault(u.device.index, None) or torch.cuda.Stream()
+    st = _PRESORT_STREAM.setdefault(u.device.index, None) or make_stream("presort")
     _PRESORT_STREAM[u.device.index] = st
     st.wait_stream(cur)  # the positions are ready
     with torch.cuda.stream(st):

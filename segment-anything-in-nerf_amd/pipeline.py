@@ -187,7 +187,8 @@ class Trainer:
         model = self.pipeline.model
         use_side = self.overlap and torch.cuda.is_available() and "sam_field" in opt.arenas
         if use_side and self._side is None:
-            self._side = {"sam": torch.cuda.Stream(), "clipseg": torch.cuda.Stream()}
+            from . import ops
+            self._side = {"sam": ops.make_stream("sam"), "clipseg": ops.make_stream("clipseg")}
             if os.environ.get("SNF_HEADS_ONE_STREAM", "0") == "1":  # A/B: both heads on one side stream
                 self._side["clipseg"] = self._side["sam"]
         if hasattr(model, "feature_streams"):
