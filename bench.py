@@ -163,6 +163,9 @@ def main():
     trainer = build_trainer(w, local_rank, world)
 
     multi = dist.is_initialized()  # world > 1 (or SNF_FORCE_COLLECTIVES=1 under torchrun: RCCL paths on one GPU)
+    # untimed, before the warm-up: the trainer times its two stream layouts on this device and keeps the faster one
+    # (Trainer.autotune_streams; SNF_AUTOTUNE_STREAMS=0 keeps the default layout)
+    stream_probe = trainer.autotune_streams() if os.environ.get("SNF_AUTOTUNE_STREAMS", "1") == "1" else {}
 
     def barrier():
         if multi:
@@ -178,7 +181,7 @@ def main():
     n_break = 3
     torch.cuda.synchronize()
     trainer.overlap = False
-    ops.PRESORT_SIDE_STREAM = False  # keep the replay on one stream
+    presort_side, ops.PRESORT_SIDE_STREAM = ops.PRESORT_SIDE_STREAM, False  # keep the replay on one stream
     wgrad_side, ops.WGRAD_SIDE_STREAM = ops.WGRAD_SIDE_STREAM, False
     ops.enable_kernel_timing("all")
     for i in range(n_break):
@@ -187,7 +190,7 @@ def main():
     breakdown = ops.kernel_timing_summary()
     ops.enable_kernel_timing(None)
     trainer.overlap = True
-    ops.PRESORT_SIDE_STREAM = True
+    ops.PRESORT_SIDE_STREAM = presort_side
     ops.WGRAD_SIDE_STREAM = wgrad_side
     trainer.train_iteration(step)  # back on the concurrent schedule before timing starts
     step += 1
@@ -311,6 +314,7 @@ def main():
             "step_frac_of_hbm_peak": b_step / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
             "roofline": roofline,
             "roofline_other_kernels": others,
+            "stream_layout_probe_ms": {k: round(v, 3) for k, v in stream_probe.items()},
             "serial_step_ms": round(sum(per_step.values()), 3),
             "kernel_ms_per_step_serial": {k: round(v, 4) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1])},
         }

@@ -23,7 +23,7 @@ import os as _os
 HASHGRID_BWD_MODE = "sorted"  # "sorted": bucketed, atomic-free (default) | "atomic": global fp32 atomics
 PRESORT_FIELD_GRID = _os.environ.get("SNF_PRESORT_FIELD", "1") == "1"
 PLANAR_FIELD_ENCODING = _os.environ.get("SNF_PLANAR_FIELD", "1") == "1"
-PRESORT_SIDE_STREAM = True  # False: forward-time sorts stay on the caller's stream (bench.py's serial replay)
+PRESORT_SIDE_STREAM = _os.environ.get("SNF_PRESORT_SIDE", "1") == "1"  # False: forward-time sorts stay on the caller's stream (bench.py's serial replay)
 HASHGRID_RUN_MAX_RES = float(_os.environ.get("SNF_HG_RUN_MAX_RES", "64"))  # levels up to this resolution aggregate runs
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_GELU = 0, 1, 2, 3
 ACT_BY_NAME = {None: ACT_NONE, "None": ACT_NONE, "none": ACT_NONE, "ReLU": ACT_RELU, "relu": ACT_RELU,

@@ -568,3 +568,40 @@ def test_bench_with_two_ranks_sharing_the_gpu():
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["parallelism"] == "ray-dp2"
     assert abs(d["value"] - 2 * 4096 * 128 / (d["ms_per_step"] * 1e-3)) <= 1e-3 * d["value"]
     assert any(k.endswith("tp") for k in d["kernel_ms_per_step_serial"]), "the table-parallel path did not run"
+
+
+def test_autotune_streams_leaves_the_training_state_untouched():
+    """Trainer.autotune_streams times the stream layouts with real train steps and must hand back the exact state it found:
+    parameters, gradients, Adam moments, step counters, sampler counters and the random streams."""
+    import copy
+    from samnerf_amd import configs, ops
+    torch.manual_seed(0)
+    tc = copy.deepcopy(configs.method_configs["samnerf_distill"])
+    tc.pipeline.datamanager.train_num_rays_per_batch = 256
+    mc = tc.pipeline.model
+    mc.log2_hashmap_size, mc.hashgrid_sizes = 12, (12, 12)
+    mc.proposal_net_args_list = [dict(a, log2_hashmap_size=11) for a in mc.proposal_net_args_list]
+    trainer = tc.setup(device="cuda")
+    trainer.setup()
+    for step in range(2):
+        trainer.train_iteration(step)
+    trainer.synchronize()
+    torch.cuda.synchronize()
+    opt = trainer.optimizers
+    before = {k: [t.clone() for t in (a.param, a.grad, a.exp_avg, a.exp_avg_sq)] for k, a in opt.arenas.items()}
+    counts = (dict(opt.step_count), dict(opt.sched_step))
+    probe_rng = torch.rand(4, device="cuda").cpu()          # what the default generator yields next ...
+    torch.cuda.set_rng_state(torch.cuda.get_rng_state())     # (no-op; keeps the call pattern explicit)
+    rng_state = torch.cuda.get_rng_state()
+    side = ops.PRESORT_SIDE_STREAM
+    try:
+        res = trainer.autotune_streams(steps=2, warm=1)
+    finally:
+        ops.PRESORT_SIDE_STREAM = side
+    assert len(res) == 2 and all(v > 0 for v in res.values())
+    assert torch.equal(torch.cuda.get_rng_state(), rng_state)
+    assert (dict(opt.step_count), dict(opt.sched_step)) == counts
+    for k, a in opt.arenas.items():
+        for got, ref in zip((a.param, a.grad, a.exp_avg, a.exp_avg_sq), before[k]):
+            assert torch.equal(got, ref), k
+    del probe_rng
