@@ -296,7 +296,7 @@ __global__ __launch_bounds__(256) void k_mlp_chain_bwd(const float* __restrict__
 // 16 DISTINCT rows -- a valid k-step.  So k-step s of the next layer uses registers 8s .. 8s+7 (split to hi / lo in
 // registers) as its B operand, and the weight planes in LDS are stored with their k axis permuted to match
 // (slot (t, s, half, j) <-> input t*32 + row(8s + j, half)): still no transposes, no LDS round trip, no barriers.
-// snf_set_gemm_mode(0) / SNF_MLP64_B3=0 select the exact-fp32 chains above.
+// Opt-in: snf_set_gemm_mode(2) (see chain_b3_on below); modes 0 and 1 run the exact-fp32 chains above.
 typedef __bf16 mc_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 mc_bf16x2 __attribute__((ext_vector_type(2)));
 typedef float mc_f32x2 __attribute__((ext_vector_type(2)));
