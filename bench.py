@@ -163,9 +163,9 @@ def main():
     trainer = build_trainer(w, local_rank, world)
 
     multi = dist.is_initialized()  # world > 1 (or SNF_FORCE_COLLECTIVES=1 under torchrun: RCCL paths on one GPU)
-    # untimed, before the warm-up: the trainer times its two stream layouts on this device and keeps the faster one
-    # (Trainer.autotune_streams; SNF_AUTOTUNE_STREAMS=0 keeps the default layout)
-    stream_probe = trainer.autotune_streams() if os.environ.get("SNF_AUTOTUNE_STREAMS", "1") == "1" else {}
+    # SNF_AUTOTUNE_STREAMS=1: untimed, before the warm-up, the trainer times its two stream layouts on this device and keeps
+    # the faster one (Trainer.autotune_streams); by default the three-stream layout is used as is
+    stream_probe = trainer.autotune_streams() if os.environ.get("SNF_AUTOTUNE_STREAMS", "0") == "1" else {}
 
     def barrier():
         if multi:

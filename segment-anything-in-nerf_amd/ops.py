@@ -362,6 +362,9 @@ def _geometry_key(sc: torch.Tensor, L: int, T: int):
 
 
 _PRESORT_STREAM = {}
+# A task stream that is idle while the nerfacto forward runs (the trainer hands over a head's stream): the forward-time sorts
+# then need no stream of their own -- the step stays on three streams, one hardware queue each.
+PRESORT_HOST_STREAM = None
 
 
 @torch.no_grad()
@@ -384,8 +387,10 @@ def hashgrid_presort(u: torch.Tensor, sc: torch.Tensor, L: int, T: int, side_str
         cache[key] = (ws, None)
         return
     cur = torch.cuda.current_stream()
-    st = _PRESORT_STREAM.setdefault(u.device.index, None) or make_stream("presort")
-    _PRESORT_STREAM[u.device.index] = st
+    st = PRESORT_HOST_STREAM
+    if st is None:
+        st = _PRESORT_STREAM.setdefault(u.device.index, None) or make_stream("presort")
+        _PRESORT_STREAM[u.device.index] = st
     st.wait_stream(cur)  # the positions are ready
     with torch.cuda.stream(st):
         ws = torch.empty(((nbytes + 3) // 4,), device=u.device, dtype=torch.int32)

@@ -13,6 +13,7 @@ from typing import Any, Dict, List, Optional, Tuple, Type
 import torch
 
 from . import distributed as D
+from . import ops as ops_mod
 from .engine import AdamOptimizerConfig, ExponentialDecaySchedulerConfig, Optimizers
 from .model import (AFTER_TRAIN_ITERATION, BEFORE_TRAIN_ITERATION, InstantiateConfig, SAMModelConfig, SceneBox)
 from .rays import RayBundle
@@ -145,6 +146,7 @@ class Trainer:
         self.overlap = os.environ.get("SNF_OVERLAP", "1") == "1"
         self.enqueue_order = os.environ.get("SNF_ENQUEUE_ORDER", "heads_first")
         self.pipeline_steps = False  # True: do not join the head streams at the end of a step (see train_iteration)
+        self.presort_host = os.environ.get("SNF_PRESORT_ON", "sam")  # "sam" | "clipseg" | "own"
         self._side = None
 
     def setup(self, test_mode="val") -> None:
@@ -194,6 +196,11 @@ class Trainer:
                 self._side["clipseg"] = self._side["sam"]
         if hasattr(model, "feature_streams"):
             model.feature_streams = self._side if use_side else None
+        # the forward-time sorts ride on the SAM head's stream, which is idle until the nerfacto forward has produced the
+        # weights: three streams in all, one hardware queue each ("own": a fourth stream -- ~1 % faster when it works, 15 %
+        # slower in the runtime's slow mode)
+        host = self.presort_host
+        ops_mod.PRESORT_HOST_STREAM = self._side[host] if (use_side and host in ("sam", "clipseg")) else None
         _, loss_dict, metrics_dict = self.pipeline.get_train_loss_dict(step=step)
         prop_updated = getattr(getattr(model, "proposal_sampler", None), "last_updated", True)
         head_losses = {h: loss_dict[k] for h, k in self.HEAD_LOSS.items() if k in loss_dict}
@@ -269,9 +276,9 @@ class Trainer:
     def autotune_streams(self, steps: int = 10, warm: int = 3, verbose: bool = False) -> Dict[str, float]:
         """Pick the stream layout of the step on THIS device by timing it (like cudnn.benchmark picks an algorithm).
 
-        How the runtime spreads HIP streams over its hardware queues differs between otherwise identical boxes: with the
-        forward-time backward sorts on their own (fourth) stream most boxes are 2-3 % faster, some 15 % slower (measured
-        over many gpurun boxes).  Runs `warm + steps` real train iterations per candidate on the trainer's own data, keeps the
+        How the runtime spreads HIP streams over its hardware queues differs between otherwise identical boxes and between
+        runs: with the forward-time backward sorts on their own (fourth) stream a step is ~1 % faster most of the time and
+        15 % slower some of the time.  Runs `warm + steps` real train iterations per candidate on the trainer's own data, keeps the
         fastest, and restores parameters, optimizer state, step counters and random generators, so training starts from the
         state it would have started from without the probe."""
         from . import ops
@@ -286,8 +293,9 @@ class Trainer:
         cuda_rng, cpu_rng = torch.cuda.get_rng_state(), torch.get_rng_state()
         dm_count = getattr(dm, "train_count", None)
         results = {}
-        for name, presort_side in (("sorts on a fourth stream", True), ("sorts on the task streams", False)):
-            ops.PRESORT_SIDE_STREAM = presort_side
+        host0 = self.presort_host
+        for name, host in (("sorts on the sam stream", "sam"), ("sorts on a fourth stream", "own")):
+            self.presort_host = host
             for i in range(warm):
                 self.train_iteration(i)
             torch.cuda.synchronize()
@@ -297,7 +305,9 @@ class Trainer:
             torch.cuda.synchronize()
             results[name] = (time.perf_counter() - t0) / steps * 1e3
         best = min(results, key=results.get)
-        ops.PRESORT_SIDE_STREAM = best == "sorts on a fourth stream"
+        # a fourth stream has to win clearly: its slow mode comes and goes within a process
+        self.presort_host = "own" if results["sorts on a fourth stream"] < 0.97 * results["sorts on the sam stream"] else "sam"
+        del host0
         # back to the state before the probe
         for k, a in opt.arenas.items():
             for dst, src in zip((a.param, a.grad, a.exp_avg, a.exp_avg_sq), snap[k]):

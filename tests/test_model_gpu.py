@@ -593,11 +593,8 @@ def test_autotune_streams_leaves_the_training_state_untouched():
     probe_rng = torch.rand(4, device="cuda").cpu()          # what the default generator yields next ...
     torch.cuda.set_rng_state(torch.cuda.get_rng_state())     # (no-op; keeps the call pattern explicit)
     rng_state = torch.cuda.get_rng_state()
-    side = ops.PRESORT_SIDE_STREAM
-    try:
-        res = trainer.autotune_streams(steps=2, warm=1)
-    finally:
-        ops.PRESORT_SIDE_STREAM = side
+    res = trainer.autotune_streams(steps=2, warm=1)
+    assert trainer.presort_host in ("sam", "own")
     assert len(res) == 2 and all(v > 0 for v in res.values())
     assert torch.equal(torch.cuda.get_rng_state(), rng_state)
     assert (dict(opt.step_count), dict(opt.sched_step)) == counts
