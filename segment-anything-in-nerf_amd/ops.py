@@ -30,8 +30,15 @@ ACT_BY_NAME = {None: ACT_NONE, "None": ACT_NONE, "none": ACT_NONE, "ReLU": ACT_R
                "Sigmoid": ACT_SIGMOID, "sigmoid": ACT_SIGMOID}
 
 
+_GEMM_MODE_ENV = [_os.environ.get("SNF_GEMM_MODE")]  # "0" / "1" / "2": initial snf_set_gemm_mode (default 1), for A/B runs
+
+
 def _L():
-    return _lib.load()
+    lib = _lib.load()
+    if _GEMM_MODE_ENV[0] is not None:
+        mode, _GEMM_MODE_ENV[0] = int(_GEMM_MODE_ENV[0]), None
+        _lib.check(lib.snf_set_gemm_mode(mode), "snf_set_gemm_mode")
+    return lib
 
 
 def _p(t: Optional[torch.Tensor]):
