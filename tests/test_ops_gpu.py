@@ -195,8 +195,10 @@ def test_wide_layers_both_gemm_modes(mode):
     ops().set_gemm_mode(mode)
     try:
         # rows >= 4096 with K <= 256 take the weight-stationary kernel (ragged row tile, 192 = 1.5 column slices, bias)
+        # (256 -> 64 and 64 -> 256 hit the 64-column variant of that kernel in the forward / the data gradient)
         for (N, I, Oo, act, has_b) in [(5000, 192, 256, "relu", False), (4099, 256, 256, None, False),
-                                       (4500, 256, 192, "relu", True), (777, 256, 192, None, False)]:
+                                       (4500, 256, 192, "relu", True), (777, 256, 192, None, False),
+                                       (4200, 256, 64, "relu", True), (4200, 64, 256, "relu", False)]:
             x = torch.randn((N, I), generator=gen) * 0.05
             w = O._linear_init(Oo, I, gen)
             b = torch.randn((Oo,), generator=gen) * 0.1 if has_b else None
