@@ -44,13 +44,24 @@ __device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b) {
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
 
-// two fp32 -> packed hi pair and packed lo pair (lo = bf16(x - hi); inf - inf = NaN is flushed to 0: the value stays in hi)
-__device__ __forceinline__ void split2(float x0, float x1, uint32_t& hi, uint32_t& lo) {
+// two fp32 -> packed hi pair and packed lo pair (lo = bf16(x - hi)): 6 VALU instructions.  +-inf gives lo = NaN (inf - inf),
+// i.e. NaN where fp32 arithmetic gives +-inf or NaN; flushing that NaN cost 4 more instructions per pair in kernels whose
+// staging is VALU-bound (compile with -DSNF_B3_FLUSH_NAN to restore it).  NaN inputs propagate as NaN either way.
+__device__ __forceinline__ void split2_flush(float x0, float x1, uint32_t& hi, uint32_t& lo) {
     hi = cvt_pk_bf16(x0, x1);
     float r0 = x0 - __uint_as_float(hi << 16), r1 = x1 - __uint_as_float(hi & 0xFFFF0000u);
     r0 = (r0 == r0) ? r0 : 0.f;
     r1 = (r1 == r1) ? r1 : 0.f;
     lo = cvt_pk_bf16(r0, r1);
+}
+
+__device__ __forceinline__ void split2(float x0, float x1, uint32_t& hi, uint32_t& lo) {
+#ifdef SNF_B3_FLUSH_NAN
+    split2_flush(x0, x1, hi, lo);
+#else
+    hi = cvt_pk_bf16(x0, x1);
+    lo = cvt_pk_bf16(x0 - __uint_as_float(hi << 16), x1 - __uint_as_float(hi & 0xFFFF0000u));
+#endif
 }
 
 __device__ __forceinline__ void split_bf16(float x, uint32_t& hi, uint32_t& lo) {
