@@ -17,6 +17,7 @@
 // per-lane multiply, and P^T is already the B operand of O^T = V^T P^T -- the same transposed chaining as mlp_chain.hip.
 #include "common.hpp"
 #include <math.h>
+#include <stdlib.h>
 
 namespace snf {
 
@@ -252,6 +253,213 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same attention on the bf16 matrix cores with the 3-term split (hi*hi + hi*lo + lo*hi, fp32 accumulate): per 32-key tile
+// 36 v_mfma_f32_32x32x16_bf16 (1152 cycles) instead of 96 v_mfma_f32_32x32x2_f32 (6144 cycles) at head dim 80.
+//   S^T[key][query] = K Q^T : A = K rows from LDS planes [key][d] (b128 per fragment), B = the lane's query row, split once
+//                             per workgroup and pre-multiplied by the softmax scale;
+//   O^T[d][query]  += V^T P^T: the accumulator registers 8s..8s+7 of S^T (after the softmax: P^T) are a valid 16-wide k-step
+//                             over the keys vrow(8s + j, half) -- the same observation as in mlp_chain.hip -- so P^T is split
+//                             in registers, and V is staged transposed with its key axis in exactly that order
+//                             (planes [d][slot], slot = 16s + 8 half + j).
+// Online softmax, relative positions and masking are those of k_attention.
+typedef __bf16 at_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 at_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float at_f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t at_cvt_pk(float a, float b) {
+    const at_f32x2 v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, at_bf16x2));
+}
+
+__device__ __forceinline__ void at_split2(float x0, float x1, uint32_t& hi, uint32_t& lo) {
+    hi = at_cvt_pk(x0, x1);
+    lo = at_cvt_pk(x0 - __uint_as_float(hi << 16), x1 - __uint_as_float(hi & 0xFFFF0000u));
+}
+
+// key row kr (0..31) of a tile -> its k-slot in the P^T operand order
+__device__ __forceinline__ int at_key_slot(int kr) {
+    const int hf = (kr >> 2) & 1, rr = (kr & 3) + 4 * (kr >> 3);
+    return (rr >> 3) * 16 + hf * 8 + (rr & 7);
+}
+
+template <int DB>
+__global__ __launch_bounds__(256) void k_attention_b3(const float* __restrict__ qkv, const float* __restrict__ rel, int T,
+                                                      int heads, int hd, int n, float scale, float* __restrict__ out) {
+    constexpr int DP = DB * 32;          // padded head dim
+    constexpr int KS = DP / 16;          // k-steps over the head dim
+    constexpr int KPB = DP + 8;          // bf16 pitch of the K planes  [32 keys][DP]
+    constexpr int VPB = 40;              // bf16 pitch of the V^T planes [DP][32 key slots]
+    __shared__ __attribute__((aligned(16))) uint16_t Kh[32 * KPB];
+    __shared__ __attribute__((aligned(16))) uint16_t Kl[32 * KPB];
+    __shared__ __attribute__((aligned(16))) uint16_t Vh[DP * VPB];
+    __shared__ __attribute__((aligned(16))) uint16_t Vl[DP * VPB];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, half = lane >> 5;
+    const int bh = blockIdx.y, b = bh / heads, h = bh % heads, C = heads * hd;
+    const int q0 = (blockIdx.x * 4 + wave) * 32;
+    const int qi = q0 + li;
+    const bool qlive = qi < T;
+    const float* base = qkv + (size_t)b * T * 3 * C + h * hd;
+    // the lane's (scaled) query row as B operands: k-step s holds d = 16s + 8 half + j
+    at_bf16x8 qh[KS], ql[KS];
+    {
+        const float* qp = base + (size_t)(qlive ? qi : T - 1) * 3 * C;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            uint32_t hq[4], lq[4];
+#pragma unroll
+            for (int p2 = 0; p2 < 4; ++p2) {
+                const int d = 16 * s + 8 * half + 2 * p2;
+                const float x0 = d < hd ? qp[d] * scale : 0.f, x1 = d + 1 < hd ? qp[d + 1] * scale : 0.f;
+                at_split2(x0, x1, hq[p2], lq[p2]);
+            }
+            qh[s] = __builtin_bit_cast(at_bf16x8, make_uint4(hq[0], hq[1], hq[2], hq[3]));
+            ql[s] = __builtin_bit_cast(at_bf16x8, make_uint4(lq[0], lq[1], lq[2], lq[3]));
+        }
+    }
+    extern __shared__ float rel_lds[];
+    const int RP = 2 * n + 1;
+    float* relw = rel_lds + (size_t)wave * 32 * RP;
+    if (rel) {
+        for (int e = lane; e < 32 * 2 * n; e += 64) {
+            const int r = e / (2 * n), j = e - r * 2 * n;
+            const int qq = q0 + r < T ? q0 + r : T - 1;
+            relw[r * RP + j] = rel[((size_t)bh * T + qq) * 2 * n + j];
+        }
+    }
+    const float* relq = rel ? relw + li * RP : nullptr;
+    f32x16 o[DB];
+#pragma unroll
+    for (int t = 0; t < DB; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    // staging: K as (key, pair of head dims), V as (pair of keys, head dim); one tile ahead in registers
+    constexpr int PPT = (16 * DP) / 256;  // pairs per thread and matrix
+    float2 kreg[PPT], vreg[PPT];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) {
+            const int e = threadIdx.x + 256 * q;
+            {   // K: e -> (key kr, dims 2*dp, 2*dp + 1)
+                const int kr = e / (DP / 2), d = (e - kr * (DP / 2)) * 2;
+                const int key = k0 + kr;
+                const float* kp = base + (size_t)(key < T ? key : T - 1) * 3 * C + C;
+                kreg[q].x = (key < T && d < hd) ? kp[d] : 0.f;
+                kreg[q].y = (key < T && d + 1 < hd) ? kp[d + 1] : 0.f;
+            }
+            {   // V: e -> (keys 2*kp2, 2*kp2 + 1, dim d)
+                const int kp2 = e / DP, d = e - kp2 * DP;
+                const int key = k0 + 2 * kp2;
+                const int dc = d < hd ? d : 0;
+                const float* v0 = base + (size_t)(key < T ? key : T - 1) * 3 * C + 2 * C + dc;
+                const float* v1 = base + (size_t)(key + 1 < T ? key + 1 : T - 1) * 3 * C + 2 * C + dc;
+                vreg[q].x = (key < T && d < hd) ? v0[0] : 0.f;
+                vreg[q].y = (key + 1 < T && d < hd) ? v1[0] : 0.f;
+            }
+        }
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < T; k0 += 32) {
+        __syncthreads();  // previous tile consumed
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) {
+            const int e = threadIdx.x + 256 * q;
+            uint32_t hh, ll;
+            {
+                const int kr = e / (DP / 2), d = (e - kr * (DP / 2)) * 2;
+                at_split2(kreg[q].x, kreg[q].y, hh, ll);
+                *reinterpret_cast<uint32_t*>(&Kh[kr * KPB + d]) = hh;
+                *reinterpret_cast<uint32_t*>(&Kl[kr * KPB + d]) = ll;
+            }
+            {
+                const int kp2 = e / DP, d = e - kp2 * DP;
+                const int slot = at_key_slot(2 * kp2);  // keys 2kp2 and 2kp2+1 sit in adjacent slots
+                at_split2(vreg[q].x, vreg[q].y, hh, ll);
+                *reinterpret_cast<uint32_t*>(&Vh[d * VPB + slot]) = hh;
+                *reinterpret_cast<uint32_t*>(&Vl[d * VPB + slot]) = ll;
+            }
+        }
+        __syncthreads();
+        if (k0 + 32 < T) fetch(k0 + 32);
+        // ---- S^T[key][query] (already scaled)
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const at_bf16x8 kh = *reinterpret_cast<const at_bf16x8*>(&Kh[li * KPB + 16 * ks + 8 * half]);
+            const at_bf16x8 kl = *reinterpret_cast<const at_bf16x8*>(&Kl[li * KPB + 16 * ks + 8 * half]);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qh[ks], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql[ks], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh[ks], s, 0, 0, 0);
+        }
+        // ---- relative-position bias, mask, online softmax (everything per lane = per query)
+        float m_tile = -INFINITY;
+        const int kh0 = relq ? k0 / n : 0, kw0 = relq ? k0 - kh0 * n : 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = k0 + vrow(r, half);
+            float v = s[r];
+            if (relq) {
+                int kh = kh0, kw = kw0 + vrow(r, half);
+                while (kw >= n) { kw -= n; ++kh; }
+                if (key < T) v += relq[kh] + relq[n + kw];
+            }
+            v = key < T ? v : -INFINITY;
+            s[r] = v;
+            m_tile = fmaxf(m_tile, v);
+        }
+        m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 32, 64));
+        const float m_new = fmaxf(m_run, m_tile);
+        const float alpha = expf(m_run - m_new);
+        float l_tile = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float pv = expf(s[r] - m_new);
+            s[r] = pv;
+            l_tile += pv;
+        }
+        l_tile += __shfl_xor(l_tile, 32, 64);
+        l_run = l_run * alpha + l_tile;
+        m_run = m_new;
+        // ---- O^T[d][query] = alpha * O^T + V^T P^T
+        at_bf16x8 ph[2], pl[2];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            uint32_t hp[4], lp[4];
+#pragma unroll
+            for (int p2 = 0; p2 < 4; ++p2) at_split2(s[8 * s2 + 2 * p2], s[8 * s2 + 2 * p2 + 1], hp[p2], lp[p2]);
+            ph[s2] = __builtin_bit_cast(at_bf16x8, make_uint4(hp[0], hp[1], hp[2], hp[3]));
+            pl[s2] = __builtin_bit_cast(at_bf16x8, make_uint4(lp[0], lp[1], lp[2], lp[3]));
+        }
+#pragma unroll
+        for (int t = 0; t < DB; ++t) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const at_bf16x8 vh = *reinterpret_cast<const at_bf16x8*>(&Vh[(t * 32 + li) * VPB + 16 * s2 + 8 * half]);
+                const at_bf16x8 vl = *reinterpret_cast<const at_bf16x8*>(&Vl[(t * 32 + li) * VPB + 16 * s2 + 8 * half]);
+                o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph[s2], o[t], 0, 0, 0);
+                o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl[s2], o[t], 0, 0, 0);
+                o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph[s2], o[t], 0, 0, 0);
+            }
+        }
+    }
+    if (qlive) {
+        const float inv = 1.f / l_run;
+        float* op = out + ((size_t)b * T + qi) * C + h * hd;
+#pragma unroll
+        for (int t = 0; t < DB; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int d = t * 32 + vrow(r, half);
+                if (d < hd) op[d] = o[t][r] * inv;
+            }
+    }
+}
+
 }  // namespace snf
 
 using namespace snf;
@@ -320,7 +528,18 @@ extern "C" int snf_attention(const float* qkv, const float* rel, int Bw, int T, 
         hipLaunchKernelGGL(k_attention<DB_>, grid, dim3(256), lds, (hipStream_t)stream, qkv, rel, T, heads, head_dim, n, scale, \
                            out);                                                                                            \
     } while (0)
-    if (DB == 1) SNF_ATT(1); else if (DB == 2) SNF_ATT(2); else SNF_ATT(3);
+    static const int b3_env = getenv("SNF_ATT_B3") ? atoi(getenv("SNF_ATT_B3")) : 1;
+    if (b3_env && b3_enabled()) {
+#define SNF_ATT_B3(DB_)                                                                                                     \
+    do {                                                                                                                    \
+        if (lds > 16 * 1024)                                                                                                \
+            hipFuncSetAttribute((const void*)k_attention_b3<DB_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);    \
+        hipLaunchKernelGGL(k_attention_b3<DB_>, grid, dim3(256), lds, (hipStream_t)stream, qkv, rel, T, heads, head_dim, n,   \
+                           scale, out);                                                                                     \
+    } while (0)
+        if (DB == 1) SNF_ATT_B3(1); else if (DB == 2) SNF_ATT_B3(2); else SNF_ATT_B3(3);
+#undef SNF_ATT_B3
+    } else if (DB == 1) SNF_ATT(1); else if (DB == 2) SNF_ATT(2); else SNF_ATT(3);
 #undef SNF_ATT
     SNF_LAUNCH_CHECK("snf_attention");
     return SNF_OK;

@@ -45,9 +45,13 @@ def test_encoder_vs_reference_fixture(golden):
     assert float((y3 - ref).abs().max()) <= 1e-4 * max(1.0, float(ref.abs().max()))
 
 
+@pytest.mark.parametrize("mode", ["fp32", "bf16x3"])
 @pytest.mark.parametrize("Bw,n,heads,hd,rel", [(3, 14, 2, 80, True), (1, 9, 1, 16, False), (2, 5, 3, 40, True)])
-def test_attention_kernel_vs_torch(Bw, n, heads, hd, rel):
+def test_attention_kernel_vs_torch(Bw, n, heads, hd, rel, mode):
+    """fp32: the exact-fp32 matrix-core kernel; bf16x3: the 3-term-split kernel (product default), N(0,1) inputs make scores of
+    magnitude ~10, so its 1e-6 relative product error shows as ~1e-5 in the softmax weights."""
     from samnerf_amd import ops
+    ops.set_gemm_mode(mode)
     g = torch.Generator().manual_seed(n + hd)
     T, C = n * n, heads * hd
     qkv = torch.randn((Bw * T, 3 * C), generator=g)
@@ -66,7 +70,7 @@ def test_attention_kernel_vs_torch(Bw, n, heads, hd, rel):
                 + torch.einsum("bhwc,wkc->bhwk", rq, Rw)[:, :, :, None, :]).view(-1, T, T)
     ref = (attn.softmax(-1) @ v).view(Bw, heads, T, hd).permute(0, 2, 1, 3).reshape(Bw * T, C)
     out = ops.attention(qkv.cuda(), Bw, T, heads, n, rph.cuda() if rel else None, rpw.cuda() if rel else None).cpu().double()
-    assert float((out - ref).abs().max()) <= 2e-5
+    assert float((out - ref).abs().max()) <= (2e-5 if mode == "fp32" else 1e-4)
 
 
 def test_layernorm_window_kernels_vs_torch():
