@@ -261,6 +261,18 @@ int snf_rowmse_loss_fwd(const float* pred, const float* target, int R, int C, fl
 int snf_rowmse_loss_bwd(const float* pred, const float* target, int R, int C, float weight, int nan_skip,
                         const float* gout, const float* out, float* dpred, snf_stream_t stream);
 
+/* ---- a19..a21, scalar tail: what autograd and the loss dict do around the kernels above, for a train step that is a
+ * static launch schedule (samnerf_amd/step_program.py) instead of an autograd graph.
+ * snf_add_scaled: y[i] += alpha * x[i], product rounded before the sum (= autograd scaling one branch's gradient by a loss
+ *   multiplier and adding it to another branch's: nerfstudio/models/nerfacto.py:333 distortion_loss_mult).
+ * snf_nerf_loss_summary: NerfactoModel.get_loss_dict / get_metrics_dict scalars (nerfacto.py:316-344) from the row sums:
+ *   out = {total, rgb_loss (= rgb_mse[0]), interlevel_scale * sum(interlevel_rows), distortion_mult * distortion,
+ *   distortion = distortion_scale * sum(distortion_rows), psnr = -10 log10(rgb_mse[0])}; interlevel_rows may be NULL. */
+int snf_add_scaled(int64_t n, float alpha, const float* x, float* y, snf_stream_t stream);
+int snf_nerf_loss_summary(const float* rgb_mse, const float* interlevel_rows, float interlevel_scale,
+                          const float* distortion_rows, float distortion_scale, float distortion_mult, int R, float* out,
+                          snf_stream_t stream);
+
 /* ---- the SAM image encoder forward (samnerf/segment_anything/modeling/image_encoder.py, common.py).
  * Dense layers are snf_linear_fwd (SNF_ACT_GELU for the MLP); these are the pieces around them.  Tokens are rows [B*T, C].
  * snf_patchify: image [B,Cin,S,S] -> rows [B*(S/P)^2, Cin*P*P] in Conv2d.weight.view(E, Cin*P*P) column order (PatchEmbed).

@@ -110,6 +110,8 @@ SIGNATURES = {
     "snf_feature_mean_bwd": [P, P, I, I, I, P, P],
     "snf_interlevel": [P, P, P, P, I, I, I, F, P, P, P],
     "snf_distortion": [P, P, I, I, F, P, P, P],
+    "snf_add_scaled": [c_int64, F, P, P, P],
+    "snf_nerf_loss_summary": [P, P, F, P, F, F, I, P, P],
     "snf_adam_step": [P, P, P, P, c_int64, F, F, F, F, I, F, I, P],
     "snf_adam_step_rows": [P, P, P, P, P, c_int64, I, F, F, F, F, I, F, I, P],
     "snf_set_adam_launch": [I, I, I],

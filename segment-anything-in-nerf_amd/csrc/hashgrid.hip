@@ -490,7 +490,7 @@ __global__ __launch_bounds__(HG_RT) void k_hg_reduce(const float* __restrict__ g
 #pragma unroll
         for (int j = 0; j < RPT; ++j) {
             const uint32_t i = c0 + tid + (uint32_t)HG_RT * j;
-            r[j] = records[i < end ? i : start];
+            r[j] = records[i < end ? i : (start < end ? start : 0u)];  // (an empty bucket is still visited when ADAM)
         }
     };
     auto gather = [&](const auto& r, auto& gg) {

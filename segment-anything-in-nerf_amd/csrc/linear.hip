@@ -340,9 +340,14 @@ using namespace snf;
 extern "C" int snf_linear_fwd(const float* X, const float* W, const float* bias, int N, int I, int O, int ldx, int ldy,
                               int act, float* Y, snf_stream_t stream) {
     SNF_REQUIRE(X && W && Y, "snf_linear_fwd: null pointer");
-    SNF_REQUIRE(N > 0 && I > 0 && O > 0 && ldx >= I && ldy >= O, "snf_linear_fwd: bad shape N=%d I=%d O=%d", N, I, O);
+    // ldx == -8: X is level-major [I/8][N][8] (two feature grids' planar output side by side)
+    SNF_REQUIRE(N > 0 && I > 0 && O > 0 && (ldx >= I || (ldx == -8 && I % 16 == 0)) && ldy >= O,
+                "snf_linear_fwd: bad shape N=%d I=%d O=%d", N, I, O);
     SNF_REQUIRE(act >= 0 && act <= 3, "snf_linear_fwd: bad activation %d", act);
-    if (b3_try_fwd(X, W, bias, N, I, O, ldx, ldy, act, Y, stream)) {
+    const int took = b3_try_fwd(X, W, bias, N, I, O, ldx, ldy, act, Y, stream);
+    SNF_REQUIRE(took >= 0 && (took > 0 || ldx > 0),
+                "snf_linear_fwd: a level-major X (ldx = -8) needs 64 <= I <= 256, I %% 16 == 0, O >= 64, aligned pointers and gemm mode >= 1");
+    if (took) {
         SNF_LAUNCH_CHECK("snf_linear_fwd(bf16x3)");
         return SNF_OK;
     }
@@ -422,8 +427,12 @@ extern "C" int snf_linear_bwd_data(const float* dY, const float* Y, const float*
     SNF_REQUIRE(dY && W && dX, "snf_linear_bwd_data: null pointer");
     SNF_REQUIRE(act == SNF_ACT_NONE || Y, "snf_linear_bwd_data: Y required for activation derivative");
     SNF_REQUIRE(act != SNF_ACT_GELU, "snf_linear_bwd_data: GELU is forward-only (image encoder inference)");
-    SNF_REQUIRE(N > 0 && I > 0 && O > 0 && lddy >= O && lddx >= I, "snf_linear_bwd_data: bad shape");
-    if (b3_try_bwd_data(dY, Y, W, N, I, O, lddy, ldy, lddx, act, dX, stream)) {
+    // lddx == -8: dX is written level-major [I/8][N][8] (the staged-gradient layout of snf_hashgrid_bwd_presorted, ld_out = 0)
+    SNF_REQUIRE(N > 0 && I > 0 && O > 0 && lddy >= O && (lddx >= I || (lddx == -8 && I % 8 == 0)), "snf_linear_bwd_data: bad shape");
+    const int took = b3_try_bwd_data(dY, Y, W, N, I, O, lddy, ldy, lddx, act, dX, stream);
+    SNF_REQUIRE(took >= 0 && (took > 0 || lddx > 0),
+                "snf_linear_bwd_data: a level-major dX (lddx = -8) needs 64 <= O <= 256, O %% 16 == 0, I >= 64, aligned pointers and gemm mode >= 1");
+    if (took) {
         SNF_LAUNCH_CHECK("snf_linear_bwd_data(bf16x3)");
         return SNF_OK;
     }
@@ -447,11 +456,15 @@ extern "C" int snf_linear_bwd_weight(const float* dY, const float* Y, const floa
     SNF_REQUIRE(act == SNF_ACT_NONE || Y, "snf_linear_bwd_weight: Y required for activation derivative");
     SNF_REQUIRE(act != SNF_ACT_GELU, "snf_linear_bwd_weight: GELU is forward-only (image encoder inference)");
     // ldx == 0: X is level-major [I/2][N][2] (the hash-grid forward's planar output); needs the vector path
-    SNF_REQUIRE(N > 0 && I > 0 && O > 0 && lddy >= O && (ldx >= I || (ldx == 0 && I % 4 == 0)), "snf_linear_bwd_weight: bad shape");
+    // ldx == -8: X is level-major [I/8][N][8] (feature grids); only the bf16x3 kernel reads that layout
+    SNF_REQUIRE(N > 0 && I > 0 && O > 0 && lddy >= O && (ldx >= I || (ldx == 0 && I % 4 == 0) || (ldx == -8 && I % 8 == 0)),
+                "snf_linear_bwd_weight: bad shape");
     if (b3_try_bwd_weight(dY, Y, X, N, I, O, lddy, ldy, ldx, act, dW, dbias, stream)) {
         SNF_LAUNCH_CHECK("snf_linear_bwd_weight(bf16x3)");
         return SNF_OK;
     }
+    SNF_REQUIRE(ldx >= 0, "snf_linear_bwd_weight: a level-major X with 8 features per level (ldx = -8) needs I, O >= 64, "
+                          "aligned pointers and gemm mode >= 1");
     // activations may be stored with padded leading dimensions (multiple of 4): the vector loaders mask pad columns
     const int vecA = aligned16(dY) && (lddy % 4 == 0) && (act == SNF_ACT_NONE || (aligned16(Y) && ldy % 4 == 0));
     const int vecB = aligned16(X) && (ldx % 4 == 0);

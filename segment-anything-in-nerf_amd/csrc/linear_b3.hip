@@ -109,6 +109,17 @@ __device__ __forceinline__ float4 b3_load_b(const float* __restrict__ B, int r, 
     return v;
 }
 
+// the same from a level-major matrix [Cn/8][rows_total][8] (the feature grids' planar output, ld = -8): column quad c..c+3 of
+// row r sits at ((c >> 3) * rows_total + r) * 8 + (c & 7)
+__device__ __forceinline__ float4 b3_load_b_planar8(const float* __restrict__ B, int r, int c, int Rn, int Cn, int rows_total) {
+    const bool ok = (r < Rn) && (c < Cn);
+    const int rc = r < Rn ? r : Rn - 1;
+    const int cc = c < Cn ? c : 0;
+    float4 v = *reinterpret_cast<const float4*>(B + ((size_t)(cc >> 3) * rows_total + rc) * 8 + (cc & 7));
+    if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+    return v;
+}
+
 // C[M,Nc] = op(A)[M,K] * B   (BT: B = W[Nc,K] row-major, i.e. forward;  !BT: B = W[K,Nc] row-major, i.e. data gradient)
 // Requirements (checked by the host wrapper): K % 4 == 0, Nc % 4 == 0, leading dimensions % 4 == 0, 16-byte aligned bases.
 // BN = columns per workgroup (64 / 128 / 192 / 256): a wave owns 32 rows x BN columns = BN/32 accumulators.  Wider tiles
@@ -272,7 +283,7 @@ __global__ __launch_bounds__(256) void k_gemm_wgrad_b3(const float* __restrict__
         for (int p = 0; p < 2; ++p) {
             const int n = n0 + 2 * kp + p;
             av[p] = b3_load_a<true>(dY, Y, n, o0 + q * 4, n_end, O, lddy, ldy, act);
-            bv[p] = b3_load_b(X, n, i0 + q * 4, n_end, I, ldx);
+            bv[p] = ldx < 0 ? b3_load_b_planar8(X, n, i0 + q * 4, n_end, I, N) : b3_load_b(X, n, i0 + q * 4, n_end, I, ldx);
         }
     };
     fetch(n_begin);
@@ -339,7 +350,15 @@ __device__ __forceinline__ void ws_split2(float x0, float x1, uint32_t& hi, uint
     lo = cvt_pk_bf16(x0 - __uint_as_float(hi << 16), x1 - __uint_as_float(hi & 0xFFFF0000u));
 }
 
-template <bool BT, bool DERIV, int BN, int RB, int THREADS, int DEPTH>
+// PA: A is level-major [K/8][M][8] (lda = -8): the fragment of lane (m, half) for k-step s -- A[m][16s + 8*half .. +8] -- is level
+//     2s + half of row m, 32 contiguous bytes, and the 32 lanes of a half-wave read 1 KB in one piece (row-major rows are
+//     lda*4 bytes apart).
+// CT: the product is accumulated transposed (C^T = W^T A^T: the weight fragment is the first MFMA operand), so a lane owns
+//     ONE row m and, per accumulator register quad, four consecutive output features; C is written level-major
+//     [Nc/8][M][8] (ldc = -8): lane (m, half) stores 16 bytes of level (col0 + 32t)/8 + q, and a wave store covers 32 rows x
+//     32 bytes = 1 KB contiguous.  This is the staged-gradient layout of the hash-grid backward (snf_hashgrid_bwd_presorted
+//     with ld_out = 0): the data gradient of a head's first layer lands where the table backward reads it.
+template <bool BT, bool DERIV, int BN, int RB, int THREADS, int DEPTH, bool PA = false, bool CT = false>
 __global__ __launch_bounds__(THREADS) void k_gemm_ws_b3(const float* __restrict__ A, const float* __restrict__ Aux,
                                                         const float* __restrict__ W, const float* __restrict__ bias, int M,
                                                         int K, int Nc, int lda, int ldaux, int ldw, int ldc, int act_in,
@@ -428,9 +447,10 @@ __global__ __launch_bounds__(THREADS) void k_gemm_ws_b3(const float* __restrict_
 #pragma unroll
         for (int b = 0; b < RB; ++b) {
             const int r = min(r0 + 32 * b + li, M - 1);
-            pa[b] = A + (size_t)r * lda + half * 8;
+            pa[b] = PA ? A + ((size_t)half * M + r) * 8 : A + (size_t)r * lda + half * 8;
             ya[b] = DERIV ? Aux + (size_t)r * ldaux + half * 8 : nullptr;
         }
+        const size_t a_step = PA ? (size_t)16 * M : (size_t)16;  // elements between the fragments of consecutive k-steps
         f32x16 acc[RB][NB];
 #pragma unroll
         for (int b = 0; b < RB; ++b)
@@ -444,8 +464,8 @@ __global__ __launch_bounds__(THREADS) void k_gemm_ws_b3(const float* __restrict_
         float4 raw[D][RB][2], rawy[DERIV ? D : 1][RB][2];
         const bool masked = DERIV && act_in != SNF_ACT_NONE;
         auto load8 = [&](int b, int s, int u) {
-            raw[u][b][0] = *reinterpret_cast<const float4*>(pa[b] + s * 16);
-            raw[u][b][1] = *reinterpret_cast<const float4*>(pa[b] + s * 16 + 4);
+            raw[u][b][0] = *reinterpret_cast<const float4*>(pa[b] + s * a_step);
+            raw[u][b][1] = *reinterpret_cast<const float4*>(pa[b] + s * a_step + 4);
             if constexpr (DERIV) {
                 if (masked) {
                     rawy[u][b][0] = *reinterpret_cast<const float4*>(ya[b] + s * 16);
@@ -495,16 +515,48 @@ __global__ __launch_bounds__(THREADS) void k_gemm_ws_b3(const float* __restrict_
                     for (int t = 0; t < NB; ++t) {
                         const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&Bh[(size_t)(32 * t + li) * pitch + ko]);
                         const bf16x8 bl = *reinterpret_cast<const bf16x8*>(&Bl[(size_t)(32 * t + li) * pitch + ko]);
+                        if constexpr (CT) {
 #pragma unroll
-                        for (int b = 0; b < RB; ++b) acc[b][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[b], bh, acc[b][t], 0, 0, 0);
+                            for (int b = 0; b < RB; ++b) acc[b][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, al[b], acc[b][t], 0, 0, 0);
 #pragma unroll
-                        for (int b = 0; b < RB; ++b) acc[b][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[b], bl, acc[b][t], 0, 0, 0);
+                            for (int b = 0; b < RB; ++b) acc[b][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl, ah[b], acc[b][t], 0, 0, 0);
 #pragma unroll
-                        for (int b = 0; b < RB; ++b) acc[b][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[b], bh, acc[b][t], 0, 0, 0);
+                            for (int b = 0; b < RB; ++b) acc[b][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, ah[b], acc[b][t], 0, 0, 0);
+                        } else {
+#pragma unroll
+                            for (int b = 0; b < RB; ++b) acc[b][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[b], bh, acc[b][t], 0, 0, 0);
+#pragma unroll
+                            for (int b = 0; b < RB; ++b) acc[b][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[b], bl, acc[b][t], 0, 0, 0);
+#pragma unroll
+                            for (int b = 0; b < RB; ++b) acc[b][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[b], bh, acc[b][t], 0, 0, 0);
+                        }
                     }
                 }
             }
         }
+        if constexpr (CT) {
+            // transposed accumulators: lane (m = li, half) holds, in registers 4q .. 4q+3, the output features
+            // col0 + 32t + 8q + 4*half + {0..3} of row m -> one 16-byte store into level (col0 + 32t)/8 + q of the level-major C
+#pragma unroll
+            for (int b = 0; b < RB; ++b) {
+                const int row = r0 + 32 * b + li;
+                if (row < M) {
+#pragma unroll
+                    for (int t = 0; t < NB; ++t)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int c0 = col0 + 32 * t + 8 * q + 4 * half;
+                            if (c0 < Nc) {  // Nc % 4 == 0
+                                float4 v = make_float4(acc[b][t][4 * q], acc[b][t][4 * q + 1], acc[b][t][4 * q + 2], acc[b][t][4 * q + 3]);
+                                if (bias != nullptr) { v.x += bias[c0]; v.y += bias[c0 + 1]; v.z += bias[c0 + 2]; v.w += bias[c0 + 3]; }
+                                v.x = b3_act_apply(v.x, act_out); v.y = b3_act_apply(v.y, act_out);
+                                v.z = b3_act_apply(v.z, act_out); v.w = b3_act_apply(v.w, act_out);
+                                *reinterpret_cast<float4*>(C + ((size_t)(c0 >> 3) * M + row) * 8 + (c0 & 7)) = v;
+                            }
+                        }
+                }
+            }
+        } else {
         // epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
 #pragma unroll
         for (int b = 0; b < RB; ++b)
@@ -519,14 +571,15 @@ __global__ __launch_bounds__(THREADS) void k_gemm_ws_b3(const float* __restrict_
                     }
                 }
             }
+        }
     }
 }
 
-template <bool BT, bool DERIV, int BN, int RB, int THREADS, int DEPTH>
+template <bool BT, bool DERIV, int BN, int RB, int THREADS, int DEPTH, bool PA = false, bool CT = false>
 static void ws_launch(dim3 grid, size_t lds, snf_stream_t stream, const float* A, const float* Aux, const float* W,
                       const float* bias, int M, int K, int Nc, int lda, int ldaux, int ldw, int ldc, int act_in, int act_out,
                       float* C) {
-    auto kern = k_gemm_ws_b3<BT, DERIV, BN, RB, THREADS, DEPTH>;
+    auto kern = k_gemm_ws_b3<BT, DERIV, BN, RB, THREADS, DEPTH, PA, CT>;
     static bool attr = false;
     if (!attr) {
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -541,6 +594,27 @@ template <bool BT, bool DERIV>
 static int ws_try(const float* A, const float* Aux, const float* W, const float* bias, int M, int K, int Nc, int lda, int ldaux,
                   int ldw, int ldc, int act_in, int act_out, float* C, snf_stream_t stream) {
     static const int on = getenv("SNF_GEMM_WS") ? atoi(getenv("SNF_GEMM_WS")) : 1;
+    const bool pa = lda < 0, ct = ldc < 0;  // level-major operands (F = 8): only this kernel reads / writes them
+    if (pa || ct) {
+        if ((pa && (lda != -8 || !BT || DERIV)) || (ct && (ldc != -8 || BT || !DERIV || (Nc % 8))) || (pa && ct) || (K % 16) ||
+            K > 256 || K < 64 || Nc < 64 || (Nc % 4))
+            return -1;
+        const int bn = 128, tile_rows = 256;
+        const size_t lds = (size_t)2 * bn * (K + 8) * sizeof(uint16_t);
+        const int gy = ceil_div(Nc, bn), tiles = ceil_div(M, tile_rows);
+        const int per_cu = lds > 80 * 1024 ? 1 : 2;
+        int gx = (256 * per_cu) / gy;
+        if (gx < 1) gx = 1;
+        if (gx > tiles) gx = tiles;
+        dim3 grid(gx, gy);
+        if constexpr (BT && !DERIV) {
+            if (pa) ws_launch<true, false, 128, 1, 512, 4, true, false>(grid, lds, stream, A, Aux, W, bias, M, K, Nc, lda, ldaux, ldw, ldc, act_in, act_out, C);
+        }
+        if constexpr (!BT && DERIV) {
+            if (ct) ws_launch<false, true, 128, 1, 512, 4, false, true>(grid, lds, stream, A, Aux, W, bias, M, K, Nc, lda, ldaux, ldw, ldc, act_in, act_out, C);
+        }
+        return 1;
+    }
     if (!on || (K % 16) || K > 256 || K < 64 || M < 4096 || Nc < 64 || (Nc % 4) || (lda % 4)) return 0;
     // BN 128, 8 waves x 32 rows, 4 k-steps of A loads in flight (2 and 8 measured the same: the loads are not latency-bound);
     // narrow outputs (Nc <= 64) and SNF_GEMM_WS_VARIANT=1 take BN 64 with 4 waves x 64 rows (two workgroups per CU)
@@ -594,6 +668,9 @@ extern "C" int snf_get_gemm_mode(void) { return g_gemm_mode; }
 // called by snf_linear_fwd / snf_linear_bwd_data for wide, aligned layers; returns 1 if it took the launch
 int snf::b3_try_fwd(const float* X, const float* W, const float* bias, int N, int I, int O, int ldx, int ldy,
                               int act, float* Y, snf_stream_t stream) {
+    if (ldx < 0)  // level-major X [I/8][N][8]: only the weight-stationary bf16x3 kernel reads it (-1: not supported)
+        return (!b3_enabled() || (((uintptr_t)X | (uintptr_t)W) & 15))
+                   ? -1 : ws_try<true, false>(X, nullptr, W, bias, N, I, O, ldx, 0, I, ldy, SNF_ACT_NONE, act, Y, stream);
     if (!b3_enabled() || I < 128 || O < 64 || (I % 4) || (O % 4) || (ldx % 4) || ((uintptr_t)X & 15) || ((uintptr_t)W & 15))
         return 0;
     if (ws_try<true, false>(X, nullptr, W, bias, N, I, O, ldx, 0, I, ldy, SNF_ACT_NONE, act, Y, stream)) return 1;
@@ -620,6 +697,10 @@ int snf::b3_try_fwd_splitk(const float* X, const float* W, int N, int I, int O, 
 
 int snf::b3_try_bwd_data(const float* dY, const float* Y, const float* W, int N, int I, int O, int lddy, int ldy,
                                    int lddx, int act, float* dX, snf_stream_t stream) {
+    if (lddx < 0)  // level-major dX [I/8][N][8]: only the weight-stationary bf16x3 kernel writes it (-1: not supported)
+        return (!b3_enabled() || (lddy % 4) || (((uintptr_t)dY | (uintptr_t)W | (uintptr_t)dX) & 15) ||
+                (act != SNF_ACT_NONE && ((ldy % 4) || ((uintptr_t)Y & 15))))
+                   ? -1 : ws_try<false, true>(dY, Y, W, nullptr, N, O, I, lddy, ldy, I, lddx, act, SNF_ACT_NONE, dX, stream);
     if (!b3_enabled() || O < 128 || I < 64 || (I % 4) || (O % 4) || (lddy % 4) || ((uintptr_t)dY & 15) ||
         ((uintptr_t)W & 15) || (act != SNF_ACT_NONE && ((ldy % 4) || ((uintptr_t)Y & 15))))
         return 0;
@@ -636,7 +717,8 @@ int snf::b3_try_bwd_data(const float* dY, const float* Y, const float* W, int N,
 
 int snf::b3_try_bwd_weight(const float* dY, const float* Y, const float* X, int N, int I, int O, int lddy, int ldy, int ldx,
                            int act, float* dW, float* dbias, snf_stream_t stream) {
-    if (!b3_enabled() || O < 64 || I < 64 || (I % 4) || (O % 4) || (lddy % 4) || (ldx % 4) || ldx == 0 || ((uintptr_t)dY & 15) ||
+    if (!b3_enabled() || O < 64 || I < 64 || (I % 4) || (O % 4) || (lddy % 4) || (ldx % 4) || ldx == 0 ||
+        (ldx < 0 && (ldx != -8 || (I % 8))) || ((uintptr_t)dY & 15) ||
         ((uintptr_t)X & 15) || (act != SNF_ACT_NONE && ((ldy % 4) || ((uintptr_t)Y & 15))))
         return 0;
     const int to = ceil_div(O, 64), ti = ceil_div(I, 64);

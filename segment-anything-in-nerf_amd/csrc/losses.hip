@@ -197,6 +197,51 @@ __global__ __launch_bounds__(256) void k_rowmse_bwd(const float* __restrict__ pr
     }
 }
 
+
+// y += alpha * x, the product rounded before the sum (what autograd does when it scales a branch's gradient and then adds
+// the branches: mul, then add -- no fused multiply-add)
+__global__ __launch_bounds__(256) void k_add_scaled(long long n, float alpha, const float* __restrict__ x,
+                                                    float* __restrict__ y) {
+#pragma clang fp contract(off)
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) {
+        const float t = alpha * x[i];
+        y[i] = y[i] + t;
+    }
+}
+
+// Scalar tail of NerfactoModel.get_loss_dict / get_metrics_dict (nerfstudio/models/nerfacto.py:316-344) in one launch:
+//   interlevel_loss = mult_i * sum(rows_i) / n_i ; distortion = sum(rows_d) / R ; distortion_loss = mult_d * distortion ;
+//   psnr = -10 log10(rgb_mse) ; total = rgb_loss + interlevel_loss + distortion_loss
+// rows_i may be NULL (eval / no proposal level).  out: {total, rgb_loss, interlevel_loss, distortion_loss, distortion, psnr}.
+__global__ __launch_bounds__(1024) void k_nerf_loss_summary(const float* __restrict__ rgb_mse,
+                                                            const float* __restrict__ rows_i, float scale_i,
+                                                            const float* __restrict__ rows_d, float scale_d, float mult_d,
+                                                            int R, float* __restrict__ out) {
+    __shared__ float si[16], sd[16];
+    float a = 0.f, b = 0.f;
+    for (int r = threadIdx.x; r < R; r += 1024) {
+        if (rows_i) a += rows_i[r];
+        b += rows_d[r];
+    }
+    a = wave_sum(a);
+    b = wave_sum(b);
+    if ((threadIdx.x & 63) == 0) { si[threadIdx.x >> 6] = a; sd[threadIdx.x >> 6] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float ta = 0.f, tb = 0.f;
+        for (int w = 0; w < 16; ++w) { ta += si[w]; tb += sd[w]; }
+        const float rgb = rgb_mse[0];
+        const float inter = ta * scale_i, dist = tb * scale_d, dloss = mult_d * dist;
+        out[0] = rgb + inter + dloss;
+        out[1] = rgb;
+        out[2] = inter;
+        out[3] = dloss;
+        out[4] = dist;
+        out[5] = -10.f * log10f(rgb);
+    }
+}
+
 }  // namespace snf
 
 using namespace snf;
@@ -242,5 +287,22 @@ extern "C" int snf_rowmse_loss_bwd(const float* pred, const float* target, int R
     hipLaunchKernelGGL(k_rowmse_bwd, dim3(blocks), dim3(256), 0, (hipStream_t)stream, pred, target, R, C, weight, nan_skip, gout,
                        out, dpred);
     SNF_LAUNCH_CHECK("snf_rowmse_loss_bwd");
+    return SNF_OK;
+}
+
+extern "C" int snf_add_scaled(int64_t n, float alpha, const float* x, float* y, snf_stream_t stream) {
+    SNF_REQUIRE(x && y && n > 0, "snf_add_scaled: bad argument");
+    hipLaunchKernelGGL(k_add_scaled, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, (long long)n, alpha, x, y);
+    SNF_LAUNCH_CHECK("snf_add_scaled");
+    return SNF_OK;
+}
+
+extern "C" int snf_nerf_loss_summary(const float* rgb_mse, const float* interlevel_rows, float interlevel_scale,
+                                     const float* distortion_rows, float distortion_scale, float distortion_mult, int R,
+                                     float* out, snf_stream_t stream) {
+    SNF_REQUIRE(rgb_mse && distortion_rows && out && R > 0, "snf_nerf_loss_summary: bad argument");
+    hipLaunchKernelGGL(k_nerf_loss_summary, dim3(1), dim3(1024), 0, (hipStream_t)stream, rgb_mse, interlevel_rows,
+                       interlevel_scale, distortion_rows, distortion_scale, distortion_mult, R, out);
+    SNF_LAUNCH_CHECK("snf_nerf_loss_summary");
     return SNF_OK;
 }

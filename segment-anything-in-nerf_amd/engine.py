@@ -115,7 +115,10 @@ class Optimizers:
                 enc = a.tables.get(pname)
                 if enc is None:
                     continue
+                # (a table evaluated more than once per step -- use_same_proposal_network with several proposal iterations --
+                # gets its gradient from several backward launches: each would apply a full Adam step with a partial gradient)
                 ok = (self.enabled and self.fuse_table_adam and a.param.is_cuda
+                      and not getattr(enc.params, "no_fused_adam", False)
                       and (not D.collectives_on() or off in owned))
                 if not ok:
                     enc.params._fused_adam = None
@@ -278,10 +281,11 @@ class Optimizers:
         self._tp_cache[k] = out
         return out
 
-    def _adam_range(self, k: str, lo: int, hi: int, lr, b1, b2, eps, t, scale, done=()) -> None:
-        """Fused Adam (+ gradient re-zeroing) on the arena elements [lo, hi) of group `k`, following the plan and leaving out
-        the ranges in `done` (already stepped by the hash-grid backward)."""
-        a = self.arenas[k]
+    def adam_pieces(self, k: str, lo: int, hi: int, done=()):
+        """The launches of a fused Adam pass over the arena elements [lo, hi) of group `k`: ("dense", x0, x1) element ranges
+        and ("rows", offsets int32, F) reachable-row lists, following the plan and leaving out the ranges in `done` (already
+        stepped by the hash-grid backward).  Shared by the eager pass below and the static step schedule (step_program.py)."""
+        out = []
         for seg in self._plan(k):
             s0, s1 = max(lo, seg[1]), min(hi, seg[2])
             if s1 <= s0:
@@ -290,15 +294,25 @@ class Optimizers:
                 pieces = [(s0, s1)]
                 for d0, d1 in done:
                     pieces = [q for x0, x1 in pieces for q in ((x0, min(x1, d0)), (max(x0, d1), x1)) if q[1] > q[0]]
-                for x0, x1 in pieces:
-                    ops.adam_step_(a.param[x0:x1], a.grad[x0:x1], a.exp_avg[x0:x1], a.exp_avg_sq[x0:x1], lr, b1, b2, eps, t,
-                                   scale, True)
+                out.extend(("dense", x0, x1) for x0, x1 in pieces)
             else:
-                offsets, F = seg[3], seg[4]
                 i0, i1 = self._cut(k, seg, s0, s1)  # rows are sorted: the slice of the list inside [s0, s1)
                 if i1 > i0:
-                    ops.adam_step_rows_(a.param, a.grad, a.exp_avg, a.exp_avg_sq, offsets[i0:i1], F, lr, b1, b2, eps, t,
-                                        scale, True)
+                    out.append(("rows", seg[3][i0:i1], seg[4]))
+        return out
+
+    def _adam_range(self, k: str, lo: int, hi: int, lr, b1, b2, eps, t, scale, done=()) -> None:
+        """Fused Adam (+ gradient re-zeroing) on the arena elements [lo, hi) of group `k`, following the plan and leaving out
+        the ranges in `done` (already stepped by the hash-grid backward)."""
+        a = self.arenas[k]
+        for piece in self.adam_pieces(k, lo, hi, done):
+            if piece[0] == "dense":
+                x0, x1 = piece[1], piece[2]
+                ops.adam_step_(a.param[x0:x1], a.grad[x0:x1], a.exp_avg[x0:x1], a.exp_avg_sq[x0:x1], lr, b1, b2, eps, t,
+                               scale, True)
+            else:
+                ops.adam_step_rows_(a.param, a.grad, a.exp_avg, a.exp_avg_sq, piece[1], piece[2], lr, b1, b2, eps, t,
+                                    scale, True)
 
     def consolidate_state(self) -> None:
         """Sharded runs keep each rank's Adam moments only for its shards of the dense segments: gather them before saving

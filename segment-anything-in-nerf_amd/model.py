@@ -204,6 +204,8 @@ class NerfactoModel(Model):
                                           **c.proposal_net_args_list[0])
             self.proposal_networks.append(network)
             self.density_fns.extend([network.density_fn for _ in range(num_prop_nets)])
+            if num_prop_nets > 1:  # one backward launch per use: the optimizer step cannot ride on any single one of them
+                network.mlp_base.encoding.params.no_fused_adam = True
         else:
             for i in range(num_prop_nets):
                 prop_net_args = c.proposal_net_args_list[min(i, len(c.proposal_net_args_list) - 1)]

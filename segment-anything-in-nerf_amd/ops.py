@@ -442,6 +442,9 @@ def _hashgrid_bwd_launch(u, g, sc, N, L, F, T, ld, col, buf, adam: Optional[Fuse
     # run aggregation pays for the ray-ordered F = 2 grids (field grid -8 %); the top-K-ordered F = 8 feature grids have
     # shorter runs and 4x the shuffle work per record (+20 % measured), so they keep the plain reduce
     nrun = hashgrid_run_levels(sc) if F == 2 else 0
+    if adam is not None and adam.done is not None:
+        raise RuntimeError("a hash table armed for the fused backward + Adam received a second backward launch in one step "
+                           "(shared table or gradient accumulation): the fused step needs the table's whole gradient")
     presorted = getattr(u, "_snf_sorted", None)
     if presorted:
         hit = presorted.get(_geometry_key(sc, L, T))

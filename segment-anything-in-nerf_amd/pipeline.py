@@ -71,6 +71,21 @@ class SyntheticSAMDataManager:
                 batch["clipseg"] = torch.randn((R, 192), device=self.device, generator=self.gen)
         return self._bundle(R), batch
 
+    def next_train_into(self, step: int, origins, directions, image, targets: Dict[str, torch.Tensor]) -> None:
+        """next_train(step) written into caller-owned buffers (the static step schedule, step_program.py): the same draws
+        from the same generator in the same order, so both paths see identical batches."""
+        self.train_count += 1
+        c = self.config
+        torch.rand(image.shape, device=self.device, generator=self.gen, out=image)
+        if c.distill_sam:
+            torch.randn(targets["sam"].shape, device=self.device, generator=self.gen, out=targets["sam"])
+            if c.use_clipseg_feature:
+                torch.randn(targets["clipseg"].shape, device=self.device, generator=self.gen, out=targets["clipseg"])
+        torch.rand(origins.shape, device=self.device, generator=self.gen, out=origins)
+        origins.sub_(0.5)
+        torch.randn(directions.shape, device=self.device, generator=self.gen, out=directions)
+        directions.div_(torch.linalg.norm(directions, dim=-1, keepdim=True))
+
     def get_param_groups(self) -> Dict[str, List]:
         return {}
 
@@ -148,6 +163,17 @@ class Trainer:
         self.pipeline_steps = False  # True: do not join the head streams at the end of a step (see train_iteration)
         self.presort_host = os.environ.get("SNF_PRESORT_ON", "sam")  # "sam" | "clipseg" | "own"
         self._side = None
+        # the step as a static launch schedule (step_program.py) instead of an autograd graph: same kernels, same arguments,
+        # ~10x less host time per step.  SNF_STATIC_STEP=0 keeps the eager path (which multi-rank runs always use).
+        self.static_step = os.environ.get("SNF_STATIC_STEP", "1") == "1"
+        self._program = None
+        self._program_off = None  # reason the static schedule is not used
+        # Optimizer semantics on steps where the proposal network gets no gradient (4 of 5 after warm-up,
+        # ray_samplers.py:566-591).  The reference pins torch < 2 (requirements.txt:32): its zero_grad() zero-FILLS the
+        # gradients, so torch.optim.Adam still steps the group -- moments decay, the step count advances, parameters move by
+        # lr * m_hat / (sqrt(v_hat) + eps).  That is the default here.  SNF_TORCH2_NONE_GRADS=1 selects what torch >= 2 does
+        # with the same script (grad = None: the group is skipped).
+        self.zero_grad_adam = os.environ.get("SNF_TORCH2_NONE_GRADS", "0") != "1"
 
     def setup(self, test_mode="val") -> None:
         self.pipeline = self.config.pipeline.setup(device=self.device, test_mode=test_mode, world_size=self.world_size,
@@ -186,8 +212,20 @@ class Trainer:
         for cb in self.callbacks:
             cb.run_callback_at_location(step, BEFORE_TRAIN_ITERATION)
         opt, scale = self.optimizers, 1.0 / D.world_size()
-        opt.arm_fused_adam()
         model = self.pipeline.model
+        if self.static_step and self._program_off is None:
+            if self._program is None:
+                from .step_program import StepProgram
+                self._program_off = StepProgram.unsupported_reason(self)
+                if self._program_off is None:
+                    self._program = StepProgram(self)
+            if self._program is not None:
+                loss, loss_dict, metrics_dict = self._program.run(step)
+                opt.scheduler_step_all(step)
+                for cb in self.callbacks:
+                    cb.run_callback_at_location(step, AFTER_TRAIN_ITERATION)
+                return loss, loss_dict, metrics_dict
+        opt.arm_fused_adam()
         use_side = self.overlap and torch.cuda.is_available() and "sam_field" in opt.arenas
         if use_side and self._side is None:
             from . import ops
@@ -217,8 +255,8 @@ class Trainer:
             def nerf_task():  # on the main stream
                 loss_rest.backward()
                 for g in rest_groups:
-                    if g == "proposal_networks" and not prop_updated:
-                        continue  # no gradient this step (ray_samplers.py:569-579): Adam skips the group, as torch does
+                    if g == "proposal_networks" and not prop_updated and not self.zero_grad_adam:
+                        continue  # torch >= 2 semantics: grad is None on a non-update step, Adam skips the group
                     opt.exchange_and_step(g)
 
             # host enqueue order (the GPU runs the three tasks concurrently; a task cannot start before the host has
@@ -256,7 +294,7 @@ class Trainer:
             loss.backward()
             # same arena slices as the three-task schedule (the sharded optimizer's layout must not depend on the schedule)
             for g in opt.arenas:
-                if g == "proposal_networks" and not prop_updated:
+                if g == "proposal_networks" and not prop_updated and not self.zero_grad_adam:
                     continue
                 if g == "sam_field":
                     first = True

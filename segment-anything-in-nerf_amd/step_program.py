@@ -1,0 +1,633 @@
+"""The samnerf train step as a STATIC LAUNCH SCHEDULE (one process per GPU, three HIP streams, no autograd graph).
+
+`Trainer.train_iteration` of the reference (nerfstudio/engine/trainer.py:409-440) runs, per step, the same fixed sequence
+of ~75 kernels: samnerf/sam_model.py:226-328 forward, the losses of nerfstudio/models/nerfacto.py:316-344 and
+sam_model.py:316-328, their backward, and Adam for four parameter groups.  Driving that sequence through
+`torch.autograd.Function`s costs ~3.8 ms of Python per step (allocations, graph bookkeeping, stream contexts) -- as long as
+the GPU needs for the step.  Here the sequence is written down ONCE:
+
+  * every intermediate lives in a buffer allocated at build time (the schedule owns its memory, like a captured graph);
+  * every C-ABI launch is recorded with its final arguments -- raw device pointers, sizes, the HIP stream it goes to;
+    replaying a step is `for fn, args in plan: fn(*args)`;
+  * the few values that change from step to step (learning rates, Adam step counts, the proposal-weight anneal) are
+    patched into the recorded argument lists before the replay;
+  * cross-stream edges are HIP events recorded / awaited at fixed points of the schedule; tensors shared between the main
+    stream and a feature-head stream are double-buffered by step parity, so the next step's forward can run under the tails
+    of this step's head tasks (what `Trainer.pipeline_steps` does with `record_stream` in the eager path).
+
+The arithmetic is the eager path's, launch for launch (`ops.py` is the reference for every argument list below); the two
+torch reductions of the eager loss dict (`rows.sum()`, `sum(losses)`) are `snf_nerf_loss_summary`, and autograd's
+"scale one branch's gradient, add the branches" is `snf_add_scaled`.  tests/test_model_gpu.py runs both paths from the
+same state and compares parameters and Adam moments after several steps.
+
+Scope: one rank (multi-rank runs keep the eager path with its collectives), `num_proposal_iterations == 1`, the fused
+nerfacto field, and the sorted hash-grid backward -- i.e. the samnerf_distill / samnerf_no_distill method configs.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib, ops
+from . import distributed as D
+
+_KERNEL, _PY = 0, 1
+
+
+class _Plan:
+    __slots__ = ("entries", "dyn")
+
+    def __init__(self) -> None:
+        self.entries: list = []          # [kind, fn, args(list), key, units, stream]
+        self.dyn: Dict[tuple, list] = {}  # dynamic value key -> [(args list, index)]
+
+
+class StepProgram:
+    """See the module docstring.  Built lazily by `Trainer.train_iteration`; `run(step)` enqueues one train step."""
+
+    # ------------------------------------------------------------------------------------------------------------
+    @staticmethod
+    def unsupported_reason(trainer) -> Optional[str]:
+        from .model import SAMModel
+        from .pipeline import SyntheticSAMDataManager  # noqa: F401
+        model = trainer.pipeline.model
+        c = model.config
+        if not torch.cuda.is_available():
+            return "no GPU"
+        if D.collectives_on():
+            return "multi-rank run (collectives on the path)"
+        if not isinstance(model, SAMModel):
+            return "not a SAMModel"
+        if c.num_proposal_iterations != 1 or c.use_same_proposal_network:
+            return "more than one proposal iteration"
+        if not model.field._fusable():
+            return "nerfacto field is not the fused 32-64-16 / 31-64-64-3 shape"
+        if ops.HASHGRID_BWD_MODE != "sorted" or not ops.PLANAR_FIELD_ENCODING:
+            return "non-default hash-grid backward mode"
+        prop = model.proposal_networks[0].mlp_base
+        if not ops.mlp_tiny_supported(prop.network.n_input_dims, prop.network.weights(), prop.network.output_activation):
+            return "proposal network is not the 10-16-1 shape"
+        R = trainer.pipeline.datamanager.config.train_num_rays_per_batch
+        P, S = c.num_proposal_samples_per_ray[0], c.num_nerf_samples_per_ray
+        if R * max(P, S) > ops.HASHGRID_BWD_MAX_SAMPLES or 8 * 16 * R * S >= (1 << 32):
+            return "batch beyond one sorted-backward launch"
+        if (R * 3) % 64:
+            return "ray count not a multiple of 64"
+        if c.distill_sam:
+            if c.patch_size > 1 and R % (c.patch_size ** 2):
+                return "ray count not a multiple of the patch area"
+            if c.use_dino_feature:
+                return "dino head"
+        if not model.arenas:
+            return "parameters are not in arenas"
+        return None
+
+    def __init__(self, trainer) -> None:
+        self.tr = trainer
+        self.model = trainer.pipeline.model
+        self.opt = trainer.optimizers
+        self.cfg = self.model.config
+        self.dev = self.model.device
+        self.lib = _lib.load()
+        c = self.cfg
+        self.R = trainer.pipeline.datamanager.config.train_num_rays_per_batch
+        self.P, self.S = c.num_proposal_samples_per_ray[0], c.num_nerf_samples_per_ray
+        self.distill = bool(c.distill_sam)
+        self.K = c.num_sam_samples if self.distill else 0
+        self.heads = (["sam"] + (["clipseg"] if c.use_clipseg_feature else [])) if self.distill else []
+        self.bufs: Dict[str, torch.Tensor] = {}
+        self.plans: Dict[tuple, _Plan] = {}
+        self.events: Dict[str, torch.cuda.Event] = {}
+        self._head_busy: Dict[tuple, bool] = {}  # (parity, head) -> a task of that parity has been enqueued
+        self.count = 0
+        # reference semantics of the optimizer on steps where the proposal network gets no gradient: the reference pins
+        # torch < 2 (requirements.txt:32), whose zero_grad() zero-fills -- Adam still steps the group (moments decay)
+        self.main = torch.cuda.current_stream()
+
+    # ------------------------------------------------------------------------------------------------------------
+    # memory
+    def buf(self, name: str, shape, dtype=torch.float32, parity: Optional[int] = None, zero: bool = False) -> torch.Tensor:
+        key = name if parity is None else f"{name}@{parity}"
+        t = self.bufs.get(key)
+        if t is None:
+            shape = tuple(int(x) for x in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+            t = (torch.zeros if zero else torch.empty)(shape, device=self.dev, dtype=dtype)
+            self.bufs[key] = t
+        return t
+
+    def event(self, name: str) -> torch.cuda.Event:
+        ev = self.events.get(name)
+        if ev is None:
+            ev = self.events[name] = torch.cuda.Event()
+        return ev
+
+    def nbytes(self) -> int:
+        return sum(t.numel() * t.element_size() for t in self.bufs.values())
+
+    # ------------------------------------------------------------------------------------------------------------
+    # recording helpers (valid while a plan is being built)
+    def _k(self, st, name: str, *args, tag: str = "", units: float = 0.0, dyn: Optional[dict] = None) -> None:
+        """Record one C-ABI launch on stream `st`; the stream handle is appended as the last argument."""
+        fn = getattr(self.lib, name)
+        a = [x.data_ptr() if isinstance(x, torch.Tensor) else x for x in args]
+        a.append(st.cuda_stream)
+        self._plan.entries.append([_KERNEL, fn, a, name + ("/" + tag if tag else ""), units, st])
+        for key, idx in (dyn or {}).items():
+            self._plan.dyn.setdefault(key, []).append((a, idx))
+
+    def _py(self, fn, *args) -> None:
+        self._plan.entries.append([_PY, fn, list(args), None, 0.0, None])
+
+    def _edge(self, src, dst, name: str) -> None:
+        """dst waits for everything enqueued on src so far (no-op when they are the same stream)."""
+        if src.stream_id == dst.stream_id:
+            return
+        ev = self.event(name)
+        self._py(ev.record, src)
+        self._py(dst.wait_event, ev)
+
+    @staticmethod
+    def _off(t: torch.Tensor, nbytes: int) -> int:
+        return t.data_ptr() + nbytes
+
+    # ------------------------------------------------------------------------------------------------------------
+    def _weights_of(self, net):
+        return net.weights()
+
+    def _table_adam(self, enc, group: str):
+        """(param, grad, exp_avg, exp_avg_sq flat views of the table, first fused level) of a hash table in its arena."""
+        a = self.opt.arenas[group]
+        pname = next(n for n, e in a.tables.items() if e is enc)
+        off, _ = a.offsets[pname]
+        n = enc.params.numel()
+        stride = (1 << enc.log2_hashmap_size) * enc.n_features_per_level
+        n_sparse = next(((seg[2] - off) // stride for seg in self.opt._plan(group) if seg[0] == "rows" and seg[1] == off), 0)
+        return (a.param[off:off + n], a.grad[off:off + n], a.exp_avg[off:off + n], a.exp_avg_sq[off:off + n], n_sparse,
+                (off + n_sparse * stride, off + n))
+
+    def _grid_bwd(self, st, g, N, enc, group, ld, col, sorted_ws, stage, with_opt: bool, done: list) -> None:
+        """Table-gradient backward of one grid from the presorted records (+ Adam of its dense levels when with_opt)."""
+        L, F, T = enc.n_levels, enc.n_features_per_level, enc.log2_hashmap_size
+        p, gbuf, m, v, n_sparse, fused_range = self._table_adam(enc, group)
+        nrun = ops.hashgrid_run_levels(enc.scalings) if F == 2 else 0
+        fuse = with_opt and self.opt.fuse_table_adam and n_sparse < L
+        if fuse:
+            oc = self.opt.config[group]["optimizer"]
+            fused = ((L - n_sparse) << T) * F
+            self._k(st, "snf_hashgrid_bwd_presorted_adam", g, N, L, F, T, ld, col, nrun, gbuf, sorted_ws, stage, n_sparse,
+                    p, m, v, 0.0, float(oc.betas[0]), float(oc.betas[1]), float(oc.eps), 1, 1.0, tag=f"F{F}L{L}",
+                    units=float(N) * 8 * F * 4 * (L + n_sparse) + 24.0 * fused, dyn={("lr", group): 15, ("t", group): 19})
+            done.append(fused_range)
+        else:
+            self._k(st, "snf_hashgrid_bwd_presorted", g, N, L, F, T, ld, col, nrun, gbuf, sorted_ws, stage, tag=f"F{F}L{L}")
+
+    def _adam(self, st, group: str, lo: int, hi: int, done) -> None:
+        a, oc = self.opt.arenas[group], self.opt.config[group]["optimizer"]
+        b1, b2, eps = float(oc.betas[0]), float(oc.betas[1]), float(oc.eps)
+        for piece in self.opt.adam_pieces(group, lo, hi, done):
+            if piece[0] == "dense":
+                x0, x1 = piece[1], piece[2]
+                self._k(st, "snf_adam_step", a.param[x0:x1], a.grad[x0:x1], a.exp_avg[x0:x1], a.exp_avg_sq[x0:x1], x1 - x0,
+                        0.0, b1, b2, eps, 1, 1.0, 1, units=32.0 * (x1 - x0), dyn={("lr", group): 5, ("t", group): 9})
+            else:
+                rows, F = piece[1], piece[2]
+                self._keep.append(rows)
+                self._k(st, "snf_adam_step_rows", a.param, a.grad, a.exp_avg, a.exp_avg_sq, rows, rows.numel(), int(F), 0.0,
+                        b1, b2, eps, 1, 1.0, 1, units=32.0 * rows.numel() * F, dyn={("lr", group): 7, ("t", group): 11})
+
+    def _sort_ws(self, name: str, N: int, L: int, T: int, parity: Optional[int] = None) -> Tuple[torch.Tensor, int]:
+        nbytes = int(self.lib.snf_hashgrid_bwd_workspace_bytes(N, L, T))
+        return self.buf(name, ((nbytes + 3) // 4,), torch.int32, parity), nbytes
+
+    def _mlp64_bwd(self, st, x, ldx, in_real, ws, out_act, y, h1, h2, dy, lddy, dy_off, dy0, dx, lddx, N, pre: str):
+        """ops._mlp64_bwd_launch: data-gradient chain + the three (two) weight-gradient GEMMs into the gradient arena."""
+        nh = len(ws) - 1
+        out = ws[-1].shape[0]
+        ldz = (out + 3) // 4 * 4
+        dh1 = self.buf(pre + "dh1", (N, 64))
+        dh2 = self.buf(pre + "dh2", (N, 64)) if nh == 2 else None
+        dz = self.buf(pre + "dz", (N, ldz))
+        tag = f"{in_real}x{'x'.join(['64'] * nh)}x{out}"
+        self._k(st, "snf_mlp64_bwd_data", dy, lddy, dy_off, dy0, y, out, ws[0], in_real, ws[1] if nh == 2 else None, ws[-1],
+                nh, out, out_act, N, h1, h2, dh1, dh2, dz, ldz, dx, lddx, tag=tag)
+        pairs = [(dh1, 64, x, ldx, in_real, ws[0])]
+        if nh == 2:
+            pairs.append((dh2, 64, h1, 64, 64, ws[1]))
+        pairs.append((dz, ldz, h2 if nh == 2 else h1, 64, 64, ws[-1]))
+        for g, ldg, a, lda, I, w in pairs:
+            O = w.shape[0]
+            self._k(st, "snf_linear_bwd_weight", g, None, a, N, I, O, ldg, 0, lda, ops.ACT_NONE, w.main_grad, None,
+                    tag=f"{I}x{O}")
+
+    # ------------------------------------------------------------------------------------------------------------
+    def _build(self, parity: int, updated: bool, with_opt: bool, overlap: bool, prop_adam_when_idle: bool) -> _Plan:
+        plan = self._plan = _Plan()
+        self._keep: list = getattr(self, "_keep", [])
+        model, cfg, opt = self.model, self.cfg, self.opt
+        R, P, S, K = self.R, self.P, self.S, self.K
+        N0, N1, NK = R * P, R * S, R * K
+        main = self.main
+        side = {h: (self.tr._side[h] if overlap else main) for h in self.heads}
+        # the forward-time sorts ride on a head stream that is idle until the nerfacto forward has produced the weights
+        host = self.tr.presort_host if self.tr.presort_host in side else None
+        sort_st = side[host] if (overlap and host and ops.PRESORT_SIDE_STREAM) else main
+        f32 = torch.float32
+        b = self.buf
+        ACT = ops
+
+        # ---- inputs (filled by `_load_inputs` before the replay) and constants
+        o, d = b("in_o", (R, 3)), b("in_d", (R, 3))
+        image = b("in_image", (R, 3))
+        t_rand, u_rand = b("in_t_rand", (R,)), b("in_u_rand", (R,))
+        if "nears" not in self.bufs:
+            b("nears", (R,)).fill_(float(model.collider.near_plane))
+            b("fars", (R,)).fill_(float(model.collider.far_plane))
+            b("one", (1,)).fill_(1.0)
+        nears, fars, one = b("nears", (R,)), b("fars", (R,)), b("one", (1,))
+
+        # ================= main stream: proposal sampler (ray_samplers.py:549-599) =================
+        prop = model.proposal_networks[0]
+        penc, pnet = prop.mlp_base.encoding, prop.mlp_base.network
+        pw0, pw1 = pnet.weights()
+        PL, PF, PT = penc.n_levels, penc.n_features_per_level, penc.log2_hashmap_size
+        sb0, eb0 = b("sb0", (R, P + 1)), b("eb0", (R, P + 1))
+        self._k(main, "snf_sample_spacing", nears, fars, t_rand, R, P, sb0, eb0)
+        u0, sel0 = b("u0", (N0, 3)), b("sel0", (N0,), torch.uint8)
+        self._k(main, "snf_positions", o, d, eb0, None, R, P, P, ops.CONTRACT_LINF, 1, u0, sel0)
+        if updated:
+            ws_p, ws_p_bytes = self._sort_ws("ws_prop", N0, PL, PT)
+            self._edge(main, sort_st, "u0_ready")
+            self._k(sort_st, "snf_hashgrid_sort", u0, penc.scalings, N0, PL, PT, ws_p, ws_p_bytes, tag=f"L{PL}")
+            if sort_st.stream_id != main.stream_id:
+                self._py(self.event("prop_sorted").record, sort_st)
+        enc0 = b("enc0", (N0, PL * PF))
+        self._k(main, "snf_hashgrid_fwd", u0, penc.params, penc.scalings, N0, PL, PF, PT, enc0, PL * PF, 0, tag=f"F{PF}L{PL}")
+        I0, H0 = pnet.n_input_dims, pw0.shape[0]
+        hid0 = b("hid0", (N0, H0)) if updated else None
+        raw0 = b("raw0", (N0, 1))
+        self._k(main, "snf_mlp_tiny_fwd", enc0, I0, pw0, pw1, I0, H0, N0, hid0, raw0, tag=f"{I0}x{H0}x1")
+        dens0 = b("dens0", (N0,))
+        self._k(main, "snf_trunc_exp_fwd", raw0, 1, sel0, N0, dens0)
+        w0 = b("w0", (R, P))
+        self._k(main, "snf_weights_fwd", dens0, 1, 1, None, eb0, R, P, w0, None)
+        sb1, eb1 = b("sb1", (R, S + 1)), b("eb1", (R, S + 1))
+        self._k(main, "snf_pdf_resample", w0, sb0, u_rand, nears, fars, R, P, S, 1.0,
+                float(model.proposal_sampler.pdf_sampler.histogram_padding), sb1, eb1, dyn={("anneal",): 8})
+
+        # ================= main stream: nerfacto field (ops._NerfactoField) =================
+        fenc, fbase, fhead = model.field.mlp_base.encoding, model.field.mlp_base.network, model.field.mlp_head
+        bw0, bw1 = fbase.weights()
+        hw0, hw1, hw2 = fhead.weights()
+        FL, FF, FT = fenc.n_levels, fenc.n_features_per_level, fenc.log2_hashmap_size
+        u1, sel1 = b("u1", (N1, 3)), b("sel1", (N1,), torch.uint8)
+        self._k(main, "snf_positions", o, d, eb1, None, R, S, S, ops.CONTRACT_LINF, 1, u1, sel1)
+        ws_f, ws_f_bytes = self._sort_ws("ws_field", N1, FL, FT)
+        self._edge(main, sort_st, "u1_ready")
+        self._k(sort_st, "snf_hashgrid_sort", u1, fenc.scalings, N1, FL, FT, ws_f, ws_f_bytes, tag=f"L{FL}")
+        if sort_st.stream_id != main.stream_id:
+            self._py(self.event("field_sorted").record, sort_st)
+        enc1 = b("enc1", (FL * FF * N1,))
+        self._k(main, "snf_hashgrid_fwd", u1, fenc.params, fenc.scalings, N1, FL, FF, FT, enc1, 0, 0, tag=f"F{FF}L{FL}")
+        C = bw1.shape[0]  # 1 + geo
+        hb1, h = b("hb1", (N1, 64)), b("h", (N1, C))
+        self._k(main, "snf_mlp64_fwd", enc1, 0, bw0, FL * FF, None, bw1, 1, C, ops.ACT_NONE, N1, hb1, None, h, C,
+                tag=f"{FL * FF}x64x{C}")
+        density1 = b("density1", (N1,))
+        self._k(main, "snf_trunc_exp_fwd", h, C, sel1, N1, density1)
+        x2 = b("x2", (N1, 32))
+        n_geo = C - 1
+        self._k(main, "snf_head_input", d, self._off(h, 4), R, S, n_geo, C, x2, 32)
+        hh1, hh2, rgb = b("hh1", (N1, 64)), b("hh2", (N1, 64)), b("rgb", (N1, 3))
+        self._k(main, "snf_mlp64_fwd", x2, 32, hw0, 16 + n_geo, hw1, hw2, 2, 3, ops.ACT_SIGMOID, N1, hh1, hh2, rgb, 3,
+                tag=f"{16 + n_geo}x64x64x3")
+        w1 = b("w1", (R, S))
+        self._k(main, "snf_weights_fwd", density1, 1, 1, None, eb1, R, S, w1, None)
+        out_rgb, depth, acc, pdepth = b("out_rgb", (R, 3)), b("out_depth", (R, 1)), b("out_acc", (R, 1)), b("out_pdepth", (R, 1))
+        self._k(main, "snf_composite_fwd", rgb, w1, None, R, S, 1, out_rgb, None, None)
+        self._k(main, "snf_composite_fwd", None, w1, eb1, R, S, 1, None, acc, depth)
+        self._k(main, "snf_composite_fwd", None, w0, eb0, R, P, 1, None, None, pdepth)
+
+        # ================= feature-sample selection, shared by the heads (sam_model.py:243-255) =================
+        if self.heads:
+            sf = model.sam_field
+            ids, wk = b("ids", (R, K), torch.int32), b("wk", (R, K), parity=parity)
+            self._k(main, "snf_topk_sharpen", w1, R, S, K, float(cfg.sharpening_temperature), ids, wk)
+            uk = b("uk", (NK, 3), parity=parity)
+            self._k(main, "snf_positions", o, d, eb1, ids, R, S, K, ops.CONTRACT_L2, 0, uk, None)
+            geo_ws = {}
+            for enc in sf.clip_encs:  # the SAM and ClipSeg grids share the two level geometries: one sort per geometry
+                key = ops._geometry_key(enc.scalings, enc.n_levels, enc.log2_hashmap_size)
+                if key not in geo_ws:
+                    ws, nb = self._sort_ws(f"ws_feat{len(geo_ws)}", NK, enc.n_levels, enc.log2_hashmap_size, parity)
+                    self._k(main, "snf_hashgrid_sort", uk, enc.scalings, NK, enc.n_levels, enc.log2_hashmap_size, ws, nb,
+                            tag=f"L{enc.n_levels}")
+                    geo_ws[key] = ws
+
+        # ================= nerf losses, forward (nerfacto.py:316-344) =================
+        mse_acc = b("mse_acc_rgb", (516,), zero=True)
+        mse_out = b("mse_out_rgb", (2,))
+        RC = R * 3 // 64
+        self._k(main, "snf_rowmse_loss_fwd", out_rgb, image, RC, 64, 1.0, 0, mse_acc, mse_out)
+        rows_d, gw_d = b("rows_d", (R,)), b("gw_d", (R, S))
+        self._k(main, "snf_distortion", sb1, w1, R, S, 1.0 / float(R), rows_d, gw_d)
+        rows_i = b("rows_i", (R,))
+        gwp = b("gwp", (R, P)) if updated else None
+        self._k(main, "snf_interlevel", sb1, w1, sb0, w0, R, S, P, 1.0 / float(R * S), rows_i, gwp)
+        summary = b("loss_summary", (8,))
+        self._k(main, "snf_nerf_loss_summary", mse_out, rows_i, float(cfg.interlevel_loss_mult) / float(R * S), rows_d,
+                1.0 / float(R), float(cfg.distortion_loss_mult), R, summary)
+
+        # ================= feature heads: one task per head on its own stream =================
+        for hname in self.heads:
+            st = side[hname]
+            self._edge(main, st, f"selected_{hname}")
+            self._head_task(st, hname, parity, with_opt, geo_ws)
+            if st.stream_id != main.stream_id:
+                self._py(self._mark_head_busy, st, parity, hname)
+
+        # ================= main stream: backward of the nerf losses =================
+        d_rgb = b("d_out_rgb", (R, 3))
+        self._k(main, "snf_rowmse_loss_bwd", out_rgb, image, RC, 64, 1.0, 0, one, mse_out, d_rgb)
+        grgb, gw = b("grgb", (N1, 3)), b("gw", (R, S))
+        self._k(main, "snf_composite_bwd", rgb, w1, d_rgb, R, S, grgb, gw)
+        self._k(main, "snf_add_scaled", N1, float(cfg.distortion_loss_mult), gw_d, gw)
+        gd1 = b("gd1", (N1,))
+        self._k(main, "snf_weights_bwd", density1, 1, 1, None, eb1, gw, R, S, gd1)
+        dx2 = b("dx2", (N1, 32))
+        self._mlp64_bwd(main, x2, 32, 16 + n_geo, (hw0, hw1, hw2), ops.ACT_SIGMOID, rgb, hh1, hh2, grgb, 3, 0, None, dx2, 32,
+                        N1, "hd_")
+        graw = b("graw", (N1,))
+        self._k(main, "snf_trunc_exp_bwd", h, C, sel1, gd1, N1, graw, 1)
+        denc1 = b("denc1", (FL * FF * N1,))
+        self._mlp64_bwd(main, enc1, 0, FL * FF, (bw0, bw1), ops.ACT_NONE, None, hb1, None, dx2, 32, 15, graw, denc1, 0, N1,
+                        "bs_")
+        if sort_st.stream_id != main.stream_id:
+            self._py(main.wait_event, self.event("field_sorted"))
+        done_f: list = []
+        self._grid_bwd(main, denc1, N1, fenc, "fields", 0, 0, ws_f, None, with_opt, done_f)
+        done_p: list = []
+        if updated:
+            gd0 = b("gd0", (N0,))
+            self._k(main, "snf_weights_bwd", dens0, 1, 1, None, eb0, gwp, R, P, gd0)
+            graw0 = b("graw0", (N0, 1))
+            self._k(main, "snf_trunc_exp_bwd", raw0, 1, sel0, gd0, N0, graw0, 1)
+            denc0 = b("denc0", (N0, I0))
+            self._k(main, "snf_mlp_tiny_bwd", graw0, enc0, I0, hid0, pw0, pw1, I0, H0, N0, denc0, I0, pw0.main_grad,
+                    pw1.main_grad, tag=f"{I0}x{H0}x1")
+            if sort_st.stream_id != main.stream_id:
+                self._py(main.wait_event, self.event("prop_sorted"))
+            stage0 = b("stage_prop", (PL * N0 * PF,))
+            self._grid_bwd(main, denc0, N0, penc, "proposal_networks", PL * PF, 0, ws_p, stage0, with_opt, done_p)
+        if with_opt:
+            self._adam(main, "fields", 0, opt.arenas["fields"].numel, done_f)
+            if updated or prop_adam_when_idle:
+                self._adam(main, "proposal_networks", 0, opt.arenas["proposal_networks"].numel, done_p)
+        self._plan = None
+        return plan
+
+    # ------------------------------------------------------------------------------------------------------------
+    def _linear_fwd_ws(self, st, x, w, bias, N, I, O, act, y, tag, name):
+        nbytes = int(self.lib.snf_linear_fwd_workspace_bytes(N, I, O))
+        ws = self.buf(name, (max(nbytes, 16) // 4,))
+        self._k(st, "snf_linear_fwd_ws", x, w, bias, N, I, O, I, O, act, y, ws, nbytes, tag=tag)
+
+    def _head_task(self, st, hname: str, parity: int, with_opt: bool, geo_ws: dict) -> None:
+        """One feature head, forward to optimizer (sam_model.py:243-277,316-328; sam_field.py:112-140)."""
+        model, cfg, opt = self.model, self.cfg, self.opt
+        R, K = self.R, self.K
+        NK = R * K
+        b = self.buf
+        sf = model.sam_field
+        encs = list(sf.clip_encs if hname == "sam" else sf.clipseg_encs)
+        net = sf.sam_net if hname == "sam" else sf.clipseg_net
+        ws_ = net.weights()
+        uk, wk = b("uk", (NK, 3), parity=parity), b("wk", (R, K), parity=parity)
+        total = sum(e.n_output_dims for e in encs)
+        enc_out = b(f"{hname}_enc", (NK, total))
+        col = 0
+        for e in encs:
+            L, F, T = e.n_levels, e.n_features_per_level, e.log2_hashmap_size
+            self._k(st, "snf_hashgrid_fwd", uk, e.params, e.scalings, NK, L, F, T, enc_out, total, col, tag=f"F{F}L{L}")
+            col += L * F
+        # the head MLP (tcnn CutlassMLP role): ReLU between layers, no output activation
+        acts, x = [enc_out], enc_out
+        for i, w in enumerate(ws_):
+            O, I = w.shape
+            y = b(f"{hname}_a{i}", (NK, O))
+            act = ops.ACT_RELU if i < len(ws_) - 1 else net.output_activation
+            self._k(st, "snf_linear_fwd", x, w, None, NK, I, O, I, O, act, y, tag=f"{I}x{O}")
+            acts.append(y)
+            x = y
+        Cf = x.shape[1]
+        fm = b(f"{hname}_fm", (R, Cf))
+        self._k(st, "snf_feature_mean_fwd", x, wk, R, K, Cf, fm)
+        conv = hname == "sam" and cfg.patch_size > 1
+        if conv:
+            c0, c1 = model.conv_head[0], model.conv_head[2]
+            p, k = cfg.patch_size, c0.weight.shape[-1]
+            kk = k * k
+            O0, O1 = c0.weight.shape[0], c1.weight.shape[0]
+            npatch = R // (p * p)
+            colb = b("cv_col", (R, Cf * kk))
+            self._k(st, "snf_patch_unfold", fm, R, p, Cf, k, colb)
+            hc = b("cv_h", (R, O0))
+            self._linear_fwd_ws(st, colb, c0.weight, c0.bias, R, Cf * kk, O0, ops.ACT_RELU, hc, f"{Cf * kk}x{O0}", "cv_ws0")
+            cm = b("cv_cm", (npatch, O0 * kk))
+            self._k(st, "snf_patch_unfold_mean", hc, R, p, O0, k, cm)
+            pred = b("cv_y", (npatch, O1))
+            self._linear_fwd_ws(st, cm, c1.weight, c1.bias, npatch, O0 * kk, O1, ops.ACT_NONE, pred, f"{O0 * kk}x{O1}pm",
+                                "cv_ws1")
+            rows, Cp = npatch, O1
+        else:
+            pred, rows, Cp = fm, R, Cf
+        target = b(f"in_{hname}", (rows, Cp), parity=parity)
+        weight = float(cfg.sam_loss_weight if hname == "sam" else cfg.clipseg_loss_weight)
+        acc, out = b(f"mse_acc_{hname}", (516,), zero=True), b(f"mse_out_{hname}", (2,))
+        self._k(st, "snf_rowmse_loss_fwd", pred, target, rows, Cp, weight, 1, acc, out)
+        # ---- backward
+        one = b("one", (1,))
+        dpred = b(f"{hname}_dpred", (rows, Cp))
+        self._k(st, "snf_rowmse_loss_bwd", pred, target, rows, Cp, weight, 1, one, out, dpred)
+        if conv:
+            w0, b0, w1, b1 = c0.weight, c0.bias, c1.weight, c1.bias
+            self._k(st, "snf_linear_bwd_weight", dpred, None, cm, npatch, O0 * kk, O1, O1, O1, O0 * kk, ops.ACT_NONE,
+                    w1.main_grad, None if b1 is None else b1.main_grad, tag=f"{O0 * kk}x{O1}pm")
+            dcm = b("cv_dcm", (npatch, O0 * kk))
+            self._k(st, "snf_linear_bwd_data", dpred, None, w1, npatch, O0 * kk, O1, O1, O1, O0 * kk, ops.ACT_NONE, dcm,
+                    tag=f"{O0 * kk}x{O1}pm")
+            dh = b("cv_dh", (R, O0))
+            self._k(st, "snf_patch_fold_mean", dcm, R, p, O0, k, dh)
+            self._k(st, "snf_linear_bwd_weight", dh, hc, colb, R, Cf * kk, O0, O0, O0, Cf * kk, ops.ACT_RELU, w0.main_grad,
+                    None if b0 is None else b0.main_grad, tag=f"{Cf * kk}x{O0}")
+            dcol = b("cv_dcol", (R, Cf * kk))
+            self._k(st, "snf_linear_bwd_data", dh, hc, w0, R, Cf * kk, O0, O0, O0, Cf * kk, ops.ACT_RELU, dcol,
+                    tag=f"{Cf * kk}x{O0}")
+            dfm = b("cv_dfm", (R, Cf))
+            self._k(st, "snf_patch_fold", dcol, R, p, Cf, k, dfm)
+        else:
+            dfm = dpred
+        gy = b(f"{hname}_dfeat", (NK, Cf))
+        self._k(st, "snf_feature_mean_bwd", dfm, wk, R, K, Cf, gy)
+        for i in range(len(ws_) - 1, -1, -1):
+            w = ws_[i]
+            O, I = w.shape
+            act = ops.ACT_RELU if i < len(ws_) - 1 else net.output_activation
+            xin, yout = acts[i], acts[i + 1]
+            gx = b(f"{hname}_dx{i}", (NK, I))
+            self._k(st, "snf_linear_bwd_data", gy, yout, w, NK, I, O, O, O, I, act, gx, tag=f"{I}x{O}")
+            self._k(st, "snf_linear_bwd_weight", gy, yout, xin, NK, I, O, O, O, I, act, w.main_grad, None, tag=f"{I}x{O}")
+            gy = gx
+        done: list = []
+        col = 0
+        for e in encs:
+            L, F, T = e.n_levels, e.n_features_per_level, e.log2_hashmap_size
+            stage = b(f"{hname}_stage", (L * NK * F,))
+            self._grid_bwd(st, gy, NK, e, "sam_field", total, col, geo_ws[ops._geometry_key(e.scalings, L, T)], stage, with_opt,
+                           done)
+            col += L * F
+        if with_opt:
+            lo_i, hi_i = self.tr._head_param_ranges()[hname]
+            arena = opt.arenas["sam_field"]
+            names = list(arena.offsets)
+            lo = arena.offsets[names[lo_i]][0]
+            hi = arena.offsets[names[hi_i]][0] if hi_i < len(names) else arena.numel
+            self._adam(st, "sam_field", lo, hi, done)
+            if conv and "conv" in opt.arenas:
+                self._adam(st, "conv", 0, opt.arenas["conv"].numel, ())
+
+    # ------------------------------------------------------------------------------------------------------------
+    # run-time pieces referenced by the recorded schedule
+    def _wait_head_free(self, main, parity: int, hname: str) -> None:
+        ev = self.events.get(f"head_done_{hname}_{parity}")
+        if ev is not None and self._head_busy.get((parity, hname)):
+            main.wait_event(ev)
+
+    def _mark_head_busy(self, st, parity: int, hname: str) -> None:
+        self.event(f"head_done_{hname}_{parity}").record(st)
+        self._head_busy[(parity, hname)] = True
+
+    def _load_inputs(self, step: int, parity: int) -> None:
+        """next_train(step) into the schedule's input buffers; the samplers' per-ray jitter (ray_samplers.py:105,318)."""
+        dm = self.tr.pipeline.datamanager
+        b = self.buf
+        R = self.R
+        into = getattr(dm, "next_train_into", None)
+        targets = {h: self.bufs[f"in_{h}@{parity}"] for h in self.heads}
+        if into is not None and "next_train" not in dm.__dict__:
+            into(step, b("in_o", (R, 3)), b("in_d", (R, 3)), b("in_image", (R, 3)), targets)
+        else:
+            rb, batch = dm.next_train(step)
+            b("in_o", (R, 3)).copy_(rb.origins.reshape(R, 3))
+            b("in_d", (R, 3)).copy_(rb.directions.reshape(R, 3))
+            b("in_image", (R, 3)).copy_(batch["image"].reshape(R, 3))
+            for h, t in targets.items():
+                t.copy_(batch[h].reshape(t.shape))
+        ps = self.model.proposal_sampler
+        for smp, name in ((ps.initial_sampler, "in_t_rand"), (ps.pdf_sampler, "in_u_rand")):
+            dst = b(name, (R,))
+            if smp.jitter_override is not None:
+                dst.copy_(smp.jitter_override.reshape(-1))
+            else:
+                torch.rand((R,), out=dst)
+
+    # ------------------------------------------------------------------------------------------------------------
+    def run(self, step: int):
+        """One train step: same contract as the eager `Trainer.train_iteration` body (callbacks are the caller's)."""
+        tr, opt, model = self.tr, self.opt, self.model
+        if torch.cuda.current_stream().stream_id != self.main.stream_id:
+            raise RuntimeError("StepProgram was built for another main stream")
+        ps = model.proposal_sampler
+        updated = bool(ps._steps_since_update > ps.update_sched(ps._step) or ps._step < 10)
+        ps.last_updated = updated
+        overlap = bool(tr.overlap and self.heads)
+        if overlap and tr._side is None:
+            tr._side = {"sam": ops.make_stream("sam"), "clipseg": ops.make_stream("clipseg")}
+        with_opt = bool(opt.enabled)
+        parity = self.count & 1
+        key = (parity, updated, with_opt, overlap, tr.presort_host, ops.PRESORT_SIDE_STREAM, tr.zero_grad_adam)
+        plan = self.plans.get(key)
+        if plan is None:
+            for h in self.heads:  # the targets' buffers exist before the first load
+                rows = self.R // (self.cfg.patch_size ** 2) if (h == "sam" and self.cfg.patch_size > 1) else self.R
+                self.buf(f"in_{h}", (rows, 256 if h == "sam" else 192), parity=parity)
+            plan = self.plans[key] = self._build(parity, updated, with_opt, overlap, tr.zero_grad_adam)
+        if overlap:  # a head task of this parity (two steps ago) may still be reading the buffers this step overwrites
+            for h in self.heads:
+                self._wait_head_free(self.main, parity, h)
+        self._load_inputs(step, parity)
+        # ---- this step's dynamic values
+        stepped = []
+        if with_opt:
+            stepped = [g for g in opt.arenas if g != "proposal_networks" or updated or tr.zero_grad_adam]
+        vals = {("anneal",): float(ps._anneal)}
+        for g in opt.arenas:
+            vals[("lr", g)] = float(opt.lr(g))
+            vals[("t", g)] = int(opt.step_count[g] + 1)
+        for k, sites in plan.dyn.items():
+            v = vals[k]
+            for a, i in sites:
+                a[i] = v
+        # ---- replay
+        sel = ops._TIMING["names"]
+        if sel is None:
+            for kind, fn, args, key_, _, _ in plan.entries:
+                if kind == _KERNEL:
+                    rc = fn(*args)
+                    if rc:
+                        _lib.check(rc, key_)
+                else:
+                    fn(*args)
+        else:
+            self._replay_timed(plan, sel)
+        for g in stepped:
+            opt.step_count[g] += 1
+        if updated:
+            ps._steps_since_update = 0
+        self.count += 1
+        # ---- results (views of the schedule's buffers: valid until the next step of the same parity overwrites them)
+        s = self.bufs["loss_summary"]
+        loss_dict = {"rgb_loss": s[1], "interlevel_loss": s[2], "distortion_loss": s[3]}
+        for h in self.heads:
+            loss_dict[tr.HEAD_LOSS[h]] = self.bufs[f"mse_out_{h}"][0]
+        metrics_dict = {"psnr": s[5], "distortion": s[4]}
+        loss = s[0]
+        if overlap and not tr.pipeline_steps:
+            for h in self.heads:
+                self.main.wait_stream(tr._side[h])
+        if self.heads and not (overlap and tr.pipeline_steps):
+            loss = loss + sum(loss_dict[tr.HEAD_LOSS[h]] for h in self.heads)
+        return loss, loss_dict, metrics_dict
+
+    def _replay_timed(self, plan: _Plan, sel) -> None:
+        """bench.py's per-launch HIP-event timing (ops.enable_kernel_timing): events go on the stream of the launch."""
+        evs = ops._TIMING["events"]
+        for kind, fn, args, key, units, st in plan.entries:
+            if kind != _KERNEL:
+                fn(*args)
+                continue
+            name = key.partition("/")[0]
+            if sel == "all" or key in sel or name in sel:
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(st)
+                rc = fn(*args)
+                b.record(st)
+                evs.setdefault(key, []).append((a, b, st.stream_id, units))
+            else:
+                rc = fn(*args)
+            if rc:
+                _lib.check(rc, key)
+
+    def outputs(self) -> Dict[str, torch.Tensor]:
+        """The model outputs of the last step (sam_model.py:233-301 keys), as views of the schedule's buffers."""
+        parity = (self.count - 1) & 1
+        out = {"rgb": self.bufs["out_rgb"], "accumulation": self.bufs["out_acc"], "depth": self.bufs["out_depth"],
+               "prop_depth_0": self.bufs["out_pdepth"]}
+        if "sam" in self.heads:
+            out["sam"] = self.bufs["cv_y"] if self.cfg.patch_size > 1 else self.bufs["sam_fm"]
+        if "clipseg" in self.heads:
+            out["clipseg"] = self.bufs["clipseg_fm"]
+        del parity
+        return out

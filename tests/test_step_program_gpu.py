@@ -1,0 +1,128 @@
+"""GPU: the static launch schedule of the train step (samnerf_amd/step_program.py) against the eager autograd path.
+
+Both run the same kernels with the same arguments; the only differences allowed are fp32 summation order inside the
+atomically accumulated weight gradients.  The eager path is itself checked against the CPU oracle and the golden
+`ministep` vectors (tests/test_model_gpu.py), so equality here carries that parity over to the schedule the trainer and
+bench.py actually run."""
+import copy
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _trainer(method: str, static: bool, R: int, T: int, P: int = 32, S: int = 32, K: int = 8, seed: int = 3):
+    from samnerf_amd import configs, tcnn_compat
+    tc = copy.deepcopy(configs.method_configs[method])
+    tc.pipeline.datamanager.train_num_rays_per_batch = R
+    tc.pipeline.datamanager.seed = seed
+    mc = tc.pipeline.model
+    mc.num_proposal_samples_per_ray, mc.num_nerf_samples_per_ray, mc.num_sam_samples = (P,), S, K
+    mc.log2_hashmap_size, mc.hashgrid_sizes = min(19, T), (min(19, T),) * 2
+    mc.proposal_net_args_list = [dict(a, log2_hashmap_size=min(17, T)) for a in mc.proposal_net_args_list]
+    tcnn_compat.manual_seed(seed)
+    torch.manual_seed(seed)  # nn.Conv2d initialises the conv head from the default generator
+    trainer = tc.setup(device="cuda")
+    trainer.setup()
+    trainer.static_step = static
+    return trainer
+
+
+def _run(trainer, steps: int):
+    torch.manual_seed(17)  # the samplers' per-ray jitter comes from the default generator
+    losses = []
+    for step in range(steps):
+        loss, ld, md = trainer.train_iteration(step)
+        trainer.synchronize()
+        losses.append({k: float(v) for k, v in ld.items()} | {"psnr": float(md["psnr"]), "distortion": float(md["distortion"])})
+    torch.cuda.synchronize()
+    return losses
+
+
+def _rel_to_max(a: torch.Tensor, b: torch.Tensor) -> float:
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+@pytest.mark.parametrize("method", ["samnerf_distill", "samnerf_no_distill"])
+def test_one_step_gives_the_eager_gradients(method):
+    """After ONE step from identical parameters, Adam's first moment is 0.1 x the gradient of every parameter: it must
+    match the eager path's to fp32 summation order, for all four groups, and so must every loss term."""
+    ref = _trainer(method, False, 512, 13)
+    l_ref = _run(ref, 1)
+    assert ref._program is None
+    new = _trainer(method, True, 512, 13)
+    l_new = _run(new, 1)
+    assert new._program is not None, new._program_off
+    for k, v in l_ref[0].items():
+        assert abs(l_new[0][k] - v) <= 1e-5 * max(1.0, abs(v)), (k, l_new[0][k], v)
+    for g, a in ref.optimizers.arenas.items():
+        b = new.optimizers.arenas[g]
+        assert _rel_to_max(b.exp_avg, a.exp_avg) <= 2e-6, g
+        assert _rel_to_max(b.exp_avg_sq, a.exp_avg_sq) <= 4e-6, g
+        assert float(b.grad.abs().max()) == 0.0, g  # re-zeroed by the fused Adam passes
+        assert new.optimizers.step_count[g] == ref.optimizers.step_count[g] == 1
+
+
+@pytest.mark.parametrize("overlap", [True, False])
+def test_trajectory_follows_the_eager_path(overlap):
+    """14 steps (the proposal network trains on every step below 10 and on every other step after that, so both variants
+    of the schedule run, on both buffer parities): per-step loss terms agree to 1e-4 relative, step counters are equal."""
+    ref = _trainer("samnerf_distill", False, 256, 12)
+    new = _trainer("samnerf_distill", True, 256, 12)
+    ref.overlap = new.overlap = overlap
+    ref.pipeline_steps = new.pipeline_steps = overlap
+    l_ref, l_new = _run(ref, 14), _run(new, 14)
+    upd = [s for s in range(14)]
+    assert new._program is not None and len(new._program.plans) >= 3  # parities x {updated, not updated}
+    for step, (a, b) in enumerate(zip(l_ref, l_new)):
+        for k, v in a.items():
+            assert abs(b[k] - v) <= 1e-4 * max(1e-3, abs(v)), (step, k, b[k], v)
+    assert dict(new.optimizers.step_count) == dict(ref.optimizers.step_count)
+    assert dict(new.optimizers.sched_step) == dict(ref.optimizers.sched_step)
+    ps_r, ps_n = ref.pipeline.model.proposal_sampler, new.pipeline.model.proposal_sampler
+    assert (ps_r._steps_since_update, ps_r._step) == (ps_n._steps_since_update, ps_n._step)
+    del upd
+
+
+def test_proposal_group_is_stepped_with_zero_gradient_on_non_update_steps():
+    """Reference semantics (torch < 2 pinned, requirements.txt:32): zero_grad() zero-fills, so on a step where the proposal
+    network gets no gradient Adam still decays its moments and moves the parameters; SNF_TORCH2_NONE_GRADS=1 skips."""
+    for static in (True, False):
+        tr = _trainer("samnerf_no_distill", static, 256, 12)
+        ps = tr.pipeline.model.proposal_sampler
+        _run(tr, 10)
+        a = tr.optimizers.arenas["proposal_networks"]
+        seen = False
+        for step in range(10, 14):
+            m0, p0, c0 = a.exp_avg.clone(), a.param.clone(), tr.optimizers.step_count["proposal_networks"]
+            tr.train_iteration(step)
+            torch.cuda.synchronize()
+            if not ps.last_updated:
+                seen = True
+                assert tr.optimizers.step_count["proposal_networks"] == c0 + 1
+                nz = m0 != 0
+                assert torch.allclose(a.exp_avg[nz], 0.9 * m0[nz], rtol=1e-6, atol=0)  # m <- beta1 m + 0 gradient
+                assert not torch.equal(a.param, p0)
+        assert seen
+
+
+def test_bench_workload_full_size_one_step():
+    """BASELINE configs[2] at full size (R=4096 x S=128, K=16, T=19): the schedule's first-moment arenas equal the eager
+    path's after one step (all 221 M parameters)."""
+    import bench
+    w = dict(bench.WORKLOADS["distill_4096x128"])
+    trs = []
+    for static in (False, True):
+        torch.manual_seed(1)
+        tr = bench.build_trainer(w, 0, 1, seed=1)
+        tr.static_step = static
+        torch.manual_seed(9)
+        tr.train_iteration(0)
+        tr.synchronize()
+        torch.cuda.synchronize()
+        trs.append(tr)
+    assert trs[1]._program is not None, trs[1]._program_off
+    for g, a in trs[0].optimizers.arenas.items():
+        b = trs[1].optimizers.arenas[g]
+        assert _rel_to_max(b.exp_avg, a.exp_avg) <= 2e-6, g
