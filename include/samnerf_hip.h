@@ -133,6 +133,12 @@ int snf_linear_fwd(const float* X, const float* W, const float* bias, int N, int
 int64_t snf_linear_fwd_workspace_bytes(int N, int I, int O);
 int snf_linear_fwd_ws(const float* X, const float* W, const float* bias, int N, int I, int O, int ldx, int ldy, int act,
                       float* Y, void* workspace, int64_t workspace_bytes, snf_stream_t stream);
+/* Level-major operands (ld = -8): a matrix with I % 8 == 0 columns stored as [I/8][N][8] -- what two F = 8 feature grids
+ * write side by side with snf_hashgrid_fwd(ld_out = 0) into one buffer (grid g at float offset g * L * N * 8).  Accepted as X
+ * by snf_linear_fwd (ldx = -8) and snf_linear_bwd_weight (ldx = -8), produced as dX by snf_linear_bwd_data (lddx = -8), whose
+ * output is then the staged gradient of snf_hashgrid_bwd_presorted[_adam] (ld_out = 0, pointer offset per grid): the
+ * [N, 192] row-major encoding of samnerf/sam_field.py:121-137 and its gradient never exist.  Needs gemm mode >= 1,
+ * 64 <= I <= 256, I % 16 == 0, O >= 64. */
 /* dX[N,I] = (dY * act'(Y)) W ;  Y is the layer OUTPUT (post-activation), may be NULL when act == NONE. */
 int snf_linear_bwd_data(const float* dY, const float* Y, const float* W, int N, int I, int O, int lddy,
                         int ldy, int lddx, int act, float* dX, snf_stream_t stream);

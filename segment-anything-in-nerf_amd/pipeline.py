@@ -161,7 +161,7 @@ class Trainer:
         self.overlap = os.environ.get("SNF_OVERLAP", "1") == "1"
         self.enqueue_order = os.environ.get("SNF_ENQUEUE_ORDER", "heads_first")
         self.pipeline_steps = False  # True: do not join the head streams at the end of a step (see train_iteration)
-        self.presort_host = os.environ.get("SNF_PRESORT_ON", "sam")  # "sam" | "clipseg" | "own"
+        self.presort_host = os.environ.get("SNF_PRESORT_ON", "auto")  # "auto" | "sam" | "clipseg" | "own"
         self._side = None
         # the step as a static launch schedule (step_program.py) instead of an autograd graph: same kernels, same arguments,
         # ~10x less host time per step.  SNF_STATIC_STEP=0 keeps the eager path (which multi-rank runs always use).
@@ -237,7 +237,7 @@ class Trainer:
         # the forward-time sorts ride on the SAM head's stream, which is idle until the nerfacto forward has produced the
         # weights: three streams in all, one hardware queue each ("own": a fourth stream -- ~1 % faster when it works, 15 %
         # slower in the runtime's slow mode)
-        host = self.presort_host
+        host = "sam" if self.presort_host == "auto" else self.presort_host
         ops_mod.PRESORT_HOST_STREAM = self._side[host] if (use_side and host in ("sam", "clipseg")) else None
         _, loss_dict, metrics_dict = self.pipeline.get_train_loss_dict(step=step)
         prop_updated = getattr(getattr(model, "proposal_sampler", None), "last_updated", True)

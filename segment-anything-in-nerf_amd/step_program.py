@@ -35,6 +35,10 @@ from . import _lib, ops
 from . import distributed as D
 
 _KERNEL, _PY = 0, 1
+import os as _os
+
+PLANAR_HEADS = _os.environ.get("SNF_PLANAR_HEADS", "1") == "1"  # level-major hand-off between the feature grids and the head MLP
+FEATURE_SORTS_ON_HEAD_STREAM = _os.environ.get("SNF_FEAT_SORT_SIDE", "1") == "1"
 
 
 class _Plan:
@@ -103,6 +107,9 @@ class StepProgram:
         self.events: Dict[str, torch.cuda.Event] = {}
         self._head_busy: Dict[tuple, bool] = {}  # (parity, head) -> a task of that parity has been enqueued
         self.count = 0
+        self._own_sort_stream = None
+        self._feat_sorted = None
+        self._feat_sort_stream_id = None
         # reference semantics of the optimizer on steps where the proposal network gets no gradient: the reference pins
         # torch < 2 (requirements.txt:32), whose zero_grad() zero-fills -- Adam still steps the group (moments decay)
         self.main = torch.cuda.current_stream()
@@ -231,9 +238,23 @@ class StepProgram:
         N0, N1, NK = R * P, R * S, R * K
         main = self.main
         side = {h: (self.tr._side[h] if overlap else main) for h in self.heads}
-        # the forward-time sorts ride on a head stream that is idle until the nerfacto forward has produced the weights
-        host = self.tr.presort_host if self.tr.presort_host in side else None
-        sort_st = side[host] if (overlap and host and ops.PRESORT_SIDE_STREAM) else main
+        # The backward sorts depend on positions only; they run beside the forward on the LEAST loaded stream.  With the steps
+        # pipelined (no join at the end of a step) the SAM stream is the busiest of the three (two 256-wide layers, the conv
+        # head, 0.4 GB of table Adam): event timeline of r02d: 3.8 / 3.6 / 2.4 ms busy per 4.06 ms step for sam / main /
+        # clipseg with the sorts on the sam stream -- so they ride on the clipseg stream (SNF_PRESORT_ON overrides); a run
+        # without feature heads gets a stream of its own for them.
+        sort_st = feat_sort_st = main
+        if overlap and ops.PRESORT_SIDE_STREAM:
+            pref = self.tr.presort_host
+            if pref == "auto":
+                pref = "clipseg" if "clipseg" in side else ("sam" if "sam" in side else "own")
+            if pref in side:
+                sort_st = side[pref]
+            else:
+                if self._own_sort_stream is None:
+                    self._own_sort_stream = ops.make_stream("presort")
+                sort_st = self._own_sort_stream
+            feat_sort_st = side.get("clipseg", main) if FEATURE_SORTS_ON_HEAD_STREAM else main
         f32 = torch.float32
         b = self.buf
         ACT = ops
@@ -317,14 +338,23 @@ class StepProgram:
             self._k(main, "snf_topk_sharpen", w1, R, S, K, float(cfg.sharpening_temperature), ids, wk)
             uk = b("uk", (NK, 3), parity=parity)
             self._k(main, "snf_positions", o, d, eb1, ids, R, S, K, ops.CONTRACT_L2, 0, uk, None)
+            for hname in self.heads:  # the heads' forward needs the selected samples only
+                self._edge(main, side[hname], f"selected_{hname}")
+            # the SAM and ClipSeg grids share the two level geometries: one sort per geometry, needed by the heads' BACKWARD
+            # only -- off the main stream's chain (it sits between the nerfacto forward and its backward there)
             geo_ws = {}
-            for enc in sf.clip_encs:  # the SAM and ClipSeg grids share the two level geometries: one sort per geometry
+            for enc in sf.clip_encs:
                 key = ops._geometry_key(enc.scalings, enc.n_levels, enc.log2_hashmap_size)
                 if key not in geo_ws:
                     ws, nb = self._sort_ws(f"ws_feat{len(geo_ws)}", NK, enc.n_levels, enc.log2_hashmap_size, parity)
-                    self._k(main, "snf_hashgrid_sort", uk, enc.scalings, NK, enc.n_levels, enc.log2_hashmap_size, ws, nb,
-                            tag=f"L{enc.n_levels}")
+                    self._k(feat_sort_st, "snf_hashgrid_sort", uk, enc.scalings, NK, enc.n_levels, enc.log2_hashmap_size, ws,
+                            nb, tag=f"L{enc.n_levels}")
                     geo_ws[key] = ws
+            self._feat_sorted = None
+            if any(side[h].stream_id != feat_sort_st.stream_id for h in self.heads):
+                self._feat_sorted = self.event(f"feat_sorted_{parity}")
+                self._py(self._feat_sorted.record, feat_sort_st)
+            self._feat_sort_stream_id = feat_sort_st.stream_id
 
         # ================= nerf losses, forward (nerfacto.py:316-344) =================
         mse_acc = b("mse_acc_rgb", (516,), zero=True)
@@ -343,7 +373,6 @@ class StepProgram:
         # ================= feature heads: one task per head on its own stream =================
         for hname in self.heads:
             st = side[hname]
-            self._edge(main, st, f"selected_{hname}")
             self._head_task(st, hname, parity, with_opt, geo_ws)
             if st.stream_id != main.stream_id:
                 self._py(self._mark_head_busy, st, parity, hname)
@@ -406,11 +435,23 @@ class StepProgram:
         ws_ = net.weights()
         uk, wk = b("uk", (NK, 3), parity=parity), b("wk", (R, K), parity=parity)
         total = sum(e.n_output_dims for e in encs)
-        enc_out = b(f"{hname}_enc", (NK, total))
+        # The encoding travels LEVEL-MAJOR ([total/8][NK][8], ld = -8) between the grids and the head's first layer: the
+        # level-at-a-time grid kernels then store whole lines (a row-major [NK,192] gets 32 bytes per 768-byte row from each
+        # level: 2x write amplification), the first layer's A fragments are 1 KB contiguous per half-wave, its data gradient
+        # is written straight into the staged-gradient layout of the table backward (no staging pass) and its weight
+        # gradient reads the same buffer.  Needs the bf16x3 GEMM kernels (gemm mode >= 1).
+        planar = (PLANAR_HEADS and int(self.lib.snf_get_gemm_mode()) >= 1 and all(e.n_features_per_level == 8 for e in encs)
+                  and total % 16 == 0 and 64 <= total <= 256)
+        ld_enc = -8 if planar else total
+        enc_out = b(f"{hname}_enc", (NK * total,) if planar else (NK, total))
         col = 0
         for e in encs:
             L, F, T = e.n_levels, e.n_features_per_level, e.log2_hashmap_size
-            self._k(st, "snf_hashgrid_fwd", uk, e.params, e.scalings, NK, L, F, T, enc_out, total, col, tag=f"F{F}L{L}")
+            if planar:
+                self._k(st, "snf_hashgrid_fwd", uk, e.params, e.scalings, NK, L, F, T, self._off(enc_out, col * NK * 4), 0, 0,
+                        tag=f"F{F}L{L}")
+            else:
+                self._k(st, "snf_hashgrid_fwd", uk, e.params, e.scalings, NK, L, F, T, enc_out, total, col, tag=f"F{F}L{L}")
             col += L * F
         # the head MLP (tcnn CutlassMLP role): ReLU between layers, no output activation
         acts, x = [enc_out], enc_out
@@ -418,7 +459,7 @@ class StepProgram:
             O, I = w.shape
             y = b(f"{hname}_a{i}", (NK, O))
             act = ops.ACT_RELU if i < len(ws_) - 1 else net.output_activation
-            self._k(st, "snf_linear_fwd", x, w, None, NK, I, O, I, O, act, y, tag=f"{I}x{O}")
+            self._k(st, "snf_linear_fwd", x, w, None, NK, I, O, ld_enc if i == 0 else I, O, act, y, tag=f"{I}x{O}")
             acts.append(y)
             x = y
         Cf = x.shape[1]
@@ -476,17 +517,23 @@ class StepProgram:
             O, I = w.shape
             act = ops.ACT_RELU if i < len(ws_) - 1 else net.output_activation
             xin, yout = acts[i], acts[i + 1]
-            gx = b(f"{hname}_dx{i}", (NK, I))
-            self._k(st, "snf_linear_bwd_data", gy, yout, w, NK, I, O, O, O, I, act, gx, tag=f"{I}x{O}")
-            self._k(st, "snf_linear_bwd_weight", gy, yout, xin, NK, I, O, O, O, I, act, w.main_grad, None, tag=f"{I}x{O}")
+            ldx = ld_enc if i == 0 else I
+            gx = b(f"{hname}_dx{i}", (NK * I,) if (i == 0 and planar) else (NK, I))
+            self._k(st, "snf_linear_bwd_data", gy, yout, w, NK, I, O, O, O, ldx, act, gx, tag=f"{I}x{O}")
+            self._k(st, "snf_linear_bwd_weight", gy, yout, xin, NK, I, O, O, O, ldx, act, w.main_grad, None, tag=f"{I}x{O}")
             gy = gx
         done: list = []
         col = 0
+        if self._feat_sorted is not None and st.stream_id != self._feat_sort_stream_id:
+            self._py(st.wait_event, self._feat_sorted)
         for e in encs:
             L, F, T = e.n_levels, e.n_features_per_level, e.log2_hashmap_size
-            stage = b(f"{hname}_stage", (L * NK * F,))
-            self._grid_bwd(st, gy, NK, e, "sam_field", total, col, geo_ws[ops._geometry_key(e.scalings, L, T)], stage, with_opt,
-                           done)
+            ws_sorted = geo_ws[ops._geometry_key(e.scalings, L, T)]
+            if planar:  # the first layer's data gradient IS the staged gradient gT[l][n][F] of this grid's levels
+                self._grid_bwd(st, self._off(gy, col * NK * 4), NK, e, "sam_field", 0, 0, ws_sorted, None, with_opt, done)
+            else:
+                stage = b(f"{hname}_stage", (L * NK * F,))
+                self._grid_bwd(st, gy, NK, e, "sam_field", total, col, ws_sorted, stage, with_opt, done)
             col += L * F
         if with_opt:
             lo_i, hi_i = self.tr._head_param_ranges()[hname]
@@ -542,8 +589,8 @@ class StepProgram:
         ps = model.proposal_sampler
         updated = bool(ps._steps_since_update > ps.update_sched(ps._step) or ps._step < 10)
         ps.last_updated = updated
-        overlap = bool(tr.overlap and self.heads)
-        if overlap and tr._side is None:
+        overlap = bool(tr.overlap)
+        if overlap and self.heads and tr._side is None:
             tr._side = {"sam": ops.make_stream("sam"), "clipseg": ops.make_stream("clipseg")}
         with_opt = bool(opt.enabled)
         parity = self.count & 1

@@ -604,3 +604,76 @@ def test_hashgrid_backward_with_fused_adam_matches_backward_then_adam(from_level
     for i, tol in ((0, 2e-6), (1, 1e-6), (2, 1e-6)):
         ref, got = out[False][i], out[True][i]
         assert float((got - ref).abs().max()) <= tol * max(1e-3, float(ref.abs().max())), i
+
+
+# ---------------------------------------------------------------------------------------------
+def _planar8(x: torch.Tensor) -> torch.Tensor:
+    """row-major [N, C] -> level-major [C/8][N][8] (flat)."""
+    N, C = x.shape
+    return x.view(N, C // 8, 8).permute(1, 0, 2).contiguous().view(-1)
+
+
+@pytest.mark.parametrize("N,I,O", [(65536, 192, 256), (5000, 192, 192), (4099, 64, 64)])
+def test_level_major_operands_of_the_head_layers(N, I, O):
+    """ld = -8: the feature grids hand their encoding to the head's first layer level-major ([I/8][N][8]).  Forward reads it
+    as the A operand, the weight gradient as X, and the data gradient is written in that layout (transposed accumulators).
+    Same arithmetic as the row-major calls: forward bit for bit, data gradient to the summation order inside one MFMA,
+    weight gradient to the order of its atomics."""
+    m = ops()
+    m.set_gemm_mode("bf16x3")
+    g = torch.Generator(device=DEV).manual_seed(N + I)
+    x = torch.randn((N, I), device=DEV, generator=g) * 0.3
+    w = torch.randn((O, I), device=DEV, generator=g) / I ** 0.5
+    gy = torch.randn((N, O), device=DEV, generator=g)
+    xp = _planar8(x)
+    st = m._stream()
+    # forward (ReLU epilogue)
+    y_ref = torch.empty((N, O), device=DEV)
+    y_pl = torch.empty((N, O), device=DEV)
+    m._launch("snf_linear_fwd", m._p(x), m._p(w), None, N, I, O, I, O, m.ACT_RELU, m._p(y_ref), st)
+    m._launch("snf_linear_fwd", m._p(xp), m._p(w), None, N, I, O, -8, O, m.ACT_RELU, m._p(y_pl), st)
+    assert torch.equal(y_pl, y_ref)
+    # data gradient (ReLU derivative from y)
+    dx_ref = torch.empty((N, I), device=DEV)
+    dx_pl = torch.full((N * I,), float("nan"), device=DEV)
+    m._launch("snf_linear_bwd_data", m._p(gy), m._p(y_ref), m._p(w), N, I, O, O, O, I, m.ACT_RELU, m._p(dx_ref), st)
+    m._launch("snf_linear_bwd_data", m._p(gy), m._p(y_ref), m._p(w), N, I, O, O, O, -8, m.ACT_RELU, m._p(dx_pl), st)
+    assert maxdiff(dx_pl, _planar8(dx_ref)) <= 2e-6 * float(dx_ref.abs().max())
+    # weight gradient
+    dw_ref = torch.zeros((O, I), device=DEV)
+    dw_pl = torch.zeros((O, I), device=DEV)
+    m._launch("snf_linear_bwd_weight", m._p(gy), m._p(y_ref), m._p(x), N, I, O, O, O, I, m.ACT_RELU, m._p(dw_ref), None, st)
+    m._launch("snf_linear_bwd_weight", m._p(gy), m._p(y_ref), m._p(xp), N, I, O, O, O, -8, m.ACT_RELU, m._p(dw_pl), None, st)
+    assert maxdiff(dw_pl, dw_ref) <= 2e-6 * float(dw_ref.abs().max())
+    # against fp64 at the bf16x3 round-off
+    ref = torch.relu(x.double() @ w.double().T)
+    assert maxdiff(y_pl, ref.float()) <= 2e-5 * max(1.0, float(ref.abs().max()))
+
+
+def test_level_major_feature_grids_feed_the_table_backward():
+    """Two F = 8 grids written level-major side by side equal the row-major concatenation, and a level-major gradient goes
+    into snf_hashgrid_bwd_presorted without the staging pass (ld_out = 0 on a pointer offset to the grid's first level)."""
+    m = ops()
+    N, L, F, T = 20000, 4, 8, 12
+    g = torch.Generator(device=DEV).manual_seed(5)
+    u = torch.rand((N, 3), device=DEV, generator=g)
+    sc = torch.tensor([16.0, 23.0, 35.0, 64.0], device=DEV)
+    tabs = [torch.randn(((L << T) * F,), device=DEV, generator=g) for _ in range(2)]
+    st = m._stream()
+    row = torch.empty((N, 2 * L * F), device=DEV)
+    pl = torch.empty((2 * L * N * F,), device=DEV)
+    for gi, tab in enumerate(tabs):
+        m._launch("snf_hashgrid_fwd", m._p(u), m._p(tab), m._p(sc), N, L, F, T, m._p(row), 2 * L * F, gi * L * F, st)
+        m._launch("snf_hashgrid_fwd", m._p(u), m._p(tab), m._p(sc), N, L, F, T, pl.data_ptr() + gi * L * N * F * 4, 0, 0, st)
+    assert torch.equal(pl, _planar8(row))
+    grad = torch.randn((N, 2 * L * F), device=DEV, generator=g)
+    gpl = _planar8(grad)
+    nbytes = int(m._L().snf_hashgrid_bwd_workspace_bytes(N, L, T))
+    ws = torch.empty(((nbytes + 3) // 4,), device=DEV, dtype=torch.int32)
+    m._launch("snf_hashgrid_sort", m._p(u), m._p(sc), N, L, T, m._p(ws), nbytes, st)
+    for gi in range(2):
+        a, bq = torch.zeros_like(tabs[gi]), torch.zeros_like(tabs[gi])
+        stage = torch.empty((L * N * F,), device=DEV)
+        m._launch("snf_hashgrid_bwd_presorted", m._p(grad), N, L, F, T, 2 * L * F, gi * L * F, 0, m._p(a), m._p(ws), m._p(stage), st)
+        m._launch("snf_hashgrid_bwd_presorted", gpl.data_ptr() + gi * L * N * F * 4, N, L, F, T, 0, 0, 0, m._p(bq), m._p(ws), None, st)
+        assert torch.equal(a, bq)
