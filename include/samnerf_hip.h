@@ -147,6 +147,15 @@ int snf_linear_bwd_data(const float* dY, const float* Y, const float* W, int N, 
 int snf_linear_bwd_weight(const float* dY, const float* Y, const float* X, int N, int I, int O, int lddy,
                           int ldy, int ldx, int act, float* dW, float* dbias, snf_stream_t stream);
 
+/* The weight gradient with a caller-provided scratch buffer (size: snf_linear_bwd_weight_workspace_bytes; 0 = this shape does
+ * not use one).  The feature-head layers (64 <= I, O <= 256, N >= 8192, no bias, gemm mode >= 1) then run a full-width
+ * kernel: a workgroup owns a chunk of rows and the whole O x I output, so dY, Y and X are read from HBM exactly once (the
+ * tiled kernel re-reads them once per 64 x 64 output tile), per-chunk partial sums go to the scratch buffer and a second
+ * small kernel adds them to dW.  Other shapes, a NULL or short workspace: identical to snf_linear_bwd_weight. */
+int64_t snf_linear_bwd_weight_workspace_bytes(int N, int I, int O);
+int snf_linear_bwd_weight_ws(const float* dY, const float* Y, const float* X, int N, int I, int O, int lddy, int ldy, int ldx,
+                             int act, float* dW, float* dbias, void* workspace, int64_t workspace_bytes, snf_stream_t stream);
+
 /* ---- a7, tiny: the proposal networks' density MLP (nerfstudio/fields/density_fields.py:80-97 with hidden_dim 16:
  *      I -> H (ReLU) -> 1, bias-free) in one launch per direction, one thread per sample.  Built for I = 10, H = 16
  *      (snf_mlp_tiny_supported).  Hid [N,H] receives the hidden activations (may be NULL at inference); the backward

@@ -489,3 +489,25 @@ extern "C" int snf_linear_bwd_weight(const float* dY, const float* Y, const floa
     SNF_LAUNCH_CHECK("snf_linear_bwd_weight");
     return SNF_OK;
 }
+
+// Weight gradient with a caller-provided scratch buffer: the feature-head shapes (64 <= I, O <= 256, N >= 8192, no bias, gemm
+// mode >= 1) run the full-width kernel of linear_b3.hip -- every operand element read once, per-chunk partial sums in the
+// scratch buffer, a second small kernel adds them to dW.  Everything else (and a NULL / short workspace) is
+// snf_linear_bwd_weight.
+extern "C" int64_t snf_linear_bwd_weight_workspace_bytes(int N, int I, int O) {
+    if (N <= 0 || I <= 0 || O <= 0) return 0;
+    return (int64_t)b3_wgrad_full_workspace_bytes(N, I, O);
+}
+
+extern "C" int snf_linear_bwd_weight_ws(const float* dY, const float* Y, const float* X, int N, int I, int O, int lddy, int ldy,
+                                        int ldx, int act, float* dW, float* dbias, void* workspace, int64_t workspace_bytes,
+                                        snf_stream_t stream) {
+    SNF_REQUIRE(dY && X && dW, "snf_linear_bwd_weight_ws: null pointer");
+    SNF_REQUIRE(act == SNF_ACT_NONE || Y, "snf_linear_bwd_weight_ws: Y required for activation derivative");
+    if (N > 0 && I > 0 && O > 0 && lddy >= O && act != SNF_ACT_GELU &&
+        b3_try_bwd_weight_full(dY, Y, X, N, I, O, lddy, ldy, ldx, act, dW, dbias, workspace, workspace_bytes, stream)) {
+        SNF_LAUNCH_CHECK("snf_linear_bwd_weight_ws");
+        return SNF_OK;
+    }
+    return snf_linear_bwd_weight(dY, Y, X, N, I, O, lddy, ldy, ldx, act, dW, dbias, stream);
+}

@@ -333,6 +333,130 @@ __global__ __launch_bounds__(256) void k_gemm_wgrad_b3(const float* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Full-width weight gradient for the feature-head layers (O, I <= 256, tens of thousands of rows).
+// The tiled kernel above gives every 64 x 64 output tile its own pass over the rows: dY is read I/64 times and X O/64 times
+// (rocprofv3 FETCH_SIZE, r02f: 2.2 GB per step for the seven launches against 1.0 GB of operands).  Here a workgroup owns a
+// chunk of ROWS and the WHOLE O x I output: every operand element is read from HBM exactly once.  8 waves as 4 (o) x 2 (i),
+// a wave accumulates 64 x 128 outputs (2 x 4 accumulator tiles = 128 registers) over its chunk; per 16-row trip both
+// operands are staged transposed as bf16 hi / lo planes [column][k = row] (48-byte pitch: the b128 fragment reads of 16
+// lanes hit 16 distinct bank quads), one k-step of 3 x 8 MFMAs per wave.  The chunk sums go to a partial buffer
+// P[chunk][O][I] with plain coalesced stores and a second small kernel adds them to dW -- no float atomics on the
+// O x I x chunks partial sums (deterministic up to the few-way split of that second pass).
+constexpr int WF_PITCH = 24;  // bf16 per LDS row: 16 k + 8 pad
+constexpr int WF_T = 512;
+
+__global__ __launch_bounds__(WF_T) void k_wgrad_full_b3(const float* __restrict__ dY, const float* __restrict__ Y,
+                                                        const float* __restrict__ X, int N, int I, int O, int lddy, int ldy,
+                                                        int ldx, int act, int rows_per_wg, float* __restrict__ P) {
+    __shared__ __attribute__((aligned(16))) uint16_t Ah[256 * WF_PITCH];
+    __shared__ __attribute__((aligned(16))) uint16_t Al[256 * WF_PITCH];
+    __shared__ __attribute__((aligned(16))) uint16_t Bh[256 * WF_PITCH];
+    __shared__ __attribute__((aligned(16))) uint16_t Bl[256 * WF_PITCH];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, half = lane >> 5, wm = wave >> 1, wn = wave & 1;
+    const int n_begin = blockIdx.x * rows_per_wg, n_end = min(N, n_begin + rows_per_wg);
+    const int kp = tid & 7, q = tid >> 3;  // row pair within the 16-row trip, column quad (columns 4q .. 4q+3)
+    const int col = q * 4;
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[u][t][i] = 0.f;
+    float4 av[2], bv[2];
+    auto fetch = [&](int n0) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int n = n0 + 2 * kp + p;
+            av[p] = b3_load_a<true>(dY, Y, n, col, n_end, O, lddy, ldy, act);
+            bv[p] = ldx < 0 ? b3_load_b_planar8(X, n, col, n_end, I, N) : b3_load_b(X, n, col, n_end, I, ldx);
+        }
+    };
+    fetch(n_begin);
+    const bool m_on[2] = {64 * wm < O, 64 * wm + 32 < O};
+    for (int n0 = n_begin; n0 < n_end; n0 += 16) {
+        __syncthreads();
+        {
+            const float a0[4] = {av[0].x, av[0].y, av[0].z, av[0].w}, a1[4] = {av[1].x, av[1].y, av[1].z, av[1].w};
+            const float b0[4] = {bv[0].x, bv[0].y, bv[0].z, bv[0].w}, b1[4] = {bv[1].x, bv[1].y, bv[1].z, bv[1].w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                uint32_t h, l;
+                split2(a0[c], a1[c], h, l);  // rows (2kp, 2kp+1) of column col + c -> k positions (2kp, 2kp+1)
+                *reinterpret_cast<uint32_t*>(&Ah[(col + c) * WF_PITCH + 2 * kp]) = h;
+                *reinterpret_cast<uint32_t*>(&Al[(col + c) * WF_PITCH + 2 * kp]) = l;
+                split2(b0[c], b1[c], h, l);
+                *reinterpret_cast<uint32_t*>(&Bh[(col + c) * WF_PITCH + 2 * kp]) = h;
+                *reinterpret_cast<uint32_t*>(&Bl[(col + c) * WF_PITCH + 2 * kp]) = l;
+            }
+        }
+        __syncthreads();
+        if (n0 + 16 < n_end) fetch(n0 + 16);
+        bf16x8 bh[4], bl[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            bh[t] = *reinterpret_cast<const bf16x8*>(&Bh[(128 * wn + 32 * t + li) * WF_PITCH + 8 * half]);
+            bl[t] = *reinterpret_cast<const bf16x8*>(&Bl[(128 * wn + 32 * t + li) * WF_PITCH + 8 * half]);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (m_on[u]) {  // wave-uniform
+                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&Ah[(64 * wm + 32 * u + li) * WF_PITCH + 8 * half]);
+                const bf16x8 al = *reinterpret_cast<const bf16x8*>(&Al[(64 * wm + 32 * u + li) * WF_PITCH + 8 * half]);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    if (128 * wn + 32 * t < I) {  // wave-uniform
+                        acc[u][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[t], acc[u][t], 0, 0, 0);
+                        acc[u][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[t], acc[u][t], 0, 0, 0);
+                        acc[u][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[t], acc[u][t], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    float* __restrict__ Pw = P + (size_t)blockIdx.x * O * I;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int i = 128 * wn + 32 * t + li;
+            if (i < I) {
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int o = 64 * wm + 32 * u + (reg & 3) + 8 * (reg >> 2) + 4 * half;
+                    if (o < O) Pw[(size_t)o * I + i] = acc[u][t][reg];
+                }
+            }
+        }
+}
+
+// dW[e] += sum over the chunks [c0, c1) of this block's slice of P[chunk][e]  (blockIdx.y splits the chunks 4 ways)
+__global__ __launch_bounds__(256) void k_wgrad_full_reduce(const float* __restrict__ P, int chunks, int OI,
+                                                           float* __restrict__ dW) {
+    const int e = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (e >= OI) return;
+    const int c0 = (int)((long long)chunks * blockIdx.y / gridDim.y), c1 = (int)((long long)chunks * (blockIdx.y + 1) / gridDim.y);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+    for (int c = c0; c < c1; ++c) {
+        const float4 v = *reinterpret_cast<const float4*>(P + (size_t)c * OI + e);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    unsafeAtomicAdd(&dW[e], s.x);
+    unsafeAtomicAdd(&dW[e + 1], s.y);
+    unsafeAtomicAdd(&dW[e + 2], s.z);
+    unsafeAtomicAdd(&dW[e + 3], s.w);
+}
+
+static int wf_rows_per_wg(int N) {
+    int rows = ceil_div(N, 256);          // one workgroup per CU
+    rows = ((rows + 15) / 16) * 16;
+    if (rows < 64) rows = 64;
+    return rows;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // Weight-stationary variant for the feature-head shapes (K <= 256, tens of thousands of rows): C[M,Nc] = op(A)[M,K] * B.
 // A head layer is 3x-5x above its HBM floor in the tiled kernel above: every 128-row tile re-stages and re-splits the
 // weights, pays two workgroup barriers per 32 k, and every A element is split once per column tile.  Here a workgroup
@@ -712,6 +836,29 @@ int snf::b3_try_bwd_data(const float* dY, const float* Y, const float* W, int N,
     else if (bn == 192) B3_LAUNCH(false, true, 192, grid, stream, dY, Y, W, none, N, O, I, lddy, ldy, I, lddx, act, SNF_ACT_NONE, dX);
     else if (bn == 128) B3_LAUNCH(false, true, 128, grid, stream, dY, Y, W, none, N, O, I, lddy, ldy, I, lddx, act, SNF_ACT_NONE, dX);
     else B3_LAUNCH(false, true, 64, grid, stream, dY, Y, W, none, N, O, I, lddy, ldy, I, lddx, act, SNF_ACT_NONE, dX);
+    return 1;
+}
+
+// full-width variant with a caller-provided partial buffer; returns 1 if it took the launch
+long long snf::b3_wgrad_full_workspace_bytes(int N, int I, int O) {
+    if (!b3_enabled() || O < 64 || O > 256 || I < 64 || I > 256 || (I % 4) || (O % 4) || N < 8192) return 0;
+    return (long long)ceil_div(N, wf_rows_per_wg(N)) * O * I * (long long)sizeof(float);
+}
+
+int snf::b3_try_bwd_weight_full(const float* dY, const float* Y, const float* X, int N, int I, int O, int lddy, int ldy, int ldx,
+                                int act, float* dW, float* dbias, void* workspace, long long workspace_bytes,
+                                snf_stream_t stream) {
+    static const int on = getenv("SNF_WGRAD_FULL") ? atoi(getenv("SNF_WGRAD_FULL")) : 1;
+    const long long need = b3_wgrad_full_workspace_bytes(N, I, O);
+    if (!on || need == 0 || dbias != nullptr || workspace == nullptr || workspace_bytes < need || (lddy % 4) ||
+        (ldx < 0 ? (ldx != -8 || (I % 8)) : (ldx < I || (ldx % 4))) || (((uintptr_t)dY | (uintptr_t)X | (uintptr_t)workspace) & 15) ||
+        (act != SNF_ACT_NONE && ((ldy % 4) || ((uintptr_t)Y & 15))))
+        return 0;
+    const int rows = wf_rows_per_wg(N), chunks = ceil_div(N, rows);
+    float* P = (float*)workspace;
+    hipLaunchKernelGGL(k_wgrad_full_b3, dim3(chunks), dim3(WF_T), 0, (hipStream_t)stream, dY, Y, X, N, I, O, lddy, ldy, ldx, act,
+                       rows, P);
+    hipLaunchKernelGGL(k_wgrad_full_reduce, dim3(ceil_div(O * I, 1024), 4), dim3(256), 0, (hipStream_t)stream, P, chunks, O * I, dW);
     return 1;
 }
 

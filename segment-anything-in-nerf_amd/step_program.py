@@ -512,6 +512,8 @@ class StepProgram:
             dfm = dpred
         gy = b(f"{hname}_dfeat", (NK, Cf))
         self._k(st, "snf_feature_mean_bwd", dfm, wk, R, K, Cf, gy)
+        wgrad_bytes = max(int(self.lib.snf_linear_bwd_weight_workspace_bytes(NK, w.shape[1], w.shape[0])) for w in ws_)
+        wgrad_ws = b(f"{hname}_wgrad_ws", (max(wgrad_bytes, 16) // 4,))
         for i in range(len(ws_) - 1, -1, -1):
             w = ws_[i]
             O, I = w.shape
@@ -520,7 +522,12 @@ class StepProgram:
             ldx = ld_enc if i == 0 else I
             gx = b(f"{hname}_dx{i}", (NK * I,) if (i == 0 and planar) else (NK, I))
             self._k(st, "snf_linear_bwd_data", gy, yout, w, NK, I, O, O, O, ldx, act, gx, tag=f"{I}x{O}")
-            self._k(st, "snf_linear_bwd_weight", gy, yout, xin, NK, I, O, O, O, ldx, act, w.main_grad, None, tag=f"{I}x{O}")
+            nb = int(self.lib.snf_linear_bwd_weight_workspace_bytes(NK, I, O))
+            if nb > 0:  # full-width weight gradient: operands read once, partial sums in a scratch buffer
+                self._k(st, "snf_linear_bwd_weight_ws", gy, yout, xin, NK, I, O, O, O, ldx, act, w.main_grad, None, wgrad_ws, nb,
+                        tag=f"{I}x{O}")
+            else:
+                self._k(st, "snf_linear_bwd_weight", gy, yout, xin, NK, I, O, O, O, ldx, act, w.main_grad, None, tag=f"{I}x{O}")
             gy = gx
         done: list = []
         col = 0

@@ -632,19 +632,22 @@ def test_level_major_operands_of_the_head_layers(N, I, O):
     y_pl = torch.empty((N, O), device=DEV)
     m._launch("snf_linear_fwd", m._p(x), m._p(w), None, N, I, O, I, O, m.ACT_RELU, m._p(y_ref), st)
     m._launch("snf_linear_fwd", m._p(xp), m._p(w), None, N, I, O, -8, O, m.ACT_RELU, m._p(y_pl), st)
-    assert torch.equal(y_pl, y_ref)
+    if I >= 128:  # the row-major call runs the same bf16x3 kernel: bit for bit
+        assert torch.equal(y_pl, y_ref)
+    else:         # narrow layers run exact fp32 when row-major: equal to the split's round-off
+        assert maxdiff(y_pl, y_ref) <= 1e-5 * float(y_ref.abs().max())
     # data gradient (ReLU derivative from y)
     dx_ref = torch.empty((N, I), device=DEV)
     dx_pl = torch.full((N * I,), float("nan"), device=DEV)
     m._launch("snf_linear_bwd_data", m._p(gy), m._p(y_ref), m._p(w), N, I, O, O, O, I, m.ACT_RELU, m._p(dx_ref), st)
     m._launch("snf_linear_bwd_data", m._p(gy), m._p(y_ref), m._p(w), N, I, O, O, O, -8, m.ACT_RELU, m._p(dx_pl), st)
-    assert maxdiff(dx_pl, _planar8(dx_ref)) <= 2e-6 * float(dx_ref.abs().max())
+    assert maxdiff(dx_pl, _planar8(dx_ref)) <= (2e-6 if O >= 128 else 1e-5) * float(dx_ref.abs().max())
     # weight gradient
     dw_ref = torch.zeros((O, I), device=DEV)
     dw_pl = torch.zeros((O, I), device=DEV)
     m._launch("snf_linear_bwd_weight", m._p(gy), m._p(y_ref), m._p(x), N, I, O, O, O, I, m.ACT_RELU, m._p(dw_ref), None, st)
     m._launch("snf_linear_bwd_weight", m._p(gy), m._p(y_ref), m._p(xp), N, I, O, O, O, -8, m.ACT_RELU, m._p(dw_pl), None, st)
-    assert maxdiff(dw_pl, dw_ref) <= 2e-6 * float(dw_ref.abs().max())
+    assert maxdiff(dw_pl, dw_ref) <= 2e-6 * float(dw_ref.abs().max())  # (both on the bf16x3 weight-gradient kernel)
     # against fp64 at the bf16x3 round-off
     ref = torch.relu(x.double() @ w.double().T)
     assert maxdiff(y_pl, ref.float()) <= 2e-5 * max(1.0, float(ref.abs().max()))
@@ -677,3 +680,37 @@ def test_level_major_feature_grids_feed_the_table_backward():
         m._launch("snf_hashgrid_bwd_presorted", m._p(grad), N, L, F, T, 2 * L * F, gi * L * F, 0, m._p(a), m._p(ws), m._p(stage), st)
         m._launch("snf_hashgrid_bwd_presorted", gpl.data_ptr() + gi * L * N * F * 4, N, L, F, T, 0, 0, 0, m._p(bq), m._p(ws), None, st)
         assert torch.equal(a, bq)
+
+
+@pytest.mark.parametrize("N,I,O,planar", [(65536, 192, 256, True), (65536, 256, 256, False), (65536, 256, 192, False),
+                                          (9000, 64, 72, False), (16411, 200, 128, False)])
+def test_full_width_weight_gradient(N, I, O, planar):
+    """snf_linear_bwd_weight_ws: a workgroup owns a chunk of rows and the whole O x I output (operands read once, partial
+    sums in the scratch buffer).  Same bf16x3 products as the tiled kernel, different summation tree: equal to 2e-6 of the
+    largest entry; against fp64 at the split's round-off."""
+    m = ops()
+    m.set_gemm_mode("bf16x3")
+    g = torch.Generator(device=DEV).manual_seed(N + I + O)
+    x = torch.randn((N, I), device=DEV, generator=g) * 0.3
+    y = torch.randn((N, O), device=DEV, generator=g)  # layer output (ReLU derivative mask)
+    gy = torch.randn((N, O), device=DEV, generator=g)
+    xin, ldx = (_planar8(x), -8) if planar else (x, I)
+    st = m._stream()
+    nb = int(m._L().snf_linear_bwd_weight_workspace_bytes(N, I, O))
+    assert nb > 0
+    ws = torch.empty((nb // 4,), device=DEV)
+    dw_full = torch.zeros((O, I), device=DEV)
+    dw_full += 1.0  # accumulates into a running buffer
+    dw_tile = torch.ones((O, I), device=DEV)
+    m._launch("snf_linear_bwd_weight_ws", m._p(gy), m._p(y), m._p(xin), N, I, O, O, O, ldx, m.ACT_RELU, m._p(dw_full), None,
+              m._p(ws), nb, st)
+    m._launch("snf_linear_bwd_weight", m._p(gy), m._p(y), m._p(xin), N, I, O, O, O, ldx, m.ACT_RELU, m._p(dw_tile), None, st)
+    ref = ((gy.double() * (y > 0)).T @ x.double()) + 1.0
+    scale = float(ref.abs().max())
+    assert maxdiff(dw_full, dw_tile) <= 2e-6 * scale
+    assert maxdiff(dw_full, ref.float()) <= 2e-5 * scale
+    # a short workspace falls back to the tiled kernel
+    dw_fb = torch.ones((O, I), device=DEV)
+    m._launch("snf_linear_bwd_weight_ws", m._p(gy), m._p(y), m._p(xin), N, I, O, O, O, ldx, m.ACT_RELU, m._p(dw_fb), None,
+              m._p(ws), 16, st)
+    assert maxdiff(dw_fb, dw_tile) <= 2e-6 * scale
