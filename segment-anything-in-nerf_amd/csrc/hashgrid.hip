@@ -726,6 +726,225 @@ __global__ __launch_bounds__(HG_RT) void k_hg_reduce(const float* __restrict__ g
     }
 }
 
+
+// ==========================================================================================
+// Fixed-point reduce pass (F = 2 grids): per-row sums as 64-bit INTEGER LDS atomics, no sort inside the bucket.
+//
+// The reduce pass above spends its time ranking records inside LDS, not moving bytes (rocprofv3, field grid: 66 % of
+// the wave cycles parked at barriers / waitcnt, ~90 VALU instructions per record, 1.85 TB/s of algorithmic traffic), all to
+// avoid float atomics: ds_add_f32 retires 0.37 lane-ops/clk/CU.  ds_add_u64 retires 6.3 (tools/ubench/lds_atomic_rate2.hip),
+// so a contribution w*g is added as a 64-bit fixed-point integer instead:
+//     q = rint(w*g * 2^s),  2^s = 2^38 / 2^e,  2^e > max |g| over the level (k_hg_level_absmax)
+// |q| < 2^38 leaves 24 bits of headroom for the 2^24 contributions a row can receive at most (2^21 samples x 8 corners), and
+// resolves every contribution to 2^-38 of the level's largest gradient -- finer than the fp32 round-off of the products
+// themselves for anything above 2^-14 of it, and EXACT in the sum: the result does not depend on the order of the
+// records, so the table gradient is bit-reproducible (the float reduce differed from run to run only through its chunking).
+// Non-finite contributions cannot be represented: they set a per-row flag and the row's gradient becomes NaN, which is
+// what a float sum (autograd's) gives.  A workgroup streams its bucket's records once (record + staged-gradient gather,
+// four in flight per thread), one barrier, then converts its rows and applies the Adam step / gradient read-modify-write.
+// ==========================================================================================
+constexpr int HG_FX_T = 256;
+constexpr int HG_FX_BITS = 38;
+
+template <int F>
+__global__ __launch_bounds__(256) void k_hg_level_absmax(const float* __restrict__ gT, int N, uint32_t* __restrict__ out_bits) {
+    const int l = blockIdx.y;
+    const float4* __restrict__ p = reinterpret_cast<const float4*>(gT + (size_t)l * N * F);
+    const long long n4 = (long long)N * F / 4;  // N * F is a multiple of 4 (F in {2, 8}; N even checked by the caller for F = 2)
+    float m = 0.f;
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long i0 = (long long)blockIdx.x * 256 + threadIdx.x; i0 < n4; i0 += 4 * stride) {
+        float4 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {  // four independent loads in flight
+            const long long i = i0 + j * stride;
+            v[j] = i < n4 ? p[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float a = fabsf(v[j].x), b = fabsf(v[j].y), c = fabsf(v[j].z), d = fabsf(v[j].w);
+            // finite values only (NaN fails the comparison, +inf is excluded explicitly): non-finite contributions are flagged per row
+            if (a < INFINITY && a > m) m = a;
+            if (b < INFINITY && b > m) m = b;
+            if (c < INFINITY && c > m) m = c;
+            if (d < INFINITY && d > m) m = d;
+        }
+    }
+#pragma unroll
+    for (int dlt = 32; dlt > 0; dlt >>= 1) m = fmaxf(m, __shfl_xor(m, dlt, 64));
+    __shared__ float wm[4];
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    // one atomic per workgroup (same-address device atomics serialise at the memory side: one per WAVE cost 100 us here)
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+        if (m > 0.f) atomicMax(&out_bits[l], __float_as_uint(m));  // non-negative floats order as uints
+    }
+}
+
+template <int F, bool ADAM>
+__global__ __launch_bounds__(HG_FX_T) void k_hg_reduce_fx(const float* __restrict__ gT, int N, int log2_T, int log2B,
+                                                          const uint32_t* __restrict__ bucket_start,
+                                                          const uint2* __restrict__ records, float* __restrict__ grad_table,
+                                                          int n_run_levels, const uint32_t* __restrict__ lvl_absmax_bits,
+                                                          HgAdam adam) {
+    __shared__ unsigned long long acc[HG_MAX_RPB * F];
+    __shared__ uint32_t bad[HG_MAX_RPB / 32];
+    const int B = 1 << log2B, log2rpb = log2_T - log2B;
+    const int rpb = 1 << log2rpb;
+    const int tid = threadIdx.x, b = blockIdx.x, l = blockIdx.y, lane = tid & 63;
+    const uint32_t start = bucket_start[l * (B + 1) + b], end = bucket_start[l * (B + 1) + b + 1];
+    const bool fuse = ADAM && l >= adam.from_level;
+    if (start == end && !fuse) return;
+    for (int i = tid; i < rpb * F; i += HG_FX_T) acc[i] = 0ull;
+    if (tid < HG_MAX_RPB / 32) bad[tid] = 0u;
+    // 2^e > M >= every finite |g| of the level; q = rint(c * 2^(BITS - e)).  (M = 0: nothing finite and non-zero lands here)
+    int e = 0;
+    frexpf(__uint_as_float(lvl_absmax_bits[l]), &e);
+    int sh = HG_FX_BITS - e;
+    sh = sh > 120 ? 120 : sh;  // keeps 2^sh and 2^-sh normal floats; levels whose largest gradient is below 2^-82 lose nothing that matters
+    const float scale = ldexpf(1.f, sh), inv = ldexpf(1.f, -sh);
+    const float* __restrict__ gl = gT + (size_t)l * N * F;
+    const bool coarse = l < n_run_levels;
+    __syncthreads();
+    // three-stage software pipeline over trips of U records per thread: the records of trip t+2 and the staged gradients of
+    // trip t+1 are in flight while trip t is accumulated, so neither global latency sits on the loop's critical path
+    constexpr int U = 4;
+    const uint32_t mask_s = (1u << HG_SAMPLE_BITS) - 1u;
+    uint2 rec0[U], rec1[U];      // records of trip t (being processed), t+1 (gathers in flight)
+    float g0[U][F], g1[U][F];
+    auto load_recs = [&](uint32_t c0, uint2 (&r)[U]) {
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const uint32_t i = c0 + tid + (uint32_t)HG_FX_T * j;
+            r[j] = records[i < end ? i : start];
+        }
+    };
+    auto gather = [&](const uint2 (&r)[U], float (&g)[U][F]) {
+#pragma unroll
+        for (int j = 0; j < U; ++j) load_row<F>(gl + (size_t)(r[j].x & mask_s) * F, g[j]);
+    };
+    constexpr uint32_t TRIP = HG_FX_T * U;
+    load_recs(start, rec0);
+    gather(rec0, g0);
+    if (start + TRIP < end) load_recs(start + TRIP, rec1);
+    for (uint32_t c0 = start; c0 < end; c0 += TRIP) {
+        uint2 rec2[U];
+        const bool has1 = c0 + TRIP < end, has2 = c0 + 2 * TRIP < end;
+        if (has1) gather(rec1, g1);
+        if (has2) load_recs(c0 + 2 * TRIP, rec2);
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            bool live = c0 + tid + (uint32_t)HG_FX_T * j < end;
+            const uint32_t row = rec0[j].x >> HG_SAMPLE_BITS;
+            const float w = __uint_as_float(rec0[j].y);
+            float v[F];
+#pragma unroll
+            for (int f = 0; f < F; ++f) v[f] = w * g0[j][f];
+            if (coarse) {
+                // runs of equal rows across adjacent lanes (consecutive samples of a ray inside one coarse cell) are summed with
+                // a segmented shuffle scan; only the run tail touches LDS -- same-address atomics serialise per lane
+                const uint32_t key = live ? row : (0xFFFFFF00u + (uint32_t)lane);
+                const uint32_t prev = __shfl_up(key, 1, 64);
+                const unsigned long long heads = __ballot((lane == 0) || (prev != key));
+                const int h = 63 - __builtin_clzll(heads & ((2ull << lane) - 1ull));
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const bool take = (lane - d) >= h;
+#pragma unroll
+                    for (int f = 0; f < F; ++f) {
+                        const float t = __shfl_up(v[f], d, 64);
+                        if (take) v[f] += t;
+                    }
+                }
+                const uint32_t next = __shfl_down(key, 1, 64);
+                live = live && ((lane == 63) || (next != key));
+            }
+            if (live) {
+                bool finite = true;
+#pragma unroll
+                for (int f = 0; f < F; ++f) finite = finite && (fabsf(v[f]) < INFINITY);
+                if (finite) {
+#pragma unroll
+                    for (int f = 0; f < F; ++f) {
+                        const long long q = __float2ll_rn(v[f] * scale);
+                        if (q != 0) atomicAdd(&acc[row * F + f], (unsigned long long)q);
+                    }
+                } else {
+                    atomicOr(&bad[row >> 5], 1u << (row & 31));
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            rec0[j] = rec1[j];
+            rec1[j] = rec2[j];
+#pragma unroll
+            for (int f = 0; f < F; ++f) g0[j][f] = g1[j][f];
+        }
+    }
+    __syncthreads();
+    // ---- epilogue: each thread converts its rows (tid, tid + T, ...), four row sets in flight
+    const size_t base = (((size_t)l << log2_T) + ((size_t)b << log2rpb)) * F;
+    float* __restrict__ slab = grad_table + base;
+    constexpr int RU = 4;
+    for (int r0 = tid; r0 < rpb; r0 += HG_FX_T * RU) {
+        float gg[RU][F], pp[RU][F], mm[RU][F], vv[RU][F];
+        bool on[RU], nz[RU];
+#pragma unroll
+        for (int j = 0; j < RU; ++j) {
+            const int r = r0 + HG_FX_T * j;
+            on[j] = r < rpb;
+            nz[j] = false;
+            if (on[j]) {
+                const bool isbad = (bad[r >> 5] >> (r & 31)) & 1u;
+#pragma unroll
+                for (int f = 0; f < F; ++f) {
+                    const long long q = (long long)acc[r * F + f];
+                    gg[j][f] = isbad ? __uint_as_float(0x7FC00000u) : __ll2float_rn(q) * inv;
+                    nz[j] = nz[j] || (q != 0) || isbad;
+                }
+                if (fuse) {
+                    load_row<F>(adam.p + base + (size_t)r * F, pp[j]);
+                    load_row<F>(adam.m + base + (size_t)r * F, mm[j]);
+                    load_row<F>(adam.v + base + (size_t)r * F, vv[j]);
+                } else if (nz[j]) {
+                    load_row<F>(slab + (size_t)r * F, pp[j]);  // the running gradient of a level left to the caller's optimizer
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < RU; ++j) {
+            if (!on[j]) continue;
+            const size_t o = base + (size_t)(r0 + HG_FX_T * j) * F;
+            if (fuse) {
+#pragma unroll
+                for (int f = 0; f < F; ++f) hg_adam1(pp[j][f], gg[j][f], mm[j][f], vv[j][f], adam);
+                if constexpr (F == 2) {
+                    *reinterpret_cast<float2*>(adam.p + o) = make_float2(pp[j][0], pp[j][1]);
+                    *reinterpret_cast<float2*>(adam.m + o) = make_float2(mm[j][0], mm[j][1]);
+                    *reinterpret_cast<float2*>(adam.v + o) = make_float2(vv[j][0], vv[j][1]);
+                } else {
+                    reinterpret_cast<float4*>(adam.p + o)[0] = make_float4(pp[j][0], pp[j][1], pp[j][2], pp[j][3]);
+                    reinterpret_cast<float4*>(adam.p + o)[1] = make_float4(pp[j][4], pp[j][5], pp[j][6], pp[j][7]);
+                    reinterpret_cast<float4*>(adam.m + o)[0] = make_float4(mm[j][0], mm[j][1], mm[j][2], mm[j][3]);
+                    reinterpret_cast<float4*>(adam.m + o)[1] = make_float4(mm[j][4], mm[j][5], mm[j][6], mm[j][7]);
+                    reinterpret_cast<float4*>(adam.v + o)[0] = make_float4(vv[j][0], vv[j][1], vv[j][2], vv[j][3]);
+                    reinterpret_cast<float4*>(adam.v + o)[1] = make_float4(vv[j][4], vv[j][5], vv[j][6], vv[j][7]);
+                }
+            } else if (nz[j]) {
+                float* dst = grad_table + o;
+                if constexpr (F == 2) {
+                    *reinterpret_cast<float2*>(dst) = make_float2(pp[j][0] + gg[j][0], pp[j][1] + gg[j][1]);
+                } else {
+                    reinterpret_cast<float4*>(dst)[0] = make_float4(pp[j][0] + gg[j][0], pp[j][1] + gg[j][1], pp[j][2] + gg[j][2], pp[j][3] + gg[j][3]);
+                    reinterpret_cast<float4*>(dst)[1] = make_float4(pp[j][4] + gg[j][4], pp[j][5] + gg[j][5], pp[j][6] + gg[j][6], pp[j][7] + gg[j][7]);
+                }
+            }
+        }
+    }
+}
+
 }  // namespace snf
 
 using namespace snf;
@@ -777,12 +996,21 @@ extern "C" int snf_hashgrid_bwd(const float* u, const float* grad_out, const flo
 }
 
 // ---- bucketed (atomic-free) backward ---------------------------------------------------------------------
+constexpr size_t HG_FX_SCRATCH = 64;  // words (L <= 64 for the fixed-point reduce)
+
+// fixed-point reduce for the F = 2 grids (SNF_HG_FX=0: the float reduce everywhere)
+static bool hg_fx_on(int F, int L, int N) {
+    static const int on = getenv("SNF_HG_FX") ? atoi(getenv("SNF_HG_FX")) : 1;
+    return on && F == 2 && L <= (int)HG_FX_SCRATCH && (N % 2) == 0;
+}
+
 static size_t hg_ws_words(int N, int L, int log2_T) {
     const HgGeom g = hg_geometry(N, log2_T);
     const size_t B = (size_t)1 << g.log2B;
-    // records (8 B each) | tile histograms | tile offsets | bucket starts (padded to 4 words) | staged gradients
+    // records (8 B each) | tile histograms | tile offsets | bucket starts (padded to 4 words) | per-level scratch of the
+    // fixed-point reduce (HG_FX_SCRATCH words, the only part a BACKWARD writes) | staged gradients
     return (size_t)L * 8 * (size_t)N * 2 + 2 * (size_t)L * g.nblk * B + (((size_t)L * (B + 1) + 3) & ~(size_t)3) +
-           (size_t)L * (size_t)N * 8;
+           HG_FX_SCRATCH + (size_t)L * (size_t)N * 8;
 }
 
 extern "C" int64_t snf_hashgrid_bwd_workspace_bytes(int N, int L, int log2_T) {
@@ -810,8 +1038,13 @@ static int hg_sort_checks(const char* who, int N, int L, int log2_T, const void*
     return SNF_OK;
 }
 
+static int hg_absmax_blocks(int N, int F) {
+    long long n = ((long long)N * F / 4 + 255) / 256 / 16;  // ~16 float4 per thread
+    return (int)(n < 1 ? 1 : (n > 64 ? 64 : n));
+}
+
 struct HgWs {
-    uint32_t *records, *hist, *offs, *bstart;
+    uint32_t *records, *hist, *offs, *bstart, *fx;
     float* gT;
 };
 
@@ -822,7 +1055,8 @@ static HgWs hg_ws_layout(void* workspace, int N, int L, const HgGeom& g) {
     w.hist = w.records + (size_t)L * 8 * (size_t)N * 2;
     w.offs = w.hist + (size_t)L * g.nblk * B;
     w.bstart = w.offs + (size_t)L * g.nblk * B;
-    w.gT = (float*)(w.bstart + (((size_t)L * (B + 1) + 3) & ~(size_t)3));
+    w.fx = w.bstart + (((size_t)L * (B + 1) + 3) & ~(size_t)3);
+    w.gT = (float*)(w.fx + HG_FX_SCRATCH);
     return w;
 }
 
@@ -837,9 +1071,11 @@ extern "C" int snf_hashgrid_sort(const float* u, const float* scalings, int N, i
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_hg_count, dim3(g.nblk, L), dim3(256), 0, st, u, scalings, N, log2_T, g.log2B, g.spt, w.hist);
     hipLaunchKernelGGL(k_hg_scan, dim3(L), dim3(1024), 0, st, N, g.log2B, g.nblk, w.hist, w.offs, w.bstart);
-    if (hg_scatter_lds_bytes(g.log2B) > 48 * 1024)
-        hipFuncSetAttribute((const void*)k_hg_scatter, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)hg_scatter_lds_bytes(g.log2B));
+    static int lds_attr = 0;  // largest dynamic-LDS size the scatter kernel has been opened for (one runtime call per growth)
+    if (hg_scatter_lds_bytes(g.log2B) > 48 * 1024 && (int)hg_scatter_lds_bytes(g.log2B) > lds_attr) {
+        lds_attr = (int)hg_scatter_lds_bytes(g.log2B);
+        hipFuncSetAttribute((const void*)k_hg_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, lds_attr);
+    }
     hipLaunchKernelGGL(k_hg_scatter, dim3(g.nblk, L), dim3(256), hg_scatter_lds_bytes(g.log2B), st, u, scalings, N, log2_T,
                        g.log2B, g.spt, w.offs, (uint2*)w.records);
     SNF_LAUNCH_CHECK("snf_hashgrid_sort");
@@ -862,11 +1098,16 @@ extern "C" int snf_hashgrid_bwd_presorted(const float* grad_out, int N, int L, i
     const HgWs w = hg_ws_layout(const_cast<void*>(sorted_workspace), N, L, g);
     const int B = 1 << g.log2B;
     hipStream_t st = (hipStream_t)stream;
-    const char* e_long = getenv("SNF_HG_LONG");
-    const uint32_t hg_long = e_long ? (uint32_t)atoi(e_long) : (uint32_t)HG_LONG;
+    static const uint32_t hg_long = getenv("SNF_HG_LONG") ? (uint32_t)atoi(getenv("SNF_HG_LONG")) : (uint32_t)HG_LONG;
     const int tblocks = ceil_div((long long)N * L, 256);
     if (F == 2) {
         if (!planar) hipLaunchKernelGGL(k_hg_stage_grad<2>, dim3(tblocks), dim3(256), 0, st, grad_out, N, L, ld_out, col_off, stage);
+        if (hg_fx_on(F, L, N)) {
+            hipMemsetAsync(w.fx, 0, L * sizeof(uint32_t), st);
+            hipLaunchKernelGGL(k_hg_level_absmax<2>, dim3(hg_absmax_blocks(N, F), L), dim3(256), 0, st, stage, N, w.fx);
+            hipLaunchKernelGGL((k_hg_reduce_fx<2, false>), dim3(B, L), dim3(HG_FX_T), 0, st, stage, N, log2_T, g.log2B, w.bstart,
+                               (const uint2*)w.records, grad_table, n_run_levels, w.fx, HgAdam{});
+        } else
         hipLaunchKernelGGL((k_hg_reduce<2, false>), dim3(B, L), dim3(HG_RT), 0, st, stage, N, log2_T, g.log2B, w.bstart,
                            (const uint2*)w.records, grad_table, hg_long, n_run_levels, HgAdam{});
     } else {
@@ -899,8 +1140,7 @@ extern "C" int snf_hashgrid_bwd_presorted_adam(const float* grad_out, int N, int
     const HgWs w = hg_ws_layout(const_cast<void*>(sorted_workspace), N, L, g);
     const int B = 1 << g.log2B;
     hipStream_t st = (hipStream_t)stream;
-    const char* e_long = getenv("SNF_HG_LONG");
-    const uint32_t hg_long = e_long ? (uint32_t)atoi(e_long) : (uint32_t)HG_LONG;
+    static const uint32_t hg_long = getenv("SNF_HG_LONG") ? (uint32_t)atoi(getenv("SNF_HG_LONG")) : (uint32_t)HG_LONG;
     const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
     HgAdam a;
     a.p = param; a.m = exp_avg; a.v = exp_avg_sq;
@@ -909,6 +1149,12 @@ extern "C" int snf_hashgrid_bwd_presorted_adam(const float* grad_out, int N, int
     const int tblocks = ceil_div((long long)N * L, 256);
     if (F == 2) {
         if (!planar) hipLaunchKernelGGL(k_hg_stage_grad<2>, dim3(tblocks), dim3(256), 0, st, grad_out, N, L, ld_out, col_off, stage);
+        if (hg_fx_on(F, L, N)) {
+            hipMemsetAsync(w.fx, 0, L * sizeof(uint32_t), st);
+            hipLaunchKernelGGL(k_hg_level_absmax<2>, dim3(hg_absmax_blocks(N, F), L), dim3(256), 0, st, stage, N, w.fx);
+            hipLaunchKernelGGL((k_hg_reduce_fx<2, true>), dim3(B, L), dim3(HG_FX_T), 0, st, stage, N, log2_T, g.log2B, w.bstart,
+                               (const uint2*)w.records, grad_table, n_run_levels, w.fx, a);
+        } else
         hipLaunchKernelGGL((k_hg_reduce<2, true>), dim3(B, L), dim3(HG_RT), 0, st, stage, N, log2_T, g.log2B, w.bstart,
                            (const uint2*)w.records, grad_table, hg_long, n_run_levels, a);
     } else {

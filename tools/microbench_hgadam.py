@@ -1,0 +1,72 @@
+"""Microbenchmark of the fused hash-grid backward + Adam (snf_hashgrid_bwd_presorted_adam) alone on the GPU, bench-shaped:
+  f8b  one F=8 feature grid 128->512 (12 dense levels), N = 65536 top-K samples
+  f8a  one F=8 feature grid 16->128 (8 reachable-row levels + 4 dense)
+  f2   the F=2 field grid 16->2048 (16 levels), N = 524288, level-major gradient
+  f2p  the F=2 proposal grid 16->128 (5 levels, T = 17), N = 262144
+usage: CASES=f8b,f2 REPS=20 python tools/microbench_hgadam.py"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import samnerf_amd  # noqa: F401
+from samnerf_amd import ops, tcnn_compat
+
+CASES = {  # N, L, F, T, base, max, planar gradient, clustered positions
+    "f8b": (65536, 12, 8, 19, 128, 512, True, False),
+    "f8a": (65536, 12, 8, 19, 16, 128, True, False),
+    "f2": (524288, 16, 2, 19, 16, 2048, True, True),
+    "f2p": (262144, 5, 2, 17, 16, 128, False, True),
+}
+REPS = int(os.environ.get("REPS", "20"))
+lib = ops._L()
+for name in os.environ.get("CASES", "f8b,f8a,f2,f2p").split(","):
+    N, L, F, T, mn, mx, planar, clustered = CASES[name]
+    growth = float(np.exp((np.log(mx) - np.log(mn)) / (L - 1)))
+    enc = tcnn_compat.Encoding(3, {"otype": "HashGrid", "n_levels": L, "n_features_per_level": F, "log2_hashmap_size": T,
+                                   "base_resolution": mn, "per_level_scale": growth}, device="cuda")
+    n_sparse, _ = enc.active_rows()
+    gen = torch.Generator(device="cuda").manual_seed(0)
+    if clustered:  # samples along rays: consecutive samples are neighbours
+        R = N // 128
+        o = torch.rand((R, 1, 3), device="cuda", generator=gen) * 0.2 + 0.4
+        d = torch.randn((R, 1, 3), device="cuda", generator=gen)
+        d = d / d.norm(dim=-1, keepdim=True)
+        t = torch.linspace(0, 0.4, 128, device="cuda").view(1, 128, 1)
+        u = (o + d * t).clamp(0.001, 0.999).reshape(N, 3).contiguous()
+    else:
+        u = torch.rand((N, 3), device="cuda", generator=gen)
+    sc = enc.scalings
+    n = enc.params.numel()
+    p, g = enc.params.data, torch.zeros(n, device="cuda")
+    m, v = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    ld = 0 if planar else L * F
+    gy = torch.randn((L * N * F,), device="cuda", generator=gen) * 1e-3
+    nbytes = int(lib.snf_hashgrid_bwd_workspace_bytes(N, L, T))
+    ws = torch.empty(((nbytes + 3) // 4,), device="cuda", dtype=torch.int32)
+    stage = torch.empty((L * N * F,), device="cuda")
+    st = ops._stream()
+    nrun = ops.hashgrid_run_levels(sc) if F == 2 else 0
+    ops._launch("snf_hashgrid_sort", ops._p(u), ops._p(sc), N, L, T, ops._p(ws), nbytes, st)
+
+    def launch(step):
+        ops._launch("snf_hashgrid_bwd_presorted_adam", ops._p(gy), N, L, F, T, ld, 0, nrun, ops._p(g), ops._p(ws),
+                    None if planar else ops._p(stage), n_sparse, ops._p(p), ops._p(m), ops._p(v), 5e-4, 0.9, 0.999, 1e-15, step,
+                    1.0, st)
+
+    for i in range(3):
+        launch(i + 1)
+    torch.cuda.synchronize()
+    evs = []
+    for i in range(REPS):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        launch(4 + i)
+        b.record()
+        evs.append((a, b))
+    torch.cuda.synchronize()
+    ts = sorted(a.elapsed_time(b) for a, b in evs)
+    med = ts[len(ts) // 2]
+    fused = ((L - n_sparse) << T) * F
+    units = float(N) * 8 * F * 4 * (L + n_sparse) + 24.0 * fused
+    print(f"{name}: N={N} L={L} F={F} sparse_levels={n_sparse}  median {med*1e3:.1f} us  min {ts[0]*1e3:.1f}  "
+          f"algorithmic {units/1e6:.0f} MB -> {units/med/1e6:.0f} GB/s ({units/med/1e6/8000:.3f} of 8 TB/s)", flush=True)
