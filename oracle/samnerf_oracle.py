@@ -622,6 +622,26 @@ def get_feature_size(h: int, w: int, largesize: int = 64):
     return largesize, largesize
 
 
+def feature_ray_grid(field: torch.Tensor, fh: int, fw: int, p: int) -> torch.Tensor:
+    """sam_model.py:371-380 for one RayBundle field [H,W,C]: linspace sub-sampling to [fh*p, fw*p], regroup into p x p
+    patches (reshape (fh, p, fw, p) then transpose(1, 2)), row-major flatten -> [fh*fw*p*p, C] in the order the chunk loop
+    (get_row_major_sliced_ray_bundle) walks it: patch-major, rows of a patch, columns of a patch."""
+    H, W = field.shape[:2]
+    hi = torch.linspace(0, H - 1, fh * p, dtype=torch.long)
+    wi = torch.linspace(0, W - 1, fw * p, dtype=torch.long)
+    hind, wind = torch.meshgrid(hi, wi, indexing="ij")
+    return field[hind.flatten(), wind.flatten()].reshape(fh, p, fw, p, -1).transpose(1, 2).reshape(fh * fw * p * p, -1)
+
+
+def clipseg_ray_grid(field: torch.Tensor, n: int = 32) -> torch.Tensor:
+    """sam_model.py:389-398: the n x n linspace sub-sampling of a RayBundle field [H,W,C] -> [n*n, C]."""
+    H, W = field.shape[:2]
+    hi = torch.linspace(0, H - 1, n, dtype=torch.long)
+    wi = torch.linspace(0, W - 1, n, dtype=torch.long)
+    hind, wind = torch.meshgrid(hi, wi, indexing="ij")
+    return field[hind.flatten(), wind.flatten()]
+
+
 def render_camera(params, cfg: PathConfig, origins: torch.Tensor, directions: torch.Tensor, chunk: int = 1 << 15):
     """get_outputs_for_camera_ray_bundle passes 1-3 (eval mode, no grad): origins/directions [H,W,3] ->
     rgb/depth/accumulation [H,W,*], sam [fh,fw,256], clipseg [32,32,192]."""
@@ -636,19 +656,12 @@ def render_camera(params, cfg: PathConfig, origins: torch.Tensor, directions: to
             fh, fw = get_feature_size(H, W)
             p = cfg.patch_size
             chunk = max(p * p, chunk - chunk % (p * p))  # whole patches per chunk (the reference's 1<<15 already is)
-            hi = torch.linspace(0, H - 1, fh * p, dtype=torch.long)
-            wi = torch.linspace(0, W - 1, fw * p, dtype=torch.long)
-            hind, wind = torch.meshgrid(hi, wi, indexing="ij")
-            fo = origins[hind.flatten(), wind.flatten()].reshape(fh, p, fw, p, 3).transpose(1, 2).reshape(-1, 3)
-            fd = directions[hind.flatten(), wind.flatten()].reshape(fh, p, fw, p, 3).transpose(1, 2).reshape(-1, 3)
+            fo, fd = feature_ray_grid(origins, fh, fw, p), feature_ray_grid(directions, fh, fw, p)
             parts = [forward(params, cfg, fo[i:i + chunk], fd[i:i + chunk], False, get_feature=("sam",))["sam"]
                      for i in range(0, fo.shape[0], chunk)]
             out["sam"] = torch.cat(parts).view(fh, fw, -1)
             if cfg.use_clipseg:
-                hi = torch.linspace(0, H - 1, 32, dtype=torch.long)
-                wi = torch.linspace(0, W - 1, 32, dtype=torch.long)
-                hind, wind = torch.meshgrid(hi, wi, indexing="ij")
-                co, cd = origins[hind.flatten(), wind.flatten()], directions[hind.flatten(), wind.flatten()]
+                co, cd = clipseg_ray_grid(origins), clipseg_ray_grid(directions)
                 parts = [forward(params, cfg, co[i:i + chunk], cd[i:i + chunk], False, get_feature=("clipseg",))["clipseg"]
                          for i in range(0, co.shape[0], chunk)]
                 out["clipseg"] = torch.cat(parts).view(32, 32, -1)

@@ -327,6 +327,28 @@ class NerfactoModel(Model):
         return {name: torch.cat(lst).view(image_height, image_width, -1) for name, lst in outputs_lists.items()}
 
 
+def feature_ray_bundle(camera_ray_bundle: RayBundle, feature_h: int, feature_w: int, p: int) -> RayBundle:
+    """samnerf/sam_model.py:371-380: the [H,W] camera bundle sub-sampled with linspace indices to [fh*p, fw*p] rays and
+    regrouped so that a row-major walk (get_row_major_sliced_ray_bundle) visits whole p x p patches one after another."""
+    sz = camera_ray_bundle.shape
+    dev = camera_ray_bundle.origins.device
+    h_indices = torch.linspace(0, sz[0] - 1, feature_h * p, dtype=torch.long, device=dev)
+    w_indices = torch.linspace(0, sz[1] - 1, feature_w * p, dtype=torch.long, device=dev)
+    hind, wind = torch.meshgrid(h_indices, w_indices, indexing="ij")
+    fb = camera_ray_bundle[hind.flatten(), wind.flatten()]
+    return fb.reshape((feature_h, p, feature_w, p))._apply_fn_to_fields(lambda x: x.transpose(1, 2))
+
+
+def clipseg_ray_bundle(camera_ray_bundle: RayBundle, feature_h: int = 32, feature_w: int = 32) -> RayBundle:
+    """samnerf/sam_model.py:389-398: the 32 x 32 linspace sub-sampling for the ClipSeg map."""
+    sz = camera_ray_bundle.shape
+    dev = camera_ray_bundle.origins.device
+    h_indices = torch.linspace(0, sz[0] - 1, feature_h, dtype=torch.long, device=dev)
+    w_indices = torch.linspace(0, sz[1] - 1, feature_w, dtype=torch.long, device=dev)
+    hind, wind = torch.meshgrid(h_indices, w_indices, indexing="ij")
+    return camera_ray_bundle[hind.flatten(), wind.flatten()].reshape((feature_h, feature_w))
+
+
 @dataclass
 class SAMModelConfig(NerfactoModelConfig):
     """samnerf/sam_model.py:140-162."""
@@ -533,11 +555,7 @@ class SAMModel(NerfactoModel):
             feature_h, feature_w = get_feature_size(image_height, image_width)
             p = self.config.patch_size
             dev = camera_ray_bundle.origins.device
-            h_indices = torch.linspace(0, sz[0] - 1, feature_h * p, dtype=torch.long, device=dev)
-            w_indices = torch.linspace(0, sz[1] - 1, feature_w * p, dtype=torch.long, device=dev)
-            hind, wind = torch.meshgrid(h_indices, w_indices, indexing="ij")
-            fb = camera_ray_bundle[hind.flatten(), wind.flatten()]
-            fb = fb.reshape((feature_h, p, feature_w, p))._apply_fn_to_fields(lambda x: x.transpose(1, 2))
+            fb = feature_ray_bundle(camera_ray_bundle, feature_h, feature_w, p)
             saved = {k: outputs_lists.pop(k) for k in list(outputs_lists)}
             run(fb, granule=p * p, get_feature=["sam"])
             sam_list = outputs_lists.get("sam", [])
@@ -546,10 +564,7 @@ class SAMModel(NerfactoModel):
             outputs_lists["sam"] = sam_list
             if self.config.use_clipseg_feature:
                 feature_h_clipseg, feature_w_clipseg = 32, 32
-                h_indices = torch.linspace(0, sz[0] - 1, feature_h_clipseg, dtype=torch.long, device=dev)
-                w_indices = torch.linspace(0, sz[1] - 1, feature_w_clipseg, dtype=torch.long, device=dev)
-                hind, wind = torch.meshgrid(h_indices, w_indices, indexing="ij")
-                cb = camera_ray_bundle[hind.flatten(), wind.flatten()].reshape((feature_h_clipseg, feature_w_clipseg))
+                cb = clipseg_ray_bundle(camera_ray_bundle, feature_h_clipseg, feature_w_clipseg)
                 saved = {k: outputs_lists.pop(k) for k in list(outputs_lists)}
                 run(cb, get_feature=["clipseg"])
                 clip_list = outputs_lists.get("clipseg", [])

@@ -619,10 +619,84 @@ def fx_vit():
     npz("vit_small", x=x, y=y_ref, t0=t0, t1=t1, t2=t2, **{"w:" + k: v for k, v in sd.items()})
 
 
+def _reference_function(path, cls, name):
+    """The source of one method of a reference class, compiled on its own (the module imports torchvision, which this
+    container lacks; the method itself is plain torch)."""
+    import ast
+    src = open(os.path.join(REF, path)).read()
+    tree = ast.parse(src)
+    node = next(f for c in tree.body if isinstance(c, ast.ClassDef) and c.name == cls
+                for f in c.body if isinstance(f, ast.FunctionDef) and f.name == name)
+    mod = ast.Module(body=[node], type_ignores=[])
+    ns = {"np": np, "torch": torch, "math": __import__("math")}
+    exec(compile(mod, path, "exec"), ns)
+    return ns[name]
+
+
+def fx_eval_regroup():
+    """The eval-path ray regroup of samnerf/sam_model.py:371-398 run with the reference's own RayBundle / TensorDataclass
+    (nerfstudio/utils/tensor_dataclass.py: __getitem__, reshape, _apply_fn_to_fields, get_row_major_sliced_ray_bundle) and
+    get_feature_size; SamPredictor.set_feature's zero-pad (segment_anything/predictor.py:100-127)."""
+    from types import SimpleNamespace
+    from samnerf.sam_utils import get_feature_size
+    arrays = {}
+    cases = [(37, 53), (48, 31), (40, 64)]
+    for ci, (H, W) in enumerate(cases):
+        g = torch.Generator().manual_seed(100 + ci)
+        ys, xs = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+        origins = torch.stack([ys, xs, torch.zeros_like(ys)], -1).float()  # the pixel a ray came from, readable
+        directions = torch.randn((H, W, 3), generator=g)
+        cam = RayBundle(origins=origins, directions=directions, pixel_area=torch.rand((H, W, 1), generator=g),
+                        camera_indices=torch.zeros((H, W, 1), dtype=torch.long))
+        sz = cam.shape
+        fh, fw = get_feature_size(H, W)
+        p = 4
+        h_indices = torch.linspace(0, sz[0] - 1, fh * p, dtype=torch.long)
+        w_indices = torch.linspace(0, sz[1] - 1, fw * p, dtype=torch.long)
+        hind, wind = torch.meshgrid(h_indices, w_indices)
+        fb = cam[hind.flatten(), wind.flatten()]
+        fb = fb.reshape((fh, p, fw, p))
+        fb = fb._apply_fn_to_fields(lambda x: x.transpose(1, 2))
+        chunk = 1000
+        parts = [fb.get_row_major_sliced_ray_bundle(i, i + chunk) for i in range(0, len(fb), chunk)]
+        fo = torch.cat([q.origins for q in parts])
+        fd = torch.cat([q.directions for q in parts])
+        fa = torch.cat([q.pixel_area for q in parts])
+        check(f"feature regroup origins {H}x{W}", O.feature_ray_grid(origins, fh, fw, p), fo)
+        check(f"feature regroup directions {H}x{W}", O.feature_ray_grid(directions, fh, fw, p), fd)
+        h_indices = torch.linspace(0, sz[0] - 1, 32, dtype=torch.long)
+        w_indices = torch.linspace(0, sz[1] - 1, 32, dtype=torch.long)
+        hind, wind = torch.meshgrid(h_indices, w_indices)
+        cb = cam[hind.flatten(), wind.flatten()].reshape((32, 32))
+        co = torch.cat([cb.get_row_major_sliced_ray_bundle(i, i + chunk).origins for i in range(0, len(cb), chunk)])
+        check(f"clipseg regroup {H}x{W}", O.clipseg_ray_grid(origins), co)
+        arrays.update({f"c{ci}_hw": np.array([H, W, fh, fw, p]), f"c{ci}_directions": directions,
+                       f"c{ci}_pixel_area": cam.pixel_area, f"c{ci}_feat_origins": fo, f"c{ci}_feat_directions": fd,
+                       f"c{ci}_feat_pixel_area": fa, f"c{ci}_clip_origins": co})
+    # set_feature: the reference's own function body on a stand-in predictor object
+    set_feature = _reference_function("samnerf/segment_anything/predictor.py", "SamPredictor", "set_feature")
+    for name, (C, fh, fw, hw) in {"land": (6, 45, 64, (360, 512)), "square": (6, 64, 64, (512, 512))}.items():
+        feat = torch.randn((C, fh, fw), generator=torch.Generator().manual_seed(7))
+        me = SimpleNamespace(model=SimpleNamespace(image_encoder=SimpleNamespace(img_size=1024), device="cpu"),
+                             reset_image=lambda: None)
+        set_feature(me, feat, hw)
+        arrays.update({f"sf_{name}_in": feat, f"sf_{name}_out": me.features, f"sf_{name}_hw": np.array(hw),
+                       f"sf_{name}_input_size": np.array(me.input_size)})
+    # (portrait: the reference concatenates a [1,C,h,h-w] block along dim 2 and torch raises -- recorded, not reproduced)
+    try:
+        me = SimpleNamespace(model=SimpleNamespace(image_encoder=SimpleNamespace(img_size=1024), device="cpu"),
+                             reset_image=lambda: None)
+        set_feature(me, torch.zeros((6, 64, 40)), (512, 320))
+        arrays["sf_portrait_reference_raises"] = np.array(0)
+    except RuntimeError:
+        arrays["sf_portrait_reference_raises"] = np.array(1)
+    npz("eval_regroup", **arrays)
+
+
 if __name__ == "__main__":
     only = set(sys.argv[1:])
     for fn in (fx_spacing, fx_contraction, fx_hashgrid, fx_mlp, fx_sh, fx_weights, fx_pdf, fx_render, fx_topk,
-               fx_losses, fx_ministep, fx_batch_builder, fx_vit):
+               fx_losses, fx_ministep, fx_batch_builder, fx_vit, fx_eval_regroup):
         if only and fn.__name__ not in only:
             continue
         print(fn.__name__)

@@ -500,3 +500,64 @@ def test_every_exported_symbol_is_documented():
     declared = sorted(set(re.findall(r"\b(snf_[a-z0-9_]+)\s*\(", hdr)))
     missing = [n for n in declared if n not in doc]
     assert not missing, missing
+
+
+def test_eval_regroup_and_set_feature_vs_reference(golden):
+    """Plugin-side eval regroup (model.feature_ray_bundle / clipseg_ray_bundle on this package's RayBundle) and the
+    SamPredictor.set_feature zero-pad against fixtures produced by the reference's own RayBundle / TensorDataclass and its
+    own set_feature body (tests/golden/make_golden.py: fx_eval_regroup)."""
+    import samnerf_amd  # noqa: F401
+    from samnerf_amd.model import clipseg_ray_bundle, feature_ray_bundle
+    from samnerf_amd.rays import RayBundle
+    from samnerf_amd.sam_utils import get_feature_size, set_feature
+    g = golden("eval_regroup")
+    for ci in range(3):
+        H, W, fh, fw, p = (int(v) for v in g[f"c{ci}_hw"])
+        assert get_feature_size(H, W) == (fh, fw)
+        ys, xs = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+        cam = RayBundle(origins=torch.stack([ys, xs, torch.zeros_like(ys)], -1).float(),
+                        directions=torch.from_numpy(g[f"c{ci}_directions"]),
+                        pixel_area=torch.from_numpy(g[f"c{ci}_pixel_area"]),
+                        camera_indices=torch.zeros((H, W, 1), dtype=torch.long))
+        fb = feature_ray_bundle(cam, fh, fw, p)
+        chunk = 1000  # the chunk loop of get_outputs_for_camera_ray_bundle walks the bundle row-major
+        parts = [fb.get_row_major_sliced_ray_bundle(i, min(i + chunk, len(fb))) for i in range(0, len(fb), chunk)]
+        assert torch.equal(torch.cat([q.origins for q in parts]), torch.from_numpy(g[f"c{ci}_feat_origins"]))
+        assert torch.equal(torch.cat([q.directions for q in parts]), torch.from_numpy(g[f"c{ci}_feat_directions"]))
+        assert torch.equal(torch.cat([q.pixel_area for q in parts]), torch.from_numpy(g[f"c{ci}_feat_pixel_area"]))
+        cb = clipseg_ray_bundle(cam)
+        assert torch.equal(cb.flatten().origins, torch.from_numpy(g[f"c{ci}_clip_origins"]))
+    for name in ("land", "square"):
+        out, input_size = set_feature(torch.from_numpy(g[f"sf_{name}_in"]), tuple(int(v) for v in g[f"sf_{name}_hw"]))
+        assert torch.equal(out, torch.from_numpy(g[f"sf_{name}_out"]))
+        assert tuple(input_size) == tuple(int(v) for v in g[f"sf_{name}_input_size"])
+    # portrait: the reference's own code raises (its zero block has the wrong axis); here the map is padded to a square
+    assert int(g["sf_portrait_reference_raises"]) == 1
+    out, input_size = set_feature(torch.ones((6, 64, 40)), (512, 320))
+    assert out.shape == (1, 6, 64, 64) and float(out[..., 40:].abs().max()) == 0.0 and input_size == (1024, 640)
+
+
+def test_plugin_entry_points_resolve():
+    """pyproject.toml registers the two methods in nerfstudio's `nerfstudio.method_configs` group
+    (nerfstudio/plugins/registry.py:35-51); every entry point must load to a MethodSpecification-shaped object whose config
+    is a TrainerConfig with this package's SAMModelConfig.  With nerfstudio importable the real registry type is used."""
+    import importlib
+    import tomli
+    import samnerf_amd  # noqa: F401
+    from samnerf_amd import model as M
+    meta = tomli.load(open(os.path.join(ROOT, "pyproject.toml"), "rb"))
+    eps = meta["project"]["entry-points"]["nerfstudio.method_configs"]
+    assert set(eps) == {"samnerf_distill_mi355x", "samnerf_no_distill_mi355x"}
+    assert meta["tool"]["setuptools"]["package-dir"]["samnerf_amd"] == "segment-anything-in-nerf_amd"
+    for name, target in eps.items():
+        mod, attr = target.split(":")
+        spec = getattr(importlib.import_module(mod), attr)
+        assert spec.config.method_name == name and isinstance(spec.description, str) and spec.description
+        mc = spec.config.pipeline.model
+        assert isinstance(mc, M.SAMModelConfig) and mc._target is M.SAMModel
+        assert mc.distill_sam == ("no_distill" not in name)
+        assert set(spec.config.optimizers) >= {"proposal_networks", "fields"}
+    plugin = importlib.import_module("samnerf_amd.plugin")
+    if plugin.HAVE_NERFSTUDIO:
+        from nerfstudio.plugins.types import MethodSpecification
+        assert isinstance(plugin.samnerf_distill, MethodSpecification)

@@ -196,3 +196,18 @@ def test_vit_oracle_vs_reference_fixture(golden):
     close(trace[1], T(g["t1"]), 2e-6)
     close(trace[2], T(g["t2"]), 2e-6)
     close(y, T(g["y"]), 2e-6)
+
+
+def test_eval_regroup(golden):
+    """The eval-path ray regroup (sam_model.py:371-398) against what the reference's own RayBundle / TensorDataclass
+    machinery produced: round 1 checked O.render_camera only against the HIP path."""
+    g = golden("eval_regroup")
+    for ci in range(3):
+        H, W, fh, fw, p = (int(v) for v in g[f"c{ci}_hw"])
+        ys, xs = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+        origins = torch.stack([ys, xs, torch.zeros_like(ys)], -1).float()
+        assert O.get_feature_size(H, W) == (fh, fw)
+        close(O.feature_ray_grid(origins, fh, fw, p), T(g[f"c{ci}_feat_origins"]))
+        close(O.feature_ray_grid(T(g[f"c{ci}_directions"]), fh, fw, p), T(g[f"c{ci}_feat_directions"]))
+        close(O.feature_ray_grid(T(g[f"c{ci}_pixel_area"]), fh, fw, p), T(g[f"c{ci}_feat_pixel_area"]))
+        close(O.clipseg_ray_grid(origins), T(g[f"c{ci}_clip_origins"]))
