@@ -135,6 +135,58 @@ def cpu_baseline(w: dict, budget_s: float):
                       f"tables, no optimizer step, {el:.1f} s of CPU work"}
 
 
+def _free(trainer) -> None:
+    """Drop a trainer's device memory (arenas, schedule buffers) before the next workload is built."""
+    import gc
+    trainer._program = None
+    trainer.pipeline = None
+    trainer.optimizers = None
+    gc.collect()
+    torch.cuda.empty_cache()
+
+
+def set_exchange_mode(mode: str) -> None:
+    """Multi-rank gradient exchange: 'table_parallel' (default: feature tables sharded by level over the ranks, ZeRO-1
+    style reduce-scatter / all-gather for the rest) or 'allreduce' (north_star's wording: full replicas, plain all-reduce of
+    every gradient, replicated Adam).  Takes effect for trainers built afterwards."""
+    from samnerf_amd import ops
+    tp = mode == "table_parallel"
+    ops.TABLE_PARALLEL = tp
+    os.environ["SNF_TABLE_PARALLEL"] = "1" if tp else "0"
+    os.environ["SNF_SHARDED_OPTIMIZER"] = "1" if tp else "0"
+
+
+def quick_measure(name: str, rank: int, local_rank: int, world: int, steps: int = 10, warmup: int = 4) -> dict:
+    """Short run of another BASELINE workload (no serial replay, no breakdown): ms per step and the metric."""
+    w = dict(WORKLOADS[name], world=world)
+    trainer = build_trainer(w, local_rank, world)
+    for i in range(warmup):
+        trainer.train_iteration(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        trainer.train_iteration(warmup + i)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    ms = el / steps * 1e3
+    feat = w["K"] * 12288 if w["method"] == "samnerf_distill" else 0
+    b_step = 3 * (w["P"] * 320 + w["S"] * 1024 + feat) * w["R"]
+    static = trainer._program is not None
+    _free(trainer)
+    return {"ms_per_step": round(ms, 4), "value": world * w["R"] * w["S"] * steps / el, "unit": "ray-samples/s", "steps": steps,
+            "warmup": warmup, "rays_per_gpu": w["R"], "step_frac_of_hbm_peak": round(b_step / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+            "static_schedule": static}
+
+
+def mfma_util() -> dict:
+    """{kernel-name substring: matrix-core busy fraction} from the committed PMC pass (tools/mfma_util.py ->
+    profiles/r02_mfma_util.json: SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES per kernel)."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "r02_mfma_util.json")))["by_entry_point"]
+    except (OSError, KeyError, ValueError):
+        return {}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -143,8 +195,13 @@ def main():
     ap.add_argument("--workload", default="distill_4096x128", choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0)
     ap.add_argument("--roofline-kernel", default=None, help="kernel key 'entry/tag' to time live (default: auto)")
+    ap.add_argument("--other-workloads", default=None,
+                    help="comma list of further BASELINE workloads measured briefly and reported under 'other_workloads' "
+                         "(default at --gpus 1 with the default workload: the other two; 'none' disables)")
+    ap.add_argument("--exchange", default="both", choices=["both", "table_parallel", "allreduce"],
+                    help="multi-rank gradient exchange to time (both: each for --steps steps, the faster one is `value`)")
     args = ap.parse_args()
-    w = WORKLOADS[args.workload]
+    w = dict(WORKLOADS[args.workload])
 
     import samnerf_amd  # noqa: F401
     from samnerf_amd import distributed as D
@@ -160,24 +217,63 @@ def main():
         from samnerf_amd import _lib
         assert _lib.load().snf_set_adam_launch(*(int(x) for x in os.environ["SNF_ADAM_LAUNCH"].split(","))) == 0
     w["world"] = world
-    trainer = build_trainer(w, local_rank, world)
-
     multi = dist.is_initialized()  # world > 1 (or SNF_FORCE_COLLECTIVES=1 under torchrun: RCCL paths on one GPU)
-    # SNF_AUTOTUNE_STREAMS=1: untimed, before the warm-up, the trainer times its two stream layouts on this device and keeps
-    # the faster one (Trainer.autotune_streams); by default the three-stream layout is used as is
-    stream_probe = trainer.autotune_streams() if os.environ.get("SNF_AUTOTUNE_STREAMS", "0") == "1" else {}
 
     def barrier():
         if multi:
             dist.barrier()
 
-    # ---- warm-up (untimed).  Afterwards a short SERIAL replay (one stream, every C-ABI launch bracketed by HIP events)
+    def timed(trainer, first_step: int, nsteps: int):
+        """EXACTLY nsteps train iterations between barrier + synchronize; max over the ranks."""
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(nsteps):
+            trainer.train_iteration(first_step + i)
+        torch.cuda.synchronize()
+        barrier()
+        el = time.perf_counter() - t0
+        if multi:
+            t = torch.tensor([el], device="cuda", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el
+
+    # ---- multi-rank: both gradient-exchange modes are timed (the default table-parallel one and north_star's plain
+    # all-reduce), each on a trainer of its own; the faster is the line's `value`, both are reported
+    exchange_modes = {}
+    modes = ["single"]
+    if multi:
+        modes = ["table_parallel", "allreduce"] if args.exchange == "both" else [args.exchange]
+    built = {}
+    for mode in modes:
+        if multi:
+            set_exchange_mode(mode)
+        tr = build_trainer(w, local_rank, world)
+        st = 0
+        for i in range(args.warmup):
+            tr.train_iteration(st)
+            st += 1
+        el = None
+        if len(modes) > 1:
+            el = timed(tr, st, args.steps)
+            st += args.steps
+            exchange_modes[mode] = {"ms_per_step": round(el / args.steps * 1e3, 4),
+                                    "value": world * w["R"] * w["S"] * args.steps / el}
+        built[mode] = (tr, st, el)
+    chosen_mode = min(modes, key=lambda m: built[m][2]) if len(modes) > 1 else modes[0]
+    for m in modes:
+        if m != chosen_mode:
+            _free(built[m][0])
+    if multi:
+        set_exchange_mode(chosen_mode)
+    trainer, step, _ = built[chosen_mode]
+    # SNF_AUTOTUNE_STREAMS=1: untimed, the trainer times its stream layouts on this device and keeps the faster one
+    stream_probe = trainer.autotune_streams() if os.environ.get("SNF_AUTOTUNE_STREAMS", "0") == "1" else {}
+
+    # ---- warm-up done.  A short SERIAL replay (one stream, every C-ABI launch bracketed by HIP events on its stream)
     # measures each kernel's own duration and picks the dominant one; the timed region below runs the real
     # (multi-stream) step and times that kernel live.
-    step = 0
-    for i in range(args.warmup):
-        trainer.train_iteration(step)
-        step += 1
     n_break = 3
     torch.cuda.synchronize()
     trainer.overlap = False
@@ -195,7 +291,6 @@ def main():
     trainer.train_iteration(step)  # back on the concurrent schedule before timing starts
     step += 1
     per_step = {k: v["total_ms"] / n_break for k, v in breakdown.items()}
-    launches = {k: v["launches"] / n_break for k, v in breakdown.items()}
 
     def model_of(key):
         """(bound, algorithmic units per launch or None, unit).  Adam is modelled per STEP (its launches cover the
@@ -218,19 +313,8 @@ def main():
         ops.enable_kernel_timing([dom])
 
     # ---- timed region: EXACTLY --steps train iterations between barrier + synchronize
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        trainer.train_iteration(step)
-        step += 1
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if multi:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = timed(trainer, step, args.steps)
+    step += args.steps
     live = ops.kernel_timing_summary() if dom is not None else {}
     ops.enable_kernel_timing(None)
 
@@ -238,35 +322,43 @@ def main():
     n_fb = min(args.steps, 20)
     trainer.optimizers.enabled = False
     trainer.train_iteration(step)
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(n_fb):
-        trainer.train_iteration(step)
-    torch.cuda.synchronize()
-    barrier()
-    elapsed_fb = time.perf_counter() - t0
+    elapsed_fb = timed(trainer, step, n_fb)
     trainer.optimizers.enabled = True
     trainer.optimizers.zero_grad_all()
-    if multi:
-        t = torch.tensor([elapsed_fb], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed_fb = float(t.item())
+    static_schedule = trainer._program is not None
+    static_off = trainer._program_off
+    n_arena_slots = adam_bytes(trainer)
+    backend = dist.get_backend() if multi else None
+
+    # ---- the other BASELINE workloads, briefly (N = 1, default workload only): configs[1] and the per-rank load of configs[3]
+    others_req = args.other_workloads
+    if others_req is None:
+        others_req = ("no_distill_4096x128,distill_16384x128" if (world == 1 and args.workload == "distill_4096x128") else "none")
+    other_workloads = {}
+    if others_req != "none":
+        _free(trainer)
+        for name in others_req.split(","):
+            other_workloads[name] = quick_measure(name, rank, local_rank, world)
 
     if rank == 0:
         R, S, K = w["R"], w["S"], w["K"]
         ms = elapsed / args.steps * 1e3
+        mu = mfma_util()
+
         def roof(key, stat, nsteps, where):
             """achieved = algorithmic units of all timed launches / their summed HIP-event duration."""
-            bound, units, unit = model_of(key)
+            bound, units, unit = model_of(key) if key != "snf_adam_step" else ("hbm", n_arena_slots, "GB/s")
             nl, total_ms = stat["launches"], stat["total_ms"]
             # Adam and the fused backward + Adam: bytes of the actual launches (reported by the launch sites)
             total_units = stat["units"] if stat.get("units", 0) > 0 else units * nl
             achieved = total_units / (total_ms * 1e-3) / (1e9 if bound == "hbm" else 1e12)
             peak = HBM_PEAK_GBPS if bound == "hbm" else FP32_MATRIX_PEAK_TFLOPS
-            return {"kernel": key, "bound": bound, "achieved": round(achieved, 2), "peak": peak, "unit": unit,
-                    "frac": round(achieved / peak, 4), "traffic": None, "avg_launch_ms": round(total_ms / max(nl, 1), 4),
-                    "launches_timed": nl, "algorithmic_units_per_launch": total_units / max(nl, 1), "measured": where}
+            out = {"kernel": key, "bound": bound, "achieved": round(achieved, 2), "peak": peak, "unit": unit,
+                   "frac": round(achieved / peak, 4), "traffic": None, "avg_launch_ms": round(total_ms / max(nl, 1), 4),
+                   "launches_timed": nl, "algorithmic_units_per_launch": total_units / max(nl, 1), "measured": where}
+            if key in mu:  # matrix-core busy cycles / shader busy cycles of this entry point's kernels (rocprofv3 PMC pass)
+                out["mfma_busy"] = mu[key]
+            return out
 
         def pmc_traffic(key):
             """HBM bytes per launch from the committed PMC passes (profiles/pmc_traffic.json, made by tools/gpu_record.sh +
@@ -290,7 +382,7 @@ def main():
             roofline["serial"] = roof(dom, breakdown[dom], n_break, "HIP events, serial replay (kernel alone on the GPU)")
         others = []
         for k in sorted(per_step, key=lambda kk: -per_step[kk]):
-            if k != dom and model_of(k)[1] and len(others) < 7:
+            if k != dom and (k == "snf_adam_step" or algorithmic_model(k, w)[1]) and len(others) < 7:
                 others.append(roof(k, breakdown[k], n_break, "HIP events, serial replay"))
         # algorithmic bytes of the whole step, for the step-level fraction
         feat = K * 12288 if w["method"] == "samnerf_distill" else 0
@@ -314,6 +406,10 @@ def main():
             "step_frac_of_hbm_peak": b_step / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
             "roofline": roofline,
             "roofline_other_kernels": others,
+            "host": {"static_schedule": static_schedule, "static_schedule_off_reason": static_off},
+            "rccl": {"backend": backend, "ranks": world, "collectives_on": bool(multi),
+                     "exchange": chosen_mode if multi else None, "exchange_modes_timed": exchange_modes},
+            "other_workloads": other_workloads,
             "stream_layout_probe_ms": {k: round(v, 3) for k, v in stream_probe.items()},
             "serial_step_ms": round(sum(per_step.values()), 3),
             "kernel_ms_per_step_serial": {k: round(v, 4) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1])},

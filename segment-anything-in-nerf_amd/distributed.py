@@ -40,8 +40,33 @@ def init_distributed(backend: Optional[str] = None) -> tuple:
             backend = os.environ.get("SNF_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        import datetime
+        # a rank that never arrives must surface as an error naming the rendezvous, not as a silent hang of the whole job
+        timeout = datetime.timedelta(seconds=float(os.environ.get("SNF_DIST_TIMEOUT", "180")))
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=timeout)
+        first_collective_check(rank, world, backend)
     return rank, local_rank, world
+
+
+def first_collective_check(rank: int, world: int, backend: str) -> None:
+    """One tiny all-reduce right after the rendezvous: the first collective is where a broken fabric / IPC setup shows
+    (HSA_ENABLE_IPC_MODE_LEGACY, a rank on the wrong device, a rank that died during start-up).  Fails with the facts a
+    user needs instead of hanging in the middle of the first train step."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if (backend == "nccl" and torch.cuda.is_available()) else "cpu"
+    t = torch.ones((1,), device=dev)
+    try:
+        dist.all_reduce(t)
+        if dev != "cpu":
+            torch.cuda.synchronize()
+        got = float(t.item())
+    except Exception as e:  # noqa: BLE001
+        raise RuntimeError(
+            f"rank {rank}/{world}: the first {backend} collective failed ({type(e).__name__}: {e}).  Check that every rank "
+            f"started (torchrun --nproc-per-node {world}), MASTER_ADDR={os.environ.get('MASTER_ADDR')} "
+            f"MASTER_PORT={os.environ.get('MASTER_PORT')} are reachable, one rank per GPU, and "
+            f"HSA_ENABLE_IPC_MODE_LEGACY=0 (current: {os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')})") from e
+    if got != float(world):
+        raise RuntimeError(f"rank {rank}/{world}: first all-reduce returned {got}, expected {world} (ranks missing or doubled)")
 
 
 # -- collectives.  backend "nccl" (= RCCL): straight through.  backend "gloo" with device tensors (tests: two ranks sharing

@@ -396,6 +396,83 @@ def test_bench_prints_the_contract_line():
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
 
 
+def _run_bench(extra, env_extra=None, launcher_ranks=0, timeout=1200):
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "SNF_FORCE_COLLECTIVES")}
+    env.update(env_extra or {})
+    cmd = [sys.executable]
+    if launcher_ranks:
+        cmd += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(launcher_ranks), "--master-addr",
+                "127.0.0.1", "--master-port", str(29300 + os.getpid() % 90)]
+    cmd += [os.path.join(root, "bench.py")] + extra
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout, cwd=root)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-500:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("workload,R,K", [("no_distill_4096x128", 4096, 3), ("distill_16384x128", 16384, 16)])
+def test_bench_other_baseline_configs_as_the_main_workload(workload, R, K):
+    """BASELINE configs[1] (samnerf_no_distill, 4096 x 128) and the per-rank load of configs[3] (samnerf_distill, 16384 x 128)
+    through bench.py at their full sample counts: one JSON line, value = R * 128 / t_step, a roofline block, and the train
+    step ran as the static launch schedule."""
+    d = _run_bench(["--workload", workload, "--steps", "3", "--warmup", "2", "--cpu-baseline-seconds", "0"])
+    assert d["config"]["name"] == workload and d["config"]["rays_per_gpu"] == R and d["value"] > 0
+    assert abs(d["value"] - R * 128 / (d["ms_per_step"] * 1e-3)) <= 1e-3 * d["value"]
+    assert abs(d["feature_samples_per_s"] - R * K / (d["ms_per_step"] * 1e-3)) <= 1e-3 * d["feature_samples_per_s"]
+    assert d["roofline"] is not None and d["roofline"]["frac"] > 0 and d["host"]["static_schedule"] is True
+    assert d["other_workloads"] == {}  # only the default workload carries the other two
+
+
+def test_bench_default_line_carries_the_other_workloads():
+    """The driver only ever runs `bench.py --gpus 1`: that line reports configs[1] and the per-rank load of configs[3] too."""
+    d = _run_bench(["--steps", "3", "--warmup", "1", "--cpu-baseline-seconds", "0"])
+    ow = d["other_workloads"]
+    assert set(ow) == {"no_distill_4096x128", "distill_16384x128"}
+    for name, v in ow.items():
+        assert v["value"] > 0 and v["ms_per_step"] > 0 and v["static_schedule"] is True, name
+    assert ow["distill_16384x128"]["rays_per_gpu"] == 16384
+    assert d["rccl"]["ranks"] == 1 and d["rccl"]["collectives_on"] is False
+
+
+def test_bench_times_both_exchange_modes_under_the_launcher():
+    """N > 1 flow with one forced-collective rank on RCCL: the table-parallel exchange AND north_star's plain all-reduce are
+    both timed, the faster one is the line's value, and the record shows backend and rank count."""
+    d = _run_bench(["--gpus", "1", "--steps", "3", "--warmup", "1", "--cpu-baseline-seconds", "0"],
+                   {"SNF_FORCE_COLLECTIVES": "1", "HSA_ENABLE_IPC_MODE_LEGACY": "0"}, launcher_ranks=1)
+    r = d["rccl"]
+    assert r["backend"] == "nccl" and r["ranks"] == 1 and r["collectives_on"] is True
+    assert set(r["exchange_modes_timed"]) == {"table_parallel", "allreduce"} and r["exchange"] in r["exchange_modes_timed"]
+    assert all(v["value"] > 0 for v in r["exchange_modes_timed"].values())
+    best = max(v["value"] for v in r["exchange_modes_timed"].values())
+    assert r["exchange_modes_timed"][r["exchange"]]["value"] == best
+
+
+def test_no_distill_train_step_at_128_samples_vs_oracle():
+    """BASELINE configs[1] sample counts (P = 64, S = 128, K = 3 unused: no feature heads) at oracle-sized tables: outputs and
+    every loss term of one samnerf_no_distill train step against the CPU oracle."""
+    from samnerf_amd.interop import load_named_params
+    R, P, S, T = 256, 64, 128, 13
+    cfg = O.PathConfig(num_proposal_samples=P, num_nerf_samples=S, distill_sam=False).small(T)
+    params = O.init_params(cfg, seed=4, table_scale=0.05)
+    o, d = O.synthetic_rays(R, 8)
+    batch = O.synthetic_batch(cfg, R, 9)
+    gen = torch.Generator().manual_seed(10)
+    t_rand, u_rand = torch.rand((R, 1), generator=gen), torch.rand((R, 1), generator=gen)
+    ref = O.forward(params, cfg, o, d, True, t_rand, u_rand, 0.7)
+    model = build_model(P, S, 3, 1, T, distill=False)
+    load_named_params(model, params)
+    out, losses = run_step(model, o, d, batch, t_rand, u_rand, 0.7)
+    assert md(out["rgb"], ref["rgb"]) <= TOL and md(out["accumulation"], ref["accumulation"]) <= TOL
+    assert md(out["depth"], ref["depth"]) <= 1e-3  # median depth: a bin mid-point far from the camera
+    ld = O.loss_dict(ref, batch, cfg)
+    assert set(ld) == set(losses)
+    for k, v in ld.items():
+        assert abs(float(losses[k]) - float(v)) <= 1e-4 * max(1.0, abs(float(v))), k
+
+
 def test_bench_under_the_multi_gpu_launcher_single_rank():
     """bench.py the way the driver starts it for N > 1 (python -m torch.distributed.run ... bench.py --gpus N), with one rank
     and SNF_FORCE_COLLECTIVES=1: process group on RCCL, table-parallel feature grids (all-gather / all-to-all in forward and
@@ -407,7 +484,7 @@ def test_bench_under_the_multi_gpu_launcher_single_rank():
     port = str(29900 + os.getpid() % 90)
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
                           "--master-addr", "127.0.0.1", "--master-port", port, os.path.join(root, "bench.py"),
-                          "--gpus", "1", "--steps", "3", "--warmup", "1", "--cpu-baseline-seconds", "0"],
+                          "--gpus", "1", "--steps", "3", "--warmup", "1", "--cpu-baseline-seconds", "0", "--exchange", "table_parallel"],
                          env=env, capture_output=True, text=True, timeout=900, cwd=root)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -559,7 +636,7 @@ def test_bench_with_two_ranks_sharing_the_gpu():
     port = str(29500 + os.getpid() % 90)
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                           "--master-addr", "127.0.0.1", "--master-port", port, os.path.join(root, "bench.py"),
-                          "--gpus", "2", "--steps", "3", "--warmup", "1", "--cpu-baseline-seconds", "0"],
+                          "--gpus", "2", "--steps", "3", "--warmup", "1", "--cpu-baseline-seconds", "0", "--exchange", "table_parallel"],
                          env=env, capture_output=True, text=True, timeout=1200, cwd=root)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]

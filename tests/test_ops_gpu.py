@@ -792,3 +792,25 @@ def test_pdf_euclidean_bins_within_the_analytic_bound(golden, mode):
     assert bool(((eb - eb_ref).abs() <= bound).all()), float(((eb - eb_ref).abs() / bound).max())
     small = eb_ref <= 50.0
     assert float(((eb - eb_ref).abs() / eb_ref.clamp_min(1e-3))[small].max()) <= 1e-4
+
+
+@pytest.mark.parametrize("N", [1 << 21, (1 << 21) + 1])
+def test_hashgrid_backward_at_the_record_limit(N):
+    """A sorted-backward record has 21 sample bits.  BASELINE configs[3] on 8 ranks, table-parallel, hands a rank the
+    feature samples of ALL ranks for its own levels: W * N = 8 * 16384 * 16 = 2^21 -- exactly the limit (hashgrid.hip: `N <=
+    1 << HG_SAMPLE_BITS`).  At the limit the presorted single launch must take it; one sample more must go through the sliced
+    path.  Both against the atomic kernel (ops.tp_accumulate calls _hashgrid_bwd_launch with these arguments)."""
+    m = ops()
+    L, F, T = 3, 8, 19  # three owned levels of a feature grid (24 slabs / 8 ranks)
+    g = torch.Generator(device=DEV).manual_seed(1)
+    u = torch.rand((N, 3), device=DEV, generator=g)
+    sc = torch.tensor([181.0, 256.0, 362.0], device=DEV)
+    G_ = torch.randn((N, L * F), device=DEV, generator=g)
+    buf = torch.zeros(((L << T) * F,), device=DEV)
+    m.hashgrid_presort(u, sc, L, T)  # what tp_presort does for an owned run
+    assert (len(getattr(u, "_snf_sorted", {})) == 1) == (N <= m.HASHGRID_BWD_MAX_SAMPLES)
+    assert m._hashgrid_bwd_launch(u, G_, sc, N, L, F, T, L * F, 0, buf, None) is False
+    ref = torch.zeros_like(buf)
+    m._launch("snf_hashgrid_bwd", m._p(u), m._p(G_), m._p(sc), N, L, F, T, L * F, 0, m._p(ref), m._stream())
+    torch.cuda.synchronize()
+    assert maxdiff(buf, ref) <= 2e-5 * float(ref.abs().max())
