@@ -679,7 +679,7 @@ def test_level_major_feature_grids_feed_the_table_backward():
         stage = torch.empty((L * N * F,), device=DEV)
         m._launch("snf_hashgrid_bwd_presorted", m._p(grad), N, L, F, T, 2 * L * F, gi * L * F, 0, m._p(a), m._p(ws), m._p(stage), st)
         m._launch("snf_hashgrid_bwd_presorted", gpl.data_ptr() + gi * L * N * F * 4, N, L, F, T, 0, 0, 0, m._p(bq), m._p(ws), None, st)
-        assert torch.equal(a, bq)
+        assert maxdiff(a, bq) <= 2e-6 * float(a.abs().max())  # (fp32 sums inside a row depend on the LDS ranking order)
 
 
 @pytest.mark.parametrize("N,I,O,planar", [(65536, 192, 256, True), (65536, 256, 256, False), (65536, 256, 192, False),
