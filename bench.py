@@ -45,7 +45,7 @@ def algorithmic_model(key: str, w: dict):
     R, P, S, K = w["R"], w["P"], w["S"], w["K"]
     name, _, tag = key.partition("/")
     if name in ("snf_hashgrid_fwd", "snf_hashgrid_bwd", "snf_hashgrid_bwd_sorted", "snf_hashgrid_bwd_sorted_ex",
-                "snf_hashgrid_bwd_presorted", "snf_hashgrid_bwd_presorted_adam"):
+                "snf_hashgrid_bwd_presorted", "snf_hashgrid_bwd_presorted_adam", "snf_hashgrid_bwd_presorted_adam_fx"):
         # (the fused backward + Adam reports its own bytes per launch -- ops._hashgrid_bwd_launch: the corner
         # contributions as below plus 24 B per parameter of the fused levels -- and roof() prefers those)
         m = re.fullmatch(r"F(\d+)L(\d+)(tp)?", tag)
@@ -303,7 +303,8 @@ def main():
     # several kernels counts with the share of its largest one: the bucketed hash-grid backward is stage/count/scan/scatter/
     # reduce, k_hg_reduce being ~60 % of it (profiles/*_kernel_stats.csv).
     largest_kernel_share = {"snf_hashgrid_bwd_sorted": 0.6, "snf_hashgrid_bwd_sorted_ex": 0.6,
-                            "snf_hashgrid_bwd_presorted": 0.9, "snf_hashgrid_bwd_presorted_adam": 0.95}
+                            "snf_hashgrid_bwd_presorted": 0.9, "snf_hashgrid_bwd_presorted_adam": 0.95,
+                            "snf_hashgrid_bwd_presorted_adam_fx": 0.95}
     dom = args.roofline_kernel
     if dom is None and per_step:
         modelled = [k for k in per_step if model_of(k)[1]]

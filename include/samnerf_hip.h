@@ -115,6 +115,22 @@ int snf_hashgrid_bwd_presorted_adam(const float* grad_out, int N, int L, int F, 
                                     int fuse_from_level, float* param, float* exp_avg, float* exp_avg_sq, float lr,
                                     float beta1, float beta2, float eps, int step, float grad_scale, snf_stream_t stream);
 
+/* The same pass with FIXED-POINT per-row sums (F = 2 and F = 8): a contribution w * g is added to its row as a 64-bit integer
+ * LDS atomic, q = rint(w g 2^s) with 2^s = 2^38 / 2^e and 2^e above the level's largest finite |g| (found by a small
+ * pre-pass), instead of being sorted by row and summed in fp32 -- ds_add_u64 retires 6.3 lane-ops/clk/CU on gfx950 against
+ * 0.37 for ds_add_f32.  The sum is exact, hence independent of the order of the records (bit-reproducible table gradients);
+ * every contribution is resolved to 2^-38 of the level's largest gradient; rows that receive a non-finite contribution
+ * become NaN as a float sum would.  `scratch`: SNF_HG_FX_SCRATCH_BYTES, private to the launch -- the sorted workspace stays
+ * read-only, so grids sharing a sort may run their backward concurrently.  fuse_from_level = L steps no level (gradient
+ * accumulation only).  snf_hashgrid_bwd_presorted[_adam] take this path by themselves for F = 2 (scratch inside their
+ * workspace; SNF_HG_FX=0 restores the float reduce). */
+#define SNF_HG_FX_SCRATCH_BYTES 256
+int snf_hashgrid_bwd_presorted_adam_fx(const float* grad_out, int N, int L, int F, int log2_T, int ld_out, int col_off,
+                                       int n_run_levels, float* grad_table, const void* sorted_workspace, float* stage,
+                                       int fuse_from_level, float* param, float* exp_avg, float* exp_avg_sq, float lr,
+                                       float beta1, float beta2, float eps, int step, float grad_scale, void* scratch,
+                                       snf_stream_t stream);
+
 /* Arithmetic of the wide (>= 128 input) dense layers: 1 (default) = bf16 3-term split on the bf16 matrix cores with fp32
  * accumulate (max abs error ~1e-6 on head-shaped data, 1/5 of the matrix cycles), 0 = exact fp32 matrix cores,
  * 2 = as 1 and the fused 64-wide chains (snf_mlp64_*) on the same split (opt-in: -9 % on those kernels, 6x their round-off).

@@ -782,22 +782,30 @@ __global__ __launch_bounds__(256) void k_hg_level_absmax(const float* __restrict
     }
 }
 
-template <int F, bool ADAM>
+// SPLIT: workgroups per bucket.  The accumulators of a whole 2048-row bucket are 32 KB at F = 2 but 128 KB at F = 8, so at
+// F = 8 two workgroups share a bucket: each streams ALL of its records (8 bytes each, cheap) but gathers and accumulates
+// only those whose row falls into its half, and owns the Adam step of that half's rows.
+template <int F, bool ADAM, int SPLIT>
 __global__ __launch_bounds__(HG_FX_T) void k_hg_reduce_fx(const float* __restrict__ gT, int N, int log2_T, int log2B,
                                                           const uint32_t* __restrict__ bucket_start,
                                                           const uint2* __restrict__ records, float* __restrict__ grad_table,
                                                           int n_run_levels, const uint32_t* __restrict__ lvl_absmax_bits,
                                                           HgAdam adam) {
-    __shared__ unsigned long long acc[HG_MAX_RPB * F];
-    __shared__ uint32_t bad[HG_MAX_RPB / 32];
+    constexpr int MAXROWS = HG_MAX_RPB / SPLIT;
+    __shared__ unsigned long long acc[MAXROWS * F];
+    __shared__ uint32_t bad[MAXROWS * F / 32];  // one bit per (row, feature): a non-finite contribution landed there
     const int B = 1 << log2B, log2rpb = log2_T - log2B;
-    const int rpb = 1 << log2rpb;
-    const int tid = threadIdx.x, b = blockIdx.x, l = blockIdx.y, lane = tid & 63;
+    const int rpb_full = 1 << log2rpb;
+    const int rpb = rpb_full >= SPLIT ? rpb_full / SPLIT : rpb_full;  // rows of this workgroup
+    const int part = rpb_full >= SPLIT ? (int)(blockIdx.x % SPLIT) : 0;
+    const int tid = threadIdx.x, b = blockIdx.x / SPLIT, l = blockIdx.y, lane = tid & 63;
+    if (rpb_full < SPLIT && (blockIdx.x % SPLIT) != 0) return;  // (tiny tables: one workgroup per bucket)
+    const uint32_t row0 = (uint32_t)part * (uint32_t)rpb;
     const uint32_t start = bucket_start[l * (B + 1) + b], end = bucket_start[l * (B + 1) + b + 1];
     const bool fuse = ADAM && l >= adam.from_level;
     if (start == end && !fuse) return;
     for (int i = tid; i < rpb * F; i += HG_FX_T) acc[i] = 0ull;
-    if (tid < HG_MAX_RPB / 32) bad[tid] = 0u;
+    for (int i = tid; i < MAXROWS * F / 32; i += HG_FX_T) bad[i] = 0u;
     // 2^e > M >= every finite |g| of the level; q = rint(c * 2^(BITS - e)).  (M = 0: nothing finite and non-zero lands here)
     int e = 0;
     frexpf(__uint_as_float(lvl_absmax_bits[l]), &e);
@@ -822,7 +830,15 @@ __global__ __launch_bounds__(HG_FX_T) void k_hg_reduce_fx(const float* __restric
     };
     auto gather = [&](const uint2 (&r)[U], float (&g)[U][F]) {
 #pragma unroll
-        for (int j = 0; j < U; ++j) load_row<F>(gl + (size_t)(r[j].x & mask_s) * F, g[j]);
+        for (int j = 0; j < U; ++j) {
+            // (SPLIT > 1: only the records of this workgroup's rows cost a gather)
+            if (SPLIT == 1 || ((r[j].x >> HG_SAMPLE_BITS) - row0) < (uint32_t)rpb)
+                load_row<F>(gl + (size_t)(r[j].x & mask_s) * F, g[j]);
+            else {
+#pragma unroll
+                for (int f = 0; f < F; ++f) g[j][f] = 0.f;
+            }
+        }
     };
     constexpr uint32_t TRIP = HG_FX_T * U;
     load_recs(start, rec0);
@@ -836,7 +852,8 @@ __global__ __launch_bounds__(HG_FX_T) void k_hg_reduce_fx(const float* __restric
 #pragma unroll
         for (int j = 0; j < U; ++j) {
             bool live = c0 + tid + (uint32_t)HG_FX_T * j < end;
-            const uint32_t row = rec0[j].x >> HG_SAMPLE_BITS;
+            const uint32_t row = (rec0[j].x >> HG_SAMPLE_BITS) - row0;  // row inside this workgroup's share
+            if (SPLIT > 1) live = live && row < (uint32_t)rpb;
             const float w = __uint_as_float(rec0[j].y);
             float v[F];
 #pragma unroll
@@ -861,17 +878,15 @@ __global__ __launch_bounds__(HG_FX_T) void k_hg_reduce_fx(const float* __restric
                 live = live && ((lane == 63) || (next != key));
             }
             if (live) {
-                bool finite = true;
 #pragma unroll
-                for (int f = 0; f < F; ++f) finite = finite && (fabsf(v[f]) < INFINITY);
-                if (finite) {
-#pragma unroll
-                    for (int f = 0; f < F; ++f) {
+                for (int f = 0; f < F; ++f) {
+                    if (fabsf(v[f]) < INFINITY) {
                         const long long q = __float2ll_rn(v[f] * scale);
                         if (q != 0) atomicAdd(&acc[row * F + f], (unsigned long long)q);
+                    } else {  // NaN / inf cannot be represented: the element becomes NaN, as a float sum would
+                        const uint32_t e = row * F + f;
+                        atomicOr(&bad[e >> 5], 1u << (e & 31));
                     }
-                } else {
-                    atomicOr(&bad[row >> 5], 1u << (row & 31));
                 }
             }
         }
@@ -885,9 +900,9 @@ __global__ __launch_bounds__(HG_FX_T) void k_hg_reduce_fx(const float* __restric
     }
     __syncthreads();
     // ---- epilogue: each thread converts its rows (tid, tid + T, ...), four row sets in flight
-    const size_t base = (((size_t)l << log2_T) + ((size_t)b << log2rpb)) * F;
+    const size_t base = (((size_t)l << log2_T) + ((size_t)b << log2rpb) + row0) * F;
     float* __restrict__ slab = grad_table + base;
-    constexpr int RU = 4;
+    constexpr int RU = F == 2 ? 4 : 2;
     for (int r0 = tid; r0 < rpb; r0 += HG_FX_T * RU) {
         float gg[RU][F], pp[RU][F], mm[RU][F], vv[RU][F];
         bool on[RU], nz[RU];
@@ -897,10 +912,11 @@ __global__ __launch_bounds__(HG_FX_T) void k_hg_reduce_fx(const float* __restric
             on[j] = r < rpb;
             nz[j] = false;
             if (on[j]) {
-                const bool isbad = (bad[r >> 5] >> (r & 31)) & 1u;
 #pragma unroll
                 for (int f = 0; f < F; ++f) {
-                    const long long q = (long long)acc[r * F + f];
+                    const uint32_t e = (uint32_t)(r * F + f);
+                    const bool isbad = (bad[e >> 5] >> (e & 31)) & 1u;
+                    const long long q = (long long)acc[e];
                     gg[j][f] = isbad ? __uint_as_float(0x7FC00000u) : __ll2float_rn(q) * inv;
                     nz[j] = nz[j] || (q != 0) || isbad;
                 }
@@ -1105,7 +1121,7 @@ extern "C" int snf_hashgrid_bwd_presorted(const float* grad_out, int N, int L, i
         if (hg_fx_on(F, L, N)) {
             hipMemsetAsync(w.fx, 0, L * sizeof(uint32_t), st);
             hipLaunchKernelGGL(k_hg_level_absmax<2>, dim3(hg_absmax_blocks(N, F), L), dim3(256), 0, st, stage, N, w.fx);
-            hipLaunchKernelGGL((k_hg_reduce_fx<2, false>), dim3(B, L), dim3(HG_FX_T), 0, st, stage, N, log2_T, g.log2B, w.bstart,
+            hipLaunchKernelGGL((k_hg_reduce_fx<2, false, 1>), dim3(B, L), dim3(HG_FX_T), 0, st, stage, N, log2_T, g.log2B, w.bstart,
                                (const uint2*)w.records, grad_table, n_run_levels, w.fx, HgAdam{});
         } else
         hipLaunchKernelGGL((k_hg_reduce<2, false>), dim3(B, L), dim3(HG_RT), 0, st, stage, N, log2_T, g.log2B, w.bstart,
@@ -1152,7 +1168,7 @@ extern "C" int snf_hashgrid_bwd_presorted_adam(const float* grad_out, int N, int
         if (hg_fx_on(F, L, N)) {
             hipMemsetAsync(w.fx, 0, L * sizeof(uint32_t), st);
             hipLaunchKernelGGL(k_hg_level_absmax<2>, dim3(hg_absmax_blocks(N, F), L), dim3(256), 0, st, stage, N, w.fx);
-            hipLaunchKernelGGL((k_hg_reduce_fx<2, true>), dim3(B, L), dim3(HG_FX_T), 0, st, stage, N, log2_T, g.log2B, w.bstart,
+            hipLaunchKernelGGL((k_hg_reduce_fx<2, true, 1>), dim3(B, L), dim3(HG_FX_T), 0, st, stage, N, log2_T, g.log2B, w.bstart,
                                (const uint2*)w.records, grad_table, n_run_levels, w.fx, a);
         } else
         hipLaunchKernelGGL((k_hg_reduce<2, true>), dim3(B, L), dim3(HG_RT), 0, st, stage, N, log2_T, g.log2B, w.bstart,
@@ -1181,4 +1197,53 @@ extern "C" int snf_hashgrid_bwd_sorted_ex(const float* u, const float* grad_out,
     const HgWs w = hg_ws_layout(workspace, N, L, g);  // the staged gradients use the tail of the same workspace
     return snf_hashgrid_bwd_presorted(grad_out, N, L, F, log2_T, ld_out, col_off, n_run_levels, grad_table, workspace, w.gT,
                                       stream);
+}
+
+// The fixed-point reduce with a caller-provided scratch area (>= SNF_HG_FX_SCRATCH_BYTES, private to this launch), for F = 2
+// and F = 8.  The sorted workspace stays read-only here, so heads that SHARE a sort (same positions, same level geometry)
+// can run their backward passes concurrently on different streams.  fuse_from_level = L: no level is stepped (plain
+// gradient accumulation into grad_table).
+extern "C" int snf_hashgrid_bwd_presorted_adam_fx(const float* grad_out, int N, int L, int F, int log2_T, int ld_out, int col_off,
+                                                  int n_run_levels, float* grad_table, const void* sorted_workspace,
+                                                  float* stage, int fuse_from_level, float* param, float* exp_avg,
+                                                  float* exp_avg_sq, float lr, float beta1, float beta2, float eps, int step,
+                                                  float grad_scale, void* scratch, snf_stream_t stream) {
+    const bool planar = ld_out == 0;
+    const bool adam_on = fuse_from_level < L;
+    SNF_REQUIRE(grad_out && grad_table && sorted_workspace && (stage || planar) && scratch &&
+                    (!adam_on || (param && exp_avg && exp_avg_sq)), "snf_hashgrid_bwd_presorted_adam_fx: null pointer");
+    SNF_REQUIRE(F == 2 || F == 8, "snf_hashgrid_bwd_presorted_adam_fx: features_per_level must be 2 or 8 (got %d)", F);
+    SNF_REQUIRE(N > 0 && L > 0 && L <= (int)HG_FX_SCRATCH && (N % 2) == 0 && N <= (1 << HG_SAMPLE_BITS) &&
+                    ((planar && col_off == 0) || ld_out >= col_off + L * F) && col_off >= 0,
+                "snf_hashgrid_bwd_presorted_adam_fx: bad shape N=%d L=%d ld_out=%d col_off=%d (N even, L <= 64)", N, L, ld_out, col_off);
+    SNF_REQUIRE(fuse_from_level >= 0 && fuse_from_level <= L && step >= 1,
+                "snf_hashgrid_bwd_presorted_adam_fx: bad fuse_from_level=%d (L=%d) or step=%d", fuse_from_level, L, step);
+    SNF_REQUIRE((((uintptr_t)grad_out | (uintptr_t)grad_table | (uintptr_t)stage | (uintptr_t)param | (uintptr_t)exp_avg |
+                  (uintptr_t)exp_avg_sq | (uintptr_t)scratch) & 15) == 0, "snf_hashgrid_bwd_presorted_adam_fx: unaligned pointer");
+    if (planar) stage = const_cast<float*>(grad_out);
+    const HgGeom g = hg_geometry(N, log2_T);
+    const HgWs w = hg_ws_layout(const_cast<void*>(sorted_workspace), N, L, g);
+    const int B = 1 << g.log2B;
+    hipStream_t st = (hipStream_t)stream;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    HgAdam a;
+    a.p = param; a.m = exp_avg; a.v = exp_avg_sq;
+    a.b1 = beta1; a.b2 = beta2; a.step_size = (float)((double)lr / bc1); a.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+    a.eps = eps; a.gs = grad_scale; a.from_level = fuse_from_level;
+    uint32_t* lvlmax = (uint32_t*)scratch;
+    const int tblocks = ceil_div((long long)N * L, 256);
+    hipMemsetAsync(lvlmax, 0, L * sizeof(uint32_t), st);
+    if (F == 2) {
+        if (!planar) hipLaunchKernelGGL(k_hg_stage_grad<2>, dim3(tblocks), dim3(256), 0, st, grad_out, N, L, ld_out, col_off, stage);
+        hipLaunchKernelGGL(k_hg_level_absmax<2>, dim3(hg_absmax_blocks(N, F), L), dim3(256), 0, st, stage, N, lvlmax);
+        hipLaunchKernelGGL((k_hg_reduce_fx<2, true, 1>), dim3(B, L), dim3(HG_FX_T), 0, st, stage, N, log2_T, g.log2B, w.bstart,
+                           (const uint2*)w.records, grad_table, n_run_levels, lvlmax, a);
+    } else {
+        if (!planar) hipLaunchKernelGGL(k_hg_stage_grad<8>, dim3(tblocks), dim3(256), 0, st, grad_out, N, L, ld_out, col_off, stage);
+        hipLaunchKernelGGL(k_hg_level_absmax<8>, dim3(hg_absmax_blocks(N, F), L), dim3(256), 0, st, stage, N, lvlmax);
+        hipLaunchKernelGGL((k_hg_reduce_fx<8, true, 2>), dim3(B * 2, L), dim3(HG_FX_T), 0, st, stage, N, log2_T, g.log2B,
+                           w.bstart, (const uint2*)w.records, grad_table, n_run_levels, lvlmax, a);
+    }
+    SNF_LAUNCH_CHECK("snf_hashgrid_bwd_presorted_adam_fx");
+    return SNF_OK;
 }

@@ -38,6 +38,10 @@ _KERNEL, _PY = 0, 1
 import os as _os
 
 PLANAR_HEADS = _os.environ.get("SNF_PLANAR_HEADS", "1") == "1"  # level-major hand-off between the feature grids and the head MLP
+# fixed-point reduce pass for the F = 8 feature tables as well: measured 12 % slower alone (1.10 vs 0.98 ms per step for the four
+# launches) and no faster inside the concurrent step (3.73-3.77 vs 3.66-3.76 ms, r02o) -- at ~1 record per row the float
+# reduce's in-bucket sort is cheap and its Adam stream already runs at 5 TB/s; off by default, kept for bit-reproducible runs
+FX_F8 = _os.environ.get("SNF_HG_FX8", "0") == "1"
 FEATURE_SORTS_ON_HEAD_STREAM = _os.environ.get("SNF_FEAT_SORT_SIDE", "1") == "1"
 
 
@@ -181,6 +185,20 @@ class StepProgram:
         p, gbuf, m, v, n_sparse, fused_range = self._table_adam(enc, group)
         nrun = ops.hashgrid_run_levels(enc.scalings) if F == 2 else 0
         fuse = with_opt and self.opt.fuse_table_adam and n_sparse < L
+        if F == 8 and FX_F8 and N % 2 == 0 and L <= 64:
+            # fixed-point reduce (order-independent sums, no in-bucket sort); scratch private to this launch: the sorted
+            # workspace is shared by the SAM and ClipSeg heads, whose backward passes run concurrently
+            oc = self.opt.config[group]["optimizer"]
+            scratch = self.buf(f"fx_scratch_{id(enc)}", (64,), torch.int32)
+            from_level = n_sparse if fuse else L
+            fused = ((L - from_level) << T) * F
+            self._k(st, "snf_hashgrid_bwd_presorted_adam_fx", g, N, L, F, T, ld, col, nrun, gbuf, sorted_ws, stage, from_level,
+                    p, m, v, 0.0, float(oc.betas[0]), float(oc.betas[1]), float(oc.eps), 1, 1.0, scratch,
+                    tag=f"F{F}L{L}", units=float(N) * 8 * F * 4 * (L + from_level) + 24.0 * fused,
+                    dyn={("lr", group): 15, ("t", group): 19})
+            if fuse:
+                done.append(fused_range)
+            return
         if fuse:
             oc = self.opt.config[group]["optimizer"]
             fused = ((L - n_sparse) << T) * F

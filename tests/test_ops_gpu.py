@@ -814,3 +814,55 @@ def test_hashgrid_backward_at_the_record_limit(N):
     m._launch("snf_hashgrid_bwd", m._p(u), m._p(G_), m._p(sc), N, L, F, T, L * F, 0, m._p(ref), m._stream())
     torch.cuda.synchronize()
     assert maxdiff(buf, ref) <= 2e-5 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("F,N,L,T,from_level", [(8, 70000, 12, 19, 0), (8, 70000, 12, 19, 8), (8, 4098, 3, 12, 3), (2, 300000, 16, 19, 5)])
+def test_fixed_point_table_backward(F, N, L, T, from_level):
+    """snf_hashgrid_bwd_presorted_adam_fx against the float reduce (snf_hashgrid_bwd_presorted_adam with SNF semantics):
+    gradients of the un-fused levels to 2e-6 of the largest entry, parameters / moments of the fused levels after the Adam
+    step to fp32 round-off; rows hit by a NaN gradient become NaN in both; two launches give bit-identical results."""
+    m = ops()
+    g = torch.Generator(device=DEV).manual_seed(F * 1000 + L)
+    u = torch.rand((N, 3), device=DEV, generator=g)
+    res = torch.floor(16.0 * (512.0 / 16.0) ** (torch.arange(L) / max(L - 1, 1))).to(DEV)
+    n = (L << T) * F
+    gy = torch.randn((L * N * F,), device=DEV, generator=g) * 1e-3   # level-major [L][N][F]
+    gy[5 * F] = float("nan")                                          # sample 5 of level 0 poisons the rows it touches
+    nbytes = int(m._L().snf_hashgrid_bwd_workspace_bytes(N, L, T))
+    ws = torch.empty(((nbytes + 3) // 4,), device=DEV, dtype=torch.int32)
+    st = m._stream()
+    m._launch("snf_hashgrid_sort", m._p(u), m._p(res), N, L, T, m._p(ws), nbytes, st)
+    nrun = m.hashgrid_run_levels(res) if F == 2 else 0
+
+    def run(fx: bool):
+        p0 = torch.randn((n,), device=DEV, generator=torch.Generator(device=DEV).manual_seed(3)) * 1e-2
+        p, gr = p0.clone(), torch.zeros(n, device=DEV)
+        mm, vv = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+        scratch = torch.zeros(64, device=DEV, dtype=torch.int32)
+        if fx:
+            m._launch("snf_hashgrid_bwd_presorted_adam_fx", m._p(gy), N, L, F, T, 0, 0, nrun, m._p(gr), m._p(ws), None, from_level,
+                      m._p(p), m._p(mm), m._p(vv), 5e-4, 0.9, 0.999, 1e-15, 1, 1.0, m._p(scratch), st)
+        elif from_level < L:
+            os_env = __import__("os").environ
+            m._launch("snf_hashgrid_bwd_presorted_adam", m._p(gy), N, L, F, T, 0, 0, nrun, m._p(gr), m._p(ws), None, from_level,
+                      m._p(p), m._p(mm), m._p(vv), 5e-4, 0.9, 0.999, 1e-15, 1, 1.0, st)
+            del os_env
+        else:
+            m._launch("snf_hashgrid_bwd_presorted", m._p(gy), N, L, F, T, 0, 0, nrun, m._p(gr), m._p(ws), None, st)
+        torch.cuda.synchronize()
+        return p, gr, mm, vv
+
+    a, b, c = run(True), run(True), run(False)
+    for x, y in zip(a, b):
+        assert torch.equal(torch.nan_to_num(x, nan=7.0), torch.nan_to_num(y, nan=7.0))  # order-independent sums
+    names = ("param", "grad", "exp_avg", "exp_avg_sq")
+    for name, x, y in zip(names, a, c):
+        assert torch.equal(torch.isnan(x), torch.isnan(y)), name
+        scale = float(torch.nan_to_num(y).abs().max())
+        tol = (2e-6 if name != "param" else 1e-6) * max(scale, 1e-30)
+        if name == "param":  # with eps = 1e-15 a row whose gradient is ~0 moves by +-lr on rounding noise: compare where it is not
+            sig = torch.nan_to_num(c[2]).abs() > 1e-3 * float(torch.nan_to_num(c[2]).abs().max())
+            assert maxdiff(torch.nan_to_num(x)[sig], torch.nan_to_num(y)[sig]) <= 5e-7
+        else:
+            assert maxdiff(torch.nan_to_num(x), torch.nan_to_num(y)) <= tol, name
+    assert bool(torch.isnan(a[1]).any() or torch.isnan(a[2]).any())  # the poisoned rows exist
