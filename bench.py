@@ -68,6 +68,8 @@ def algorithmic_model(key: str, w: dict):
     if name.startswith("snf_mlp64"):
         dims = [int(x) for x in tag.split("x")]
         macs = sum(a * b for a, b in zip(dims[:-1], dims[1:]))
+        if name == "snf_mlp64_bwd_fused":  # data-gradient chain + weight gradients
+            macs *= 2
         return "mfma", 2.0 * R * S * macs, "TFLOP/s"
     return None, None, None
 

@@ -213,6 +213,18 @@ int snf_mlp64_bwd_data(const float* dY, int lddy, int dy_col_off, const float* d
                        int out_act, int64_t N, const float* H1, const float* H2, float* dH1, float* dH2, float* dZ,
                        int lddz, float* dX, int lddx, snf_stream_t stream);
 
+/* The data-gradient chain AND the weight gradients of the same net in one pass: the wave that holds dH^T (and reads H for the
+ * ReLU mask anyway) forms dW = dA^T B itself on the bf16 matrix cores (3-term split, fp32 accumulate) through a per-wave LDS
+ * transpose, so dH1 / dH2 / dZ are never written and X / H1 / H2 are read once instead of twice (-1.2 GB of HBM traffic per
+ * train step for the two nerfacto nets).  dW0 [64, in_real], dW1 [64,64], dWout [out,64] are ACCUMULATED (plain adds by one
+ * reduce kernel over per-workgroup partials in `workspace`: snf_mlp64_bwd_fused_workspace_bytes(n_hidden) bytes).  X as in
+ * snf_mlp64_fwd (ldx = 0: level-major).  Replaces snf_mlp64_bwd_data + three snf_linear_bwd_weight calls. */
+int64_t snf_mlp64_bwd_fused_workspace_bytes(int n_hidden);
+int snf_mlp64_bwd_fused(const float* dY, int lddy, int dy_col_off, const float* dY0, const float* Y, int ldy, const float* X,
+                        int ldx, const float* W0, int in_real, const float* W1, const float* Wout, int n_hidden, int out,
+                        int out_act, int64_t N, const float* H1, const float* H2, float* dX, int lddx, float* dW0, float* dW1,
+                        float* dWout, void* workspace, int64_t workspace_bytes, snf_stream_t stream);
+
 /* ---- a13: SH degree-4 basis of the raw unit direction (nerfstudio/utils/math.py:27-73) written to
  *      the first 16 columns of the colour-MLP input, with the geo features copied behind it
  *      (torch.cat of fields/nerfacto_field.py:336-343).  dirs [R,3]; geo points at h[:,1] of the

@@ -99,6 +99,7 @@ SIGNATURES = {
     "snf_linear_bwd_weight_ws": [P, P, P, I, I, I, I, I, I, I, P, P, P, c_int64, P],
     "snf_mlp64_fwd": [P, I, P, I, P, P, I, I, I, c_int64, P, P, P, I, P],
     "snf_mlp64_bwd_data": [P, I, I, P, P, I, P, I, P, P, I, I, I, c_int64, P, P, P, P, P, I, P, I, P],
+    "snf_mlp64_bwd_fused": [P, I, I, P, P, I, P, I, P, I, P, P, I, I, I, c_int64, P, P, P, I, P, P, P, P, c_int64, P],
     "snf_head_input": [P, P, I, I, I, I, P, I, P],
     "snf_weights_fwd": [P, I, I, P, P, I, I, P, P, P],
     "snf_weights_bwd": [P, I, I, P, P, P, I, I, P, P],
@@ -166,6 +167,8 @@ def load(auto_build: bool = True) -> ctypes.CDLL:
     lib.snf_hashgrid_bwd_workspace_bytes.argtypes = [c_int, c_int, c_int]
     lib.snf_linear_fwd_workspace_bytes.restype = c_int64
     lib.snf_linear_fwd_workspace_bytes.argtypes = [c_int, c_int, c_int]
+    lib.snf_mlp64_bwd_fused_workspace_bytes.restype = c_int64
+    lib.snf_mlp64_bwd_fused_workspace_bytes.argtypes = [c_int]
     lib.snf_linear_bwd_weight_workspace_bytes.restype = c_int64
     lib.snf_linear_bwd_weight_workspace_bytes.argtypes = [c_int, c_int, c_int]
     for name, argtypes in SIGNATURES.items():

@@ -534,6 +534,309 @@ __global__ __launch_bounds__(256) void k_mlp_chain_bwd_b3(const float* __restric
     }
 }
 
+// ==================================================================================================================
+// Data-gradient chain WITH the weight gradients (snf_mlp64_bwd_fused).
+//
+// k_mlp_chain_bwd leaves dW to three tall-skinny GEMMs per net that re-read what it has just written: per step and for the
+// two nets 1.2 GB of hidden activations and their gradients go out to HBM and come back (rocprofv3 FETCH/WRITE_SIZE, r02f:
+// chain backward 1.3 GB, 64-wide weight-gradient launches 0.74 GB + part of the 2.3 GB of the bf16x3 kernel).  Here the
+// wave that holds dH^T (and has H in registers for the ReLU mask anyway) forms the products itself:
+//     dW[o][i] = sum_s dA[s][o] * B[s][i]      (dA in {dZ, dH2, dH1},  B in {H2 | H1, H1, X})
+// on v_mfma_f32_32x32x16_bf16 with the 3-term split (the arithmetic of k_gemm_wgrad_b3), contraction over the wave's 32
+// samples.  Both operands need the SAMPLE index along k, i.e. per lane 8 consecutive samples of one neuron, while the chain
+// keeps one sample per lane: each matrix takes one trip through a per-wave LDS buffer, written transposed T[neuron][sample]
+// (ds_write_b32, conflict-free) and read back as two ds_read_b128 per fragment (pitch 36 floats: 16 lanes hit 16 distinct
+// bank quads).  A wave's LDS traffic is ordered, so no barrier is needed; the A-side fragments are held in registers while
+// the B-side matrix reuses the buffer.  The running sums (8 accumulator tiles for the colour net) stay in registers over the
+// wave's whole tile loop; at the end the 8 waves of a workgroup fold them through LDS and the workgroup writes ONE partial
+// [Wout | W1 | W0] to the workspace; k_chain_wgrad_reduce adds the partials to the gradient arena (no float atomics).
+// 256 threads, one wave per SIMD (the 8 accumulator tiles on top of the chain's working set need the whole 512-entry register
+// file: at two waves per SIMD the compiler spills 170 registers per lane), one workgroup per CU; LDS: weights 33 KB + 4 x
+// (9 KB staging + 4.5 KB dZ^T).
+constexpr int WG_TP = 36;            // floats per transposed row: 32 samples + 4 pad
+constexpr int WG_T = 256;
+constexpr int WG_WAVES = WG_T / 64;
+constexpr int WG_STAGE = 64 * WG_TP;  // one staged 64-neuron matrix
+constexpr int WG_DZ = 32 * WG_TP;     // the (zero-padded) output-gradient matrix
+
+__device__ __forceinline__ void wg_frag(const float* __restrict__ T, int row, int ks, int half, mc_bf16x8& hi, mc_bf16x8& lo) {
+    const float4 v0 = *reinterpret_cast<const float4*>(&T[row * WG_TP + 16 * ks + 8 * half]);
+    const float4 v1 = *reinterpret_cast<const float4*>(&T[row * WG_TP + 16 * ks + 8 * half + 4]);
+    uint32_t h[4], l[4];
+    mc_split2(v0.x, v0.y, h[0], l[0]);
+    mc_split2(v0.z, v0.w, h[1], l[1]);
+    mc_split2(v1.x, v1.y, h[2], l[2]);
+    mc_split2(v1.z, v1.w, h[3], l[3]);
+    hi = __builtin_bit_cast(mc_bf16x8, make_uint4(h[0], h[1], h[2], h[3]));
+    lo = __builtin_bit_cast(mc_bf16x8, make_uint4(l[0], l[1], l[2], l[3]));
+}
+
+// a 64-wide accumulator-layout tile pair (lane = sample, registers = neurons) -> T[neuron][sample]
+__device__ __forceinline__ void wg_put64(float* __restrict__ T, const f32x16 (&a)[2], int li, int half) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) T[(t * 32 + krow(r, half)) * WG_TP + li] = a[t][r];
+}
+
+__device__ __forceinline__ f32x16 wg_mma3(const mc_bf16x8& ah, const mc_bf16x8& al, const mc_bf16x8& bh, const mc_bf16x8& bl,
+                                          f32x16 acc) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+}
+
+#define WG_LDS_ORDER() asm volatile("" ::: "memory")  // compiler fence between the staging and the fragment reads of a wave
+
+// partial layout per workgroup (floats): Wout [32][64] | W1 [64][64] (NH == 2) | W0 [64][32]
+constexpr int wg_partial_floats(int NH) { return 32 * 64 + (NH == 2 ? 64 * 64 : 0) + 64 * 32; }
+
+template <int NH>
+__global__ __launch_bounds__(WG_T) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_mlp_chain_bwd_wg(const float* __restrict__ dY, int lddy, int dy_col_off,
+                                                           const float* __restrict__ dY0, const float* __restrict__ Yout,
+                                                           int ldy, const float* __restrict__ X, int ldx,
+                                                           const float* __restrict__ W0, int in_real,
+                                                           const float* __restrict__ W1, const float* __restrict__ Wout,
+                                                           int out, int out_act, long long N, const float* __restrict__ H1,
+                                                           const float* __restrict__ H2, float* __restrict__ dX, int lddx,
+                                                           float* __restrict__ P) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    ChainWeights cw;
+    load_chain_weights<NH>(lds, cw, W0, in_real, W1, Wout, out);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 31, half = lane >> 5;
+    float* __restrict__ stage_all = lds + chain_lds_floats(NH);           // [WG_WAVES][WG_STAGE]
+    float* __restrict__ T = stage_all + wave * WG_STAGE;
+    float* __restrict__ Z = stage_all + WG_WAVES * WG_STAGE + wave * WG_DZ;  // dZ^T, rows >= out stay zero
+    for (int i = lane; i < WG_DZ; i += 64) Z[i] = 0.f;
+    const int outp = (out + 1) & ~1;
+    const int hsteps = outp >> 1;
+    constexpr int NT = NH == 2 ? 8 : 4;
+    f32x16 acc[NT];  // NH == 2: [0,1] Wout (k tiles), [2..5] W1 (u*2 + t), [6,7] W0 (u) ; NH == 1: [0,1] Wout, [2,3] W0
+#pragma unroll
+    for (int i = 0; i < NT; ++i) acc[i] = zero16();
+    const long long ntiles = (N + 31) / 32;
+    for (long long tile = (long long)blockIdx.x * WG_WAVES + wave; tile < ntiles; tile += (long long)gridDim.x * WG_WAVES) {
+        const long long s = tile * 32 + li;
+        const bool ok = s < N;
+        const long long sc = ok ? s : N - 1;
+        // ---- dZ, dLast^T[k][s] = sum_o Wout[o][k] dZ^T[o][s]; dZ^T goes to its LDS matrix on the way
+        f32x16 dl[2] = {zero16(), zero16()};
+        for (int st = 0; st < hsteps; ++st) {
+            const int o = half * hsteps + st;
+            float dz = 0.f;
+            if (o < out && ok) {  // rows beyond N contribute nothing to the weight gradients
+                dz = (o == 0 && dY0 != nullptr) ? dY0[sc] : dY[sc * lddy + dy_col_off + o];
+                if (out_act == SNF_ACT_SIGMOID) {
+                    const float yv = Yout[sc * ldy + o];
+                    dz *= yv * (1.f - yv);
+                }
+            }
+            if (o < 32) Z[o * WG_TP + li] = dz;
+            const int oc = o < 32 ? o : 31;
+            dl[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(cw.wo[oc * MC_P1 + li], dz, dl[0], 0, 0, 0);
+            dl[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(cw.wo[oc * MC_P1 + 32 + li], dz, dl[1], 0, 0, 0);
+        }
+        WG_LDS_ORDER();
+        mc_bf16x8 zh[2], zl[2];  // A side of dWout: dZ^T rows 0..31, k-steps 0, 1
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) wg_frag(Z, li, ks, half, zh[ks], zl[ks]);
+        f32x16 hh[2];
+        // ---- last hidden layer: its activations are the B side of dWout and the ReLU mask of dLast
+        load_h64(NH == 2 ? H2 : H1, sc, hh, half);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dl[t][r] = hh[t][r] > 0.f ? dl[t][r] : 0.f;
+        wg_put64(T, hh, li, half);  // (the activations are dead after this: registers free for the products below)
+        WG_LDS_ORDER();
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                mc_bf16x8 bh, bl;
+                wg_frag(T, 32 * t + li, ks, half, bh, bl);
+                acc[t] = wg_mma3(zh[ks], zl[ks], bh, bl, acc[t]);
+            }
+        if constexpr (NH == 2) {
+            // dH1^T[k1][s] = sum_k2 W1[k2][k1] dH2^T[k2][s]
+            f32x16 d1[2] = {zero16(), zero16()};
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int k2 = u * 32 + krow(r, half);
+                    const float b = dl[u][r];
+                    d1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(cw.w1[k2 * MC_P1 + li], b, d1[0], 0, 0, 0);
+                    d1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(cw.w1[k2 * MC_P1 + 32 + li], b, d1[1], 0, 0, 0);
+                }
+            // dW1 = dH2^T (A side, staged now) x H1 (B side, staged after the A fragments are in registers)
+            WG_LDS_ORDER();
+            wg_put64(T, dl, li, half);
+            WG_LDS_ORDER();
+            mc_bf16x8 ah[2][2], al[2][2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) wg_frag(T, 32 * u + li, ks, half, ah[u][ks], al[u][ks]);
+            load_h64(H1, sc, hh, half);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dl[t][r] = hh[t][r] > 0.f ? d1[t][r] : 0.f;  // dl is dH1^T from here on
+            WG_LDS_ORDER();
+            wg_put64(T, hh, li, half);
+            WG_LDS_ORDER();
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    mc_bf16x8 bh, bl;
+                    wg_frag(T, 32 * t + li, ks, half, bh, bl);
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) acc[2 + u * 2 + t] = wg_mma3(ah[u][ks], al[u][ks], bh, bl, acc[2 + u * 2 + t]);
+                }
+        }
+        // ---- dl is dH1^T now.  dX^T[i][s] = sum_k1 W0[k1][i] dH1^T[k1][s]
+        if (dX != nullptr) {
+            f32x16 dx = zero16();
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    dx = __builtin_amdgcn_mfma_f32_32x32x2f32(cw.w0[(t * 32 + krow(r, half)) * MC_P0 + li], dl[t][r], dx, 0,
+                                                              0, 0);
+            if (ok) {
+                if (lddx == 0) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const long long lv = 4 * q + 2 * half;
+                        *reinterpret_cast<float2*>(dX + (lv * N + s) * 2) = make_float2(dx[4 * q], dx[4 * q + 1]);
+                        *reinterpret_cast<float2*>(dX + ((lv + 1) * N + s) * 2) = make_float2(dx[4 * q + 2], dx[4 * q + 3]);
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        *reinterpret_cast<float4*>(dX + s * lddx + 8 * q + 4 * half) =
+                            make_float4(dx[4 * q], dx[4 * q + 1], dx[4 * q + 2], dx[4 * q + 3]);
+                }
+            }
+        }
+        // ---- dW0 = dH1^T (A side) x X (B side: this lane's half of the input row, features half*16 .. +15)
+        WG_LDS_ORDER();
+        wg_put64(T, dl, li, half);
+        WG_LDS_ORDER();
+        mc_bf16x8 a0h[2][2], a0l[2][2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) wg_frag(T, 32 * u + li, ks, half, a0h[u][ks], a0l[u][ks]);
+        float x[16];
+        if (ldx == 0) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float2 v = *reinterpret_cast<const float2*>(X + ((long long)(half * 8 + q) * N + sc) * 2);
+                x[2 * q] = v.x; x[2 * q + 1] = v.y;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 v = *reinterpret_cast<const float4*>(X + sc * ldx + half * 16 + 4 * q);
+                x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
+            }
+        }
+        WG_LDS_ORDER();
+#pragma unroll
+        for (int i = 0; i < 16; ++i) T[(half * 16 + i) * WG_TP + li] = (half * 16 + i < in_real) ? x[i] : 0.f;
+        WG_LDS_ORDER();
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            mc_bf16x8 bh, bl;
+            wg_frag(T, li, ks, half, bh, bl);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) acc[NT - 2 + u] = wg_mma3(a0h[u][ks], a0l[u][ks], bh, bl, acc[NT - 2 + u]);
+        }
+        WG_LDS_ORDER();
+    }
+    // ---- fold the 8 waves' sums through LDS (two tiles per round: 7 x 8 KB in the staging area), wave 0 collects
+    __syncthreads();
+    float* __restrict__ R = stage_all;  // [wave - 1][2][16][64]
+#pragma unroll
+    for (int q = 0; q < NT / 2; ++q) {
+        if (wave > 0) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) R[((wave - 1) * 2 + j) * 1024 + r * 64 + lane] = acc[2 * q + j][r];
+        }
+        __syncthreads();
+        if (wave == 0) {
+            for (int w2 = 0; w2 < WG_WAVES - 1; ++w2)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[2 * q + j][r] += R[(w2 * 2 + j) * 1024 + r * 64 + lane];
+        }
+        __syncthreads();
+    }
+    if (wave == 0) {
+        // accumulator tile (m-tile u, n-tile t): element (row = 32u + krow(r, half), col = 32t + li)
+        float* __restrict__ Pw = P + (size_t)blockIdx.x * wg_partial_floats(NH);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Pw[krow(r, half) * 64 + 32 * t + li] = acc[t][r];  // Wout [32][64]
+        float* __restrict__ P1 = Pw + 32 * 64;
+        if constexpr (NH == 2) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) P1[(32 * u + krow(r, half)) * 64 + 32 * t + li] = acc[2 + u * 2 + t][r];
+            P1 += 64 * 64;
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) P1[(32 * u + krow(r, half)) * 32 + li] = acc[NT - 2 + u][r];  // W0 [64][32]
+    }
+}
+
+// dWout[o][k] (o < out), dW1[k2][k1], dW0[k1][i] (i < in_real) += sum over the workgroup partials
+__global__ __launch_bounds__(256) void k_chain_wgrad_reduce(const float* __restrict__ P, int nwg, int NH, int out, int in_real,
+                                                            float* __restrict__ dWout, float* __restrict__ dW1,
+                                                            float* __restrict__ dW0) {
+    const int per = 32 * 64 + (NH == 2 ? 64 * 64 : 0) + 64 * 32;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= per) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int w = 0;
+    for (; w + 4 <= nwg; w += 4) {
+        s0 += P[(size_t)w * per + e];
+        s1 += P[(size_t)(w + 1) * per + e];
+        s2 += P[(size_t)(w + 2) * per + e];
+        s3 += P[(size_t)(w + 3) * per + e];
+    }
+    for (; w < nwg; ++w) s0 += P[(size_t)w * per + e];
+    const float sum = (s0 + s1) + (s2 + s3);
+    if (e < 32 * 64) {
+        const int o = e / 64, k = e % 64;
+        if (o < out) dWout[o * 64 + k] += sum;
+        return;
+    }
+    int r = e - 32 * 64;
+    if (NH == 2) {
+        if (r < 64 * 64) {
+            dW1[r] += sum;
+            return;
+        }
+        r -= 64 * 64;
+    }
+    const int k1 = r / 32, i = r % 32;
+    if (i < in_real) dW0[k1 * in_real + i] += sum;
+}
+
 // opt-in (snf_set_gemm_mode(2)): measured on the train step's two nets against the fp32 chains -- colour net forward
 // 0.131 -> 0.087 ms, base net forward 0.104 -> 0.090, colour net backward 0.189 -> 0.168, base net backward 0.130 -> 0.161
 // (its chain starts from <= 16 output gradients padded to a 32-wide k-step), step time -1 %: with the matrix work cut 5x the
@@ -616,5 +919,58 @@ extern "C" int snf_mlp64_bwd_data(const float* dY, int lddy, int dy_col_off, con
                            (hipStream_t)stream, dY, lddy, dy_col_off, dY0, Y, ldy, W0, in_real, W1, Wout, out, out_act,
                            (long long)N, H1, H2, dH1, dH2, dZ, lddz, dX, lddx);
     SNF_LAUNCH_CHECK("snf_mlp64_bwd_data");
+    return SNF_OK;
+}
+
+// ---- data-gradient chain + weight gradients in one pass (k_mlp_chain_bwd_wg) -------------------------------------------------
+extern "C" int64_t snf_mlp64_bwd_fused_workspace_bytes(int n_hidden) {
+    if (n_hidden != 1 && n_hidden != 2) return 0;
+    return (int64_t)256 * wg_partial_floats(n_hidden) * (int64_t)sizeof(float);
+}
+
+extern "C" int snf_mlp64_bwd_fused(const float* dY, int lddy, int dy_col_off, const float* dY0, const float* Y, int ldy,
+                                   const float* X, int ldx, const float* W0, int in_real, const float* W1, const float* Wout,
+                                   int n_hidden, int out, int out_act, int64_t N, const float* H1, const float* H2, float* dX,
+                                   int lddx, float* dW0, float* dW1, float* dWout, void* workspace, int64_t workspace_bytes,
+                                   snf_stream_t stream) {
+    int rc = chain_common_checks("snf_mlp64_bwd_fused", in_real, n_hidden, out, N);
+    if (rc) return rc;
+    SNF_REQUIRE(dY && X && W0 && Wout && H1 && dW0 && dWout && workspace && (n_hidden == 1 || (W1 && H2 && dW1)),
+                "snf_mlp64_bwd_fused: null pointer");
+    SNF_REQUIRE(out_act != SNF_ACT_SIGMOID || Y, "snf_mlp64_bwd_fused: Y required for the sigmoid derivative");
+    SNF_REQUIRE(out_act != SNF_ACT_RELU, "snf_mlp64_bwd_fused: ReLU output activation is not supported");
+    SNF_REQUIRE((ldx == 0 || (ldx >= MC_IN && ldx % 4 == 0)) && ((uintptr_t)X % 16) == 0,
+                "snf_mlp64_bwd_fused: X must be [N, ldx>=32] (ldx %% 4 == 0) or level-major (ldx = 0), 16-byte aligned");
+    SNF_REQUIRE(!dX || ((lddx == 0 || (lddx >= MC_IN && lddx % 4 == 0)) && ((uintptr_t)dX % 16) == 0),
+                "snf_mlp64_bwd_fused: bad dX layout");
+    SNF_REQUIRE(((uintptr_t)H1 % 16) == 0 && (!H2 || ((uintptr_t)H2 % 16) == 0) && ((uintptr_t)workspace % 16) == 0,
+                "snf_mlp64_bwd_fused: unaligned H1 / H2 / workspace");
+    SNF_REQUIRE(workspace_bytes >= snf_mlp64_bwd_fused_workspace_bytes(n_hidden), "snf_mlp64_bwd_fused: workspace too small");
+    const long long ntiles = (N + 31) / 32;
+    long long blocks = (ntiles + WG_WAVES - 1) / WG_WAVES;
+    if (blocks > 256) blocks = 256;  // persistent: one workgroup per CU (LDS)
+    float* P = (float*)workspace;
+    const size_t lds = (size_t)(chain_lds_floats(n_hidden) + WG_WAVES * (WG_STAGE + WG_DZ)) * sizeof(float);
+    hipStream_t st = (hipStream_t)stream;
+    if (n_hidden == 2) {
+        static bool attr2 = false;
+        if (!attr2) {
+            hipFuncSetAttribute((const void*)k_mlp_chain_bwd_wg<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr2 = true;
+        }
+        hipLaunchKernelGGL(k_mlp_chain_bwd_wg<2>, dim3((unsigned)blocks), dim3(WG_T), lds, st, dY, lddy, dy_col_off, dY0, Y, ldy, X,
+                           ldx, W0, in_real, W1, Wout, out, out_act, (long long)N, H1, H2, dX, lddx, P);
+    } else {
+        static bool attr1 = false;
+        if (!attr1) {
+            hipFuncSetAttribute((const void*)k_mlp_chain_bwd_wg<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr1 = true;
+        }
+        hipLaunchKernelGGL(k_mlp_chain_bwd_wg<1>, dim3((unsigned)blocks), dim3(WG_T), lds, st, dY, lddy, dy_col_off, dY0, Y, ldy, X,
+                           ldx, W0, in_real, W1, Wout, out, out_act, (long long)N, H1, H2, dX, lddx, P);
+    }
+    hipLaunchKernelGGL(k_chain_wgrad_reduce, dim3(ceil_div(wg_partial_floats(n_hidden), 256)), dim3(256), 0, st, P, (int)blocks,
+                       n_hidden, out, in_real, dWout, dW1, dW0);
+    SNF_LAUNCH_CHECK("snf_mlp64_bwd_fused");
     return SNF_OK;
 }

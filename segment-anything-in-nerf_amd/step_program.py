@@ -42,6 +42,7 @@ PLANAR_HEADS = _os.environ.get("SNF_PLANAR_HEADS", "1") == "1"  # level-major ha
 # launches) and no faster inside the concurrent step (3.73-3.77 vs 3.66-3.76 ms, r02o) -- at ~1 record per row the float
 # reduce's in-bucket sort is cheap and its Adam stream already runs at 5 TB/s; off by default, kept for bit-reproducible runs
 FX_F8 = _os.environ.get("SNF_HG_FX8", "0") == "1"
+FUSED_CHAIN_WGRAD = _os.environ.get("SNF_FUSED_CHAIN_WGRAD", "1") == "1"  # weight gradients of the 64-wide nets inside the chain
 FEATURE_SORTS_ON_HEAD_STREAM = _os.environ.get("SNF_FEAT_SORT_SIDE", "1") == "1"
 
 
@@ -231,11 +232,19 @@ class StepProgram:
         """ops._mlp64_bwd_launch: data-gradient chain + the three (two) weight-gradient GEMMs into the gradient arena."""
         nh = len(ws) - 1
         out = ws[-1].shape[0]
+        tag = f"{in_real}x{'x'.join(['64'] * nh)}x{out}"
+        if FUSED_CHAIN_WGRAD and int(self.lib.snf_get_gemm_mode()) >= 1:
+            # the chain forms its own weight gradients (bf16x3, per-wave LDS transposes): dH1 / dH2 / dZ are never written
+            nb = int(self.lib.snf_mlp64_bwd_fused_workspace_bytes(nh))
+            wsb = self.buf(pre + "wgrad_ws", (nb // 4,))
+            self._k(st, "snf_mlp64_bwd_fused", dy, lddy, dy_off, dy0, y, out, x, ldx, ws[0], in_real, ws[1] if nh == 2 else None,
+                    ws[-1], nh, out, out_act, N, h1, h2, dx, lddx, ws[0].main_grad, ws[1].main_grad if nh == 2 else None,
+                    ws[-1].main_grad, wsb, nb, tag=tag)
+            return
         ldz = (out + 3) // 4 * 4
         dh1 = self.buf(pre + "dh1", (N, 64))
         dh2 = self.buf(pre + "dh2", (N, 64)) if nh == 2 else None
         dz = self.buf(pre + "dz", (N, ldz))
-        tag = f"{in_real}x{'x'.join(['64'] * nh)}x{out}"
         self._k(st, "snf_mlp64_bwd_data", dy, lddy, dy_off, dy0, y, out, ws[0], in_real, ws[1] if nh == 2 else None, ws[-1],
                 nh, out, out_act, N, h1, h2, dh1, dh2, dz, ldz, dx, lddx, tag=tag)
         pairs = [(dh1, 64, x, ldx, in_real, ws[0])]

@@ -866,3 +866,66 @@ def test_fixed_point_table_backward(F, N, L, T, from_level):
         else:
             assert maxdiff(torch.nan_to_num(x), torch.nan_to_num(y)) <= tol, name
     assert bool(torch.isnan(a[1]).any() or torch.isnan(a[2]).any())  # the poisoned rows exist
+
+
+@pytest.mark.parametrize("cfg", [(31, 2, 3, "sigmoid", 32, False), (32, 1, 16, None, 0, True), (32, 2, 32, None, 40, False)])
+@pytest.mark.parametrize("N", [33, 5000, 70001])
+def test_mlp64_backward_with_fused_weight_gradients(cfg, N):
+    """snf_mlp64_bwd_fused = snf_mlp64_bwd_data + the net's three (two) weight-gradient GEMMs in one pass: dX bit for bit
+    (same chain), weight gradients to the bf16x3 round-off against an fp64 reference and against the separate launches."""
+    in_real, nh, out, act, ldx, planar = cfg
+    m = ops()
+    m.set_gemm_mode("bf16x3")
+    g = torch.Generator(device=DEV).manual_seed(N + in_real)
+    x = torch.randn((N, 32), device=DEV, generator=g)
+    x[:, in_real:] = 7.0  # pad columns must be ignored
+    ws = [torch.randn((64, in_real), device=DEV, generator=g) / in_real ** 0.5]
+    if nh == 2:
+        ws.append(torch.randn((64, 64), device=DEV, generator=g) / 8.0)
+    ws.append(torch.randn((out, 64), device=DEV, generator=g) / 8.0)
+    out_act = m.ACT_BY_NAME[act]
+    xin = x
+    if planar:  # level-major [16][N][2]
+        xin = x.view(N, 16, 2).permute(1, 0, 2).contiguous().view(-1)
+    elif ldx > 32:
+        xin = torch.cat([x, torch.full((N, ldx - 32), 3.0, device=DEV)], 1).contiguous()
+    with torch.no_grad():
+        y, h1, h2 = m._mlp64_fwd_launch(xin, in_real, ws, out_act, True, N if planar else 0)
+    dy = torch.randn((N, out), device=DEV, generator=g)
+    st = m._stream()
+    # separate launches (reference): data gradient + weight gradients into zeroed buffers
+    for w in ws:
+        w.requires_grad_(True)
+        w.main_grad = torch.zeros_like(w)
+    dx_ref, _ = m._mlp64_bwd_launch(xin, in_real, ws, out_act, y, h1, h2, dy, out, 0, None, True, N if planar else 0)
+    ref = [w.main_grad.clone() for w in ws]
+    # fused
+    gw = [torch.full_like(w, 0.5) for w in ws]  # accumulates into running buffers
+    nb = int(m._L().snf_mlp64_bwd_fused_workspace_bytes(nh))
+    wsb = torch.empty((nb // 4,), device=DEV)
+    dx = torch.empty_like(dx_ref)
+    m._launch("snf_mlp64_bwd_fused", m._p(dy), out, 0, None, m._p(y), out, m._p(xin), 0 if planar else xin.shape[1], m._p(ws[0]),
+              in_real, m._p(ws[1]) if nh == 2 else None, m._p(ws[-1]), nh, out, out_act, N, m._p(h1), m._p(h2) if nh == 2 else None,
+              m._p(dx), 0 if planar else 32, m._p(gw[0]), m._p(gw[1]) if nh == 2 else None, m._p(gw[-1]), m._p(wsb), nb, st)
+    torch.cuda.synchronize()
+    assert torch.equal(dx, dx_ref)
+    # fp64 reference of the weight gradients
+    xd = x[:, :in_real].double()
+    acts, a = [xd], xd
+    wd = [w.detach().double() for w in ws]
+    for i, w in enumerate(wd[:-1]):
+        a = torch.relu(a @ w.T)
+        acts.append(a)
+    z = a @ wd[-1].T
+    yy = torch.sigmoid(z) if act == "sigmoid" else z
+    dz = dy.double() * (yy * (1 - yy) if act == "sigmoid" else 1.0)
+    grads = [None] * len(wd)
+    gcur = dz
+    for i in range(len(wd) - 1, -1, -1):
+        grads[i] = gcur.T @ acts[i]
+        if i > 0:
+            gcur = (gcur @ wd[i]) * (acts[i] > 0)
+    for i, (got, r64, r32) in enumerate(zip(gw, grads, ref)):
+        scale = float(r64.abs().max())
+        assert maxdiff(got - 0.5, r64.float()) <= 3e-5 * scale, i
+        assert maxdiff(got - 0.5, r32) <= 3e-5 * scale, i

@@ -58,8 +58,11 @@ def test_one_step_gives_the_eager_gradients(method):
         assert abs(l_new[0][k] - v) <= 1e-5 * max(1.0, abs(v)), (k, l_new[0][k], v)
     for g, a in ref.optimizers.arenas.items():
         b = new.optimizers.arenas[g]
-        assert _rel_to_max(b.exp_avg, a.exp_avg) <= 2e-6, g
-        assert _rel_to_max(b.exp_avg_sq, a.exp_avg_sq) <= 4e-6, g
+        # (the schedule forms the 64-wide nets' weight gradients inside the chain kernel on the bf16 3-term split, the eager
+        # path on the exact-fp32 matrix cores: 1e-5 of the largest entry; everything else is the same kernel on both sides)
+        tol = 3e-5 if g == "fields" else 2e-6
+        assert _rel_to_max(b.exp_avg, a.exp_avg) <= tol, g
+        assert _rel_to_max(b.exp_avg_sq, a.exp_avg_sq) <= 2 * tol, g
         assert float(b.grad.abs().max()) == 0.0, g  # re-zeroed by the fused Adam passes
         assert new.optimizers.step_count[g] == ref.optimizers.step_count[g] == 1
 
@@ -125,4 +128,4 @@ def test_bench_workload_full_size_one_step():
     assert trs[1]._program is not None, trs[1]._program_off
     for g, a in trs[0].optimizers.arenas.items():
         b = trs[1].optimizers.arenas[g]
-        assert _rel_to_max(b.exp_avg, a.exp_avg) <= 2e-6, g
+        assert _rel_to_max(b.exp_avg, a.exp_avg) <= (3e-5 if g == "fields" else 2e-6), g
