@@ -344,6 +344,16 @@ def render_depth_acc(weights, ebins, want_acc: bool = True):
     return depth, acc
 
 
+@torch.no_grad()
+def accumulation(weights) -> torch.Tensor:
+    """AccumulationRenderer: sum_s w [R,1] from the compositing kernel (no colours, no depth)."""
+    weights = _chk(weights, "weights")
+    R, S = weights.shape
+    acc = torch.empty((R, 1), device=weights.device, dtype=torch.float32)
+    _launch("snf_composite_fwd", _p(None), _p(weights), _p(None), R, S, 1, _p(None), _p(acc), _p(None), _stream())
+    return acc
+
+
 # ---------------------------------------------------------------------------------------------
 # hash grid
 # ---------------------------------------------------------------------------------------------

@@ -22,9 +22,16 @@ class RGBRenderer(nn.Module):
 
 
 class AccumulationRenderer(nn.Module):
+    """renderers.py:200-223: sum of the weights along a ray.  On the device it is the accumulation output of the compositing
+    kernel (snf_composite_fwd); nothing on this path differentiates through it (it feeds the viewer / metrics only), so the
+    kernel result is returned detached -- a caller that does need d(accumulation)/d(weights) gets torch.sum."""
+
     @classmethod
-    def forward(cls, weights: torch.Tensor, ray_indices=None, num_rays=None) -> torch.Tensor:
-        return torch.sum(weights, dim=-2)
+    def forward(cls, weights: torch.Tensor, ray_indices=None, num_rays=None, differentiable: bool = False) -> torch.Tensor:
+        if differentiable or not weights.is_cuda:
+            return torch.sum(weights, dim=-2)
+        w = weights[..., 0] if weights.dim() == 3 else weights
+        return ops.accumulation(w.detach())
 
 
 class DepthRenderer(nn.Module):

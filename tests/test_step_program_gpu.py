@@ -129,3 +129,44 @@ def test_bench_workload_full_size_one_step():
     for g, a in trs[0].optimizers.arenas.items():
         b = trs[1].optimizers.arenas[g]
         assert _rel_to_max(b.exp_avg, a.exp_avg) <= (3e-5 if g == "fields" else 2e-6), g
+
+
+def test_checkpoint_round_trip_continues_the_same_trajectory(tmp_path):
+    """Trainer.save_checkpoint / load_checkpoint (trainer.py:379-406 contract: step, pipeline state_dict, optimizer state):
+    a run resumed from the file takes exactly the steps the uninterrupted run takes (same fixed batch and jitter)."""
+    import copy
+
+    def fixed(tr):
+        dm = tr.pipeline.datamanager
+        batch = dm.next_train(0)
+        dm.next_train = lambda step: (copy.copy(batch[0]), batch[1])
+        g = torch.Generator(device="cuda").manual_seed(5)
+        ps = tr.pipeline.model.proposal_sampler
+        ps.initial_sampler.jitter_override = torch.rand((256, 1), device="cuda", generator=g)
+        ps.pdf_sampler.jitter_override = torch.rand((256, 1), device="cuda", generator=g)
+
+    a = _trainer("samnerf_distill", True, 256, 12)
+    fixed(a)
+    for step in range(3):
+        a.train_iteration(step)
+    path = str(tmp_path / "step-000000002.ckpt")
+    a.save_checkpoint(path, 2)
+    for step in range(3, 5):
+        a.train_iteration(step)
+    a.synchronize()
+    torch.cuda.synchronize()
+    b = _trainer("samnerf_distill", True, 256, 12, seed=99)  # different initial parameters: everything must come from the file
+    fixed(b)
+    assert b.load_checkpoint(path) == 3
+    ps_a, ps_b = a.pipeline.model.proposal_sampler, b.pipeline.model.proposal_sampler
+    ps_b._step, ps_b._steps_since_update = 2, 0  # (the reference does not checkpoint the sampler's counters either)
+    for step in range(3, 5):
+        b.train_iteration(step)
+    b.synchronize()
+    torch.cuda.synchronize()
+    assert dict(a.optimizers.step_count) == dict(b.optimizers.step_count)
+    for g, arena in a.optimizers.arenas.items():
+        other = b.optimizers.arenas[g]
+        assert _rel_to_max(other.param, arena.param) <= 1e-5, g
+        assert _rel_to_max(other.exp_avg, arena.exp_avg) <= 1e-4, g
+    del ps_a
