@@ -136,17 +136,18 @@ def test_checkpoint_round_trip_continues_the_same_trajectory(tmp_path):
     a run resumed from the file takes exactly the steps the uninterrupted run takes (same fixed batch and jitter)."""
     import copy
 
-    def fixed(tr):
+    def fixed(tr, batch=None):
         dm = tr.pipeline.datamanager
-        batch = dm.next_train(0)
+        batch = batch or dm.next_train(0)
         dm.next_train = lambda step: (copy.copy(batch[0]), batch[1])
         g = torch.Generator(device="cuda").manual_seed(5)
         ps = tr.pipeline.model.proposal_sampler
         ps.initial_sampler.jitter_override = torch.rand((256, 1), device="cuda", generator=g)
         ps.pdf_sampler.jitter_override = torch.rand((256, 1), device="cuda", generator=g)
+        return batch
 
     a = _trainer("samnerf_distill", True, 256, 12)
-    fixed(a)
+    batch = fixed(a)
     for step in range(3):
         a.train_iteration(step)
     path = str(tmp_path / "step-000000002.ckpt")
@@ -156,7 +157,7 @@ def test_checkpoint_round_trip_continues_the_same_trajectory(tmp_path):
     a.synchronize()
     torch.cuda.synchronize()
     b = _trainer("samnerf_distill", True, 256, 12, seed=99)  # different initial parameters: everything must come from the file
-    fixed(b)
+    fixed(b, batch)
     assert b.load_checkpoint(path) == 3
     ps_a, ps_b = a.pipeline.model.proposal_sampler, b.pipeline.model.proposal_sampler
     ps_b._step, ps_b._steps_since_update = 2, 0  # (the reference does not checkpoint the sampler's counters either)
