@@ -43,6 +43,8 @@ PLANAR_HEADS = _os.environ.get("SNF_PLANAR_HEADS", "1") == "1"  # level-major ha
 # reduce's in-bucket sort is cheap and its Adam stream already runs at 5 TB/s; off by default, kept for bit-reproducible runs
 FX_F8 = _os.environ.get("SNF_HG_FX8", "0") == "1"
 FUSED_CHAIN_WGRAD = _os.environ.get("SNF_FUSED_CHAIN_WGRAD", "1") == "1"  # weight gradients of the 64-wide nets inside the chain
+_pbs = _os.environ.get("SNF_PROP_BWD_SIDE")
+PROP_BWD_SIDE = None if _pbs is None else (_pbs == "1")  # None: on the side stream only when there are no feature heads
 FEATURE_SORTS_ON_HEAD_STREAM = _os.environ.get("SNF_FEAT_SORT_SIDE", "1") == "1"
 
 
@@ -396,6 +398,7 @@ class StepProgram:
         summary = b("loss_summary", (8,))
         self._k(main, "snf_nerf_loss_summary", mse_out, rows_i, float(cfg.interlevel_loss_mult) / float(R * S), rows_d,
                 1.0 / float(R), float(cfg.distortion_loss_mult), R, summary)
+        self._losses_mark = len(plan.entries)  # the proposal backward's inputs exist from here on
 
         # ================= feature heads: one task per head on its own stream =================
         for hname in self.heads:
@@ -425,22 +428,43 @@ class StepProgram:
         done_f: list = []
         self._grid_bwd(main, denc1, N1, fenc, "fields", 0, 0, ws_f, None, with_opt, done_f)
         done_p: list = []
+        # The proposal network's backward (interlevel loss -> weights -> tiny MLP -> its hash grid) shares nothing with the
+        # field's backward but the forward results.  Without feature heads the GPU is otherwise on ONE stream during the
+        # backward, so that chain goes to the (then idle) sort stream and runs beside the field backward; with heads the three
+        # streams already saturate the chip and it stays on the main stream (SNF_PROP_BWD_SIDE=1/0 overrides).
+        side_prop = PROP_BWD_SIDE if PROP_BWD_SIDE is not None else (not self.heads)
+        prop_st = sort_st if (updated and side_prop and sort_st.stream_id != main.stream_id) else main
+        prop_block = []
         if updated:
+            mark = len(plan.entries)
             gd0 = b("gd0", (N0,))
-            self._k(main, "snf_weights_bwd", dens0, 1, 1, None, eb0, gwp, R, P, gd0)
+            self._k(prop_st, "snf_weights_bwd", dens0, 1, 1, None, eb0, gwp, R, P, gd0)
             graw0 = b("graw0", (N0, 1))
-            self._k(main, "snf_trunc_exp_bwd", raw0, 1, sel0, gd0, N0, graw0, 1)
+            self._k(prop_st, "snf_trunc_exp_bwd", raw0, 1, sel0, gd0, N0, graw0, 1)
             denc0 = b("denc0", (N0, I0))
-            self._k(main, "snf_mlp_tiny_bwd", graw0, enc0, I0, hid0, pw0, pw1, I0, H0, N0, denc0, I0, pw0.main_grad,
+            self._k(prop_st, "snf_mlp_tiny_bwd", graw0, enc0, I0, hid0, pw0, pw1, I0, H0, N0, denc0, I0, pw0.main_grad,
                     pw1.main_grad, tag=f"{I0}x{H0}x1")
-            if sort_st.stream_id != main.stream_id:
-                self._py(main.wait_event, self.event("prop_sorted"))
+            if sort_st.stream_id != prop_st.stream_id:
+                self._py(prop_st.wait_event, self.event("prop_sorted"))
             stage0 = b("stage_prop", (PL * N0 * PF,))
-            self._grid_bwd(main, denc0, N0, penc, "proposal_networks", PL * PF, 0, ws_p, stage0, with_opt, done_p)
+            self._grid_bwd(prop_st, denc0, N0, penc, "proposal_networks", PL * PF, 0, ws_p, stage0, with_opt, done_p)
+            if with_opt and prop_st.stream_id != main.stream_id:
+                self._adam(prop_st, "proposal_networks", 0, opt.arenas["proposal_networks"].numel, done_p)
+            if prop_st.stream_id != main.stream_id:
+                # issue the side chain right after the nerf losses (its inputs), i.e. before the field backward on the host too
+                prop_block = plan.entries[mark:]
+                del plan.entries[mark:]
         if with_opt:
             self._adam(main, "fields", 0, opt.arenas["fields"].numel, done_f)
-            if updated or prop_adam_when_idle:
+            if (updated and prop_st.stream_id == main.stream_id) or (not updated and prop_adam_when_idle):
                 self._adam(main, "proposal_networks", 0, opt.arenas["proposal_networks"].numel, done_p)
+        if prop_block:
+            ev_in, ev_out = self.event("prop_bwd_inputs"), self.event("prop_bwd_done")
+            at = self._losses_mark
+            block = [[_PY, ev_in.record, [main], None, 0.0, None], [_PY, prop_st.wait_event, [ev_in], None, 0.0, None]] + prop_block \
+                    + [[_PY, ev_out.record, [prop_st], None, 0.0, None]]
+            plan.entries[at:at] = block
+            self._py(main.wait_event, ev_out)  # the next step's proposal forward reads the stepped parameters
         self._plan = None
         return plan
 
