@@ -3,6 +3,11 @@
 PyTorch is plumbing here (device memory, streams, autograd bookkeeping); every numeric step runs in a
 hand-written gfx950 kernel.  There is no CPU / eager fallback: tensors must live on a ROCm device.
 
+This module holds the parts with process-wide state (stream factory, weight-gradient companion streams, the hash-grid
+backward modes and their forward-time sorts) and the ops built on them (hash grids, dense layers, the fused 64-wide nets,
+the nerfacto field); the stateless groups live in ops_sampling / ops_render / ops_losses / ops_data / ops_vit / ops_optim
+and are re-exported here, so `samnerf_amd.ops.<name>` is the one public spelling.
+
 Gradient-arena convention: a parameter tensor may carry a `main_grad` attribute (an fp32 view into the
 model's flat gradient arena, see `arena.py`).  When present, the backward kernels accumulate straight into
 it and autograd receives `None` for that parameter -- no per-step zero-filled temporaries, and the arena is
@@ -11,134 +16,28 @@ the RCCL all-reduce buffer.  Without it the functions behave like ordinary autog
 from __future__ import annotations
 
 import ctypes
+import os as _os
 from typing import List, Optional, Sequence, Tuple
 
 import torch
 
 from . import _lib
-
-CONTRACT_NONE, CONTRACT_LINF, CONTRACT_L2 = 0, 1, 2
-import os as _os
+from ._opcore import *  # noqa: F401,F403
+from ._opcore import (_FN, _L, _TIMING, _chk, _has_gpu, _launch, _linear_fwd_ws, _p, _stream)  # noqa: F401
+from .ops_data import *  # noqa: F401,F403
+from .ops_losses import *  # noqa: F401,F403
+from .ops_losses import _Distortion, _Interlevel, _RowMSELoss  # noqa: F401
+from .ops_optim import *  # noqa: F401,F403
+from .ops_render import *  # noqa: F401,F403
+from .ops_render import _CompositeRGB, _FeatureMean, _HeadInput, _TruncExpSel, _Weights  # noqa: F401
+from .ops_sampling import *  # noqa: F401,F403
+from .ops_vit import *  # noqa: F401,F403
 
 HASHGRID_BWD_MODE = "sorted"  # "sorted": bucketed, atomic-free (default) | "atomic": global fp32 atomics
 PRESORT_FIELD_GRID = _os.environ.get("SNF_PRESORT_FIELD", "1") == "1"
 PLANAR_FIELD_ENCODING = _os.environ.get("SNF_PLANAR_FIELD", "1") == "1"
 PRESORT_SIDE_STREAM = _os.environ.get("SNF_PRESORT_SIDE", "1") == "1"  # False: forward-time sorts stay on the caller's stream (bench.py's serial replay)
 HASHGRID_RUN_MAX_RES = float(_os.environ.get("SNF_HG_RUN_MAX_RES", "64"))  # levels up to this resolution aggregate runs
-ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_GELU = 0, 1, 2, 3
-ACT_BY_NAME = {None: ACT_NONE, "None": ACT_NONE, "none": ACT_NONE, "ReLU": ACT_RELU, "relu": ACT_RELU,
-               "Sigmoid": ACT_SIGMOID, "sigmoid": ACT_SIGMOID}
-
-
-_GEMM_MODE_ENV = [_os.environ.get("SNF_GEMM_MODE")]  # "0" / "1" / "2": initial snf_set_gemm_mode (default 1), for A/B runs
-
-
-def _L():
-    lib = _lib.load()
-    if _GEMM_MODE_ENV[0] is not None:
-        mode, _GEMM_MODE_ENV[0] = int(_GEMM_MODE_ENV[0]), None
-        _lib.check(lib.snf_set_gemm_mode(mode), "snf_set_gemm_mode")
-    return lib
-
-
-def _p(t: Optional[torch.Tensor]):
-    """Raw device pointer for a c_void_p argument (ctypes converts a plain int / None itself: no wrapper object)."""
-    return None if t is None else t.data_ptr()
-
-
-_DEVICE_INDEX: Optional[int] = None
-_HAS_GPU: Optional[bool] = None
-
-
-def _has_gpu() -> bool:
-    global _HAS_GPU
-    if _HAS_GPU is None:
-        _HAS_GPU = torch.cuda.is_available()
-    return _HAS_GPU
-
-
-def _stream():
-    """Raw handle of the current HIP stream of this process's device (one process per GPU).  The torch.cuda.Stream object
-    behind torch.cuda.current_stream() costs ~9 us per call on the host -- 0.6 ms per train step at ~60 launches."""
-    global _DEVICE_INDEX
-    if _DEVICE_INDEX is None:
-        _DEVICE_INDEX = torch.cuda.current_device()
-    return torch._C._cuda_getCurrentRawStream(_DEVICE_INDEX)
-
-
-def _chk(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:
-    if not t.is_cuda:
-        raise RuntimeError(f"{name}: expected a ROCm device tensor; the MI355X path has no CPU fallback")
-    if t.dtype != dtype:
-        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
-    if not t.is_contiguous():
-        t = t.contiguous()
-    return t
-
-
-# --- per-kernel HIP-event timing (bench.py): events are recorded on torch's current stream, which is the stream
-# every kernel is launched on (see _stream()).
-_TIMING = {"names": None, "events": {}}
-
-
-def enable_kernel_timing(names=None) -> None:
-    """names: iterable of C-ABI entry-point names (optionally 'name/tag'), or 'all'."""
-    _TIMING["names"] = None if names is None else ("all" if names == "all" else set(names))
-    _TIMING["events"] = {}
-
-
-def kernel_timing_summary() -> dict:
-    """-> {name: {"launches": n, "total_ms": t, "avg_ms": t/n}} (synchronises)."""
-    torch.cuda.synchronize()
-    out = {}
-    for name, evs in _TIMING["events"].items():
-        tot = sum(e[0].elapsed_time(e[1]) for e in evs)
-        out[name] = {"launches": len(evs), "total_ms": tot, "avg_ms": tot / max(len(evs), 1),
-                     "units": sum(e[3] for e in evs)}
-    return out
-
-
-def kernel_timeline(base_event) -> list:
-    """-> [(start_ms, end_ms, stream_id, key)] relative to `base_event` for every timed launch (synchronises)."""
-    torch.cuda.synchronize()
-    out = []
-    for key, evs in _TIMING["events"].items():
-        for a, b, sid, _ in evs:
-            out.append((base_event.elapsed_time(a), base_event.elapsed_time(b), sid, key))
-    return sorted(out)
-
-
-_FN: dict = {}  # C-ABI entry points by name (one attribute lookup on the ctypes library per name)
-
-
-def _launch(name: str, *args, tag: str = "", units: float = 0.0) -> None:
-    """`units`: algorithmic bytes / flops of this launch when the caller knows them (summed by kernel_timing_summary)."""
-    fn = _FN.get(name)
-    if fn is None:
-        fn = _FN[name] = getattr(_L(), name)
-    sel = _TIMING["names"]
-    if sel is None:  # the hot path: no timing bookkeeping, no key formatting
-        rc = fn(*args)
-        if rc:
-            _lib.check(rc, name)
-        return
-    key = name + ("/" + tag if tag else "")
-    if sel == "all" or key in sel or name in sel:
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        rc = fn(*args)
-        b.record()
-        _TIMING["events"].setdefault(key, []).append((a, b, torch.cuda.current_stream().stream_id, units))
-    else:
-        rc = fn(*args)
-    _lib.check(rc, name)
-
-
-def set_gemm_mode(mode: str) -> None:
-    """'bf16x3' (default: wide layers on the bf16 matrix cores, 3-term split, fp32 accumulate), 'fp32' (exact) or
-    'bf16x3+chains' (the fused 64-wide MLPs on the split as well)."""
-    _lib.check(_L().snf_set_gemm_mode({"fp32": 0, "bf16x3": 1, "bf16x3+chains": 2}[mode]), "snf_set_gemm_mode")
-
 
 # ---------------------------------------------------------------------------------------------
 # stream factory
@@ -275,83 +174,6 @@ def _grad_target(param: torch.Tensor) -> Tuple[torch.Tensor, bool]:
     if mg is not None:
         return mg, True
     return torch.zeros_like(param), False
-
-
-# ---------------------------------------------------------------------------------------------
-# no-grad sampling ops
-# ---------------------------------------------------------------------------------------------
-@torch.no_grad()
-def sample_spacing(nears, fars, num_samples: int, t_rand=None):
-    nears, fars = _chk(nears.reshape(-1), "nears"), _chk(fars.reshape(-1), "fars")
-    R = nears.numel()
-    t = None if t_rand is None else _chk(t_rand.reshape(-1), "t_rand")
-    sb = torch.empty((R, num_samples + 1), device=nears.device, dtype=torch.float32)
-    eb = torch.empty_like(sb)
-    _launch("snf_sample_spacing", _p(nears), _p(fars), _p(t), R, num_samples, _p(sb), _p(eb), _stream())
-    return sb, eb
-
-
-@torch.no_grad()
-def positions(origins, directions, ebins, ids=None, contraction: int = CONTRACT_LINF, use_selector: bool = True):
-    """-> (u [R*K,3] normalised positions, selector [R*K] uint8 or None)."""
-    origins, directions, ebins = _chk(origins, "origins"), _chk(directions, "directions"), _chk(ebins, "ebins")
-    R, n = ebins.shape[0], ebins.shape[1] - 1
-    if ids is not None:
-        ids = _chk(ids, "ids", torch.int32)
-        K = ids.shape[1]
-    else:
-        K = n
-    u = torch.empty((R * K, 3), device=ebins.device, dtype=torch.float32)
-    sel = torch.empty((R * K,), device=ebins.device, dtype=torch.uint8) if use_selector else None
-    _launch("snf_positions", _p(origins), _p(directions), _p(ebins), _p(ids), R, n, K, contraction,
-                                  int(use_selector), _p(u), _p(sel), _stream())
-    return u, sel
-
-
-@torch.no_grad()
-def pdf_resample(weights, sbins_in, nears, fars, num_samples: int, u_rand=None, anneal: float = 1.0,
-                 histogram_padding: float = 0.01):
-    weights, sbins_in = _chk(weights, "weights"), _chk(sbins_in, "sbins_in")
-    nears, fars = _chk(nears.reshape(-1), "nears"), _chk(fars.reshape(-1), "fars")
-    R, Pn = weights.shape
-    u = None if u_rand is None else _chk(u_rand.reshape(-1), "u_rand")
-    sb = torch.empty((R, num_samples + 1), device=weights.device, dtype=torch.float32)
-    eb = torch.empty_like(sb)
-    _launch("snf_pdf_resample", _p(weights), _p(sbins_in), _p(u), _p(nears), _p(fars), R, Pn, num_samples,
-                                     float(anneal), float(histogram_padding), _p(sb), _p(eb), _stream())
-    return sb, eb
-
-
-@torch.no_grad()
-def topk_sharpen(weights, k: int, temperature: float = 10.0):
-    weights = _chk(weights, "weights")
-    R, S = weights.shape
-    ids = torch.empty((R, k), device=weights.device, dtype=torch.int32)
-    w = torch.empty((R, k), device=weights.device, dtype=torch.float32)
-    _launch("snf_topk_sharpen", _p(weights), R, S, k, float(temperature), _p(ids), _p(w), _stream())
-    return w, ids
-
-
-@torch.no_grad()
-def render_depth_acc(weights, ebins, want_acc: bool = True):
-    """median depth [R,1] (+ accumulation [R,1]); no gradient (as in the reference's use)."""
-    weights, ebins = _chk(weights, "weights"), _chk(ebins, "ebins")
-    R, S = weights.shape
-    depth = torch.empty((R, 1), device=weights.device, dtype=torch.float32)
-    acc = torch.empty((R, 1), device=weights.device, dtype=torch.float32) if want_acc else None
-    _launch("snf_composite_fwd", _p(None), _p(weights), _p(ebins), R, S, 1, _p(None), _p(acc), _p(depth),
-                                      _stream())
-    return depth, acc
-
-
-@torch.no_grad()
-def accumulation(weights) -> torch.Tensor:
-    """AccumulationRenderer: sum_s w [R,1] from the compositing kernel (no colours, no depth)."""
-    weights = _chk(weights, "weights")
-    R, S = weights.shape
-    acc = torch.empty((R, 1), device=weights.device, dtype=torch.float32)
-    _launch("snf_composite_fwd", _p(None), _p(weights), _p(None), R, S, 1, _p(None), _p(acc), _p(None), _stream())
-    return acc
 
 
 # ---------------------------------------------------------------------------------------------
@@ -758,13 +580,6 @@ def mlp_tiny(x, w0, w1) -> torch.Tensor:
 # ---------------------------------------------------------------------------------------------
 # SAM conv head as GEMMs (csrc/patchconv.hip)
 # ---------------------------------------------------------------------------------------------
-def _linear_fwd_ws(x, w, b, N: int, I: int, O: int, act: int, y, st, tag: str) -> None:
-    """snf_linear_fwd with the split-K scratch buffer the shape asks for (long-K layers with few output tiles)."""
-    nbytes = int(_L().snf_linear_fwd_workspace_bytes(N, I, O))
-    ws = torch.empty((max(nbytes, 16) // 4,), device=x.device, dtype=torch.float32)
-    _launch("snf_linear_fwd_ws", _p(x), _p(w), _p(b), N, I, O, I, O, act, _p(y), _p(ws), nbytes, st, tag=tag)
-
-
 class _ConvHead(torch.autograd.Function):
     """Conv2d(C,C,k,pad) -> ReLU -> Conv2d(C,C,k,pad) -> mean over the p x p patch (samnerf/sam_model.py:196-200,259-264)
     on channel-last rows x [R, C] -> [R/p^2, C]: unfold + GEMM + ReLU, then patch-mean of the unfolded rows + GEMM."""
@@ -997,406 +812,3 @@ def nerfacto_field(u, sel, dirs, R: int, S: int, spec, table, base_ws, head_ws):
     """-> (density [R*S], rgb [R*S,3]); base_ws = (W0 [64,32], W1 [16,64]), head_ws = (W0 [64,31], W1 [64,64], W2 [3,64])."""
     return _NerfactoField.apply(u, sel, dirs, R, S, spec, table, *base_ws, *head_ws)
 
-
-# ---------------------------------------------------------------------------------------------
-# colour-MLP input: SH16(dir) ++ geo features (columns 1.. of the base-MLP output)
-# ---------------------------------------------------------------------------------------------
-class _HeadInput(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, dirs, h, R: int, S: int):
-        dirs, h = _chk(dirs, "dirs"), _chk(h, "h")
-        n_geo = h.shape[1] - 1
-        out = torch.empty((R * S, 16 + n_geo), device=h.device, dtype=torch.float32)
-        geo = ctypes.c_void_p(h.data_ptr() + 4)
-        _launch("snf_head_input", _p(dirs), geo, R, S, n_geo, h.shape[1], _p(out), 16 + n_geo, _stream())
-        ctx.n_geo = n_geo
-        return out
-
-    @staticmethod
-    def backward(ctx, g):
-        # d h[:, 1:] = g[:, 16:], d h[:, 0] = 0 (the density column gets its gradient from weights_from_raw)
-        gh = torch.zeros((g.shape[0], 1 + ctx.n_geo), device=g.device, dtype=g.dtype)
-        gh[:, 1:] = g[:, 16:]
-        return None, gh, None, None
-
-
-def head_input(dirs, h, R: int, S: int) -> torch.Tensor:
-    return _HeadInput.apply(dirs, h, R, S)
-
-
-# ---------------------------------------------------------------------------------------------
-# trunc_exp * selector + get_weights
-# ---------------------------------------------------------------------------------------------
-class _Weights(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, h, selector, ebins, R: int, n: int, is_density: bool):
-        """h [R*n, C]: column 0 is the pre-activation density (or the density itself when is_density)."""
-        h, ebins = _chk(h, "h"), _chk(ebins, "ebins")
-        C = h.shape[1]
-        w = torch.empty((R, n), device=h.device, dtype=torch.float32)
-        _launch("snf_weights_fwd", _p(h), C, int(is_density), _p(selector), _p(ebins), R, n, _p(w), _p(None),
-                                        _stream())
-        ctx.save_for_backward(h, ebins)
-        ctx.selector = selector
-        ctx.dims = (R, n, C, int(is_density))
-        return w
-
-    @staticmethod
-    def backward(ctx, gw):
-        h, ebins = ctx.saved_tensors
-        R, n, C, is_density = ctx.dims
-        gw = _chk(gw, "grad_w")
-        gh = torch.zeros_like(h) if C > 1 else torch.empty_like(h)
-        _launch("snf_weights_bwd", _p(h), C, is_density, _p(ctx.selector), _p(ebins), _p(gw), R, n, _p(gh),
-                                        _stream())
-        return gh, None, None, None, None, None
-
-
-def weights_from_raw(h, selector, ebins, R: int, n: int) -> torch.Tensor:
-    """fused trunc_exp * selector + get_weights from the pre-activation density column h[:, 0]."""
-    return _Weights.apply(h, selector, ebins, R, n, False)
-
-
-def weights_from_density(density, ebins) -> torch.Tensor:
-    """RaySamples.get_weights(densities): density [R,n] (or [R,n,1]) -> weights [R,n]."""
-    R, n = ebins.shape[0], ebins.shape[1] - 1
-    return _Weights.apply(density.reshape(R * n, 1), None, ebins, R, n, True)
-
-
-@torch.no_grad()
-def density_from_raw(h, selector, ebins, R: int, n: int) -> torch.Tensor:
-    """trunc_exp(h[:,0]) * selector as [R,n] (inspection / API parity; the train path uses weights_from_raw)."""
-    h, ebins = _chk(h, "h"), _chk(ebins, "ebins")
-    w = torch.empty((R, n), device=h.device, dtype=torch.float32)
-    d = torch.empty((R, n), device=h.device, dtype=torch.float32)
-    _launch("snf_weights_fwd", _p(h), h.shape[1], 0, _p(selector), _p(ebins), R, n, _p(w), _p(d), _stream())
-    return d
-
-
-class _TruncExpSel(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, h, selector):
-        h = _chk(h, "h")
-        N, C = h.shape
-        d = torch.empty((N,), device=h.device, dtype=torch.float32)
-        _launch("snf_trunc_exp_fwd", _p(h), C, _p(selector), N, _p(d), _stream())
-        ctx.save_for_backward(h)
-        ctx.selector = selector
-        return d
-
-    @staticmethod
-    def backward(ctx, gd):
-        (h,) = ctx.saved_tensors
-        N, C = h.shape
-        gd = _chk(gd, "grad_density")
-        gh = torch.zeros_like(h) if C > 1 else torch.empty_like(h)
-        _launch("snf_trunc_exp_bwd", _p(h), C, _p(ctx.selector), _p(gd), N, _p(gh), C, _stream())
-        return gh, None
-
-
-def trunc_exp_sel(h, selector=None) -> torch.Tensor:
-    """density [N] = trunc_exp(h[:, 0]) * selector (h is the [N, C] base-MLP output; column 0 = raw density)."""
-    return _TruncExpSel.apply(h, selector)
-
-
-# ---------------------------------------------------------------------------------------------
-# RGB composite ('last_sample' background)
-# ---------------------------------------------------------------------------------------------
-class _CompositeRGB(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, rgb, weights, training: bool):
-        rgb, weights = _chk(rgb, "rgb"), _chk(weights, "weights")
-        R, S = weights.shape
-        out = torch.empty((R, 3), device=rgb.device, dtype=torch.float32)
-        _launch("snf_composite_fwd", _p(rgb), _p(weights), _p(None), R, S, int(training), _p(out), _p(None),
-                                          _p(None), _stream())
-        ctx.save_for_backward(rgb, weights)
-        ctx.training = training
-        return out
-
-    @staticmethod
-    def backward(ctx, g):
-        if not ctx.training:
-            raise RuntimeError("composite_rgb backward is defined for training mode only (eval renders under no_grad)")
-        rgb, weights = ctx.saved_tensors
-        R, S = weights.shape
-        g = _chk(g, "grad_rgb")
-        grgb = torch.empty_like(rgb)
-        gw = torch.empty_like(weights)
-        _launch("snf_composite_bwd", _p(rgb), _p(weights), _p(g), R, S, _p(grgb), _p(gw), _stream())
-        return grgb, gw, None
-
-
-def composite_rgb(rgb, weights, training: bool) -> torch.Tensor:
-    """rgb [R,S,3] (or [R*S,3]), weights [R,S] -> [R,3]."""
-    return _CompositeRGB.apply(rgb, weights, training)
-
-
-# ---------------------------------------------------------------------------------------------
-# MeanRenderer
-# ---------------------------------------------------------------------------------------------
-class _FeatureMean(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, embeds, w, R: int, K: int):
-        embeds, w = _chk(embeds, "embeds"), _chk(w, "w")
-        C = embeds.shape[-1]
-        out = torch.empty((R, C), device=embeds.device, dtype=torch.float32)
-        _launch("snf_feature_mean_fwd", _p(embeds), _p(w), R, K, C, _p(out), _stream())
-        ctx.save_for_backward(w)
-        ctx.dims = (R, K, C)
-        return out
-
-    @staticmethod
-    def backward(ctx, g):
-        (w,) = ctx.saved_tensors
-        R, K, C = ctx.dims
-        g = _chk(g, "grad_out")
-        ge = torch.empty((R * K, C), device=g.device, dtype=torch.float32)
-        _launch("snf_feature_mean_bwd", _p(g), _p(w), R, K, C, _p(ge), _stream())
-        return ge, None, None, None
-
-
-def feature_mean(embeds, w, R: int, K: int) -> torch.Tensor:
-    """embeds [R*K, C]; w [R,K] (treated as a constant, as the reference detaches it)."""
-    return _FeatureMean.apply(embeds, w.detach(), R, K)
-
-
-# ---------------------------------------------------------------------------------------------
-# regularisers: value + gradient in one kernel pass each
-# ---------------------------------------------------------------------------------------------
-class _RowMSELoss(torch.autograd.Function):
-    """weight * mean_r mean_c (pred - target)^2, optionally skipping NaN rows (nanmean); one launch per direction."""
-
-    @staticmethod
-    def forward(ctx, pred, target, weight: float, nan_skip: bool):
-        pred, target = _chk(pred, "pred"), _chk(target, "target")
-        assert pred.shape == target.shape
-        C = pred.shape[-1]
-        R = pred.numel() // C
-        acc = torch.zeros((516,), device=pred.device, dtype=torch.float32)  # SNF_ROWMSE_SCRATCH_WORDS
-        out = torch.empty((2,), device=pred.device, dtype=torch.float32)
-        _launch("snf_rowmse_loss_fwd", _p(pred), _p(target), R, C, float(weight), int(nan_skip), _p(acc), _p(out), _stream())
-        ctx.args = (R, C, float(weight), int(nan_skip))
-        ctx.save_for_backward(pred, target, out)
-        return out[0]
-
-    @staticmethod
-    def backward(ctx, g):
-        pred, target, out = ctx.saved_tensors
-        R, C, weight, nan_skip = ctx.args
-        g = g.contiguous()
-        dpred = torch.empty_like(pred)
-        _launch("snf_rowmse_loss_bwd", _p(pred), _p(target), R, C, weight, nan_skip, _p(g), _p(out), _p(dpred), _stream())
-        return dpred, None, None, None
-
-
-def mse_loss(pred, target, weight: float = 1.0) -> torch.Tensor:
-    """weight * nn.MSELoss()(pred, target) (mean over all elements; NaN propagates).  A plain mean does not care about the
-    row shape: [R, 3] colours are viewed as 64-wide rows so that one wave covers 64 elements instead of 3."""
-    if pred.is_contiguous() and target.is_contiguous() and pred.shape[-1] < 64 and pred.numel() % 64 == 0:
-        out = _RowMSELoss.apply(pred.view(-1, 64), target.detach().view(-1, 64), weight, False)
-        return out
-    return _RowMSELoss.apply(pred, target.detach(), weight, False)
-
-
-def rowmse_nanmean_loss(pred, target, weight: float = 1.0) -> torch.Tensor:
-    """weight * mse_loss(pred, target, reduction='none').mean(-1).nanmean() (samnerf/sam_model.py:316-328)."""
-    return _RowMSELoss.apply(pred, target.detach(), weight, True)
-
-
-class _Interlevel(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, w_prop, sbins_prop, sbins_fine, w_fine):
-        w_prop, sbins_prop = _chk(w_prop, "w_prop"), _chk(sbins_prop, "sbins_prop")
-        sbins_fine, w_fine = _chk(sbins_fine, "sbins_fine"), _chk(w_fine, "w_fine")
-        R, Pn = w_prop.shape
-        S = w_fine.shape[1]
-        rows = torch.empty((R,), device=w_prop.device, dtype=torch.float32)
-        need = ctx.needs_input_grad[0]
-        gwp = torch.empty_like(w_prop) if need else None
-        _launch("snf_interlevel", _p(sbins_fine), _p(w_fine), _p(sbins_prop), _p(w_prop), R, S, Pn,
-                                       1.0 / float(R * S), _p(rows), _p(gwp), _stream())
-        ctx.gwp = gwp
-        return rows.sum() / float(R * S)
-
-    @staticmethod
-    def backward(ctx, g):
-        return (ctx.gwp * g if ctx.gwp is not None else None), None, None, None
-
-
-def interlevel_loss(w_prop, sbins_prop, sbins_fine, w_fine) -> torch.Tensor:
-    """mean(clip(w - w_outer, 0)^2 / (w + 1e-7)); gradient flows to w_prop only (fine side is detached)."""
-    return _Interlevel.apply(w_prop, sbins_prop, sbins_fine.detach(), w_fine.detach())
-
-
-class _Distortion(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, w, sbins):
-        w, sbins = _chk(w, "w"), _chk(sbins, "sbins")
-        R, S = w.shape
-        rows = torch.empty((R,), device=w.device, dtype=torch.float32)
-        need = ctx.needs_input_grad[0]
-        gw = torch.empty_like(w) if need else None
-        _launch("snf_distortion", _p(sbins), _p(w), R, S, 1.0 / float(R), _p(rows), _p(gw), _stream())
-        ctx.gw = gw
-        return rows.sum() / float(R)
-
-    @staticmethod
-    def backward(ctx, g):
-        return (ctx.gw * g if ctx.gw is not None else None), None
-
-
-def distortion_loss(w, sbins) -> torch.Tensor:
-    return _Distortion.apply(w, sbins)
-
-
-# ---------------------------------------------------------------------------------------------
-# batch builder (csrc/batch.hip; SURVEY 8f rank 2) -- no gradients flow through these
-# ---------------------------------------------------------------------------------------------
-@torch.no_grad()
-def pixel_indices(u, batch_size: int, patch: int, num_images: int, H: int, W: int) -> torch.Tensor:
-    """u [batch_size / patch^2, 3] ~ U[0,1) -> (camera, row, col) int64 [batch_size, 3]."""
-    u = _chk(u, "u")
-    assert u.shape == (batch_size // (patch * patch), 3)
-    out = torch.empty((batch_size, 3), device=u.device, dtype=torch.int64)
-    _launch("snf_pixel_indices", _p(u), batch_size, patch, num_images, H, W, _p(out), _stream())
-    return out
-
-
-@torch.no_grad()
-def generate_rays(indices, c2w, intrinsics):
-    """indices [R,3] int64, c2w [N,3,4], intrinsics [N,4] -> origins [R,3], directions [R,3], pixel_area [R,1],
-    camera_indices [R,1] int64."""
-    assert indices.is_cuda and indices.dtype == torch.int64 and indices.is_contiguous()
-    c2w, intrinsics = _chk(c2w, "c2w"), _chk(intrinsics, "intrinsics")
-    R, N, dev = indices.shape[0], c2w.shape[0], indices.device
-    o = torch.empty((R, 3), device=dev, dtype=torch.float32)
-    d = torch.empty((R, 3), device=dev, dtype=torch.float32)
-    pa = torch.empty((R, 1), device=dev, dtype=torch.float32)
-    ci = torch.empty((R, 1), device=dev, dtype=torch.int64)
-    _launch("snf_generate_rays", _p(indices), R, _p(c2w), _p(intrinsics), N, _p(o), _p(d), _p(pa), _p(ci), _stream())
-    return o, d, pa, ci
-
-
-@torch.no_grad()
-def gather_nearest(points, features, image_shape, point_stride: int = 1, point_offset: int = 0) -> torch.Tensor:
-    """features[cam, long(row * fh/H), long(col * fw/W)] for every point_stride-th point of `points` [B,3] int64."""
-    assert points.is_cuda and points.dtype == torch.int64 and points.is_contiguous()
-    features = _chk(features, "features")
-    N, fh, fw, C = features.shape
-    B = points.shape[0] // point_stride
-    out = torch.empty((B, C), device=points.device, dtype=torch.float32)
-    _launch("snf_gather_nearest", _p(points), B, point_stride, point_offset, _p(features), N, fh, fw, C, int(image_shape[0]),
-            int(image_shape[1]), _p(out), _stream())
-    return out
-
-
-# ---------------------------------------------------------------------------------------------
-# image-encoder pieces (csrc/vit.hip; SURVEY 8f rank 3) -- inference only
-# ---------------------------------------------------------------------------------------------
-@torch.no_grad()
-def linear_nograd(x, w, b=None, act: int = ACT_NONE) -> torch.Tensor:
-    """Y = act(X W^T + b) without autograd bookkeeping (split-K scratch when the shape asks for it)."""
-    x, w = _chk(x, "x"), _chk(w, "w")
-    N, I = x.shape
-    O = w.shape[0]
-    y = torch.empty((N, O), device=x.device, dtype=torch.float32)
-    _linear_fwd_ws(x, w, b, N, I, O, act, y, _stream(), f"{I}x{O}")
-    return y
-
-
-@torch.no_grad()
-def patchify(img, P: int) -> torch.Tensor:
-    img = _chk(img, "img")
-    B, Cin, S, _ = img.shape
-    rows = torch.empty((B * (S // P) ** 2, Cin * P * P), device=img.device, dtype=torch.float32)
-    _launch("snf_patchify", _p(img), B, Cin, S, P, _p(rows), _stream())
-    return rows
-
-
-@torch.no_grad()
-def layernorm(x, weight, bias, eps: float, residual=None, want_sum: bool = False):
-    """LayerNorm(x + residual) over the last axis of [N, C]; with want_sum also returns x + residual."""
-    x = _chk(x, "x")
-    N, C = x.shape
-    y = torch.empty_like(x)
-    s = torch.empty_like(x) if want_sum else None
-    _launch("snf_layernorm", _p(x), _p(residual), N, C, _p(weight), _p(bias), float(eps), _p(s), _p(y), _stream())
-    return (y, s) if want_sum else y
-
-
-@torch.no_grad()
-def window_partition(x, B: int, H: int, W: int, ws: int) -> torch.Tensor:
-    C = x.shape[-1]
-    nW = ((H + ws - 1) // ws) * ((W + ws - 1) // ws)
-    out = torch.empty((B * nW * ws * ws, C), device=x.device, dtype=torch.float32)
-    _launch("snf_window_partition", _p(x), B, H, W, C, ws, _p(out), _stream())
-    return out
-
-
-@torch.no_grad()
-def window_merge_add(windows, shortcut, B: int, H: int, W: int, ws: int) -> torch.Tensor:
-    C = shortcut.shape[-1]
-    out = torch.empty((B * H * W, C), device=shortcut.device, dtype=torch.float32)
-    _launch("snf_window_merge_add", _p(windows), _p(shortcut), B, H, W, C, ws, _p(out), _stream())
-    return out
-
-
-@torch.no_grad()
-def attention(qkv, Bw: int, T: int, heads: int, n: int, rel_pos_h=None, rel_pos_w=None) -> torch.Tensor:
-    """qkv [Bw*T, 3*C] -> [Bw*T, C]: softmax(hd^-0.5 q k^T + decomposed rel-pos) v per (window, head)."""
-    qkv = _chk(qkv, "qkv")
-    C = qkv.shape[1] // 3
-    hd = C // heads
-    rel = None
-    if rel_pos_h is not None:
-        assert rel_pos_h.shape == (2 * n - 1, hd) and rel_pos_w.shape == (2 * n - 1, hd), "rel-pos tables must have 2n-1 rows"
-        rel = torch.empty((Bw * heads * T, 2 * n), device=qkv.device, dtype=torch.float32)
-        _launch("snf_relpos", _p(qkv), Bw, T, heads, hd, n, _p(_chk(rel_pos_h, "rel_pos_h")), _p(_chk(rel_pos_w, "rel_pos_w")),
-                _p(rel), _stream())
-    out = torch.empty((Bw * T, C), device=qkv.device, dtype=torch.float32)
-    _launch("snf_attention", _p(qkv), _p(rel), Bw, T, heads, hd, n, float(hd ** -0.5), _p(out), _stream(),
-            units=4.0 * Bw * heads * T * T * hd)
-    return out
-
-
-@torch.no_grad()
-def patch_unfold(x, p: int, k: int) -> torch.Tensor:
-    x = _chk(x, "x")
-    R, C = x.shape
-    col = torch.empty((R, C * k * k), device=x.device, dtype=torch.float32)
-    _launch("snf_patch_unfold", _p(x), R, p, C, k, _p(col), _stream())
-    return col
-
-
-# ---------------------------------------------------------------------------------------------
-# arena kernels
-# ---------------------------------------------------------------------------------------------
-@torch.no_grad()
-def adam_step_(p, g, m, v, lr: float, beta1: float, beta2: float, eps: float, step: int, grad_scale: float = 1.0,
-               zero_grad: bool = True) -> None:
-    for t in (p, g, m, v):
-        assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
-    _launch("snf_adam_step", _p(p), _p(g), _p(m), _p(v), p.numel(), float(lr), float(beta1), float(beta2),
-                                  float(eps), int(step), float(grad_scale), int(zero_grad), _stream(),
-            units=32.0 * p.numel())  # p, g, m, v read + p, m, v, g(zero) written
-
-
-@torch.no_grad()
-def adam_step_rows_(p, g, m, v, rows, F: int, lr: float, beta1: float, beta2: float, eps: float, step: int,
-                    grad_scale: float = 1.0, zero_grad: bool = True) -> None:
-    """Adam on the listed rows only: rows int32 = element offsets (from the arena bases p, g, m, v) of F-float rows."""
-    for t in (p, g, m, v):
-        assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
-    assert rows.is_cuda and rows.dtype == torch.int32 and rows.is_contiguous()
-    n = rows.numel()
-    if n == 0:
-        return
-    _launch("snf_adam_step_rows", _p(p), _p(g), _p(m), _p(v), _p(rows), n, int(F), float(lr), float(beta1), float(beta2),
-            float(eps), int(step), float(grad_scale), int(zero_grad), _stream(), units=32.0 * n * F)
-
-
-@torch.no_grad()
-def fill_uniform_(x, seed: int, lo: float, hi: float) -> None:
-    assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
-    _launch("snf_fill_uniform", _p(x), x.numel(), int(seed), float(lo), float(hi), _stream())

@@ -26,7 +26,8 @@ def test_library_exports_every_declared_symbol():
     for name in _lib.SIGNATURES:
         assert name in declared
     assert lib.snf_version() >= 100
-    assert lib.snf_hashgrid_bwd_workspace_bytes(65536, 12, 19) == 4 * (12 * 8 * 65536 * 2 + 2 * 12 * 64 * 256 + 3084
+    # records | tile histograms + offsets | bucket starts | 64-word scratch of the fixed-point reduce | staged gradients
+    assert lib.snf_hashgrid_bwd_workspace_bytes(65536, 12, 19) == 4 * (12 * 8 * 65536 * 2 + 2 * 12 * 64 * 256 + 3084 + 64
                                                                         + 12 * 65536 * 8)
 
 
