@@ -450,7 +450,8 @@ __global__ __launch_bounds__(256) void k_wgrad_full_reduce(const float* __restri
 }
 
 static int wf_rows_per_wg(int N) {
-    int rows = ceil_div(N, 256);          // one workgroup per CU
+    static const int chunks = getenv("SNF_WGRAD_FULL_CHUNKS") ? atoi(getenv("SNF_WGRAD_FULL_CHUNKS")) : 256;
+    int rows = ceil_div(N, chunks > 0 ? chunks : 256);  // default: one workgroup per CU
     rows = ((rows + 15) / 16) * 16;
     if (rows < 64) rows = 64;
     return rows;

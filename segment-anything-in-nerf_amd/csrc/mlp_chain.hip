@@ -803,23 +803,32 @@ __global__ __launch_bounds__(WG_T) __attribute__((amdgpu_waves_per_eu(1, 1))) vo
     }
 }
 
-// dWout[o][k] (o < out), dW1[k2][k1], dW0[k1][i] (i < in_real) += sum over the workgroup partials
+// dWout[o][k] (o < out), dW1[k2][k1], dW0[k1][i] (i < in_real) += sum over the workgroup partials.
+// 32 outputs x 8 slices of the partial list per workgroup (a thread sums nwg/8 partials, the 8 slices meet in LDS): 256
+// workgroups with 8 independent load chains each instead of 32 workgroups walking all 256 partials in sequence (49 us
+// under load for 8 MB); the summation tree is fixed, so the result is deterministic.
 __global__ __launch_bounds__(256) void k_chain_wgrad_reduce(const float* __restrict__ P, int nwg, int NH, int out, int in_real,
                                                             float* __restrict__ dWout, float* __restrict__ dW1,
                                                             float* __restrict__ dW0) {
+    __shared__ float part[8][32];
     const int per = 32 * 64 + (NH == 2 ? 64 * 64 : 0) + 64 * 32;
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= per) return;
+    const int ol = threadIdx.x & 31, slice = threadIdx.x >> 5;
+    const int e = blockIdx.x * 32 + ol;  // per is a multiple of 32
+    const int w0 = (int)((long long)nwg * slice / 8), w1 = (int)((long long)nwg * (slice + 1) / 8);
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int w = 0;
-    for (; w + 4 <= nwg; w += 4) {
+    int w = w0;
+    for (; w + 4 <= w1; w += 4) {
         s0 += P[(size_t)w * per + e];
         s1 += P[(size_t)(w + 1) * per + e];
         s2 += P[(size_t)(w + 2) * per + e];
         s3 += P[(size_t)(w + 3) * per + e];
     }
-    for (; w < nwg; ++w) s0 += P[(size_t)w * per + e];
-    const float sum = (s0 + s1) + (s2 + s3);
+    for (; w < w1; ++w) s0 += P[(size_t)w * per + e];
+    part[slice][ol] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (slice != 0) return;
+    const float sum = ((part[0][ol] + part[1][ol]) + (part[2][ol] + part[3][ol])) +
+                      ((part[4][ol] + part[5][ol]) + (part[6][ol] + part[7][ol]));
     if (e < 32 * 64) {
         const int o = e / 64, k = e % 64;
         if (o < out) dWout[o * 64 + k] += sum;
@@ -969,7 +978,7 @@ extern "C" int snf_mlp64_bwd_fused(const float* dY, int lddy, int dy_col_off, co
         hipLaunchKernelGGL(k_mlp_chain_bwd_wg<1>, dim3((unsigned)blocks), dim3(WG_T), lds, st, dY, lddy, dy_col_off, dY0, Y, ldy, X,
                            ldx, W0, in_real, W1, Wout, out, out_act, (long long)N, H1, H2, dX, lddx, P);
     }
-    hipLaunchKernelGGL(k_chain_wgrad_reduce, dim3(ceil_div(wg_partial_floats(n_hidden), 256)), dim3(256), 0, st, P, (int)blocks,
+    hipLaunchKernelGGL(k_chain_wgrad_reduce, dim3(wg_partial_floats(n_hidden) / 32), dim3(256), 0, st, P, (int)blocks,
                        n_hidden, out, in_real, dWout, dW1, dW0);
     SNF_LAUNCH_CHECK("snf_mlp64_bwd_fused");
     return SNF_OK;
