@@ -312,8 +312,15 @@ def test_training_trajectory_and_psnr_match_oracle():
         out = O.forward(ref, cfg, o, d, True, t_rand, u_rand, O.proposal_anneal(step), prop_requires_grad=updated)
         loss = sum(O.loss_dict(out, batch, cfg).values())
         loss.backward()
+        if trainer.zero_grad_adam:
+            # the reference pins torch < 2 (requirements.txt:32): zero_grad() zero-fills, so on a non-update step the proposal
+            # parameters carry a ZERO gradient and Adam still steps them; torch >= 2 (this container) leaves grad = None and
+            # would skip them -- mirror the pinned behaviour
+            for n, v in ref.items():
+                if v.grad is None:
+                    v.grad = torch.zeros_like(v)
         for opt in opts.values():
-            opt.step()  # parameters without a gradient (proposal nets on a non-update step) are skipped by torch
+            opt.step()
         ref_losses.append(float(loss))
     assert all(updated_steps[:10]) and not all(updated_steps[10:])
     rel = [abs(a - b) / abs(b) for a, b in zip(hip_losses, ref_losses)]
