@@ -817,7 +817,10 @@ __global__ __launch_bounds__(HG_FX_T) void k_hg_reduce_fx(const float* __restric
     __syncthreads();
     // three-stage software pipeline over trips of U records per thread: the records of trip t+2 and the staged gradients of
     // trip t+1 are in flight while trip t is accumulated, so neither global latency sits on the loop's critical path
-    constexpr int U = 4;
+#ifndef SNF_FX_U
+#define SNF_FX_U 4
+#endif
+    constexpr int U = SNF_FX_U;
     const uint32_t mask_s = (1u << HG_SAMPLE_BITS) - 1u;
     uint2 rec0[U], rec1[U];      // records of trip t (being processed), t+1 (gathers in flight)
     float g0[U][F], g1[U][F];
@@ -1090,7 +1093,7 @@ extern "C" int snf_hashgrid_sort(const float* u, const float* scalings, int N, i
     static int lds_attr = 0;  // largest dynamic-LDS size the scatter kernel has been opened for (one runtime call per growth)
     if (hg_scatter_lds_bytes(g.log2B) > 48 * 1024 && (int)hg_scatter_lds_bytes(g.log2B) > lds_attr) {
         lds_attr = (int)hg_scatter_lds_bytes(g.log2B);
-        hipFuncSetAttribute((const void*)k_hg_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, lds_attr);
+        (void)hipFuncSetAttribute((const void*)k_hg_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, lds_attr);
     }
     hipLaunchKernelGGL(k_hg_scatter, dim3(g.nblk, L), dim3(256), hg_scatter_lds_bytes(g.log2B), st, u, scalings, N, log2_T,
                        g.log2B, g.spt, w.offs, (uint2*)w.records);
@@ -1119,7 +1122,7 @@ extern "C" int snf_hashgrid_bwd_presorted(const float* grad_out, int N, int L, i
     if (F == 2) {
         if (!planar) hipLaunchKernelGGL(k_hg_stage_grad<2>, dim3(tblocks), dim3(256), 0, st, grad_out, N, L, ld_out, col_off, stage);
         if (hg_fx_on(F, L, N)) {
-            hipMemsetAsync(w.fx, 0, L * sizeof(uint32_t), st);
+            (void)hipMemsetAsync(w.fx, 0, L * sizeof(uint32_t), st);
             hipLaunchKernelGGL(k_hg_level_absmax<2>, dim3(hg_absmax_blocks(N, F), L), dim3(256), 0, st, stage, N, w.fx);
             hipLaunchKernelGGL((k_hg_reduce_fx<2, false, 1>), dim3(B, L), dim3(HG_FX_T), 0, st, stage, N, log2_T, g.log2B, w.bstart,
                                (const uint2*)w.records, grad_table, n_run_levels, w.fx, HgAdam{});
@@ -1166,7 +1169,7 @@ extern "C" int snf_hashgrid_bwd_presorted_adam(const float* grad_out, int N, int
     if (F == 2) {
         if (!planar) hipLaunchKernelGGL(k_hg_stage_grad<2>, dim3(tblocks), dim3(256), 0, st, grad_out, N, L, ld_out, col_off, stage);
         if (hg_fx_on(F, L, N)) {
-            hipMemsetAsync(w.fx, 0, L * sizeof(uint32_t), st);
+            (void)hipMemsetAsync(w.fx, 0, L * sizeof(uint32_t), st);
             hipLaunchKernelGGL(k_hg_level_absmax<2>, dim3(hg_absmax_blocks(N, F), L), dim3(256), 0, st, stage, N, w.fx);
             hipLaunchKernelGGL((k_hg_reduce_fx<2, true, 1>), dim3(B, L), dim3(HG_FX_T), 0, st, stage, N, log2_T, g.log2B, w.bstart,
                                (const uint2*)w.records, grad_table, n_run_levels, w.fx, a);
@@ -1232,7 +1235,7 @@ extern "C" int snf_hashgrid_bwd_presorted_adam_fx(const float* grad_out, int N, 
     a.eps = eps; a.gs = grad_scale; a.from_level = fuse_from_level;
     uint32_t* lvlmax = (uint32_t*)scratch;
     const int tblocks = ceil_div((long long)N * L, 256);
-    hipMemsetAsync(lvlmax, 0, L * sizeof(uint32_t), st);
+    (void)hipMemsetAsync(lvlmax, 0, L * sizeof(uint32_t), st);
     if (F == 2) {
         if (!planar) hipLaunchKernelGGL(k_hg_stage_grad<2>, dim3(tblocks), dim3(256), 0, st, grad_out, N, L, ld_out, col_off, stage);
         hipLaunchKernelGGL(k_hg_level_absmax<2>, dim3(hg_absmax_blocks(N, F), L), dim3(256), 0, st, stage, N, lvlmax);

@@ -714,6 +714,13 @@ static void ws_launch(dim3 grid, size_t lds, snf_stream_t stream, const float* A
                        act_in, act_out, C);
 }
 
+// SNF_GEMM_WS_SMALL_LDS=<bytes>: weight slices whose 128-column LDS image exceeds <bytes> take the 64-column kernel (half the
+// LDS, two workgroups per CU) -- a 135 KB workgroup (K = 256) can only start on a CU no co-running kernel occupies
+static int ws_small_lds(size_t lds128) {
+    static const long long limit = getenv("SNF_GEMM_WS_SMALL_LDS") ? atoll(getenv("SNF_GEMM_WS_SMALL_LDS")) : (1LL << 40);
+    return (long long)lds128 > limit;
+}
+
 // takes the launch when the shape fits the weight-stationary kernel (K % 16 == 0, K <= 256, many rows); SNF_GEMM_WS=0 disables
 template <bool BT, bool DERIV>
 static int ws_try(const float* A, const float* Aux, const float* W, const float* bias, int M, int K, int Nc, int lda, int ldaux,
@@ -724,7 +731,8 @@ static int ws_try(const float* A, const float* Aux, const float* W, const float*
         if ((pa && (lda != -8 || !BT || DERIV)) || (ct && (ldc != -8 || BT || !DERIV || (Nc % 8))) || (pa && ct) || (K % 16) ||
             K > 256 || K < 64 || Nc < 64 || (Nc % 4))
             return -1;
-        const int bn = 128, tile_rows = 256;
+        const int small = ws_small_lds((size_t)2 * 128 * (K + 8) * sizeof(uint16_t));
+        const int bn = small ? 64 : 128, tile_rows = 256;
         const size_t lds = (size_t)2 * bn * (K + 8) * sizeof(uint16_t);
         const int gy = ceil_div(Nc, bn), tiles = ceil_div(M, tile_rows);
         const int per_cu = lds > 80 * 1024 ? 1 : 2;
@@ -733,10 +741,12 @@ static int ws_try(const float* A, const float* Aux, const float* W, const float*
         if (gx > tiles) gx = tiles;
         dim3 grid(gx, gy);
         if constexpr (BT && !DERIV) {
-            if (pa) ws_launch<true, false, 128, 1, 512, 4, true, false>(grid, lds, stream, A, Aux, W, bias, M, K, Nc, lda, ldaux, ldw, ldc, act_in, act_out, C);
+            if (pa && !small) ws_launch<true, false, 128, 1, 512, 4, true, false>(grid, lds, stream, A, Aux, W, bias, M, K, Nc, lda, ldaux, ldw, ldc, act_in, act_out, C);
+            if (pa && small) ws_launch<true, false, 64, 2, 256, 2, true, false>(grid, lds, stream, A, Aux, W, bias, M, K, Nc, lda, ldaux, ldw, ldc, act_in, act_out, C);
         }
         if constexpr (!BT && DERIV) {
-            if (ct) ws_launch<false, true, 128, 1, 512, 4, false, true>(grid, lds, stream, A, Aux, W, bias, M, K, Nc, lda, ldaux, ldw, ldc, act_in, act_out, C);
+            if (ct && !small) ws_launch<false, true, 128, 1, 512, 4, false, true>(grid, lds, stream, A, Aux, W, bias, M, K, Nc, lda, ldaux, ldw, ldc, act_in, act_out, C);
+            if (ct && small) ws_launch<false, true, 64, 2, 256, 2, false, true>(grid, lds, stream, A, Aux, W, bias, M, K, Nc, lda, ldaux, ldw, ldc, act_in, act_out, C);
         }
         return 1;
     }
@@ -744,7 +754,7 @@ static int ws_try(const float* A, const float* Aux, const float* W, const float*
     // BN 128, 8 waves x 32 rows, 4 k-steps of A loads in flight (2 and 8 measured the same: the loads are not latency-bound);
     // narrow outputs (Nc <= 64) and SNF_GEMM_WS_VARIANT=1 take BN 64 with 4 waves x 64 rows (two workgroups per CU)
     static const int variant = getenv("SNF_GEMM_WS_VARIANT") ? atoi(getenv("SNF_GEMM_WS_VARIANT")) : 0;
-    const int v = (Nc <= 64 || variant == 1) ? 1 : 0;
+    const int v = (Nc <= 64 || variant == 1 || ws_small_lds((size_t)2 * 128 * (K + 8) * sizeof(uint16_t))) ? 1 : 0;
     const int bn = v == 1 ? 64 : 128, tile_rows = 256;
     const size_t lds = (size_t)2 * bn * (K + 8) * sizeof(uint16_t);
     const int gy = ceil_div(Nc, bn), tiles = ceil_div(M, tile_rows);
