@@ -171,3 +171,68 @@ def test_checkpoint_round_trip_continues_the_same_trajectory(tmp_path):
         assert _rel_to_max(other.param, arena.param) <= 1e-5, g
         assert _rel_to_max(other.exp_avg, arena.exp_avg) <= 1e-4, g
     del ps_a
+
+
+def test_static_schedule_against_the_reference_ministep(golden):
+    """The product path itself -- the static launch schedule, level-major head encodings, fixed-point table backward, fused
+    chain weight gradients -- on the reference-generated `ministep` fixture (tests/golden/make_golden.py: the reference's own
+    torch components composed into one train step): rendered outputs within 1e-4, every loss term, and EVERY parameter
+    gradient within 2e-4 of its largest entry."""
+    import copy
+    import numpy as np
+    from oracle import samnerf_oracle as O
+    from samnerf_amd import configs, tcnn_compat
+    from samnerf_amd.interop import load_named_params, named_grads
+    from samnerf_amd.rays import RayBundle
+    from samnerf_amd.step_program import StepProgram
+    g = golden("ministep")
+    P, S, K, patch, T, R = (int(g[k]) for k in ("P", "S", "K", "patch", "log2_T", "num_rays"))
+    cfg = O.PathConfig(num_proposal_samples=P, num_nerf_samples=S, num_sam_samples=K, patch_size=patch).small(T)
+    params = O.init_params(cfg, seed=int(g["seed_params"]), table_scale=float(g["table_scale"]))
+    tc = copy.deepcopy(configs.method_configs["samnerf_distill"])
+    tc.pipeline.datamanager.train_num_rays_per_batch = R
+    mc = tc.pipeline.model
+    mc.num_proposal_samples_per_ray, mc.num_nerf_samples_per_ray, mc.num_sam_samples, mc.patch_size = (P,), S, K, patch
+    mc.log2_hashmap_size, mc.hashgrid_sizes = min(19, T), (min(19, T),) * 2
+    mc.proposal_net_args_list = [dict(a, log2_hashmap_size=min(17, T)) for a in mc.proposal_net_args_list]
+    tcnn_compat.manual_seed(0)
+    trainer = tc.setup(device="cuda")
+    trainer.setup()
+    model = trainer.pipeline.model
+    load_named_params(model, params)
+    o, d = torch.from_numpy(g["origins"]), torch.from_numpy(g["directions"])
+    batch = {k: v.cuda() for k, v in O.synthetic_batch(cfg, R, int(g["seed_batch"])).items()}
+    rb = RayBundle(origins=o.cuda(), directions=d.cuda(), pixel_area=torch.full((R, 1), 1e-6, device="cuda"),
+                   camera_indices=torch.zeros((R, 1), dtype=torch.long, device="cuda"))
+    trainer.pipeline.datamanager.next_train = lambda step: (copy.copy(rb), batch)
+    ps = model.proposal_sampler
+    ps.initial_sampler.jitter_override = torch.from_numpy(g["t_rand"]).cuda()
+    ps.pdf_sampler.jitter_override = torch.from_numpy(g["u_rand"]).cuda()
+    ps.set_anneal(float(g["anneal"]))
+    assert StepProgram.unsupported_reason(trainer) is None
+    prog = StepProgram(trainer)
+    trainer.optimizers.enabled = False  # gradients stay in the arenas
+    loss, ld, md_ = prog.run(0)
+    for st in (trainer._side or {}).values():
+        torch.cuda.current_stream().wait_stream(st)
+    torch.cuda.synchronize()
+    out = prog.outputs()
+
+    def md(a, b):
+        return float((a.detach().cpu().double().reshape(-1) - torch.as_tensor(np.asarray(b)).double().reshape(-1)).abs().max())
+
+    assert md(prog.bufs["sb1"], g["sbins_fine"]) <= 1e-5
+    assert md(prog.bufs["w0"], g["w_prop"]) <= 1e-5 and md(prog.bufs["w1"], g["w_fine"]) <= 1e-5
+    assert md(out["rgb"], g["rgb"]) <= 1e-4 and md(out["accumulation"], g["accumulation"]) <= 1e-4
+    assert md(out["sam"], g["sam"]) <= 1e-4 and md(out["clipseg"], g["clipseg"]) <= 1e-4
+    for key in ("depth", "prop_depth_0"):
+        rel = np.abs(out[key].cpu().numpy().reshape(-1) - g[key].reshape(-1)) / np.abs(g[key].reshape(-1))
+        assert rel.max() <= 1e-4, key
+    for k in ("rgb_loss", "interlevel_loss", "distortion_loss", "sam_loss", "clipseg_loss"):
+        assert abs(float(ld[k]) - float(g[k])) <= 1e-5 * max(1.0, abs(float(g[k]))), k
+    assert abs(float(md_["psnr"]) + 10.0 * np.log10(float(g["rgb_loss"]))) <= 1e-3
+    grads = named_grads(model)
+    for k in params:
+        ref = g["grad_" + k]
+        scale = max(float(np.abs(ref).max()), 1e-8)
+        assert md(grads[k].reshape(ref.shape), ref) <= 2e-4 * scale + 1e-7, (k, md(grads[k].reshape(ref.shape), ref) / scale)
