@@ -348,9 +348,12 @@ def fx_losses():
 # ---------------------------------------------------------------------------------------------
 def fx_ministep():
     """One composed train step through the reference's own components."""
-    R, T = 64, 11
-    cfg = O.PathConfig(num_proposal_samples=64, num_nerf_samples=48, num_sam_samples=16, patch_size=4).small(T)
-    params = O.init_params(cfg, seed=0, table_scale=0.1)
+    _ministep("ministep", 64, 11, 48, 0.1, 200)
+
+
+def _ministep(name, R, T, S, table_scale, anneal_step):
+    cfg = O.PathConfig(num_proposal_samples=64, num_nerf_samples=S, num_sam_samples=16, patch_size=4).small(T)
+    params = O.init_params(cfg, seed=0, table_scale=table_scale)
     o, d = O.synthetic_rays(R, 0)
     batch = O.synthetic_batch(cfg, R, 1)
     linf, l2 = SceneContraction(order=float("inf")), SceneContraction()
@@ -399,7 +402,7 @@ def fx_ministep():
     sampler = ProposalNetworkSampler(num_proposal_samples_per_ray=(cfg.num_proposal_samples,),
                                      num_nerf_samples_per_ray=cfg.num_nerf_samples,
                                      num_proposal_network_iterations=1, single_jitter=True)
-    anneal = O.proposal_anneal(200)
+    anneal = O.proposal_anneal(anneal_step)
     sampler.set_anneal(anneal)
     torch.manual_seed(123)
     ray_samples, weights_list, ray_samples_list = sampler(rb, density_fns=[density_fn])
@@ -483,7 +486,7 @@ def fx_ministep():
     for k, g in ref_grads.items():
         check("mini grad " + k, g, op[k].grad, 2e-6)
         arrays["grad_" + k] = g
-    npz("ministep", seed_params=0, table_scale=0.1, log2_T=T, num_rays=R, seed_rays=0, seed_batch=1,
+    npz(name, seed_params=0, table_scale=table_scale, log2_T=T, num_rays=R, seed_rays=0, seed_batch=1,
         P=cfg.num_proposal_samples, S=cfg.num_nerf_samples, K=cfg.num_sam_samples, patch=cfg.patch_size,
         anneal=anneal, t_rand=t_rand, u_rand=u_rand, origins=o, directions=d,
         sbins_prop=oo["sbins_prop"], sbins_fine=sb_f, w_prop=weights_list[0][..., 0], w_fine=weights[..., 0],

@@ -50,7 +50,7 @@ def run_step(model, o, d, batch, t_rand, u_rand, anneal):
     return out, losses
 
 
-def test_ministep_golden(golden):
+def test_ministep_golden(golden, grad_parity):
     from samnerf_amd.interop import load_named_params, named_grads
     g = golden("ministep")
     P, S, K, patch, T = int(g["P"]), int(g["S"]), int(g["K"]), int(g["patch"]), int(g["log2_T"])
@@ -78,16 +78,14 @@ def test_ministep_golden(golden):
         assert abs(float(losses[k]) - float(g[k])) <= 1e-5 * max(1.0, abs(float(g[k]))), k
     sum(losses.values()).backward()
     grads = named_grads(model)
-    for k in params:
-        ref = g["grad_" + k]
-        scale = max(float(np.abs(ref).max()), 1e-8)
-        assert md(grads[k].reshape(ref.shape), ref) <= 2e-4 * scale + 1e-7, (k, md(grads[k].reshape(ref.shape), ref) / scale)
+    grad_parity(grads, {k: g["grad_" + k] for k in params})
 
 
 @pytest.mark.parametrize("shape", [(256, 64, 128, 16, 4, 14), (208, 64, 32, 16, 4, 13), (192, 64, 48, 3, 1, 12)])
-def test_step_vs_oracle(shape):
-    """BASELINE-shaped sample counts (S=128, K=16) at table sizes the CPU oracle handles in seconds."""
-    from samnerf_amd.interop import load_named_params
+def test_step_vs_oracle(shape, grad_parity):
+    """BASELINE-shaped sample counts (S=128, K=16) at table sizes the CPU oracle handles in seconds: outputs, losses and
+    every parameter gradient."""
+    from samnerf_amd.interop import load_named_params, named_grads
     R, P, S, K, patch, T = shape
     clipseg = patch > 1
     cfg = O.PathConfig(num_proposal_samples=P, num_nerf_samples=S, num_sam_samples=K, patch_size=patch,
@@ -97,7 +95,8 @@ def test_step_vs_oracle(shape):
     batch = O.synthetic_batch(cfg, R, 6)
     gen = torch.Generator().manual_seed(7)
     t_rand, u_rand = torch.rand((R, 1), generator=gen), torch.rand((R, 1), generator=gen)
-    ref = O.forward(params, cfg, o, d, True, t_rand, u_rand, 0.5)
+    op = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    ref = O.forward(op, cfg, o, d, True, t_rand, u_rand, 0.5)
     model = build_model(P, S, K, patch, T, clipseg=clipseg)
     load_named_params(model, params)
     out, losses = run_step(model, o, d, batch, t_rand, u_rand, 0.5)
@@ -108,6 +107,10 @@ def test_step_vs_oracle(shape):
     ld = O.loss_dict(ref, batch, cfg)
     for k, v in ld.items():
         assert abs(float(losses[k]) - float(v)) <= 1e-4 * max(1.0, abs(float(v))), k
+    sum(ld.values()).backward()
+    sum(losses.values()).backward()
+    grads = named_grads(model)
+    grad_parity(grads, {k: v.grad.numpy() for k, v in op.items() if v.grad is not None and k in grads})
 
 
 def test_eval_mode_and_no_distill():

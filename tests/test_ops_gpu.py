@@ -775,8 +775,8 @@ def test_trunc_exp_golden_on_the_kernel(golden):
 @pytest.mark.parametrize("mode", ["train", "eval"])
 def test_pdf_euclidean_bins_within_the_analytic_bound(golden, mode):
     """The euclidean bin edges are e = s^-1(b s_far + (1 - b) s_near) with s^-1(y) = 1 / (2 - 2y) beyond y = 1/2
-    (ray_samplers.py:242-246): de/dy = 2 e^2, so an s-space difference db and the fp32 roundings of y (one ulp = 6e-8 near 1)
-    move e by 2 e^2 (|db| (s_far - s_near) + ulp).  The kernel's s-bins must match the reference to 4e-6, and its e-bins
+    (ray_samplers.py:242-246) and 2y below: de/dy = 2 max(e, 1)^2, so an s-space difference db and the fp32 roundings of y (one ulp = 6e-8 near 1)
+    move e by 2 max(e, 1)^2 (|db| (s_far - s_near) + ulp).  The kernel's s-bins must match the reference to 4e-6, and its e-bins
     must sit inside that bound element by element (round 1 accepted a flat 1e-3 relative); below e = 50 that is 1e-4 flat."""
     g = golden(f"pdf_{mode}")
     u = G(g["u_rand"]) if mode == "train" else None
@@ -789,7 +789,8 @@ def test_pdf_euclidean_bins_within_the_analytic_bound(golden, mode):
     s_fn = lambda x: torch.where(x < 1, x / 2, 1 - 1 / (2 * x))  # noqa: E731
     span = s_fn(far) - s_fn(near)
     # y = b s_far + (1 - b) s_near is three fp32 roundings on either side (kernel and reference): up to 6 ulps of y apart
-    bound = 2.0 * eb_ref ** 2 * (db * span + 6 * 6e-8) + 4e-7 * eb_ref
+    slope = 2.0 * torch.clamp(eb_ref, min=1.0) ** 2  # s^-1(y) = 2y below y = 1/2 (e < 1): slope 2 there
+    bound = slope * (db * span + 6 * 6e-8) + 4e-7 * eb_ref
     assert bool(((eb - eb_ref).abs() <= bound).all()), float(((eb - eb_ref).abs() / bound).max())
     small = eb_ref <= 50.0
     assert float(((eb - eb_ref).abs() / eb_ref.clamp_min(1e-3))[small].max()) <= 1e-4

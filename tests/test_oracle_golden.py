@@ -211,3 +211,32 @@ def test_eval_regroup(golden):
         close(O.feature_ray_grid(T(g[f"c{ci}_directions"]), fh, fw, p), T(g[f"c{ci}_feat_directions"]))
         close(O.feature_ray_grid(T(g[f"c{ci}_pixel_area"]), fh, fw, p), T(g[f"c{ci}_feat_pixel_area"]))
         close(O.clipseg_ray_grid(origins), T(g[f"c{ci}_clip_origins"]))
+
+
+def test_gradient_conditioning():
+    """Why the composed-step gradient tests (conftest.grad_parity) use a relative L1 criterion: the oracle's own train step in
+    fp32 and in fp64 (same parameters, rays, jitter).  The first-layer ReLU masks of the fields flip for the few (sample, unit)
+    pairs whose pre-activation is inside the fp32 rounding of zero, which moves single rows / table entries by up to ~1 % of the
+    tensor's largest entry while the rest agrees to 1e-5; the last layers agree to 2e-5 everywhere."""
+    R, P, S, K, patch, T = 192, 64, 48, 3, 1, 12
+    cfg = O.PathConfig(num_proposal_samples=P, num_nerf_samples=S, num_sam_samples=K, patch_size=patch, use_clipseg=False).small(T)
+    params = O.init_params(cfg, seed=3, table_scale=0.05)
+    o, d = O.synthetic_rays(R, 5)
+    batch = O.synthetic_batch(cfg, R, 6)
+    gen = torch.Generator().manual_seed(7)
+    t_rand, u_rand = torch.rand((R, 1), generator=gen), torch.rand((R, 1), generator=gen)
+    grads = {}
+    for dt in (torch.float32, torch.float64):
+        op = {k: v.clone().to(dt).requires_grad_(True) for k, v in params.items()}
+        ref = O.forward(op, cfg, o.to(dt), d.to(dt), True, t_rand.to(dt), u_rand.to(dt), 0.5)
+        b = {k: (v.to(dt) if v.is_floating_point() else v) for k, v in batch.items()}
+        sum(O.loss_dict(ref, b, cfg).values()).backward()
+        grads[dt] = {k: v.grad.double() for k, v in op.items() if v.grad is not None}
+    l1, mx = {}, {}
+    for k, g64 in grads[torch.float64].items():
+        e = (grads[torch.float32][k] - g64).abs()
+        l1[k], mx[k] = float(e.sum() / g64.abs().sum()), float(e.max() / g64.abs().max())
+    assert max(l1.values()) <= 5e-3, l1
+    assert max(mx[k] for k in ("head_w2", "sam_w1", "base_w1")) <= 1e-4, mx
+    # the flip signature: outliers of >1e-3 of the largest entry in tensors whose relative L1 error stays at 1e-3
+    assert max(mx["field_table"], mx["base_w0"], mx["sam_w0"]) >= 1e-3 >= max(l1["field_table"], l1["base_w0"], l1["sam_w0"]), (l1, mx)
