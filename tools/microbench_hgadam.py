@@ -16,17 +16,39 @@ CASES = {  # N, L, F, T, base, max, planar gradient, clustered positions
     "f8a": (65536, 12, 8, 19, 16, 128, True, False),
     "f2": (524288, 16, 2, 19, 16, 2048, True, True),
     "f2p": (262144, 5, 2, 17, 16, 128, False, True),
+    # probes of the coarse-level tail: the same sample counts with every level hashed (no bucket holds more than 8N/256 records)
+    "f2_fine": (524288, 16, 2, 19, 256, 2048, True, True),
+    "f2p_fine": (262144, 5, 2, 17, 128, 512, False, True),
 }
 REPS = int(os.environ.get("REPS", "20"))
 lib = ops._L()
+REAL = {}
+if os.environ.get("POS") == "real":  # positions of a bench-shaped train step (fine / proposal / top-K samples) instead of synthetic ones
+    import bench
+    tr = bench.build_trainer(bench.WORKLOADS["distill_4096x128"], 0, 1)
+    for i in range(3):
+        tr.train_iteration(i)
+    torch.cuda.synchronize()
+    bufs = tr._program.bufs
+    REAL = {v.shape[0]: v.clone() for k, v in bufs.items() if k in ("u0", "u1", "uk@0")}
+    print("real positions for N =", sorted(REAL), flush=True)
+    for st in (tr._side or {}).values():
+        torch.cuda.current_stream().wait_stream(st)
+    torch.cuda.synchronize()
+    del tr, bufs
 for name in os.environ.get("CASES", "f8b,f8a,f2,f2p").split(","):
+    if name.startswith("lvl"):  # lvl<res>[p]: one F=2 level of that resolution alone (p: the proposal grid's N and T)
+        res = int(name[3:].rstrip("p"))
+        CASES[name] = (262144, 1, 2, 17, res, res, False, True) if name.endswith("p") else (524288, 1, 2, 19, res, res, True, True)
     N, L, F, T, mn, mx, planar, clustered = CASES[name]
-    growth = float(np.exp((np.log(mx) - np.log(mn)) / (L - 1)))
+    growth = float(np.exp((np.log(mx) - np.log(mn)) / (L - 1))) if L > 1 else 1.0
     enc = tcnn_compat.Encoding(3, {"otype": "HashGrid", "n_levels": L, "n_features_per_level": F, "log2_hashmap_size": T,
                                    "base_resolution": mn, "per_level_scale": growth}, device="cuda")
     n_sparse, _ = enc.active_rows()
     gen = torch.Generator(device="cuda").manual_seed(0)
-    if clustered:  # samples along rays: consecutive samples are neighbours
+    if N in REAL:
+        u = REAL[N]
+    elif clustered:  # samples along rays: consecutive samples are neighbours
         R = N // 128
         o = torch.rand((R, 1, 3), device="cuda", generator=gen) * 0.2 + 0.4
         d = torch.randn((R, 1, 3), device="cuda", generator=gen)
@@ -46,6 +68,7 @@ for name in os.environ.get("CASES", "f8b,f8a,f2,f2p").split(","):
     stage = torch.empty((L * N * F,), device="cuda")
     st = ops._stream()
     nrun = ops.hashgrid_run_levels(sc) if F == 2 else 0
+    nrun = int(os.environ.get("NRUN", nrun))
     ops._launch("snf_hashgrid_sort", ops._p(u), ops._p(sc), N, L, T, ops._p(ws), nbytes, st)
 
     def launch(step):
