@@ -804,7 +804,13 @@ __global__ __launch_bounds__(HG_FX_T) void k_hg_reduce_fx(const float* __restric
     const uint32_t start = bucket_start[l * (B + 1) + b], end = bucket_start[l * (B + 1) + b + 1];
     const bool fuse = ADAM && l >= adam.from_level;
     if (start == end && !fuse) return;
-    for (int i = tid; i < rpb * F; i += HG_FX_T) acc[i] = 0ull;
+    // Small tables (rpb < MAXROWS, e.g. the T = 17 proposal grid) leave accumulator space unused: it holds up to 8 copies of the
+    // bucket's rows, lane j adding into copy j % copies.  Integer sums commute, so the epilogue adds the copies in any order; at a
+    // coarse level, where runs of adjacent lanes hit ONE row (same-address LDS atomics serialise), this cuts the conflict depth.
+    int copies = MAXROWS / rpb;
+    copies = copies > 8 ? 8 : copies;  // (both powers of two)
+    const uint32_t copy_off = (uint32_t)(lane & (copies - 1)) * (uint32_t)rpb;
+    for (int i = tid; i < rpb * copies * F; i += HG_FX_T) acc[i] = 0ull;
     for (int i = tid; i < MAXROWS * F / 32; i += HG_FX_T) bad[i] = 0u;
     // 2^e > M >= every finite |g| of the level; q = rint(c * 2^(BITS - e)).  (M = 0: nothing finite and non-zero lands here)
     int e = 0;
@@ -868,7 +874,7 @@ __global__ __launch_bounds__(HG_FX_T) void k_hg_reduce_fx(const float* __restric
                 for (int f = 0; f < F; ++f) {
                     if (fabsf(v[f]) < INFINITY) {
                         const long long q = __float2ll_rn(v[f] * scale);
-                        if (q != 0) atomicAdd(&acc[row * F + f], (unsigned long long)q);
+                        if (q != 0) atomicAdd(&acc[(copy_off + row) * F + f], (unsigned long long)q);
                     } else {  // NaN / inf cannot be represented: the element becomes NaN, as a float sum would
                         const uint32_t e = row * F + f;
                         atomicOr(&bad[e >> 5], 1u << (e & 31));
@@ -902,7 +908,9 @@ __global__ __launch_bounds__(HG_FX_T) void k_hg_reduce_fx(const float* __restric
                 for (int f = 0; f < F; ++f) {
                     const uint32_t e = (uint32_t)(r * F + f);
                     const bool isbad = (bad[e >> 5] >> (e & 31)) & 1u;
-                    const long long q = (long long)acc[e];
+                    unsigned long long qs = acc[e];
+                    for (int c = 1; c < copies; ++c) qs += acc[(uint32_t)c * (uint32_t)(rpb * F) + e];
+                    const long long q = (long long)qs;
                     gg[j][f] = isbad ? __uint_as_float(0x7FC00000u) : __ll2float_rn(q) * inv;
                     nz[j] = nz[j] || (q != 0) || isbad;
                 }
