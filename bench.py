@@ -55,7 +55,8 @@ def algorithmic_model(key: str, w: dict):
         rw = 1 if name.endswith("fwd") else 2
         # F=8: feature grids on the R*K top-K samples; F=2: proposal grid (L=5, R*P samples) or field grid (L=16, R*S).
         # Table-parallel feature grids (multi-GPU): a launch covers the L levels this rank owns at the samples of all ranks.
-        n = R * K * w.get("world", 1) if F == 8 else (R * P if L == 5 else R * S)
+        # (its forward is one launch per destination rank: R*K samples each)
+        n = R * K * (w.get("world", 1) if (m.group(3) and rw == 2) else 1) if F == 8 else (R * P if L == 5 else R * S)
         return "hbm", float(n * L * 8 * F * 4 * rw), "GB/s"
     if name.startswith("snf_linear"):
         pm = tag.endswith("pm")  # conv head: second convolution, on the patch means

@@ -153,10 +153,12 @@ class Optimizers:
 
     # -- data-parallel exchange + step (distributed.sharded_step) ---------------------------------------------------
     def exchange_and_step(self, k: str, first: Optional[int] = None, last: Optional[int] = None, count_step: bool = True,
-                          extra: Optional[List[str]] = None) -> None:
+                          extra: Optional[List[str]] = None, done: Optional[list] = None) -> None:
         """Gradient mean over the ranks + Adam for group `k` (or its parameters [first, last)), on the current stream.
         world == 1: plain fused Adam.  world > 1: reduce-scatter, Adam on this rank's shard, all-gather of the parameters
-        (or all-reduce + replicated Adam when `self.sharded` is off)."""
+        (or all-reduce + replicated Adam when `self.sharded` is off).
+        done: arena element ranges this step's backward has already stepped, when the caller knows them (the static launch
+        schedule, which does not arm `FusedAdam` objects per step); default: ask the armed tables."""
         from . import distributed as D
         ops.join_wgrad_stream()  # weight gradients of this task may still be running on the companion stream
         if not self.enabled:  # measurement of the forward+backward alone (bench.py): gradients keep accumulating
@@ -172,7 +174,7 @@ class Optimizers:
             self.step_count[k] += 1
         scale, lr, t = 1.0 / D.world_size(), self.lr(k), self.step_count[k]
         b1, b2, eps = oc.betas[0], oc.betas[1], oc.eps
-        done = self._take_fused(k, lo, hi, t)
+        done = self._take_fused(k, lo, hi, t) if done is None else list(done)
         if not D.collectives_on():
             self._adam_range(k, lo, hi, lr, b1, b2, eps, t, scale, done)
             return

@@ -20,8 +20,18 @@ torch reductions of the eager loss dict (`rows.sum()`, `sum(losses)`) are `snf_n
 "scale one branch's gradient, add the branches" is `snf_add_scaled`.  tests/test_model_gpu.py runs both paths from the
 same state and compares parameters and Adam moments after several steps.
 
-Scope: one rank (multi-rank runs keep the eager path with its collectives), `num_proposal_iterations == 1`, the fused
-nerfacto field, and the sorted hash-grid backward -- i.e. the samnerf_distill / samnerf_no_distill method configs.
+Scope: `num_proposal_iterations == 1`, the fused nerfacto field, and the sorted hash-grid backward -- i.e. the
+samnerf_distill / samnerf_no_distill method configs -- on one rank or many.
+
+Multi-rank (one process per GPU, RCCL): the schedule is the same list with the collectives of the eager path recorded at fixed
+points of it (every rank replays the same list from one host thread, so the ranks issue their collectives in the same order):
+  * table-parallel feature grids (distributed.TableParallelLayout): all-gather of the top-K positions, this rank's level runs
+    evaluated at every rank's samples straight into the all-to-all send buffer -- laid out [destination][level][sample][8], so
+    what arrives is the level-major encoding the head's first layer reads -- the mirror-image all-to-all of its data gradient,
+    and the fused backward + Adam (gradient scale 1/W) on the owned levels only;
+  * everything replicated (field / proposal grids, MLPs, conv head): gradients land in the arenas and
+    `Optimizers.exchange_and_step` -- reduce-scatter, Adam on the own shard, all-gather -- is called at its place in the list,
+    on the stream of its task.
 """
 from __future__ import annotations
 
@@ -68,8 +78,6 @@ class StepProgram:
         c = model.config
         if not torch.cuda.is_available():
             return "no GPU"
-        if D.collectives_on():
-            return "multi-rank run (collectives on the path)"
         if not isinstance(model, SAMModel):
             return "not a SAMModel"
         if c.num_proposal_iterations != 1 or c.use_same_proposal_network:
@@ -94,6 +102,17 @@ class StepProgram:
                 return "dino head"
         if not model.arenas:
             return "parameters are not in arenas"
+        if D.collectives_on() and c.distill_sam:
+            sf = model.sam_field
+            heads = [list(sf.clip_encs)] + ([list(sf.clipseg_encs)] if c.use_clipseg_feature else [])
+            layouts = [ops.table_parallel_layout(tuple(e.spec for e in h)) for h in heads]
+            if any(l is not None for l in layouts):
+                total = [sum(e.n_output_dims for e in h) for h in heads]
+                if not (PLANAR_HEADS and int(_lib.load().snf_get_gemm_mode()) >= 1 and all(l is not None for l in layouts)
+                        and all(t % 16 == 0 and 64 <= t <= 256 for t in total)):
+                    return "table-parallel heads need the level-major head path"
+                if R * c.num_sam_samples * D.world_size() > ops.HASHGRID_BWD_MAX_SAMPLES:
+                    return "gathered feature samples beyond one sorted-backward launch"
         return None
 
     def __init__(self, trainer) -> None:
@@ -114,6 +133,10 @@ class StepProgram:
         self.events: Dict[str, torch.cuda.Event] = {}
         self._head_busy: Dict[tuple, bool] = {}  # (parity, head) -> a task of that parity has been enqueued
         self.count = 0
+        self.multi = bool(D.collectives_on())
+        self.world = D.world_size() if self.multi else 1
+        self.rank = torch.distributed.get_rank() if self.multi else 0
+        self._tp_params: list = []  # tables whose levels are spread over the ranks (stale elsewhere after a step)
         self._own_sort_stream = None
         self._feat_sorted = None
         self._feat_sort_stream_id = None
@@ -182,22 +205,35 @@ class StepProgram:
         return (a.param[off:off + n], a.grad[off:off + n], a.exp_avg[off:off + n], a.exp_avg_sq[off:off + n], n_sparse,
                 (off + n_sparse * stride, off + n))
 
-    def _grid_bwd(self, st, g, N, enc, group, ld, col, sorted_ws, stage, with_opt: bool, done: list) -> None:
-        """Table-gradient backward of one grid from the presorted records (+ Adam of its dense levels when with_opt)."""
+    def _grid_bwd(self, st, g, N, enc, group, ld, col, sorted_ws, stage, with_opt: bool, done: list, run=None,
+                  grad_scale: float = 1.0) -> None:
+        """Table-gradient backward of one grid from the presorted records (+ Adam of its dense levels when with_opt).
+        run = (first level, levels): only that level run of the table (table-parallel ownership); `g` / the sort are the run's."""
         L, F, T = enc.n_levels, enc.n_features_per_level, enc.log2_hashmap_size
         p, gbuf, m, v, n_sparse, fused_range = self._table_adam(enc, group)
-        nrun = ops.hashgrid_run_levels(enc.scalings) if F == 2 else 0
+        sc = enc.scalings
+        tag = f"F{F}L{L}"
+        if run is not None:
+            l0, L = run
+            a, e = (l0 << T) * F, ((l0 + L) << T) * F
+            p, gbuf, m, v = p[a:e], gbuf[a:e], m[a:e], v[a:e]
+            sc = ops._sc_run(enc.scalings, l0, L)
+            first_fused = fused_range[0] - n_sparse * ((1 << T) * F)  # arena offset of the table
+            n_sparse = min(max(n_sparse - l0, 0), L)
+            fused_range = (first_fused + ((l0 + n_sparse) << T) * F, first_fused + ((l0 + L) << T) * F)
+            tag = f"F{F}L{L}tp"
+        nrun = ops.hashgrid_run_levels(sc) if F == 2 else 0
         fuse = with_opt and self.opt.fuse_table_adam and n_sparse < L
         if F == 8 and FX_F8 and N % 2 == 0 and L <= 64:
             # fixed-point reduce (order-independent sums, no in-bucket sort); scratch private to this launch: the sorted
             # workspace is shared by the SAM and ClipSeg heads, whose backward passes run concurrently
             oc = self.opt.config[group]["optimizer"]
-            scratch = self.buf(f"fx_scratch_{id(enc)}", (64,), torch.int32)
+            scratch = self.buf(f"fx_scratch_{id(enc)}_{run}", (64,), torch.int32)
             from_level = n_sparse if fuse else L
             fused = ((L - from_level) << T) * F
             self._k(st, "snf_hashgrid_bwd_presorted_adam_fx", g, N, L, F, T, ld, col, nrun, gbuf, sorted_ws, stage, from_level,
-                    p, m, v, 0.0, float(oc.betas[0]), float(oc.betas[1]), float(oc.eps), 1, 1.0, scratch,
-                    tag=f"F{F}L{L}", units=float(N) * 8 * F * 4 * (L + from_level) + 24.0 * fused,
+                    p, m, v, 0.0, float(oc.betas[0]), float(oc.betas[1]), float(oc.eps), 1, float(grad_scale), scratch,
+                    tag=tag, units=float(N) * 8 * F * 4 * (L + from_level) + 24.0 * fused,
                     dyn={("lr", group): 15, ("t", group): 19})
             if fuse:
                 done.append(fused_range)
@@ -206,11 +242,32 @@ class StepProgram:
             oc = self.opt.config[group]["optimizer"]
             fused = ((L - n_sparse) << T) * F
             self._k(st, "snf_hashgrid_bwd_presorted_adam", g, N, L, F, T, ld, col, nrun, gbuf, sorted_ws, stage, n_sparse,
-                    p, m, v, 0.0, float(oc.betas[0]), float(oc.betas[1]), float(oc.eps), 1, 1.0, tag=f"F{F}L{L}",
+                    p, m, v, 0.0, float(oc.betas[0]), float(oc.betas[1]), float(oc.eps), 1, float(grad_scale), tag=tag,
                     units=float(N) * 8 * F * 4 * (L + n_sparse) + 24.0 * fused, dyn={("lr", group): 15, ("t", group): 19})
             done.append(fused_range)
         else:
-            self._k(st, "snf_hashgrid_bwd_presorted", g, N, L, F, T, ld, col, nrun, gbuf, sorted_ws, stage, tag=f"F{F}L{L}")
+            self._k(st, "snf_hashgrid_bwd_presorted", g, N, L, F, T, ld, col, nrun, gbuf, sorted_ws, stage, tag=tag)
+
+    # -- multi-rank pieces, executed at their place in the replayed list (every rank issues them in the same order) -------
+    def _collective(self, st, kind: str, out: torch.Tensor, inp: torch.Tensor) -> None:
+        with torch.cuda.stream(st):
+            (D._all_gather_into if kind == "all_gather" else D._all_to_all)(out, inp)
+
+    def _copy(self, st, dst: torch.Tensor, src: torch.Tensor) -> None:
+        with torch.cuda.stream(st):
+            dst.copy_(src)
+
+    def _exchange(self, st, group: str, first, last, count_step: bool, done) -> None:
+        """Gradient mean over the ranks + Adam of one replicated group (or slice of it) on stream `st`."""
+        with torch.cuda.stream(st):
+            self.opt.exchange_and_step(group, first, last, count_step=count_step, done=done)
+
+    def _opt_step(self, st, group: str, lo: int, hi: int, done, first=None, last=None, count_step: bool = True) -> None:
+        """Optimizer step of arena elements [lo, hi) of `group`: recorded Adam launches on one rank, the exchange otherwise."""
+        if self.multi:
+            self._py(self._exchange, st, group, first, last, count_step, list(done))
+        else:
+            self._adam(st, group, lo, hi, done)
 
     def _adam(self, st, group: str, lo: int, hi: int, done) -> None:
         a, oc = self.opt.arenas[group], self.opt.config[group]["optimizer"]
@@ -367,18 +424,34 @@ class StepProgram:
             self._k(main, "snf_topk_sharpen", w1, R, S, K, float(cfg.sharpening_temperature), ids, wk)
             uk = b("uk", (NK, 3), parity=parity)
             self._k(main, "snf_positions", o, d, eb1, ids, R, S, K, ops.CONTRACT_L2, 0, uk, None)
+            # table-parallel grids: every rank's top-K positions, gathered once for both heads (rank order)
+            self._tp_layout = ops.table_parallel_layout(tuple(e.spec for e in sf.clip_encs)) if self.multi else None
+            uk_all = None
+            if self._tp_layout is not None:
+                uk_all = b("uk_all", (self.world * NK, 3), parity=parity)
+                self._py(self._collective, main, "all_gather", uk_all, uk)
             for hname in self.heads:  # the heads' forward needs the selected samples only
                 self._edge(main, side[hname], f"selected_{hname}")
             # the SAM and ClipSeg grids share the two level geometries: one sort per geometry, needed by the heads' BACKWARD
             # only -- off the main stream's chain (it sits between the nerfacto forward and its backward there)
             geo_ws = {}
-            for enc in sf.clip_encs:
-                key = ops._geometry_key(enc.scalings, enc.n_levels, enc.log2_hashmap_size)
-                if key not in geo_ws:
-                    ws, nb = self._sort_ws(f"ws_feat{len(geo_ws)}", NK, enc.n_levels, enc.log2_hashmap_size, parity)
-                    self._k(feat_sort_st, "snf_hashgrid_sort", uk, enc.scalings, NK, enc.n_levels, enc.log2_hashmap_size, ws,
-                            nb, tag=f"L{enc.n_levels}")
-                    geo_ws[key] = ws
+            if self._tp_layout is not None:
+                # (the heads share the ownership layout as well: one sort per owned level run, over the gathered positions)
+                for gi, l0, nl, _ in self._tp_layout.runs(self.rank):
+                    enc = sf.clip_encs[gi]
+                    T = enc.log2_hashmap_size
+                    ws, nb = self._sort_ws(f"ws_feat_tp{gi}_{l0}_{nl}", self.world * NK, nl, T, parity)
+                    self._k(feat_sort_st, "snf_hashgrid_sort", uk_all, ops._sc_run(enc.scalings, l0, nl), self.world * NK, nl, T,
+                            ws, nb, tag=f"L{nl}tp")
+                    geo_ws[(gi, l0, nl)] = ws
+            else:
+                for enc in sf.clip_encs:
+                    key = ops._geometry_key(enc.scalings, enc.n_levels, enc.log2_hashmap_size)
+                    if key not in geo_ws:
+                        ws, nb = self._sort_ws(f"ws_feat{len(geo_ws)}", NK, enc.n_levels, enc.log2_hashmap_size, parity)
+                        self._k(feat_sort_st, "snf_hashgrid_sort", uk, enc.scalings, NK, enc.n_levels, enc.log2_hashmap_size, ws,
+                                nb, tag=f"L{enc.n_levels}")
+                        geo_ws[key] = ws
             self._feat_sorted = None
             if any(side[h].stream_id != feat_sort_st.stream_id for h in self.heads):
                 self._feat_sorted = self.event(f"feat_sorted_{parity}")
@@ -426,7 +499,8 @@ class StepProgram:
         if sort_st.stream_id != main.stream_id:
             self._py(main.wait_event, self.event("field_sorted"))
         done_f: list = []
-        self._grid_bwd(main, denc1, N1, fenc, "fields", 0, 0, ws_f, None, with_opt, done_f)
+        fuse_local = with_opt and not self.multi  # across ranks the gradient mean comes first (exchange_and_step)
+        self._grid_bwd(main, denc1, N1, fenc, "fields", 0, 0, ws_f, None, fuse_local, done_f)
         done_p: list = []
         # The proposal network's backward (interlevel loss -> weights -> tiny MLP -> its hash grid) shares nothing with the
         # field's backward but the forward results.  Without feature heads the GPU is otherwise on ONE stream during the
@@ -447,17 +521,17 @@ class StepProgram:
             if sort_st.stream_id != prop_st.stream_id:
                 self._py(prop_st.wait_event, self.event("prop_sorted"))
             stage0 = b("stage_prop", (PL * N0 * PF,))
-            self._grid_bwd(prop_st, denc0, N0, penc, "proposal_networks", PL * PF, 0, ws_p, stage0, with_opt, done_p)
+            self._grid_bwd(prop_st, denc0, N0, penc, "proposal_networks", PL * PF, 0, ws_p, stage0, fuse_local, done_p)
             if with_opt and prop_st.stream_id != main.stream_id:
-                self._adam(prop_st, "proposal_networks", 0, opt.arenas["proposal_networks"].numel, done_p)
+                self._opt_step(prop_st, "proposal_networks", 0, opt.arenas["proposal_networks"].numel, done_p)
             if prop_st.stream_id != main.stream_id:
                 # issue the side chain right after the nerf losses (its inputs), i.e. before the field backward on the host too
                 prop_block = plan.entries[mark:]
                 del plan.entries[mark:]
         if with_opt:
-            self._adam(main, "fields", 0, opt.arenas["fields"].numel, done_f)
+            self._opt_step(main, "fields", 0, opt.arenas["fields"].numel, done_f)
             if (updated and prop_st.stream_id == main.stream_id) or (not updated and prop_adam_when_idle):
-                self._adam(main, "proposal_networks", 0, opt.arenas["proposal_networks"].numel, done_p)
+                self._opt_step(main, "proposal_networks", 0, opt.arenas["proposal_networks"].numel, done_p)
         if prop_block:
             ev_in, ev_out = self.event("prop_bwd_inputs"), self.event("prop_bwd_done")
             at = self._losses_mark
@@ -495,15 +569,36 @@ class StepProgram:
                   and total % 16 == 0 and 64 <= total <= 256)
         ld_enc = -8 if planar else total
         enc_out = b(f"{hname}_enc", (NK * total,) if planar else (NK, total))
-        col = 0
-        for e in encs:
-            L, F, T = e.n_levels, e.n_features_per_level, e.log2_hashmap_size
-            if planar:
-                self._k(st, "snf_hashgrid_fwd", uk, e.params, e.scalings, NK, L, F, T, self._off(enc_out, col * NK * 4), 0, 0,
-                        tag=f"F{F}L{L}")
-            else:
-                self._k(st, "snf_hashgrid_fwd", uk, e.params, e.scalings, NK, L, F, T, enc_out, total, col, tag=f"F{F}L{L}")
-            col += L * F
+        layout = ops.table_parallel_layout(tuple(e.spec for e in encs)) if self.multi else None
+        W = self.world
+        if layout is not None:
+            # Table-parallel: this rank evaluates its level runs at the samples of EVERY rank, one launch per (run, destination)
+            # writing level-major into the send buffer [destination][own level][sample][8]; after the all-to-all the blocks sit in
+            # owner = level order, i.e. `enc_out` is the level-major encoding [total/8][NK][8] the first layer reads.
+            assert planar and self._tp_layout is not None and layout.runs(self.rank) == self._tp_layout.runs(self.rank)
+            per = layout.per
+            uk_all = b("uk_all", (W * NK, 3), parity=parity)
+            send = b(f"{hname}_tp_send", (W * per * NK * 8,))
+            for gi, l0, nl, col in layout.runs(self.rank):
+                e = encs[gi]
+                F, T = e.n_features_per_level, e.log2_hashmap_size
+                slab = self._off(e.params, ((l0 << T) * F) * 4)
+                for w in range(W):
+                    self._k(st, "snf_hashgrid_fwd", self._off(uk_all, w * NK * 12), slab, ops._sc_run(e.scalings, l0, nl), NK, nl, F, T,
+                            self._off(send, ((w * per + col // F) * NK * 8) * 4), 0, 0, tag=f"F{F}L{nl}tp")
+                if not any(e.params is q for q in self._tp_params):
+                    self._tp_params.append(e.params)
+            self._py(self._collective, st, "all_to_all", enc_out, send)
+        else:
+            col = 0
+            for e in encs:
+                L, F, T = e.n_levels, e.n_features_per_level, e.log2_hashmap_size
+                if planar:
+                    self._k(st, "snf_hashgrid_fwd", uk, e.params, e.scalings, NK, L, F, T, self._off(enc_out, col * NK * 4), 0, 0,
+                            tag=f"F{F}L{L}")
+                else:
+                    self._k(st, "snf_hashgrid_fwd", uk, e.params, e.scalings, NK, L, F, T, enc_out, total, col, tag=f"F{F}L{L}")
+                col += L * F
         # the head MLP (tcnn CutlassMLP role): ReLU between layers, no output activation
         acts, x = [enc_out], enc_out
         for i, w in enumerate(ws_):
@@ -584,24 +679,39 @@ class StepProgram:
         col = 0
         if self._feat_sorted is not None and st.stream_id != self._feat_sort_stream_id:
             self._py(st.wait_event, self._feat_sorted)
-        for e in encs:
-            L, F, T = e.n_levels, e.n_features_per_level, e.log2_hashmap_size
-            ws_sorted = geo_ws[ops._geometry_key(e.scalings, L, T)]
-            if planar:  # the first layer's data gradient IS the staged gradient gT[l][n][F] of this grid's levels
-                self._grid_bwd(st, self._off(gy, col * NK * 4), NK, e, "sam_field", 0, 0, ws_sorted, None, with_opt, done)
-            else:
-                stage = b(f"{hname}_stage", (L * NK * F,))
-                self._grid_bwd(st, gy, NK, e, "sam_field", total, col, ws_sorted, stage, with_opt, done)
-            col += L * F
+        if layout is not None:
+            # the first layer's data gradient [owner][own level][NK][8] goes back to the owners; what arrives is
+            # [source rank][own level][NK][8], regrouped to the staged-gradient layout [own level][W*NK][8] of the table backward
+            # over the gathered samples (rank order, like uk_all)
+            per = layout.per
+            grecv = b(f"{hname}_tp_grecv", (W * per * NK * 8,))
+            gstage = b(f"{hname}_tp_gstage", (per * W * NK * 8,))
+            self._py(self._collective, st, "all_to_all", grecv, gy)
+            self._py(self._copy, st, gstage.view(per, W, NK * 8), grecv.view(W, per, NK * 8).transpose(0, 1))
+            for gi, l0, nl, col in layout.runs(self.rank):
+                e = encs[gi]
+                self._grid_bwd(st, self._off(gstage, ((col // 8) * W * NK * 8) * 4), W * NK, e, "sam_field", 0, 0,
+                               geo_ws[(gi, l0, nl)], None, with_opt, done, run=(l0, nl), grad_scale=1.0 / W)
+        else:
+            fuse_local = with_opt and not self.multi
+            for e in encs:
+                L, F, T = e.n_levels, e.n_features_per_level, e.log2_hashmap_size
+                ws_sorted = geo_ws[ops._geometry_key(e.scalings, L, T)]
+                if planar:  # the first layer's data gradient IS the staged gradient gT[l][n][F] of this grid's levels
+                    self._grid_bwd(st, self._off(gy, col * NK * 4), NK, e, "sam_field", 0, 0, ws_sorted, None, fuse_local, done)
+                else:
+                    stage = b(f"{hname}_stage", (L * NK * F,))
+                    self._grid_bwd(st, gy, NK, e, "sam_field", total, col, ws_sorted, stage, fuse_local, done)
+                col += L * F
         if with_opt:
             lo_i, hi_i = self.tr._head_param_ranges()[hname]
             arena = opt.arenas["sam_field"]
             names = list(arena.offsets)
             lo = arena.offsets[names[lo_i]][0]
             hi = arena.offsets[names[hi_i]][0] if hi_i < len(names) else arena.numel
-            self._adam(st, "sam_field", lo, hi, done)
+            self._opt_step(st, "sam_field", lo, hi, done, first=lo_i, last=hi_i, count_step=(hname == self.heads[0]))
             if conv and "conv" in opt.arenas:
-                self._adam(st, "conv", 0, opt.arenas["conv"].numel, ())
+                self._opt_step(st, "conv", 0, opt.arenas["conv"].numel, ())
 
     # ------------------------------------------------------------------------------------------------------------
     # run-time pieces referenced by the recorded schedule
@@ -652,7 +762,7 @@ class StepProgram:
             tr._side = {"sam": ops.make_stream("sam"), "clipseg": ops.make_stream("clipseg")}
         with_opt = bool(opt.enabled)
         parity = self.count & 1
-        key = (parity, updated, with_opt, overlap, tr.presort_host, ops.PRESORT_SIDE_STREAM, tr.zero_grad_adam)
+        key = (parity, updated, with_opt, overlap, tr.presort_host, ops.PRESORT_SIDE_STREAM, tr.zero_grad_adam, self.world)
         plan = self.plans.get(key)
         if plan is None:
             for h in self.heads:  # the targets' buffers exist before the first load
@@ -687,8 +797,12 @@ class StepProgram:
                     fn(*args)
         else:
             self._replay_timed(plan, sel)
-        for g in stepped:
-            opt.step_count[g] += 1
+        if not self.multi:  # (exchange_and_step counts the steps of its group itself)
+            for g in stepped:
+                opt.step_count[g] += 1
+        elif with_opt:
+            for p_ in self._tp_params:  # the other ranks' copies of the owned levels are behind now (refreshed before eval / saving)
+                p_._tp_stale = True
         if updated:
             ps._steps_since_update = 0
         self.count += 1

@@ -575,13 +575,13 @@ if rank == 0:
     torch.save({"losses": losses, **{f"{k}.{n}": getattr(a, n).cpu() for k, a in opt.arenas.items()
                                      for n in ("param", "exp_avg", "exp_avg_sq", "grad")}}, OUT)
 if MODE == "ranks":
-    torch.save({"losses": losses}, OUT + f".rank{rank}")
+    torch.save({"losses": losses, "static": trainer._program is not None, "why_not": trainer._program_off}, OUT + f".rank{rank}")
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
 """
 
 
-def _run_two_rank(tmp_path, nstep: int):
+def _run_two_rank(tmp_path, nstep: int, static: bool = True):
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     base = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "SNF_FORCE_COLLECTIVES")}
@@ -592,20 +592,25 @@ def _run_two_rank(tmp_path, nstep: int):
     assert ref.returncode == 0, ref.stderr[-3000:]
     procs = [subprocess.Popen([sys.executable, "-c", _TWO_RANK_SCRIPT], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
                               env=dict(base, SNF_MODE="ranks", SNF_OUT=rk_out, SNF_DIST_BACKEND="gloo", RANK=str(r),
-                                       LOCAL_RANK=str(r), WORLD_SIZE="2")) for r in range(2)]
+                                       LOCAL_RANK=str(r), WORLD_SIZE="2", SNF_STATIC_STEP="1" if static else "0"))
+             for r in range(2)]
     outs = [p.communicate(timeout=900) for p in procs]
     for p, (so, se) in zip(procs, outs):
         assert p.returncode == 0, se[-3000:]
     a, b = torch.load(ref_out), torch.load(rk_out)
-    l0, l1 = torch.load(rk_out + ".rank0")["losses"], torch.load(rk_out + ".rank1")["losses"]
+    r0, r1 = torch.load(rk_out + ".rank0"), torch.load(rk_out + ".rank1")
+    l0, l1 = r0["losses"], r1["losses"]
+    assert r0["static"] == static and r1["static"] == static, (r0["why_not"], r1["why_not"])  # the path under test is the one that ran
     for step in range(nstep):  # the reference interleaves (step, rank)
         assert abs(l0[step] - a["losses"][2 * step]) <= 2e-4 * abs(a["losses"][2 * step]), (step, l0, a["losses"])
         assert abs(l1[step] - a["losses"][2 * step + 1]) <= 2e-4 * abs(a["losses"][2 * step + 1]), (step, l1, a["losses"])
     return a, b
 
 
-def test_two_ranks_on_one_gpu_match_accumulated_single_process(tmp_path):
-    """The whole multi-GPU train step with the real kernels and two ranks: ray data-parallelism, table-parallel feature grids
+@pytest.mark.parametrize("static", [True, False], ids=["static_schedule", "eager"])
+def test_two_ranks_on_one_gpu_match_accumulated_single_process(tmp_path, static):
+    """The whole multi-GPU train step with the real kernels and two ranks, as the static launch schedule with its recorded
+    collectives (step_program.py, the default) and as the eager autograd path: ray data-parallelism, table-parallel feature grids
     (all-gather / all-to-all in forward and backward), fused backward + Adam on the owned levels, sharded exchange of the
     replicated groups, consolidation.  RCCL refuses two ranks on one device, so the ranks share cuda:0 and the collectives go
     through gloo with host staging (distributed._staged); the arithmetic and the schedule are the product's.  Reference: one
@@ -615,11 +620,11 @@ def test_two_ranks_on_one_gpu_match_accumulated_single_process(tmp_path):
     only (measured 1e-7 of the largest entry).  Three steps check the schedule (step counts, re-zeroing, owned levels,
     consolidation); there Adam (eps 1e-15, scale-free) turns the rounding noise of near-zero gradients into lr-sized
     differences on a vanishing fraction of the entries, so parameters are compared where the first moment is significant."""
-    a, b = _run_two_rank(tmp_path, 1)
+    a, b = _run_two_rank(tmp_path, 1, static)
     for k in [k for k in a if k.endswith(".exp_avg")]:
         scale = float(a[k].abs().max())
         assert scale > 0 and float((a[k] - b[k]).abs().max()) <= 1e-5 * scale, (k, scale, float((a[k] - b[k]).abs().max()))
-    a, b = _run_two_rank(tmp_path, 3)
+    a, b = _run_two_rank(tmp_path, 3, static)
     for k in a:
         if k == "losses":
             continue
