@@ -164,6 +164,10 @@ template <int F> constexpr int hg_chunk() { return 2048; }
 constexpr int HG_MAX_RPB = 2048; // rows per bucket (HG_ROWS_PT per reduce thread)
 constexpr int HG_ROWS_PT = HG_MAX_RPB / HG_RT;
 constexpr int HG_LONG = 16;      // segments longer than this are reduced by a wave
+#ifndef SNF_HG_EPI
+#define SNF_HG_EPI 2
+#endif
+constexpr int HG_EPI = SNF_HG_EPI;  // rows per thread in flight in the fused Adam epilogue of the float reduce
 
 struct HgGeom {
     int log2B, log2rpb, spt, nblk;  // buckets, rows per bucket, samples per thread in count/scatter, tiles
@@ -642,14 +646,14 @@ __global__ __launch_bounds__(HG_RT) void k_hg_reduce(const float* __restrict__ g
     }
     if constexpr (ADAM) {
         if (fuse) {
-            // ---- fused optimizer epilogue: every owned row, two rows (6 row loads) in flight per thread
+            // ---- fused optimizer epilogue: every owned row, HG_EPI rows (3 row loads each) in flight per thread
             const size_t base = (((size_t)l << log2_T) + ((size_t)b << log2rpb)) * F;
 #pragma unroll
-            for (int q0 = 0; q0 < HG_ROWS_PT; q0 += 2) {
-                float pp[2][F], mm[2][F], vv[2][F], gg[2][F];
-                bool on[2];
+            for (int q0 = 0; q0 < HG_ROWS_PT; q0 += HG_EPI) {
+                float pp[HG_EPI][F], mm[HG_EPI][F], vv[HG_EPI][F], gg[HG_EPI][F];
+                bool on[HG_EPI];
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
+                for (int j = 0; j < HG_EPI; ++j) {
                     const int r = tid + (q0 + j) * HG_RT;
                     on[j] = r < rpb;
                     if (on[j]) {
@@ -661,7 +665,7 @@ __global__ __launch_bounds__(HG_RT) void k_hg_reduce(const float* __restrict__ g
                     }
                 }
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
+                for (int j = 0; j < HG_EPI; ++j) {
                     if (on[j]) {
                         const int r = tid + (q0 + j) * HG_RT;
                         const size_t o = base + (size_t)r * F;

@@ -56,6 +56,11 @@ FUSED_CHAIN_WGRAD = _os.environ.get("SNF_FUSED_CHAIN_WGRAD", "1") == "1"  # weig
 _pbs = _os.environ.get("SNF_PROP_BWD_SIDE")
 PROP_BWD_SIDE = None if _pbs is None else (_pbs == "1")  # None: on the side stream only when there are no feature heads
 FEATURE_SORTS_ON_HEAD_STREAM = _os.environ.get("SNF_FEAT_SORT_SIDE", "1") == "1"
+# Without feature heads the step is ONE dependency chain on the main stream.  Its head -- sampling, the proposal network, the
+# resampling, the positions and the backward sorts -- needs last step's PROPOSAL update only, not the field's: it is recorded on
+# the side stream (where the proposal backward + Adam of the previous step already ran) and so runs under the tail of the
+# previous step's field backward.  What it produces and the main stream reads late is double-buffered by step parity.
+XSTEP_PROLOGUE = _os.environ.get("SNF_XSTEP_PROLOGUE", "1") == "1"
 
 
 class _Plan:
@@ -316,19 +321,10 @@ class StepProgram:
                     tag=f"{I}x{O}")
 
     # ------------------------------------------------------------------------------------------------------------
-    def _build(self, parity: int, updated: bool, with_opt: bool, overlap: bool, prop_adam_when_idle: bool) -> _Plan:
-        plan = self._plan = _Plan()
-        self._keep: list = getattr(self, "_keep", [])
-        model, cfg, opt = self.model, self.cfg, self.opt
-        R, P, S, K = self.R, self.P, self.S, self.K
-        N0, N1, NK = R * P, R * S, R * K
+    def _side_streams(self, overlap: bool):
+        """(head streams, stream of the forward-time sorts, stream of the feature sorts, stream of the step's prologue)."""
         main = self.main
         side = {h: (self.tr._side[h] if overlap else main) for h in self.heads}
-        # The backward sorts depend on positions only; they run beside the forward on the LEAST loaded stream.  With the steps
-        # pipelined (no join at the end of a step) the SAM stream is the busiest of the three (two 256-wide layers, the conv
-        # head, 0.4 GB of table Adam): event timeline of r02d: 3.8 / 3.6 / 2.4 ms busy per 4.06 ms step for sam / main /
-        # clipseg with the sorts on the sam stream -- so they ride on the clipseg stream (SNF_PRESORT_ON overrides); a run
-        # without feature heads gets a stream of its own for them.
         sort_st = feat_sort_st = main
         if overlap and ops.PRESORT_SIDE_STREAM:
             pref = self.tr.presort_host
@@ -341,14 +337,32 @@ class StepProgram:
                     self._own_sort_stream = ops.make_stream("presort")
                 sort_st = self._own_sort_stream
             feat_sort_st = side.get("clipseg", main) if FEATURE_SORTS_ON_HEAD_STREAM else main
+        xstep = XSTEP_PROLOGUE and not self.heads and not self.multi and sort_st.stream_id != main.stream_id
+        return side, sort_st, feat_sort_st, (sort_st if xstep else main)
+
+    def _build(self, parity: int, updated: bool, with_opt: bool, overlap: bool, prop_adam_when_idle: bool) -> _Plan:
+        plan = self._plan = _Plan()
+        self._keep: list = getattr(self, "_keep", [])
+        model, cfg, opt = self.model, self.cfg, self.opt
+        R, P, S, K = self.R, self.P, self.S, self.K
+        N0, N1, NK = R * P, R * S, R * K
+        main = self.main
+        # The backward sorts depend on positions only; they run beside the forward on the LEAST loaded stream.  With the steps
+        # pipelined (no join at the end of a step) the SAM stream is the busiest of the three (two 256-wide layers, the conv
+        # head, 0.4 GB of table Adam): event timeline of r02d: 3.8 / 3.6 / 2.4 ms busy per 4.06 ms step for sam / main /
+        # clipseg with the sorts on the sam stream -- so they ride on the clipseg stream (SNF_PRESORT_ON overrides); a run
+        # without feature heads gets a stream of its own for them.
+        side, sort_st, feat_sort_st, pre = self._side_streams(overlap)
+        xstep = pre.stream_id != main.stream_id  # the step's prologue runs on the side stream, under the previous step's tail
+        pp = parity if xstep else None
         f32 = torch.float32
         b = self.buf
         ACT = ops
 
         # ---- inputs (filled by `_load_inputs` before the replay) and constants
-        o, d = b("in_o", (R, 3)), b("in_d", (R, 3))
-        image = b("in_image", (R, 3))
-        t_rand, u_rand = b("in_t_rand", (R,)), b("in_u_rand", (R,))
+        o, d = b("in_o", (R, 3), parity=pp), b("in_d", (R, 3), parity=pp)
+        image = b("in_image", (R, 3), parity=pp)
+        t_rand, u_rand = b("in_t_rand", (R,), parity=pp), b("in_u_rand", (R,), parity=pp)
         if "nears" not in self.bufs:
             b("nears", (R,)).fill_(float(model.collider.near_plane))
             b("fars", (R,)).fill_(float(model.collider.far_plane))
@@ -356,32 +370,34 @@ class StepProgram:
         nears, fars, one = b("nears", (R,)), b("fars", (R,)), b("one", (1,))
 
         # ================= main stream: proposal sampler (ray_samplers.py:549-599) =================
+        if xstep:  # last step's nerf losses (the last main-stream readers of what this block overwrites) are through
+            self._py(pre.wait_event, self.event("losses_done"))
         prop = model.proposal_networks[0]
         penc, pnet = prop.mlp_base.encoding, prop.mlp_base.network
         pw0, pw1 = pnet.weights()
         PL, PF, PT = penc.n_levels, penc.n_features_per_level, penc.log2_hashmap_size
         sb0, eb0 = b("sb0", (R, P + 1)), b("eb0", (R, P + 1))
-        self._k(main, "snf_sample_spacing", nears, fars, t_rand, R, P, sb0, eb0)
+        self._k(pre, "snf_sample_spacing", nears, fars, t_rand, R, P, sb0, eb0)
         u0, sel0 = b("u0", (N0, 3)), b("sel0", (N0,), torch.uint8)
-        self._k(main, "snf_positions", o, d, eb0, None, R, P, P, ops.CONTRACT_LINF, 1, u0, sel0)
+        self._k(pre, "snf_positions", o, d, eb0, None, R, P, P, ops.CONTRACT_LINF, 1, u0, sel0)
         if updated:
             ws_p, ws_p_bytes = self._sort_ws("ws_prop", N0, PL, PT)
-            self._edge(main, sort_st, "u0_ready")
+            self._edge(pre, sort_st, "u0_ready")
             self._k(sort_st, "snf_hashgrid_sort", u0, penc.scalings, N0, PL, PT, ws_p, ws_p_bytes, tag=f"L{PL}")
             if sort_st.stream_id != main.stream_id:
                 self._py(self.event("prop_sorted").record, sort_st)
         enc0 = b("enc0", (N0, PL * PF))
-        self._k(main, "snf_hashgrid_fwd", u0, penc.params, penc.scalings, N0, PL, PF, PT, enc0, PL * PF, 0, tag=f"F{PF}L{PL}")
+        self._k(pre, "snf_hashgrid_fwd", u0, penc.params, penc.scalings, N0, PL, PF, PT, enc0, PL * PF, 0, tag=f"F{PF}L{PL}")
         I0, H0 = pnet.n_input_dims, pw0.shape[0]
         hid0 = b("hid0", (N0, H0)) if updated else None
         raw0 = b("raw0", (N0, 1))
-        self._k(main, "snf_mlp_tiny_fwd", enc0, I0, pw0, pw1, I0, H0, N0, hid0, raw0, tag=f"{I0}x{H0}x1")
+        self._k(pre, "snf_mlp_tiny_fwd", enc0, I0, pw0, pw1, I0, H0, N0, hid0, raw0, tag=f"{I0}x{H0}x1")
         dens0 = b("dens0", (N0,))
-        self._k(main, "snf_trunc_exp_fwd", raw0, 1, sel0, N0, dens0)
+        self._k(pre, "snf_trunc_exp_fwd", raw0, 1, sel0, N0, dens0)
         w0 = b("w0", (R, P))
-        self._k(main, "snf_weights_fwd", dens0, 1, 1, None, eb0, R, P, w0, None)
-        sb1, eb1 = b("sb1", (R, S + 1)), b("eb1", (R, S + 1))
-        self._k(main, "snf_pdf_resample", w0, sb0, u_rand, nears, fars, R, P, S, 1.0,
+        self._k(pre, "snf_weights_fwd", dens0, 1, 1, None, eb0, R, P, w0, None)
+        sb1, eb1 = b("sb1", (R, S + 1), parity=pp), b("eb1", (R, S + 1), parity=pp)
+        self._k(pre, "snf_pdf_resample", w0, sb0, u_rand, nears, fars, R, P, S, 1.0,
                 float(model.proposal_sampler.pdf_sampler.histogram_padding), sb1, eb1, dyn={("anneal",): 8})
 
         # ================= main stream: nerfacto field (ops._NerfactoField) =================
@@ -389,10 +405,11 @@ class StepProgram:
         bw0, bw1 = fbase.weights()
         hw0, hw1, hw2 = fhead.weights()
         FL, FF, FT = fenc.n_levels, fenc.n_features_per_level, fenc.log2_hashmap_size
-        u1, sel1 = b("u1", (N1, 3)), b("sel1", (N1,), torch.uint8)
-        self._k(main, "snf_positions", o, d, eb1, None, R, S, S, ops.CONTRACT_LINF, 1, u1, sel1)
-        ws_f, ws_f_bytes = self._sort_ws("ws_field", N1, FL, FT)
-        self._edge(main, sort_st, "u1_ready")
+        u1, sel1 = b("u1", (N1, 3), parity=pp), b("sel1", (N1,), torch.uint8, parity=pp)
+        self._k(pre, "snf_positions", o, d, eb1, None, R, S, S, ops.CONTRACT_LINF, 1, u1, sel1)
+        ws_f, ws_f_bytes = self._sort_ws("ws_field", N1, FL, FT, pp)
+        self._edge(pre, sort_st, "u1_ready")
+        self._edge(pre, main, "prologue_done")
         self._k(sort_st, "snf_hashgrid_sort", u1, fenc.scalings, N1, FL, FT, ws_f, ws_f_bytes, tag=f"L{FL}")
         if sort_st.stream_id != main.stream_id:
             self._py(self.event("field_sorted").record, sort_st)
@@ -471,6 +488,8 @@ class StepProgram:
         summary = b("loss_summary", (8,))
         self._k(main, "snf_nerf_loss_summary", mse_out, rows_i, float(cfg.interlevel_loss_mult) / float(R * S), rows_d,
                 1.0 / float(R), float(cfg.distortion_loss_mult), R, summary)
+        if xstep:
+            self._py(self.event("losses_done").record, main)
         self._losses_mark = len(plan.entries)  # the proposal backward's inputs exist from here on
 
         # ================= feature heads: one task per head on its own stream =================
@@ -506,7 +525,7 @@ class StepProgram:
         # field's backward but the forward results.  Without feature heads the GPU is otherwise on ONE stream during the
         # backward, so that chain goes to the (then idle) sort stream and runs beside the field backward; with heads the three
         # streams already saturate the chip and it stays on the main stream (SNF_PROP_BWD_SIDE=1/0 overrides).
-        side_prop = PROP_BWD_SIDE if PROP_BWD_SIDE is not None else (not self.heads)
+        side_prop = True if xstep else (PROP_BWD_SIDE if PROP_BWD_SIDE is not None else (not self.heads))
         prop_st = sort_st if (updated and side_prop and sort_st.stream_id != main.stream_id) else main
         prop_block = []
         if updated:
@@ -531,14 +550,17 @@ class StepProgram:
         if with_opt:
             self._opt_step(main, "fields", 0, opt.arenas["fields"].numel, done_f)
             if (updated and prop_st.stream_id == main.stream_id) or (not updated and prop_adam_when_idle):
-                self._opt_step(main, "proposal_networks", 0, opt.arenas["proposal_networks"].numel, done_p)
+                # (a step without a proposal backward: zero gradients, the moments decay.  With the prologue on the side stream
+                # it goes there too -- the next prologue reads these parameters)
+                self._opt_step(pre, "proposal_networks", 0, opt.arenas["proposal_networks"].numel, done_p)
         if prop_block:
             ev_in, ev_out = self.event("prop_bwd_inputs"), self.event("prop_bwd_done")
             at = self._losses_mark
             block = [[_PY, ev_in.record, [main], None, 0.0, None], [_PY, prop_st.wait_event, [ev_in], None, 0.0, None]] + prop_block \
                     + [[_PY, ev_out.record, [prop_st], None, 0.0, None]]
             plan.entries[at:at] = block
-            self._py(main.wait_event, ev_out)  # the next step's proposal forward reads the stepped parameters
+            if not xstep:
+                self._py(main.wait_event, ev_out)  # the next step's proposal forward reads the stepped parameters
         self._plan = None
         return plan
 
@@ -724,29 +746,37 @@ class StepProgram:
         self.event(f"head_done_{hname}_{parity}").record(st)
         self._head_busy[(parity, hname)] = True
 
-    def _load_inputs(self, step: int, parity: int) -> None:
+    def _load_inputs(self, step: int, parity: int, overlap: bool) -> None:
         """next_train(step) into the schedule's input buffers; the samplers' per-ray jitter (ray_samplers.py:105,318)."""
         dm = self.tr.pipeline.datamanager
-        b = self.buf
         R = self.R
-        into = getattr(dm, "next_train_into", None)
-        targets = {h: self.bufs[f"in_{h}@{parity}"] for h in self.heads}
-        if into is not None and "next_train" not in dm.__dict__:
-            into(step, b("in_o", (R, 3)), b("in_d", (R, 3)), b("in_image", (R, 3)), targets)
-        else:
-            rb, batch = dm.next_train(step)
-            b("in_o", (R, 3)).copy_(rb.origins.reshape(R, 3))
-            b("in_d", (R, 3)).copy_(rb.directions.reshape(R, 3))
-            b("in_image", (R, 3)).copy_(batch["image"].reshape(R, 3))
-            for h, t in targets.items():
-                t.copy_(batch[h].reshape(t.shape))
-        ps = self.model.proposal_sampler
-        for smp, name in ((ps.initial_sampler, "in_t_rand"), (ps.pdf_sampler, "in_u_rand")):
-            dst = b(name, (R,))
-            if smp.jitter_override is not None:
-                dst.copy_(smp.jitter_override.reshape(-1))
+        _, _, _, pre = self._side_streams(overlap)
+        xstep = pre.stream_id != self.main.stream_id
+        pp = parity if xstep else None
+        if xstep:
+            # the prologue's stream loads its own inputs (parity buffers: the previous step's backward still reads the other set);
+            # what this parity held was last read two steps ago, which the previous step's losses (awaited here) came after
+            pre.wait_event(self.event("losses_done"))
+        b = lambda name, shape: self.buf(name, shape, parity=pp)  # noqa: E731
+        with torch.cuda.stream(pre):
+            into = getattr(dm, "next_train_into", None)
+            targets = {h: self.bufs[f"in_{h}@{parity}"] for h in self.heads}
+            if into is not None and "next_train" not in dm.__dict__:
+                into(step, b("in_o", (R, 3)), b("in_d", (R, 3)), b("in_image", (R, 3)), targets)
             else:
-                torch.rand((R,), out=dst)
+                rb, batch = dm.next_train(step)
+                b("in_o", (R, 3)).copy_(rb.origins.reshape(R, 3))
+                b("in_d", (R, 3)).copy_(rb.directions.reshape(R, 3))
+                b("in_image", (R, 3)).copy_(batch["image"].reshape(R, 3))
+                for h, t in targets.items():
+                    t.copy_(batch[h].reshape(t.shape))
+            ps = self.model.proposal_sampler
+            for smp, name in ((ps.initial_sampler, "in_t_rand"), (ps.pdf_sampler, "in_u_rand")):
+                dst = b(name, (R,))
+                if smp.jitter_override is not None:
+                    dst.copy_(smp.jitter_override.reshape(-1))
+                else:
+                    torch.rand((R,), out=dst)
 
     # ------------------------------------------------------------------------------------------------------------
     def run(self, step: int):
@@ -772,7 +802,7 @@ class StepProgram:
         if overlap:  # a head task of this parity (two steps ago) may still be reading the buffers this step overwrites
             for h in self.heads:
                 self._wait_head_free(self.main, parity, h)
-        self._load_inputs(step, parity)
+        self._load_inputs(step, parity, overlap)
         # ---- this step's dynamic values
         stepped = []
         if with_opt:

@@ -88,6 +88,42 @@ def test_trajectory_follows_the_eager_path(overlap):
     del upd
 
 
+def test_prologue_on_the_side_stream_keeps_the_trajectory(monkeypatch):
+    """samnerf_no_distill: the head of step t+1 (sampling, proposal network, resampling, sorts) runs on the side stream under the
+    field backward of step t, on parity buffers.  Steps are enqueued back to back (no host synchronisation in between, so the
+    overlap is real).  After 2 steps the field group's first moments are BIT-identical to the serial schedule's (its kernels
+    are order-independent; the proposal network's tiny-MLP weight gradients use float atomics).  After 16 steps (update and
+    non-update steps, both parities) the two schedules differ by no more than the serial schedule differs from itself run to
+    run (the atomics' rounding noise, amplified by Adam: 1e-3 of the largest moment, so the bound is 10x the measured noise or
+    2 % of the largest moment) -- a clobbered or stale buffer changes the samples of a step, i.e. the gradient by O(1)."""
+    from samnerf_amd import step_program
+
+    def run(on: bool, steps: int):
+        monkeypatch.setattr(step_program, "XSTEP_PROLOGUE", on)
+        tr = _trainer("samnerf_no_distill", True, 1024, 13, P=64, S=64)
+        tr.pipeline_steps = True
+        torch.manual_seed(17)
+        for step in range(steps):
+            tr.train_iteration(step)
+        tr.synchronize()
+        torch.cuda.synchronize()
+        prog = tr._program
+        _, _, _, pre = prog._side_streams(True)
+        assert (pre.stream_id != prog.main.stream_id) == on
+        return {g: a.exp_avg.clone() for g, a in tr.optimizers.arenas.items()}, dict(tr.optimizers.step_count)
+
+    (a, ca), (c, cc) = run(False, 2), run(True, 2)
+    assert ca == cc
+    assert torch.equal(a["fields"], c["fields"])
+    assert _rel_to_max(c["proposal_networks"], a["proposal_networks"]) <= 1e-4  # (float atomics: 1.4e-5 seen run to run)
+    (a, ca), (b, _), (c, cc) = run(False, 16), run(False, 16), run(True, 16)
+    assert ca == cc
+    for g in a:
+        noise = float((a[g] - b[g]).abs().max())
+        diff = float((a[g] - c[g]).abs().max())
+        assert diff <= max(10.0 * noise, 2e-2 * float(a[g].abs().max())), (g, diff, noise, float(a[g].abs().max()))
+
+
 def test_proposal_group_is_stepped_with_zero_gradient_on_non_update_steps():
     """Reference semantics (torch < 2 pinned, requirements.txt:32): zero_grad() zero-fills, so on a step where the proposal
     network gets no gradient Adam still decays its moments and moves the parameters; SNF_TORCH2_NONE_GRADS=1 skips."""

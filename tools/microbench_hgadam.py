@@ -17,6 +17,8 @@ CASES = {  # N, L, F, T, base, max, planar gradient, clustered positions
     "f2": (524288, 16, 2, 19, 16, 2048, True, True),
     "f2p": (262144, 5, 2, 17, 16, 128, False, True),
     # probes of the coarse-level tail: the same sample counts with every level hashed (no bucket holds more than 8N/256 records)
+    "f8a_sparse": (65536, 8, 8, 19, 16, 90, True, False),   # the reachable-row levels of f8a alone
+    "f8a_dense": (65536, 4, 8, 19, 99, 128, True, False),   # its dense levels alone
     "f2_fine": (524288, 16, 2, 19, 256, 2048, True, True),
     "f2p_fine": (262144, 5, 2, 17, 128, 512, False, True),
 }
@@ -71,7 +73,15 @@ for name in os.environ.get("CASES", "f8b,f8a,f2,f2p").split(","):
     nrun = int(os.environ.get("NRUN", nrun))
     ops._launch("snf_hashgrid_sort", ops._p(u), ops._p(sc), N, L, T, ops._p(ws), nbytes, st)
 
+    fx8 = F == 8 and os.environ.get("FX8") == "1"  # the fixed-point reduce for an F = 8 grid (snf_hashgrid_bwd_presorted_adam_fx)
+    scratch = torch.zeros((64,), device="cuda", dtype=torch.int32)
+
     def launch(step):
+        if fx8:
+            ops._launch("snf_hashgrid_bwd_presorted_adam_fx", ops._p(gy), N, L, F, T, ld, 0, nrun, ops._p(g), ops._p(ws),
+                        None if planar else ops._p(stage), n_sparse, ops._p(p), ops._p(m), ops._p(v), 5e-4, 0.9, 0.999, 1e-15, step,
+                        1.0, ops._p(scratch), st)
+            return
         ops._launch("snf_hashgrid_bwd_presorted_adam", ops._p(gy), N, L, F, T, ld, 0, nrun, ops._p(g), ops._p(ws),
                     None if planar else ops._p(stage), n_sparse, ops._p(p), ops._p(m), ops._p(v), 5e-4, 0.9, 0.999, 1e-15, step,
                     1.0, st)
