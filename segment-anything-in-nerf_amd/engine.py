@@ -349,11 +349,31 @@ class Optimizers:
             self.sched_step[k] += 1
 
     def state_dict(self) -> Dict[str, Any]:
-        return {k: {"exp_avg": a.exp_avg, "exp_avg_sq": a.exp_avg_sq, "step": self.step_count[k],
-                    "sched_step": self.sched_step[k]} for k, a in self.arenas.items()}
+        """Per group: Adam's step count, the scheduler position and the moments PER PARAMETER, keyed by the parameter's name in
+        registration order -- the order torch.optim numbers its `state` entries in, so entry i of the reference's
+        `{group: optimizer.state_dict()}` (trainer.py:399-401) is the i-th name here.  The tensors are views of the arenas (no
+        padding travels).  Multi-rank: call `consolidate_state()` on EVERY rank first (it is a collective)."""
+        out = {}
+        for k, a in self.arenas.items():
+            state = {}
+            for name, (off, shape) in a.offsets.items():
+                n = int(np.prod(shape)) if len(shape) else 1
+                state[name] = {"exp_avg": a.exp_avg[off:off + n].view(shape), "exp_avg_sq": a.exp_avg_sq[off:off + n].view(shape)}
+            out[k] = {"step": self.step_count[k], "sched_step": self.sched_step[k], "state": state}
+        return out
 
     def load_optimizers(self, loaded_state: Dict[str, Any]) -> None:
         for k, v in loaded_state.items():
-            self.arenas[k].exp_avg.copy_(v["exp_avg"])
-            self.arenas[k].exp_avg_sq.copy_(v["exp_avg_sq"])
+            a = self.arenas[k]
+            if "state" in v:
+                missing = set(a.offsets) - set(v["state"])
+                if missing:
+                    raise KeyError(f"optimizer state of group {k!r} lacks {sorted(missing)}")
+                for name, (off, shape) in a.offsets.items():
+                    n = int(np.prod(shape)) if len(shape) else 1
+                    a.exp_avg[off:off + n].copy_(v["state"][name]["exp_avg"].reshape(-1))
+                    a.exp_avg_sq[off:off + n].copy_(v["state"][name]["exp_avg_sq"].reshape(-1))
+            else:  # flat arenas (checkpoints written before the per-parameter layout)
+                a.exp_avg.copy_(v["exp_avg"])
+                a.exp_avg_sq.copy_(v["exp_avg_sq"])
             self.step_count[k], self.sched_step[k] = v["step"], v["sched_step"]

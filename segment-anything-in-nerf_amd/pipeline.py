@@ -373,10 +373,15 @@ class Trainer:
                 main.wait_stream(st)
 
     def save_checkpoint(self, path: str, step: int) -> None:
-        """trainer.py:379-406: {step, pipeline state_dict, optimizers}."""
+        """trainer.py:379-406: {step, pipeline state_dict, optimizers}.  COLLECTIVE on a multi-rank run: every rank calls it
+        (the table-parallel levels and the sharded Adam moments are gathered first), rank 0 writes the file -- the reference's
+        `if self.local_rank == 0: save` pattern around this call would deadlock in consolidate_state."""
         self.synchronize()
         self.optimizers.consolidate_state()
-        torch.save({"step": step, "pipeline": self.pipeline.state_dict(), "optimizers": self.optimizers.state_dict()}, path)
+        if not D.collectives_on() or torch.distributed.get_rank() == 0:
+            torch.save({"step": step, "pipeline": self.pipeline.state_dict(), "optimizers": self.optimizers.state_dict()}, path)
+        if D.collectives_on():
+            torch.distributed.barrier()
 
     def load_checkpoint(self, path: str) -> int:
         st = torch.load(path, map_location=self.device)

@@ -411,6 +411,18 @@ def _engine_worker(rank, world, port, q, table_parallel):
     opt.consolidate_state()
     for got, ref in ((a.param, pr), (a.exp_avg, mr), (a.exp_avg_sq, vr)):
         ok = ok and torch.allclose(got, ref, rtol=1e-5, atol=1e-7)
+    # checkpoint payload: per-parameter moments keyed by name (whole on every rank after the consolidation) into a fresh optimizer
+    sd = copy.deepcopy(opt.state_dict())
+    ok = ok and list(sd["sam_field"]["state"]) == names and sd["sam_field"]["step"] == 3
+    ok = ok and all(v["exp_avg"].shape == tuple(a.offsets[n][1]) for n, v in sd["sam_field"]["state"].items())
+    arenas2 = mc.setup(scene_box=model.SceneBox(), num_train_data=2, device="cpu").build_arenas()
+    opt2 = engine.Optimizers(copy.deepcopy(configs.method_configs["samnerf_distill"].optimizers), arenas2)
+    opt2.load_optimizers(sd)
+    a2 = arenas2["sam_field"]
+    for name, (off, shape) in a.offsets.items():
+        n = int(np.prod(shape))
+        ok = ok and torch.equal(a2.exp_avg[off:off + n], a.exp_avg[off:off + n]) and torch.equal(a2.exp_avg_sq[off:off + n], a.exp_avg_sq[off:off + n])
+    ok = ok and opt2.step_count["sam_field"] == 3
     q.put((rank, bool(ok)))
     torch.distributed.destroy_process_group()
 
