@@ -159,7 +159,7 @@ def set_exchange_mode(mode: str) -> None:
     os.environ["SNF_SHARDED_OPTIMIZER"] = "1" if tp else "0"
 
 
-def quick_measure(name: str, rank: int, local_rank: int, world: int, steps: int = 10, warmup: int = 4) -> dict:
+def quick_measure(name: str, rank: int, local_rank: int, world: int, steps: int = 20, warmup: int = 6) -> dict:
     """Short run of another BASELINE workload (no serial replay, no breakdown): ms per step and the metric."""
     w = dict(WORKLOADS[name], world=world)
     trainer = build_trainer(w, local_rank, world)

@@ -795,10 +795,17 @@ class StepProgram:
         key = (parity, updated, with_opt, overlap, tr.presort_host, ops.PRESORT_SIDE_STREAM, tr.zero_grad_adam, self.world)
         plan = self.plans.get(key)
         if plan is None:
-            for h in self.heads:  # the targets' buffers exist before the first load
-                rows = self.R // (self.cfg.patch_size ** 2) if (h == "sam" and self.cfg.patch_size > 1) else self.R
-                self.buf(f"in_{h}", (rows, 256 if h == "sam" else 192), parity=parity)
-            plan = self.plans[key] = self._build(parity, updated, with_opt, overlap, tr.zero_grad_adam)
+            # build every variant of this configuration now (both buffer parities x proposal update or not): the first step pays
+            # for all of them, no later step stalls the host in the middle of a run
+            for par in (parity, parity ^ 1):
+                for h in self.heads:  # the targets' buffers exist before the first load
+                    rows = self.R // (self.cfg.patch_size ** 2) if (h == "sam" and self.cfg.patch_size > 1) else self.R
+                    self.buf(f"in_{h}", (rows, 256 if h == "sam" else 192), parity=par)
+                for upd in (updated, not updated):
+                    k2 = (par, upd) + key[2:]
+                    if k2 not in self.plans:
+                        self.plans[k2] = self._build(par, upd, with_opt, overlap, tr.zero_grad_adam)
+            plan = self.plans[key]
         if overlap:  # a head task of this parity (two steps ago) may still be reading the buffers this step overwrites
             for h in self.heads:
                 self._wait_head_free(self.main, parity, h)
