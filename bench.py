@@ -60,8 +60,11 @@ def algorithmic_model(key: str, w: dict):
         return "hbm", float(n * L * 8 * F * 4 * rw), "GB/s"
     if name.startswith("snf_linear"):
         pm = tag.endswith("pm")  # conv head: second convolution, on the patch means
-        i, o = (int(x) for x in tag.rstrip("pm").split("x"))
-        if i >= 1024:  # conv head as GEMMs: first convolution on every ray row, second on the patch means
+        rendered = tag.endswith("r")  # a head's last layer, after the weighted mean over the K samples: one row per ray
+        i, o = (int(x) for x in tag.rstrip("pmr").split("x"))
+        if rendered:
+            n = R
+        elif i >= 1024:  # conv head as GEMMs: first convolution on every ray row, second on the patch means
             n = R // (w["patch"] ** 2) if pm else R
         else:
             n = R * K if max(i, o) >= 192 else R * S

@@ -56,6 +56,12 @@ FUSED_CHAIN_WGRAD = _os.environ.get("SNF_FUSED_CHAIN_WGRAD", "1") == "1"  # weig
 _pbs = _os.environ.get("SNF_PROP_BWD_SIDE")
 PROP_BWD_SIDE = None if _pbs is None else (_pbs == "1")  # None: on the side stream only when there are no feature heads
 FEATURE_SORTS_ON_HEAD_STREAM = _os.environ.get("SNF_FEAT_SORT_SIDE", "1") == "1"
+# The head's last layer is linear (no bias, no output activation) and the renderer after it is a weighted sum over the K samples
+# of a ray (MeanRenderer, sam_model.py:126-137; the weights are detached, sam_model.py:260-277):
+#     sum_k w_k (W h_k)  =  W (sum_k w_k h_k)
+# so the schedule renders the HIDDEN activations [R*K, 256] -> [R, 256] first and runs the last layer -- forward, data gradient,
+# weight gradient -- on R rows instead of R*K.  Same real-number result, fp32 rounding in a different order (1e-7).
+MEAN_BEFORE_LAST_LAYER = _os.environ.get("SNF_MEAN_BEFORE_LAST", "1") == "1"
 # Without feature heads the step is ONE dependency chain on the main stream.  Its head -- sampling, the proposal network, the
 # resampling, the positions and the backward sorts -- needs last step's PROPOSAL update only, not the field's: it is recorded on
 # the side stream (where the proposal backward + Adam of the previous step already ran) and so runs under the tail of the
@@ -623,16 +629,26 @@ class StepProgram:
                 col += L * F
         # the head MLP (tcnn CutlassMLP role): ReLU between layers, no output activation
         acts, x = [enc_out], enc_out
-        for i, w in enumerate(ws_):
+        nl = len(ws_)
+        commute = (MEAN_BEFORE_LAST_LAYER and nl >= 2 and net.output_activation == ops.ACT_NONE and ws_[-1].shape[1] % 4 == 0)
+        for i, w in enumerate(ws_[:nl - 1] if commute else ws_):
             O, I = w.shape
             y = b(f"{hname}_a{i}", (NK, O))
-            act = ops.ACT_RELU if i < len(ws_) - 1 else net.output_activation
+            act = ops.ACT_RELU if i < nl - 1 else net.output_activation
             self._k(st, "snf_linear_fwd", x, w, None, NK, I, O, ld_enc if i == 0 else I, O, act, y, tag=f"{I}x{O}")
             acts.append(y)
             x = y
-        Cf = x.shape[1]
-        fm = b(f"{hname}_fm", (R, Cf))
-        self._k(st, "snf_feature_mean_fwd", x, wk, R, K, Cf, fm)
+        if commute:
+            w_last = ws_[-1]
+            Cf, Ih = w_last.shape
+            hbar = b(f"{hname}_hbar", (R, Ih))
+            self._k(st, "snf_feature_mean_fwd", x, wk, R, K, Ih, hbar)
+            fm = b(f"{hname}_fm", (R, Cf))
+            self._k(st, "snf_linear_fwd", hbar, w_last, None, R, Ih, Cf, Ih, Cf, ops.ACT_NONE, fm, tag=f"{Ih}x{Cf}r")
+        else:
+            Cf = x.shape[1]
+            fm = b(f"{hname}_fm", (R, Cf))
+            self._k(st, "snf_feature_mean_fwd", x, wk, R, K, Cf, fm)
         conv = hname == "sam" and cfg.patch_size > 1
         if conv:
             c0, c1 = model.conv_head[0], model.conv_head[2]
@@ -678,14 +694,23 @@ class StepProgram:
             self._k(st, "snf_patch_fold", dcol, R, p, Cf, k, dfm)
         else:
             dfm = dpred
-        gy = b(f"{hname}_dfeat", (NK, Cf))
-        self._k(st, "snf_feature_mean_bwd", dfm, wk, R, K, Cf, gy)
         wgrad_bytes = max(int(self.lib.snf_linear_bwd_weight_workspace_bytes(NK, w.shape[1], w.shape[0])) for w in ws_)
         wgrad_ws = b(f"{hname}_wgrad_ws", (max(wgrad_bytes, 16) // 4,))
-        for i in range(len(ws_) - 1, -1, -1):
+        if commute:
+            # last layer on the R rendered rows: dW = dfm^T hbar, d(hbar) = dfm W; then every sample's share w_k d(hbar)
+            self._k(st, "snf_linear_bwd_weight", dfm, None, hbar, R, Ih, Cf, Cf, Cf, Ih, ops.ACT_NONE, w_last.main_grad, None,
+                    tag=f"{Ih}x{Cf}r")
+            dhbar = b(f"{hname}_dhbar", (R, Ih))
+            self._k(st, "snf_linear_bwd_data", dfm, None, w_last, R, Ih, Cf, Cf, Cf, Ih, ops.ACT_NONE, dhbar, tag=f"{Ih}x{Cf}r")
+            gy = b(f"{hname}_dfeat", (NK, Ih))
+            self._k(st, "snf_feature_mean_bwd", dhbar, wk, R, K, Ih, gy)
+        else:
+            gy = b(f"{hname}_dfeat", (NK, Cf))
+            self._k(st, "snf_feature_mean_bwd", dfm, wk, R, K, Cf, gy)
+        for i in range(nl - (2 if commute else 1), -1, -1):
             w = ws_[i]
             O, I = w.shape
-            act = ops.ACT_RELU if i < len(ws_) - 1 else net.output_activation
+            act = ops.ACT_RELU if i < nl - 1 else net.output_activation
             xin, yout = acts[i], acts[i + 1]
             ldx = ld_enc if i == 0 else I
             gx = b(f"{hname}_dx{i}", (NK * I,) if (i == 0 and planar) else (NK, I))

