@@ -80,13 +80,22 @@ __device__ __forceinline__ void split4(const float4 v, uint2& hi, uint2& lo) {
     lo = make_uint2(l0, l1);
 }
 
+// rscale != NULL: row m of A is rscale[m] * A[m / rgroup][:] (see k_gemm_ws_b3)
 template <bool DERIV>
 __device__ __forceinline__ float4 b3_load_a(const float* __restrict__ A, const float* __restrict__ Aux, int row, int k, int M,
-                                            int K, int lda, int ldaux, int act) {
+                                            int K, int lda, int ldaux, int act, const float* __restrict__ rscale = nullptr,
+                                            int rgroup = 1) {
     const bool ok = (row < M) && (k < K);
     const int rc = row < M ? row : M - 1;
     const int kc = k < K ? k : 0;
-    float4 v = *reinterpret_cast<const float4*>(A + (size_t)rc * lda + kc);
+    float4 v;
+    if (rscale != nullptr) {
+        v = *reinterpret_cast<const float4*>(A + (size_t)(rc / rgroup) * lda + kc);
+        const float q = rscale[rc];
+        v.x *= q; v.y *= q; v.z *= q; v.w *= q;
+    } else {
+        v = *reinterpret_cast<const float4*>(A + (size_t)rc * lda + kc);
+    }
     if constexpr (DERIV) {
         if (act != SNF_ACT_NONE) {
             const float4 y = *reinterpret_cast<const float4*>(Aux + (size_t)rc * ldaux + kc);
@@ -347,7 +356,8 @@ constexpr int WF_T = 512;
 
 __global__ __launch_bounds__(WF_T) void k_wgrad_full_b3(const float* __restrict__ dY, const float* __restrict__ Y,
                                                         const float* __restrict__ X, int N, int I, int O, int lddy, int ldy,
-                                                        int ldx, int act, int rows_per_wg, float* __restrict__ P) {
+                                                        int ldx, int act, int rows_per_wg, float* __restrict__ P,
+                                                        const float* __restrict__ rscale, int rgroup) {
     __shared__ __attribute__((aligned(16))) uint16_t Ah[256 * WF_PITCH];
     __shared__ __attribute__((aligned(16))) uint16_t Al[256 * WF_PITCH];
     __shared__ __attribute__((aligned(16))) uint16_t Bh[256 * WF_PITCH];
@@ -369,7 +379,7 @@ __global__ __launch_bounds__(WF_T) void k_wgrad_full_b3(const float* __restrict_
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             const int n = n0 + 2 * kp + p;
-            av[p] = b3_load_a<true>(dY, Y, n, col, n_end, O, lddy, ldy, act);
+            av[p] = b3_load_a<true>(dY, Y, n, col, n_end, O, lddy, ldy, act, rscale, rgroup);
             bv[p] = ldx < 0 ? b3_load_b_planar8(X, n, col, n_end, I, N) : b3_load_b(X, n, col, n_end, I, ldx);
         }
     };
@@ -483,11 +493,14 @@ __device__ __forceinline__ void ws_split2(float x0, float x1, uint32_t& hi, uint
 //     [Nc/8][M][8] (ldc = -8): lane (m, half) stores 16 bytes of level (col0 + 32t)/8 + q, and a wave store covers 32 rows x
 //     32 bytes = 1 KB contiguous.  This is the staged-gradient layout of the hash-grid backward (snf_hashgrid_bwd_presorted
 //     with ld_out = 0): the data gradient of a head's first layer lands where the table backward reads it.
+// rscale != NULL ("grouped rows", data gradient only): row m of A is rscale[m] * A[m / rgroup][:] -- the gradient of a weighted
+//     mean over rgroup consecutive rows (MeanRenderer over a ray's samples), never materialised: A holds one row per group.
 template <bool BT, bool DERIV, int BN, int RB, int THREADS, int DEPTH, bool PA = false, bool CT = false>
 __global__ __launch_bounds__(THREADS) void k_gemm_ws_b3(const float* __restrict__ A, const float* __restrict__ Aux,
                                                         const float* __restrict__ W, const float* __restrict__ bias, int M,
                                                         int K, int Nc, int lda, int ldaux, int ldw, int ldc, int act_in,
-                                                        int act_out, float* __restrict__ C) {
+                                                        int act_out, float* __restrict__ C,
+                                                        const float* __restrict__ rscale = nullptr, int rgroup = 1) {
     constexpr int NB = BN / 32;
     constexpr int TILE_ROWS = (THREADS / 64) * 32 * RB;
     extern __shared__ __attribute__((aligned(16))) uint16_t ws_lds[];
@@ -569,12 +582,16 @@ __global__ __launch_bounds__(THREADS) void k_gemm_ws_b3(const float* __restrict_
         // rows of this lane in its row blocks (clamped: out-of-range rows are computed and dropped)
         const float* __restrict__ pa[RB];
         const float* __restrict__ ya[RB];
+        float rs[RB];
 #pragma unroll
         for (int b = 0; b < RB; ++b) {
             const int r = min(r0 + 32 * b + li, M - 1);
-            pa[b] = PA ? A + ((size_t)half * M + r) * 8 : A + (size_t)r * lda + half * 8;
+            const int ra = (DERIV && rscale != nullptr) ? r / rgroup : r;
+            pa[b] = PA ? A + ((size_t)half * M + r) * 8 : A + (size_t)ra * lda + half * 8;
             ya[b] = DERIV ? Aux + (size_t)r * ldaux + half * 8 : nullptr;
+            rs[b] = (DERIV && rscale != nullptr) ? rscale[r] : 1.f;
         }
+        const bool scaled = DERIV && rscale != nullptr;
         const size_t a_step = PA ? (size_t)16 * M : (size_t)16;  // elements between the fragments of consecutive k-steps
         f32x16 acc[RB][NB];
 #pragma unroll
@@ -601,6 +618,11 @@ __global__ __launch_bounds__(THREADS) void k_gemm_ws_b3(const float* __restrict_
         auto frag = [&](int b, int u, bf16x8& hi, bf16x8& lo) {
             float4 v0 = raw[u][b][0], v1 = raw[u][b][1];
             if constexpr (DERIV) {
+                if (scaled) {  // (the product the separate broadcast kernel would have written, then masked: same bits)
+                    const float q = rs[b];
+                    v0.x *= q; v0.y *= q; v0.z *= q; v0.w *= q;
+                    v1.x *= q; v1.y *= q; v1.z *= q; v1.w *= q;
+                }
                 if (masked) {
                     const float4 y0 = rawy[u][b][0], y1 = rawy[u][b][1];
                     v0.x *= b3_act_deriv(y0.x, act_in); v0.y *= b3_act_deriv(y0.y, act_in);
@@ -703,7 +725,7 @@ __global__ __launch_bounds__(THREADS) void k_gemm_ws_b3(const float* __restrict_
 template <bool BT, bool DERIV, int BN, int RB, int THREADS, int DEPTH, bool PA = false, bool CT = false>
 static void ws_launch(dim3 grid, size_t lds, snf_stream_t stream, const float* A, const float* Aux, const float* W,
                       const float* bias, int M, int K, int Nc, int lda, int ldaux, int ldw, int ldc, int act_in, int act_out,
-                      float* C) {
+                      float* C, const float* rscale = nullptr, int rgroup = 1) {
     auto kern = k_gemm_ws_b3<BT, DERIV, BN, RB, THREADS, DEPTH, PA, CT>;
     static bool attr = false;
     if (!attr) {
@@ -711,7 +733,7 @@ static void ws_launch(dim3 grid, size_t lds, snf_stream_t stream, const float* A
         attr = true;
     }
     hipLaunchKernelGGL(kern, grid, dim3(THREADS), lds, (hipStream_t)stream, A, Aux, W, bias, M, K, Nc, lda, ldaux, ldw, ldc,
-                       act_in, act_out, C);
+                       act_in, act_out, C, rscale, rgroup);
 }
 
 // SNF_GEMM_WS_SMALL_LDS=<bytes>: weight slices whose 128-column LDS image exceeds <bytes> take the 64-column kernel (half the
@@ -724,7 +746,8 @@ static int ws_small_lds(size_t lds128) {
 // takes the launch when the shape fits the weight-stationary kernel (K % 16 == 0, K <= 256, many rows); SNF_GEMM_WS=0 disables
 template <bool BT, bool DERIV>
 static int ws_try(const float* A, const float* Aux, const float* W, const float* bias, int M, int K, int Nc, int lda, int ldaux,
-                  int ldw, int ldc, int act_in, int act_out, float* C, snf_stream_t stream) {
+                  int ldw, int ldc, int act_in, int act_out, float* C, snf_stream_t stream, const float* rscale = nullptr,
+                  int rgroup = 1) {
     static const int on = getenv("SNF_GEMM_WS") ? atoi(getenv("SNF_GEMM_WS")) : 1;
     const bool pa = lda < 0, ct = ldc < 0;  // level-major operands (F = 8): only this kernel reads / writes them
     if (pa || ct) {
@@ -745,8 +768,8 @@ static int ws_try(const float* A, const float* Aux, const float* W, const float*
             if (pa && small) ws_launch<true, false, 64, 2, 256, 2, true, false>(grid, lds, stream, A, Aux, W, bias, M, K, Nc, lda, ldaux, ldw, ldc, act_in, act_out, C);
         }
         if constexpr (!BT && DERIV) {
-            if (ct && !small) ws_launch<false, true, 128, 1, 512, 4, false, true>(grid, lds, stream, A, Aux, W, bias, M, K, Nc, lda, ldaux, ldw, ldc, act_in, act_out, C);
-            if (ct && small) ws_launch<false, true, 64, 2, 256, 2, false, true>(grid, lds, stream, A, Aux, W, bias, M, K, Nc, lda, ldaux, ldw, ldc, act_in, act_out, C);
+            if (ct && !small) ws_launch<false, true, 128, 1, 512, 4, false, true>(grid, lds, stream, A, Aux, W, bias, M, K, Nc, lda, ldaux, ldw, ldc, act_in, act_out, C, rscale, rgroup);
+            if (ct && small) ws_launch<false, true, 64, 2, 256, 2, false, true>(grid, lds, stream, A, Aux, W, bias, M, K, Nc, lda, ldaux, ldw, ldc, act_in, act_out, C, rscale, rgroup);
         }
         return 1;
     }
@@ -763,8 +786,8 @@ static int ws_try(const float* A, const float* Aux, const float* W, const float*
     if (gx < 1) gx = 1;
     if (gx > tiles) gx = tiles;
     dim3 grid(gx, gy);
-    if (v == 0) ws_launch<BT, DERIV, 128, 1, 512, 4>(grid, lds, stream, A, Aux, W, bias, M, K, Nc, lda, ldaux, ldw, ldc, act_in, act_out, C);
-    else ws_launch<BT, DERIV, 64, 2, 256, 2>(grid, lds, stream, A, Aux, W, bias, M, K, Nc, lda, ldaux, ldw, ldc, act_in, act_out, C);
+    if (v == 0) ws_launch<BT, DERIV, 128, 1, 512, 4>(grid, lds, stream, A, Aux, W, bias, M, K, Nc, lda, ldaux, ldw, ldc, act_in, act_out, C, rscale, rgroup);
+    else ws_launch<BT, DERIV, 64, 2, 256, 2>(grid, lds, stream, A, Aux, W, bias, M, K, Nc, lda, ldaux, ldw, ldc, act_in, act_out, C, rscale, rgroup);
     return 1;
 }
 
@@ -831,11 +854,15 @@ int snf::b3_try_fwd_splitk(const float* X, const float* W, int N, int I, int O, 
 }
 
 int snf::b3_try_bwd_data(const float* dY, const float* Y, const float* W, int N, int I, int O, int lddy, int ldy,
-                                   int lddx, int act, float* dX, snf_stream_t stream) {
+                                   int lddx, int act, float* dX, snf_stream_t stream, const float* rscale, int rgroup) {
     if (lddx < 0)  // level-major dX [I/8][N][8]: only the weight-stationary bf16x3 kernel writes it (-1: not supported)
         return (!b3_enabled() || (lddy % 4) || (((uintptr_t)dY | (uintptr_t)W | (uintptr_t)dX) & 15) ||
                 (act != SNF_ACT_NONE && ((ldy % 4) || ((uintptr_t)Y & 15))))
-                   ? -1 : ws_try<false, true>(dY, Y, W, nullptr, N, O, I, lddy, ldy, I, lddx, act, SNF_ACT_NONE, dX, stream);
+                   ? -1 : ws_try<false, true>(dY, Y, W, nullptr, N, O, I, lddy, ldy, I, lddx, act, SNF_ACT_NONE, dX, stream, rscale, rgroup);
+    if (rscale != nullptr)  // grouped rows: the weight-stationary kernel or nothing
+        return (!b3_enabled() || (I % 4) || (O % 4) || (lddy % 4) || (((uintptr_t)dY | (uintptr_t)W) & 15) ||
+                (act != SNF_ACT_NONE && ((ldy % 4) || ((uintptr_t)Y & 15))))
+                   ? -1 : (ws_try<false, true>(dY, Y, W, nullptr, N, O, I, lddy, ldy, I, lddx, act, SNF_ACT_NONE, dX, stream, rscale, rgroup) ? 1 : -1);
     if (!b3_enabled() || O < 128 || I < 64 || (I % 4) || (O % 4) || (lddy % 4) || ((uintptr_t)dY & 15) ||
         ((uintptr_t)W & 15) || (act != SNF_ACT_NONE && ((ldy % 4) || ((uintptr_t)Y & 15))))
         return 0;
@@ -858,7 +885,7 @@ long long snf::b3_wgrad_full_workspace_bytes(int N, int I, int O) {
 
 int snf::b3_try_bwd_weight_full(const float* dY, const float* Y, const float* X, int N, int I, int O, int lddy, int ldy, int ldx,
                                 int act, float* dW, float* dbias, void* workspace, long long workspace_bytes,
-                                snf_stream_t stream) {
+                                snf_stream_t stream, const float* rscale, int rgroup) {
     static const int on = getenv("SNF_WGRAD_FULL") ? atoi(getenv("SNF_WGRAD_FULL")) : 1;
     const long long need = b3_wgrad_full_workspace_bytes(N, I, O);
     if (!on || need == 0 || dbias != nullptr || workspace == nullptr || workspace_bytes < need || (lddy % 4) ||
@@ -868,7 +895,7 @@ int snf::b3_try_bwd_weight_full(const float* dY, const float* Y, const float* X,
     const int rows = wf_rows_per_wg(N), chunks = ceil_div(N, rows);
     float* P = (float*)workspace;
     hipLaunchKernelGGL(k_wgrad_full_b3, dim3(chunks), dim3(WF_T), 0, (hipStream_t)stream, dY, Y, X, N, I, O, lddy, ldy, ldx, act,
-                       rows, P);
+                       rows, P, rscale, rgroup);
     hipLaunchKernelGGL(k_wgrad_full_reduce, dim3(ceil_div(O * I, 1024), 4), dim3(256), 0, (hipStream_t)stream, P, chunks, O * I, dW);
     return 1;
 }

@@ -62,6 +62,7 @@ FEATURE_SORTS_ON_HEAD_STREAM = _os.environ.get("SNF_FEAT_SORT_SIDE", "1") == "1"
 # so the schedule renders the HIDDEN activations [R*K, 256] -> [R, 256] first and runs the last layer -- forward, data gradient,
 # weight gradient -- on R rows instead of R*K.  Same real-number result, fp32 rounding in a different order (1e-7).
 MEAN_BEFORE_LAST_LAYER = _os.environ.get("SNF_MEAN_BEFORE_LAST", "1") == "1"
+ROWS_OPERAND = _os.environ.get("SNF_ROWS_OPERAND", "1") == "1"  # ... and its gradient broadcast formed inside the GEMM loaders
 # Without feature heads the step is ONE dependency chain on the main stream.  Its head -- sampling, the proposal network, the
 # resampling, the positions and the backward sorts -- needs last step's PROPOSAL update only, not the field's: it is recorded on
 # the side stream (where the proposal backward + Adam of the previous step already ran) and so runs under the tail of the
@@ -629,12 +630,12 @@ class StepProgram:
                 col += L * F
         # the head MLP (tcnn CutlassMLP role): ReLU between layers, no output activation
         acts, x = [enc_out], enc_out
-        nl = len(ws_)
-        commute = (MEAN_BEFORE_LAST_LAYER and nl >= 2 and net.output_activation == ops.ACT_NONE and ws_[-1].shape[1] % 4 == 0)
-        for i, w in enumerate(ws_[:nl - 1] if commute else ws_):
+        n_lay = len(ws_)
+        commute = (MEAN_BEFORE_LAST_LAYER and n_lay >= 2 and net.output_activation == ops.ACT_NONE and ws_[-1].shape[1] % 4 == 0)
+        for i, w in enumerate(ws_[:n_lay - 1] if commute else ws_):
             O, I = w.shape
             y = b(f"{hname}_a{i}", (NK, O))
-            act = ops.ACT_RELU if i < nl - 1 else net.output_activation
+            act = ops.ACT_RELU if i < n_lay - 1 else net.output_activation
             self._k(st, "snf_linear_fwd", x, w, None, NK, I, O, ld_enc if i == 0 else I, O, act, y, tag=f"{I}x{O}")
             acts.append(y)
             x = y
@@ -702,20 +703,35 @@ class StepProgram:
                     tag=f"{Ih}x{Cf}r")
             dhbar = b(f"{hname}_dhbar", (R, Ih))
             self._k(st, "snf_linear_bwd_data", dfm, None, w_last, R, Ih, Cf, Cf, Cf, Ih, ops.ACT_NONE, dhbar, tag=f"{Ih}x{Cf}r")
-            gy = b(f"{hname}_dfeat", (NK, Ih))
-            self._k(st, "snf_feature_mean_bwd", dhbar, wk, R, K, Ih, gy)
+            # the samples' shares w_k d(hbar) are formed by the loaders of the next layer's two gradient kernels when those are the
+            # weight-stationary / full-width bf16-split kernels (snf_linear_bwd_*_rows); written out otherwise
+            wp = ws_[n_lay - 2]
+            rows_ok = (ROWS_OPERAND and int(self.lib.snf_get_gemm_mode()) >= 1 and NK >= 4096 and
+                       int(self.lib.snf_linear_bwd_weight_workspace_bytes(NK, wp.shape[1], wp.shape[0])) > 0 and
+                       64 <= wp.shape[0] <= 256 and wp.shape[0] % 16 == 0 and wp.shape[1] >= 64)
+            gy = dhbar
+            if not rows_ok:
+                gy = b(f"{hname}_dfeat", (NK, Ih))
+                self._k(st, "snf_feature_mean_bwd", dhbar, wk, R, K, Ih, gy)
         else:
+            rows_ok = False
             gy = b(f"{hname}_dfeat", (NK, Cf))
             self._k(st, "snf_feature_mean_bwd", dfm, wk, R, K, Cf, gy)
-        for i in range(nl - (2 if commute else 1), -1, -1):
+        for i in range(n_lay - (2 if commute else 1), -1, -1):
             w = ws_[i]
             O, I = w.shape
-            act = ops.ACT_RELU if i < nl - 1 else net.output_activation
+            act = ops.ACT_RELU if i < n_lay - 1 else net.output_activation
             xin, yout = acts[i], acts[i + 1]
             ldx = ld_enc if i == 0 else I
             gx = b(f"{hname}_dx{i}", (NK * I,) if (i == 0 and planar) else (NK, I))
-            self._k(st, "snf_linear_bwd_data", gy, yout, w, NK, I, O, O, O, ldx, act, gx, tag=f"{I}x{O}")
             nb = int(self.lib.snf_linear_bwd_weight_workspace_bytes(NK, I, O))
+            if rows_ok and i == n_lay - 2:
+                self._k(st, "snf_linear_bwd_data_rows", gy, wk, K, yout, w, NK, I, O, O, O, ldx, act, gx, tag=f"{I}x{O}")
+                self._k(st, "snf_linear_bwd_weight_rows", gy, wk, K, yout, xin, NK, I, O, O, O, ldx, act, w.main_grad, wgrad_ws, nb,
+                        tag=f"{I}x{O}")
+                gy = gx
+                continue
+            self._k(st, "snf_linear_bwd_data", gy, yout, w, NK, I, O, O, O, ldx, act, gx, tag=f"{I}x{O}")
             if nb > 0:  # full-width weight gradient: operands read once, partial sums in a scratch buffer
                 self._k(st, "snf_linear_bwd_weight_ws", gy, yout, xin, NK, I, O, O, O, ldx, act, w.main_grad, None, wgrad_ws, nb,
                         tag=f"{I}x{O}")

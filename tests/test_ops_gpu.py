@@ -716,6 +716,45 @@ def test_full_width_weight_gradient(N, I, O, planar):
     assert maxdiff(dw_fb, dw_tile) <= 2e-6 * scale
 
 
+@pytest.mark.parametrize("R,K,I,O,planar_dx", [(4096, 16, 192, 256, True), (4096, 16, 256, 256, False), (1024, 8, 64, 128, False)])
+def test_gradient_of_a_weighted_row_mean_as_a_gemm_operand(R, K, I, O, planar_dx):
+    """snf_linear_bwd_data_rows / snf_linear_bwd_weight_rows: dY[n,:] = w[n] * dYg[n / K, :] formed inside the loaders.  The data
+    gradient equals snf_feature_mean_bwd + snf_linear_bwd_data BIT for bit (row-major and level-major dX); the weight gradient
+    equals snf_feature_mean_bwd + snf_linear_bwd_weight_ws up to the order in which its partial sums are added."""
+    m = ops()
+    m.set_gemm_mode("bf16x3")
+    N = R * K
+    g = torch.Generator(device=DEV).manual_seed(R + K + I + O)
+    dyg = torch.randn((R, O), device=DEV, generator=g)
+    wk = torch.rand((R, K), device=DEV, generator=g)
+    y = torch.randn((N, O), device=DEV, generator=g)   # layer output: ReLU derivative mask
+    w = torch.randn((O, I), device=DEV, generator=g) * 0.1
+    x = torch.randn((N, I), device=DEV, generator=g) * 0.3
+    st = m._stream()
+    gy = torch.empty((N, O), device=DEV)
+    m._launch("snf_feature_mean_bwd", m._p(dyg), m._p(wk), R, K, O, m._p(gy), st)
+    lddx = -8 if planar_dx else I
+    dx_ref, dx = torch.empty((N * I,), device=DEV), torch.empty((N * I,), device=DEV)
+    m._launch("snf_linear_bwd_data", m._p(gy), m._p(y), m._p(w), N, I, O, O, O, lddx, m.ACT_RELU, m._p(dx_ref), st)
+    m._launch("snf_linear_bwd_data_rows", m._p(dyg), m._p(wk), K, m._p(y), m._p(w), N, I, O, O, O, lddx, m.ACT_RELU, m._p(dx), st)
+    assert torch.equal(dx, dx_ref)
+    ref = ((wk.reshape(N, 1).double() * dyg.double().repeat_interleave(K, 0)) * (y > 0)) @ w.double()
+    got = dx.view(I // 8, N, 8).permute(1, 0, 2).reshape(N, I) if planar_dx else dx.view(N, I)
+    assert maxdiff(got, ref.float()) <= 2e-5 * float(ref.abs().max())
+    nb = int(m._L().snf_linear_bwd_weight_workspace_bytes(N, I, O))
+    assert nb > 0
+    ws = torch.empty((nb // 4,), device=DEV)
+    dw_ref, dw = torch.zeros((O, I), device=DEV), torch.zeros((O, I), device=DEV)
+    m._launch("snf_linear_bwd_weight_ws", m._p(gy), m._p(y), m._p(x), N, I, O, O, O, I, m.ACT_RELU, m._p(dw_ref), None, m._p(ws), nb, st)
+    m._launch("snf_linear_bwd_weight_rows", m._p(dyg), m._p(wk), K, m._p(y), m._p(x), N, I, O, O, O, I, m.ACT_RELU, m._p(dw),
+              m._p(ws), nb, st)
+    assert maxdiff(dw, dw_ref) <= 1e-6 * float(dw_ref.abs().max())
+    # shapes the kernels do not take are an error, not a silent fallback
+    with pytest.raises(RuntimeError):
+        m._launch("snf_linear_bwd_weight_rows", m._p(dyg), m._p(wk), K, m._p(y), m._p(x), N, I, O, O, O, I, m.ACT_RELU, m._p(dw),
+                  m._p(ws), 16, st)
+
+
 # ---------------------------------------------------------------------------------------------
 # parity soft spots of round 1 (VERDICT r01): golden edge rows and the clamp branch on the HIP kernels themselves
 def test_weights_golden_edge_rows_on_the_kernel(golden):
