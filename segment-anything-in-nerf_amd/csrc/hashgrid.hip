@@ -793,8 +793,8 @@ template <int F, bool ADAM, int SPLIT>
 __global__ __launch_bounds__(HG_FX_T) void k_hg_reduce_fx(const float* __restrict__ gT, int N, int log2_T, int log2B,
                                                           const uint32_t* __restrict__ bucket_start,
                                                           const uint2* __restrict__ records, float* __restrict__ grad_table,
-                                                          int n_run_levels, const uint32_t* __restrict__ lvl_absmax_bits,
-                                                          HgAdam adam) {
+                                                          int xcd_from_level, int n_merge_levels,
+                                                          const uint32_t* __restrict__ lvl_absmax_bits, HgAdam adam) {
     constexpr int MAXROWS = HG_MAX_RPB / SPLIT;
     __shared__ unsigned long long acc[MAXROWS * F];
     __shared__ uint32_t bad[MAXROWS * F / 32];  // one bit per (row, feature): a non-finite contribution landed there
@@ -802,7 +802,23 @@ __global__ __launch_bounds__(HG_FX_T) void k_hg_reduce_fx(const float* __restric
     const int rpb_full = 1 << log2rpb;
     const int rpb = rpb_full >= SPLIT ? rpb_full / SPLIT : rpb_full;  // rows of this workgroup
     const int part = rpb_full >= SPLIT ? (int)(blockIdx.x % SPLIT) : 0;
-    const int tid = threadIdx.x, b = blockIdx.x / SPLIT, l = blockIdx.y, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63;
+    int b = blockIdx.x / SPLIT, l = blockIdx.y;
+    if (SPLIT == 1 && xcd_from_level < (int)gridDim.y) {
+        // XCD-aware order for the levels >= xcd_from_level (uniform cost): workgroups go to the 8 XCDs round-robin by linear id,
+        // and every (bucket, level) workgroup gathers from the WHOLE staged-gradient slab of its level (4 MB at N = 2^19, the
+        // size of one L2).  In launch order ~4 levels are resident at once and every L2 sees all of them; here XCD c takes a
+        // CONTIGUOUS run of the level-major (level, bucket) list, so an L2 serves one level at a time.  The coarse levels before
+        // xcd_from_level keep the plain order: their workgroups are the long ones and want all CUs.
+        const int lin = (int)blockIdx.x + (int)blockIdx.y * B;
+        const int plain = xcd_from_level * B;
+        if (lin >= plain) {
+            const int rem = lin - plain, per_xcd = (((int)gridDim.y - xcd_from_level) * B) >> 3;  // B % 8 == 0
+            const int f = (rem & 7) * per_xcd + (rem >> 3);
+            l = xcd_from_level + f / B;
+            b = f % B;
+        }
+    }
     if (rpb_full < SPLIT && (blockIdx.x % SPLIT) != 0) return;  // (tiny tables: one workgroup per bucket)
     const uint32_t row0 = (uint32_t)part * (uint32_t)rpb;
     const uint32_t start = bucket_start[l * (B + 1) + b], end = bucket_start[l * (B + 1) + b + 1];
@@ -823,7 +839,9 @@ __global__ __launch_bounds__(HG_FX_T) void k_hg_reduce_fx(const float* __restric
     sh = sh > 120 ? 120 : sh;  // keeps 2^sh and 2^-sh normal floats; levels whose largest gradient is below 2^-82 lose nothing that matters
     const float scale = ldexpf(1.f, sh), inv = ldexpf(1.f, -sh);
     const float* __restrict__ gl = gT + (size_t)l * N * F;
-    (void)n_run_levels;
+    // (wave-uniform.  Small tables already spread a row over `copies` accumulators: merging on top of 4 copies measured slower,
+    //  proposal grid 84 -> 96 us; without copies it takes the field grid's five coarse levels from 354 to 219 us)
+    const bool merge = l < n_merge_levels && copies < 4;
     __syncthreads();
     // three-stage software pipeline over trips of U records per thread: the records of trip t+2 and the staged gradients of
     // trip t+1 are in flight while trip t is accumulated, so neither global latency sits on the loop's critical path
@@ -873,7 +891,54 @@ __global__ __launch_bounds__(HG_FX_T) void k_hg_reduce_fx(const float* __restric
             for (int f = 0; f < F; ++f) v[f] = w * g0[j][f];
             // (no run aggregation here: the segmented shuffle scan the float reduce uses on coarse levels costs more than the
             // same-address integer LDS atomics it saves -- level 16^3 alone 333 -> 188 us, the proposal grid 156 -> 106 us)
-            if (live) {
+            if (F == 2 && merge) {
+                // Coarse level: the lanes of a quad mostly carry ONE row (neighbouring samples of a ray in one cell), and
+                // same-address LDS atomics serialise.  The integer contributions of equal rows are added inside the quad first --
+                // two DPP exchanges (lane ^ 1, then lane ^ 2 among the survivors), exact, so the result stays order-independent --
+                // and one lane per group issues the atomic: up to 4x fewer conflicting atomics for ~24 VALU instructions (the
+                // segmented 64-lane shuffle scan of the float reduce cost more than it saved here).
+                long long q[F];
+                bool fin = true;
+#pragma unroll
+                for (int f = 0; f < F; ++f) {
+                    const bool ok = fabsf(v[f]) < INFINITY;
+                    fin = fin && ok;
+                    q[f] = ok ? __float2ll_rn(v[f] * scale) : 0ll;
+                }
+                if (live && !fin) {
+#pragma unroll
+                    for (int f = 0; f < F; ++f) {
+                        if (!(fabsf(v[f]) < INFINITY)) {
+                            const uint32_t e = row * F + f;
+                            atomicOr(&bad[e >> 5], 1u << (e & 31));
+                        }
+                    }
+                }
+                uint32_t key = live ? row : (0xFFFF0000u | (uint32_t)lane);  // dead lanes never match a neighbour
+                int alive = live ? 1 : 0;
+                // step 1: partner lane ^ 1 (quad_perm [1,0,3,2]); step 2: partner lane ^ 2 (quad_perm [2,3,0,1])
+#define SNF_QUAD_STEP(CTRL, BIT)                                                                                         \
+                {                                                                                                          \
+                    const uint32_t pk = (uint32_t)__builtin_amdgcn_mov_dpp((int)key, CTRL, 0xF, 0xF, true);               \
+                    const int pa = __builtin_amdgcn_mov_dpp(alive, CTRL, 0xF, 0xF, true);                                  \
+                    const bool same = alive && pa && pk == key;                                                            \
+                    _Pragma("unroll") for (int f = 0; f < F; ++f) {                                                        \
+                        const int lo = __builtin_amdgcn_mov_dpp((int)(uint32_t)(unsigned long long)q[f], CTRL, 0xF, 0xF, true);          \
+                        const int hi = __builtin_amdgcn_mov_dpp((int)(uint32_t)((unsigned long long)q[f] >> 32), CTRL, 0xF, 0xF, true);  \
+                        const long long pq = (long long)(((unsigned long long)(uint32_t)hi << 32) | (unsigned long long)(uint32_t)lo);   \
+                        if (same && !(lane & BIT)) q[f] += pq;                                                             \
+                    }                                                                                                      \
+                    if (same && (lane & BIT)) alive = 0;                                                                   \
+                }
+                SNF_QUAD_STEP(0xB1, 1)
+                SNF_QUAD_STEP(0x4E, 2)
+#undef SNF_QUAD_STEP
+                if (alive) {
+#pragma unroll
+                    for (int f = 0; f < F; ++f)
+                        if (q[f] != 0) atomicAdd(&acc[(copy_off + row) * F + f], (unsigned long long)q[f]);
+                }
+            } else if (live) {
 #pragma unroll
                 for (int f = 0; f < F; ++f) {
                     if (fabsf(v[f]) < INFINITY) {
@@ -1013,6 +1078,20 @@ extern "C" int snf_hashgrid_bwd(const float* u, const float* grad_out, const flo
 constexpr size_t HG_FX_SCRATCH = 64;  // words (L <= 64 for the fixed-point reduce)
 
 // fixed-point reduce for the F = 2 grids (SNF_HG_FX=0: the float reduce everywhere)
+// first level of the XCD-aware workgroup order of the fixed-point reduce (k_hg_reduce_fx): the leading `n_run_levels` coarse levels
+// keep the plain order; SNF_HG_XCD=0 switches it off (returns L)
+static int hg_xcd_from(int n_run_levels, int L, int B) {
+    static const int on = getenv("SNF_HG_XCD") ? atoi(getenv("SNF_HG_XCD")) : 1;
+    if (!on || (B % 8) != 0 || n_run_levels >= L) return L;
+    return n_run_levels < 0 ? 0 : n_run_levels;
+}
+
+// leading levels whose equal-row contributions are merged inside lane quads before the LDS atomics (SNF_HG_MERGE=0: none)
+static int hg_merge_levels(int n_run_levels) {
+    static const int on = getenv("SNF_HG_MERGE") ? atoi(getenv("SNF_HG_MERGE")) : 1;
+    return on ? n_run_levels : 0;
+}
+
 static bool hg_fx_on(int F, int L, int N) {
     static const int on = getenv("SNF_HG_FX") ? atoi(getenv("SNF_HG_FX")) : 1;
     return on && F == 2 && L <= (int)HG_FX_SCRATCH && (N % 2) == 0;
@@ -1120,7 +1199,7 @@ extern "C" int snf_hashgrid_bwd_presorted(const float* grad_out, int N, int L, i
             (void)hipMemsetAsync(w.fx, 0, L * sizeof(uint32_t), st);
             hipLaunchKernelGGL(k_hg_level_absmax<2>, dim3(hg_absmax_blocks(N, F), L), dim3(256), 0, st, stage, N, w.fx);
             hipLaunchKernelGGL((k_hg_reduce_fx<2, false, 1>), dim3(B, L), dim3(HG_FX_T), 0, st, stage, N, log2_T, g.log2B, w.bstart,
-                               (const uint2*)w.records, grad_table, n_run_levels, w.fx, HgAdam{});
+                               (const uint2*)w.records, grad_table, hg_xcd_from(n_run_levels, L, B), hg_merge_levels(n_run_levels), w.fx, HgAdam{});
         } else
         hipLaunchKernelGGL((k_hg_reduce<2, false>), dim3(B, L), dim3(HG_RT), 0, st, stage, N, log2_T, g.log2B, w.bstart,
                            (const uint2*)w.records, grad_table, hg_long, n_run_levels, HgAdam{});
@@ -1167,7 +1246,7 @@ extern "C" int snf_hashgrid_bwd_presorted_adam(const float* grad_out, int N, int
             (void)hipMemsetAsync(w.fx, 0, L * sizeof(uint32_t), st);
             hipLaunchKernelGGL(k_hg_level_absmax<2>, dim3(hg_absmax_blocks(N, F), L), dim3(256), 0, st, stage, N, w.fx);
             hipLaunchKernelGGL((k_hg_reduce_fx<2, true, 1>), dim3(B, L), dim3(HG_FX_T), 0, st, stage, N, log2_T, g.log2B, w.bstart,
-                               (const uint2*)w.records, grad_table, n_run_levels, w.fx, a);
+                               (const uint2*)w.records, grad_table, hg_xcd_from(n_run_levels, L, B), hg_merge_levels(n_run_levels), w.fx, a);
         } else
         hipLaunchKernelGGL((k_hg_reduce<2, true>), dim3(B, L), dim3(HG_RT), 0, st, stage, N, log2_T, g.log2B, w.bstart,
                            (const uint2*)w.records, grad_table, hg_long, n_run_levels, a);
@@ -1235,12 +1314,12 @@ extern "C" int snf_hashgrid_bwd_presorted_adam_fx(const float* grad_out, int N, 
         if (!planar) hipLaunchKernelGGL(k_hg_stage_grad<2>, dim3(tblocks), dim3(256), 0, st, grad_out, N, L, ld_out, col_off, stage);
         hipLaunchKernelGGL(k_hg_level_absmax<2>, dim3(hg_absmax_blocks(N, F), L), dim3(256), 0, st, stage, N, lvlmax);
         hipLaunchKernelGGL((k_hg_reduce_fx<2, true, 1>), dim3(B, L), dim3(HG_FX_T), 0, st, stage, N, log2_T, g.log2B, w.bstart,
-                           (const uint2*)w.records, grad_table, n_run_levels, lvlmax, a);
+                           (const uint2*)w.records, grad_table, hg_xcd_from(n_run_levels, L, B), hg_merge_levels(n_run_levels), lvlmax, a);
     } else {
         if (!planar) hipLaunchKernelGGL(k_hg_stage_grad<8>, dim3(tblocks), dim3(256), 0, st, grad_out, N, L, ld_out, col_off, stage);
         hipLaunchKernelGGL(k_hg_level_absmax<8>, dim3(hg_absmax_blocks(N, F), L), dim3(256), 0, st, stage, N, lvlmax);
         hipLaunchKernelGGL((k_hg_reduce_fx<8, true, 2>), dim3(B * 2, L), dim3(HG_FX_T), 0, st, stage, N, log2_T, g.log2B,
-                           w.bstart, (const uint2*)w.records, grad_table, n_run_levels, lvlmax, a);
+                           w.bstart, (const uint2*)w.records, grad_table, L, 0, lvlmax, a);
     }
     SNF_LAUNCH_CHECK("snf_hashgrid_bwd_presorted_adam_fx");
     return SNF_OK;

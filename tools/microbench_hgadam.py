@@ -19,6 +19,8 @@ CASES = {  # N, L, F, T, base, max, planar gradient, clustered positions
     # probes of the coarse-level tail: the same sample counts with every level hashed (no bucket holds more than 8N/256 records)
     "f8a_sparse": (65536, 8, 8, 19, 16, 90, True, False),   # the reachable-row levels of f8a alone
     "f8a_dense": (65536, 4, 8, 19, 99, 128, True, False),   # its dense levels alone
+    "f2c": (524288, 5, 2, 19, 16, 58, True, True),        # the field grid's five coarse levels alone
+    "f2f": (524288, 11, 2, 19, 80, 2048, True, True),     # its eleven fine levels alone
     "f2_fine": (524288, 16, 2, 19, 256, 2048, True, True),
     "f2p_fine": (262144, 5, 2, 17, 128, 512, False, True),
 }
