@@ -747,7 +747,10 @@ __global__ __launch_bounds__(HG_RT) void k_hg_reduce(const float* __restrict__ g
 // what a float sum (autograd's) gives.  A workgroup streams its bucket's records once (record + staged-gradient gather,
 // four in flight per thread), one barrier, then converts its rows and applies the Adam step / gradient read-modify-write.
 // ==========================================================================================
-constexpr int HG_FX_T = 256;
+#ifndef SNF_FX_T
+#define SNF_FX_T 512
+#endif
+constexpr int HG_FX_T = SNF_FX_T;
 constexpr int HG_FX_BITS = 38;
 
 template <int F>
