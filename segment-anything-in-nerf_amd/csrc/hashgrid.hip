@@ -160,7 +160,10 @@ __global__ __launch_bounds__(256) void k_hashgrid_bwd(const float* __restrict__ 
 constexpr int HG_MAX_LOG2B = 12;
 constexpr int HG_RT = 512;       // threads of the reduce workgroup (8 waves; 4 workgroups per CU)
 // records sorted per trip through LDS (16 KB of payload at F = 2, 64 KB at F = 8; a 1024-record chunk for F = 8 measured slower)
-template <int F> constexpr int hg_chunk() { return 2048; }
+#ifndef SNF_HG_CHUNK8
+#define SNF_HG_CHUNK8 2048
+#endif
+template <int F> constexpr int hg_chunk() { return F == 8 ? SNF_HG_CHUNK8 : 2048; }
 constexpr int HG_MAX_RPB = 2048; // rows per bucket (HG_ROWS_PT per reduce thread)
 constexpr int HG_ROWS_PT = HG_MAX_RPB / HG_RT;
 constexpr int HG_LONG = 16;      // segments longer than this are reduced by a wave
