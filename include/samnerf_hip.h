@@ -172,17 +172,24 @@ int64_t snf_linear_bwd_weight_workspace_bytes(int N, int I, int O);
 int snf_linear_bwd_weight_ws(const float* dY, const float* Y, const float* X, int N, int I, int O, int lddy, int ldy, int ldx,
                              int act, float* dW, float* dbias, void* workspace, int64_t workspace_bytes, snf_stream_t stream);
 
-/* The two gradients of a layer whose output gradient is the gradient of a weighted mean over `group` consecutive rows
- * (MeanRenderer over the K samples of a ray, samnerf/sam_model.py:126-137: dY[n,:] = row_scale[n] * dYg[n / group, :],
- * dYg [N/group, lddy], row_scale [N] = the detached rendering weights): the loaders of the GEMM kernels form that product,
- * the [N, O] gradient snf_feature_mean_bwd would write is never materialised.  Same bits as writing it and calling
- * snf_linear_bwd_data / snf_linear_bwd_weight_ws.  Only the kernels named in the error text support it (SNF_ERR_ARG otherwise):
- * check snf_linear_bwd_weight_workspace_bytes(N, I, O) > 0 and gemm mode >= 1 first. */
-int snf_linear_bwd_data_rows(const float* dYg, const float* row_scale, int group, const float* Y, const float* W, int N, int I,
-                             int O, int lddy, int ldy, int lddx, int act, float* dX, snf_stream_t stream);
-int snf_linear_bwd_weight_rows(const float* dYg, const float* row_scale, int group, const float* Y, const float* X, int N, int I,
-                               int O, int lddy, int ldy, int ldx, int act, float* dW, void* workspace, int64_t workspace_bytes,
-                               snf_stream_t stream);
+/* A hidden layer whose ReLU output is only ever (a) rendered -- the weighted mean over `group` consecutive rows (MeanRenderer
+ * over the K samples of a ray, samnerf/sam_model.py:126-137, applied BEFORE the network's linear last layer:
+ * sum_k w_k (W h_k) = W (sum_k w_k h_k)) -- and (b) differentiated through its ReLU:
+ *   snf_linear_fwd_mean   Hbar[n / group, :] = sum_k row_weight[n] * relu(X W^T)[n, :]  ([N/group, O]) and the ReLU mask as bits,
+ *                         Ymask [N][O/8] bytes, bit c of a row = (y[c] > 0); the activations themselves go to Y only if Y != NULL.
+ *   snf_linear_bwd_*_rows the layer's two gradients when dY[n,:] = row_scale[n] * dYg[n / group, :] (dYg [N/group, lddy],
+ *                         row_scale [N] = the detached rendering weights): the loaders form that product, the [N, O] gradient
+ *                         snf_feature_mean_bwd would write is never materialised.  y_is_mask != 0: Y is the bit mask above
+ *                         (ldy = bytes per row) instead of the fp32 activations.  Same bits as the unfused sequence.
+ * Only the weight-stationary / full-width bf16-split kernels implement these (SNF_ERR_ARG otherwise, conditions in the error
+ * text): N >= 8192, 64 <= I, O <= 256, gemm mode >= 1, snf_linear_bwd_weight_workspace_bytes(N, I, O) > 0. */
+int snf_linear_fwd_mean(const float* X, const float* W, int N, int I, int O, int ldx, const float* row_weight, int group,
+                        float* Hbar, uint8_t* Ymask, float* Y, int ldy, snf_stream_t stream);
+int snf_linear_bwd_data_rows(const float* dYg, const float* row_scale, int group, const float* Y, int y_is_mask, const float* W,
+                             int N, int I, int O, int lddy, int ldy, int lddx, int act, float* dX, snf_stream_t stream);
+int snf_linear_bwd_weight_rows(const float* dYg, const float* row_scale, int group, const float* Y, int y_is_mask, const float* X,
+                               int N, int I, int O, int lddy, int ldy, int ldx, int act, float* dW, void* workspace,
+                               int64_t workspace_bytes, snf_stream_t stream);
 
 /* ---- a7, tiny: the proposal networks' density MLP (nerfstudio/fields/density_fields.py:80-97 with hidden_dim 16:
  *      I -> H (ReLU) -> 1, bias-free) in one launch per direction, one thread per sample.  Built for I = 10, H = 16

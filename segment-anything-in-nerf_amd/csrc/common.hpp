@@ -96,11 +96,13 @@ int b3_try_fwd_splitk(const float* X, const float* W, int N, int I, int O, int l
 int b3_try_bwd_weight(const float* dY, const float* Y, const float* X, int N, int I, int O, int lddy, int ldy, int ldx,
                       int act, float* dW, float* dbias, snf_stream_t stream);
 int b3_try_bwd_data(const float* dY, const float* Y, const float* W, int N, int I, int O, int lddy, int ldy, int lddx,
-                    int act, float* dX, snf_stream_t stream, const float* rscale = nullptr, int rgroup = 1);
+                    int act, float* dX, snf_stream_t stream, const float* rscale = nullptr, int rgroup = 1, int aux_bits = 0);
+int b3_try_fwd_mean(const float* X, const float* W, int N, int I, int O, int ldx, int ldy, float* Y, const float* wk, int group,
+                    float* hbar, uint8_t* ybits, snf_stream_t stream);
 long long b3_wgrad_full_workspace_bytes(int N, int I, int O);
 int b3_try_bwd_weight_full(const float* dY, const float* Y, const float* X, int N, int I, int O, int lddy, int ldy, int ldx,
                            int act, float* dW, float* dbias, void* workspace, long long workspace_bytes, snf_stream_t stream,
-                           const float* rscale = nullptr, int rgroup = 1);
+                           const float* rscale = nullptr, int rgroup = 1, int aux_bits = 0);
 bool b3_enabled();  // snf_set_gemm_mode(1): bf16 3-term split on the matrix cores (default); 0: exact fp32
 
 }  // namespace snf

@@ -513,14 +513,28 @@ extern "C" int snf_linear_bwd_weight_ws(const float* dY, const float* Y, const f
 }
 
 // ---- the same two gradients when dY is the gradient of a weighted mean over `group` consecutive rows and is never written out
-extern "C" int snf_linear_bwd_data_rows(const float* dYg, const float* row_scale, int group, const float* Y, const float* W,
-                                        int N, int I, int O, int lddy, int ldy, int lddx, int act, float* dX,
+extern "C" int snf_linear_fwd_mean(const float* X, const float* W, int N, int I, int O, int ldx, const float* row_weight, int group,
+                                   float* Hbar, uint8_t* Ymask, float* Y, int ldy, snf_stream_t stream) {
+    SNF_REQUIRE(X && W && row_weight && Hbar && Ymask, "snf_linear_fwd_mean: null pointer");
+    SNF_REQUIRE(N > 0 && I > 0 && O > 0 && (ldx >= I || (ldx == -8 && I % 16 == 0)) && (Y == nullptr || ldy >= O),
+                "snf_linear_fwd_mean: bad shape N=%d I=%d O=%d", N, I, O);
+    const int took = b3_try_fwd_mean(X, W, N, I, O, ldx, Y ? ldy : O, Y, row_weight, group, Hbar, Ymask, stream);
+    SNF_REQUIRE(took > 0, "snf_linear_fwd_mean: needs the weight-stationary bf16-split kernel (group == 16, N %% 16 == 0, O %% 32 == 0, "
+                          "64 <= I <= 256, I %% 16 == 0, N >= 4096, aligned pointers, gemm mode >= 1); use snf_linear_fwd + "
+                          "snf_feature_mean_fwd otherwise");
+    SNF_LAUNCH_CHECK("snf_linear_fwd_mean");
+    return SNF_OK;
+}
+
+extern "C" int snf_linear_bwd_data_rows(const float* dYg, const float* row_scale, int group, const float* Y, int y_is_mask,
+                                        const float* W, int N, int I, int O, int lddy, int ldy, int lddx, int act, float* dX,
                                         snf_stream_t stream) {
     SNF_REQUIRE(dYg && row_scale && W && dX, "snf_linear_bwd_data_rows: null pointer");
     SNF_REQUIRE(act == SNF_ACT_NONE || Y, "snf_linear_bwd_data_rows: Y required for activation derivative");
     SNF_REQUIRE(N > 0 && I > 0 && O > 0 && group > 0 && lddy >= O && (lddx >= I || (lddx == -8 && I % 8 == 0)) &&
                     act != SNF_ACT_GELU, "snf_linear_bwd_data_rows: bad shape");
-    const int took = b3_try_bwd_data(dYg, Y, W, N, I, O, lddy, ldy, lddx, act, dX, stream, row_scale, group);
+    SNF_REQUIRE(!y_is_mask || (act == SNF_ACT_RELU && O % 8 == 0), "snf_linear_bwd_data_rows: a bit mask stands for a ReLU output");
+    const int took = b3_try_bwd_data(dYg, Y, W, N, I, O, lddy, ldy, lddx, act, dX, stream, row_scale, group, y_is_mask ? 1 : 0);
     SNF_REQUIRE(took > 0, "snf_linear_bwd_data_rows: needs the weight-stationary bf16-split kernel (64 <= O <= 256, O %% 16 == 0, "
                           "I >= 64, N >= 4096, aligned pointers, gemm mode >= 1); write the broadcast gradient with "
                           "snf_feature_mean_bwd and call snf_linear_bwd_data otherwise");
@@ -528,14 +542,15 @@ extern "C" int snf_linear_bwd_data_rows(const float* dYg, const float* row_scale
     return SNF_OK;
 }
 
-extern "C" int snf_linear_bwd_weight_rows(const float* dYg, const float* row_scale, int group, const float* Y, const float* X,
-                                          int N, int I, int O, int lddy, int ldy, int ldx, int act, float* dW, void* workspace,
-                                          int64_t workspace_bytes, snf_stream_t stream) {
+extern "C" int snf_linear_bwd_weight_rows(const float* dYg, const float* row_scale, int group, const float* Y, int y_is_mask,
+                                          const float* X, int N, int I, int O, int lddy, int ldy, int ldx, int act, float* dW,
+                                          void* workspace, int64_t workspace_bytes, snf_stream_t stream) {
     SNF_REQUIRE(dYg && row_scale && X && dW, "snf_linear_bwd_weight_rows: null pointer");
     SNF_REQUIRE(act == SNF_ACT_NONE || Y, "snf_linear_bwd_weight_rows: Y required for activation derivative");
     SNF_REQUIRE(N > 0 && I > 0 && O > 0 && group > 0 && lddy >= O && act != SNF_ACT_GELU, "snf_linear_bwd_weight_rows: bad shape");
+    SNF_REQUIRE(!y_is_mask || (act == SNF_ACT_RELU && O % 8 == 0), "snf_linear_bwd_weight_rows: a bit mask stands for a ReLU output");
     const int took = b3_try_bwd_weight_full(dYg, Y, X, N, I, O, lddy, ldy, ldx, act, dW, nullptr, workspace, workspace_bytes, stream,
-                                            row_scale, group);
+                                            row_scale, group, y_is_mask ? 1 : 0);
     SNF_REQUIRE(took > 0, "snf_linear_bwd_weight_rows: needs the full-width kernel (snf_linear_bwd_weight_workspace_bytes > 0 and a "
                           "workspace of that size); write the broadcast gradient with snf_feature_mean_bwd and call "
                           "snf_linear_bwd_weight_ws otherwise");

@@ -84,7 +84,7 @@ __device__ __forceinline__ void split4(const float4 v, uint2& hi, uint2& lo) {
 template <bool DERIV>
 __device__ __forceinline__ float4 b3_load_a(const float* __restrict__ A, const float* __restrict__ Aux, int row, int k, int M,
                                             int K, int lda, int ldaux, int act, const float* __restrict__ rscale = nullptr,
-                                            int rgroup = 1) {
+                                            int rgroup = 1, int aux_bits = 0) {
     const bool ok = (row < M) && (k < K);
     const int rc = row < M ? row : M - 1;
     const int kc = k < K ? k : 0;
@@ -97,7 +97,10 @@ __device__ __forceinline__ float4 b3_load_a(const float* __restrict__ A, const f
         v = *reinterpret_cast<const float4*>(A + (size_t)rc * lda + kc);
     }
     if constexpr (DERIV) {
-        if (act != SNF_ACT_NONE) {
+        if (act != SNF_ACT_NONE && aux_bits) {  // Aux: ReLU mask bits [M][ldaux bytes]
+            const uint32_t m = reinterpret_cast<const uint8_t*>(Aux)[(size_t)rc * ldaux + (kc >> 3)] >> (kc & 4);
+            v.x = (m & 1u) ? v.x : 0.f; v.y = (m & 2u) ? v.y : 0.f; v.z = (m & 4u) ? v.z : 0.f; v.w = (m & 8u) ? v.w : 0.f;
+        } else if (act != SNF_ACT_NONE) {
             const float4 y = *reinterpret_cast<const float4*>(Aux + (size_t)rc * ldaux + kc);
             v.x *= b3_act_deriv(y.x, act);
             v.y *= b3_act_deriv(y.y, act);
@@ -357,7 +360,7 @@ constexpr int WF_T = 512;
 __global__ __launch_bounds__(WF_T) void k_wgrad_full_b3(const float* __restrict__ dY, const float* __restrict__ Y,
                                                         const float* __restrict__ X, int N, int I, int O, int lddy, int ldy,
                                                         int ldx, int act, int rows_per_wg, float* __restrict__ P,
-                                                        const float* __restrict__ rscale, int rgroup) {
+                                                        const float* __restrict__ rscale, int rgroup, int aux_bits) {
     __shared__ __attribute__((aligned(16))) uint16_t Ah[256 * WF_PITCH];
     __shared__ __attribute__((aligned(16))) uint16_t Al[256 * WF_PITCH];
     __shared__ __attribute__((aligned(16))) uint16_t Bh[256 * WF_PITCH];
@@ -379,7 +382,7 @@ __global__ __launch_bounds__(WF_T) void k_wgrad_full_b3(const float* __restrict_
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             const int n = n0 + 2 * kp + p;
-            av[p] = b3_load_a<true>(dY, Y, n, col, n_end, O, lddy, ldy, act, rscale, rgroup);
+            av[p] = b3_load_a<true>(dY, Y, n, col, n_end, O, lddy, ldy, act, rscale, rgroup, aux_bits);
             bv[p] = ldx < 0 ? b3_load_b_planar8(X, n, col, n_end, I, N) : b3_load_b(X, n, col, n_end, I, ldx);
         }
     };
@@ -495,12 +498,18 @@ __device__ __forceinline__ void ws_split2(float x0, float x1, uint32_t& hi, uint
 //     with ld_out = 0): the data gradient of a head's first layer lands where the table backward reads it.
 // rscale != NULL ("grouped rows", data gradient only): row m of A is rscale[m] * A[m / rgroup][:] -- the gradient of a weighted
 //     mean over rgroup consecutive rows (MeanRenderer over a ray's samples), never materialised: A holds one row per group.
+// aux_bits (data gradient): Aux is the ReLU mask of the layer's output as BITS, [M][ldaux bytes], bit c of a row = (y[c] > 0).
+// hbar != NULL (forward, ReLU, rgroup == 16): the epilogue renders the activations -- hbar[m / 16][c] = sum_k rscale[16 (m/16) + k]
+//     * y[16 (m/16) + k][c] -- and writes the ReLU mask bits to ybits; C may then be NULL: the activations themselves are not
+//     needed again (the layer after it runs on the rendered rows, the backward needs the mask only).
 template <bool BT, bool DERIV, int BN, int RB, int THREADS, int DEPTH, bool PA = false, bool CT = false>
 __global__ __launch_bounds__(THREADS) void k_gemm_ws_b3(const float* __restrict__ A, const float* __restrict__ Aux,
                                                         const float* __restrict__ W, const float* __restrict__ bias, int M,
                                                         int K, int Nc, int lda, int ldaux, int ldw, int ldc, int act_in,
                                                         int act_out, float* __restrict__ C,
-                                                        const float* __restrict__ rscale = nullptr, int rgroup = 1) {
+                                                        const float* __restrict__ rscale = nullptr, int rgroup = 1,
+                                                        int aux_bits = 0, float* __restrict__ hbar = nullptr,
+                                                        uint8_t* __restrict__ ybits = nullptr) {
     constexpr int NB = BN / 32;
     constexpr int TILE_ROWS = (THREADS / 64) * 32 * RB;
     extern __shared__ __attribute__((aligned(16))) uint16_t ws_lds[];
@@ -604,7 +613,13 @@ __global__ __launch_bounds__(THREADS) void k_gemm_ws_b3(const float* __restrict_
         // the mask is applied when a fragment is built, so nothing waits on a load before its k-step comes up
         constexpr int D = DEPTH;
         float4 raw[D][RB][2], rawy[DERIV ? D : 1][RB][2];
-        const bool masked = DERIV && act_in != SNF_ACT_NONE;
+        uint32_t rawm[DERIV ? D : 1][RB];
+        const bool masked = DERIV && act_in != SNF_ACT_NONE && !aux_bits;
+        const bool bitmask = DERIV && act_in != SNF_ACT_NONE && aux_bits;
+        const uint8_t* __restrict__ mb[RB];
+#pragma unroll
+        for (int b = 0; b < RB; ++b)
+            mb[b] = bitmask ? reinterpret_cast<const uint8_t*>(Aux) + (size_t)min(r0 + 32 * b + li, M - 1) * ldaux + half : nullptr;
         auto load8 = [&](int b, int s, int u) {
             raw[u][b][0] = *reinterpret_cast<const float4*>(pa[b] + s * a_step);
             raw[u][b][1] = *reinterpret_cast<const float4*>(pa[b] + s * a_step + 4);
@@ -613,6 +628,7 @@ __global__ __launch_bounds__(THREADS) void k_gemm_ws_b3(const float* __restrict_
                     rawy[u][b][0] = *reinterpret_cast<const float4*>(ya[b] + s * 16);
                     rawy[u][b][1] = *reinterpret_cast<const float4*>(ya[b] + s * 16 + 4);
                 }
+                if (bitmask) rawm[u][b] = mb[b][2 * s];  // columns 16 s + 8 half .. + 8 of the row: one byte
             }
         };
         auto frag = [&](int b, int u, bf16x8& hi, bf16x8& lo) {
@@ -622,6 +638,11 @@ __global__ __launch_bounds__(THREADS) void k_gemm_ws_b3(const float* __restrict_
                     const float q = rs[b];
                     v0.x *= q; v0.y *= q; v0.z *= q; v0.w *= q;
                     v1.x *= q; v1.y *= q; v1.z *= q; v1.w *= q;
+                }
+                if (bitmask) {
+                    const uint32_t m = rawm[u][b];
+                    v0.x = (m & 1u) ? v0.x : 0.f; v0.y = (m & 2u) ? v0.y : 0.f; v0.z = (m & 4u) ? v0.z : 0.f; v0.w = (m & 8u) ? v0.w : 0.f;
+                    v1.x = (m & 16u) ? v1.x : 0.f; v1.y = (m & 32u) ? v1.y : 0.f; v1.z = (m & 64u) ? v1.z : 0.f; v1.w = (m & 128u) ? v1.w : 0.f;
                 }
                 if (masked) {
                     const float4 y0 = rawy[u][b][0], y1 = rawy[u][b][1];
@@ -703,6 +724,38 @@ __global__ __launch_bounds__(THREADS) void k_gemm_ws_b3(const float* __restrict_
                         }
                 }
             }
+        } else if (BT && !DERIV && hbar != nullptr) {
+            // rendered epilogue (see the header): registers 0..7 of a lane are rows of the block's first group of 16, 8..15 of its
+            // second; the other half-wave holds the other 8 rows of each group
+#pragma unroll
+            for (int b = 0; b < RB; ++b) {
+                float wr[16];
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int row = r0 + 32 * b + (reg & 3) + 8 * (reg >> 2) + 4 * half;
+                    wr[reg] = row < M ? rscale[row] : 0.f;
+                }
+#pragma unroll
+                for (int t = 0; t < NB; ++t) {
+                    const int c = col0 + 32 * t + li;
+                    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        const int row = r0 + 32 * b + (reg & 3) + 8 * (reg >> 2) + 4 * half;
+                        const float v = fmaxf(acc[b][t][reg] + bcol[t], 0.f);
+                        const unsigned long long bal = __ballot(v > 0.f && c < Nc);
+                        if (li == 0 && row < M)
+                            *reinterpret_cast<uint32_t*>(ybits + (size_t)row * (Nc >> 3) + ((col0 + 32 * t) >> 3)) =
+                                half ? (uint32_t)(bal >> 32) : (uint32_t)bal;
+                        if (reg < 8) s0 += wr[reg] * v; else s1 += wr[reg] * v;
+                        if (C != nullptr && row < M && c < Nc) C[(size_t)row * ldc + c] = v;
+                    }
+                    s0 += __shfl_xor(s0, 32, 64);
+                    s1 += __shfl_xor(s1, 32, 64);
+                    const int g = ((r0 + 32 * b) >> 4) + half;  // half 0 writes the first group, half 1 the second
+                    if (c < Nc && g * 16 < M) hbar[(size_t)g * Nc + c] = half ? s1 : s0;
+                }
+            }
         } else {
         // epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
 #pragma unroll
@@ -725,7 +778,8 @@ __global__ __launch_bounds__(THREADS) void k_gemm_ws_b3(const float* __restrict_
 template <bool BT, bool DERIV, int BN, int RB, int THREADS, int DEPTH, bool PA = false, bool CT = false>
 static void ws_launch(dim3 grid, size_t lds, snf_stream_t stream, const float* A, const float* Aux, const float* W,
                       const float* bias, int M, int K, int Nc, int lda, int ldaux, int ldw, int ldc, int act_in, int act_out,
-                      float* C, const float* rscale = nullptr, int rgroup = 1) {
+                      float* C, const float* rscale = nullptr, int rgroup = 1, int aux_bits = 0, float* hbar = nullptr,
+                      uint8_t* ybits = nullptr) {
     auto kern = k_gemm_ws_b3<BT, DERIV, BN, RB, THREADS, DEPTH, PA, CT>;
     static bool attr = false;
     if (!attr) {
@@ -733,7 +787,7 @@ static void ws_launch(dim3 grid, size_t lds, snf_stream_t stream, const float* A
         attr = true;
     }
     hipLaunchKernelGGL(kern, grid, dim3(THREADS), lds, (hipStream_t)stream, A, Aux, W, bias, M, K, Nc, lda, ldaux, ldw, ldc,
-                       act_in, act_out, C, rscale, rgroup);
+                       act_in, act_out, C, rscale, rgroup, aux_bits, hbar, ybits);
 }
 
 // SNF_GEMM_WS_SMALL_LDS=<bytes>: weight slices whose 128-column LDS image exceeds <bytes> take the 64-column kernel (half the
@@ -747,7 +801,7 @@ static int ws_small_lds(size_t lds128) {
 template <bool BT, bool DERIV>
 static int ws_try(const float* A, const float* Aux, const float* W, const float* bias, int M, int K, int Nc, int lda, int ldaux,
                   int ldw, int ldc, int act_in, int act_out, float* C, snf_stream_t stream, const float* rscale = nullptr,
-                  int rgroup = 1) {
+                  int rgroup = 1, int aux_bits = 0, float* hbar = nullptr, uint8_t* ybits = nullptr) {
     static const int on = getenv("SNF_GEMM_WS") ? atoi(getenv("SNF_GEMM_WS")) : 1;
     const bool pa = lda < 0, ct = ldc < 0;  // level-major operands (F = 8): only this kernel reads / writes them
     if (pa || ct) {
@@ -764,12 +818,12 @@ static int ws_try(const float* A, const float* Aux, const float* W, const float*
         if (gx > tiles) gx = tiles;
         dim3 grid(gx, gy);
         if constexpr (BT && !DERIV) {
-            if (pa && !small) ws_launch<true, false, 128, 1, 512, 4, true, false>(grid, lds, stream, A, Aux, W, bias, M, K, Nc, lda, ldaux, ldw, ldc, act_in, act_out, C);
-            if (pa && small) ws_launch<true, false, 64, 2, 256, 2, true, false>(grid, lds, stream, A, Aux, W, bias, M, K, Nc, lda, ldaux, ldw, ldc, act_in, act_out, C);
+            if (pa && !small) ws_launch<true, false, 128, 1, 512, 4, true, false>(grid, lds, stream, A, Aux, W, bias, M, K, Nc, lda, ldaux, ldw, ldc, act_in, act_out, C, rscale, rgroup, 0, hbar, ybits);
+            if (pa && small) ws_launch<true, false, 64, 2, 256, 2, true, false>(grid, lds, stream, A, Aux, W, bias, M, K, Nc, lda, ldaux, ldw, ldc, act_in, act_out, C, rscale, rgroup, 0, hbar, ybits);
         }
         if constexpr (!BT && DERIV) {
-            if (ct && !small) ws_launch<false, true, 128, 1, 512, 4, false, true>(grid, lds, stream, A, Aux, W, bias, M, K, Nc, lda, ldaux, ldw, ldc, act_in, act_out, C, rscale, rgroup);
-            if (ct && small) ws_launch<false, true, 64, 2, 256, 2, false, true>(grid, lds, stream, A, Aux, W, bias, M, K, Nc, lda, ldaux, ldw, ldc, act_in, act_out, C, rscale, rgroup);
+            if (ct && !small) ws_launch<false, true, 128, 1, 512, 4, false, true>(grid, lds, stream, A, Aux, W, bias, M, K, Nc, lda, ldaux, ldw, ldc, act_in, act_out, C, rscale, rgroup, aux_bits);
+            if (ct && small) ws_launch<false, true, 64, 2, 256, 2, false, true>(grid, lds, stream, A, Aux, W, bias, M, K, Nc, lda, ldaux, ldw, ldc, act_in, act_out, C, rscale, rgroup, aux_bits);
         }
         return 1;
     }
@@ -786,8 +840,8 @@ static int ws_try(const float* A, const float* Aux, const float* W, const float*
     if (gx < 1) gx = 1;
     if (gx > tiles) gx = tiles;
     dim3 grid(gx, gy);
-    if (v == 0) ws_launch<BT, DERIV, 128, 1, 512, 4>(grid, lds, stream, A, Aux, W, bias, M, K, Nc, lda, ldaux, ldw, ldc, act_in, act_out, C, rscale, rgroup);
-    else ws_launch<BT, DERIV, 64, 2, 256, 2>(grid, lds, stream, A, Aux, W, bias, M, K, Nc, lda, ldaux, ldw, ldc, act_in, act_out, C, rscale, rgroup);
+    if (v == 0) ws_launch<BT, DERIV, 128, 1, 512, 4>(grid, lds, stream, A, Aux, W, bias, M, K, Nc, lda, ldaux, ldw, ldc, act_in, act_out, C, rscale, rgroup, aux_bits, hbar, ybits);
+    else ws_launch<BT, DERIV, 64, 2, 256, 2>(grid, lds, stream, A, Aux, W, bias, M, K, Nc, lda, ldaux, ldw, ldc, act_in, act_out, C, rscale, rgroup, aux_bits, hbar, ybits);
     return 1;
 }
 
@@ -842,6 +896,15 @@ int snf::b3_try_fwd(const float* X, const float* W, const float* bias, int N, in
     return 1;
 }
 
+// forward + ReLU with the rendered epilogue (hbar, mask bits; Y may be NULL): the weight-stationary kernel or nothing (-1)
+int snf::b3_try_fwd_mean(const float* X, const float* W, int N, int I, int O, int ldx, int ldy, float* Y, const float* wk, int group,
+                         float* hbar, uint8_t* ybits, snf_stream_t stream) {
+    if (!b3_enabled() || group != 16 || (N % 16) || (O % 32) || (((uintptr_t)X | (uintptr_t)W | (uintptr_t)hbar | (uintptr_t)ybits) & 15))
+        return -1;
+    return ws_try<true, false>(X, nullptr, W, nullptr, N, I, O, ldx, 0, I, ldy, SNF_ACT_NONE, SNF_ACT_RELU, Y, stream, wk, group, 0,
+                               hbar, ybits) > 0 ? 1 : -1;
+}
+
 int snf::b3_try_fwd_splitk(const float* X, const float* W, int N, int I, int O, int ldx, int ksplit, int splits, float* P,
                            snf_stream_t stream) {
     if (!b3_enabled() || I < 128 || O < 64 || (I % 4) || (O % 4) || (ldx % 4) || ((uintptr_t)X & 15) || ((uintptr_t)W & 15))
@@ -854,15 +917,15 @@ int snf::b3_try_fwd_splitk(const float* X, const float* W, int N, int I, int O, 
 }
 
 int snf::b3_try_bwd_data(const float* dY, const float* Y, const float* W, int N, int I, int O, int lddy, int ldy,
-                                   int lddx, int act, float* dX, snf_stream_t stream, const float* rscale, int rgroup) {
+                                   int lddx, int act, float* dX, snf_stream_t stream, const float* rscale, int rgroup,
+                                   int aux_bits) {
+    const bool y_bad = act != SNF_ACT_NONE && !aux_bits && ((ldy % 4) || ((uintptr_t)Y & 15));
     if (lddx < 0)  // level-major dX [I/8][N][8]: only the weight-stationary bf16x3 kernel writes it (-1: not supported)
-        return (!b3_enabled() || (lddy % 4) || (((uintptr_t)dY | (uintptr_t)W | (uintptr_t)dX) & 15) ||
-                (act != SNF_ACT_NONE && ((ldy % 4) || ((uintptr_t)Y & 15))))
-                   ? -1 : ws_try<false, true>(dY, Y, W, nullptr, N, O, I, lddy, ldy, I, lddx, act, SNF_ACT_NONE, dX, stream, rscale, rgroup);
-    if (rscale != nullptr)  // grouped rows: the weight-stationary kernel or nothing
-        return (!b3_enabled() || (I % 4) || (O % 4) || (lddy % 4) || (((uintptr_t)dY | (uintptr_t)W) & 15) ||
-                (act != SNF_ACT_NONE && ((ldy % 4) || ((uintptr_t)Y & 15))))
-                   ? -1 : (ws_try<false, true>(dY, Y, W, nullptr, N, O, I, lddy, ldy, I, lddx, act, SNF_ACT_NONE, dX, stream, rscale, rgroup) ? 1 : -1);
+        return (!b3_enabled() || (lddy % 4) || (((uintptr_t)dY | (uintptr_t)W | (uintptr_t)dX) & 15) || y_bad)
+                   ? -1 : ws_try<false, true>(dY, Y, W, nullptr, N, O, I, lddy, ldy, I, lddx, act, SNF_ACT_NONE, dX, stream, rscale, rgroup, aux_bits);
+    if (rscale != nullptr || aux_bits)  // grouped rows / mask bits: the weight-stationary kernel or nothing
+        return (!b3_enabled() || (I % 4) || (O % 4) || (lddy % 4) || (((uintptr_t)dY | (uintptr_t)W) & 15) || y_bad)
+                   ? -1 : (ws_try<false, true>(dY, Y, W, nullptr, N, O, I, lddy, ldy, I, lddx, act, SNF_ACT_NONE, dX, stream, rscale, rgroup, aux_bits) ? 1 : -1);
     if (!b3_enabled() || O < 128 || I < 64 || (I % 4) || (O % 4) || (lddy % 4) || ((uintptr_t)dY & 15) ||
         ((uintptr_t)W & 15) || (act != SNF_ACT_NONE && ((ldy % 4) || ((uintptr_t)Y & 15))))
         return 0;
@@ -885,17 +948,17 @@ long long snf::b3_wgrad_full_workspace_bytes(int N, int I, int O) {
 
 int snf::b3_try_bwd_weight_full(const float* dY, const float* Y, const float* X, int N, int I, int O, int lddy, int ldy, int ldx,
                                 int act, float* dW, float* dbias, void* workspace, long long workspace_bytes,
-                                snf_stream_t stream, const float* rscale, int rgroup) {
+                                snf_stream_t stream, const float* rscale, int rgroup, int aux_bits) {
     static const int on = getenv("SNF_WGRAD_FULL") ? atoi(getenv("SNF_WGRAD_FULL")) : 1;
     const long long need = b3_wgrad_full_workspace_bytes(N, I, O);
     if (!on || need == 0 || dbias != nullptr || workspace == nullptr || workspace_bytes < need || (lddy % 4) ||
         (ldx < 0 ? (ldx != -8 || (I % 8)) : (ldx < I || (ldx % 4))) || (((uintptr_t)dY | (uintptr_t)X | (uintptr_t)workspace) & 15) ||
-        (act != SNF_ACT_NONE && ((ldy % 4) || ((uintptr_t)Y & 15))))
+        (act != SNF_ACT_NONE && !aux_bits && ((ldy % 4) || ((uintptr_t)Y & 15))) || (aux_bits && (O % 8)))
         return 0;
     const int rows = wf_rows_per_wg(N), chunks = ceil_div(N, rows);
     float* P = (float*)workspace;
     hipLaunchKernelGGL(k_wgrad_full_b3, dim3(chunks), dim3(WF_T), 0, (hipStream_t)stream, dY, Y, X, N, I, O, lddy, ldy, ldx, act,
-                       rows, P, rscale, rgroup);
+                       rows, P, rscale, rgroup, aux_bits);
     hipLaunchKernelGGL(k_wgrad_full_reduce, dim3(ceil_div(O * I, 1024), 4), dim3(256), 0, (hipStream_t)stream, P, chunks, O * I, dW);
     return 1;
 }

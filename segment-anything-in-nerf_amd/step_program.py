@@ -63,6 +63,7 @@ FEATURE_SORTS_ON_HEAD_STREAM = _os.environ.get("SNF_FEAT_SORT_SIDE", "1") == "1"
 # weight gradient -- on R rows instead of R*K.  Same real-number result, fp32 rounding in a different order (1e-7).
 MEAN_BEFORE_LAST_LAYER = _os.environ.get("SNF_MEAN_BEFORE_LAST", "1") == "1"
 ROWS_OPERAND = _os.environ.get("SNF_ROWS_OPERAND", "1") == "1"  # ... and its gradient broadcast formed inside the GEMM loaders
+FUSED_MEAN_EPILOGUE = _os.environ.get("SNF_FUSED_MEAN", "1") == "1"  # ... and the mean itself in the hidden layer's GEMM epilogue
 # Without feature heads the step is ONE dependency chain on the main stream.  Its head -- sampling, the proposal network, the
 # resampling, the positions and the backward sorts -- needs last step's PROPOSAL update only, not the field's: it is recorded on
 # the side stream (where the proposal backward + Adam of the previous step already ran) and so runs under the tail of the
@@ -632,18 +633,37 @@ class StepProgram:
         acts, x = [enc_out], enc_out
         n_lay = len(ws_)
         commute = (MEAN_BEFORE_LAST_LAYER and n_lay >= 2 and net.output_activation == ops.ACT_NONE and ws_[-1].shape[1] % 4 == 0)
+        # ... then the last hidden layer's output is only rendered and differentiated through its ReLU: the weight-stationary /
+        # full-width bf16-split kernels form the broadcast gradient in their loaders (rows_ok) and, for K = 16, render in the
+        # forward GEMM's epilogue and keep the ReLU mask as bits instead of the activations (fuse_mean)
+        rows_ok = fuse_mean = False
+        if commute:
+            wp = ws_[n_lay - 2]
+            rows_ok = (ROWS_OPERAND and int(self.lib.snf_get_gemm_mode()) >= 1 and NK >= 8192 and
+                       int(self.lib.snf_linear_bwd_weight_workspace_bytes(NK, wp.shape[1], wp.shape[0])) > 0 and
+                       64 <= wp.shape[0] <= 256 and wp.shape[0] % 16 == 0 and 64 <= wp.shape[1] <= 256 and wp.shape[1] % 16 == 0)
+            fuse_mean = rows_ok and FUSED_MEAN_EPILOGUE and K == 16 and wp.shape[0] % 32 == 0
         for i, w in enumerate(ws_[:n_lay - 1] if commute else ws_):
             O, I = w.shape
-            y = b(f"{hname}_a{i}", (NK, O))
             act = ops.ACT_RELU if i < n_lay - 1 else net.output_activation
+            if fuse_mean and i == n_lay - 2:
+                hbar = b(f"{hname}_hbar", (R, O))
+                ymask = b(f"{hname}_mask{i}", (NK, O // 8), torch.uint8)
+                self._k(st, "snf_linear_fwd_mean", x, w, NK, I, O, ld_enc if i == 0 else I, wk, K, hbar, ymask, None, O,
+                        tag=f"{I}x{O}")
+                acts.append(ymask)
+                x = None
+                continue
+            y = b(f"{hname}_a{i}", (NK, O))
             self._k(st, "snf_linear_fwd", x, w, None, NK, I, O, ld_enc if i == 0 else I, O, act, y, tag=f"{I}x{O}")
             acts.append(y)
             x = y
         if commute:
             w_last = ws_[-1]
             Cf, Ih = w_last.shape
-            hbar = b(f"{hname}_hbar", (R, Ih))
-            self._k(st, "snf_feature_mean_fwd", x, wk, R, K, Ih, hbar)
+            if not fuse_mean:
+                hbar = b(f"{hname}_hbar", (R, Ih))
+                self._k(st, "snf_feature_mean_fwd", x, wk, R, K, Ih, hbar)
             fm = b(f"{hname}_fm", (R, Cf))
             self._k(st, "snf_linear_fwd", hbar, w_last, None, R, Ih, Cf, Ih, Cf, ops.ACT_NONE, fm, tag=f"{Ih}x{Cf}r")
         else:
@@ -703,18 +723,12 @@ class StepProgram:
                     tag=f"{Ih}x{Cf}r")
             dhbar = b(f"{hname}_dhbar", (R, Ih))
             self._k(st, "snf_linear_bwd_data", dfm, None, w_last, R, Ih, Cf, Cf, Cf, Ih, ops.ACT_NONE, dhbar, tag=f"{Ih}x{Cf}r")
-            # the samples' shares w_k d(hbar) are formed by the loaders of the next layer's two gradient kernels when those are the
-            # weight-stationary / full-width bf16-split kernels (snf_linear_bwd_*_rows); written out otherwise
-            wp = ws_[n_lay - 2]
-            rows_ok = (ROWS_OPERAND and int(self.lib.snf_get_gemm_mode()) >= 1 and NK >= 4096 and
-                       int(self.lib.snf_linear_bwd_weight_workspace_bytes(NK, wp.shape[1], wp.shape[0])) > 0 and
-                       64 <= wp.shape[0] <= 256 and wp.shape[0] % 16 == 0 and wp.shape[1] >= 64)
+            # the samples' shares w_k d(hbar): formed by the loaders of the layer below (rows_ok) or written out
             gy = dhbar
             if not rows_ok:
                 gy = b(f"{hname}_dfeat", (NK, Ih))
                 self._k(st, "snf_feature_mean_bwd", dhbar, wk, R, K, Ih, gy)
         else:
-            rows_ok = False
             gy = b(f"{hname}_dfeat", (NK, Cf))
             self._k(st, "snf_feature_mean_bwd", dfm, wk, R, K, Cf, gy)
         for i in range(n_lay - (2 if commute else 1), -1, -1):
@@ -726,9 +740,10 @@ class StepProgram:
             gx = b(f"{hname}_dx{i}", (NK * I,) if (i == 0 and planar) else (NK, I))
             nb = int(self.lib.snf_linear_bwd_weight_workspace_bytes(NK, I, O))
             if rows_ok and i == n_lay - 2:
-                self._k(st, "snf_linear_bwd_data_rows", gy, wk, K, yout, w, NK, I, O, O, O, ldx, act, gx, tag=f"{I}x{O}")
-                self._k(st, "snf_linear_bwd_weight_rows", gy, wk, K, yout, xin, NK, I, O, O, O, ldx, act, w.main_grad, wgrad_ws, nb,
-                        tag=f"{I}x{O}")
+                bits, ldy = (1, O // 8) if fuse_mean else (0, O)
+                self._k(st, "snf_linear_bwd_data_rows", gy, wk, K, yout, bits, w, NK, I, O, O, ldy, ldx, act, gx, tag=f"{I}x{O}")
+                self._k(st, "snf_linear_bwd_weight_rows", gy, wk, K, yout, bits, xin, NK, I, O, O, ldy, ldx, act, w.main_grad, wgrad_ws,
+                        nb, tag=f"{I}x{O}")
                 gy = gx
                 continue
             self._k(st, "snf_linear_bwd_data", gy, yout, w, NK, I, O, O, O, ldx, act, gx, tag=f"{I}x{O}")

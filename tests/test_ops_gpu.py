@@ -736,7 +736,7 @@ def test_gradient_of_a_weighted_row_mean_as_a_gemm_operand(R, K, I, O, planar_dx
     lddx = -8 if planar_dx else I
     dx_ref, dx = torch.empty((N * I,), device=DEV), torch.empty((N * I,), device=DEV)
     m._launch("snf_linear_bwd_data", m._p(gy), m._p(y), m._p(w), N, I, O, O, O, lddx, m.ACT_RELU, m._p(dx_ref), st)
-    m._launch("snf_linear_bwd_data_rows", m._p(dyg), m._p(wk), K, m._p(y), m._p(w), N, I, O, O, O, lddx, m.ACT_RELU, m._p(dx), st)
+    m._launch("snf_linear_bwd_data_rows", m._p(dyg), m._p(wk), K, m._p(y), 0, m._p(w), N, I, O, O, O, lddx, m.ACT_RELU, m._p(dx), st)
     assert torch.equal(dx, dx_ref)
     ref = ((wk.reshape(N, 1).double() * dyg.double().repeat_interleave(K, 0)) * (y > 0)) @ w.double()
     got = dx.view(I // 8, N, 8).permute(1, 0, 2).reshape(N, I) if planar_dx else dx.view(N, I)
@@ -746,13 +746,62 @@ def test_gradient_of_a_weighted_row_mean_as_a_gemm_operand(R, K, I, O, planar_dx
     ws = torch.empty((nb // 4,), device=DEV)
     dw_ref, dw = torch.zeros((O, I), device=DEV), torch.zeros((O, I), device=DEV)
     m._launch("snf_linear_bwd_weight_ws", m._p(gy), m._p(y), m._p(x), N, I, O, O, O, I, m.ACT_RELU, m._p(dw_ref), None, m._p(ws), nb, st)
-    m._launch("snf_linear_bwd_weight_rows", m._p(dyg), m._p(wk), K, m._p(y), m._p(x), N, I, O, O, O, I, m.ACT_RELU, m._p(dw),
+    m._launch("snf_linear_bwd_weight_rows", m._p(dyg), m._p(wk), K, m._p(y), 0, m._p(x), N, I, O, O, O, I, m.ACT_RELU, m._p(dw),
               m._p(ws), nb, st)
     assert maxdiff(dw, dw_ref) <= 1e-6 * float(dw_ref.abs().max())
     # shapes the kernels do not take are an error, not a silent fallback
     with pytest.raises(RuntimeError):
-        m._launch("snf_linear_bwd_weight_rows", m._p(dyg), m._p(wk), K, m._p(y), m._p(x), N, I, O, O, O, I, m.ACT_RELU, m._p(dw),
+        m._launch("snf_linear_bwd_weight_rows", m._p(dyg), m._p(wk), K, m._p(y), 0, m._p(x), N, I, O, O, O, I, m.ACT_RELU, m._p(dw),
                   m._p(ws), 16, st)
+
+
+@pytest.mark.parametrize("R,I,O,planar", [(4096, 192, 256, True), (1024, 128, 128, False)])
+def test_hidden_layer_rendered_in_the_gemm_epilogue(R, I, O, planar):
+    """snf_linear_fwd_mean: hbar = weighted mean over 16 consecutive rows of relu(X W^T), formed in the GEMM's epilogue, plus the
+    ReLU mask as bits -- against snf_linear_fwd + snf_feature_mean_fwd (same products, the 16-term sum in a different order) and
+    the sign of the stored activations; then both gradients of the layer from the bit mask equal the ones from the fp32
+    activations bit for bit (data gradient) / to the order of the partial sums (weight gradient)."""
+    m = ops()
+    m.set_gemm_mode("bf16x3")
+    K = 16
+    N = R * K
+    g = torch.Generator(device=DEV).manual_seed(R + I + O)
+    x = torch.randn((N, I), device=DEV, generator=g) * 0.3
+    w = torch.randn((O, I), device=DEV, generator=g) * 0.1
+    wk = torch.rand((R, K), device=DEV, generator=g)
+    xin, ldx = (_planar8(x), -8) if planar else (x, I)
+    st = m._stream()
+    y = torch.empty((N, O), device=DEV)
+    m._launch("snf_linear_fwd", m._p(xin), m._p(w), None, N, I, O, ldx, O, m.ACT_RELU, m._p(y), st)
+    ref = torch.empty((R, O), device=DEV)
+    m._launch("snf_feature_mean_fwd", m._p(y), m._p(wk), R, K, O, m._p(ref), st)
+    hbar = torch.empty((R, O), device=DEV)
+    mask = torch.zeros((N, O // 8), device=DEV, dtype=torch.uint8)
+    y2 = torch.empty((N, O), device=DEV)
+    for keep in (y2, None):  # with and without writing the activations
+        hbar.zero_(); mask.zero_()
+        m._launch("snf_linear_fwd_mean", m._p(xin), m._p(w), N, I, O, ldx, m._p(wk), K, m._p(hbar), m._p(mask),
+                  None if keep is None else m._p(keep), O, st)
+        assert maxdiff(hbar, ref) <= 2e-6 * float(ref.abs().max())
+        bits = ((mask.view(N, O // 8, 1) >> torch.arange(8, device=DEV, dtype=torch.uint8).view(1, 1, 8)) & 1).view(N, O).bool()
+        assert torch.equal(bits, y > 0)
+    assert torch.equal(y2, y)
+    exact = (wk.reshape(R, K, 1).double() * torch.relu(x.double() @ w.double().T).view(R, K, O)).sum(1)
+    assert maxdiff(hbar, exact.float()) <= 2e-5 * float(exact.abs().max())
+    # the backward from the mask
+    dyg = torch.randn((R, O), device=DEV, generator=g)
+    dx_ref, dx = torch.empty((N, I), device=DEV), torch.empty((N, I), device=DEV)
+    m._launch("snf_linear_bwd_data_rows", m._p(dyg), m._p(wk), K, m._p(y), 0, m._p(w), N, I, O, O, O, I, m.ACT_RELU, m._p(dx_ref), st)
+    m._launch("snf_linear_bwd_data_rows", m._p(dyg), m._p(wk), K, m._p(mask), 1, m._p(w), N, I, O, O, O // 8, I, m.ACT_RELU, m._p(dx), st)
+    assert torch.equal(dx, dx_ref)
+    nb = int(m._L().snf_linear_bwd_weight_workspace_bytes(N, I, O))
+    ws = torch.empty((nb // 4,), device=DEV)
+    dw_ref, dw = torch.zeros((O, I), device=DEV), torch.zeros((O, I), device=DEV)
+    m._launch("snf_linear_bwd_weight_rows", m._p(dyg), m._p(wk), K, m._p(y), 0, m._p(xin), N, I, O, O, O, ldx, m.ACT_RELU, m._p(dw_ref),
+              m._p(ws), nb, st)
+    m._launch("snf_linear_bwd_weight_rows", m._p(dyg), m._p(wk), K, m._p(mask), 1, m._p(xin), N, I, O, O, O // 8, ldx, m.ACT_RELU,
+              m._p(dw), m._p(ws), nb, st)
+    assert maxdiff(dw, dw_ref) <= 1e-6 * float(dw_ref.abs().max())
 
 
 # ---------------------------------------------------------------------------------------------
