@@ -196,8 +196,8 @@ def mfma_util() -> dict:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="distill_4096x128", choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0)
     ap.add_argument("--roofline-kernel", default=None, help="kernel key 'entry/tag' to time live (default: auto)")
