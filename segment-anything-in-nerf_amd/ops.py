@@ -58,7 +58,9 @@ def make_stream(name: str) -> "torch.cuda.Stream":
         while _STREAMS_MADE["n"] % 4 != slot % 4:
             _STREAMS_MADE["filler"].append(torch.cuda.Stream())
             _STREAMS_MADE["n"] += 1
-    st = torch.cuda.Stream()
+    # SNF_STREAM_PRIORITY="sam:-1,presort:-1": HIP stream priority per task stream (-1 high, 0 default) -- measurement hook
+    prio = dict(kv.split(":") for kv in _os.environ.get("SNF_STREAM_PRIORITY", "").split(",") if ":" in kv)
+    st = torch.cuda.Stream(priority=int(prio[name])) if name in prio else torch.cuda.Stream()
     _STREAMS_MADE["n"] += 1
     _STREAMS_MADE["names"][st.stream_id] = name
     return st
