@@ -44,6 +44,9 @@ def algorithmic_model(key: str, w: dict):
     (8 corners x F floats x 4 B per level per sample; backward = read-modify-write)."""
     R, P, S, K = w["R"], w["P"], w["S"], w["K"]
     name, _, tag = key.partition("/")
+    if name == "snf_hashgrid_bwd_presorted_adam_pair":  # both F = 8 grids of a head in one launch ("F8L12+12"); the launch site
+        m = re.fullmatch(r"F8L(\d+)\+(\d+)", tag)        # reports its own bytes (gathers + 24 B per fused parameter)
+        return ("hbm", float(R * K * (int(m.group(1)) + int(m.group(2))) * 8 * 8 * 4 * 2), "GB/s") if m else (None, None, None)
     if name in ("snf_hashgrid_fwd", "snf_hashgrid_bwd", "snf_hashgrid_bwd_sorted", "snf_hashgrid_bwd_sorted_ex",
                 "snf_hashgrid_bwd_presorted", "snf_hashgrid_bwd_presorted_adam", "snf_hashgrid_bwd_presorted_adam_fx"):
         # (the fused backward + Adam reports its own bytes per launch -- ops._hashgrid_bwd_launch: the corner
@@ -310,6 +313,7 @@ def main():
     # reduce, k_hg_reduce being ~60 % of it (profiles/*_kernel_stats.csv).
     largest_kernel_share = {"snf_hashgrid_bwd_sorted": 0.6, "snf_hashgrid_bwd_sorted_ex": 0.6,
                             "snf_hashgrid_bwd_presorted": 0.9, "snf_hashgrid_bwd_presorted_adam": 0.95,
+                            "snf_hashgrid_bwd_presorted_adam_pair": 1.0,
                             "snf_hashgrid_bwd_presorted_adam_fx": 0.95}
     dom = args.roofline_kernel
     if dom is None and per_step:

@@ -115,6 +115,17 @@ int snf_hashgrid_bwd_presorted_adam(const float* grad_out, int N, int L, int F, 
                                     int fuse_from_level, float* param, float* exp_avg, float* exp_avg_sq, float lr,
                                     float beta1, float beta2, float eps, int step, float grad_scale, snf_stream_t stream);
 
+/* snf_hashgrid_bwd_presorted_adam for the TWO F = 8 grids of a feature head (clip_encs / clipseg_encs, samnerf/sam_field.py:38-94:
+ * same samples N, same log2_T, level-major gradients = ld_out 0) in one reduce launch: one tail instead of two, and the
+ * latency-bound reachable-row levels of one grid share the CUs with the bandwidth-bound dense levels of the other.  Same
+ * arithmetic per table as two snf_hashgrid_bwd_presorted_adam calls; the hyper-parameters are the group's. */
+int snf_hashgrid_bwd_presorted_adam_pair(const float* grad_out0, const float* grad_out1, int N, int L0, int L1, int log2_T,
+                                         float* grad_table0, float* grad_table1, const void* sorted_workspace0,
+                                         const void* sorted_workspace1, int fuse_from_level0, int fuse_from_level1, float* param0,
+                                         float* exp_avg0, float* exp_avg_sq0, float* param1, float* exp_avg1, float* exp_avg_sq1,
+                                         float lr, float beta1, float beta2, float eps, int step, float grad_scale,
+                                         snf_stream_t stream);
+
 /* The same pass with FIXED-POINT per-row sums (F = 2 and F = 8): a contribution w * g is added to its row as a 64-bit integer
  * LDS atomic, q = rint(w g 2^s) with 2^s = 2^38 / 2^e and 2^e above the level's largest finite |g| (found by a small
  * pre-pass), instead of being sorted by row and summed in fp32 -- ds_add_u64 retires 6.3 lane-ops/clk/CU on gfx950 against

@@ -455,11 +455,24 @@ __device__ __forceinline__ void hg_adam1(float& p, float g, float& m, float& v, 
     p = p - a.step_size * (m / denom);
 }
 
+// A second grid in the same launch (snf_hashgrid_bwd_presorted_adam_pair: the two F = 8 grids of a feature head, same N / T):
+// blockIdx.y covers the levels of both; with `interleave` (equal level counts) even y = first grid, odd y = second, so the
+// latency-bound reachable-row levels of one grid are resident together with the bandwidth-bound dense levels of the other.
+struct HgSecond {
+    const float* gT;
+    const uint32_t* bucket_start;
+    const uint2* records;
+    float* grad_table;
+    HgAdam adam;
+    int first_levels;  // levels of the first grid; >= gridDim.y: there is no second grid
+    int interleave;
+};
+
 template <int F, bool ADAM>
 __global__ __launch_bounds__(HG_RT) void k_hg_reduce(const float* __restrict__ gT, int N, int log2_T, int log2B,
                                                      const uint32_t* __restrict__ bucket_start,
                                                      const uint2* __restrict__ records, float* __restrict__ grad_table,
-                                                     uint32_t hg_long, int n_run_levels, HgAdam adam) {
+                                                     uint32_t hg_long, int n_run_levels, HgAdam adam, HgSecond sec) {
     constexpr int CHUNK = hg_chunk<F>();
     constexpr int RPT = CHUNK / HG_RT;
     __shared__ uint32_t cnt[HG_MAX_RPB + 1];  // per-row counts, then exclusive offsets
@@ -469,7 +482,21 @@ __global__ __launch_bounds__(HG_RT) void k_hg_reduce(const float* __restrict__ g
     __shared__ uint32_t n_long;
     const int B = 1 << log2B, log2rpb = log2_T - log2B;
     const int rpb = 1 << log2rpb;
-    const int tid = threadIdx.x, b = blockIdx.x, l = blockIdx.y;
+    const int tid = threadIdx.x, b = blockIdx.x;
+    int l = blockIdx.y;
+    if (sec.first_levels < (int)gridDim.y) {  // (uniform over the workgroup)
+        bool second;
+        if (sec.interleave) {
+            second = l & 1;
+            l >>= 1;
+        } else {
+            second = l >= sec.first_levels;
+            if (second) l -= sec.first_levels;
+        }
+        if (second) {
+            gT = sec.gT; bucket_start = sec.bucket_start; records = sec.records; grad_table = sec.grad_table; adam = sec.adam;
+        }
+    }
     const int lane = tid & 63, wave = tid >> 6;
     const uint32_t start = bucket_start[l * (B + 1) + b], end = bucket_start[l * (B + 1) + b + 1];
     const bool fuse = ADAM && l >= adam.from_level;
@@ -1092,6 +1119,12 @@ static int hg_xcd_from(int n_run_levels, int L, int B) {
     return n_run_levels < 0 ? 0 : n_run_levels;
 }
 
+static HgSecond hg_no_second() {
+    HgSecond s{};
+    s.first_levels = 1 << 30;
+    return s;
+}
+
 // leading levels whose equal-row contributions are merged inside lane quads before the LDS atomics (SNF_HG_MERGE=0: none)
 static int hg_merge_levels(int n_run_levels) {
     static const int on = getenv("SNF_HG_MERGE") ? atoi(getenv("SNF_HG_MERGE")) : 1;
@@ -1208,11 +1241,11 @@ extern "C" int snf_hashgrid_bwd_presorted(const float* grad_out, int N, int L, i
                                (const uint2*)w.records, grad_table, hg_xcd_from(n_run_levels, L, B), hg_merge_levels(n_run_levels), w.fx, HgAdam{});
         } else
         hipLaunchKernelGGL((k_hg_reduce<2, false>), dim3(B, L), dim3(HG_RT), 0, st, stage, N, log2_T, g.log2B, w.bstart,
-                           (const uint2*)w.records, grad_table, hg_long, n_run_levels, HgAdam{});
+                           (const uint2*)w.records, grad_table, hg_long, n_run_levels, HgAdam{}, hg_no_second());
     } else {
         if (!planar) hipLaunchKernelGGL(k_hg_stage_grad<8>, dim3(tblocks), dim3(256), 0, st, grad_out, N, L, ld_out, col_off, stage);
         hipLaunchKernelGGL((k_hg_reduce<8, false>), dim3(B, L), dim3(HG_RT), 0, st, stage, N, log2_T, g.log2B, w.bstart,
-                           (const uint2*)w.records, grad_table, hg_long, n_run_levels, HgAdam{});
+                           (const uint2*)w.records, grad_table, hg_long, n_run_levels, HgAdam{}, hg_no_second());
     }
     SNF_LAUNCH_CHECK("snf_hashgrid_bwd_presorted");
     return SNF_OK;
@@ -1255,13 +1288,52 @@ extern "C" int snf_hashgrid_bwd_presorted_adam(const float* grad_out, int N, int
                                (const uint2*)w.records, grad_table, hg_xcd_from(n_run_levels, L, B), hg_merge_levels(n_run_levels), w.fx, a);
         } else
         hipLaunchKernelGGL((k_hg_reduce<2, true>), dim3(B, L), dim3(HG_RT), 0, st, stage, N, log2_T, g.log2B, w.bstart,
-                           (const uint2*)w.records, grad_table, hg_long, n_run_levels, a);
+                           (const uint2*)w.records, grad_table, hg_long, n_run_levels, a, hg_no_second());
     } else {
         if (!planar) hipLaunchKernelGGL(k_hg_stage_grad<8>, dim3(tblocks), dim3(256), 0, st, grad_out, N, L, ld_out, col_off, stage);
         hipLaunchKernelGGL((k_hg_reduce<8, true>), dim3(B, L), dim3(HG_RT), 0, st, stage, N, log2_T, g.log2B, w.bstart,
-                           (const uint2*)w.records, grad_table, hg_long, n_run_levels, a);
+                           (const uint2*)w.records, grad_table, hg_long, n_run_levels, a, hg_no_second());
     }
     SNF_LAUNCH_CHECK("snf_hashgrid_bwd_presorted_adam");
+    return SNF_OK;
+}
+
+// The two F = 8 grids of a feature head (same samples, same table size, level-major gradients) in ONE reduce launch: one tail
+// instead of two and the two kinds of levels mixed on the CUs (alone: 427 us against 220 + 287 us, tools/microbench_hgadam.py).
+extern "C" int snf_hashgrid_bwd_presorted_adam_pair(const float* grad_out0, const float* grad_out1, int N, int L0, int L1, int log2_T,
+                                                    float* grad_table0, float* grad_table1, const void* sorted_workspace0,
+                                                    const void* sorted_workspace1, int fuse_from_level0, int fuse_from_level1,
+                                                    float* param0, float* exp_avg0, float* exp_avg_sq0, float* param1,
+                                                    float* exp_avg1, float* exp_avg_sq1, float lr, float beta1, float beta2,
+                                                    float eps, int step, float grad_scale, snf_stream_t stream) {
+    SNF_REQUIRE(grad_out0 && grad_out1 && grad_table0 && grad_table1 && sorted_workspace0 && sorted_workspace1 && param0 && param1 &&
+                    exp_avg0 && exp_avg1 && exp_avg_sq0 && exp_avg_sq1, "snf_hashgrid_bwd_presorted_adam_pair: null pointer");
+    SNF_REQUIRE(N > 0 && L0 > 0 && L1 > 0 && L0 + L1 <= 65535 && N <= (1 << HG_SAMPLE_BITS) && fuse_from_level0 >= 0 &&
+                    fuse_from_level0 <= L0 && fuse_from_level1 >= 0 && fuse_from_level1 <= L1 && step >= 1,
+                "snf_hashgrid_bwd_presorted_adam_pair: bad shape N=%d L=%d+%d or fuse levels / step", N, L0, L1);
+    SNF_REQUIRE((((uintptr_t)grad_out0 | (uintptr_t)grad_out1 | (uintptr_t)grad_table0 | (uintptr_t)grad_table1 | (uintptr_t)param0 |
+                  (uintptr_t)param1 | (uintptr_t)exp_avg0 | (uintptr_t)exp_avg1 | (uintptr_t)exp_avg_sq0 | (uintptr_t)exp_avg_sq1) & 15) == 0,
+                "snf_hashgrid_bwd_presorted_adam_pair: unaligned pointer");
+    const HgGeom g = hg_geometry(N, log2_T);
+    const HgWs w0 = hg_ws_layout(const_cast<void*>(sorted_workspace0), N, L0, g);
+    const HgWs w1 = hg_ws_layout(const_cast<void*>(sorted_workspace1), N, L1, g);
+    const int B = 1 << g.log2B;
+    static const uint32_t hg_long = getenv("SNF_HG_LONG") ? (uint32_t)atoi(getenv("SNF_HG_LONG")) : (uint32_t)HG_LONG;
+    static const int interleave = getenv("SNF_HG_PAIR_INTERLEAVE") ? atoi(getenv("SNF_HG_PAIR_INTERLEAVE")) : 1;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    HgAdam a;
+    a.p = param0; a.m = exp_avg0; a.v = exp_avg_sq0;
+    a.b1 = beta1; a.b2 = beta2; a.step_size = (float)((double)lr / bc1); a.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+    a.eps = eps; a.gs = grad_scale; a.from_level = fuse_from_level0;
+    HgSecond s2{};
+    s2.gT = grad_out1; s2.bucket_start = w1.bstart; s2.records = (const uint2*)w1.records; s2.grad_table = grad_table1;
+    s2.adam = a;
+    s2.adam.p = param1; s2.adam.m = exp_avg1; s2.adam.v = exp_avg_sq1; s2.adam.from_level = fuse_from_level1;
+    s2.first_levels = L0;
+    s2.interleave = (interleave && L0 == L1) ? 1 : 0;
+    hipLaunchKernelGGL((k_hg_reduce<8, true>), dim3(B, L0 + L1), dim3(HG_RT), 0, (hipStream_t)stream, grad_out0, N, log2_T, g.log2B,
+                       w0.bstart, (const uint2*)w0.records, grad_table0, hg_long, 0, a, s2);
+    SNF_LAUNCH_CHECK("snf_hashgrid_bwd_presorted_adam_pair");
     return SNF_OK;
 }
 

@@ -63,6 +63,7 @@ FEATURE_SORTS_ON_HEAD_STREAM = _os.environ.get("SNF_FEAT_SORT_SIDE", "1") == "1"
 # weight gradient -- on R rows instead of R*K.  Same real-number result, fp32 rounding in a different order (1e-7).
 MEAN_BEFORE_LAST_LAYER = _os.environ.get("SNF_MEAN_BEFORE_LAST", "1") == "1"
 ROWS_OPERAND = _os.environ.get("SNF_ROWS_OPERAND", "1") == "1"  # ... and its gradient broadcast formed inside the GEMM loaders
+PAIR_GRID_BWD = _os.environ.get("SNF_PAIR_GRID_BWD", "1") == "1"  # both feature grids of a head in one table-backward launch
 FUSED_MEAN_EPILOGUE = _os.environ.get("SNF_FUSED_MEAN", "1") == "1"  # ... and the mean itself in the hidden layer's GEMM epilogue
 # Without feature heads the step is ONE dependency chain on the main stream.  Its head -- sampling, the proposal network, the
 # resampling, the positions and the backward sorts -- needs last step's PROPOSAL update only, not the field's: it is recorded on
@@ -772,7 +773,27 @@ class StepProgram:
                                geo_ws[(gi, l0, nl)], None, with_opt, done, run=(l0, nl), grad_scale=1.0 / W)
         else:
             fuse_local = with_opt and not self.multi
-            for e in encs:
+            pair = (PAIR_GRID_BWD and planar and len(encs) == 2 and not FX_F8 and all(e.n_features_per_level == 8 for e in encs)
+                    and encs[0].log2_hashmap_size == encs[1].log2_hashmap_size)
+            if pair:
+                # both grids of the head in one reduce launch (snf_hashgrid_bwd_presorted_adam_pair)
+                e0, e1 = encs
+                T = e0.log2_hashmap_size
+                oc = opt.config["sam_field"]["optimizer"]
+                tabs = [self._table_adam(e, "sam_field") for e in encs]
+                fuse = fuse_local and opt.fuse_table_adam
+                frm = [t[4] if fuse else e.n_levels for t, e in zip(tabs, encs)]
+                units = sum(float(NK) * 8 * 8 * 4 * (e.n_levels + f) + 24.0 * (((e.n_levels - f) << T) * 8) for e, f in zip(encs, frm))
+                self._k(st, "snf_hashgrid_bwd_presorted_adam_pair", gy, self._off(gy, e0.n_levels * 8 * NK * 4), NK, e0.n_levels,
+                        e1.n_levels, T, tabs[0][1], tabs[1][1], geo_ws[ops._geometry_key(e0.scalings, e0.n_levels, T)],
+                        geo_ws[ops._geometry_key(e1.scalings, e1.n_levels, T)], frm[0], frm[1], tabs[0][0], tabs[0][2], tabs[0][3],
+                        tabs[1][0], tabs[1][2], tabs[1][3], 0.0, float(oc.betas[0]), float(oc.betas[1]), float(oc.eps), 1, 1.0,
+                        tag=f"F8L{e0.n_levels}+{e1.n_levels}", units=units, dyn={("lr", "sam_field"): 18, ("t", "sam_field"): 22})
+                if fuse:
+                    for t, e, f in zip(tabs, encs, frm):
+                        if f < e.n_levels:
+                            done.append(t[5])
+            for e in ([] if pair else encs):
                 L, F, T = e.n_levels, e.n_features_per_level, e.log2_hashmap_size
                 ws_sorted = geo_ws[ops._geometry_key(e.scalings, L, T)]
                 if planar:  # the first layer's data gradient IS the staged gradient gT[l][n][F] of this grid's levels

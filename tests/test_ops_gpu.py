@@ -606,6 +606,46 @@ def test_hashgrid_backward_with_fused_adam_matches_backward_then_adam(from_level
         assert float((got - ref).abs().max()) <= tol * max(1e-3, float(ref.abs().max())), i
 
 
+@pytest.mark.parametrize("L0,L1,from0,from1", [(4, 4, 1, 0), (3, 5, 3, 2)])
+def test_both_grids_of_a_head_in_one_table_backward_launch(L0, L1, from0, from1):
+    """snf_hashgrid_bwd_presorted_adam_pair (two F = 8 tables, level-major gradients, one reduce launch; interleaved level order
+    when L0 == L1) against two snf_hashgrid_bwd_presorted_adam launches: parameters, moments and the gradients left below the
+    fused levels, to the float reduce's summation order."""
+    m = ops()
+    T, N, F = 14, 30000, 8
+    gen = torch.Generator(device="cuda").manual_seed(L0 * 10 + L1)
+    u = torch.rand((N, 3), device="cuda", generator=gen)
+    st = m._stream()
+    grids = []
+    for L, lo, hi in ((L0, 16, 64), (L1, 64, 256)):
+        sc = O.hash_scalings(L, lo, hi).cuda()
+        n = (L << T) * F
+        nbytes = int(m._L().snf_hashgrid_bwd_workspace_bytes(N, L, T))
+        ws = torch.empty(((nbytes + 3) // 4,), device="cuda", dtype=torch.int32)
+        m._launch("snf_hashgrid_sort", m._p(u), m._p(sc), N, L, T, m._p(ws), nbytes, st)
+        grids.append(dict(L=L, ws=ws, n=n, p=torch.rand((n,), device="cuda", generator=gen) - 0.5,
+                          m=(torch.rand((n,), device="cuda", generator=gen) - 0.5) * 1e-3,
+                          v=torch.rand((n,), device="cuda", generator=gen) * 1e-6,
+                          gy=torch.randn((L * N * F,), device="cuda", generator=gen) * 1e-2))
+    hyper = (1e-2, 0.9, 0.999, 1e-15, 3, 0.5)
+    ref, got = [], []
+    for g, frm in zip(grids, (from0, from1)):
+        p, mm, vv, gt = g["p"].clone(), g["m"].clone(), g["v"].clone(), torch.zeros((g["n"],), device="cuda")
+        m._launch("snf_hashgrid_bwd_presorted_adam", m._p(g["gy"]), N, g["L"], F, T, 0, 0, 0, m._p(gt), m._p(g["ws"]), None, frm,
+                  m._p(p), m._p(mm), m._p(vv), *hyper, st)
+        ref.append((p, mm, vv, gt))
+        got.append((g["p"].clone(), g["m"].clone(), g["v"].clone(), torch.zeros((g["n"],), device="cuda")))
+    m._launch("snf_hashgrid_bwd_presorted_adam_pair", m._p(grids[0]["gy"]), m._p(grids[1]["gy"]), N, L0, L1, T, m._p(got[0][3]),
+              m._p(got[1][3]), m._p(grids[0]["ws"]), m._p(grids[1]["ws"]), from0, from1, m._p(got[0][0]), m._p(got[0][1]),
+              m._p(got[0][2]), m._p(got[1][0]), m._p(got[1][1]), m._p(got[1][2]), *hyper, st)
+    for gi in range(2):
+        if (from0, from1)[gi] < grids[gi]["L"]:
+            assert float((ref[gi][0] - grids[gi]["p"]).abs().max()) > 1e-3  # the step moved something
+        for i, tol in ((0, 2e-6), (1, 1e-6), (2, 1e-6), (3, 1e-5)):
+            r, g_ = ref[gi][i], got[gi][i]
+            assert float((g_ - r).abs().max()) <= tol * max(1e-3, float(r.abs().max())), (gi, i)
+
+
 # ---------------------------------------------------------------------------------------------
 def _planar8(x: torch.Tensor) -> torch.Tensor:
     """row-major [N, C] -> level-major [C/8][N][8] (flat)."""

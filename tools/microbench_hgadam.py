@@ -17,6 +17,7 @@ CASES = {  # N, L, F, T, base, max, planar gradient, clustered positions
     "f2": (524288, 16, 2, 19, 16, 2048, True, True),
     "f2p": (262144, 5, 2, 17, 16, 128, False, True),
     # probes of the coarse-level tail: the same sample counts with every level hashed (no bucket holds more than 8N/256 records)
+    "f8ab": (65536, 24, 8, 19, 16, 512, True, False),       # both grids of a head as ONE 24-level launch (what a paired launch would cost)
     "f8a_sparse": (65536, 8, 8, 19, 16, 90, True, False),   # the reachable-row levels of f8a alone
     "f8a_dense": (65536, 4, 8, 19, 99, 128, True, False),   # its dense levels alone
     "f2c": (524288, 5, 2, 19, 16, 58, True, True),        # the field grid's five coarse levels alone
