@@ -271,3 +271,62 @@ def test_static_schedule_against_the_reference_ministep(golden, grad_parity):
     assert abs(float(md_["psnr"]) + 10.0 * np.log10(float(g["rgb_loss"]))) <= 1e-3
     grads = named_grads(model)
     grad_parity(grads, {k: g["grad_" + k] for k in params})
+
+
+def test_rendered_head_path_against_the_oracle(grad_parity):
+    """R x K = 8192 feature samples: the size from which the schedule renders the heads' hidden activations inside the GEMMs
+    (snf_linear_fwd_mean, snf_linear_bwd_*_rows, both grids of a head in one table-backward launch) -- outputs, losses and every
+    parameter gradient against the CPU oracle on the same rays (the oracle applies the last layer per sample and renders after
+    it, sam_field.py:121-137 / sam_model.py:126-137)."""
+    import copy
+    from oracle import samnerf_oracle as O
+    from samnerf_amd import configs, tcnn_compat
+    from samnerf_amd.interop import load_named_params, named_grads
+    from samnerf_amd.rays import RayBundle
+    from samnerf_amd.step_program import StepProgram
+    R, P, S, K, patch, T = 512, 64, 32, 16, 4, 13
+    cfg = O.PathConfig(num_proposal_samples=P, num_nerf_samples=S, num_sam_samples=K, patch_size=patch).small(T)
+    params = O.init_params(cfg, seed=11, table_scale=0.05)
+    o, d = O.synthetic_rays(R, 12)
+    batch = O.synthetic_batch(cfg, R, 13)
+    gen = torch.Generator().manual_seed(14)
+    t_rand, u_rand = torch.rand((R, 1), generator=gen), torch.rand((R, 1), generator=gen)
+    op = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    ref = O.forward(op, cfg, o, d, True, t_rand, u_rand, 1.0)
+    rl = O.loss_dict(ref, batch, cfg)
+    sum(rl.values()).backward()
+    tc = copy.deepcopy(configs.method_configs["samnerf_distill"])
+    tc.pipeline.datamanager.train_num_rays_per_batch = R
+    mc = tc.pipeline.model
+    mc.num_proposal_samples_per_ray, mc.num_nerf_samples_per_ray, mc.num_sam_samples, mc.patch_size = (P,), S, K, patch
+    mc.log2_hashmap_size, mc.hashgrid_sizes = T, (T, T)
+    mc.proposal_net_args_list = [dict(a, log2_hashmap_size=T) for a in mc.proposal_net_args_list]
+    tcnn_compat.manual_seed(0)
+    trainer = tc.setup(device="cuda")
+    trainer.setup()
+    model = trainer.pipeline.model
+    load_named_params(model, params)
+    rb = RayBundle(origins=o.cuda(), directions=d.cuda(), pixel_area=torch.full((R, 1), 1e-6, device="cuda"),
+                   camera_indices=torch.zeros((R, 1), dtype=torch.long, device="cuda"))
+    dev_batch = {k: v.cuda() for k, v in batch.items()}
+    trainer.pipeline.datamanager.next_train = lambda step: (copy.copy(rb), dev_batch)
+    ps = model.proposal_sampler
+    ps.initial_sampler.jitter_override, ps.pdf_sampler.jitter_override = t_rand.cuda(), u_rand.cuda()
+    ps.set_anneal(1.0)
+    assert StepProgram.unsupported_reason(trainer) is None
+    prog = StepProgram(trainer)
+    trainer.optimizers.enabled = False
+    loss, ld, _ = prog.run(0)
+    for st in (trainer._side or {}).values():
+        torch.cuda.current_stream().wait_stream(st)
+    torch.cuda.synchronize()
+    names = {e[3].partition("/")[0] for plan in prog.plans.values() for e in plan.entries if e[0] == 0}
+    assert {"snf_linear_fwd_mean", "snf_linear_bwd_data_rows", "snf_linear_bwd_weight_rows",
+            "snf_hashgrid_bwd_presorted_adam_pair"} <= names, names
+    out = prog.outputs()
+    for k in ("rgb", "sam", "clipseg"):
+        assert float((out[k].cpu() - ref[k].detach()).abs().max()) <= 1e-4, k
+    for k, v in rl.items():
+        assert abs(float(ld[k]) - float(v)) <= 1e-4 * max(1.0, abs(float(v))), k
+    grads = named_grads(model)
+    grad_parity(grads, {k: v.grad.numpy() for k, v in op.items() if v.grad is not None and k in grads})
