@@ -311,6 +311,14 @@ __device__ __forceinline__ void mc_split2(float x0, float x1, uint32_t& hi, uint
     lo = mc_cvt_pk(x0 - __uint_as_float(hi << 16), x1 - __uint_as_float(hi & 0xFFFF0000u));
 }
 
+// three bf16 pieces (24 mantissa bits): hi + mid + lo reproduces an fp32 value to its last bit or two
+__device__ __forceinline__ void mc_split3(float x0, float x1, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
+    hi = mc_cvt_pk(x0, x1);
+    const float r0 = x0 - __uint_as_float(hi << 16), r1 = x1 - __uint_as_float(hi & 0xFFFF0000u);
+    mid = mc_cvt_pk(r0, r1);
+    lo = mc_cvt_pk(r0 - __uint_as_float(mid << 16), r1 - __uint_as_float(mid & 0xFFFF0000u));
+}
+
 constexpr int MC_BP32 = 40;  // bf16 elements per plane row with 32 k-slots (80 B: conflict-free b128 reads)
 constexpr int MC_BP64 = 72;  // ... with 64 k-slots (144 B)
 
@@ -334,6 +342,56 @@ __device__ __forceinline__ void mc_stage(uint16_t* __restrict__ Ph, uint16_t* __
         mc_split2(get(m, mc_slot_k<LIN>(sl)), get(m, mc_slot_k<LIN>(sl + 1)), h, l);
         *reinterpret_cast<uint32_t*>(&Ph[m * pitch + sl]) = h;
         *reinterpret_cast<uint32_t*>(&Pl[m * pitch + sl]) = l;
+    }
+}
+
+// the same with three planes (hi / mid / lo)
+template <bool LIN, class G>
+__device__ __forceinline__ void mc_stage3(uint16_t* __restrict__ Ph, uint16_t* __restrict__ Pm, uint16_t* __restrict__ Pl, int pitch,
+                                          int rows, int slots, G get) {
+    const int pairs = slots >> 1;
+    for (int i = threadIdx.x; i < rows * pairs; i += blockDim.x) {
+        const int m = i / pairs, sl = (i - m * pairs) * 2;
+        uint32_t h, md, l;
+        mc_split3(get(m, mc_slot_k<LIN>(sl)), get(m, mc_slot_k<LIN>(sl + 1)), h, md, l);
+        *reinterpret_cast<uint32_t*>(&Ph[m * pitch + sl]) = h;
+        *reinterpret_cast<uint32_t*>(&Pm[m * pitch + sl]) = md;
+        *reinterpret_cast<uint32_t*>(&Pl[m * pitch + sl]) = l;
+    }
+}
+
+// Six-product variant of mc_layer_b3: both operands as hi + mid + lo, products hh + hm + mh + mm + hl + lh (the dropped ml, lm,
+// ll are <= 2^-24 of the product): fp32-level accuracy (1e-7) at 6 x 32 matrix cycles per 16 k against 8 x 64 for the fp32 MFMA.
+template <int NT, int NU, bool LIN>
+__device__ __forceinline__ void mc_layer_b6(const uint16_t* __restrict__ Ph, const uint16_t* __restrict__ Pm,
+                                            const uint16_t* __restrict__ Pl, int pitch, const f32x16 (&act)[NT], f32x16 (&out)[NU],
+                                            int li, int half) {
+#pragma unroll
+    for (int u = 0; u < NU; ++u) out[u] = zero16();
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            uint32_t h[4], md[4], l[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) mc_split3(act[t][8 * s + 2 * p], act[t][8 * s + 2 * p + 1], h[p], md[p], l[p]);
+            const mc_bf16x8 bh = __builtin_bit_cast(mc_bf16x8, make_uint4(h[0], h[1], h[2], h[3]));
+            const mc_bf16x8 bm = __builtin_bit_cast(mc_bf16x8, make_uint4(md[0], md[1], md[2], md[3]));
+            const mc_bf16x8 bl = __builtin_bit_cast(mc_bf16x8, make_uint4(l[0], l[1], l[2], l[3]));
+            const int slot0 = t * 32 + s * 16 + half * 8;
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                const mc_bf16x8 ah = *reinterpret_cast<const mc_bf16x8*>(&Ph[(u * 32 + li) * pitch + slot0]);
+                const mc_bf16x8 am = *reinterpret_cast<const mc_bf16x8*>(&Pm[(u * 32 + li) * pitch + slot0]);
+                const mc_bf16x8 al = *reinterpret_cast<const mc_bf16x8*>(&Pl[(u * 32 + li) * pitch + slot0]);
+                out[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, out[u], 0, 0, 0);  // smallest terms first
+                out[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, out[u], 0, 0, 0);
+                out[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, out[u], 0, 0, 0);
+                out[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, out[u], 0, 0, 0);
+                out[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, out[u], 0, 0, 0);
+                out[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, out[u], 0, 0, 0);
+            }
+        }
     }
 }
 
@@ -366,26 +424,36 @@ __device__ __forceinline__ void mc_layer_b3(const uint16_t* __restrict__ Ph, con
     }
 }
 
-constexpr int chain_b3_lds_elems(int NH) {  // bf16 elements, both planes of every matrix
-    return 2 * (MC_H * MC_BP32 + (NH == 2 ? MC_H * MC_BP64 : 0) + 32 * MC_BP64);
+constexpr int chain_b3_lds_elems(int NH, int planes = 2) {  // bf16 elements, all planes of every matrix
+    return planes * (MC_H * MC_BP32 + (NH == 2 ? MC_H * MC_BP64 : 0) + 32 * MC_BP64);
 }
 
-template <int NH>
+template <int NH, int PLANES = 2>
 __global__ __launch_bounds__(256) void k_mlp_chain_fwd_b3(const float* __restrict__ X, int ldx, const float* __restrict__ W0,
                                                           int in_real, const float* __restrict__ W1,
                                                           const float* __restrict__ Wout, int out, int out_act, long long N,
                                                           float* __restrict__ H1, float* __restrict__ H2,
                                                           float* __restrict__ Y, int ldy) {
     extern __shared__ __attribute__((aligned(16))) uint16_t ldsb[];
+    constexpr int SZ0 = MC_H * MC_BP32, SZ1 = (NH == 2 ? MC_H * MC_BP64 : 0), SZO = 32 * MC_BP64;
     uint16_t* p0h = ldsb;                          // W0  [64][MC_BP32]  LIN slots over the 32 inputs
-    uint16_t* p0l = p0h + MC_H * MC_BP32;
-    uint16_t* p1h = p0l + MC_H * MC_BP32;          // W1  [64][MC_BP64]  (NH == 2)
-    uint16_t* p1l = p1h + (NH == 2 ? MC_H * MC_BP64 : 0);
-    uint16_t* poh = p1l + (NH == 2 ? MC_H * MC_BP64 : 0);  // Wout [32][MC_BP64], rows >= out zero
-    uint16_t* pol = poh + 32 * MC_BP64;
-    mc_stage<true>(p0h, p0l, MC_BP32, MC_H, MC_IN, [&](int m, int k) { return k < in_real ? W0[m * in_real + k] : 0.f; });
-    if constexpr (NH == 2) mc_stage<false>(p1h, p1l, MC_BP64, MC_H, MC_H, [&](int m, int k) { return W1[m * MC_H + k]; });
-    mc_stage<false>(poh, pol, MC_BP64, 32, MC_H, [&](int m, int k) { return m < out ? Wout[m * MC_H + k] : 0.f; });
+    uint16_t* p0l = p0h + SZ0;
+    uint16_t* p1h = p0l + SZ0;                     // W1  [64][MC_BP64]  (NH == 2)
+    uint16_t* p1l = p1h + SZ1;
+    uint16_t* poh = p1l + SZ1;                     // Wout [32][MC_BP64], rows >= out zero
+    uint16_t* pol = poh + SZO;
+    uint16_t* p0m = pol + SZO;                     // the mid planes (PLANES == 3) behind the hi / lo ones
+    uint16_t* p1m = p0m + SZ0;
+    uint16_t* pom = p1m + SZ1;
+    if constexpr (PLANES == 3) {
+        mc_stage3<true>(p0h, p0m, p0l, MC_BP32, MC_H, MC_IN, [&](int m, int k) { return k < in_real ? W0[m * in_real + k] : 0.f; });
+        if constexpr (NH == 2) mc_stage3<false>(p1h, p1m, p1l, MC_BP64, MC_H, MC_H, [&](int m, int k) { return W1[m * MC_H + k]; });
+        mc_stage3<false>(poh, pom, pol, MC_BP64, 32, MC_H, [&](int m, int k) { return m < out ? Wout[m * MC_H + k] : 0.f; });
+    } else {
+        mc_stage<true>(p0h, p0l, MC_BP32, MC_H, MC_IN, [&](int m, int k) { return k < in_real ? W0[m * in_real + k] : 0.f; });
+        if constexpr (NH == 2) mc_stage<false>(p1h, p1l, MC_BP64, MC_H, MC_H, [&](int m, int k) { return W1[m * MC_H + k]; });
+        mc_stage<false>(poh, pol, MC_BP64, 32, MC_H, [&](int m, int k) { return m < out ? Wout[m * MC_H + k] : 0.f; });
+    }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 31, half = lane >> 5;
@@ -412,7 +480,8 @@ __global__ __launch_bounds__(256) void k_mlp_chain_fwd_b3(const float* __restric
         for (int i = 0; i < 16; ++i)
             if (half * 16 + i >= in_real) x[0][i] = 0.f;  // pad columns may hold anything (select, not multiply)
         f32x16 h1[2];
-        mc_layer_b3<1, 2, true>(p0h, p0l, MC_BP32, x, h1, li, half);
+        if constexpr (PLANES == 3) mc_layer_b6<1, 2, true>(p0h, p0m, p0l, MC_BP32, x, h1, li, half);
+        else mc_layer_b3<1, 2, true>(p0h, p0l, MC_BP32, x, h1, li, half);
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -420,7 +489,8 @@ __global__ __launch_bounds__(256) void k_mlp_chain_fwd_b3(const float* __restric
         if (H1 != nullptr && ok) store_h64(H1, s, h1, half);
         f32x16 last[2];
         if constexpr (NH == 2) {
-            mc_layer_b3<2, 2, false>(p1h, p1l, MC_BP64, h1, last, li, half);
+            if constexpr (PLANES == 3) mc_layer_b6<2, 2, false>(p1h, p1m, p1l, MC_BP64, h1, last, li, half);
+            else mc_layer_b3<2, 2, false>(p1h, p1l, MC_BP64, h1, last, li, half);
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -431,7 +501,8 @@ __global__ __launch_bounds__(256) void k_mlp_chain_fwd_b3(const float* __restric
             last[1] = h1[1];
         }
         f32x16 y[1];
-        mc_layer_b3<2, 1, false>(poh, pol, MC_BP64, last, y, li, half);
+        if constexpr (PLANES == 3) mc_layer_b6<2, 1, false>(poh, pom, pol, MC_BP64, last, y, li, half);
+        else mc_layer_b3<2, 1, false>(poh, pol, MC_BP64, last, y, li, half);
         if (ok) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -877,12 +948,22 @@ extern "C" int snf_mlp64_fwd(const float* X, int ldx, const float* W0, int in_re
     const long long ntiles = (N + 31) / 32;
     long long blocks = (ntiles + 3) / 4;
     if (blocks > 256 * 4) blocks = 256 * 4;  // persistent: <= 4 workgroups per CU
+    // gemm mode 1 (default): the forward chains on the six-product bf16 split (fp32-level accuracy, 2.7x less matrix time than the
+    // fp32 MFMA); SNF_CHAIN_FWD_X6=0 keeps the fp32 MFMA there.  Mode 0: fp32 MFMA.  Mode 2: the three-product split.
+    static const int x6 = getenv("SNF_CHAIN_FWD_X6") ? atoi(getenv("SNF_CHAIN_FWD_X6")) : 1;
     if (chain_b3_on()) {
         if (n_hidden == 2)
             hipLaunchKernelGGL(k_mlp_chain_fwd_b3<2>, dim3((unsigned)blocks), dim3(256), chain_b3_lds_elems(2) * sizeof(uint16_t),
                                (hipStream_t)stream, X, ldx, W0, in_real, W1, Wout, out, out_act, (long long)N, H1, H2, Y, ldy);
         else
             hipLaunchKernelGGL(k_mlp_chain_fwd_b3<1>, dim3((unsigned)blocks), dim3(256), chain_b3_lds_elems(1) * sizeof(uint16_t),
+                               (hipStream_t)stream, X, ldx, W0, in_real, W1, Wout, out, out_act, (long long)N, H1, H2, Y, ldy);
+    } else if (x6 && snf_get_gemm_mode() == 1) {
+        if (n_hidden == 2)
+            hipLaunchKernelGGL((k_mlp_chain_fwd_b3<2, 3>), dim3((unsigned)blocks), dim3(256), chain_b3_lds_elems(2, 3) * sizeof(uint16_t),
+                               (hipStream_t)stream, X, ldx, W0, in_real, W1, Wout, out, out_act, (long long)N, H1, H2, Y, ldy);
+        else
+            hipLaunchKernelGGL((k_mlp_chain_fwd_b3<1, 3>), dim3((unsigned)blocks), dim3(256), chain_b3_lds_elems(1, 3) * sizeof(uint16_t),
                                (hipStream_t)stream, X, ldx, W0, in_real, W1, Wout, out, out_act, (long long)N, H1, H2, Y, ldy);
     } else if (n_hidden == 2)
         hipLaunchKernelGGL(k_mlp_chain_fwd<2>, dim3((unsigned)blocks), dim3(256), chain_lds_floats(2) * sizeof(float),

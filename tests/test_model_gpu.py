@@ -639,7 +639,7 @@ def test_two_ranks_on_one_gpu_match_accumulated_single_process(tmp_path, static)
             # reference process -- eager path -- before it: their bf16-split GEMMs round differently (7e-6 of the largest
             # gradient entry after one step, checked above at 1e-5), and three Adam steps at eps = 1e-15 spread that further)
             loose = static and k.startswith("sam_field")
-            b_sig, b_max, b_cnt = (5e-4, 5e-3, 3e-2) if loose else (6e-5, 1.5e-3, 2e-3)
+            b_sig, b_max, b_cnt = (5e-4, 5e-3, 3e-2) if loose else (6e-5, 1.5e-3, 5e-3 if static else 2e-3)
             assert float(d[sig].max()) <= b_sig and float(d.max()) <= b_max and int((d > 1e-5).sum()) <= b_cnt * d.numel(), info
         else:
             assert float(d.max()) <= (1e-2 if static else 2e-3) * max(float(a[k].abs().max()), 1e-30), (k, float(d.max()))
