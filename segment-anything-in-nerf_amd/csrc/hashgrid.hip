@@ -468,8 +468,13 @@ struct HgSecond {
     int interleave;
 };
 
+#ifndef SNF_HG_RT_MINWG
+#define SNF_HG_RT_MINWG 4
+#endif
+// (HIP: the second launch-bounds value is the minimum WAVES per SIMD.  Two 8-wave workgroups per CU -- LDS allows it at F = 8 --
+// are 4 waves per SIMD, i.e. <= 128 VGPRs; without the hint the compiler took 130: ONE workgroup per CU)
 template <int F, bool ADAM>
-__global__ __launch_bounds__(HG_RT) void k_hg_reduce(const float* __restrict__ gT, int N, int log2_T, int log2B,
+__global__ __launch_bounds__(HG_RT, SNF_HG_RT_MINWG) void k_hg_reduce(const float* __restrict__ gT, int N, int log2_T, int log2B,
                                                      const uint32_t* __restrict__ bucket_start,
                                                      const uint2* __restrict__ records, float* __restrict__ grad_table,
                                                      uint32_t hg_long, int n_run_levels, HgAdam adam, HgSecond sec) {
