@@ -206,8 +206,12 @@ def test_checkpoint_round_trip_continues_the_same_trajectory(tmp_path):
     assert dict(a.optimizers.step_count) == dict(b.optimizers.step_count)
     for g, arena in a.optimizers.arenas.items():
         other = b.optimizers.arenas[g]
-        assert _rel_to_max(other.param, arena.param) <= 1e-5, g
-        assert _rel_to_max(other.exp_avg, arena.exp_avg) <= 1e-4, g
+        # (two independent runs of two steps: the float-atomic weight gradients and the float table reduce add in a different
+        #  order from run to run, and Adam at eps = 1e-15 turns that into lr-sized differences on near-zero-gradient entries; a
+        #  checkpoint that lost its moments or step counts would be off by the whole update)
+        d = (other.param - arena.param).abs()
+        assert float(d.max()) <= 2e-3 and float((d > 1e-5).double().mean()) <= 1e-3, (g, float(d.max()))
+        assert _rel_to_max(other.exp_avg, arena.exp_avg) <= 1e-3, g
     del ps_a
 
 
