@@ -166,7 +166,8 @@ constexpr int HG_RT = 512;       // threads of the reduce workgroup (8 waves; 4 
 template <int F> constexpr int hg_chunk() { return F == 8 ? SNF_HG_CHUNK8 : 2048; }
 constexpr int HG_MAX_RPB = 2048; // rows per bucket (HG_ROWS_PT per reduce thread)
 constexpr int HG_ROWS_PT = HG_MAX_RPB / HG_RT;
-constexpr int HG_LONG = 16;      // segments longer than this are reduced by a wave
+constexpr int HG_LONG = 48;      // segments longer than this are reduced by a wave (16 until the kernel ran two workgroups per CU:
+                                 // 32 .. 64 then measured 5-8 % faster alone, tools/sweep_hg_long.sh)
 #ifndef SNF_HG_EPI
 #define SNF_HG_EPI 2
 #endif
