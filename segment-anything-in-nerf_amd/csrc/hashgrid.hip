@@ -283,7 +283,10 @@ constexpr int HG_SAMPLE_BITS = 21;  // N <= 2^21 per launch (row_in_bucket needs
 // counting-sorted by bucket in LDS and leaves as one contiguous run per bucket (~128 B at 256 buckets) instead of 8-byte
 // stores to 256 different cache lines -- the store-transaction count, not the byte count, bounded the direct version
 // (rocprofv3: 84 % of its wave cycles were issue stalls behind the store queue).
-constexpr int HG_SB_SPT = 2;                      // samples per thread per batch
+#ifndef SNF_HG_SB_SPT
+#define SNF_HG_SB_SPT 2
+#endif
+constexpr int HG_SB_SPT = SNF_HG_SB_SPT;          // samples per thread per batch (1: 64-B runs, 7 workgroups per CU; 4: 256-B runs, 1)
 constexpr int HG_SB_REC = 256 * HG_SB_SPT * 8;    // 4096 staged records (32 KB)
 
 inline size_t hg_scatter_lds_bytes(int log2B) {
