@@ -248,7 +248,9 @@ int snf_mlp64_bwd_data(const float* dY, int lddy, int dy_col_off, const float* d
  * transpose, so dH1 / dH2 / dZ are never written and X / H1 / H2 are read once instead of twice (-1.2 GB of HBM traffic per
  * train step for the two nerfacto nets).  dW0 [64, in_real], dW1 [64,64], dWout [out,64] are ACCUMULATED (plain adds by one
  * reduce kernel over per-workgroup partials in `workspace`: snf_mlp64_bwd_fused_workspace_bytes(n_hidden) bytes).  X as in
- * snf_mlp64_fwd (ldx = 0: level-major).  Replaces snf_mlp64_bwd_data + three snf_linear_bwd_weight calls. */
+ * snf_mlp64_fwd (ldx = 0: level-major).  Replaces snf_mlp64_bwd_data + three snf_linear_bwd_weight calls.  * H1 = H2 = NULL ("recompute", gemm mode 1): the hidden activations are formed again from X inside the kernel with the forward's
+ * own arithmetic (bit-identical), so snf_mlp64_fwd may be called with H1 = H2 = NULL as well and the [N,64] activations never reach
+ * HBM. */
 int64_t snf_mlp64_bwd_fused_workspace_bytes(int n_hidden);
 int snf_mlp64_bwd_fused(const float* dY, int lddy, int dy_col_off, const float* dY0, const float* Y, int ldy, const float* X,
                         int ldx, const float* W0, int in_real, const float* W1, const float* Wout, int n_hidden, int out,

@@ -662,7 +662,14 @@ __device__ __forceinline__ f32x16 wg_mma3(const mc_bf16x8& ah, const mc_bf16x8& 
 // partial layout per workgroup (floats): Wout [32][64] | W1 [64][64] (NH == 2) | W0 [64][32]
 constexpr int wg_partial_floats(int NH) { return 32 * 64 + (NH == 2 ? 64 * 64 : 0) + 64 * 32; }
 
-template <int NH>
+// RC ("recompute"): H1 / H2 are NOT read -- the hidden activations are formed again from X with the forward's own arithmetic
+// (mc_layer_b6 on the same three-plane weights: bit-identical to what k_mlp_chain_fwd_b3<NH, 3> computed, so the ReLU masks and
+// the weight-gradient operands are the forward's), and the forward does not have to write them: 0.4 GB less written and 0.4 GB
+// less read per step for the two field nets.  The two-hidden-layer net forms H1 twice (once on the way to H2, once when it is
+// needed itself) rather than keeping 32 more registers alive.
+constexpr int wg_rc_lds_elems(int NH) { return 3 * (MC_H * MC_BP32 + (NH == 2 ? MC_H * MC_BP64 : 0)); }
+
+template <int NH, bool RC = false>
 __global__ __launch_bounds__(WG_T) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_mlp_chain_bwd_wg(const float* __restrict__ dY, int lddy, int dy_col_off,
                                                            const float* __restrict__ dY0, const float* __restrict__ Yout,
                                                            int ldy, const float* __restrict__ X, int ldx,
@@ -680,6 +687,19 @@ __global__ __launch_bounds__(WG_T) __attribute__((amdgpu_waves_per_eu(1, 1))) vo
     float* __restrict__ T = stage_all + wave * WG_STAGE;
     float* __restrict__ Z = stage_all + WG_WAVES * WG_STAGE + wave * WG_DZ;  // dZ^T, rows >= out stay zero
     for (int i = lane; i < WG_DZ; i += 64) Z[i] = 0.f;
+    // RC: W0 (LIN slots) and W1 as hi / mid / lo bf16 planes behind the staging area, exactly as the forward kernel stages them
+    constexpr int RS0 = MC_H * MC_BP32, RS1 = NH == 2 ? MC_H * MC_BP64 : 0;
+    uint16_t* __restrict__ r0h = reinterpret_cast<uint16_t*>(stage_all + WG_WAVES * (WG_STAGE + WG_DZ));
+    uint16_t* __restrict__ r0m = r0h + RS0;
+    uint16_t* __restrict__ r0l = r0m + RS0;
+    uint16_t* __restrict__ r1h = r0l + RS0;
+    uint16_t* __restrict__ r1m = r1h + RS1;
+    uint16_t* __restrict__ r1l = r1m + RS1;
+    if constexpr (RC) {
+        mc_stage3<true>(r0h, r0m, r0l, MC_BP32, MC_H, MC_IN, [&](int m, int k) { return k < in_real ? W0[m * in_real + k] : 0.f; });
+        if constexpr (NH == 2) mc_stage3<false>(r1h, r1m, r1l, MC_BP64, MC_H, MC_H, [&](int m, int k) { return W1[m * MC_H + k]; });
+        __syncthreads();
+    }
     const int outp = (out + 1) & ~1;
     const int hsteps = outp >> 1;
     constexpr int NT = NH == 2 ? 8 : 4;
@@ -691,6 +711,32 @@ __global__ __launch_bounds__(WG_T) __attribute__((amdgpu_waves_per_eu(1, 1))) vo
         const long long s = tile * 32 + li;
         const bool ok = s < N;
         const long long sc = ok ? s : N - 1;
+        f32x16 xr[1];  // RC: this lane's half of the input row (features half*16 .. +15), pad columns zero as in the forward
+        if constexpr (RC) {
+            if (ldx == 0) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const float2 v = *reinterpret_cast<const float2*>(X + ((long long)(half * 8 + q) * N + sc) * 2);
+                    xr[0][2 * q] = v.x; xr[0][2 * q + 1] = v.y;
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 v = *reinterpret_cast<const float4*>(X + sc * ldx + half * 16 + 4 * q);
+                    xr[0][4 * q] = v.x; xr[0][4 * q + 1] = v.y; xr[0][4 * q + 2] = v.z; xr[0][4 * q + 3] = v.w;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                if (half * 16 + i >= in_real) xr[0][i] = 0.f;
+        }
+        auto hidden1 = [&](f32x16 (&h)[2]) {  // H1^T tile pair of this wave's 32 samples, ReLU applied
+            mc_layer_b6<1, 2, true>(r0h, r0m, r0l, MC_BP32, xr, h, li, half);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) h[t][r] = fmaxf(h[t][r], 0.f);
+        };
         // ---- dZ, dLast^T[k][s] = sum_o Wout[o][k] dZ^T[o][s]; dZ^T goes to its LDS matrix on the way
         f32x16 dl[2] = {zero16(), zero16()};
         for (int st = 0; st < hsteps; ++st) {
@@ -714,7 +760,21 @@ __global__ __launch_bounds__(WG_T) __attribute__((amdgpu_waves_per_eu(1, 1))) vo
         for (int ks = 0; ks < 2; ++ks) wg_frag(Z, li, ks, half, zh[ks], zl[ks]);
         f32x16 hh[2];
         // ---- last hidden layer: its activations are the B side of dWout and the ReLU mask of dLast
-        load_h64(NH == 2 ? H2 : H1, sc, hh, half);
+        if constexpr (RC) {
+            if constexpr (NH == 2) {
+                f32x16 h1t[2];
+                hidden1(h1t);
+                mc_layer_b6<2, 2, false>(r1h, r1m, r1l, MC_BP64, h1t, hh, li, half);
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) hh[t][r] = fmaxf(hh[t][r], 0.f);
+            } else {
+                hidden1(hh);
+            }
+        } else {
+            load_h64(NH == 2 ? H2 : H1, sc, hh, half);
+        }
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -750,7 +810,8 @@ __global__ __launch_bounds__(WG_T) __attribute__((amdgpu_waves_per_eu(1, 1))) vo
             for (int u = 0; u < 2; ++u)
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) wg_frag(T, 32 * u + li, ks, half, ah[u][ks], al[u][ks]);
-            load_h64(H1, sc, hh, half);
+            if constexpr (RC) hidden1(hh);
+            else load_h64(H1, sc, hh, half);
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -803,7 +864,10 @@ __global__ __launch_bounds__(WG_T) __attribute__((amdgpu_waves_per_eu(1, 1))) vo
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) wg_frag(T, 32 * u + li, ks, half, a0h[u][ks], a0l[u][ks]);
         float x[16];
-        if (ldx == 0) {
+        if constexpr (RC) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) x[i] = xr[0][i];
+        } else if (ldx == 0) {
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const float2 v = *reinterpret_cast<const float2*>(X + ((long long)(half * 8 + q) * N + sc) * 2);
@@ -1025,40 +1089,40 @@ extern "C" int snf_mlp64_bwd_fused(const float* dY, int lddy, int dy_col_off, co
                                    snf_stream_t stream) {
     int rc = chain_common_checks("snf_mlp64_bwd_fused", in_real, n_hidden, out, N);
     if (rc) return rc;
-    SNF_REQUIRE(dY && X && W0 && Wout && H1 && dW0 && dWout && workspace && (n_hidden == 1 || (W1 && H2 && dW1)),
+    const bool recompute = H1 == nullptr;  // the hidden activations are formed again from X (six-product forward arithmetic)
+    SNF_REQUIRE(dY && X && W0 && Wout && dW0 && dWout && workspace && (n_hidden == 1 || (W1 && dW1 && (recompute || H2))),
                 "snf_mlp64_bwd_fused: null pointer");
+    SNF_REQUIRE(!recompute || (H2 == nullptr && snf_get_gemm_mode() == 1),
+                "snf_mlp64_bwd_fused: H1 = NULL (recompute) needs H2 = NULL and gemm mode 1 (the forward whose arithmetic it repeats)");
     SNF_REQUIRE(out_act != SNF_ACT_SIGMOID || Y, "snf_mlp64_bwd_fused: Y required for the sigmoid derivative");
     SNF_REQUIRE(out_act != SNF_ACT_RELU, "snf_mlp64_bwd_fused: ReLU output activation is not supported");
     SNF_REQUIRE((ldx == 0 || (ldx >= MC_IN && ldx % 4 == 0)) && ((uintptr_t)X % 16) == 0,
                 "snf_mlp64_bwd_fused: X must be [N, ldx>=32] (ldx %% 4 == 0) or level-major (ldx = 0), 16-byte aligned");
     SNF_REQUIRE(!dX || ((lddx == 0 || (lddx >= MC_IN && lddx % 4 == 0)) && ((uintptr_t)dX % 16) == 0),
                 "snf_mlp64_bwd_fused: bad dX layout");
-    SNF_REQUIRE(((uintptr_t)H1 % 16) == 0 && (!H2 || ((uintptr_t)H2 % 16) == 0) && ((uintptr_t)workspace % 16) == 0,
+    SNF_REQUIRE((!H1 || ((uintptr_t)H1 % 16) == 0) && (!H2 || ((uintptr_t)H2 % 16) == 0) && ((uintptr_t)workspace % 16) == 0,
                 "snf_mlp64_bwd_fused: unaligned H1 / H2 / workspace");
     SNF_REQUIRE(workspace_bytes >= snf_mlp64_bwd_fused_workspace_bytes(n_hidden), "snf_mlp64_bwd_fused: workspace too small");
     const long long ntiles = (N + 31) / 32;
     long long blocks = (ntiles + WG_WAVES - 1) / WG_WAVES;
     if (blocks > 256) blocks = 256;  // persistent: one workgroup per CU (LDS)
     float* P = (float*)workspace;
-    const size_t lds = (size_t)(chain_lds_floats(n_hidden) + WG_WAVES * (WG_STAGE + WG_DZ)) * sizeof(float);
+    const size_t lds = (size_t)(chain_lds_floats(n_hidden) + WG_WAVES * (WG_STAGE + WG_DZ)) * sizeof(float) +
+                       (recompute ? (size_t)wg_rc_lds_elems(n_hidden) * sizeof(uint16_t) : 0);
     hipStream_t st = (hipStream_t)stream;
-    if (n_hidden == 2) {
-        static bool attr2 = false;
-        if (!attr2) {
-            hipFuncSetAttribute((const void*)k_mlp_chain_bwd_wg<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr2 = true;
+    auto launch = [&](auto kern, bool& attr) {
+        if (!attr) {
+            hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr = true;
         }
-        hipLaunchKernelGGL(k_mlp_chain_bwd_wg<2>, dim3((unsigned)blocks), dim3(WG_T), lds, st, dY, lddy, dy_col_off, dY0, Y, ldy, X,
-                           ldx, W0, in_real, W1, Wout, out, out_act, (long long)N, H1, H2, dX, lddx, P);
-    } else {
-        static bool attr1 = false;
-        if (!attr1) {
-            hipFuncSetAttribute((const void*)k_mlp_chain_bwd_wg<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr1 = true;
-        }
-        hipLaunchKernelGGL(k_mlp_chain_bwd_wg<1>, dim3((unsigned)blocks), dim3(WG_T), lds, st, dY, lddy, dy_col_off, dY0, Y, ldy, X,
-                           ldx, W0, in_real, W1, Wout, out, out_act, (long long)N, H1, H2, dX, lddx, P);
-    }
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(WG_T), lds, st, dY, lddy, dy_col_off, dY0, Y, ldy, X, ldx, W0, in_real,
+                           W1, Wout, out, out_act, (long long)N, H1, H2, dX, lddx, P);
+    };
+    static bool a20 = false, a21 = false, a10 = false, a11 = false;
+    if (n_hidden == 2 && recompute) launch(k_mlp_chain_bwd_wg<2, true>, a21);
+    else if (n_hidden == 2) launch(k_mlp_chain_bwd_wg<2, false>, a20);
+    else if (recompute) launch(k_mlp_chain_bwd_wg<1, true>, a11);
+    else launch(k_mlp_chain_bwd_wg<1, false>, a10);
     hipLaunchKernelGGL(k_chain_wgrad_reduce, dim3(wg_partial_floats(n_hidden) / 32), dim3(256), 0, st, P, (int)blocks,
                        n_hidden, out, in_real, dWout, dW1, dW0);
     SNF_LAUNCH_CHECK("snf_mlp64_bwd_fused");

@@ -53,6 +53,10 @@ PLANAR_HEADS = _os.environ.get("SNF_PLANAR_HEADS", "1") == "1"  # level-major ha
 # reduce's in-bucket sort is cheap and its Adam stream already runs at 5 TB/s; off by default, kept for bit-reproducible runs
 FX_F8 = _os.environ.get("SNF_HG_FX8", "0") == "1"
 FUSED_CHAIN_WGRAD = _os.environ.get("SNF_FUSED_CHAIN_WGRAD", "1") == "1"  # weight gradients of the 64-wide nets inside the chain
+# ... and their hidden activations formed again there from the inputs (bit-identical to the forward's) instead of being written
+# by the forward and read back: needs the fused backward and the six-product forward arithmetic of gemm mode 1
+CHAIN_RECOMPUTE = (_os.environ.get("SNF_CHAIN_RECOMPUTE", "1") == "1" and FUSED_CHAIN_WGRAD
+                   and _os.environ.get("SNF_CHAIN_FWD_X6", "1") != "0")
 _pbs = _os.environ.get("SNF_PROP_BWD_SIDE")
 PROP_BWD_SIDE = None if _pbs is None else (_pbs == "1")  # None: on the side stream only when there are no feature heads
 FEATURE_SORTS_ON_HEAD_STREAM = _os.environ.get("SNF_FEAT_SORT_SIDE", "1") == "1"
@@ -301,6 +305,9 @@ class StepProgram:
         nbytes = int(self.lib.snf_hashgrid_bwd_workspace_bytes(N, L, T))
         return self.buf(name, ((nbytes + 3) // 4,), torch.int32, parity), nbytes
 
+    def _chain_recompute(self) -> bool:
+        return CHAIN_RECOMPUTE and int(self.lib.snf_get_gemm_mode()) == 1
+
     def _mlp64_bwd(self, st, x, ldx, in_real, ws, out_act, y, h1, h2, dy, lddy, dy_off, dy0, dx, lddx, N, pre: str):
         """ops._mlp64_bwd_launch: data-gradient chain + the three (two) weight-gradient GEMMs into the gradient arena."""
         nh = len(ws) - 1
@@ -425,7 +432,8 @@ class StepProgram:
         enc1 = b("enc1", (FL * FF * N1,))
         self._k(main, "snf_hashgrid_fwd", u1, fenc.params, fenc.scalings, N1, FL, FF, FT, enc1, 0, 0, tag=f"F{FF}L{FL}")
         C = bw1.shape[0]  # 1 + geo
-        hb1, h = b("hb1", (N1, 64)), b("h", (N1, C))
+        rc = self._chain_recompute()  # the hidden activations of the two field nets are not stored
+        hb1, h = (None if rc else b("hb1", (N1, 64))), b("h", (N1, C))
         self._k(main, "snf_mlp64_fwd", enc1, 0, bw0, FL * FF, None, bw1, 1, C, ops.ACT_NONE, N1, hb1, None, h, C,
                 tag=f"{FL * FF}x64x{C}")
         density1 = b("density1", (N1,))
@@ -433,7 +441,7 @@ class StepProgram:
         x2 = b("x2", (N1, 32))
         n_geo = C - 1
         self._k(main, "snf_head_input", d, self._off(h, 4), R, S, n_geo, C, x2, 32)
-        hh1, hh2, rgb = b("hh1", (N1, 64)), b("hh2", (N1, 64)), b("rgb", (N1, 3))
+        hh1, hh2, rgb = (None if rc else b("hh1", (N1, 64))), (None if rc else b("hh2", (N1, 64))), b("rgb", (N1, 3))
         self._k(main, "snf_mlp64_fwd", x2, 32, hw0, 16 + n_geo, hw1, hw2, 2, 3, ops.ACT_SIGMOID, N1, hh1, hh2, rgb, 3,
                 tag=f"{16 + n_geo}x64x64x3")
         w1 = b("w1", (R, S))

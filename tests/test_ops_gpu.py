@@ -1060,3 +1060,19 @@ def test_mlp64_backward_with_fused_weight_gradients(cfg, N):
         scale = float(r64.abs().max())
         assert maxdiff(got - 0.5, r64.float()) <= 3e-5 * scale, i
         assert maxdiff(got - 0.5, r32) <= 3e-5 * scale, i
+    # H1 = H2 = NULL: the hidden activations are formed again from X with the forward's arithmetic -- the same bits as reading
+    # the stored ones, so the data gradient and the weight gradients are the ones of the call above (the forward then does not
+    # have to write them at all)
+    gw2 = [torch.full_like(w, 0.5) for w in ws]
+    dx2 = torch.empty_like(dx_ref)
+    m._launch("snf_mlp64_bwd_fused", m._p(dy), out, 0, None, m._p(y), out, m._p(xin), 0 if planar else xin.shape[1], m._p(ws[0]),
+              in_real, m._p(ws[1]) if nh == 2 else None, m._p(ws[-1]), nh, out, out_act, N, None, None,
+              m._p(dx2), 0 if planar else 32, m._p(gw2[0]), m._p(gw2[1]) if nh == 2 else None, m._p(gw2[-1]), m._p(wsb), nb, st)
+    torch.cuda.synchronize()
+    assert torch.equal(dx2, dx)
+    for a_, b_ in zip(gw2, gw):
+        assert torch.equal(a_, b_)
+    y2 = torch.empty_like(y)  # ... and the forward without the hidden outputs gives the same y
+    m._launch("snf_mlp64_fwd", m._p(xin), 0 if planar else xin.shape[1], m._p(ws[0]), in_real, m._p(ws[1]) if nh == 2 else None,
+              m._p(ws[-1]), nh, out, out_act, N, None, None, m._p(y2), out, st)
+    assert torch.equal(y2, y)
