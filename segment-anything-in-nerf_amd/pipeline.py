@@ -211,7 +211,7 @@ class Trainer:
     def train_iteration(self, step: int):
         for cb in self.callbacks:
             cb.run_callback_at_location(step, BEFORE_TRAIN_ITERATION)
-        opt, scale = self.optimizers, 1.0 / D.world_size()
+        opt = self.optimizers
         model = self.pipeline.model
         if self.static_step and self._program_off is None:
             if self._program is None:
@@ -246,8 +246,6 @@ class Trainer:
         if use_side and len(head_losses) > 0:
             main = torch.cuda.current_stream()
             ranges = self._head_param_ranges()
-            arena = opt.arenas["sam_field"]
-            names = list(arena.offsets)
             rest_groups = [g for g in opt.arenas if g not in ("sam_field", "conv")]
             loss_rest = sum(rest)
             loss = loss_rest.detach()
@@ -268,8 +266,6 @@ class Trainer:
             for h, lv in head_losses.items():
                 st = self._side[h]
                 lo_i, hi_i = ranges[h]
-                lo = arena.offsets[names[lo_i]][0]
-                hi = arena.offsets[names[hi_i]][0] if hi_i < len(names) else arena.numel
                 with torch.cuda.stream(st):
                     lv.backward()
                     opt.exchange_and_step("sam_field", lo_i, hi_i, count_step=first_head)

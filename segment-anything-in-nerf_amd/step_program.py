@@ -371,9 +371,7 @@ class StepProgram:
         side, sort_st, feat_sort_st, pre = self._side_streams(overlap)
         xstep = pre.stream_id != main.stream_id  # the step's prologue runs on the side stream, under the previous step's tail
         pp = parity if xstep else None
-        f32 = torch.float32
         b = self.buf
-        ACT = ops
 
         # ---- inputs (filled by `_load_inputs` before the replay) and constants
         o, d = b("in_o", (R, 3), parity=pp), b("in_d", (R, 3), parity=pp)
