@@ -118,13 +118,16 @@ int snf_hashgrid_bwd_presorted_adam(const float* grad_out, int N, int L, int F, 
 /* snf_hashgrid_bwd_presorted_adam for the TWO F = 8 grids of a feature head (clip_encs / clipseg_encs, samnerf/sam_field.py:38-94:
  * same samples N, same log2_T, level-major gradients = ld_out 0) in one reduce launch: one tail instead of two, and the
  * latency-bound reachable-row levels of one grid share the CUs with the bandwidth-bound dense levels of the other.  Same
- * arithmetic per table as two snf_hashgrid_bwd_presorted_adam calls; the hyper-parameters are the group's. */
+ * arithmetic per table as two snf_hashgrid_bwd_presorted_adam calls; the hyper-parameters are the group's.
+ * reachable0 / reachable1 (may be NULL): bitmaps over the rows of the levels below fuse_from_level (bit (l << log2_T) + row: the
+ * row can be addressed by some input, Encoding.active_rows).  With a bitmap the launch also steps those rows -- zero gradient or
+ * not -- so the WHOLE table is stepped here and no snf_adam_step_rows pass (and no gradient write for those levels) is needed. */
 int snf_hashgrid_bwd_presorted_adam_pair(const float* grad_out0, const float* grad_out1, int N, int L0, int L1, int log2_T,
                                          float* grad_table0, float* grad_table1, const void* sorted_workspace0,
                                          const void* sorted_workspace1, int fuse_from_level0, int fuse_from_level1, float* param0,
                                          float* exp_avg0, float* exp_avg_sq0, float* param1, float* exp_avg1, float* exp_avg_sq1,
-                                         float lr, float beta1, float beta2, float eps, int step, float grad_scale,
-                                         snf_stream_t stream);
+                                         const uint32_t* reachable0, const uint32_t* reachable1, float lr, float beta1,
+                                         float beta2, float eps, int step, float grad_scale, snf_stream_t stream);
 
 /* The same pass with FIXED-POINT per-row sums (F = 2 and F = 8): a contribution w * g is added to its row as a 64-bit integer
  * LDS atomic, q = rint(w g 2^s) with 2^s = 2^38 / 2^e and 2^e above the level's largest finite |g| (found by a small

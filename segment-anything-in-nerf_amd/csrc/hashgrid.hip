@@ -449,6 +449,10 @@ struct HgAdam {
     float *p, *m, *v;
     float b1, b2, step_size, inv_sqrt_bc2, eps, gs;
     int from_level;
+    // float reduce only: bit (l << T) + row set = row `row` of the level l < from_level can be addressed at all (Encoding.active_rows).
+    // With the bitmap the reduce pass steps THOSE rows of the levels below from_level too (the others never move: exact, section 4.0),
+    // i.e. the whole table in one launch -- no gradient written for them, no separate snf_adam_step_rows pass.
+    const uint32_t* reach;
 };
 
 __device__ __forceinline__ void hg_adam1(float& p, float g, float& m, float& v, const HgAdam& a) {  // == optim.hip adam1
@@ -508,7 +512,8 @@ __global__ __launch_bounds__(HG_RT, SNF_HG_RT_MINWG) void k_hg_reduce(const floa
     }
     const int lane = tid & 63, wave = tid >> 6;
     const uint32_t start = bucket_start[l * (B + 1) + b], end = bucket_start[l * (B + 1) + b + 1];
-    const bool fuse = ADAM && l >= adam.from_level;
+    const bool dense_level = l >= adam.from_level;
+    const bool fuse = ADAM && (dense_level || adam.reach != nullptr);
     if (start == end && !fuse) return;  // nothing lands in this bucket: leave the slab untouched
     bool any_long = false;
     float* __restrict__ slab = grad_table + (((size_t)l << log2_T) + ((size_t)b << log2rpb)) * F;
@@ -695,6 +700,10 @@ __global__ __launch_bounds__(HG_RT, SNF_HG_RT_MINWG) void k_hg_reduce(const floa
                 for (int j = 0; j < HG_EPI; ++j) {
                     const int r = tid + (q0 + j) * HG_RT;
                     on[j] = r < rpb;
+                    if (on[j] && !dense_level) {  // reachable-row level: only the rows an input can address exist for Adam
+                        const uint32_t gr = ((uint32_t)l << log2_T) + ((uint32_t)b << log2rpb) + (uint32_t)r;
+                        on[j] = (adam.reach[gr >> 5] >> (gr & 31)) & 1u;
+                    }
                     if (on[j]) {
                         const size_t o = base + (size_t)r * F;
                         load_row<F>(adam.p + o, pp[j]);
@@ -1283,7 +1292,7 @@ extern "C" int snf_hashgrid_bwd_presorted_adam(const float* grad_out, int N, int
     hipStream_t st = (hipStream_t)stream;
     static const uint32_t hg_long = getenv("SNF_HG_LONG") ? (uint32_t)atoi(getenv("SNF_HG_LONG")) : (uint32_t)HG_LONG;
     const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
-    HgAdam a;
+    HgAdam a{};
     a.p = param; a.m = exp_avg; a.v = exp_avg_sq;
     a.b1 = beta1; a.b2 = beta2; a.step_size = (float)((double)lr / bc1); a.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
     a.eps = eps; a.gs = grad_scale; a.from_level = fuse_from_level;
@@ -1313,8 +1322,9 @@ extern "C" int snf_hashgrid_bwd_presorted_adam_pair(const float* grad_out0, cons
                                                     float* grad_table0, float* grad_table1, const void* sorted_workspace0,
                                                     const void* sorted_workspace1, int fuse_from_level0, int fuse_from_level1,
                                                     float* param0, float* exp_avg0, float* exp_avg_sq0, float* param1,
-                                                    float* exp_avg1, float* exp_avg_sq1, float lr, float beta1, float beta2,
-                                                    float eps, int step, float grad_scale, snf_stream_t stream) {
+                                                    float* exp_avg1, float* exp_avg_sq1, const uint32_t* reachable0,
+                                                    const uint32_t* reachable1, float lr, float beta1, float beta2, float eps,
+                                                    int step, float grad_scale, snf_stream_t stream) {
     SNF_REQUIRE(grad_out0 && grad_out1 && grad_table0 && grad_table1 && sorted_workspace0 && sorted_workspace1 && param0 && param1 &&
                     exp_avg0 && exp_avg1 && exp_avg_sq0 && exp_avg_sq1, "snf_hashgrid_bwd_presorted_adam_pair: null pointer");
     SNF_REQUIRE(N > 0 && L0 > 0 && L1 > 0 && L0 + L1 <= 65535 && N <= (1 << HG_SAMPLE_BITS) && fuse_from_level0 >= 0 &&
@@ -1330,14 +1340,16 @@ extern "C" int snf_hashgrid_bwd_presorted_adam_pair(const float* grad_out0, cons
     static const uint32_t hg_long = getenv("SNF_HG_LONG") ? (uint32_t)atoi(getenv("SNF_HG_LONG")) : (uint32_t)HG_LONG;
     static const int interleave = getenv("SNF_HG_PAIR_INTERLEAVE") ? atoi(getenv("SNF_HG_PAIR_INTERLEAVE")) : 1;
     const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
-    HgAdam a;
+    HgAdam a{};
     a.p = param0; a.m = exp_avg0; a.v = exp_avg_sq0;
     a.b1 = beta1; a.b2 = beta2; a.step_size = (float)((double)lr / bc1); a.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
     a.eps = eps; a.gs = grad_scale; a.from_level = fuse_from_level0;
+    a.reach = fuse_from_level0 < L0 ? reachable0 : nullptr;  // (no level stepped: plain gradient accumulation everywhere)
     HgSecond s2{};
     s2.gT = grad_out1; s2.bucket_start = w1.bstart; s2.records = (const uint2*)w1.records; s2.grad_table = grad_table1;
     s2.adam = a;
     s2.adam.p = param1; s2.adam.m = exp_avg1; s2.adam.v = exp_avg_sq1; s2.adam.from_level = fuse_from_level1;
+    s2.adam.reach = fuse_from_level1 < L1 ? reachable1 : nullptr;
     s2.first_levels = L0;
     s2.interleave = (interleave && L0 == L1) ? 1 : 0;
     if (fuse_from_level0 >= L0 && fuse_from_level1 >= L1)  // nothing to step: plain gradient accumulation for both tables
@@ -1394,7 +1406,7 @@ extern "C" int snf_hashgrid_bwd_presorted_adam_fx(const float* grad_out, int N, 
     const int B = 1 << g.log2B;
     hipStream_t st = (hipStream_t)stream;
     const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
-    HgAdam a;
+    HgAdam a{};
     a.p = param; a.m = exp_avg; a.v = exp_avg_sq;
     a.b1 = beta1; a.b2 = beta2; a.step_size = (float)((double)lr / bc1); a.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
     a.eps = eps; a.gs = grad_scale; a.from_level = fuse_from_level;

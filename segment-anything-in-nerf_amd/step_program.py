@@ -67,6 +67,7 @@ FEATURE_SORTS_ON_HEAD_STREAM = _os.environ.get("SNF_FEAT_SORT_SIDE", "1") == "1"
 # weight gradient -- on R rows instead of R*K.  Same real-number result, fp32 rounding in a different order (1e-7).
 MEAN_BEFORE_LAST_LAYER = _os.environ.get("SNF_MEAN_BEFORE_LAST", "1") == "1"
 ROWS_OPERAND = _os.environ.get("SNF_ROWS_OPERAND", "1") == "1"  # ... and its gradient broadcast formed inside the GEMM loaders
+SPARSE_ADAM_IN_REDUCE = _os.environ.get("SNF_SPARSE_ADAM_IN_REDUCE", "1") == "1"  # reachable rows of the coarse levels stepped there too
 PAIR_GRID_BWD = _os.environ.get("SNF_PAIR_GRID_BWD", "1") == "1"  # both feature grids of a head in one table-backward launch
 FUSED_MEAN_EPILOGUE = _os.environ.get("SNF_FUSED_MEAN", "1") == "1"  # ... and the mean itself in the hidden layer's GEMM epilogue
 # Without feature heads the step is ONE dependency chain on the main stream.  Its head -- sampling, the proposal network, the
@@ -789,15 +790,29 @@ class StepProgram:
                 tabs = [self._table_adam(e, "sam_field") for e in encs]
                 fuse = fuse_local and opt.fuse_table_adam
                 frm = [t[4] if fuse else e.n_levels for t, e in zip(tabs, encs)]
-                units = sum(float(NK) * 8 * 8 * 4 * (e.n_levels + f) + 24.0 * (((e.n_levels - f) << T) * 8) for e, f in zip(encs, frm))
+                # reachable-row bitmaps: the launch then steps the rows of the levels below `frm` as well -- the whole table
+                reach = [None, None]
+                if fuse and SPARSE_ADAM_IN_REDUCE and opt.skip_unreachable_rows:
+                    for i, (t, e) in enumerate(zip(tabs, encs)):
+                        if 0 < t[4] < e.n_levels:
+                            ns, bits = e.reachable_bits()
+                            assert ns == t[4], (ns, t[4])
+                            reach[i] = bits
+                            self._keep.append(bits)
+                units = sum(float(NK) * 8 * 8 * 4 * (e.n_levels + (0 if r is not None else f)) + 24.0 * (((e.n_levels - f) << T) * 8)
+                            for e, f, r in zip(encs, frm, reach))
                 self._k(st, "snf_hashgrid_bwd_presorted_adam_pair", gy, self._off(gy, e0.n_levels * 8 * NK * 4), NK, e0.n_levels,
                         e1.n_levels, T, tabs[0][1], tabs[1][1], geo_ws[ops._geometry_key(e0.scalings, e0.n_levels, T)],
                         geo_ws[ops._geometry_key(e1.scalings, e1.n_levels, T)], frm[0], frm[1], tabs[0][0], tabs[0][2], tabs[0][3],
-                        tabs[1][0], tabs[1][2], tabs[1][3], 0.0, float(oc.betas[0]), float(oc.betas[1]), float(oc.eps), 1, 1.0,
-                        tag=f"F8L{e0.n_levels}+{e1.n_levels}", units=units, dyn={("lr", "sam_field"): 18, ("t", "sam_field"): 22})
+                        tabs[1][0], tabs[1][2], tabs[1][3], reach[0], reach[1], 0.0, float(oc.betas[0]), float(oc.betas[1]),
+                        float(oc.eps), 1, 1.0, tag=f"F8L{e0.n_levels}+{e1.n_levels}", units=units,
+                        dyn={("lr", "sam_field"): 20, ("t", "sam_field"): 24})
                 if fuse:
-                    for t, e, f in zip(tabs, encs, frm):
-                        if f < e.n_levels:
+                    for t, e, f, r in zip(tabs, encs, frm, reach):
+                        if r is not None:
+                            n_tab = e.params.numel()
+                            done.append((t[5][1] - n_tab, t[5][1]))  # the whole table
+                        elif f < e.n_levels:
                             done.append(t[5])
             for e in ([] if pair else encs):
                 L, F, T = e.n_levels, e.n_features_per_level, e.log2_hashmap_size

@@ -110,6 +110,22 @@ class Encoding(nn.Module):
             return 0, torch.empty((0,), device=dev, dtype=torch.int64)
         return n_sparse, torch.cat(rows)
 
+    def reachable_bits(self) -> Tuple[int, torch.Tensor]:
+        """(n_sparse, bitmap): `active_rows` as one bit per row of the first n_sparse levels (int32 words, bit (l << T) + row),
+        what snf_hashgrid_bwd_presorted_adam_pair takes to step the reachable rows of those levels itself."""
+        cached = self.__dict__.get("_reach_bits")
+        if cached is None:
+            n_sparse, rows = self.active_rows()
+            words = torch.zeros((max(1, (n_sparse << self.log2_hashmap_size) // 32),), device=self.params.device, dtype=torch.int32)
+            if n_sparse:
+                vals = torch.bitwise_left_shift(torch.ones_like(rows), rows & 31)  # distinct bits: the sum is the OR
+                acc = torch.zeros((words.numel(),), device=rows.device, dtype=torch.int64)
+                acc.index_put_((rows >> 5,), vals, accumulate=True)
+                words = (acc & 0xFFFFFFFF).to(torch.int64)
+                words = torch.where(words >= (1 << 31), words - (1 << 32), words).to(torch.int32)
+            cached = self.__dict__["_reach_bits"] = (n_sparse, words.contiguous())
+        return cached
+
     @property
     def spec(self) -> Tuple[torch.Tensor, int, int, int]:
         return (self.scalings, self.n_levels, self.n_features_per_level, self.log2_hashmap_size)

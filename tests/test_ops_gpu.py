@@ -638,13 +638,75 @@ def test_both_grids_of_a_head_in_one_table_backward_launch(L0, L1, from0, from1)
         got.append((g["p"].clone(), g["m"].clone(), g["v"].clone(), torch.zeros((g["n"],), device="cuda")))
     m._launch("snf_hashgrid_bwd_presorted_adam_pair", m._p(grids[0]["gy"]), m._p(grids[1]["gy"]), N, L0, L1, T, m._p(got[0][3]),
               m._p(got[1][3]), m._p(grids[0]["ws"]), m._p(grids[1]["ws"]), from0, from1, m._p(got[0][0]), m._p(got[0][1]),
-              m._p(got[0][2]), m._p(got[1][0]), m._p(got[1][1]), m._p(got[1][2]), *hyper, st)
+              m._p(got[0][2]), m._p(got[1][0]), m._p(got[1][1]), m._p(got[1][2]), None, None, *hyper, st)
     for gi in range(2):
         if (from0, from1)[gi] < grids[gi]["L"]:
             assert float((ref[gi][0] - grids[gi]["p"]).abs().max()) > 1e-3  # the step moved something
         for i, tol in ((0, 2e-6), (1, 1e-6), (2, 1e-6), (3, 1e-5)):
             r, g_ = ref[gi][i], got[gi][i]
             assert float((g_ - r).abs().max()) <= tol * max(1e-3, float(r.abs().max())), (gi, i)
+
+
+def test_pair_launch_steps_the_reachable_rows_of_the_coarse_levels_itself():
+    """snf_hashgrid_bwd_presorted_adam_pair with reachable-row bitmaps: the levels below fuse_from_level are stepped inside the
+    launch on exactly the rows of the bitmap (Encoding.reachable_bits), the others are left alone -- against the launch without
+    bitmaps followed by snf_adam_step_rows on the same rows.  Gradient buffers end up zero either way."""
+    m = ops()
+    from samnerf_amd import tcnn_compat
+    T, N, F, L = 14, 30000, 8, 6
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    u = torch.rand((N, 3), device="cuda", generator=gen)
+    st = m._stream()
+    encs = [tcnn_compat.Encoding(3, {"otype": "HashGrid", "n_levels": L, "n_features_per_level": F, "log2_hashmap_size": T,
+                                     "base_resolution": lo, "per_level_scale": (hi / lo) ** (1.0 / (L - 1))}, device="cuda")
+            for lo, hi in ((4, 20), (16, 64))]
+    grids = []
+    for e in encs:
+        n_sparse, rows = e.active_rows()
+        ns2, bits = e.reachable_bits()
+        assert ns2 == n_sparse
+        # the bitmap is the row list
+        chk = torch.zeros((n_sparse << T,), dtype=torch.bool, device="cuda")
+        chk[rows] = True
+        words = bits.to(torch.int64) & 0xFFFFFFFF
+        unpacked = ((words.view(-1, 1) >> torch.arange(32, device="cuda").view(1, 32)) & 1).bool().view(-1)[:n_sparse << T]
+        assert torch.equal(unpacked, chk)
+        n = (L << T) * F
+        nbytes = int(m._L().snf_hashgrid_bwd_workspace_bytes(N, L, T))
+        ws = torch.empty(((nbytes + 3) // 4,), device="cuda", dtype=torch.int32)
+        m._launch("snf_hashgrid_sort", m._p(u), m._p(e.scalings), N, L, T, m._p(ws), nbytes, st)
+        grids.append(dict(ws=ws, n=n, ns=n_sparse, rows=rows, bits=bits, p=torch.rand((n,), device="cuda", generator=gen) - 0.5,
+                          m=(torch.rand((n,), device="cuda", generator=gen) - 0.5) * 1e-3,
+                          v=torch.rand((n,), device="cuda", generator=gen) * 1e-6,
+                          gy=torch.randn((L * N * F,), device="cuda", generator=gen) * 1e-2))
+    assert grids[0]["ns"] > 0  # the coarse grid has reachable-row levels
+    hyper = (1e-2, 0.9, 0.999, 1e-15, 3, 0.5)
+    res = {}
+    for with_bits in (False, True):
+        st8 = [(g["p"].clone(), g["m"].clone(), g["v"].clone(), torch.zeros((g["n"],), device="cuda")) for g in grids]
+        bits = [g["bits"] if (with_bits and 0 < g["ns"] < L) else None for g in grids]
+        m._launch("snf_hashgrid_bwd_presorted_adam_pair", m._p(grids[0]["gy"]), m._p(grids[1]["gy"]), N, L, L, T, m._p(st8[0][3]),
+                  m._p(st8[1][3]), m._p(grids[0]["ws"]), m._p(grids[1]["ws"]), grids[0]["ns"], grids[1]["ns"], m._p(st8[0][0]),
+                  m._p(st8[0][1]), m._p(st8[0][2]), m._p(st8[1][0]), m._p(st8[1][1]), m._p(st8[1][2]),
+                  None if bits[0] is None else m._p(bits[0]), None if bits[1] is None else m._p(bits[1]), *hyper, st)
+        if not with_bits:
+            for g, (p, mm, vv, gt) in zip(grids, st8):
+                if g["ns"]:
+                    offs = (g["rows"] * F).to(torch.int32).contiguous()
+                    m.adam_step_rows_(p, gt, mm, vv, offs, F, *hyper, True)
+        torch.cuda.synchronize()
+        res[with_bits] = st8
+    for gi in range(2):
+        for i, tol in ((0, 2e-6), (1, 1e-6), (2, 1e-6)):
+            r, g_ = res[False][gi][i], res[True][gi][i]
+            assert float((g_ - r).abs().max()) <= tol * max(1e-3, float(r.abs().max())), (gi, i)
+        assert float(res[True][gi][3].abs().max()) == 0.0 and float(res[False][gi][3].abs().max()) == 0.0
+    # rows outside the bitmap did not move
+    g0 = grids[0]
+    sparse_elems = (g0["ns"] << T) * F
+    untouched = torch.ones((g0["ns"] << T,), dtype=torch.bool, device="cuda")
+    untouched[g0["rows"]] = False
+    assert torch.equal(res[True][0][0][:sparse_elems].view(-1, F)[untouched], g0["p"][:sparse_elems].view(-1, F)[untouched])
 
 
 # ---------------------------------------------------------------------------------------------
