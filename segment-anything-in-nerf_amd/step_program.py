@@ -799,7 +799,10 @@ class StepProgram:
                             assert ns == t[4], (ns, t[4])
                             reach[i] = bits
                             self._keep.append(bits)
+                # algorithmic bytes: every corner contribution read once (+ written back as a gradient on levels left to the caller's
+                # optimizer); p / exp_avg / exp_avg_sq read + written for every stepped parameter (dense levels, reachable rows)
                 units = sum(float(NK) * 8 * 8 * 4 * (e.n_levels + (0 if r is not None else f)) + 24.0 * (((e.n_levels - f) << T) * 8)
+                            + (24.0 * 8 * int(e.active_rows()[1].numel()) if r is not None else 0.0)
                             for e, f, r in zip(encs, frm, reach))
                 self._k(st, "snf_hashgrid_bwd_presorted_adam_pair", gy, self._off(gy, e0.n_levels * 8 * NK * 4), NK, e0.n_levels,
                         e1.n_levels, T, tabs[0][1], tabs[1][1], geo_ws[ops._geometry_key(e0.scalings, e0.n_levels, T)],
