@@ -361,15 +361,20 @@ __global__ __launch_bounds__(WF_T) void k_wgrad_full_b3(const float* __restrict_
                                                         const float* __restrict__ X, int N, int I, int O, int lddy, int ldy,
                                                         int ldx, int act, int rows_per_wg, float* __restrict__ P,
                                                         const float* __restrict__ rscale, int rgroup, int aux_bits) {
-    __shared__ __attribute__((aligned(16))) uint16_t Ah[256 * WF_PITCH];
-    __shared__ __attribute__((aligned(16))) uint16_t Al[256 * WF_PITCH];
-    __shared__ __attribute__((aligned(16))) uint16_t Bh[256 * WF_PITCH];
-    __shared__ __attribute__((aligned(16))) uint16_t Bl[256 * WF_PITCH];
+    // two copies of the four planes: a trip's MFMAs read one while the next trip's rows are split into the other -- one
+    // workgroup barrier per 16 rows, and the staging (VALU + LDS stores) of some waves runs under the MFMAs of the others
+    __shared__ __attribute__((aligned(16))) uint16_t Ah[2][256 * WF_PITCH];
+    __shared__ __attribute__((aligned(16))) uint16_t Al[2][256 * WF_PITCH];
+    __shared__ __attribute__((aligned(16))) uint16_t Bh[2][256 * WF_PITCH];
+    __shared__ __attribute__((aligned(16))) uint16_t Bl[2][256 * WF_PITCH];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, half = lane >> 5, wm = wave >> 1, wn = wave & 1;
     const int n_begin = blockIdx.x * rows_per_wg, n_end = min(N, n_begin + rows_per_wg);
     const int kp = tid & 7, q = tid >> 3;  // row pair within the 16-row trip, column quad (columns 4q .. 4q+3)
     const int col = q * 4;
+    // the I columns go to the two wave columns in equal runs of 32-column tiles (192 = 96 + 96, not 128 + 64: the waves of a
+    // SIMD share wn, so an uneven split leaves two SIMDs with twice the MFMAs of the other two)
+    const int tiles_i = (I + 31) >> 5, nt = (tiles_i + 1) >> 1, i_base = 32 * nt * wn;
     f32x16 acc[2][4];
 #pragma unroll
     for (int u = 0; u < 2; ++u)
@@ -386,55 +391,64 @@ __global__ __launch_bounds__(WF_T) void k_wgrad_full_b3(const float* __restrict_
             bv[p] = ldx < 0 ? b3_load_b_planar8(X, n, col, n_end, I, N) : b3_load_b(X, n, col, n_end, I, ldx);
         }
     };
-    fetch(n_begin);
-    const bool m_on[2] = {64 * wm < O, 64 * wm + 32 < O};
-    for (int n0 = n_begin; n0 < n_end; n0 += 16) {
-        __syncthreads();
-        {
-            const float a0[4] = {av[0].x, av[0].y, av[0].z, av[0].w}, a1[4] = {av[1].x, av[1].y, av[1].z, av[1].w};
-            const float b0[4] = {bv[0].x, bv[0].y, bv[0].z, bv[0].w}, b1[4] = {bv[1].x, bv[1].y, bv[1].z, bv[1].w};
+    auto stage = [&](int buf) {
+        const float a0[4] = {av[0].x, av[0].y, av[0].z, av[0].w}, a1[4] = {av[1].x, av[1].y, av[1].z, av[1].w};
+        const float b0[4] = {bv[0].x, bv[0].y, bv[0].z, bv[0].w}, b1[4] = {bv[1].x, bv[1].y, bv[1].z, bv[1].w};
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                uint32_t h, l;
-                split2(a0[c], a1[c], h, l);  // rows (2kp, 2kp+1) of column col + c -> k positions (2kp, 2kp+1)
-                *reinterpret_cast<uint32_t*>(&Ah[(col + c) * WF_PITCH + 2 * kp]) = h;
-                *reinterpret_cast<uint32_t*>(&Al[(col + c) * WF_PITCH + 2 * kp]) = l;
-                split2(b0[c], b1[c], h, l);
-                *reinterpret_cast<uint32_t*>(&Bh[(col + c) * WF_PITCH + 2 * kp]) = h;
-                *reinterpret_cast<uint32_t*>(&Bl[(col + c) * WF_PITCH + 2 * kp]) = l;
-            }
+        for (int c = 0; c < 4; ++c) {
+            uint32_t h, l;
+            split2(a0[c], a1[c], h, l);  // rows (2kp, 2kp+1) of column col + c -> k positions (2kp, 2kp+1)
+            *reinterpret_cast<uint32_t*>(&Ah[buf][(col + c) * WF_PITCH + 2 * kp]) = h;
+            *reinterpret_cast<uint32_t*>(&Al[buf][(col + c) * WF_PITCH + 2 * kp]) = l;
+            split2(b0[c], b1[c], h, l);
+            *reinterpret_cast<uint32_t*>(&Bh[buf][(col + c) * WF_PITCH + 2 * kp]) = h;
+            *reinterpret_cast<uint32_t*>(&Bl[buf][(col + c) * WF_PITCH + 2 * kp]) = l;
         }
-        __syncthreads();
-        if (n0 + 16 < n_end) fetch(n0 + 16);
-        bf16x8 bh[4], bl[4];
+    };
+    fetch(n_begin);
+    stage(0);
+    __syncthreads();
+    if (n_begin + 16 < n_end) fetch(n_begin + 16);
+    const bool m_on[2] = {64 * wm < O, 64 * wm + 32 < O};
+    int buf = 0;
+    for (int n0 = n_begin; n0 < n_end; n0 += 16, buf ^= 1) {
+        bf16x8 bh[4], bl[4], ah[2], al[2];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            bh[t] = *reinterpret_cast<const bf16x8*>(&Bh[(128 * wn + 32 * t + li) * WF_PITCH + 8 * half]);
-            bl[t] = *reinterpret_cast<const bf16x8*>(&Bl[(128 * wn + 32 * t + li) * WF_PITCH + 8 * half]);
+            bh[t] = *reinterpret_cast<const bf16x8*>(&Bh[buf][(i_base + 32 * t + li) * WF_PITCH + 8 * half]);
+            bl[t] = *reinterpret_cast<const bf16x8*>(&Bl[buf][(i_base + 32 * t + li) * WF_PITCH + 8 * half]);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            ah[u] = *reinterpret_cast<const bf16x8*>(&Ah[buf][(64 * wm + 32 * u + li) * WF_PITCH + 8 * half]);
+            al[u] = *reinterpret_cast<const bf16x8*>(&Al[buf][(64 * wm + 32 * u + li) * WF_PITCH + 8 * half]);
+        }
+        if (n0 + 16 < n_end) {  // the next trip's rows (fetched a trip ago) into the other copy, then the fetch after that
+            stage(buf ^ 1);
+            if (n0 + 32 < n_end) fetch(n0 + 32);
         }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             if (m_on[u]) {  // wave-uniform
-                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&Ah[(64 * wm + 32 * u + li) * WF_PITCH + 8 * half]);
-                const bf16x8 al = *reinterpret_cast<const bf16x8*>(&Al[(64 * wm + 32 * u + li) * WF_PITCH + 8 * half]);
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    if (128 * wn + 32 * t < I) {  // wave-uniform
-                        acc[u][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[t], acc[u][t], 0, 0, 0);
-                        acc[u][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[t], acc[u][t], 0, 0, 0);
-                        acc[u][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[t], acc[u][t], 0, 0, 0);
+                    if (t < nt && i_base + 32 * t < I) {  // wave-uniform
+                        acc[u][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[u], bh[t], acc[u][t], 0, 0, 0);
+                        acc[u][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[u], bl[t], acc[u][t], 0, 0, 0);
+                        acc[u][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[u], bh[t], acc[u][t], 0, 0, 0);
                     }
                 }
             }
         }
+        __syncthreads();
     }
     float* __restrict__ Pw = P + (size_t)blockIdx.x * O * I;
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const int i = 128 * wn + 32 * t + li;
-            if (i < I) {
+            const int i = i_base + 32 * t + li;
+            if (t < nt && i < I) {
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) {
                     const int o = 64 * wm + 32 * u + (reg & 3) + 8 * (reg >> 2) + 4 * half;
@@ -502,7 +516,11 @@ __device__ __forceinline__ void ws_split2(float x0, float x1, uint32_t& hi, uint
 // hbar != NULL (forward, ReLU, rgroup == 16): the epilogue renders the activations -- hbar[m / 16][c] = sum_k rscale[16 (m/16) + k]
 //     * y[16 (m/16) + k][c] -- and writes the ReLU mask bits to ybits; C may then be NULL: the activations themselves are not
 //     needed again (the layer after it runs on the rendered rows, the backward needs the mask only).
-template <bool BT, bool DERIV, int BN, int RB, int THREADS, int DEPTH, bool PA = false, bool CT = false>
+// AM (data gradient): how the derivative mask arrives, fixed at compile time -- 0 none, 1 the activations (fp32), 2 mask bits;
+//     -1: decided per launch from act_in / aux_bits (loads under launch-uniform branches: the compiler then waits for ALL loads in
+//     flight before every k-step, s_waitcnt vmcnt(0), and the D-deep prefetch hides nothing).  All loads of the k loop are
+//     unconditional for that reason too: the refill past the last k-step re-reads the last one.
+template <bool BT, bool DERIV, int BN, int RB, int THREADS, int DEPTH, bool PA = false, bool CT = false, int AM = -1>
 __global__ __launch_bounds__(THREADS) void k_gemm_ws_b3(const float* __restrict__ A, const float* __restrict__ Aux,
                                                         const float* __restrict__ W, const float* __restrict__ bias, int M,
                                                         int K, int Nc, int lda, int ldaux, int ldw, int ldc, int act_in,
@@ -546,15 +564,27 @@ __global__ __launch_bounds__(THREADS) void k_gemm_ws_b3(const float* __restrict_
             }
         }
     } else {
+        // an item = (column quad q, k pair): two float4 of W in, four (column, k pair) dwords per plane out.  LDS stores bank on
+        // (dword address) mod 32 within 32-lane groups and a column is 132 (mod 32: 4) dwords from the next, so a group of lanes
+        // takes 8 quads x 4 k pairs and lane (qq, kk) writes its four columns rotated by qq / 2: the banks 16 (q & 1) +
+        // 4 ((c + q / 2) & 3) + kk are all distinct (quads fastest over the lanes: 16-way conflicts, ~7 us of a 50 us launch)
         constexpr int NQ = BN / 4;  // column quads
-        const int kp = K >> 1;      // k pairs
+        const int kp = K >> 1;      // k pairs (K % 16 == 0: a multiple of 8)
         const int total = NQ * kp;
+        auto item = [&](int e, int& q, int& k, int& rot) {
+            const int l5 = e & 31, blk = e >> 5;
+            const int qq = l5 >> 2, kk = l5 & 3;
+            q = (blk % (NQ / 8)) * 8 + qq;
+            k = ((blk / (NQ / 8)) * 4 + kk) * 2;
+            rot = qq >> 1;
+        };
         for (int e0 = tid; e0 < total; e0 += THREADS * (PB / 2)) {
             float4 v0[PB / 2], v1[PB / 2];
 #pragma unroll
             for (int u = 0; u < PB / 2; ++u) {
                 const int e = e0 + THREADS * u;
-                const int q = e % NQ, k = (e / NQ) * 2;
+                int q, k, rot;
+                item(e, q, k, rot);
                 v0[u] = make_float4(0.f, 0.f, 0.f, 0.f);
                 v1[u] = v0[u];
                 if (e < total && col0 + q * 4 < Nc) {  // Nc % 4 == 0
@@ -566,12 +596,15 @@ __global__ __launch_bounds__(THREADS) void k_gemm_ws_b3(const float* __restrict_
             for (int u = 0; u < PB / 2; ++u) {
                 const int e = e0 + THREADS * u;
                 if (e < total) {
-                    const int q = e % NQ, k = (e / NQ) * 2;
-                    const float a0[4] = {v0[u].x, v0[u].y, v0[u].z, v0[u].w}, a1[4] = {v1[u].x, v1[u].y, v1[u].z, v1[u].w};
+                    int q, k, rot;
+                    item(e, q, k, rot);
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) {
+                    for (int cc = 0; cc < 4; ++cc) {
+                        const int c = (cc + rot) & 3;
+                        const float a0 = c == 0 ? v0[u].x : c == 1 ? v0[u].y : c == 2 ? v0[u].z : v0[u].w;
+                        const float a1 = c == 0 ? v1[u].x : c == 1 ? v1[u].y : c == 2 ? v1[u].z : v1[u].w;
                         uint32_t h, l;
-                        split2(a0[c], a1[c], h, l);  // (k, k+1) of column n = 4q + c
+                        split2(a0, a1, h, l);  // (k, k+1) of column n = 4q + c
                         *reinterpret_cast<uint32_t*>(&Bh[(size_t)(q * 4 + c) * pitch + k]) = h;
                         *reinterpret_cast<uint32_t*>(&Bl[(size_t)(q * 4 + c) * pitch + k]) = l;
                     }
@@ -614,13 +647,16 @@ __global__ __launch_bounds__(THREADS) void k_gemm_ws_b3(const float* __restrict_
         constexpr int D = DEPTH;
         float4 raw[D][RB][2], rawy[DERIV ? D : 1][RB][2];
         uint32_t rawm[DERIV ? D : 1][RB];
-        const bool masked = DERIV && act_in != SNF_ACT_NONE && !aux_bits;
-        const bool bitmask = DERIV && act_in != SNF_ACT_NONE && aux_bits;
+        const bool masked = DERIV && (AM < 0 ? (act_in != SNF_ACT_NONE && !aux_bits) : AM == 1);
+        const bool bitmask = DERIV && (AM < 0 ? (act_in != SNF_ACT_NONE && aux_bits) : AM == 2);
         const uint8_t* __restrict__ mb[RB];
 #pragma unroll
         for (int b = 0; b < RB; ++b)
             mb[b] = bitmask ? reinterpret_cast<const uint8_t*>(Aux) + (size_t)min(r0 + 32 * b + li, M - 1) * ldaux + half : nullptr;
         auto load8 = [&](int b, int s, int u) {
+#if defined(SNF_WS_ABLATE) && (SNF_WS_ABLATE & 4)
+            if (M > 0) return;
+#endif
             raw[u][b][0] = *reinterpret_cast<const float4*>(pa[b] + s * a_step);
             raw[u][b][1] = *reinterpret_cast<const float4*>(pa[b] + s * a_step + 4);
             if constexpr (DERIV) {
@@ -662,46 +698,57 @@ __global__ __launch_bounds__(THREADS) void k_gemm_ws_b3(const float* __restrict_
         };
 #pragma unroll
         for (int u = 0; u < D; ++u) {
-            if (u < ksteps) {
 #pragma unroll
-                for (int b = 0; b < RB; ++b) load8(b, u, u);
-            }
+            for (int b = 0; b < RB; ++b) load8(b, min(u, ksteps - 1), u);
         }
         for (int s = 0; s < ksteps; s += D) {
 #pragma unroll
             for (int u = 0; u < D; ++u) {
-                if (s + u < ksteps) {
-                    bf16x8 ah[RB], al[RB];
-#pragma unroll
-                    for (int b = 0; b < RB; ++b) frag(b, u, ah[b], al[b]);
-                    if (s + u + D < ksteps) {  // refill this buffer D k-steps ahead
-#pragma unroll
-                        for (int b = 0; b < RB; ++b) load8(b, s + u + D, u);
-                    }
-                    const int ko = (s + u) * 16 + half * 8;
+                // this k-step's weight fragments first: their LDS latency passes under the split of the A fragments below
+                bf16x8 bh[NB], bl[NB];
+                {
+                    const int ko = min(s + u, ksteps - 1) * 16 + half * 8;
 #pragma unroll
                     for (int t = 0; t < NB; ++t) {
-                        const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&Bh[(size_t)(32 * t + li) * pitch + ko]);
-                        const bf16x8 bl = *reinterpret_cast<const bf16x8*>(&Bl[(size_t)(32 * t + li) * pitch + ko]);
+                        bh[t] = *reinterpret_cast<const bf16x8*>(&Bh[(size_t)(32 * t + li) * pitch + ko]);
+                        bl[t] = *reinterpret_cast<const bf16x8*>(&Bl[(size_t)(32 * t + li) * pitch + ko]);
+                    }
+                }
+                bf16x8 ah[RB], al[RB];
+#pragma unroll
+                for (int b = 0; b < RB; ++b) frag(b, u, ah[b], al[b]);
+                // refill this buffer D k-steps ahead (unconditional, clamped: see AM above)
+#pragma unroll
+                for (int b = 0; b < RB; ++b) load8(b, min(s + u + D, ksteps - 1), u);
+#if defined(SNF_WS_ABLATE) && (SNF_WS_ABLATE & 2)
+                if (s + u < 0) {
+#else
+                if (s + u < ksteps) {
+#endif
+#pragma unroll
+                    for (int t = 0; t < NB; ++t) {
                         if constexpr (CT) {
 #pragma unroll
-                            for (int b = 0; b < RB; ++b) acc[b][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, al[b], acc[b][t], 0, 0, 0);
+                            for (int b = 0; b < RB; ++b) acc[b][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[t], al[b], acc[b][t], 0, 0, 0);
 #pragma unroll
-                            for (int b = 0; b < RB; ++b) acc[b][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl, ah[b], acc[b][t], 0, 0, 0);
+                            for (int b = 0; b < RB; ++b) acc[b][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[t], ah[b], acc[b][t], 0, 0, 0);
 #pragma unroll
-                            for (int b = 0; b < RB; ++b) acc[b][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, ah[b], acc[b][t], 0, 0, 0);
+                            for (int b = 0; b < RB; ++b) acc[b][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[t], ah[b], acc[b][t], 0, 0, 0);
                         } else {
 #pragma unroll
-                            for (int b = 0; b < RB; ++b) acc[b][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[b], bh, acc[b][t], 0, 0, 0);
+                            for (int b = 0; b < RB; ++b) acc[b][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[b], bh[t], acc[b][t], 0, 0, 0);
 #pragma unroll
-                            for (int b = 0; b < RB; ++b) acc[b][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[b], bl, acc[b][t], 0, 0, 0);
+                            for (int b = 0; b < RB; ++b) acc[b][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[b], bl[t], acc[b][t], 0, 0, 0);
 #pragma unroll
-                            for (int b = 0; b < RB; ++b) acc[b][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[b], bh, acc[b][t], 0, 0, 0);
+                            for (int b = 0; b < RB; ++b) acc[b][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[b], bh[t], acc[b][t], 0, 0, 0);
                         }
                     }
                 }
             }
         }
+#if defined(SNF_WS_ABLATE) && (SNF_WS_ABLATE & 1)
+        if (acc[0][0][0] != 1234.5f) continue;
+#endif
         if constexpr (CT) {
             // transposed accumulators: lane (m = li, half) holds, in registers 4q .. 4q+3, the output features
             // col0 + 32t + 8q + 4*half + {0..3} of row m -> one 16-byte store into level (col0 + 32t)/8 + q of the level-major C
@@ -728,6 +775,9 @@ __global__ __launch_bounds__(THREADS) void k_gemm_ws_b3(const float* __restrict_
             // rendered epilogue (see the header): registers 0..7 of a lane are rows of the block's first group of 16, 8..15 of its
             // second; the other half-wave holds the other 8 rows of each group
 #pragma unroll
+            // the mask words of a row (32 columns each, one per column tile) are gathered in lane (reg, half) of the row's register
+            // and leave as ONE store of NB words per row (a 4-byte store per row and column tile by lane 0 before: 64 store
+            // instructions and as many exec-mask round trips per wave and tile)
             for (int b = 0; b < RB; ++b) {
                 float wr[16];
 #pragma unroll
@@ -735,18 +785,19 @@ __global__ __launch_bounds__(THREADS) void k_gemm_ws_b3(const float* __restrict_
                     const int row = r0 + 32 * b + (reg & 3) + 8 * (reg >> 2) + 4 * half;
                     wr[reg] = row < M ? rscale[row] : 0.f;
                 }
+                uint32_t mw[NB];
 #pragma unroll
                 for (int t = 0; t < NB; ++t) {
                     const int c = col0 + 32 * t + li;
                     float s0 = 0.f, s1 = 0.f;
+                    mw[t] = 0u;
 #pragma unroll
                     for (int reg = 0; reg < 16; ++reg) {
                         const int row = r0 + 32 * b + (reg & 3) + 8 * (reg >> 2) + 4 * half;
                         const float v = fmaxf(acc[b][t][reg] + bcol[t], 0.f);
                         const unsigned long long bal = __ballot(v > 0.f && c < Nc);
-                        if (li == 0 && row < M)
-                            *reinterpret_cast<uint32_t*>(ybits + (size_t)row * (Nc >> 3) + ((col0 + 32 * t) >> 3)) =
-                                half ? (uint32_t)(bal >> 32) : (uint32_t)bal;
+                        const uint32_t mine = half ? (uint32_t)(bal >> 32) : (uint32_t)bal;
+                        mw[t] = li == reg ? mine : mw[t];
                         if (reg < 8) s0 += wr[reg] * v; else s1 += wr[reg] * v;
                         if (C != nullptr && row < M && c < Nc) C[(size_t)row * ldc + c] = v;
                     }
@@ -754,6 +805,24 @@ __global__ __launch_bounds__(THREADS) void k_gemm_ws_b3(const float* __restrict_
                     s1 += __shfl_xor(s1, 32, 64);
                     const int g = ((r0 + 32 * b) >> 4) + half;  // half 0 writes the first group, half 1 the second
                     if (c < Nc && g * 16 < M) hbar[(size_t)g * Nc + c] = half ? s1 : s0;
+                }
+                if (li < 16) {  // lane (li, half) holds the words of row (li & 3) + 8 (li >> 2) + 4 half
+                    const int row = r0 + 32 * b + (li & 3) + 8 * (li >> 2) + 4 * half;
+                    if (row < M) {
+                        uint32_t* __restrict__ dst = reinterpret_cast<uint32_t*>(ybits + (size_t)row * (Nc >> 3) + (col0 >> 3));
+                        if constexpr (NB == 4) {
+                            if (col0 + 128 <= Nc && ((Nc >> 3) & 15) == 0) *reinterpret_cast<uint4*>(dst) = make_uint4(mw[0], mw[1], mw[2], mw[3]);
+                            else {
+#pragma unroll
+                                for (int t = 0; t < NB; ++t)
+                                    if (col0 + 32 * t < Nc) dst[t] = mw[t];
+                            }
+                        } else {
+#pragma unroll
+                            for (int t = 0; t < NB; ++t)
+                                if (col0 + 32 * t < Nc) dst[t] = mw[t];
+                        }
+                    }
                 }
             }
         } else {
@@ -775,12 +844,12 @@ __global__ __launch_bounds__(THREADS) void k_gemm_ws_b3(const float* __restrict_
     }
 }
 
-template <bool BT, bool DERIV, int BN, int RB, int THREADS, int DEPTH, bool PA = false, bool CT = false>
+template <bool BT, bool DERIV, int BN, int RB, int THREADS, int DEPTH, bool PA = false, bool CT = false, int AM = -1>
 static void ws_launch(dim3 grid, size_t lds, snf_stream_t stream, const float* A, const float* Aux, const float* W,
                       const float* bias, int M, int K, int Nc, int lda, int ldaux, int ldw, int ldc, int act_in, int act_out,
                       float* C, const float* rscale = nullptr, int rgroup = 1, int aux_bits = 0, float* hbar = nullptr,
                       uint8_t* ybits = nullptr) {
-    auto kern = k_gemm_ws_b3<BT, DERIV, BN, RB, THREADS, DEPTH, PA, CT>;
+    auto kern = k_gemm_ws_b3<BT, DERIV, BN, RB, THREADS, DEPTH, PA, CT, AM>;
     static bool attr = false;
     if (!attr) {
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -809,7 +878,11 @@ static int ws_try(const float* A, const float* Aux, const float* W, const float*
             K > 256 || K < 64 || Nc < 64 || (Nc % 4))
             return -1;
         const int small = ws_small_lds((size_t)2 * 128 * (K + 8) * sizeof(uint16_t));
-        const int bn = small ? 64 : 128, tile_rows = 256;
+        // 96-column slices where they tile the output exactly and 128 does not (192 = 2 x 96: the second 128-column slice would
+        // run half its MFMAs on columns that do not exist) -- the data gradient from mask bits only (the step's head layers)
+        static const int bn96_on = getenv("SNF_GEMM_WS_BN96") ? atoi(getenv("SNF_GEMM_WS_BN96")) : 1;
+        const bool bn96 = bn96_on && ct && !small && (Nc % 96) == 0 && (Nc % 128) != 0 && act_in != SNF_ACT_NONE && aux_bits;
+        const int bn = small ? 64 : bn96 ? 96 : 128, tile_rows = 256;
         const size_t lds = (size_t)2 * bn * (K + 8) * sizeof(uint16_t);
         const int gy = ceil_div(Nc, bn), tiles = ceil_div(M, tile_rows);
         const int per_cu = lds > 80 * 1024 ? 1 : 2;
@@ -822,7 +895,11 @@ static int ws_try(const float* A, const float* Aux, const float* W, const float*
             if (pa && small) ws_launch<true, false, 64, 2, 256, 2, true, false>(grid, lds, stream, A, Aux, W, bias, M, K, Nc, lda, ldaux, ldw, ldc, act_in, act_out, C, rscale, rgroup, 0, hbar, ybits);
         }
         if constexpr (!BT && DERIV) {
-            if (ct && !small) ws_launch<false, true, 128, 1, 512, 4, false, true>(grid, lds, stream, A, Aux, W, bias, M, K, Nc, lda, ldaux, ldw, ldc, act_in, act_out, C, rscale, rgroup, aux_bits);
+            const int am = act_in == SNF_ACT_NONE ? 0 : aux_bits ? 2 : 1;
+            if (ct && !small && am == 0) ws_launch<false, true, 128, 1, 512, 4, false, true, 0>(grid, lds, stream, A, Aux, W, bias, M, K, Nc, lda, ldaux, ldw, ldc, act_in, act_out, C, rscale, rgroup, aux_bits);
+            if (ct && !small && am == 1) ws_launch<false, true, 128, 1, 512, 4, false, true, 1>(grid, lds, stream, A, Aux, W, bias, M, K, Nc, lda, ldaux, ldw, ldc, act_in, act_out, C, rscale, rgroup, aux_bits);
+            if (ct && bn96) ws_launch<false, true, 96, 1, 512, 4, false, true, 2>(grid, lds, stream, A, Aux, W, bias, M, K, Nc, lda, ldaux, ldw, ldc, act_in, act_out, C, rscale, rgroup, aux_bits);
+            if (ct && !small && am == 2 && !bn96) ws_launch<false, true, 128, 1, 512, 4, false, true, 2>(grid, lds, stream, A, Aux, W, bias, M, K, Nc, lda, ldaux, ldw, ldc, act_in, act_out, C, rscale, rgroup, aux_bits);
             if (ct && small) ws_launch<false, true, 64, 2, 256, 2, false, true>(grid, lds, stream, A, Aux, W, bias, M, K, Nc, lda, ldaux, ldw, ldc, act_in, act_out, C, rscale, rgroup, aux_bits);
         }
         return 1;
@@ -840,8 +917,14 @@ static int ws_try(const float* A, const float* Aux, const float* W, const float*
     if (gx < 1) gx = 1;
     if (gx > tiles) gx = tiles;
     dim3 grid(gx, gy);
-    if (v == 0) ws_launch<BT, DERIV, 128, 1, 512, 4>(grid, lds, stream, A, Aux, W, bias, M, K, Nc, lda, ldaux, ldw, ldc, act_in, act_out, C, rscale, rgroup, aux_bits, hbar, ybits);
-    else ws_launch<BT, DERIV, 64, 2, 256, 2>(grid, lds, stream, A, Aux, W, bias, M, K, Nc, lda, ldaux, ldw, ldc, act_in, act_out, C, rscale, rgroup, aux_bits, hbar, ybits);
+    const int am = !DERIV ? -1 : act_in == SNF_ACT_NONE ? 0 : aux_bits ? 2 : 1;
+    if (v == 0 && am == -1) ws_launch<BT, DERIV, 128, 1, 512, 4>(grid, lds, stream, A, Aux, W, bias, M, K, Nc, lda, ldaux, ldw, ldc, act_in, act_out, C, rscale, rgroup, aux_bits, hbar, ybits);
+    if constexpr (DERIV) {
+        if (v == 0 && am == 0) ws_launch<BT, DERIV, 128, 1, 512, 4, false, false, 0>(grid, lds, stream, A, Aux, W, bias, M, K, Nc, lda, ldaux, ldw, ldc, act_in, act_out, C, rscale, rgroup, aux_bits, hbar, ybits);
+        if (v == 0 && am == 1) ws_launch<BT, DERIV, 128, 1, 512, 4, false, false, 1>(grid, lds, stream, A, Aux, W, bias, M, K, Nc, lda, ldaux, ldw, ldc, act_in, act_out, C, rscale, rgroup, aux_bits, hbar, ybits);
+        if (v == 0 && am == 2) ws_launch<BT, DERIV, 128, 1, 512, 4, false, false, 2>(grid, lds, stream, A, Aux, W, bias, M, K, Nc, lda, ldaux, ldw, ldc, act_in, act_out, C, rscale, rgroup, aux_bits, hbar, ybits);
+    }
+    if (v != 0) ws_launch<BT, DERIV, 64, 2, 256, 2>(grid, lds, stream, A, Aux, W, bias, M, K, Nc, lda, ldaux, ldw, ldc, act_in, act_out, C, rscale, rgroup, aux_bits, hbar, ybits);
     return 1;
 }
 

@@ -8,31 +8,34 @@ duration from the kernel trace at the nominal 2.4 GHz -- the clock under a profi
 Writes profiles/r02_mfma_util.json (read by bench.py for `roofline_other_kernels[*].mfma_busy`)."""
 import collections, csv, glob, json, os, re, sys
 
-d = sys.argv[1]
+d = sys.argv[1]  # directory of the counter pass, or a summary .json written earlier
 out_path = sys.argv[2] if len(sys.argv) > 2 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
                                                             "profiles", "r02_mfma_util.json")
 CLK_GHZ, SIMDS = 2.4, 1024
-cc = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)[0]
-kt = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)[0]
-dur = {}
-for r in csv.DictReader(open(kt)):
-    dur[r["Dispatch_Id"]] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
-agg = collections.defaultdict(lambda: collections.defaultdict(float))
-for r in csv.DictReader(open(cc)):
-    name = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "").replace("snf::", "")
-    a = agg[name]
-    a[r["Counter_Name"]] += float(r["Counter_Value"])
-    if r["Counter_Name"] == "SQ_BUSY_CYCLES":
-        a["calls"] += 1
-        a["ns"] += dur.get(r["Dispatch_Id"], 0)
-by_kernel = {}
-for name, a in agg.items():
-    if a.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) <= 0 or a["ns"] <= 0:
-        continue
-    by_kernel[name] = {"calls": int(a["calls"]), "avg_us": round(a["ns"] / a["calls"] / 1e3, 1),
-                       "mfma_busy": round(a["SQ_VALU_MFMA_BUSY_CYCLES"] / (a["ns"] * CLK_GHZ * SIMDS), 4),
-                       "mfma_mops_f32": a.get("SQ_INSTS_VALU_MFMA_MOPS_F32", 0.0),
-                       "mfma_mops_bf16": a.get("SQ_INSTS_VALU_MFMA_MOPS_BF16", 0.0)}
+if d.endswith(".json"):  # an earlier summary of this script (the raw CSVs are not kept): only the entry-point table is rebuilt
+    by_kernel = json.load(open(d))["by_kernel"]
+else:
+    cc = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)[0]
+    kt = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)[0]
+    dur = {}
+    for r in csv.DictReader(open(kt)):
+        dur[r["Dispatch_Id"]] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    for r in csv.DictReader(open(cc)):
+        name = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "").replace("snf::", "")
+        a = agg[name]
+        a[r["Counter_Name"]] += float(r["Counter_Value"])
+        if r["Counter_Name"] == "SQ_BUSY_CYCLES":
+            a["calls"] += 1
+            a["ns"] += dur.get(r["Dispatch_Id"], 0)
+    by_kernel = {}
+    for name, a in agg.items():
+        if a.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) <= 0 or a["ns"] <= 0:
+            continue
+        by_kernel[name] = {"calls": int(a["calls"]), "avg_us": round(a["ns"] / a["calls"] / 1e3, 1),
+                           "mfma_busy": round(a["SQ_VALU_MFMA_BUSY_CYCLES"] / (a["ns"] * CLK_GHZ * SIMDS), 4),
+                           "mfma_mops_f32": a.get("SQ_INSTS_VALU_MFMA_MOPS_F32", 0.0),
+                           "mfma_mops_bf16": a.get("SQ_INSTS_VALU_MFMA_MOPS_BF16", 0.0)}
 
 
 def find(sub):
@@ -42,18 +45,30 @@ def find(sub):
 
 # C-ABI entry points of bench.py's kernel table -> the kernel that does their matrix work
 entry = {
-    "snf_mlp64_fwd/31x64x64x3": find("k_mlp_chain_fwd<2>"), "snf_mlp64_fwd/32x64x16": find("k_mlp_chain_fwd<1>"),
-    "snf_mlp64_bwd_data/31x64x64x3": find("k_mlp_chain_bwd<2>"), "snf_mlp64_bwd_data/32x64x16": find("k_mlp_chain_bwd<1>"),
-    "snf_mlp64_bwd_fused/31x64x64x3": find("k_mlp_chain_bwd_wg<2>"), "snf_mlp64_bwd_fused/32x64x16": find("k_mlp_chain_bwd_wg<1>"),
+    "snf_mlp64_fwd/31x64x64x3": find("k_mlp_chain_fwd_b3<2,") or find("k_mlp_chain_fwd<2"),
+    "snf_mlp64_fwd/32x64x16": find("k_mlp_chain_fwd_b3<1,") or find("k_mlp_chain_fwd<1"),
+    "snf_mlp64_bwd_data/31x64x64x3": find("k_mlp_chain_bwd<2"), "snf_mlp64_bwd_data/32x64x16": find("k_mlp_chain_bwd<1"),
+    "snf_mlp64_bwd_fused/31x64x64x3": find("k_mlp_chain_bwd_wg<2"), "snf_mlp64_bwd_fused/32x64x16": find("k_mlp_chain_bwd_wg<1"),
     "snf_linear_fwd/192x256": find("k_gemm_ws_b3<true, false, 128, 1, 512, 4, true"),
+    "snf_linear_fwd_mean/192x256": find("k_gemm_ws_b3<true, false, 128, 1, 512, 4, true"),
     "snf_linear_fwd/256x256": find("k_gemm_ws_b3<true, false, 128, 1, 512, 4, false"),
     "snf_linear_fwd/256x192": find("k_gemm_ws_b3<true, false, 128, 1, 512, 4, false"),
+    "snf_linear_fwd/256x256r": find("k_gemm_ws_b3<true, false, 128, 1, 512, 4, false"),
+    "snf_linear_fwd/256x192r": find("k_gemm_ws_b3<true, false, 128, 1, 512, 4, false"),
     "snf_linear_bwd_data/192x256": find("k_gemm_ws_b3<false, true, 128, 1, 512, 4, false, true"),
+    "snf_linear_bwd_data_rows/192x256": find("k_gemm_ws_b3<false, true, 128, 1, 512, 4, false, true"),
     "snf_linear_bwd_data/256x256": find("k_gemm_ws_b3<false, true, 128, 1, 512, 4, false, false"),
     "snf_linear_bwd_data/256x192": find("k_gemm_ws_b3<false, true, 128, 1, 512, 4, false, false"),
+    "snf_linear_bwd_data_rows/256x256": find("k_gemm_ws_b3<false, true, 128, 1, 512, 4, false, false"),
+    "snf_linear_bwd_data_rows/256x192": find("k_gemm_ws_b3<false, true, 128, 1, 512, 4, false, false"),
+    "snf_linear_bwd_data/256x256r": find("k_gemm_ws_b3<false, true, 128, 1, 512, 4, false, false"),
+    "snf_linear_bwd_data/256x192r": find("k_gemm_ws_b3<false, true, 128, 1, 512, 4, false, false"),
     "snf_linear_bwd_weight_ws/192x256": find("k_wgrad_full_b3"), "snf_linear_bwd_weight_ws/256x256": find("k_wgrad_full_b3"),
     "snf_linear_bwd_weight_ws/256x192": find("k_wgrad_full_b3"),
+    "snf_linear_bwd_weight_rows/192x256": find("k_wgrad_full_b3"), "snf_linear_bwd_weight_rows/256x256": find("k_wgrad_full_b3"),
+    "snf_linear_bwd_weight_rows/256x192": find("k_wgrad_full_b3"),
     "snf_linear_bwd_weight/64x64": find("k_gemm_wgrad_b3"), "snf_linear_bwd_weight/2304x256": find("k_gemm_wgrad_b3"),
+    "snf_linear_bwd_weight/256x256r": find("k_gemm_wgrad_b3"), "snf_linear_bwd_weight/256x192r": find("k_gemm_wgrad_b3"),
     "snf_linear_bwd_weight/31x64": find("k_gemm_wgrad<true>"), "snf_linear_bwd_weight/32x64": find("k_gemm_wgrad<true>"),
     "snf_linear_bwd_weight/64x16": find("k_gemm_wgrad<true>"), "snf_linear_bwd_weight/64x3": find("k_gemm_wgrad<true>"),
     "snf_linear_fwd_ws/2304x256": find("k_gemm_rows_b3<true, false, 64>"),
