@@ -794,7 +794,7 @@ __global__ __launch_bounds__(THREADS) void k_gemm_ws_b3(const float* __restrict_
 #pragma unroll
                     for (int reg = 0; reg < 16; ++reg) {
                         const int row = r0 + 32 * b + (reg & 3) + 8 * (reg >> 2) + 4 * half;
-                        const float v = fmaxf(acc[b][t][reg] + bcol[t], 0.f);
+                        const float v = fmaxf(acc[b][t][reg], 0.f);  // (no bias on this path: b3_try_fwd_mean)
                         const unsigned long long bal = __ballot(v > 0.f && c < Nc);
                         const uint32_t mine = half ? (uint32_t)(bal >> 32) : (uint32_t)bal;
                         mw[t] = li == reg ? mine : mw[t];
