@@ -904,7 +904,8 @@ static int ws_try(const float* A, const float* Aux, const float* W, const float*
         }
         return 1;
     }
-    if (!on || (K % 16) || K > 256 || K < 64 || M < 4096 || Nc < 64 || (Nc % 4) || (lda % 4)) return 0;
+    static const int min_rows = getenv("SNF_GEMM_WS_MIN_ROWS") ? atoi(getenv("SNF_GEMM_WS_MIN_ROWS")) : 4096;
+    if (!on || (K % 16) || K > 256 || K < 64 || M < min_rows || Nc < 64 || (Nc % 4) || (lda % 4)) return 0;
     // BN 128, 8 waves x 32 rows, 4 k-steps of A loads in flight (2 and 8 measured the same: the loads are not latency-bound);
     // narrow outputs (Nc <= 64) and SNF_GEMM_WS_VARIANT=1 take BN 64 with 4 waves x 64 rows (two workgroups per CU)
     static const int variant = getenv("SNF_GEMM_WS_VARIANT") ? atoi(getenv("SNF_GEMM_WS_VARIANT")) : 0;

@@ -56,7 +56,8 @@ entry = {
     "snf_linear_fwd/256x256r": find("k_gemm_ws_b3<true, false, 128, 1, 512, 4, false"),
     "snf_linear_fwd/256x192r": find("k_gemm_ws_b3<true, false, 128, 1, 512, 4, false"),
     "snf_linear_bwd_data/192x256": find("k_gemm_ws_b3<false, true, 128, 1, 512, 4, false, true"),
-    "snf_linear_bwd_data_rows/192x256": find("k_gemm_ws_b3<false, true, 128, 1, 512, 4, false, true"),
+    "snf_linear_bwd_data_rows/192x256": find("k_gemm_ws_b3<false, true, 96, 1, 512, 4, false, true")
+                                        or find("k_gemm_ws_b3<false, true, 128, 1, 512, 4, false, true"),
     "snf_linear_bwd_data/256x256": find("k_gemm_ws_b3<false, true, 128, 1, 512, 4, false, false"),
     "snf_linear_bwd_data/256x192": find("k_gemm_ws_b3<false, true, 128, 1, 512, 4, false, false"),
     "snf_linear_bwd_data_rows/256x256": find("k_gemm_ws_b3<false, true, 128, 1, 512, 4, false, false"),
