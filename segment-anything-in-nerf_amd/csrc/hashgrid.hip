@@ -1352,11 +1352,14 @@ extern "C" int snf_hashgrid_bwd_presorted_adam_pair(const float* grad_out0, cons
     s2.adam.reach = fuse_from_level1 < L1 ? reachable1 : nullptr;
     s2.first_levels = L0;
     s2.interleave = (interleave && L0 == L1) ? 1 : 0;
+    // SNF_HG_PAIR_PAD_LDS=<bytes> of unused dynamic LDS: 12288 leaves ONE workgroup per CU (a probe of CU sharing with the GEMMs
+    // of the other head's stream)
+    static const int pad_lds = getenv("SNF_HG_PAIR_PAD_LDS") ? atoi(getenv("SNF_HG_PAIR_PAD_LDS")) : 0;
     if (fuse_from_level0 >= L0 && fuse_from_level1 >= L1)  // nothing to step: plain gradient accumulation for both tables
         hipLaunchKernelGGL((k_hg_reduce<8, false>), dim3(B, L0 + L1), dim3(HG_RT), 0, (hipStream_t)stream, grad_out0, N, log2_T,
                            g.log2B, w0.bstart, (const uint2*)w0.records, grad_table0, hg_long, 0, a, s2);
     else
-        hipLaunchKernelGGL((k_hg_reduce<8, true>), dim3(B, L0 + L1), dim3(HG_RT), 0, (hipStream_t)stream, grad_out0, N, log2_T,
+        hipLaunchKernelGGL((k_hg_reduce<8, true>), dim3(B, L0 + L1), dim3(HG_RT), pad_lds, (hipStream_t)stream, grad_out0, N, log2_T,
                            g.log2B, w0.bstart, (const uint2*)w0.records, grad_table0, hg_long, 0, a, s2);
     SNF_LAUNCH_CHECK("snf_hashgrid_bwd_presorted_adam_pair");
     return SNF_OK;
