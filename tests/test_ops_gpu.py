@@ -858,7 +858,7 @@ def test_gradient_of_a_weighted_row_mean_as_a_gemm_operand(R, K, I, O, planar_dx
                   m._p(ws), 16, st)
 
 
-@pytest.mark.parametrize("R,I,O,planar", [(4096, 192, 256, True), (1024, 128, 128, False)])
+@pytest.mark.parametrize("R,I,O,planar", [(4096, 192, 256, True), (1024, 128, 128, False), (1024, 96, 128, True)])
 def test_hidden_layer_rendered_in_the_gemm_epilogue(R, I, O, planar):
     """snf_linear_fwd_mean: hbar = weighted mean over 16 consecutive rows of relu(X W^T), formed in the GEMM's epilogue, plus the
     ReLU mask as bits -- against snf_linear_fwd + snf_feature_mean_fwd (same products, the 16-term sum in a different order) and
@@ -897,6 +897,10 @@ def test_hidden_layer_rendered_in_the_gemm_epilogue(R, I, O, planar):
     m._launch("snf_linear_bwd_data_rows", m._p(dyg), m._p(wk), K, m._p(y), 0, m._p(w), N, I, O, O, O, I, m.ACT_RELU, m._p(dx_ref), st)
     m._launch("snf_linear_bwd_data_rows", m._p(dyg), m._p(wk), K, m._p(mask), 1, m._p(w), N, I, O, O, O // 8, I, m.ACT_RELU, m._p(dx), st)
     assert torch.equal(dx, dx_ref)
+    # ... and level-major (the step's layout; 96-column weight slices when I = 96 or 192): the same numbers, regrouped
+    dxp = torch.empty((N * I,), device=DEV)
+    m._launch("snf_linear_bwd_data_rows", m._p(dyg), m._p(wk), K, m._p(mask), 1, m._p(w), N, I, O, O, O // 8, -8, m.ACT_RELU, m._p(dxp), st)
+    assert torch.equal(dxp.view(I // 8, N, 8).permute(1, 0, 2).reshape(N, I), dx_ref)
     nb = int(m._L().snf_linear_bwd_weight_workspace_bytes(N, I, O))
     ws = torch.empty((nb // 4,), device=DEV)
     dw_ref, dw = torch.zeros((O, I), device=DEV), torch.zeros((O, I), device=DEV)
