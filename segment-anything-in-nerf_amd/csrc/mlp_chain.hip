@@ -429,7 +429,12 @@ constexpr int chain_b3_lds_elems(int NH, int planes = 2) {  // bf16 elements, al
 }
 
 template <int NH, int PLANES = 2>
-__global__ __launch_bounds__(256) void k_mlp_chain_fwd_b3(const float* __restrict__ X, int ldx, const float* __restrict__ W0,
+// 2 waves per SIMD (<= 256 registers; the two-hidden-layer six-product chain spills 156 B): measured again on the final kernels,
+// alone 0.079 -> 0.073 ms and 0.048 -> 0.045 ms, the step +-0 (the first measurement, before the recompute backward, had it slower)
+#ifndef SNF_CHAIN_FWD_WAVES
+#define SNF_CHAIN_FWD_WAVES 2
+#endif
+__global__ __launch_bounds__(256, SNF_CHAIN_FWD_WAVES) void k_mlp_chain_fwd_b3(const float* __restrict__ X, int ldx, const float* __restrict__ W0,
                                                           int in_real, const float* __restrict__ W1,
                                                           const float* __restrict__ Wout, int out, int out_act, long long N,
                                                           float* __restrict__ H1, float* __restrict__ H2,
@@ -670,7 +675,12 @@ constexpr int wg_partial_floats(int NH) { return 32 * 64 + (NH == 2 ? 64 * 64 : 
 constexpr int wg_rc_lds_elems(int NH) { return 3 * (MC_H * MC_BP32 + (NH == 2 ? MC_H * MC_BP64 : 0)); }
 
 template <int NH, bool RC = false>
-__global__ __launch_bounds__(WG_T) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_mlp_chain_bwd_wg(const float* __restrict__ dY, int lddy, int dy_col_off,
+// one hidden layer: 2 waves per SIMD = 252 registers instead of 280, no spills -- a workgroup then fits beside one workgroup of
+// the table reduce on a CU (co-residency); alone 0.129 -> 0.126 ms
+#ifndef SNF_WG_WAVES_NH1
+#define SNF_WG_WAVES_NH1 2
+#endif
+__global__ __launch_bounds__(WG_T) __attribute__((amdgpu_waves_per_eu(NH == 1 ? SNF_WG_WAVES_NH1 : 1, NH == 1 ? SNF_WG_WAVES_NH1 : 1))) void k_mlp_chain_bwd_wg(const float* __restrict__ dY, int lddy, int dy_col_off,
                                                            const float* __restrict__ dY0, const float* __restrict__ Yout,
                                                            int ldy, const float* __restrict__ X, int ldx,
                                                            const float* __restrict__ W0, int in_real,
