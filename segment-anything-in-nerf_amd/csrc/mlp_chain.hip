@@ -429,10 +429,10 @@ constexpr int chain_b3_lds_elems(int NH, int planes = 2) {  // bf16 elements, al
 }
 
 template <int NH, int PLANES = 2>
-// 2 waves per SIMD (<= 256 registers; the two-hidden-layer six-product chain spills 156 B): measured again on the final kernels,
-// alone 0.079 -> 0.073 ms and 0.048 -> 0.045 ms, the step +-0 (the first measurement, before the recompute backward, had it slower)
+// SNF_CHAIN_FWD_WAVES=2 (<= 256 registers): the two-hidden-layer six-product chain then spills 156 B per lane -- alone 0.079 ->
+// 0.073 ms, but +53 MB of scratch traffic per step (PMC, r02k) in a step that is pinned by its HBM-bound kernels: not the default
 #ifndef SNF_CHAIN_FWD_WAVES
-#define SNF_CHAIN_FWD_WAVES 2
+#define SNF_CHAIN_FWD_WAVES 1
 #endif
 __global__ __launch_bounds__(256, SNF_CHAIN_FWD_WAVES) void k_mlp_chain_fwd_b3(const float* __restrict__ X, int ldx, const float* __restrict__ W0,
                                                           int in_real, const float* __restrict__ W1,
