@@ -35,6 +35,34 @@ __device__ __forceinline__ void load_row(const float* __restrict__ p, float (&o)
     }
 }
 
+// Adam moments of a fused backward + Adam: read once and written once per step, never gathered -- SNF_HG_NT_MV = 1 marks those
+// accesses non-temporal (bit 0: loads, bit 1: stores), a compile-time probe (round 1 measured +9 % for p / m / v together)
+#ifndef SNF_HG_NT_MV
+#define SNF_HG_NT_MV 0
+#endif
+typedef float hg_f4v __attribute__((ext_vector_type(4)));
+template <int F>
+__device__ __forceinline__ void load_row_mv(const float* __restrict__ p, float (&o)[F]) {
+    if constexpr (F == 8 && (SNF_HG_NT_MV & 1)) {
+        const hg_f4v a = __builtin_nontemporal_load(reinterpret_cast<const hg_f4v*>(p));
+        const hg_f4v b = __builtin_nontemporal_load(reinterpret_cast<const hg_f4v*>(p + 4));
+        o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w;
+        o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+    } else {
+        load_row<F>(p, o);
+    }
+}
+__device__ __forceinline__ void store_row8_mv(float* __restrict__ p, const float (&v)[8]) {
+    if constexpr ((SNF_HG_NT_MV & 2) != 0) {
+        const hg_f4v a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
+        __builtin_nontemporal_store(a, reinterpret_cast<hg_f4v*>(p));
+        __builtin_nontemporal_store(b, reinterpret_cast<hg_f4v*>(p + 4));
+    } else {
+        reinterpret_cast<float4*>(p)[0] = make_float4(v[0], v[1], v[2], v[3]);
+        reinterpret_cast<float4*>(p)[1] = make_float4(v[4], v[5], v[6], v[7]);
+    }
+}
+
 struct Corners {
     uint32_t idx[8];
     float ox, oy, oz;
@@ -707,8 +735,8 @@ __global__ __launch_bounds__(HG_RT, SNF_HG_RT_MINWG) void k_hg_reduce(const floa
                     if (on[j]) {
                         const size_t o = base + (size_t)r * F;
                         load_row<F>(adam.p + o, pp[j]);
-                        load_row<F>(adam.m + o, mm[j]);
-                        load_row<F>(adam.v + o, vv[j]);
+                        load_row_mv<F>(adam.m + o, mm[j]);
+                        load_row_mv<F>(adam.v + o, vv[j]);
                         if (any_long) load_row<F>(slab + (size_t)r * F, gg[j]);  // wave sums of long segments went there
                     }
                 }
@@ -730,10 +758,8 @@ __global__ __launch_bounds__(HG_RT, SNF_HG_RT_MINWG) void k_hg_reduce(const floa
                         if constexpr (F == 8) {
                             reinterpret_cast<float4*>(adam.p + o)[0] = make_float4(pp[j][0], pp[j][1], pp[j][2], pp[j][3]);
                             reinterpret_cast<float4*>(adam.p + o)[1] = make_float4(pp[j][4], pp[j][5], pp[j][6], pp[j][7]);
-                            reinterpret_cast<float4*>(adam.m + o)[0] = make_float4(mm[j][0], mm[j][1], mm[j][2], mm[j][3]);
-                            reinterpret_cast<float4*>(adam.m + o)[1] = make_float4(mm[j][4], mm[j][5], mm[j][6], mm[j][7]);
-                            reinterpret_cast<float4*>(adam.v + o)[0] = make_float4(vv[j][0], vv[j][1], vv[j][2], vv[j][3]);
-                            reinterpret_cast<float4*>(adam.v + o)[1] = make_float4(vv[j][4], vv[j][5], vv[j][6], vv[j][7]);
+                            store_row8_mv(adam.m + o, mm[j]);
+                            store_row8_mv(adam.v + o, vv[j]);
                             if (had) {
                                 reinterpret_cast<float4*>(slab + (size_t)r * F)[0] = make_float4(0.f, 0.f, 0.f, 0.f);
                                 reinterpret_cast<float4*>(slab + (size_t)r * F)[1] = make_float4(0.f, 0.f, 0.f, 0.f);
