@@ -1142,3 +1142,40 @@ def test_mlp64_backward_with_fused_weight_gradients(cfg, N):
     m._launch("snf_mlp64_fwd", m._p(xin), 0 if planar else xin.shape[1], m._p(ws[0]), in_real, m._p(ws[1]) if nh == 2 else None,
               m._p(ws[-1]), nh, out, out_act, N, None, None, m._p(y2), out, st)
     assert torch.equal(y2, y)
+
+
+def test_rendered_head_entry_points_refuse_what_they_cannot_do():
+    """snf_linear_fwd_mean / snf_linear_bwd_data_rows: shapes outside the weight-stationary kernel, a mean over anything but 16 rows,
+    a bit mask for a layer that is not a ReLU, gemm mode 0 -- an error code and a message, never another kernel's result."""
+    m = ops()
+    m.set_gemm_mode("bf16x3")
+    R, K, I, O = 512, 16, 192, 256
+    N = R * K
+    x = torch.randn((N, I), device=DEV)
+    w = torch.randn((O, I), device=DEV) * 0.1
+    wk = torch.rand((R, K), device=DEV)
+    hbar = torch.empty((R, O), device=DEV)
+    mask = torch.zeros((N, O // 8), device=DEV, dtype=torch.uint8)
+    dyg = torch.randn((R, O), device=DEV)
+    dx = torch.empty((N, I), device=DEV)
+    st = m._stream()
+    ok = lambda: m._launch("snf_linear_fwd_mean", m._p(x), m._p(w), N, I, O, I, m._p(wk), 16, m._p(hbar), m._p(mask), None, O, st)
+    ok()
+    with pytest.raises(RuntimeError):  # groups of 8 rows
+        m._launch("snf_linear_fwd_mean", m._p(x), m._p(w), N, I, O, I, m._p(wk), 8, m._p(hbar), m._p(mask), None, O, st)
+    with pytest.raises(RuntimeError):  # too few rows for the weight-stationary kernel
+        m._launch("snf_linear_fwd_mean", m._p(x), m._p(w), 1024, I, O, I, m._p(wk), 16, m._p(hbar), m._p(mask), None, O, st)
+    with pytest.raises(RuntimeError):  # null mask
+        m._launch("snf_linear_fwd_mean", m._p(x), m._p(w), N, I, O, I, m._p(wk), 16, m._p(hbar), None, None, O, st)
+    with pytest.raises(RuntimeError):  # a bit mask only stands for a ReLU output
+        m._launch("snf_linear_bwd_data_rows", m._p(dyg), m._p(wk), K, m._p(mask), 1, m._p(w), N, I, O, O, O // 8, I, m.ACT_NONE, m._p(dx), st)
+    with pytest.raises(RuntimeError):  # level-major dX needs I % 8 == 0
+        m._launch("snf_linear_bwd_data_rows", m._p(dyg), m._p(wk), K, m._p(mask), 1, m._p(w), N, 196, O, O, O // 8, -8, m.ACT_RELU, m._p(dx), st)
+    m.set_gemm_mode("fp32")
+    try:
+        with pytest.raises(RuntimeError):  # exact-fp32 mode has no rendered epilogue: the caller composes the two plain entry points
+            ok()
+    finally:
+        m.set_gemm_mode("bf16x3")
+    ok()
+    torch.cuda.synchronize()
