@@ -858,7 +858,9 @@ def test_gradient_of_a_weighted_row_mean_as_a_gemm_operand(R, K, I, O, planar_dx
                   m._p(ws), 16, st)
 
 
-@pytest.mark.parametrize("R,I,O,planar", [(4096, 192, 256, True), (1024, 128, 128, False), (1024, 96, 128, True)])
+@pytest.mark.parametrize("R,I,O,planar", [(4096, 192, 256, True), (1024, 128, 128, False), (1024, 96, 128, True),
+                                          (520, 128, 192, False),   # a partial last row tile, a half-empty second column slice
+                                          (512, 128, 64, False), (512, 256, 256, True)])
 def test_hidden_layer_rendered_in_the_gemm_epilogue(R, I, O, planar):
     """snf_linear_fwd_mean: hbar = weighted mean over 16 consecutive rows of relu(X W^T), formed in the GEMM's epilogue, plus the
     ReLU mask as bits -- against snf_linear_fwd + snf_feature_mean_fwd (same products, the 16-term sum in a different order) and
