@@ -283,9 +283,15 @@ __device__ __forceinline__ int at_key_slot(int kr) {
     return (rr >> 3) * 16 + hf * 8 + (rr & 7);
 }
 
+// two waves per SIMD (<= 256 registers, no spills at head dim 80): with ONE (312 registers) nothing hid the barriers and the
+// load latencies of the key loop -- 14x14 windows 0.207 -> 0.128 ms, 64x64 global without positions 0.85 -> 0.53 ms
+#ifndef SNF_ATT_WAVES
+#define SNF_ATT_WAVES 2
+#endif
 template <int DB>
-__global__ __launch_bounds__(256) void k_attention_b3(const float* __restrict__ qkv, const float* __restrict__ rel, int T,
-                                                      int heads, int hd, int n, float scale, float* __restrict__ out) {
+__global__ __launch_bounds__(256, SNF_ATT_WAVES) void k_attention_b3(const float* __restrict__ qkv, const float* __restrict__ rel, int T,
+                                                      int heads, int hd, int n, float scale, float* __restrict__ out,
+                                                      int rel_direct) {
     constexpr int DP = DB * 32;          // padded head dim
     constexpr int KS = DP / 16;          // k-steps over the head dim
     constexpr int KPB = DP + 8;          // bf16 pitch of the K planes  [32 keys][DP]
@@ -320,14 +326,18 @@ __global__ __launch_bounds__(256) void k_attention_b3(const float* __restrict__ 
     extern __shared__ float rel_lds[];
     const int RP = 2 * n + 1;
     float* relw = rel_lds + (size_t)wave * 32 * RP;
-    if (rel) {
+    // rel_direct (grid side a multiple of 32: a 32-key tile lies inside ONE row of keys): the lane reads its query's one row term
+    // and 16 column terms per tile straight from global memory (four float4) -- no per-wave copy of the [32][2n] position rows in
+    // LDS, which at n = 64 was 66 KB per workgroup and left one workgroup per CU
+    const float* __restrict__ relg = (rel && rel_direct) ? rel + ((size_t)bh * T + (qlive ? qi : T - 1)) * 2 * n : nullptr;
+    if (rel && !rel_direct) {
         for (int e = lane; e < 32 * 2 * n; e += 64) {
             const int r = e / (2 * n), j = e - r * 2 * n;
             const int qq = q0 + r < T ? q0 + r : T - 1;
             relw[r * RP + j] = rel[((size_t)bh * T + qq) * 2 * n + j];
         }
     }
-    const float* relq = rel ? relw + li * RP : nullptr;
+    const float* relq = (rel && !rel_direct) ? relw + li * RP : nullptr;
     f32x16 o[DB];
 #pragma unroll
     for (int t = 0; t < DB; ++t)
@@ -396,11 +406,22 @@ __global__ __launch_bounds__(256) void k_attention_b3(const float* __restrict__ 
         }
         // ---- relative-position bias, mask, online softmax (everything per lane = per query)
         float m_tile = -INFINITY;
-        const int kh0 = relq ? k0 / n : 0, kw0 = relq ? k0 - kh0 * n : 0;
+        const int kh0 = rel ? k0 / n : 0, kw0 = rel ? k0 - kh0 * n : 0;
+        float rrow = 0.f;
+        float4 rcol[4];
+        if (relg) {  // registers 4g .. 4g+3 are the keys k0 + 8g + 4 half + {0..3}
+            rrow = relg[kh0];
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) rcol[g4] = *reinterpret_cast<const float4*>(relg + n + kw0 + 8 * g4 + 4 * half);
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int key = k0 + vrow(r, half);
             float v = s[r];
+            if (relg) {
+                const float4 c4 = rcol[r >> 2];
+                v += rrow + ((r & 3) == 0 ? c4.x : (r & 3) == 1 ? c4.y : (r & 3) == 2 ? c4.z : c4.w);
+            }
             if (relq) {
                 int kh = kh0, kw = kw0 + vrow(r, half);
                 while (kw >= n) { kw -= n; ++kh; }
@@ -519,7 +540,10 @@ extern "C" int snf_attention(const float* qkv, const float* rel, int Bw, int T, 
     SNF_REQUIRE(!rel || (n > 0 && T == n * n), "snf_attention: relative positions need T == n*n");
     dim3 grid(ceil_div(T, 128), Bw * heads);
     const int DB = (head_dim + 31) / 32;
-    const size_t lds = rel ? (size_t)4 * 32 * (2 * n + 1) * sizeof(float) : 0;
+    static const int b3_env = getenv("SNF_ATT_B3") ? atoi(getenv("SNF_ATT_B3")) : 1;
+    static const int direct_env = getenv("SNF_ATT_REL_DIRECT") ? atoi(getenv("SNF_ATT_REL_DIRECT")) : 1;
+    const int rel_direct = (rel && direct_env && b3_env && b3_enabled() && (n % 32) == 0 && (((uintptr_t)rel) & 15) == 0) ? 1 : 0;
+    const size_t lds = (rel && !rel_direct) ? (size_t)4 * 32 * (2 * n + 1) * sizeof(float) : 0;
     SNF_REQUIRE(lds <= 100 * 1024, "snf_attention: grid side n=%d too large for the relative-position staging", n);
 #define SNF_ATT(DB_)                                                                                                        \
     do {                                                                                                                    \
@@ -528,14 +552,13 @@ extern "C" int snf_attention(const float* qkv, const float* rel, int Bw, int T, 
         hipLaunchKernelGGL(k_attention<DB_>, grid, dim3(256), lds, (hipStream_t)stream, qkv, rel, T, heads, head_dim, n, scale, \
                            out);                                                                                            \
     } while (0)
-    static const int b3_env = getenv("SNF_ATT_B3") ? atoi(getenv("SNF_ATT_B3")) : 1;
     if (b3_env && b3_enabled()) {
 #define SNF_ATT_B3(DB_)                                                                                                     \
     do {                                                                                                                    \
         if (lds > 16 * 1024)                                                                                                \
             hipFuncSetAttribute((const void*)k_attention_b3<DB_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);    \
         hipLaunchKernelGGL(k_attention_b3<DB_>, grid, dim3(256), lds, (hipStream_t)stream, qkv, rel, T, heads, head_dim, n,   \
-                           scale, out);                                                                                     \
+                           scale, out, rel_direct);                                                                         \
     } while (0)
         if (DB == 1) SNF_ATT_B3(1); else if (DB == 2) SNF_ATT_B3(2); else SNF_ATT_B3(3);
 #undef SNF_ATT_B3
