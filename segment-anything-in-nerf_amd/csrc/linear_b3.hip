@@ -137,8 +137,11 @@ __device__ __forceinline__ float4 b3_load_b_planar8(const float* __restrict__ B,
 // BN = columns per workgroup (64 / 128 / 192 / 256): a wave owns 32 rows x BN columns = BN/32 accumulators.  Wider tiles
 // split every A element fewer times and run more MFMAs per staged k-tile; measured on the head shapes 128 is the best
 // (+10 % over 64), 192 / 256 lose it again to register pressure and two-workgroup occupancy (SNF_B3_BN overrides the cap).
+#ifndef SNF_B3_ROWS_WAVES
+#define SNF_B3_ROWS_WAVES 1
+#endif
 template <bool BT, bool DERIV, int BN>
-__global__ __launch_bounds__(256) void k_gemm_rows_b3(const float* __restrict__ A, const float* __restrict__ Aux,
+__global__ __launch_bounds__(256, SNF_B3_ROWS_WAVES) void k_gemm_rows_b3(const float* __restrict__ A, const float* __restrict__ Aux,
                                                       const float* __restrict__ B, const float* __restrict__ bias, int M,
                                                       int K, int Nc, int lda, int ldaux, int ldb, int ldc, int act_in,
                                                       int act_out, float* __restrict__ C, int ksplit = 0,
