@@ -62,6 +62,49 @@ __global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ x, 
     }
 }
 
+// the same with the row held in registers (C = 256 NV, 16-byte aligned rows: ViT-H's 1280 is NV = 5): one read of x (and res),
+// float4 accesses, the reductions from registers.  The lane owns four consecutive columns here instead of every 64th, so the two
+// wave sums add in another order than k_layernorm's (fp32 rounding only).
+template <int NV>
+__global__ __launch_bounds__(256) void k_layernorm_reg(const float* __restrict__ x, const float* __restrict__ res, int N, int C,
+                                                       const float* __restrict__ w, const float* __restrict__ b, float eps,
+                                                       float* __restrict__ sum_out, float* __restrict__ y) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= N) return;
+    const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * C);
+    const float4* rr = res ? reinterpret_cast<const float4*>(res + (size_t)row * C) : nullptr;
+    float4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+        v[q] = xr[lane + 64 * q];
+        if (rr) {
+            const float4 r4 = rr[lane + 64 * q];
+            v[q].x += r4.x; v[q].y += r4.y; v[q].z += r4.z; v[q].w += r4.w;
+        }
+        s += (v[q].x + v[q].y) + (v[q].z + v[q].w);
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float var = 0.f;
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+        const float d0 = v[q].x - mean, d1 = v[q].y - mean, d2 = v[q].z - mean, d3 = v[q].w - mean;
+        var += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+    }
+    const float inv = 1.f / sqrtf(wave_sum(var) / (float)C + eps);
+    const float4* w4 = reinterpret_cast<const float4*>(w);
+    const float4* b4 = reinterpret_cast<const float4*>(b);
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+        const int c4 = lane + 64 * q;
+        if (sum_out) reinterpret_cast<float4*>(sum_out + (size_t)row * C)[c4] = v[q];
+        const float4 ww = w4[c4], bb = b4[c4];
+        reinterpret_cast<float4*>(y + (size_t)row * C)[c4] =
+            make_float4((v[q].x - mean) * inv * ww.x + bb.x, (v[q].y - mean) * inv * ww.y + bb.y,
+                        (v[q].z - mean) * inv * ww.z + bb.z, (v[q].w - mean) * inv * ww.w + bb.w);
+    }
+}
+
 // x [B,H,W,C] -> windows [B * nWh * nWw, ws, ws, C], zero padded to multiples of ws
 __global__ __launch_bounds__(256) void k_window_partition(const float* __restrict__ x, int B, int H, int W, int C, int ws,
                                                           float* __restrict__ out) {
@@ -96,7 +139,9 @@ __global__ __launch_bounds__(256) void k_window_merge_add(const float* __restric
 // rel[bh][i][0..n) = q_i . rel_pos_h[ih - kh + n - 1],  rel[bh][i][n..2n) = q_i . rel_pos_w[iw - kw + n - 1]   (q unscaled)
 // qkv [Bw*T, 3*C].  One workgroup per (bh, query row ih): the n queries of that row, the n table rows rel_pos_h[ih - kh + n-1]
 // and the whole rel_pos_w table are staged in LDS (pitch hd+1), then every thread forms its (iw, j) dot products from LDS.
-__global__ __launch_bounds__(256) void k_relpos(const float* __restrict__ qkv, int Bw, int T, int heads, int hd, int n,
+// Workgroup size = blockDim.x (1024 threads at n = 64, whose 82 KB of LDS leave one workgroup per CU: with 256 threads that was
+// one wave per SIMD).  A thread forms FOUR consecutive j of a query at a time: one LDS read of q[c] serves four products.
+__global__ __launch_bounds__(1024) void k_relpos(const float* __restrict__ qkv, int Bw, int T, int heads, int hd, int n,
                                                 const float* __restrict__ rph, const float* __restrict__ rpw,
                                                 float* __restrict__ rel) {
     extern __shared__ float rp_lds[];
@@ -105,23 +150,48 @@ __global__ __launch_bounds__(256) void k_relpos(const float* __restrict__ qkv, i
     float* hs = qs + n * P;             // [n][P]      rel_pos_h rows for kh = 0..n-1
     float* ws = hs + n * P;             // [2n-1][P]   rel_pos_w
     const int ih = blockIdx.x, bh = blockIdx.y, b = bh / heads, h = bh % heads, C = heads * hd;
-    for (int e = threadIdx.x; e < n * hd; e += 256) {
+    const int nt = blockDim.x;
+    for (int e = threadIdx.x; e < n * hd; e += nt) {
         const int r = e / hd, c = e - r * hd;
         qs[r * P + c] = qkv[((size_t)b * T + ih * n + r) * 3 * C + h * hd + c];
         hs[r * P + c] = rph[(size_t)(ih - r + n - 1) * hd + c];
     }
-    for (int e = threadIdx.x; e < (2 * n - 1) * hd; e += 256) {
+    for (int e = threadIdx.x; e < (2 * n - 1) * hd; e += nt) {
         const int r = e / hd, c = e - r * hd;
         ws[r * P + c] = rpw[e];
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < n * 2 * n; e += 256) {
-        const int iw = e / (2 * n), j = e - iw * 2 * n;
+    const int jb = (2 * n + 3) >> 2;  // blocks of four j per query
+    if (n * jb < nt) {  // small grids (14 x 14 windows: 98 blocks for 256 threads): one j per thread keeps the lanes busy
+        for (int e = threadIdx.x; e < n * 2 * n; e += nt) {
+            const int iw = e / (2 * n), j = e - iw * 2 * n;
+            const float* q = qs + iw * P;
+            const float* r = j < n ? hs + j * P : ws + (iw - (j - n) + n - 1) * P;
+            float a = 0.f;
+            for (int c = 0; c < hd; ++c) a += q[c] * r[c];
+            rel[(((size_t)bh * T) + ih * n + iw) * 2 * n + j] = a;
+        }
+        return;
+    }
+    for (int e = threadIdx.x; e < n * jb; e += nt) {
+        const int iw = e / jb, j0 = (e - iw * jb) * 4;
         const float* q = qs + iw * P;
-        const float* r = j < n ? hs + j * P : ws + (iw - (j - n) + n - 1) * P;
-        float a = 0.f;
-        for (int c = 0; c < hd; ++c) a += q[c] * r[c];
-        rel[(((size_t)bh * T) + ih * n + iw) * 2 * n + j] = a;
+        const float* r[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = min(j0 + u, 2 * n - 1);
+            r[u] = j < n ? hs + j * P : ws + (iw - (j - n) + n - 1) * P;
+        }
+        float a[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < hd; ++c) {  // (each sum in the order of the single-j loop it replaces: same bits)
+            const float qc = q[c];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) a[u] += qc * r[u][c];
+        }
+        float* o = rel + (((size_t)bh * T) + ih * n + iw) * 2 * n + j0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (j0 + u < 2 * n) o[u] = a[u];
     }
 }
 
@@ -497,6 +567,15 @@ extern "C" int snf_patchify(const float* img, int B, int Cin, int S, int P, floa
 extern "C" int snf_layernorm(const float* x, const float* residual, int N, int C, const float* weight, const float* bias,
                              float eps, float* sum_out, float* y, snf_stream_t stream) {
     SNF_REQUIRE(x && weight && bias && y && N > 0 && C > 0, "snf_layernorm: bad argument");
+    const bool al16 = ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)weight | (uintptr_t)bias | (uintptr_t)residual | (uintptr_t)sum_out) & 15) == 0);
+    static const int reg_on = getenv("SNF_LN_REG") ? atoi(getenv("SNF_LN_REG")) : 1;
+    const int nv = (reg_on && al16 && C % 256 == 0) ? C / 256 : 0;
+#define SNF_LN(NV_) hipLaunchKernelGGL(k_layernorm_reg<NV_>, dim3(ceil_div(N, 4)), dim3(256), 0, (hipStream_t)stream, x, residual, N, \
+                                       C, weight, bias, eps, sum_out, y)
+    if (nv == 1) SNF_LN(1); else if (nv == 2) SNF_LN(2); else if (nv == 3) SNF_LN(3); else if (nv == 4) SNF_LN(4);
+    else if (nv == 5) SNF_LN(5); else if (nv == 6) SNF_LN(6); else if (nv == 8) SNF_LN(8);
+    else
+#undef SNF_LN
     hipLaunchKernelGGL(k_layernorm, dim3(ceil_div(N, 4)), dim3(256), 0, (hipStream_t)stream, x, residual, N, C, weight, bias,
                        eps, sum_out, y);
     SNF_LAUNCH_CHECK("snf_layernorm");
@@ -527,7 +606,8 @@ extern "C" int snf_relpos(const float* qkv, int Bw, int T, int heads, int head_d
     const size_t lds = (size_t)(4 * n - 1) * (head_dim + 1) * sizeof(float);
     SNF_REQUIRE(lds <= 160 * 1024, "snf_relpos: n * head_dim too large for the LDS staging");
     if (lds > 48 * 1024) hipFuncSetAttribute((const void*)k_relpos, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_relpos, dim3(n, Bw * heads), dim3(256), lds, (hipStream_t)stream, qkv, Bw, T, heads, head_dim, n,
+    const int threads = lds > 40 * 1024 ? 1024 : 256;  // LDS-limited to one or two workgroups per CU: make them big
+    hipLaunchKernelGGL(k_relpos, dim3(n, Bw * heads), dim3(threads), lds, (hipStream_t)stream, qkv, Bw, T, heads, head_dim, n,
                        rel_pos_h, rel_pos_w, rel);
     SNF_LAUNCH_CHECK("snf_relpos");
     return SNF_OK;

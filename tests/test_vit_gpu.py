@@ -81,6 +81,20 @@ def test_layernorm_window_kernels_vs_torch():
     y, s = ops.layernorm(x.cuda(), w.cuda(), b.cuda(), 1e-6, residual=r.cuda(), want_sum=True)
     ref = torch.nn.functional.layer_norm((x + r).double(), (96,), w.double(), b.double(), 1e-6)
     assert float((y.cpu().double() - ref).abs().max()) <= 1e-5 and torch.equal(s.cpu(), x + r)
+    # rows of 256 NV columns take the register-resident kernel (ViT-H: 1280): with / without residual, a row count that is not a
+    # multiple of the four rows of a workgroup
+    for C2, with_res in ((1280, True), (1280, False), (256, True), (768, False)):
+        x2, r2 = torch.randn((301, C2), generator=g), torch.randn((301, C2), generator=g)
+        w2, b2 = torch.randn((C2,), generator=g), torch.randn((C2,), generator=g)
+        if with_res:
+            y2, s2 = ops.layernorm(x2.cuda(), w2.cuda(), b2.cuda(), 1e-6, residual=r2.cuda(), want_sum=True)
+            assert torch.equal(s2.cpu(), x2 + r2)
+            ref2 = torch.nn.functional.layer_norm((x2 + r2).double(), (C2,), w2.double(), b2.double(), 1e-6)
+        else:
+            y2 = ops.layernorm(x2.cuda(), w2.cuda(), b2.cuda(), 1e-6)
+            y2 = y2[0] if isinstance(y2, tuple) else y2
+            ref2 = torch.nn.functional.layer_norm(x2.double(), (C2,), w2.double(), b2.double(), 1e-6)
+        assert float((y2.cpu().double() - ref2).abs().max()) <= 2e-5
     B, H, W, C, ws = 2, 14, 14, 8, 5
     t = torch.randn((B, H, W, C), generator=g)
     win, pad_hw = V.window_partition(t, ws)
