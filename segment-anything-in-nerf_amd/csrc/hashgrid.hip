@@ -933,7 +933,7 @@ __global__ __launch_bounds__(HG_FX_T) void k_hg_reduce_fx(const float* __restric
 #pragma unroll
         for (int j = 0; j < U; ++j) {
             const uint32_t i = c0 + tid + (uint32_t)HG_FX_T * j;
-            r[j] = records[i < end ? i : start];
+            r[j] = records[i < end ? i : (start < end ? start : 0u)];  // (an empty bucket is still visited when ADAM: never read past the array)
         }
     };
     auto gather = [&](const uint2 (&r)[U], float (&g)[U][F]) {

@@ -41,8 +41,11 @@ def init_distributed(backend: Optional[str] = None) -> tuple:
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
         import datetime
-        # a rank that never arrives must surface as an error naming the rendezvous, not as a silent hang of the whole job
-        timeout = datetime.timedelta(seconds=float(os.environ.get("SNF_DIST_TIMEOUT", "180")))
+        # The group timeout is the watchdog of EVERY collective of the job (RCCL) / the per-operation timeout (gloo): it has to
+        # outlast a rank-0 checkpoint write, a rank-0-only eval or a first-use build on one rank, so it keeps torch's order of
+        # magnitude (30 min).  Only the START-UP is bounded tightly: the first collective runs on a temporary group with its own
+        # short timeout, so a rank that never arrives surfaces as an error naming the rendezvous instead of a silent hang.
+        timeout = datetime.timedelta(seconds=float(os.environ.get("SNF_DIST_TIMEOUT", "1800")))
         dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=timeout)
         first_collective_check(rank, world, backend)
     return rank, local_rank, world
@@ -54,8 +57,11 @@ def first_collective_check(rank: int, world: int, backend: str) -> None:
     user needs instead of hanging in the middle of the first train step."""
     dev = torch.device("cuda", torch.cuda.current_device()) if (backend == "nccl" and torch.cuda.is_available()) else "cpu"
     t = torch.ones((1,), device=dev)
+    import datetime
+    startup = datetime.timedelta(seconds=float(os.environ.get("SNF_DIST_STARTUP_TIMEOUT", "180")))
     try:
-        dist.all_reduce(t)
+        probe = dist.new_group(ranks=list(range(world)), timeout=startup, backend=backend)  # (collective: every rank makes it)
+        dist.all_reduce(t, group=probe)
         if dev != "cpu":
             torch.cuda.synchronize()
         got = float(t.item())
@@ -67,6 +73,10 @@ def first_collective_check(rank: int, world: int, backend: str) -> None:
             f"HSA_ENABLE_IPC_MODE_LEGACY=0 (current: {os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')})") from e
     if got != float(world):
         raise RuntimeError(f"rank {rank}/{world}: first all-reduce returned {got}, expected {world} (ranks missing or doubled)")
+    try:
+        dist.destroy_process_group(probe)
+    except Exception:  # noqa: BLE001  (older torch: sub-groups cannot be destroyed one by one; it is idle from here on)
+        pass
 
 
 # -- collectives.  backend "nccl" (= RCCL): straight through.  backend "gloo" with device tensors (tests: two ranks sharing

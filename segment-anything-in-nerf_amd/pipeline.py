@@ -164,7 +164,7 @@ class Trainer:
         self.presort_host = os.environ.get("SNF_PRESORT_ON", "auto")  # "auto" | "sam" | "clipseg" | "own"
         self._side = None
         # the step as a static launch schedule (step_program.py) instead of an autograd graph: same kernels, same arguments,
-        # ~10x less host time per step.  SNF_STATIC_STEP=0 keeps the eager path (which multi-rank runs always use).
+        # ~10x less host time per step, on one rank or many.  SNF_STATIC_STEP=0 keeps the eager autograd path.
         self.static_step = os.environ.get("SNF_STATIC_STEP", "1") == "1"
         self._program = None
         self._program_off = None  # reason the static schedule is not used
@@ -367,6 +367,9 @@ class Trainer:
             main = torch.cuda.current_stream()
             for st in self._side.values():
                 main.wait_stream(st)
+        if self._program is not None and torch.cuda.is_available():
+            # (without feature heads the proposal backward + Adam and the next prologue live on the schedule's own side stream)
+            self._program.join_side_streams()
 
     def save_checkpoint(self, path: str, step: int) -> None:
         """trainer.py:379-406: {step, pipeline state_dict, optimizers}.  COLLECTIVE on a multi-rank run: every rank calls it

@@ -170,10 +170,12 @@ class StepProgram:
     def buf(self, name: str, shape, dtype=torch.float32, parity: Optional[int] = None, zero: bool = False) -> torch.Tensor:
         key = name if parity is None else f"{name}@{parity}"
         t = self.bufs.get(key)
+        shape = tuple(int(x) for x in (shape if isinstance(shape, (tuple, list)) else (shape,)))
         if t is None:
-            shape = tuple(int(x) for x in (shape if isinstance(shape, (tuple, list)) else (shape,)))
             t = (torch.zeros if zero else torch.empty)(shape, device=self.dev, dtype=dtype)
             self.bufs[key] = t
+        elif tuple(t.shape) != shape or t.dtype != dtype:
+            raise RuntimeError(f"schedule buffer {key!r} exists as {tuple(t.shape)} {t.dtype}, requested {shape} {dtype}")
         return t
 
     def event(self, name: str) -> torch.cuda.Event:
@@ -502,7 +504,8 @@ class StepProgram:
         self._k(main, "snf_distortion", sb1, w1, R, S, 1.0 / float(R), rows_d, gw_d)
         rows_i = b("rows_i", (R,))
         gwp = b("gwp", (R, P)) if updated else None
-        self._k(main, "snf_interlevel", sb1, w1, sb0, w0, R, S, P, 1.0 / float(R * S), rows_i, gwp)
+        # (the loss rows stay unscaled -- the summary applies the multiplier; the gradient carries it, as autograd's does)
+        self._k(main, "snf_interlevel", sb1, w1, sb0, w0, R, S, P, float(cfg.interlevel_loss_mult) / float(R * S), rows_i, gwp)
         summary = b("loss_summary", (8,))
         self._k(main, "snf_nerf_loss_summary", mse_out, rows_i, float(cfg.interlevel_loss_mult) / float(R * S), rows_d,
                 1.0 / float(R), float(cfg.distortion_loss_mult), R, summary)
@@ -849,6 +852,14 @@ class StepProgram:
         self.event(f"head_done_{hname}_{parity}").record(st)
         self._head_busy[(parity, hname)] = True
 
+    def _target_shape(self, hname: str) -> Tuple[int, int]:
+        """(rows, channels) of a head's distillation target: what its prediction has (sam_model.py:259-277,316-328)."""
+        sf = self.model.sam_field
+        if hname == "sam" and self.cfg.patch_size > 1:
+            return self.R // (self.cfg.patch_size ** 2), int(self.model.conv_head[2].weight.shape[0])
+        net = sf.sam_net if hname == "sam" else sf.clipseg_net
+        return self.R, int(net.n_output_dims)
+
     def _load_inputs(self, step: int, parity: int, overlap: bool) -> None:
         """next_train(step) into the schedule's input buffers; the samplers' per-ray jitter (ray_samplers.py:105,318)."""
         dm = self.tr.pipeline.datamanager
@@ -902,8 +913,7 @@ class StepProgram:
             # for all of them, no later step stalls the host in the middle of a run
             for par in (parity, parity ^ 1):
                 for h in self.heads:  # the targets' buffers exist before the first load
-                    rows = self.R // (self.cfg.patch_size ** 2) if (h == "sam" and self.cfg.patch_size > 1) else self.R
-                    self.buf(f"in_{h}", (rows, 256 if h == "sam" else 192), parity=par)
+                    self.buf(f"in_{h}", self._target_shape(h), parity=par)
                 for upd in (updated, not updated):
                     k2 = (par, upd) + key[2:]
                     if k2 not in self.plans:
@@ -939,7 +949,8 @@ class StepProgram:
             self._replay_timed(plan, sel)
         if not self.multi:  # (exchange_and_step counts the steps of its group itself)
             for g in stepped:
-                opt.step_count[g] += 1
+                if ("t", g) in plan.dyn:  # only groups this schedule has an Adam launch for (not 'conv' without a conv head)
+                    opt.step_count[g] += 1
         elif with_opt:
             for p_ in self._tp_params:  # the other ranks' copies of the owned levels are behind now (refreshed before eval / saving)
                 p_._tp_stale = True
@@ -956,9 +967,17 @@ class StepProgram:
         if overlap and not tr.pipeline_steps:
             for h in self.heads:
                 self.main.wait_stream(tr._side[h])
+            self.join_side_streams()
         if self.heads and not (overlap and tr.pipeline_steps):
             loss = loss + sum(loss_dict[tr.HEAD_LOSS[h]] for h in self.heads)
         return loss, loss_dict, metrics_dict
+
+    def join_side_streams(self) -> None:
+        """Order the main stream after everything the schedule has put on its own side stream (the forward-time sorts and,
+        without feature heads, the proposal backward + Adam and the next step's prologue).  `Trainer.synchronize()` and every
+        un-pipelined step call it: parameters and moments of `proposal_networks` are then safe to read on the main stream."""
+        if self._own_sort_stream is not None:
+            self.main.wait_stream(self._own_sort_stream)
 
     def _replay_timed(self, plan: _Plan, sel) -> None:
         """bench.py's per-launch HIP-event timing (ops.enable_kernel_timing): events go on the stream of the launch."""

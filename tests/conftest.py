@@ -37,6 +37,7 @@ def golden():
 
 
 LAST_LAYERS = ("sam_w1", "clipseg_w1", "head_w2", "conv1_w", "conv1_b", "conv0_w", "conv0_b")
+OUTLIER = 1e-4  # an element is an outlier when it differs by more than this fraction of its tensor's largest entry
 
 
 @pytest.fixture(scope="session")
@@ -47,28 +48,53 @@ def grad_parity():
     unit) pair whose pre-activation lies within the ~2e-6 rounding of positions / interpolation of zero.  One flipped pair moves
     one row of that layer's weight gradient, and the table entries that sample touches, by ~1/sqrt(samples) of their size:
     0.5-4 % of the tensor's largest entry in a few elements, next to ~1e-5 everywhere else (tools/debug_ministep.py traces
-    each outlier to its one sample).  So every tensor is held to a relative L1 error of 5e-3 -- a wrong term, level or scale
-    is O(1) there -- and the tensors behind their network's last ReLU to 2e-4 of their largest entry.  The oracle evaluated in
-    fp32 and in fp64 differs from itself in exactly this pattern (tests/test_oracle_golden.py::test_gradient_conditioning:
-    field_table 6e-3 / base_w0 5e-3 / sam_w0 8e-3 of the largest entry, 1e-3 relative L1).  The proposal network's gradient
-    comes from the interlevel loss alone, which is ~5e-11 in these untrained configurations -- a difference of nearly equal
-    histograms (its fp32 and fp64 evaluations are 1e-3 apart): held to 3e-2; the loss kernels' own tests (test_ops_gpu.py)
-    check that backward on well-conditioned inputs."""
+    each outlier to its one sample).  The oracle evaluated in fp32 and in fp64 differs from itself in exactly this pattern
+    (tests/test_oracle_golden.py::test_gradient_conditioning; counted in the same units as here: field_table 1 % of its
+    elements above 1e-4 of the largest entry and up to 1.5e-2 of it, base_w0 10 of 64 rows, sam_w0 5 of 256 rows, the hash
+    tables 0.1-0.2 %, every tensor behind its network's last ReLU none at all).  So every tensor is held to FOUR bounds, so that
+    outliers are bounded in mass, in size and in NUMBER:
+      * relative L1 error <= 5e-3 (a wrong term, level or scale is O(1) there; measured 1e-3);
+      * largest error <= 6e-2 of the largest entry (a flip moves an entry by at most a few per cent; a wrong contribution
+        confined to a few rows or entries is O(1) of them) and <= 2e-4 for the tensors behind their network's last ReLU;
+      * outliers (|err| > 1e-4 of the largest entry) in at most 3 % of a hash table's elements and in at most 25 % of the rows
+        of a weight matrix upstream of a ReLU (a flipped (sample, unit) pair owns ONE row), none behind the last ReLU;
+    the report lists count and rows per tensor.  The proposal network's gradient comes from the interlevel loss alone, which is
+    ~5e-11 in these untrained configurations -- a difference of nearly equal histograms (its fp32 and fp64 evaluations are
+    1e-3 apart): relative L1 <= 3e-2 only; the loss kernels' own tests (test_ops_gpu.py) check that backward on well-conditioned
+    inputs."""
     import numpy as np
 
-    def check(got, ref, l1_tol=5e-3, max_tol=2e-4):
-        l1, mx = {}, {}
+    def check(got, ref, l1_tol=5e-3, max_tol=2e-4, big_tol=6e-2, table_frac=3e-2, row_frac=0.25):
+        l1, mx, cnt, rows, shape = {}, {}, {}, {}, {}
         for k, r in ref.items():
             r = np.asarray(r, dtype=np.float64)
             a = got[k]
             a = a.detach().cpu().double().numpy() if hasattr(a, "detach") else np.asarray(a, dtype=np.float64)
             err = np.abs(a.reshape(r.shape) - r)
-            l1[k], mx[k] = float(err.sum() / np.abs(r).sum()), float(err.max() / np.abs(r).max())
-        report = {k: f"{l1[k]:.1e}/{mx[k]:.1e}" for k in l1}
-        assert max(v for k, v in l1.items() if not k.startswith("prop_")) <= l1_tol, report
+            top = np.abs(r).max()
+            l1[k], mx[k] = float(err.sum() / np.abs(r).sum()), float(err.max() / top)
+            bad = err > OUTLIER * top
+            cnt[k] = int(bad.sum())
+            rows[k] = int(bad.reshape(bad.shape[0], -1).any(axis=1).sum()) if bad.ndim >= 2 else cnt[k]
+            shape[k] = r.shape
+        report = {k: f"{l1[k]:.1e}/{mx[k]:.1e}/{cnt[k]}of{int(np.prod(shape[k]))}/{rows[k]}rows" for k in l1}
+        if os.environ.get("SNF_PARITY_VERBOSE"):
+            print("[grad_parity] L1 / max / outliers / rows:", report, flush=True)
+        nonprop = [k for k in l1 if not k.startswith("prop_")]
+        assert max(l1[k] for k in nonprop) <= l1_tol, report
         assert max([v for k, v in l1.items() if k.startswith("prop_")] or [0.0]) <= 3e-2, report
         strict = [k for k in LAST_LAYERS if k in mx]
         assert strict and max(mx[k] for k in strict) <= max_tol, report
+        assert all(cnt[k] == 0 for k in strict), report
+        for k in nonprop:
+            if k in strict:
+                continue
+            assert mx[k] <= big_tol, (k, report)
+            n = int(np.prod(shape[k]))
+            if k.endswith("_table") or "_table" in k:
+                assert cnt[k] <= table_frac * n, (k, report)
+            elif len(shape[k]) >= 2:
+                assert rows[k] <= max(2, row_frac * shape[k][0]), (k, report)
         return report
 
     return check

@@ -69,6 +69,28 @@ def test_one_step_gives_the_eager_gradients(method):
         assert new.optimizers.step_count[g] == ref.optimizers.step_count[g] == 1
 
 
+def test_loss_multipliers_scale_the_gradients_like_autograd(monkeypatch):
+    """interlevel_loss_mult / distortion_loss_mult other than the defaults (nerfacto.py:316-344 multiplies the loss terms, so
+    autograd scales their gradients): the schedule's proposal-network and field moments after one step equal the eager path's.
+    (the schedule applied interlevel_loss_mult to the reported loss only.)"""
+    from samnerf_amd import configs
+    base = configs.method_configs["samnerf_no_distill"].pipeline.model
+    monkeypatch.setattr(base, "interlevel_loss_mult", 3.0)
+    monkeypatch.setattr(base, "distortion_loss_mult", 0.01)
+    ref = _trainer("samnerf_no_distill", False, 512, 13)
+    l_ref = _run(ref, 1)
+    new = _trainer("samnerf_no_distill", True, 512, 13)
+    l_new = _run(new, 1)
+    assert new._program is not None and ref._program is None
+    assert new.pipeline.model.config.interlevel_loss_mult == 3.0
+    for k, v in l_ref[0].items():
+        assert abs(l_new[0][k] - v) <= 1e-5 * max(1.0, abs(v)), (k, l_new[0][k], v)
+    for g, a in ref.optimizers.arenas.items():
+        b = new.optimizers.arenas[g]
+        assert float(a.exp_avg.abs().max()) > 0
+        assert _rel_to_max(b.exp_avg, a.exp_avg) <= (3e-5 if g == "fields" else 2e-6), g
+
+
 @pytest.mark.parametrize("overlap", [True, False])
 def test_trajectory_follows_the_eager_path(overlap):
     """14 steps (the proposal network trains on every step below 10 and on every other step after that, so both variants
