@@ -48,7 +48,8 @@ def algorithmic_model(key: str, w: dict):
         m = re.fullmatch(r"F8L(\d+)\+(\d+)", tag)        # reports its own bytes (gathers + 24 B per fused parameter)
         return ("hbm", float(R * K * (int(m.group(1)) + int(m.group(2))) * 8 * 8 * 4 * 2), "GB/s") if m else (None, None, None)
     if name in ("snf_hashgrid_fwd", "snf_hashgrid_bwd", "snf_hashgrid_bwd_sorted", "snf_hashgrid_bwd_sorted_ex",
-                "snf_hashgrid_bwd_presorted", "snf_hashgrid_bwd_presorted_adam", "snf_hashgrid_bwd_presorted_adam_fx"):
+                "snf_hashgrid_bwd_presorted", "snf_hashgrid_bwd_presorted_adam", "snf_hashgrid_bwd_presorted_adam_sp",
+                "snf_hashgrid_bwd_presorted_adam_fx"):
         # (the fused backward + Adam reports its own bytes per launch -- ops._hashgrid_bwd_launch: the corner
         # contributions as below plus 24 B per parameter of the fused levels -- and roof() prefers those)
         m = re.fullmatch(r"F(\d+)L(\d+)(tp)?", tag)
@@ -313,6 +314,7 @@ def main():
     # reduce, k_hg_reduce being ~60 % of it (profiles/*_kernel_stats.csv).
     largest_kernel_share = {"snf_hashgrid_bwd_sorted": 0.6, "snf_hashgrid_bwd_sorted_ex": 0.6,
                             "snf_hashgrid_bwd_presorted": 0.9, "snf_hashgrid_bwd_presorted_adam": 0.95,
+                            "snf_hashgrid_bwd_presorted_adam_sp": 0.9,
                             "snf_hashgrid_bwd_presorted_adam_pair": 1.0,
                             "snf_hashgrid_bwd_presorted_adam_fx": 0.95}
     dom = args.roofline_kernel

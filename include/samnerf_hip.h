@@ -115,19 +115,38 @@ int snf_hashgrid_bwd_presorted_adam(const float* grad_out, int N, int L, int F, 
                                     int fuse_from_level, float* param, float* exp_avg, float* exp_avg_sq, float lr,
                                     float beta1, float beta2, float eps, int step, float grad_scale, snf_stream_t stream);
 
-/* snf_hashgrid_bwd_presorted_adam for the TWO F = 8 grids of a feature head (clip_encs / clipseg_encs, samnerf/sam_field.py:38-94:
- * same samples N, same log2_T, level-major gradients = ld_out 0) in one reduce launch: one tail instead of two, and the
- * latency-bound reachable-row levels of one grid share the CUs with the bandwidth-bound dense levels of the other.  Same
- * arithmetic per table as two snf_hashgrid_bwd_presorted_adam calls; the hyper-parameters are the group's.
- * reachable0 / reachable1 (may be NULL): bitmaps over the rows of the levels below fuse_from_level (bit (l << log2_T) + row: the
- * row can be addressed by some input, Encoding.active_rows).  With a bitmap the launch also steps those rows -- zero gradient or
- * not -- so the WHOLE table is stepped here and no snf_adam_step_rows pass (and no gradient write for those levels) is needed. */
+/* Reachable-row levels (round 3).  A level of resolution s addresses at most (s + 3)^3 of its 2^log2_T rows (Encoding.active_rows
+ * on the host side; exact: the other rows never receive a gradient and torch.optim.Adam leaves a parameter with g = m = v = 0
+ * where it is).  For the leading `sparse_levels` levels of a table the caller passes the static lists of those rows --
+ * reach_rows: (level << log2_T) + row, ascending; reach_start[level * B + bucket], B = 2^snf_hashgrid_bucket_bits(N, log2_T), with
+ * one closing entry -- and the reduce pass handles those levels by a fixed-point sum over COMPACT row indices with replicated
+ * accumulators (no same-address pile-up where hundreds of records share a row) and applies Adam to exactly the listed rows, zero
+ * gradient or not: the call then steps the WHOLE table (no gradient is written for those levels, no snf_adam_step_rows pass).
+ * sparse_step = 0: those levels only add their sums to grad_table (gradient exchange between ranks first, optimizer off).
+ * sparse_levels <= fuse_from_level; sparse_max_rows = the longest list of a bucket, at most snf_hashgrid_sparse_max_rows(F);
+ * scratch: SNF_HG_FX_SCRATCH_BYTES private to the call (may be NULL for F = 2 or without reachable-row levels).  Replaces, for the
+ * hash tables, torch.optim.Adam.step of nerfstudio/engine/optimizers.py:131-147 like snf_hashgrid_bwd_presorted_adam. */
+int snf_hashgrid_bucket_bits(int N, int log2_T);
+int snf_hashgrid_sparse_max_rows(int F);
+int snf_hashgrid_bwd_presorted_adam_sp(const float* grad_out, int N, int L, int F, int log2_T, int ld_out, int col_off,
+                                       int n_run_levels, float* grad_table, const void* sorted_workspace, float* stage,
+                                       int fuse_from_level, float* param, float* exp_avg, float* exp_avg_sq, float lr,
+                                       float beta1, float beta2, float eps, int step, float grad_scale,
+                                       const uint32_t* reach_rows, const uint32_t* reach_start, int sparse_levels,
+                                       int sparse_max_rows, int sparse_step, void* scratch, snf_stream_t stream);
+
+/* snf_hashgrid_bwd_presorted_adam_sp for the TWO F = 8 grids of a feature head (clip_encs / clipseg_encs, samnerf/sam_field.py:38-94:
+ * same samples N, same log2_T, level-major gradients = ld_out 0): the bucket-wide levels of both tables in ONE reduce launch (one
+ * tail instead of two), the reachable-row levels of each in front of it.  Same arithmetic per table as two single-table calls;
+ * the hyper-parameters are the group's.  scratch: SNF_HG_FX_SCRATCH_BYTES, needed when either table has reachable-row levels. */
 int snf_hashgrid_bwd_presorted_adam_pair(const float* grad_out0, const float* grad_out1, int N, int L0, int L1, int log2_T,
                                          float* grad_table0, float* grad_table1, const void* sorted_workspace0,
                                          const void* sorted_workspace1, int fuse_from_level0, int fuse_from_level1, float* param0,
                                          float* exp_avg0, float* exp_avg_sq0, float* param1, float* exp_avg1, float* exp_avg_sq1,
-                                         const uint32_t* reachable0, const uint32_t* reachable1, float lr, float beta1,
-                                         float beta2, float eps, int step, float grad_scale, snf_stream_t stream);
+                                         const uint32_t* reach_rows0, const uint32_t* reach_start0, int sparse_levels0,
+                                         const uint32_t* reach_rows1, const uint32_t* reach_start1, int sparse_levels1,
+                                         int sparse_max_rows, int sparse_step, void* scratch, float lr, float beta1, float beta2,
+                                         float eps, int step, float grad_scale, snf_stream_t stream);
 
 /* The same pass with FIXED-POINT per-row sums (F = 2 and F = 8): a contribution w * g is added to its row as a 64-bit integer
  * LDS atomic, q = rint(w g 2^s) with 2^s = 2^38 / 2^e and 2^e above the level's largest finite |g| (found by a small

@@ -477,10 +477,6 @@ struct HgAdam {
     float *p, *m, *v;
     float b1, b2, step_size, inv_sqrt_bc2, eps, gs;
     int from_level;
-    // float reduce only: bit (l << T) + row set = row `row` of the level l < from_level can be addressed at all (Encoding.active_rows).
-    // With the bitmap the reduce pass steps THOSE rows of the levels below from_level too (the others never move: exact, section 4.0),
-    // i.e. the whole table in one launch -- no gradient written for them, no separate snf_adam_step_rows pass.
-    const uint32_t* reach;
 };
 
 __device__ __forceinline__ void hg_adam1(float& p, float g, float& m, float& v, const HgAdam& a) {  // == optim.hip adam1
@@ -500,8 +496,9 @@ struct HgSecond {
     const uint2* records;
     float* grad_table;
     HgAdam adam;
-    int first_levels;  // levels of the first grid; >= gridDim.y: there is no second grid
+    int first_levels;  // levels of the first grid IN THIS LAUNCH; >= gridDim.y: there is no second grid
     int interleave;
+    int level0;        // first level of the second grid covered by this launch (its leading levels went to k_hg_reduce_sparse)
 };
 
 #ifndef SNF_HG_RT_MINWG
@@ -513,7 +510,7 @@ template <int F, bool ADAM>
 __global__ __launch_bounds__(HG_RT, SNF_HG_RT_MINWG) void k_hg_reduce(const float* __restrict__ gT, int N, int log2_T, int log2B,
                                                      const uint32_t* __restrict__ bucket_start,
                                                      const uint2* __restrict__ records, float* __restrict__ grad_table,
-                                                     uint32_t hg_long, int n_run_levels, HgAdam adam, HgSecond sec) {
+                                                     uint32_t hg_long, int n_run_levels, int level0, HgAdam adam, HgSecond sec) {
     constexpr int CHUNK = hg_chunk<F>();
     constexpr int RPT = CHUNK / HG_RT;
     __shared__ uint32_t cnt[HG_MAX_RPB + 1];  // per-row counts, then exclusive offsets
@@ -536,12 +533,13 @@ __global__ __launch_bounds__(HG_RT, SNF_HG_RT_MINWG) void k_hg_reduce(const floa
         }
         if (second) {
             gT = sec.gT; bucket_start = sec.bucket_start; records = sec.records; grad_table = sec.grad_table; adam = sec.adam;
+            level0 = sec.level0;
         }
     }
+    l += level0;  // (a launch may cover the level sub-range [level0, level0 + n) of its table; all indices below are absolute)
     const int lane = tid & 63, wave = tid >> 6;
     const uint32_t start = bucket_start[l * (B + 1) + b], end = bucket_start[l * (B + 1) + b + 1];
-    const bool dense_level = l >= adam.from_level;
-    const bool fuse = ADAM && (dense_level || adam.reach != nullptr);
+    const bool fuse = ADAM && l >= adam.from_level;
     if (start == end && !fuse) return;  // nothing lands in this bucket: leave the slab untouched
     bool any_long = false;
     float* __restrict__ slab = grad_table + (((size_t)l << log2_T) + ((size_t)b << log2rpb)) * F;
@@ -728,10 +726,6 @@ __global__ __launch_bounds__(HG_RT, SNF_HG_RT_MINWG) void k_hg_reduce(const floa
                 for (int j = 0; j < HG_EPI; ++j) {
                     const int r = tid + (q0 + j) * HG_RT;
                     on[j] = r < rpb;
-                    if (on[j] && !dense_level) {  // reachable-row level: only the rows an input can address exist for Adam
-                        const uint32_t gr = ((uint32_t)l << log2_T) + ((uint32_t)b << log2rpb) + (uint32_t)r;
-                        on[j] = (adam.reach[gr >> 5] >> (gr & 31)) & 1u;
-                    }
                     if (on[j]) {
                         const size_t o = base + (size_t)r * F;
                         load_row<F>(adam.p + o, pp[j]);
@@ -870,7 +864,7 @@ template <int F, bool ADAM, int SPLIT>
 __global__ __launch_bounds__(HG_FX_T) void k_hg_reduce_fx(const float* __restrict__ gT, int N, int log2_T, int log2B,
                                                           const uint32_t* __restrict__ bucket_start,
                                                           const uint2* __restrict__ records, float* __restrict__ grad_table,
-                                                          int xcd_from_level, int n_merge_levels,
+                                                          int xcd_from_level, int n_merge_levels, int level0,
                                                           const uint32_t* __restrict__ lvl_absmax_bits, HgAdam adam) {
     constexpr int MAXROWS = HG_MAX_RPB / SPLIT;
     __shared__ unsigned long long acc[MAXROWS * F];
@@ -897,6 +891,10 @@ __global__ __launch_bounds__(HG_FX_T) void k_hg_reduce_fx(const float* __restric
         }
     }
     if (rpb_full < SPLIT && (blockIdx.x % SPLIT) != 0) return;  // (tiny tables: one workgroup per bucket)
+    // (a launch may cover the level sub-range [level0, level0 + gridDim.y) of its table: xcd_from_level / n_merge_levels above are
+    //  relative to the launch, every index below is absolute)
+    const bool merge_level = l < n_merge_levels;
+    l += level0;
     const uint32_t row0 = (uint32_t)part * (uint32_t)rpb;
     const uint32_t start = bucket_start[l * (B + 1) + b], end = bucket_start[l * (B + 1) + b + 1];
     const bool fuse = ADAM && l >= adam.from_level;
@@ -918,7 +916,7 @@ __global__ __launch_bounds__(HG_FX_T) void k_hg_reduce_fx(const float* __restric
     const float* __restrict__ gl = gT + (size_t)l * N * F;
     // (wave-uniform.  Small tables already spread a row over `copies` accumulators: merging on top of 4 copies measured slower,
     //  proposal grid 84 -> 96 us; without copies it takes the field grid's five coarse levels from 354 to 219 us)
-    const bool merge = l < n_merge_levels && copies < 4;
+    const bool merge = merge_level && copies < 4;
     __syncthreads();
     // three-stage software pipeline over trips of U records per thread: the records of trip t+2 and the staged gradients of
     // trip t+1 are in flight while trip t is accumulated, so neither global latency sits on the loop's critical path
@@ -1101,6 +1099,154 @@ __global__ __launch_bounds__(HG_FX_T) void k_hg_reduce_fx(const float* __restric
     }
 }
 
+// ==========================================================================================
+// Reachable-row levels (round 3): fixed-point reduce over COMPACT row indices, Adam fused.
+//
+// A level of resolution s can only ever address the <= (s + 3)^3 rows its lattice hashes to (Encoding.active_rows).
+// On the coarse levels of a T = 19 table that is 19 ... ~900 of a bucket's 2048 rows, each receiving 100 ... 2 records of a
+// 65 536-sample step -- the regime where the float reduce above ranks hundreds of records on ONE LDS counter (same-address
+// atomics serialise: the eight such levels of a 16 -> 128 feature grid took as long as its four dense levels, which move 4x
+// the bytes) and where the plain fixed-point reduce piles its 64-bit atomics on a handful of addresses.
+// Here the bucket's reachable rows (a static, sorted list per (level, bucket)) get compact indices 0 .. nrows-1 through a
+// 2048-entry LDS lookup, and the accumulator array holds as many COPIES of the nrows x F sums as fit (lane j adds into copy
+// j mod copies; 64 copies when nrows <= 16: no two lanes of a wave ever share an address).  Integer sums commute, so the copies
+// are added in any order and the result stays exact and order-independent.  The epilogue applies Adam to exactly the reachable
+// rows -- zero gradient or not, like snf_adam_step_rows -- so these levels write no gradient and need no separate optimizer
+// pass; without ADAM the sums are added to the gradient table.
+// ==========================================================================================
+constexpr int HG_SP_T = 512;
+template <int F> constexpr int hg_sp_acc_words() { return F == 8 ? 8192 : 4096; }  // 64-bit accumulators: 64 KB (F = 8), 32 KB (F = 2)
+template <int F> constexpr int hg_sp_max_rows() { return hg_sp_acc_words<F>() / F; }   // reachable rows per bucket this kernel takes
+
+template <int F> inline size_t hg_sp_lds_bytes(int log2rpb) {
+    return (size_t)hg_sp_acc_words<F>() * 8 + (size_t)hg_sp_acc_words<F>() / 32 * 4 + ((size_t)2 << log2rpb);
+}
+
+template <int F, bool ADAM>
+__global__ __launch_bounds__(HG_SP_T) void k_hg_reduce_sparse(const float* __restrict__ gT, int N, int log2_T, int log2B,
+                                                              const uint32_t* __restrict__ bucket_start,
+                                                              const uint2* __restrict__ records, float* __restrict__ grad_table,
+                                                              const uint32_t* __restrict__ reach_rows,
+                                                              const uint32_t* __restrict__ reach_start,
+                                                              const uint32_t* __restrict__ lvl_absmax_bits, HgAdam adam) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long sp_lds[];
+    constexpr int ACC = hg_sp_acc_words<F>();
+    unsigned long long* acc = sp_lds;                                    // [copies][nrows][F]
+    uint32_t* bad = reinterpret_cast<uint32_t*>(acc + ACC);               // one bit per (row, feature): non-finite contribution
+    uint16_t* lookup = reinterpret_cast<uint16_t*>(bad + ACC / 32);       // row in bucket -> compact index (0xFFFF: unreachable)
+    const int B = 1 << log2B, log2rpb = log2_T - log2B, rpb = 1 << log2rpb;
+    const int tid = threadIdx.x, lane = tid & 63, b = blockIdx.x, l = blockIdx.y;
+    const uint32_t rs = reach_start[l * B + b];
+    const int nrows = (int)(reach_start[l * B + b + 1] - rs);
+    if (nrows <= 0) return;  // no row of this bucket can be addressed: no record lands here, nothing to step
+    const uint32_t start = bucket_start[l * (B + 1) + b], end = bucket_start[l * (B + 1) + b + 1];
+    if (!ADAM && start == end) return;
+    int copies = ACC / (nrows * F);
+    copies = copies >= 64 ? 64 : (copies < 1 ? 1 : 1 << (31 - __clz(copies)));  // power of two, at most one per lane
+    const uint32_t copy_off = (uint32_t)(lane & (copies - 1)) * (uint32_t)(nrows * F);
+    for (int i = tid; i < rpb; i += HG_SP_T) lookup[i] = 0xFFFFu;
+    for (int i = tid; i < copies * nrows * F; i += HG_SP_T) acc[i] = 0ull;
+    for (int i = tid; i < (nrows * F + 31) / 32; i += HG_SP_T) bad[i] = 0u;
+    __syncthreads();
+    for (int i = tid; i < nrows; i += HG_SP_T) lookup[reach_rows[rs + i] & (uint32_t)(rpb - 1)] = (uint16_t)i;
+    int e = 0;
+    frexpf(__uint_as_float(lvl_absmax_bits[l]), &e);
+    int sh = HG_FX_BITS - e;
+    sh = sh > 120 ? 120 : sh;
+    const float scale = ldexpf(1.f, sh), inv = ldexpf(1.f, -sh);
+    const float* __restrict__ gl = gT + (size_t)l * N * F;
+    __syncthreads();
+    constexpr int U = 4;
+    const uint32_t mask_s = (1u << HG_SAMPLE_BITS) - 1u;
+    uint2 rec0[U], rec1[U];
+    float g0[U][F], g1[U][F];
+    auto load_recs = [&](uint32_t c0, uint2 (&r)[U]) {
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const uint32_t i = c0 + tid + (uint32_t)HG_SP_T * j;
+            r[j] = records[i < end ? i : (start < end ? start : 0u)];
+        }
+    };
+    auto gather = [&](const uint2 (&r)[U], float (&g)[U][F]) {
+#pragma unroll
+        for (int j = 0; j < U; ++j) load_row<F>(gl + (size_t)(r[j].x & mask_s) * F, g[j]);
+    };
+    constexpr uint32_t TRIP = HG_SP_T * U;
+    load_recs(start, rec0);
+    gather(rec0, g0);
+    if (start + TRIP < end) load_recs(start + TRIP, rec1);
+    for (uint32_t c0 = start; c0 < end; c0 += TRIP) {
+        uint2 rec2[U];
+        const bool has1 = c0 + TRIP < end, has2 = c0 + 2 * TRIP < end;
+        if (has1) gather(rec1, g1);
+        if (has2) load_recs(c0 + 2 * TRIP, rec2);
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const bool live = c0 + tid + (uint32_t)HG_SP_T * j < end;
+            const uint32_t idx = lookup[rec0[j].x >> HG_SAMPLE_BITS];
+            if (live && idx != 0xFFFFu) {
+                const float w = __uint_as_float(rec0[j].y);
+#pragma unroll
+                for (int f = 0; f < F; ++f) {
+                    const float v = w * g0[j][f];
+                    if (fabsf(v) < INFINITY) {
+                        const long long q = __float2ll_rn(v * scale);
+                        if (q != 0) atomicAdd(&acc[copy_off + idx * F + f], (unsigned long long)q);
+                    } else {
+                        const uint32_t eb = idx * F + f;
+                        atomicOr(&bad[eb >> 5], 1u << (eb & 31));
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            rec0[j] = rec1[j];
+            rec1[j] = rec2[j];
+#pragma unroll
+            for (int f = 0; f < F; ++f) g0[j][f] = g1[j][f];
+        }
+    }
+    __syncthreads();
+    // ---- epilogue: one thread per reachable row
+    for (int i = tid; i < nrows; i += HG_SP_T) {
+        const size_t o = (size_t)reach_rows[rs + i] * F;  // (the list holds (level << T) + row: an offset into the whole table)
+        float gg[F];
+        bool nz = false;
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+            const uint32_t eb = (uint32_t)(i * F + f);
+            unsigned long long qs = acc[eb];
+            for (int c = 1; c < copies; ++c) qs += acc[(uint32_t)c * (uint32_t)(nrows * F) + eb];
+            const bool isbad = (bad[eb >> 5] >> (eb & 31)) & 1u;
+            gg[f] = isbad ? __uint_as_float(0x7FC00000u) : __ll2float_rn((long long)qs) * inv;
+            nz = nz || qs != 0ull || isbad;
+        }
+        if constexpr (ADAM) {
+            float pp[F], mm[F], vv[F];
+            load_row<F>(adam.p + o, pp);
+            load_row<F>(adam.m + o, mm);
+            load_row<F>(adam.v + o, vv);
+#pragma unroll
+            for (int f = 0; f < F; ++f) hg_adam1(pp[f], gg[f], mm[f], vv[f], adam);
+            if constexpr (F == 2) {
+                *reinterpret_cast<float2*>(adam.p + o) = make_float2(pp[0], pp[1]);
+                *reinterpret_cast<float2*>(adam.m + o) = make_float2(mm[0], mm[1]);
+                *reinterpret_cast<float2*>(adam.v + o) = make_float2(vv[0], vv[1]);
+            } else {
+                reinterpret_cast<float4*>(adam.p + o)[0] = make_float4(pp[0], pp[1], pp[2], pp[3]);
+                reinterpret_cast<float4*>(adam.p + o)[1] = make_float4(pp[4], pp[5], pp[6], pp[7]);
+                reinterpret_cast<float4*>(adam.m + o)[0] = make_float4(mm[0], mm[1], mm[2], mm[3]);
+                reinterpret_cast<float4*>(adam.m + o)[1] = make_float4(mm[4], mm[5], mm[6], mm[7]);
+                reinterpret_cast<float4*>(adam.v + o)[0] = make_float4(vv[0], vv[1], vv[2], vv[3]);
+                reinterpret_cast<float4*>(adam.v + o)[1] = make_float4(vv[4], vv[5], vv[6], vv[7]);
+            }
+        } else if (nz) {
+            row_rmw<F>(grad_table + o, gg);
+        }
+    }
+}
+
 }  // namespace snf
 
 using namespace snf;
@@ -1258,6 +1404,102 @@ extern "C" int snf_hashgrid_sort(const float* u, const float* scalings, int N, i
     return SNF_OK;
 }
 
+// What the reduce pass of ONE table needs besides the records: the reachable-row lists of its leading `levels` levels
+// (Encoding.reach_lists: sorted (level << T) + row per (level, bucket), and the [levels * B + 1] list offsets).  levels = 0: none,
+// every level goes through the bucket-wide kernels.
+struct HgSparse {
+    const uint32_t* rows;
+    const uint32_t* start;
+    int levels;
+};
+
+static void hg_fill_adam(HgAdam& a, float* param, float* exp_avg, float* exp_avg_sq, float lr, float beta1, float beta2, float eps,
+                         int step, float grad_scale, int from_level) {
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    a.p = param; a.m = exp_avg; a.v = exp_avg_sq;
+    a.b1 = beta1; a.b2 = beta2; a.step_size = (float)((double)lr / bc1); a.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+    a.eps = eps; a.gs = grad_scale; a.from_level = from_level;
+}
+
+template <int F>
+static void hg_launch_sparse(hipStream_t st, const float* stage, int N, int log2_T, const HgGeom& g, const HgWs& w, float* grad_table,
+                             const HgSparse& sp, const uint32_t* lvlmax, bool adam_on, const HgAdam& a) {
+    const int B = 1 << g.log2B;
+    const size_t lds = hg_sp_lds_bytes<F>(g.log2rpb);
+    static bool attr_done[2] = {false, false};
+    if (lds > 48 * 1024 && !attr_done[adam_on ? 1 : 0]) {
+        attr_done[adam_on ? 1 : 0] = true;
+        if (adam_on) (void)hipFuncSetAttribute((const void*)k_hg_reduce_sparse<F, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        else (void)hipFuncSetAttribute((const void*)k_hg_reduce_sparse<F, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
+    if (adam_on)
+        hipLaunchKernelGGL((k_hg_reduce_sparse<F, true>), dim3(B, sp.levels), dim3(HG_SP_T), lds, st, stage, N, log2_T, g.log2B, w.bstart,
+                           (const uint2*)w.records, grad_table, sp.rows, sp.start, lvlmax, a);
+    else
+        hipLaunchKernelGGL((k_hg_reduce_sparse<F, false>), dim3(B, sp.levels), dim3(HG_SP_T), lds, st, stage, N, log2_T, g.log2B, w.bstart,
+                           (const uint2*)w.records, grad_table, sp.rows, sp.start, lvlmax, a);
+}
+
+// The reduce pass of one table from its staged (level-major) gradient: reachable-row levels [0, sp.levels) through
+// k_hg_reduce_sparse (stepped there when adam_on), the rest through the fixed-point reduce (F = 2) or the float reduce (F = 8)
+// with Adam fused on the levels >= a.from_level.  lvlmax: per-level scratch of the fixed-point kernels (HG_FX_SCRATCH words).
+static void hg_reduce_one(hipStream_t st, int F, const float* stage, int N, int L, int log2_T, const HgGeom& g, const HgWs& w,
+                          float* grad_table, int n_run_levels, bool adam_on, bool sparse_step, HgAdam a, HgSparse sp,
+                          uint32_t* lvlmax) {
+    const int B = 1 << g.log2B;
+    static const uint32_t hg_long = getenv("SNF_HG_LONG") ? (uint32_t)atoi(getenv("SNF_HG_LONG")) : (uint32_t)HG_LONG;
+    const bool fx = hg_fx_on(F, L, N);
+    const int s0 = sp.levels;  // first level of the bucket-wide kernels
+    const int nfx = fx ? L : s0;  // levels whose largest |g| the fixed-point kernels need
+    if (nfx > 0) {
+        (void)hipMemsetAsync(lvlmax, 0, nfx * sizeof(uint32_t), st);
+        if (F == 2) hipLaunchKernelGGL(k_hg_level_absmax<2>, dim3(hg_absmax_blocks(N, F), nfx), dim3(256), 0, st, stage, N, lvlmax);
+        else hipLaunchKernelGGL(k_hg_level_absmax<8>, dim3(hg_absmax_blocks(N, F), nfx), dim3(256), 0, st, stage, N, lvlmax);
+    }
+    if (s0 > 0) {
+        if (F == 2) hg_launch_sparse<2>(st, stage, N, log2_T, g, w, grad_table, sp, lvlmax, sparse_step, a);
+        else hg_launch_sparse<8>(st, stage, N, log2_T, g, w, grad_table, sp, lvlmax, sparse_step, a);
+    }
+    const int Lr = L - s0;
+    if (Lr <= 0) return;
+    const int nrun = n_run_levels > s0 ? n_run_levels - s0 : 0;  // (relative to the launch)
+    if (F == 2 && fx) {
+        if (adam_on)
+            hipLaunchKernelGGL((k_hg_reduce_fx<2, true, 1>), dim3(B, Lr), dim3(HG_FX_T), 0, st, stage, N, log2_T, g.log2B, w.bstart,
+                               (const uint2*)w.records, grad_table, hg_xcd_from(nrun, Lr, B), hg_merge_levels(nrun), s0, lvlmax, a);
+        else
+            hipLaunchKernelGGL((k_hg_reduce_fx<2, false, 1>), dim3(B, Lr), dim3(HG_FX_T), 0, st, stage, N, log2_T, g.log2B, w.bstart,
+                               (const uint2*)w.records, grad_table, hg_xcd_from(nrun, Lr, B), hg_merge_levels(nrun), s0, lvlmax, HgAdam{});
+    } else if (F == 2) {
+        if (adam_on)
+            hipLaunchKernelGGL((k_hg_reduce<2, true>), dim3(B, Lr), dim3(HG_RT), 0, st, stage, N, log2_T, g.log2B, w.bstart,
+                               (const uint2*)w.records, grad_table, hg_long, nrun, s0, a, hg_no_second());
+        else
+            hipLaunchKernelGGL((k_hg_reduce<2, false>), dim3(B, Lr), dim3(HG_RT), 0, st, stage, N, log2_T, g.log2B, w.bstart,
+                               (const uint2*)w.records, grad_table, hg_long, nrun, s0, HgAdam{}, hg_no_second());
+    } else {
+        if (adam_on)
+            hipLaunchKernelGGL((k_hg_reduce<8, true>), dim3(B, Lr), dim3(HG_RT), 0, st, stage, N, log2_T, g.log2B, w.bstart,
+                               (const uint2*)w.records, grad_table, hg_long, nrun, s0, a, hg_no_second());
+        else
+            hipLaunchKernelGGL((k_hg_reduce<8, false>), dim3(B, Lr), dim3(HG_RT), 0, st, stage, N, log2_T, g.log2B, w.bstart,
+                               (const uint2*)w.records, grad_table, hg_long, nrun, s0, HgAdam{}, hg_no_second());
+    }
+}
+
+static void hg_stage(hipStream_t st, int F, const float* grad_out, int N, int L, int ld_out, int col_off, float* stage) {
+    const int tblocks = ceil_div((long long)N * L, 256);
+    if (F == 2) hipLaunchKernelGGL(k_hg_stage_grad<2>, dim3(tblocks), dim3(256), 0, st, grad_out, N, L, ld_out, col_off, stage);
+    else hipLaunchKernelGGL(k_hg_stage_grad<8>, dim3(tblocks), dim3(256), 0, st, grad_out, N, L, ld_out, col_off, stage);
+}
+
+extern "C" int snf_hashgrid_bucket_bits(int N, int log2_T) {
+    if (N <= 0 || log2_T < 1 || log2_T > 26) return -1;
+    return hg_geometry(N, log2_T).log2B;
+}
+
+extern "C" int snf_hashgrid_sparse_max_rows(int F) { return F == 8 ? hg_sp_max_rows<8>() : (F == 2 ? hg_sp_max_rows<2>() : 0); }
+
 extern "C" int snf_hashgrid_bwd_presorted(const float* grad_out, int N, int L, int F, int log2_T, int ld_out, int col_off,
                                           int n_run_levels, float* grad_table, const void* sorted_workspace, float* stage,
                                           snf_stream_t stream) {
@@ -1272,36 +1514,24 @@ extern "C" int snf_hashgrid_bwd_presorted(const float* grad_out, int N, int L, i
     if (planar) stage = const_cast<float*>(grad_out);
     const HgGeom g = hg_geometry(N, log2_T);
     const HgWs w = hg_ws_layout(const_cast<void*>(sorted_workspace), N, L, g);
-    const int B = 1 << g.log2B;
     hipStream_t st = (hipStream_t)stream;
-    static const uint32_t hg_long = getenv("SNF_HG_LONG") ? (uint32_t)atoi(getenv("SNF_HG_LONG")) : (uint32_t)HG_LONG;
-    const int tblocks = ceil_div((long long)N * L, 256);
-    if (F == 2) {
-        if (!planar) hipLaunchKernelGGL(k_hg_stage_grad<2>, dim3(tblocks), dim3(256), 0, st, grad_out, N, L, ld_out, col_off, stage);
-        if (hg_fx_on(F, L, N)) {
-            (void)hipMemsetAsync(w.fx, 0, L * sizeof(uint32_t), st);
-            hipLaunchKernelGGL(k_hg_level_absmax<2>, dim3(hg_absmax_blocks(N, F), L), dim3(256), 0, st, stage, N, w.fx);
-            hipLaunchKernelGGL((k_hg_reduce_fx<2, false, 1>), dim3(B, L), dim3(HG_FX_T), 0, st, stage, N, log2_T, g.log2B, w.bstart,
-                               (const uint2*)w.records, grad_table, hg_xcd_from(n_run_levels, L, B), hg_merge_levels(n_run_levels), w.fx, HgAdam{});
-        } else
-        hipLaunchKernelGGL((k_hg_reduce<2, false>), dim3(B, L), dim3(HG_RT), 0, st, stage, N, log2_T, g.log2B, w.bstart,
-                           (const uint2*)w.records, grad_table, hg_long, n_run_levels, HgAdam{}, hg_no_second());
-    } else {
-        if (!planar) hipLaunchKernelGGL(k_hg_stage_grad<8>, dim3(tblocks), dim3(256), 0, st, grad_out, N, L, ld_out, col_off, stage);
-        hipLaunchKernelGGL((k_hg_reduce<8, false>), dim3(B, L), dim3(HG_RT), 0, st, stage, N, log2_T, g.log2B, w.bstart,
-                           (const uint2*)w.records, grad_table, hg_long, n_run_levels, HgAdam{}, hg_no_second());
-    }
+    if (!planar) hg_stage(st, F, grad_out, N, L, ld_out, col_off, stage);
+    hg_reduce_one(st, F, stage, N, L, log2_T, g, w, grad_table, n_run_levels, false, false, HgAdam{}, HgSparse{nullptr, nullptr, 0}, w.fx);
     SNF_LAUNCH_CHECK("snf_hashgrid_bwd_presorted");
     return SNF_OK;
 }
 
-extern "C" int snf_hashgrid_bwd_presorted_adam(const float* grad_out, int N, int L, int F, int log2_T, int ld_out, int col_off,
-                                               int n_run_levels, float* grad_table, const void* sorted_workspace, float* stage,
-                                               int fuse_from_level, float* param, float* exp_avg, float* exp_avg_sq, float lr,
-                                               float beta1, float beta2, float eps, int step, float grad_scale,
-                                               snf_stream_t stream) {
+extern "C" int snf_hashgrid_bwd_presorted_adam_sp(const float* grad_out, int N, int L, int F, int log2_T, int ld_out, int col_off,
+                                                  int n_run_levels, float* grad_table, const void* sorted_workspace, float* stage,
+                                                  int fuse_from_level, float* param, float* exp_avg, float* exp_avg_sq, float lr,
+                                                  float beta1, float beta2, float eps, int step, float grad_scale,
+                                                  const uint32_t* reach_rows, const uint32_t* reach_start, int sparse_levels,
+                                                  int sparse_max_rows, int sparse_step, void* scratch, snf_stream_t stream) {
     const bool planar = ld_out == 0;  // grad_out is already level-major [L][N][F]: it IS the staged gradient
-    SNF_REQUIRE(grad_out && grad_table && sorted_workspace && (stage || planar) && param && exp_avg && exp_avg_sq,
+    // (fuse_from_level = L and sparse_step = 0: nothing is stepped -- plain gradient accumulation, param & co. may be NULL)
+    const bool step_sparse = sparse_levels > 0 && sparse_step != 0;
+    const bool adam_on = fuse_from_level < L || step_sparse;
+    SNF_REQUIRE(grad_out && grad_table && sorted_workspace && (stage || planar) && (!adam_on || (param && exp_avg && exp_avg_sq)),
                 "snf_hashgrid_bwd_presorted_adam: null pointer");
     SNF_REQUIRE(F == 2 || F == 8, "snf_hashgrid_bwd_presorted_adam: features_per_level must be 2 or 8 (got %d)", F);
     SNF_REQUIRE(N > 0 && L > 0 && N <= (1 << HG_SAMPLE_BITS) && ((planar && col_off == 0) || ld_out >= col_off + L * F) &&
@@ -1310,83 +1540,114 @@ extern "C" int snf_hashgrid_bwd_presorted_adam(const float* grad_out, int N, int
     if (planar) stage = const_cast<float*>(grad_out);
     SNF_REQUIRE(fuse_from_level >= 0 && fuse_from_level <= L && step >= 1,
                 "snf_hashgrid_bwd_presorted_adam: bad fuse_from_level=%d (L=%d) or step=%d", fuse_from_level, L, step);
+    SNF_REQUIRE(sparse_levels >= 0 && sparse_levels <= fuse_from_level && sparse_levels <= (int)HG_FX_SCRATCH &&
+                    (sparse_levels == 0 || (reach_rows && reach_start && sparse_max_rows <= snf_hashgrid_sparse_max_rows(F))),
+                "snf_hashgrid_bwd_presorted_adam: reachable-row levels %d must be <= fuse_from_level %d, come with their row lists "
+                "and hold at most %d rows per bucket (got %d)", sparse_levels, fuse_from_level, snf_hashgrid_sparse_max_rows(F),
+                sparse_max_rows);
     SNF_REQUIRE((((uintptr_t)grad_out | (uintptr_t)grad_table | (uintptr_t)stage | (uintptr_t)param | (uintptr_t)exp_avg |
-                  (uintptr_t)exp_avg_sq) & 15) == 0, "snf_hashgrid_bwd_presorted_adam: unaligned pointer");
+                  (uintptr_t)exp_avg_sq | (uintptr_t)scratch) & 15) == 0, "snf_hashgrid_bwd_presorted_adam: unaligned pointer");
     const HgGeom g = hg_geometry(N, log2_T);
     const HgWs w = hg_ws_layout(const_cast<void*>(sorted_workspace), N, L, g);
-    const int B = 1 << g.log2B;
+    uint32_t* lvlmax = scratch ? (uint32_t*)scratch : w.fx;
+    SNF_REQUIRE(scratch || F == 2 || sparse_levels == 0,
+                "snf_hashgrid_bwd_presorted_adam: F = 8 reachable-row levels need a scratch buffer (the sort may be shared)");
+    SNF_REQUIRE(!hg_fx_on(F, L, N) || L <= (int)HG_FX_SCRATCH, "snf_hashgrid_bwd_presorted_adam: too many levels");
     hipStream_t st = (hipStream_t)stream;
-    static const uint32_t hg_long = getenv("SNF_HG_LONG") ? (uint32_t)atoi(getenv("SNF_HG_LONG")) : (uint32_t)HG_LONG;
-    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
     HgAdam a{};
-    a.p = param; a.m = exp_avg; a.v = exp_avg_sq;
-    a.b1 = beta1; a.b2 = beta2; a.step_size = (float)((double)lr / bc1); a.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
-    a.eps = eps; a.gs = grad_scale; a.from_level = fuse_from_level;
-    const int tblocks = ceil_div((long long)N * L, 256);
-    if (F == 2) {
-        if (!planar) hipLaunchKernelGGL(k_hg_stage_grad<2>, dim3(tblocks), dim3(256), 0, st, grad_out, N, L, ld_out, col_off, stage);
-        if (hg_fx_on(F, L, N)) {
-            (void)hipMemsetAsync(w.fx, 0, L * sizeof(uint32_t), st);
-            hipLaunchKernelGGL(k_hg_level_absmax<2>, dim3(hg_absmax_blocks(N, F), L), dim3(256), 0, st, stage, N, w.fx);
-            hipLaunchKernelGGL((k_hg_reduce_fx<2, true, 1>), dim3(B, L), dim3(HG_FX_T), 0, st, stage, N, log2_T, g.log2B, w.bstart,
-                               (const uint2*)w.records, grad_table, hg_xcd_from(n_run_levels, L, B), hg_merge_levels(n_run_levels), w.fx, a);
-        } else
-        hipLaunchKernelGGL((k_hg_reduce<2, true>), dim3(B, L), dim3(HG_RT), 0, st, stage, N, log2_T, g.log2B, w.bstart,
-                           (const uint2*)w.records, grad_table, hg_long, n_run_levels, a, hg_no_second());
-    } else {
-        if (!planar) hipLaunchKernelGGL(k_hg_stage_grad<8>, dim3(tblocks), dim3(256), 0, st, grad_out, N, L, ld_out, col_off, stage);
-        hipLaunchKernelGGL((k_hg_reduce<8, true>), dim3(B, L), dim3(HG_RT), 0, st, stage, N, log2_T, g.log2B, w.bstart,
-                           (const uint2*)w.records, grad_table, hg_long, n_run_levels, a, hg_no_second());
-    }
+    hg_fill_adam(a, param, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step, grad_scale, fuse_from_level);
+    if (!planar) hg_stage(st, F, grad_out, N, L, ld_out, col_off, stage);
+    hg_reduce_one(st, F, stage, N, L, log2_T, g, w, grad_table, n_run_levels, fuse_from_level < L, step_sparse, a,
+                  HgSparse{reach_rows, reach_start, sparse_levels}, lvlmax);
     SNF_LAUNCH_CHECK("snf_hashgrid_bwd_presorted_adam");
     return SNF_OK;
 }
 
-// The two F = 8 grids of a feature head (same samples, same table size, level-major gradients) in ONE reduce launch: one tail
-// instead of two and the two kinds of levels mixed on the CUs (alone: 427 us against 220 + 287 us, tools/microbench_hgadam.py).
+extern "C" int snf_hashgrid_bwd_presorted_adam(const float* grad_out, int N, int L, int F, int log2_T, int ld_out, int col_off,
+                                               int n_run_levels, float* grad_table, const void* sorted_workspace, float* stage,
+                                               int fuse_from_level, float* param, float* exp_avg, float* exp_avg_sq, float lr,
+                                               float beta1, float beta2, float eps, int step, float grad_scale,
+                                               snf_stream_t stream) {
+    SNF_REQUIRE(param && exp_avg && exp_avg_sq, "snf_hashgrid_bwd_presorted_adam: null pointer");
+    return snf_hashgrid_bwd_presorted_adam_sp(grad_out, N, L, F, log2_T, ld_out, col_off, n_run_levels, grad_table, sorted_workspace,
+                                              stage, fuse_from_level, param, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step,
+                                              grad_scale, nullptr, nullptr, 0, 0, 0, nullptr, stream);
+}
+
+// The two F = 8 grids of a feature head (same samples, same table size, level-major gradients): the bucket-wide levels of both in
+// ONE float-reduce launch (one tail instead of two), their reachable-row levels in k_hg_reduce_sparse launches in front of it.
 extern "C" int snf_hashgrid_bwd_presorted_adam_pair(const float* grad_out0, const float* grad_out1, int N, int L0, int L1, int log2_T,
                                                     float* grad_table0, float* grad_table1, const void* sorted_workspace0,
                                                     const void* sorted_workspace1, int fuse_from_level0, int fuse_from_level1,
                                                     float* param0, float* exp_avg0, float* exp_avg_sq0, float* param1,
-                                                    float* exp_avg1, float* exp_avg_sq1, const uint32_t* reachable0,
-                                                    const uint32_t* reachable1, float lr, float beta1, float beta2, float eps,
+                                                    float* exp_avg1, float* exp_avg_sq1, const uint32_t* reach_rows0,
+                                                    const uint32_t* reach_start0, int sparse_levels0, const uint32_t* reach_rows1,
+                                                    const uint32_t* reach_start1, int sparse_levels1, int sparse_max_rows,
+                                                    int sparse_step, void* scratch, float lr, float beta1, float beta2, float eps,
                                                     int step, float grad_scale, snf_stream_t stream) {
     SNF_REQUIRE(grad_out0 && grad_out1 && grad_table0 && grad_table1 && sorted_workspace0 && sorted_workspace1 && param0 && param1 &&
                     exp_avg0 && exp_avg1 && exp_avg_sq0 && exp_avg_sq1, "snf_hashgrid_bwd_presorted_adam_pair: null pointer");
     SNF_REQUIRE(N > 0 && L0 > 0 && L1 > 0 && L0 + L1 <= 65535 && N <= (1 << HG_SAMPLE_BITS) && fuse_from_level0 >= 0 &&
                     fuse_from_level0 <= L0 && fuse_from_level1 >= 0 && fuse_from_level1 <= L1 && step >= 1,
                 "snf_hashgrid_bwd_presorted_adam_pair: bad shape N=%d L=%d+%d or fuse levels / step", N, L0, L1);
+    SNF_REQUIRE(sparse_levels0 >= 0 && sparse_levels0 <= fuse_from_level0 && sparse_levels1 >= 0 && sparse_levels1 <= fuse_from_level1 &&
+                    sparse_levels0 + sparse_levels1 <= (int)HG_FX_SCRATCH &&
+                    (sparse_levels0 == 0 || (reach_rows0 && reach_start0)) && (sparse_levels1 == 0 || (reach_rows1 && reach_start1)) &&
+                    (sparse_levels0 + sparse_levels1 == 0 || (scratch && sparse_max_rows <= hg_sp_max_rows<8>())),
+                "snf_hashgrid_bwd_presorted_adam_pair: reachable-row levels %d / %d need their row lists, a scratch buffer and at most "
+                "%d rows per bucket (got %d)", sparse_levels0, sparse_levels1, hg_sp_max_rows<8>(), sparse_max_rows);
     SNF_REQUIRE((((uintptr_t)grad_out0 | (uintptr_t)grad_out1 | (uintptr_t)grad_table0 | (uintptr_t)grad_table1 | (uintptr_t)param0 |
-                  (uintptr_t)param1 | (uintptr_t)exp_avg0 | (uintptr_t)exp_avg1 | (uintptr_t)exp_avg_sq0 | (uintptr_t)exp_avg_sq1) & 15) == 0,
-                "snf_hashgrid_bwd_presorted_adam_pair: unaligned pointer");
+                  (uintptr_t)param1 | (uintptr_t)exp_avg0 | (uintptr_t)exp_avg1 | (uintptr_t)exp_avg_sq0 | (uintptr_t)exp_avg_sq1 |
+                  (uintptr_t)scratch) & 15) == 0, "snf_hashgrid_bwd_presorted_adam_pair: unaligned pointer");
     const HgGeom g = hg_geometry(N, log2_T);
     const HgWs w0 = hg_ws_layout(const_cast<void*>(sorted_workspace0), N, L0, g);
     const HgWs w1 = hg_ws_layout(const_cast<void*>(sorted_workspace1), N, L1, g);
     const int B = 1 << g.log2B;
+    hipStream_t st = (hipStream_t)stream;
     static const uint32_t hg_long = getenv("SNF_HG_LONG") ? (uint32_t)atoi(getenv("SNF_HG_LONG")) : (uint32_t)HG_LONG;
-    static const int interleave = getenv("SNF_HG_PAIR_INTERLEAVE") ? atoi(getenv("SNF_HG_PAIR_INTERLEAVE")) : 1;
-    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    const bool on0 = sparse_step != 0, on1 = sparse_step != 0;  // the reachable-row levels are stepped (else: gradients only)
     HgAdam a{};
-    a.p = param0; a.m = exp_avg0; a.v = exp_avg_sq0;
-    a.b1 = beta1; a.b2 = beta2; a.step_size = (float)((double)lr / bc1); a.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
-    a.eps = eps; a.gs = grad_scale; a.from_level = fuse_from_level0;
-    a.reach = fuse_from_level0 < L0 ? reachable0 : nullptr;  // (no level stepped: plain gradient accumulation everywhere)
+    hg_fill_adam(a, param0, exp_avg0, exp_avg_sq0, lr, beta1, beta2, eps, step, grad_scale, fuse_from_level0);
     HgSecond s2{};
     s2.gT = grad_out1; s2.bucket_start = w1.bstart; s2.records = (const uint2*)w1.records; s2.grad_table = grad_table1;
-    s2.adam = a;
-    s2.adam.p = param1; s2.adam.m = exp_avg1; s2.adam.v = exp_avg_sq1; s2.adam.from_level = fuse_from_level1;
-    s2.adam.reach = fuse_from_level1 < L1 ? reachable1 : nullptr;
-    s2.first_levels = L0;
-    s2.interleave = (interleave && L0 == L1) ? 1 : 0;
-    // SNF_HG_PAIR_PAD_LDS=<bytes> of unused dynamic LDS: 12288 leaves ONE workgroup per CU (a probe of CU sharing with the GEMMs
-    // of the other head's stream)
-    static const int pad_lds = getenv("SNF_HG_PAIR_PAD_LDS") ? atoi(getenv("SNF_HG_PAIR_PAD_LDS")) : 0;
-    if (fuse_from_level0 >= L0 && fuse_from_level1 >= L1)  // nothing to step: plain gradient accumulation for both tables
-        hipLaunchKernelGGL((k_hg_reduce<8, false>), dim3(B, L0 + L1), dim3(HG_RT), 0, (hipStream_t)stream, grad_out0, N, log2_T,
-                           g.log2B, w0.bstart, (const uint2*)w0.records, grad_table0, hg_long, 0, a, s2);
-    else
-        hipLaunchKernelGGL((k_hg_reduce<8, true>), dim3(B, L0 + L1), dim3(HG_RT), pad_lds, (hipStream_t)stream, grad_out0, N, log2_T,
-                           g.log2B, w0.bstart, (const uint2*)w0.records, grad_table0, hg_long, 0, a, s2);
+    hg_fill_adam(s2.adam, param1, exp_avg1, exp_avg_sq1, lr, beta1, beta2, eps, step, grad_scale, fuse_from_level1);
+    // ---- reachable-row levels: per table, fixed-point over compact rows (their largest |g| per level first)
+    uint32_t* lvlmax = (uint32_t*)scratch;
+    if (sparse_levels0 + sparse_levels1 > 0) (void)hipMemsetAsync(lvlmax, 0, (size_t)(sparse_levels0 + sparse_levels1) * sizeof(uint32_t), st);
+    if (sparse_levels0 > 0) {
+        hipLaunchKernelGGL(k_hg_level_absmax<8>, dim3(hg_absmax_blocks(N, 8), sparse_levels0), dim3(256), 0, st, grad_out0, N, lvlmax);
+        hg_launch_sparse<8>(st, grad_out0, N, log2_T, g, w0, grad_table0, HgSparse{reach_rows0, reach_start0, sparse_levels0}, lvlmax, on0, a);
+    }
+    if (sparse_levels1 > 0) {
+        hipLaunchKernelGGL(k_hg_level_absmax<8>, dim3(hg_absmax_blocks(N, 8), sparse_levels1), dim3(256), 0, st, grad_out1, N,
+                           lvlmax + sparse_levels0);
+        hg_launch_sparse<8>(st, grad_out1, N, log2_T, g, w1, grad_table1, HgSparse{reach_rows1, reach_start1, sparse_levels1},
+                            lvlmax + sparse_levels0, on1, s2.adam);
+    }
+    // ---- bucket-wide levels of both tables in one launch
+    const int r0 = L0 - sparse_levels0, r1 = L1 - sparse_levels1;
+    if (r0 + r1 > 0) {
+        static const int interleave = getenv("SNF_HG_PAIR_INTERLEAVE") ? atoi(getenv("SNF_HG_PAIR_INTERLEAVE")) : 1;
+        s2.first_levels = r0;
+        s2.interleave = (interleave && r0 == r1) ? 1 : 0;
+        s2.level0 = sparse_levels1;
+        const float* gfirst = grad_out0;
+        int lvl0 = sparse_levels0;
+        if (r0 == 0) {  // only the second table has bucket-wide levels: it becomes the launch's (single) table
+            a = s2.adam; gfirst = grad_out1; lvl0 = sparse_levels1;
+            s2 = hg_no_second();
+        } else if (r1 == 0) {
+            s2 = hg_no_second();
+        }
+        const HgWs& wf = (r0 == 0) ? w1 : w0;
+        float* gtf = (r0 == 0) ? grad_table1 : grad_table0;
+        if (fuse_from_level0 >= L0 && fuse_from_level1 >= L1)  // nothing bucket-wide to step: plain gradient accumulation
+            hipLaunchKernelGGL((k_hg_reduce<8, false>), dim3(B, r0 + r1), dim3(HG_RT), 0, st, gfirst, N, log2_T, g.log2B, wf.bstart,
+                               (const uint2*)wf.records, gtf, hg_long, 0, lvl0, a, s2);
+        else
+            hipLaunchKernelGGL((k_hg_reduce<8, true>), dim3(B, r0 + r1), dim3(HG_RT), 0, st, gfirst, N, log2_T, g.log2B, wf.bstart,
+                               (const uint2*)wf.records, gtf, hg_long, 0, lvl0, a, s2);
+    }
     SNF_LAUNCH_CHECK("snf_hashgrid_bwd_presorted_adam_pair");
     return SNF_OK;
 }
@@ -1409,9 +1670,9 @@ extern "C" int snf_hashgrid_bwd_sorted_ex(const float* u, const float* grad_out,
 }
 
 // The fixed-point reduce with a caller-provided scratch area (>= SNF_HG_FX_SCRATCH_BYTES, private to this launch), for F = 2
-// and F = 8.  The sorted workspace stays read-only here, so heads that SHARE a sort (same positions, same level geometry)
-// can run their backward passes concurrently on different streams.  fuse_from_level = L: no level is stepped (plain
-// gradient accumulation into grad_table).
+// and F = 8 (every level bucket-wide).  The sorted workspace stays read-only here, so heads that SHARE a sort (same positions,
+// same level geometry) can run their backward passes concurrently on different streams.  fuse_from_level = L: no level is stepped
+// (plain gradient accumulation into grad_table).
 extern "C" int snf_hashgrid_bwd_presorted_adam_fx(const float* grad_out, int N, int L, int F, int log2_T, int ld_out, int col_off,
                                                   int n_run_levels, float* grad_table, const void* sorted_workspace,
                                                   float* stage, int fuse_from_level, float* param, float* exp_avg,
@@ -1434,24 +1695,19 @@ extern "C" int snf_hashgrid_bwd_presorted_adam_fx(const float* grad_out, int N, 
     const HgWs w = hg_ws_layout(const_cast<void*>(sorted_workspace), N, L, g);
     const int B = 1 << g.log2B;
     hipStream_t st = (hipStream_t)stream;
-    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
     HgAdam a{};
-    a.p = param; a.m = exp_avg; a.v = exp_avg_sq;
-    a.b1 = beta1; a.b2 = beta2; a.step_size = (float)((double)lr / bc1); a.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
-    a.eps = eps; a.gs = grad_scale; a.from_level = fuse_from_level;
+    hg_fill_adam(a, param, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step, grad_scale, fuse_from_level);
     uint32_t* lvlmax = (uint32_t*)scratch;
-    const int tblocks = ceil_div((long long)N * L, 256);
     (void)hipMemsetAsync(lvlmax, 0, L * sizeof(uint32_t), st);
+    if (!planar) hg_stage(st, F, grad_out, N, L, ld_out, col_off, stage);
     if (F == 2) {
-        if (!planar) hipLaunchKernelGGL(k_hg_stage_grad<2>, dim3(tblocks), dim3(256), 0, st, grad_out, N, L, ld_out, col_off, stage);
         hipLaunchKernelGGL(k_hg_level_absmax<2>, dim3(hg_absmax_blocks(N, F), L), dim3(256), 0, st, stage, N, lvlmax);
         hipLaunchKernelGGL((k_hg_reduce_fx<2, true, 1>), dim3(B, L), dim3(HG_FX_T), 0, st, stage, N, log2_T, g.log2B, w.bstart,
-                           (const uint2*)w.records, grad_table, hg_xcd_from(n_run_levels, L, B), hg_merge_levels(n_run_levels), lvlmax, a);
+                           (const uint2*)w.records, grad_table, hg_xcd_from(n_run_levels, L, B), hg_merge_levels(n_run_levels), 0, lvlmax, a);
     } else {
-        if (!planar) hipLaunchKernelGGL(k_hg_stage_grad<8>, dim3(tblocks), dim3(256), 0, st, grad_out, N, L, ld_out, col_off, stage);
         hipLaunchKernelGGL(k_hg_level_absmax<8>, dim3(hg_absmax_blocks(N, F), L), dim3(256), 0, st, stage, N, lvlmax);
         hipLaunchKernelGGL((k_hg_reduce_fx<8, true, 2>), dim3(B * 2, L), dim3(HG_FX_T), 0, st, stage, N, log2_T, g.log2B,
-                           w.bstart, (const uint2*)w.records, grad_table, L, 0, lvlmax, a);
+                           w.bstart, (const uint2*)w.records, grad_table, L, 0, 0, lvlmax, a);
     }
     SNF_LAUNCH_CHECK("snf_hashgrid_bwd_presorted_adam_fx");
     return SNF_OK;

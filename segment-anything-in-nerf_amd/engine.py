@@ -299,7 +299,7 @@ class Optimizers:
                 out.extend(("dense", x0, x1) for x0, x1 in pieces)
             else:
                 if any(d0 <= s0 and s1 <= d1 for d0, d1 in done):
-                    continue  # (the backward stepped these reachable rows itself: snf_hashgrid_bwd_presorted_adam_pair with bitmaps)
+                    continue  # (the backward stepped these reachable rows itself: k_hg_reduce_sparse inside snf_hashgrid_bwd_presorted_adam_sp / _pair)
                 i0, i1 = self._cut(k, seg, s0, s1)  # rows are sorted: the slice of the list inside [s0, s1)
                 if i1 > i0:
                     out.append(("rows", seg[3][i0:i1], seg[4]))

@@ -67,9 +67,9 @@ FEATURE_SORTS_ON_HEAD_STREAM = _os.environ.get("SNF_FEAT_SORT_SIDE", "1") == "1"
 # weight gradient -- on R rows instead of R*K.  Same real-number result, fp32 rounding in a different order (1e-7).
 MEAN_BEFORE_LAST_LAYER = _os.environ.get("SNF_MEAN_BEFORE_LAST", "1") == "1"
 ROWS_OPERAND = _os.environ.get("SNF_ROWS_OPERAND", "1") == "1"  # ... and its gradient broadcast formed inside the GEMM loaders
-# reachable rows of the heads' coarse levels stepped inside that launch too (bitmap): -0.14 GB and no row-Adam pass for the head tables,
-# but the launch itself 0.41 -> 0.44 ms alone and the step unchanged -- opt-in
-SPARSE_ADAM_IN_REDUCE = _os.environ.get("SNF_SPARSE_ADAM_IN_REDUCE", "0") == "1"
+# The reachable-row (coarse) levels of every hash table are reduced over compact row indices and stepped inside the table backward
+# (k_hg_reduce_sparse, round 3): no gradient is written for them and no snf_adam_step_rows pass follows.  0: round-2 behaviour.
+SPARSE_LEVELS = _os.environ.get("SNF_HG_SPARSE_LEVELS", "1") == "1"
 PAIR_GRID_BWD = _os.environ.get("SNF_PAIR_GRID_BWD", "1") == "1"  # both feature grids of a head in one table-backward launch
 FUSED_MEAN_EPILOGUE = _os.environ.get("SNF_FUSED_MEAN", "1") == "1"  # ... and the mean itself in the hidden layer's GEMM epilogue
 # Without feature heads the step is ONE dependency chain on the main stream.  Its head -- sampling, the proposal network, the
@@ -247,6 +247,24 @@ class StepProgram:
             tag = f"F{F}L{L}tp"
         nrun = ops.hashgrid_run_levels(sc) if F == 2 else 0
         fuse = with_opt and self.opt.fuse_table_adam and n_sparse < L
+        sp = self._sparse_lists(enc, N, n_sparse) if (run is None and not (F == 8 and FX_F8)) else None
+        if sp is not None:
+            # reachable-row levels through the compact fixed-point reduce; with the optimizer on this launch steps the WHOLE table
+            step_it = bool(with_opt and self.opt.fuse_table_adam)
+            oc = self.opt.config[group]["optimizer"]
+            ns, rows, start, longest = sp
+            scratch = self.buf(f"sp_scratch_{id(enc)}", (64,), torch.int32)
+            n_tab = (L << T) * F
+            fused = ((L - ns) << T) * F if step_it else 0
+            reach_params = int(rows.numel()) * F if step_it else 0
+            self._k(st, "snf_hashgrid_bwd_presorted_adam_sp", g, N, L, F, T, ld, col, nrun, gbuf, sorted_ws, stage, ns if step_it else L,
+                    p if step_it else None, m if step_it else None, v if step_it else None, 0.0, float(oc.betas[0]), float(oc.betas[1]),
+                    float(oc.eps), 1, float(grad_scale), rows, start, ns, longest, 1 if step_it else 0, scratch, tag=tag,
+                    units=float(N) * 8 * F * 4 * (L + (0 if step_it else L)) + 24.0 * (fused + reach_params),
+                    dyn={("lr", group): 15, ("t", group): 19})
+            if step_it:
+                done.append((fused_range[1] - n_tab, fused_range[1]))  # the whole table
+            return
         if F == 8 and FX_F8 and N % 2 == 0 and L <= 64:
             # fixed-point reduce (order-independent sums, no in-bucket sort); scratch private to this launch: the sorted
             # workspace is shared by the SAM and ClipSeg heads, whose backward passes run concurrently
@@ -305,6 +323,19 @@ class StepProgram:
                 self._keep.append(rows)
                 self._k(st, "snf_adam_step_rows", a.param, a.grad, a.exp_avg, a.exp_avg_sq, rows, rows.numel(), int(F), 0.0,
                         b1, b2, eps, 1, 1.0, 1, units=32.0 * rows.numel() * F, dyn={("lr", group): 7, ("t", group): 11})
+
+    def _sparse_lists(self, enc, N: int, n_sparse: int):
+        """(levels, rows, list offsets, longest list) of a table's reachable-row levels for a backward over N samples, or None
+        when the table has none / the switch is off / a bucket's list is too long for the compact reduce."""
+        if not (SPARSE_LEVELS and n_sparse > 0 and self.opt.skip_unreachable_rows):
+            return None
+        F, T = enc.n_features_per_level, enc.log2_hashmap_size
+        log2B = int(self.lib.snf_hashgrid_bucket_bits(int(N), int(T)))
+        ns, rows, start, longest = enc.reach_lists(log2B, int(self.lib.snf_hashgrid_sparse_max_rows(F)))
+        if ns != n_sparse:  # (all or nothing: the optimizer plan treats the table's leading n_sparse levels as one row list)
+            return None
+        self._keep.extend((rows, start))
+        return ns, rows, start, longest
 
     def _sort_ws(self, name: str, N: int, L: int, T: int, parity: Optional[int] = None) -> Tuple[torch.Tensor, int]:
         nbytes = int(self.lib.snf_hashgrid_bwd_workspace_bytes(N, L, T))
@@ -795,29 +826,32 @@ class StepProgram:
                 tabs = [self._table_adam(e, "sam_field") for e in encs]
                 fuse = fuse_local and opt.fuse_table_adam
                 frm = [t[4] if fuse else e.n_levels for t, e in zip(tabs, encs)]
-                # reachable-row bitmaps: the launch then steps the rows of the levels below `frm` as well -- the whole table
-                reach = [None, None]
-                if fuse and SPARSE_ADAM_IN_REDUCE and opt.skip_unreachable_rows:
-                    for i, (t, e) in enumerate(zip(tabs, encs)):
-                        if 0 < t[4] < e.n_levels:
-                            ns, bits = e.reachable_bits()
-                            assert ns == t[4], (ns, t[4])
-                            reach[i] = bits
-                            self._keep.append(bits)
-                # algorithmic bytes: every corner contribution read once (+ written back as a gradient on levels left to the caller's
-                # optimizer); p / exp_avg / exp_avg_sq read + written for every stepped parameter (dense levels, reachable rows)
-                units = sum(float(NK) * 8 * 8 * 4 * (e.n_levels + (0 if r is not None else f)) + 24.0 * (((e.n_levels - f) << T) * 8)
-                            + (24.0 * 8 * int(e.active_rows()[1].numel()) if r is not None else 0.0)
-                            for e, f, r in zip(encs, frm, reach))
+                # reachable-row levels of either table: compact fixed-point reduce in front of the paired launch, stepped there
+                # when the optimizer is on -- the launch then steps the whole table
+                sps = [self._sparse_lists(e, NK, t[4]) for t, e in zip(tabs, encs)]
+                nsp = [sp[0] if sp is not None else 0 for sp in sps]
+                longest = max([sp[3] for sp in sps if sp is not None] or [0])
+                scratch = self.buf(f"{hname}_sp_scratch", (64,), torch.int32)
+                # algorithmic bytes: every corner contribution read once (+ written back as a gradient on the levels left to the
+                # caller's optimizer); p / exp_avg / exp_avg_sq read + written for every stepped parameter (dense levels, reachable rows)
+                units = 0.0
+                for e, t, f, sp in zip(encs, tabs, frm, sps):
+                    left = (f - (sp[0] if sp is not None else 0)) if fuse else e.n_levels  # levels whose gradient is written back
+                    units += float(NK) * 8 * 8 * 4 * (e.n_levels + left) + 24.0 * (((e.n_levels - f) << T) * 8)
+                    if fuse and sp is not None:
+                        units += 24.0 * 8 * int(sp[1].numel())
                 self._k(st, "snf_hashgrid_bwd_presorted_adam_pair", gy, self._off(gy, e0.n_levels * 8 * NK * 4), NK, e0.n_levels,
                         e1.n_levels, T, tabs[0][1], tabs[1][1], geo_ws[ops._geometry_key(e0.scalings, e0.n_levels, T)],
                         geo_ws[ops._geometry_key(e1.scalings, e1.n_levels, T)], frm[0], frm[1], tabs[0][0], tabs[0][2], tabs[0][3],
-                        tabs[1][0], tabs[1][2], tabs[1][3], reach[0], reach[1], 0.0, float(oc.betas[0]), float(oc.betas[1]),
+                        tabs[1][0], tabs[1][2], tabs[1][3],
+                        sps[0][1] if sps[0] is not None else None, sps[0][2] if sps[0] is not None else None, nsp[0],
+                        sps[1][1] if sps[1] is not None else None, sps[1][2] if sps[1] is not None else None, nsp[1], longest,
+                        1 if fuse else 0, scratch, 0.0, float(oc.betas[0]), float(oc.betas[1]),
                         float(oc.eps), 1, 1.0, tag=f"F8L{e0.n_levels}+{e1.n_levels}", units=units,
-                        dyn={("lr", "sam_field"): 20, ("t", "sam_field"): 24})
+                        dyn={("lr", "sam_field"): 27, ("t", "sam_field"): 31})
                 if fuse:
-                    for t, e, f, r in zip(tabs, encs, frm, reach):
-                        if r is not None:
+                    for t, e, f, sp in zip(tabs, encs, frm, sps):
+                        if sp is not None:
                             n_tab = e.params.numel()
                             done.append((t[5][1] - n_tab, t[5][1]))  # the whole table
                         elif f < e.n_levels:

@@ -110,21 +110,26 @@ class Encoding(nn.Module):
             return 0, torch.empty((0,), device=dev, dtype=torch.int64)
         return n_sparse, torch.cat(rows)
 
-    def reachable_bits(self) -> Tuple[int, torch.Tensor]:
-        """(n_sparse, bitmap): `active_rows` as one bit per row of the first n_sparse levels (int32 words, bit (l << T) + row),
-        what snf_hashgrid_bwd_presorted_adam_pair takes to step the reachable rows of those levels itself."""
-        cached = self.__dict__.get("_reach_bits")
-        if cached is None:
+    def reach_lists(self, log2B: int, max_rows: int):
+        """`active_rows` grouped by the (level, bucket) workgroups of the table backward's reduce pass (B = 2^log2B buckets of
+        2^(T - log2B) consecutive rows per level): (n_sparse, rows int32 [(level << T) + row, ascending], start int32
+        [n_sparse * B + 1], longest list).  What snf_hashgrid_bwd_presorted_adam_sp / _pair take to reduce AND step the
+        reachable-row levels over compact row indices.  n_sparse = 0 (and no lists) when a bucket's list would exceed `max_rows`."""
+        cache = self.__dict__.setdefault("_reach_lists", {})
+        key = (int(log2B), int(max_rows))
+        if key not in cache:
             n_sparse, rows = self.active_rows()
-            words = torch.zeros((max(1, (n_sparse << self.log2_hashmap_size) // 32),), device=self.params.device, dtype=torch.int32)
-            if n_sparse:
-                vals = torch.bitwise_left_shift(torch.ones_like(rows), rows & 31)  # distinct bits: the sum is the OR
-                acc = torch.zeros((words.numel(),), device=rows.device, dtype=torch.int64)
-                acc.index_put_((rows >> 5,), vals, accumulate=True)
-                words = (acc & 0xFFFFFFFF).to(torch.int64)
-                words = torch.where(words >= (1 << 31), words - (1 << 32), words).to(torch.int32)
-            cached = self.__dict__["_reach_bits"] = (n_sparse, words.contiguous())
-        return cached
+            T = self.log2_hashmap_size
+            out = (0, None, None, 0)
+            if n_sparse and T >= log2B:
+                nb = n_sparse << log2B
+                bucket = rows >> (T - log2B)  # = level * B + bucket: ascending with the rows
+                start = torch.searchsorted(bucket, torch.arange(nb + 1, device=rows.device, dtype=torch.int64))
+                longest = int((start[1:] - start[:-1]).max())
+                if longest <= max_rows:
+                    out = (n_sparse, rows.to(torch.int32).contiguous(), start.to(torch.int32).contiguous(), longest)
+            cache[key] = out
+        return cache[key]
 
     @property
     def spec(self) -> Tuple[torch.Tensor, int, int, int]:

@@ -148,15 +148,16 @@ def test_pair_launch_at_full_table_size():
     assert a["frm"] > 0 and b["frm"] == 0  # the 16 -> 128 grid has reachable-row levels, the 128 -> 512 grid has none
     m._launch("snf_hashgrid_bwd_presorted_adam_pair", m._p(a["gy"]), m._p(b["gy"]), N, a["L"], b["L"], a["T"], m._p(a["gt"]),
               m._p(b["gt"]), m._p(a["ws"]), m._p(b["ws"]), a["frm"], b["frm"], m._p(a["p"]), m._p(a["m"]), m._p(a["v"]),
-              m._p(b["p"]), m._p(b["m"]), m._p(b["v"]), None, None, 1e-2, 0.9, 0.999, 1e-15, 1, 1.0, s)
+              m._p(b["p"]), m._p(b["m"]), m._p(b["v"]), None, None, 0, None, None, 0, 0, 0, None, 1e-2, 0.9, 0.999, 1e-15, 1, 1.0, s)
     torch.cuda.synchronize()
     for la, name in zip(launch, res):
         g_ref, ns, table = res[name]
         gmax = float(g_ref.abs().max())
         cut = (ns << la["T"]) * 8
         # levels below `frm`: the gradient is left in the table-gradient buffer, parameters untouched
-        assert float((la["gt"].cpu()[:cut] - g_ref[:cut]).abs().max()) <= 2e-5 * gmax
-        assert torch.equal(la["p"].cpu()[:cut], table[:cut])
+        if cut:
+            assert float((la["gt"].cpu()[:cut] - g_ref[:cut]).abs().max()) <= 2e-5 * gmax
+            assert torch.equal(la["p"].cpu()[:cut], table[:cut])
         # fused levels: exp_avg = 0.1 g
         assert float((la["m"].cpu()[cut:] - 0.1 * g_ref[cut:]).abs().max()) <= 2e-5 * 0.1 * gmax
         assert float(la["gt"][cut:].abs().max()) == 0.0

@@ -638,7 +638,7 @@ def test_both_grids_of_a_head_in_one_table_backward_launch(L0, L1, from0, from1)
         got.append((g["p"].clone(), g["m"].clone(), g["v"].clone(), torch.zeros((g["n"],), device="cuda")))
     m._launch("snf_hashgrid_bwd_presorted_adam_pair", m._p(grids[0]["gy"]), m._p(grids[1]["gy"]), N, L0, L1, T, m._p(got[0][3]),
               m._p(got[1][3]), m._p(grids[0]["ws"]), m._p(grids[1]["ws"]), from0, from1, m._p(got[0][0]), m._p(got[0][1]),
-              m._p(got[0][2]), m._p(got[1][0]), m._p(got[1][1]), m._p(got[1][2]), None, None, *hyper, st)
+              m._p(got[0][2]), m._p(got[1][0]), m._p(got[1][1]), m._p(got[1][2]), None, None, 0, None, None, 0, 0, 0, None, *hyper, st)
     for gi in range(2):
         if (from0, from1)[gi] < grids[gi]["L"]:
             assert float((ref[gi][0] - grids[gi]["p"]).abs().max()) > 1e-3  # the step moved something
@@ -647,66 +647,143 @@ def test_both_grids_of_a_head_in_one_table_backward_launch(L0, L1, from0, from1)
             assert float((g_ - r).abs().max()) <= tol * max(1e-3, float(r.abs().max())), (gi, i)
 
 
-def test_pair_launch_steps_the_reachable_rows_of_the_coarse_levels_itself():
-    """snf_hashgrid_bwd_presorted_adam_pair with reachable-row bitmaps: the levels below fuse_from_level are stepped inside the
-    launch on exactly the rows of the bitmap (Encoding.reachable_bits), the others are left alone -- against the launch without
-    bitmaps followed by snf_adam_step_rows on the same rows.  Gradient buffers end up zero either way."""
-    m = ops()
+def _reach_lists(m, enc, N):
+    F, T = enc.n_features_per_level, enc.log2_hashmap_size
+    log2B = int(m._L().snf_hashgrid_bucket_bits(N, T))
+    return enc.reach_lists(log2B, int(m._L().snf_hashgrid_sparse_max_rows(F)))
+
+
+def _coarse_encoding(F, L, T, lo, hi):
     from samnerf_amd import tcnn_compat
-    T, N, F, L = 14, 30000, 8, 6
-    gen = torch.Generator(device="cuda").manual_seed(5)
-    u = torch.rand((N, 3), device="cuda", generator=gen)
+    return tcnn_compat.Encoding(3, {"otype": "HashGrid", "n_levels": L, "n_features_per_level": F, "log2_hashmap_size": T,
+                                    "base_resolution": lo, "per_level_scale": (hi / lo) ** (1.0 / (L - 1))}, device="cuda")
+
+
+def _ray_points(N, gen):
+    """N points on N/64 rays: consecutive samples share coarse cells, like the samples of a train step."""
+    R = N // 64
+    o = torch.rand((R, 1, 3), device="cuda", generator=gen)
+    d = torch.randn((R, 1, 3), device="cuda", generator=gen) * 0.3
+    t = torch.linspace(0, 1, 64, device="cuda").view(1, 64, 1)
+    return (o + d * t).clamp(0.0, 1.0).reshape(R * 64, 3).contiguous()
+
+
+@pytest.mark.parametrize("F,L,T,lo,hi,N,step_it", [(8, 6, 14, 4, 20, 30016, True), (8, 6, 14, 4, 20, 30016, False),
+                                                   (2, 6, 15, 4, 24, 120000, True), (2, 5, 12, 2, 8, 8192, True),
+                                                   (8, 12, 19, 16, 128, 65536, True)])
+def test_reachable_row_levels_reduced_over_compact_rows(F, L, T, lo, hi, N, step_it):
+    """snf_hashgrid_bwd_presorted_adam_sp with the reachable-row lists (k_hg_reduce_sparse: fixed-point sums over compact row
+    indices, replicated accumulators, Adam on exactly the listed rows) against the launch without lists followed by
+    snf_adam_step_rows on the same rows: parameters, both moments, gradient buffers.  step_it = False: the levels only add their sums
+    to the gradient table.  The last case is the 16 -> 128 feature grid at full size with the sample count of the bench step."""
+    m = ops()
+    gen = torch.Generator(device="cuda").manual_seed(F * 100 + L)
+    e = _coarse_encoding(F, L, T, lo, hi)
+    u = _ray_points(N, gen)
+    ns, rows, start, longest = _reach_lists(m, e, N)
+    n_sparse, rows64 = e.active_rows()
+    assert ns == n_sparse and ns > 0 and longest > 0
+    assert torch.equal(rows.long(), rows64)
+    n = (L << T) * F
     st = m._stream()
-    encs = [tcnn_compat.Encoding(3, {"otype": "HashGrid", "n_levels": L, "n_features_per_level": F, "log2_hashmap_size": T,
-                                     "base_resolution": lo, "per_level_scale": (hi / lo) ** (1.0 / (L - 1))}, device="cuda")
-            for lo, hi in ((4, 20), (16, 64))]
+    nbytes = int(m._L().snf_hashgrid_bwd_workspace_bytes(N, L, T))
+    ws = torch.empty(((nbytes + 3) // 4,), device="cuda", dtype=torch.int32)
+    m._launch("snf_hashgrid_sort", m._p(u), m._p(e.scalings), N, L, T, m._p(ws), nbytes, st)
+    p0 = torch.rand((n,), device="cuda", generator=gen) - 0.5
+    m0 = (torch.rand((n,), device="cuda", generator=gen) - 0.5) * 1e-3
+    v0 = torch.rand((n,), device="cuda", generator=gen) * 1e-6
+    gy = torch.randn((L * N * F,), device="cuda", generator=gen) * 1e-2  # level-major staged gradient
+    hyper = (1e-2, 0.9, 0.999, 1e-15, 3, 0.5)
+    nrun = m.hashgrid_run_levels(e.scalings) if F == 2 else 0
+    scratch = torch.zeros((64,), device="cuda", dtype=torch.int32)
+    res = {}
+    for with_lists in (False, True):
+        p, mm, vv, gt = p0.clone(), m0.clone(), v0.clone(), torch.zeros((n,), device="cuda")
+        frm = ns if step_it else L
+        if with_lists:
+            m._launch("snf_hashgrid_bwd_presorted_adam_sp", m._p(gy), N, L, F, T, 0, 0, nrun, m._p(gt), m._p(ws), None, frm,
+                      m._p(p), m._p(mm), m._p(vv), *hyper, m._p(rows), m._p(start), ns, longest, 1 if step_it else 0, m._p(scratch), st)
+        else:
+            m._launch("snf_hashgrid_bwd_presorted_adam", m._p(gy), N, L, F, T, 0, 0, nrun, m._p(gt), m._p(ws), None, frm,
+                      m._p(p), m._p(mm), m._p(vv), *hyper, st)
+            if step_it:
+                offs = (rows64 * F).to(torch.int32).contiguous()
+                m.adam_step_rows_(p, gt, mm, vv, offs, F, *hyper, True)
+        torch.cuda.synchronize()
+        res[with_lists] = (p, mm, vv, gt)
+    if step_it:
+        assert float((res[False][0] - p0).abs().max()) > 1e-3  # the step moved something
+        for i, tol in ((0, 2e-6), (1, 1e-6), (2, 1e-6)):
+            r, g_ = res[False][i], res[True][i]
+            assert float((g_ - r).abs().max()) <= tol * max(1e-3, float(r.abs().max())), i
+        assert float(res[True][3].abs().max()) == 0.0 and float(res[False][3].abs().max()) == 0.0
+        # rows outside the lists did not move
+        sparse_elems = (ns << T) * F
+        untouched = torch.ones((ns << T,), dtype=torch.bool, device="cuda")
+        untouched[rows64] = False
+        assert torch.equal(res[True][0][:sparse_elems].view(-1, F)[untouched], p0[:sparse_elems].view(-1, F)[untouched])
+    else:
+        for i in range(3):
+            assert torch.equal(res[True][i], res[False][i]) and torch.equal(res[True][i], (p0, m0, v0)[i])
+        scale = float(res[False][3].abs().max())
+        assert scale > 0 and float((res[True][3] - res[False][3]).abs().max()) <= 1e-5 * scale
+    # the fixed-point sums are order-independent: a second run gives the same bits
+    p, mm, vv, gt = p0.clone(), m0.clone(), v0.clone(), torch.zeros((n,), device="cuda")
+    m._launch("snf_hashgrid_bwd_presorted_adam_sp", m._p(gy), N, L, F, T, 0, 0, nrun, m._p(gt), m._p(ws), None, ns if step_it else L,
+              m._p(p), m._p(mm), m._p(vv), *hyper, m._p(rows), m._p(start), ns, longest, 1 if step_it else 0, m._p(scratch), st)
+    torch.cuda.synchronize()
+    sparse_elems = (ns << T) * F
+    assert torch.equal(mm[:sparse_elems], res[True][1][:sparse_elems]) and torch.equal(gt[:sparse_elems], res[True][3][:sparse_elems])
+
+
+def test_pair_launch_with_reachable_row_levels():
+    """snf_hashgrid_bwd_presorted_adam_pair with the reachable-row lists of the coarse grid: those levels are reduced and stepped by
+    k_hg_reduce_sparse in front of the paired launch, which covers the remaining levels of both tables -- against the launch without
+    lists followed by snf_adam_step_rows.  Gradient buffers end up zero either way."""
+    m = ops()
+    T, N, F, L = 14, 30016, 8, 6
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    u = _ray_points(N, gen)
+    st = m._stream()
+    encs = [_coarse_encoding(F, L, T, lo, hi) for lo, hi in ((4, 20), (16, 64))]
     grids = []
     for e in encs:
-        n_sparse, rows = e.active_rows()
-        ns2, bits = e.reachable_bits()
-        assert ns2 == n_sparse
-        # the bitmap is the row list
-        chk = torch.zeros((n_sparse << T,), dtype=torch.bool, device="cuda")
-        chk[rows] = True
-        words = bits.to(torch.int64) & 0xFFFFFFFF
-        unpacked = ((words.view(-1, 1) >> torch.arange(32, device="cuda").view(1, 32)) & 1).bool().view(-1)[:n_sparse << T]
-        assert torch.equal(unpacked, chk)
+        ns, rows, start, longest = _reach_lists(m, e, N)
+        n_sparse, rows64 = e.active_rows()
+        assert ns == n_sparse
         n = (L << T) * F
         nbytes = int(m._L().snf_hashgrid_bwd_workspace_bytes(N, L, T))
         ws = torch.empty(((nbytes + 3) // 4,), device="cuda", dtype=torch.int32)
         m._launch("snf_hashgrid_sort", m._p(u), m._p(e.scalings), N, L, T, m._p(ws), nbytes, st)
-        grids.append(dict(ws=ws, n=n, ns=n_sparse, rows=rows, bits=bits, p=torch.rand((n,), device="cuda", generator=gen) - 0.5,
+        grids.append(dict(ws=ws, n=n, ns=ns, rows=rows, start=start, longest=longest, rows64=rows64,
+                          p=torch.rand((n,), device="cuda", generator=gen) - 0.5,
                           m=(torch.rand((n,), device="cuda", generator=gen) - 0.5) * 1e-3,
                           v=torch.rand((n,), device="cuda", generator=gen) * 1e-6,
                           gy=torch.randn((L * N * F,), device="cuda", generator=gen) * 1e-2))
     assert grids[0]["ns"] > 0  # the coarse grid has reachable-row levels
     hyper = (1e-2, 0.9, 0.999, 1e-15, 3, 0.5)
+    scratch = torch.zeros((64,), device="cuda", dtype=torch.int32)
     res = {}
-    for with_bits in (False, True):
+    for with_lists in (False, True):
         st8 = [(g["p"].clone(), g["m"].clone(), g["v"].clone(), torch.zeros((g["n"],), device="cuda")) for g in grids]
-        bits = [g["bits"] if (with_bits and 0 < g["ns"] < L) else None for g in grids]
+        lists = [((m._p(g["rows"]), m._p(g["start"]), g["ns"]) if (with_lists and g["ns"] > 0) else (None, None, 0)) for g in grids]
+        longest = max(g["longest"] for g in grids) if with_lists else 0
         m._launch("snf_hashgrid_bwd_presorted_adam_pair", m._p(grids[0]["gy"]), m._p(grids[1]["gy"]), N, L, L, T, m._p(st8[0][3]),
                   m._p(st8[1][3]), m._p(grids[0]["ws"]), m._p(grids[1]["ws"]), grids[0]["ns"], grids[1]["ns"], m._p(st8[0][0]),
                   m._p(st8[0][1]), m._p(st8[0][2]), m._p(st8[1][0]), m._p(st8[1][1]), m._p(st8[1][2]),
-                  None if bits[0] is None else m._p(bits[0]), None if bits[1] is None else m._p(bits[1]), *hyper, st)
-        if not with_bits:
+                  *lists[0], *lists[1], longest, 1 if with_lists else 0, m._p(scratch), *hyper, st)
+        if not with_lists:
             for g, (p, mm, vv, gt) in zip(grids, st8):
                 if g["ns"]:
-                    offs = (g["rows"] * F).to(torch.int32).contiguous()
+                    offs = (g["rows64"] * F).to(torch.int32).contiguous()
                     m.adam_step_rows_(p, gt, mm, vv, offs, F, *hyper, True)
         torch.cuda.synchronize()
-        res[with_bits] = st8
+        res[with_lists] = st8
     for gi in range(2):
         for i, tol in ((0, 2e-6), (1, 1e-6), (2, 1e-6)):
             r, g_ = res[False][gi][i], res[True][gi][i]
             assert float((g_ - r).abs().max()) <= tol * max(1e-3, float(r.abs().max())), (gi, i)
         assert float(res[True][gi][3].abs().max()) == 0.0 and float(res[False][gi][3].abs().max()) == 0.0
-    # rows outside the bitmap did not move
-    g0 = grids[0]
-    sparse_elems = (g0["ns"] << T) * F
-    untouched = torch.ones((g0["ns"] << T,), dtype=torch.bool, device="cuda")
-    untouched[g0["rows"]] = False
-    assert torch.equal(res[True][0][0][:sparse_elems].view(-1, F)[untouched], g0["p"][:sparse_elems].view(-1, F)[untouched])
 
 
 # ---------------------------------------------------------------------------------------------

@@ -79,7 +79,26 @@ for name in os.environ.get("CASES", "f8b,f8a,f2,f2p").split(","):
     fx8 = F == 8 and os.environ.get("FX8") == "1"  # the fixed-point reduce for an F = 8 grid (snf_hashgrid_bwd_presorted_adam_fx)
     scratch = torch.zeros((64,), device="cuda", dtype=torch.int32)
 
+    sp = os.environ.get("SP") == "1"  # reachable-row levels over compact rows (snf_hashgrid_bwd_presorted_adam_sp): the WHOLE table is stepped
+    rows_adam = os.environ.get("ROWS_ADAM") == "1"  # ... the round-2 equivalent: + snf_adam_step_rows on the reachable rows
+    if sp or rows_adam:
+        log2B = int(lib.snf_hashgrid_bucket_bits(N, T))
+        ns, rows, start, longest = enc.reach_lists(log2B, int(lib.snf_hashgrid_sparse_max_rows(F)))
+        assert ns == n_sparse, (ns, n_sparse)
+        offs = (rows.long() * F).to(torch.int32).contiguous() if ns else None
+
     def launch(step):
+        if sp and n_sparse:
+            ops._launch("snf_hashgrid_bwd_presorted_adam_sp", ops._p(gy), N, L, F, T, ld, 0, nrun, ops._p(g), ops._p(ws),
+                        None if planar else ops._p(stage), n_sparse, ops._p(p), ops._p(m), ops._p(v), 5e-4, 0.9, 0.999, 1e-15, step,
+                        1.0, ops._p(rows), ops._p(start), ns, longest, 1, ops._p(scratch), st)
+            return
+        if rows_adam and n_sparse:
+            ops._launch("snf_hashgrid_bwd_presorted_adam", ops._p(gy), N, L, F, T, ld, 0, nrun, ops._p(g), ops._p(ws),
+                        None if planar else ops._p(stage), n_sparse, ops._p(p), ops._p(m), ops._p(v), 5e-4, 0.9, 0.999, 1e-15, step,
+                        1.0, st)
+            ops.adam_step_rows_(p, g, m, v, offs, F, 5e-4, 0.9, 0.999, 1e-15, step, 1.0, True)
+            return
         if fx8:
             ops._launch("snf_hashgrid_bwd_presorted_adam_fx", ops._p(gy), N, L, F, T, ld, 0, nrun, ops._p(g), ops._p(ws),
                         None if planar else ops._p(stage), n_sparse, ops._p(p), ops._p(m), ops._p(v), 5e-4, 0.9, 0.999, 1e-15, step,
