@@ -298,11 +298,15 @@ class Optimizers:
                     pieces = [q for x0, x1 in pieces for q in ((x0, min(x1, d0)), (max(x0, d1), x1)) if q[1] > q[0]]
                 out.extend(("dense", x0, x1) for x0, x1 in pieces)
             else:
-                if any(d0 <= s0 and s1 <= d1 for d0, d1 in done):
-                    continue  # (the backward stepped these reachable rows itself: k_hg_reduce_sparse inside snf_hashgrid_bwd_presorted_adam_sp / _pair)
-                i0, i1 = self._cut(k, seg, s0, s1)  # rows are sorted: the slice of the list inside [s0, s1)
-                if i1 > i0:
-                    out.append(("rows", seg[3][i0:i1], seg[4]))
+                # (reachable rows the backward stepped itself -- k_hg_reduce_sparse inside snf_hashgrid_bwd_presorted_adam_sp / _pair,
+                #  whole leading levels -- are left out; the rows are sorted, so what remains of [s0, s1) is slices of the list)
+                pieces = [(s0, s1)]
+                for d0, d1 in done:
+                    pieces = [q for x0, x1 in pieces for q in ((x0, min(x1, d0)), (max(x0, d1), x1)) if q[1] > q[0]]
+                for x0, x1 in pieces:
+                    i0, i1 = self._cut(k, seg, x0, x1)
+                    if i1 > i0:
+                        out.append(("rows", seg[3][i0:i1], seg[4]))
         return out
 
     def _adam_range(self, k: str, lo: int, hi: int, lr, b1, b2, eps, t, scale, done=()) -> None:

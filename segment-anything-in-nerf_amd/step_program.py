@@ -70,6 +70,9 @@ ROWS_OPERAND = _os.environ.get("SNF_ROWS_OPERAND", "1") == "1"  # ... and its gr
 # The reachable-row (coarse) levels of every hash table are reduced over compact row indices and stepped inside the table backward
 # (k_hg_reduce_sparse, round 3): no gradient is written for them and no snf_adam_step_rows pass follows.  0: round-2 behaviour.
 SPARSE_LEVELS = _os.environ.get("SNF_HG_SPARSE_LEVELS", "1") == "1"
+# ... for the F = 2 tables too (measured: +0.07 ms on the field grid alone -- its coarse levels are bound by the 8-byte gathers of
+# the staged gradient, which the compact reduce does not remove, and the quad-merged bucket-wide kernel already avoids the pile-up)
+SPARSE_LEVELS_F2 = _os.environ.get("SNF_HG_SPARSE_LEVELS_F2", "0") == "1"
 PAIR_GRID_BWD = _os.environ.get("SNF_PAIR_GRID_BWD", "1") == "1"  # both feature grids of a head in one table-backward launch
 FUSED_MEAN_EPILOGUE = _os.environ.get("SNF_FUSED_MEAN", "1") == "1"  # ... and the mean itself in the hidden layer's GEMM epilogue
 # Without feature heads the step is ONE dependency chain on the main stream.  Its head -- sampling, the proposal network, the
@@ -252,18 +255,22 @@ class StepProgram:
             # reachable-row levels through the compact fixed-point reduce; with the optimizer on this launch steps the WHOLE table
             step_it = bool(with_opt and self.opt.fuse_table_adam)
             oc = self.opt.config[group]["optimizer"]
-            ns, rows, start, longest = sp
+            ns, rows, start, longest = sp  # (ns <= n_sparse: the levels in between keep the gradient write + row-Adam pass)
             scratch = self.buf(f"sp_scratch_{id(enc)}", (64,), torch.int32)
-            n_tab = (L << T) * F
-            fused = ((L - ns) << T) * F if step_it else 0
+            n_tab, stride = (L << T) * F, (1 << T) * F
+            fused = ((L - n_sparse) << T) * F if step_it else 0
             reach_params = int(rows.numel()) * F if step_it else 0
-            self._k(st, "snf_hashgrid_bwd_presorted_adam_sp", g, N, L, F, T, ld, col, nrun, gbuf, sorted_ws, stage, ns if step_it else L,
-                    p if step_it else None, m if step_it else None, v if step_it else None, 0.0, float(oc.betas[0]), float(oc.betas[1]),
-                    float(oc.eps), 1, float(grad_scale), rows, start, ns, longest, 1 if step_it else 0, scratch, tag=tag,
-                    units=float(N) * 8 * F * 4 * (L + (0 if step_it else L)) + 24.0 * (fused + reach_params),
-                    dyn={("lr", group): 15, ("t", group): 19})
+            left = (n_sparse - ns) if step_it else L  # levels whose gradient is written back
+            self._k(st, "snf_hashgrid_bwd_presorted_adam_sp", g, N, L, F, T, ld, col, nrun, gbuf, sorted_ws, stage,
+                    n_sparse if step_it else L, p if step_it else None, m if step_it else None, v if step_it else None, 0.0,
+                    float(oc.betas[0]), float(oc.betas[1]), float(oc.eps), 1, float(grad_scale), rows, start, ns, longest,
+                    1 if step_it else 0, scratch, tag=tag,
+                    units=float(N) * 8 * F * 4 * (L + left) + 24.0 * (fused + reach_params), dyn={("lr", group): 15, ("t", group): 19})
             if step_it:
-                done.append((fused_range[1] - n_tab, fused_range[1]))  # the whole table
+                t0 = fused_range[1] - n_tab
+                done.append((t0, t0 + ns * stride))  # the reachable rows of the leading ns levels
+                if n_sparse < L:
+                    done.append(fused_range)         # the dense levels
             return
         if F == 8 and FX_F8 and N % 2 == 0 and L <= 64:
             # fixed-point reduce (order-independent sums, no in-bucket sort); scratch private to this launch: the sorted
@@ -327,13 +334,14 @@ class StepProgram:
     def _sparse_lists(self, enc, N: int, n_sparse: int):
         """(levels, rows, list offsets, longest list) of a table's reachable-row levels for a backward over N samples, or None
         when the table has none / the switch is off / a bucket's list is too long for the compact reduce."""
-        if not (SPARSE_LEVELS and n_sparse > 0 and self.opt.skip_unreachable_rows):
-            return None
         F, T = enc.n_features_per_level, enc.log2_hashmap_size
+        if not (SPARSE_LEVELS and n_sparse > 0 and self.opt.skip_unreachable_rows and (F == 8 or SPARSE_LEVELS_F2)):
+            return None
         log2B = int(self.lib.snf_hashgrid_bucket_bits(int(N), int(T)))
         ns, rows, start, longest = enc.reach_lists(log2B, int(self.lib.snf_hashgrid_sparse_max_rows(F)))
-        if ns != n_sparse:  # (all or nothing: the optimizer plan treats the table's leading n_sparse levels as one row list)
+        if ns == 0:
             return None
+        assert ns <= n_sparse
         self._keep.extend((rows, start))
         return ns, rows, start, longest
 
@@ -837,6 +845,7 @@ class StepProgram:
                 units = 0.0
                 for e, t, f, sp in zip(encs, tabs, frm, sps):
                     left = (f - (sp[0] if sp is not None else 0)) if fuse else e.n_levels  # levels whose gradient is written back
+                    assert sp is None or sp[0] <= t[4]
                     units += float(NK) * 8 * 8 * 4 * (e.n_levels + left) + 24.0 * (((e.n_levels - f) << T) * 8)
                     if fuse and sp is not None:
                         units += 24.0 * 8 * int(sp[1].numel())
@@ -851,10 +860,10 @@ class StepProgram:
                         dyn={("lr", "sam_field"): 27, ("t", "sam_field"): 31})
                 if fuse:
                     for t, e, f, sp in zip(tabs, encs, frm, sps):
-                        if sp is not None:
-                            n_tab = e.params.numel()
-                            done.append((t[5][1] - n_tab, t[5][1]))  # the whole table
-                        elif f < e.n_levels:
+                        if sp is not None:  # the reachable rows of the leading sp[0] levels were stepped by the launch
+                            t0 = t[5][1] - e.params.numel()
+                            done.append((t0, t0 + ((sp[0] << T) * 8)))
+                        if f < e.n_levels:
                             done.append(t[5])
             for e in ([] if pair else encs):
                 L, F, T = e.n_levels, e.n_features_per_level, e.log2_hashmap_size

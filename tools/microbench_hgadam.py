@@ -84,14 +84,18 @@ for name in os.environ.get("CASES", "f8b,f8a,f2,f2p").split(","):
     if sp or rows_adam:
         log2B = int(lib.snf_hashgrid_bucket_bits(N, T))
         ns, rows, start, longest = enc.reach_lists(log2B, int(lib.snf_hashgrid_sparse_max_rows(F)))
-        assert ns == n_sparse, (ns, n_sparse)
-        offs = (rows.long() * F).to(torch.int32).contiguous() if ns else None
+        _, rows64 = enc.active_rows()
+        offs = (rows64 * F).to(torch.int32).contiguous() if n_sparse else None
+        rest = (rows64[rows.numel():] * F).to(torch.int32).contiguous() if ns else offs  # levels [ns, n_sparse): row-Adam as before
+        print(f"  reachable-row levels {n_sparse}, through the compact reduce {ns}", flush=True)
 
     def launch(step):
-        if sp and n_sparse:
+        if sp and n_sparse and ns:
             ops._launch("snf_hashgrid_bwd_presorted_adam_sp", ops._p(gy), N, L, F, T, ld, 0, nrun, ops._p(g), ops._p(ws),
                         None if planar else ops._p(stage), n_sparse, ops._p(p), ops._p(m), ops._p(v), 5e-4, 0.9, 0.999, 1e-15, step,
                         1.0, ops._p(rows), ops._p(start), ns, longest, 1, ops._p(scratch), st)
+            if rest is not None and rest.numel():
+                ops.adam_step_rows_(p, g, m, v, rest, F, 5e-4, 0.9, 0.999, 1e-15, step, 1.0, True)
             return
         if rows_adam and n_sparse:
             ops._launch("snf_hashgrid_bwd_presorted_adam", ops._p(gy), N, L, F, T, ld, 0, nrun, ops._p(g), ops._p(ws),
