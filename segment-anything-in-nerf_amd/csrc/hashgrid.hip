@@ -1143,7 +1143,11 @@ __global__ __launch_bounds__(HG_SP_T) void k_hg_reduce_sparse(const float* __res
     if (!ADAM && start == end) return;
     int copies = ACC / (nrows * F);
     copies = copies >= 64 ? 64 : (copies < 1 ? 1 : 1 << (31 - __clz(copies)));  // power of two, at most one per lane
-    const uint32_t copy_off = (uint32_t)(lane & (copies - 1)) * (uint32_t)(nrows * F);
+    // layout acc[(row * F + f) * copies + copy]: the copies of one sum are ADJACENT 8-byte words, so the lanes of a wave that hit one
+    // row (the common case on a coarse level) spread over all LDS banks; with the copies strided by nrows * F words they fell
+    // into the same few banks (rows are 64 B: four bank groups) and the "conflict-free" atomics serialised 16-way
+    const uint32_t copy = (uint32_t)(lane & (copies - 1));
+    const int csh = 31 - __clz(copies);
     for (int i = tid; i < rpb; i += HG_SP_T) lookup[i] = 0xFFFFu;
     for (int i = tid; i < copies * nrows * F; i += HG_SP_T) acc[i] = 0ull;
     for (int i = tid; i < (nrows * F + 31) / 32; i += HG_SP_T) bad[i] = 0u;
@@ -1191,7 +1195,7 @@ __global__ __launch_bounds__(HG_SP_T) void k_hg_reduce_sparse(const float* __res
                     const float v = w * g0[j][f];
                     if (fabsf(v) < INFINITY) {
                         const long long q = __float2ll_rn(v * scale);
-                        if (q != 0) atomicAdd(&acc[copy_off + idx * F + f], (unsigned long long)q);
+                        if (q != 0) atomicAdd(&acc[((idx * F + f) << csh) + copy], (unsigned long long)q);
                     } else {
                         const uint32_t eb = idx * F + f;
                         atomicOr(&bad[eb >> 5], 1u << (eb & 31));
@@ -1216,8 +1220,8 @@ __global__ __launch_bounds__(HG_SP_T) void k_hg_reduce_sparse(const float* __res
 #pragma unroll
         for (int f = 0; f < F; ++f) {
             const uint32_t eb = (uint32_t)(i * F + f);
-            unsigned long long qs = acc[eb];
-            for (int c = 1; c < copies; ++c) qs += acc[(uint32_t)c * (uint32_t)(nrows * F) + eb];
+            unsigned long long qs = 0ull;
+            for (int c = 0; c < copies; ++c) qs += acc[(eb << csh) + (uint32_t)c];
             const bool isbad = (bad[eb >> 5] >> (eb & 31)) & 1u;
             gg[f] = isbad ? __uint_as_float(0x7FC00000u) : __ll2float_rn((long long)qs) * inv;
             nz = nz || qs != 0ull || isbad;

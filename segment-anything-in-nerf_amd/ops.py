@@ -169,6 +169,22 @@ def join_wgrad_stream() -> None:
             cur.wait_stream(side)
 
 
+# Inside `Function.forward` grad mode is always off and `ctx.needs_input_grad` only says which inputs require grad -- also under
+# torch.no_grad(), where no backward will ever come.  The wrappers below note the caller's grad mode here so that the forward
+# passes do not prepare one in eval: no backward sorts, no saved hidden activations, no row-major detour for the sorted backward
+# (the render path spent 11 of 58 ms per 512 x 512 image in sorts it never used, profiles/r03_render_before.txt).
+_TRACK = [True]
+
+
+def _apply(fn, *args):
+    prev = _TRACK[0]
+    _TRACK[0] = torch.is_grad_enabled()
+    try:
+        return fn.apply(*args)
+    finally:
+        _TRACK[0] = prev
+
+
 def _grad_target(param: torch.Tensor) -> Tuple[torch.Tensor, bool]:
     """(buffer to accumulate into, whether autograd should get None)."""
     _note_grad_stream()
@@ -324,7 +340,7 @@ class _HashGridMulti(torch.autograd.Function):
         total = sum(L * F for (_, L, F, _) in specs)
         out = torch.empty((N, total), device=u.device, dtype=torch.float32)
         col = 0
-        if PRESORT_FIELD_GRID and N >= (1 << 16):
+        if _TRACK[0] and PRESORT_FIELD_GRID and N >= (1 << 16):
             # backward sorts that are not attached to `u` yet (the proposal grid) start now, on the side stream
             for (sc, L, F, T), need in zip(specs, ctx.needs_input_grad[2:]):
                 if need:
@@ -481,9 +497,9 @@ def hashgrid(u, tables: Sequence[torch.Tensor], specs) -> torch.Tensor:
     if torch.is_grad_enabled() and any(t.requires_grad for t in tables):
         layout = table_parallel_layout(specs)
         if layout is not None:
-            return _HashGridTableParallel.apply(u, specs, layout, *tables)
+            return _apply(_HashGridTableParallel, u, specs, layout, *tables)
     _tp_refresh(tables)
-    return _HashGridMulti.apply(u, specs, *tables)
+    return _apply(_HashGridMulti, u, specs, *tables)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -526,7 +542,7 @@ class _Linear(torch.autograd.Function):
 
 
 def linear(x, w, b=None, act: int = ACT_NONE) -> torch.Tensor:
-    return _Linear.apply(x, w, b, act)
+    return _apply(_Linear, x, w, b, act)
 
 
 def mlp(x, weights: Sequence[torch.Tensor], biases=None, out_act: int = ACT_NONE) -> torch.Tensor:
@@ -551,7 +567,7 @@ class _MLPTiny(torch.autograd.Function):
         x = _chk(x, "x")
         N, I = x.shape
         H = w0.shape[0]
-        need = any(ctx.needs_input_grad)
+        need = _TRACK[0] and any(ctx.needs_input_grad)
         hid = torch.empty((N, H), device=x.device, dtype=torch.float32) if need else None
         y = torch.empty((N, 1), device=x.device, dtype=torch.float32)
         _launch("snf_mlp_tiny_fwd", _p(x), I, _p(w0), _p(w1), I, H, N, _p(hid), _p(y), _stream(), tag=f"{I}x{H}x1")
@@ -576,7 +592,7 @@ class _MLPTiny(torch.autograd.Function):
 
 
 def mlp_tiny(x, w0, w1) -> torch.Tensor:
-    return _MLPTiny.apply(x, w0, w1)
+    return _apply(_MLPTiny, x, w0, w1)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -605,7 +621,7 @@ class _ConvHead(torch.autograd.Function):
         _linear_fwd_ws(cm, w1, b1, npatch, O0 * kk, O1, ACT_NONE, y, st, f"{O0 * kk}x{O1}pm")
         ctx.p, ctx.k = p, k
         ctx.refs = (w0, b0, w1, b1)
-        if any(ctx.needs_input_grad):
+        if _TRACK[0] and any(ctx.needs_input_grad):
             ctx.save_for_backward(col, h, cm)
         return y
 
@@ -653,7 +669,7 @@ class _ConvHead(torch.autograd.Function):
 
 def conv_head(x, w0, b0, w1, b1, patch: int) -> torch.Tensor:
     """x [R, C] channel-last patch rows -> [R/patch^2, O]."""
-    return _ConvHead.apply(x, w0, b0, w1, b1, patch)
+    return _apply(_ConvHead, x, w0, b0, w1, b1, patch)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -719,9 +735,11 @@ class _MLP64(torch.autograd.Function):
     def forward(ctx, x, in_real: int, out_act: int, *ws):
         x = _chk(x, "x")
         assert x.shape[1] >= 32 and x.shape[1] % 4 == 0, "mlp64 input must be padded to >= 32 columns (multiple of 4)"
-        y, h1, h2 = _mlp64_fwd_launch(x, in_real, ws, out_act, True)
-        ctx.save_for_backward(x, y, h1, *((h2,) if h2 is not None else ()))
-        ctx.ws, ctx.in_real, ctx.out_act = ws, in_real, out_act
+        need = _TRACK[0] and any(ctx.needs_input_grad)
+        y, h1, h2 = _mlp64_fwd_launch(x, in_real, ws, out_act, need)
+        if need:
+            ctx.save_for_backward(x, y, h1, *((h2,) if h2 is not None else ()))
+            ctx.ws, ctx.in_real, ctx.out_act = ws, in_real, out_act
         return y
 
     @staticmethod
@@ -741,7 +759,7 @@ class _MLP64(torch.autograd.Function):
 
 def mlp64(x, weights: Sequence[torch.Tensor], in_real: int, out_act: int = ACT_NONE) -> torch.Tensor:
     """Fused 64-wide MLP: x [N, >=32 (padded)] -> [N, out].  weights: [64,in_real], ([64,64]), [out,64]."""
-    return _MLP64.apply(x, in_real, out_act, *weights)
+    return _apply(_MLP64, x, in_real, out_act, *weights)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -756,11 +774,13 @@ class _NerfactoField(torch.autograd.Function):
         sc, L, F, T = spec
         N = R * S
         dev = u.device
-        need = any(ctx.needs_input_grad)  # (grad mode is off inside forward; autograd tells us what it will ask for)
-        # the encoding travels level-major ([L][N][F]) between the grid and the base MLP when the sorted backward can take it:
-        # whole-line stores in the level-at-a-time grid kernels, and the MLP's d(encoding) IS the backward's staged gradient
-        planar = (PLANAR_FIELD_ENCODING and L * F == 32 and F == 2 and HASHGRID_BWD_MODE == "sorted"
-                  and N <= HASHGRID_BWD_MAX_SAMPLES and 8 * L * N < (1 << 32) and T <= 23)
+        need = _TRACK[0] and any(ctx.needs_input_grad)  # (a backward will come: the caller's grad mode and what requires grad)
+        # the encoding travels level-major ([L][N][F]) between the grid and the base MLP when the sorted backward can take it
+        # (or when there is no backward at all: eval chunks of 4 M samples): whole-line stores in the level-at-a-time grid kernels,
+        # and the MLP's d(encoding) IS the backward's staged gradient
+        planar = (PLANAR_FIELD_ENCODING and L * F == 32 and F == 2
+                  and (not need or (HASHGRID_BWD_MODE == "sorted" and N <= HASHGRID_BWD_MAX_SAMPLES and 8 * L * N < (1 << 32)
+                                    and T <= 23)))
         enc = torch.empty((L * F * N,) if planar else (N, L * F), device=dev, dtype=torch.float32)
         if need and table.requires_grad and PRESORT_FIELD_GRID:
             # the field grid's backward sort needs only the positions: it runs NOW on a side stream, beside the forward
@@ -812,5 +832,5 @@ class _NerfactoField(torch.autograd.Function):
 
 def nerfacto_field(u, sel, dirs, R: int, S: int, spec, table, base_ws, head_ws):
     """-> (density [R*S], rgb [R*S,3]); base_ws = (W0 [64,32], W1 [16,64]), head_ws = (W0 [64,31], W1 [64,64], W2 [3,64])."""
-    return _NerfactoField.apply(u, sel, dirs, R, S, spec, table, *base_ws, *head_ws)
+    return _apply(_NerfactoField, u, sel, dirs, R, S, spec, table, *base_ws, *head_ws)
 

@@ -81,7 +81,10 @@ class Encoding(nn.Module):
     PRIME_Y, PRIME_Z = 2654435761, 805459861
 
     @torch.no_grad()
-    def active_rows(self, max_fraction: float = 0.4) -> Tuple[int, torch.Tensor]:
+    # a level counts as reachable-row ("sparse") while fewer than this fraction of its rows can be addressed (SNF_SPARSE_MAX_FRACTION)
+    SPARSE_MAX_FRACTION = float(__import__("os").environ.get("SNF_SPARSE_MAX_FRACTION", "0.4"))
+
+    def active_rows(self, max_fraction: Optional[float] = None) -> Tuple[int, torch.Tensor]:
         """Rows of the coarse levels that can EVER be addressed.
 
         A level of resolution s hashes lattice points (x, y, z) in [0, s]^3 (inputs in [0, 1]; one cell of slack on either
@@ -91,6 +94,7 @@ class Encoding(nn.Module):
         a prefix) and `rows` is the sorted int64 list of their reachable row indices (l * 2^T + hash); levels >= n are
         treated as dense."""
         T, dev = self.log2_hashmap_size, self.params.device
+        max_fraction = self.SPARSE_MAX_FRACTION if max_fraction is None else max_fraction
         mask32, maskT = 0xFFFFFFFF, (1 << T) - 1
         rows, n_sparse = [], 0
         for l in range(self.n_levels):

@@ -38,6 +38,7 @@ def golden():
 
 LAST_LAYERS = ("sam_w1", "clipseg_w1", "head_w2", "conv1_w", "conv1_b", "conv0_w", "conv0_b")
 OUTLIER = 1e-4  # an element is an outlier when it differs by more than this fraction of its tensor's largest entry
+TABLE_LEVELS = {"prop_table": 5, "field_table": 16}  # (the feature tables have 12)
 
 
 @pytest.fixture(scope="session")
@@ -48,24 +49,27 @@ def grad_parity():
     unit) pair whose pre-activation lies within the ~2e-6 rounding of positions / interpolation of zero.  One flipped pair moves
     one row of that layer's weight gradient, and the table entries that sample touches, by ~1/sqrt(samples) of their size:
     0.5-4 % of the tensor's largest entry in a few elements, next to ~1e-5 everywhere else (tools/debug_ministep.py traces
-    each outlier to its one sample).  The oracle evaluated in fp32 and in fp64 differs from itself in exactly this pattern
-    (tests/test_oracle_golden.py::test_gradient_conditioning; counted in the same units as here: field_table 1 % of its
-    elements above 1e-4 of the largest entry and up to 1.5e-2 of it, base_w0 10 of 64 rows, sam_w0 5 of 256 rows, the hash
-    tables 0.1-0.2 %, every tensor behind its network's last ReLU none at all).  So every tensor is held to FOUR bounds, so that
-    outliers are bounded in mass, in size and in NUMBER:
-      * relative L1 error <= 5e-3 (a wrong term, level or scale is O(1) there; measured 1e-3);
-      * largest error <= 6e-2 of the largest entry (a flip moves an entry by at most a few per cent; a wrong contribution
-        confined to a few rows or entries is O(1) of them) and <= 2e-4 for the tensors behind their network's last ReLU;
-      * outliers (|err| > 1e-4 of the largest entry) in at most 3 % of a hash table's elements and in at most 25 % of the rows
-        of a weight matrix upstream of a ReLU (a flipped (sample, unit) pair owns ONE row), none behind the last ReLU;
-    the report lists count and rows per tensor.  The proposal network's gradient comes from the interlevel loss alone, which is
-    ~5e-11 in these untrained configurations -- a difference of nearly equal histograms (its fp32 and fp64 evaluations are
-    1e-3 apart): relative L1 <= 3e-2 only; the loss kernels' own tests (test_ops_gpu.py) check that backward on well-conditioned
-    inputs."""
+    each outlier to its one sample).  It is a property of the function: the oracle evaluated in fp32 and in fp64 differs from
+    itself in exactly this pattern (tests/test_oracle_golden.py::test_gradient_conditioning; counted as here, oracle fp32 against
+    oracle fp64 at 9 k samples: field_table 1 % of its elements above 1e-4 of the largest entry, base_w0 12 % of its elements in
+    10 of 64 rows, sam_w0 5 of 256 rows, every tensor behind its network's last ReLU none at all; the number of flipped pairs
+    grows with samples x units, so a bound on the outlier COUNT cannot be a constant -- VERDICT r02 asked for 0.1 %, which the
+    reference's own arithmetic misses by two orders of magnitude).  What a flip cannot do is change a slice by much: it moves one
+    row of a first-layer gradient by ~1 % and leaves the per-level sums of a table where they are.  So every tensor is held to:
+      * relative L1 error <= 5e-3 over the tensor (a wrong term or scale is O(1) there; measured 1e-3);
+      * relative L1 error PER SLICE -- every row of a weight matrix, every level of a hash table -- <= 0.15 / 0.03: a wrong
+        contribution confined to a few rows of a weight gradient or to one level of a table is O(1) of THAT slice however small
+        its share of the tensor (the gap of the tensor-wide L1 bound VERDICT r02 pointed out);
+      * largest error <= 6e-2 of the largest entry (a flip moves an entry by a few per cent at most);
+      * behind a network's last ReLU (LAST_LAYERS): largest error <= 2e-4 and NO outlier at 1e-4;
+    and the report lists, per tensor, L1 / max / outlier count / rows (levels) containing one / worst slice, printed with
+    SNF_PARITY_VERBOSE=1.  The proposal network's gradient comes from the interlevel loss alone, which is ~5e-11 in these
+    untrained configurations -- a difference of nearly equal histograms (its fp32 and fp64 evaluations are 1e-3 apart): relative
+    L1 <= 3e-2 only; the loss kernels' own tests (test_ops_gpu.py) check that backward on well-conditioned inputs."""
     import numpy as np
 
-    def check(got, ref, l1_tol=5e-3, max_tol=2e-4, big_tol=6e-2, table_frac=3e-2, row_frac=0.25):
-        l1, mx, cnt, rows, shape = {}, {}, {}, {}, {}
+    def check(got, ref, l1_tol=5e-3, max_tol=2e-4, big_tol=6e-2, row_tol=0.15, level_tol=0.03):
+        l1, mx, cnt, rows, worst, shape = {}, {}, {}, {}, {}, {}
         for k, r in ref.items():
             r = np.asarray(r, dtype=np.float64)
             a = got[k]
@@ -74,12 +78,20 @@ def grad_parity():
             top = np.abs(r).max()
             l1[k], mx[k] = float(err.sum() / np.abs(r).sum()), float(err.max() / top)
             bad = err > OUTLIER * top
-            cnt[k] = int(bad.sum())
-            rows[k] = int(bad.reshape(bad.shape[0], -1).any(axis=1).sum()) if bad.ndim >= 2 else cnt[k]
-            shape[k] = r.shape
-        report = {k: f"{l1[k]:.1e}/{mx[k]:.1e}/{cnt[k]}of{int(np.prod(shape[k]))}/{rows[k]}rows" for k in l1}
+            cnt[k], shape[k] = int(bad.sum()), r.shape
+            if "_table" in k:  # slices = levels
+                nl = TABLE_LEVELS.get(k, 12)
+                e2, r2, b2 = err.reshape(nl, -1), np.abs(r).reshape(nl, -1), bad.reshape(nl, -1)
+            elif r.ndim >= 2:   # slices = rows (output units)
+                e2, r2, b2 = err.reshape(r.shape[0], -1), np.abs(r).reshape(r.shape[0], -1), bad.reshape(r.shape[0], -1)
+            else:
+                e2, r2, b2 = err.reshape(1, -1), np.abs(r).reshape(1, -1), bad.reshape(1, -1)
+            rows[k] = int(b2.any(axis=1).sum())
+            # (slices that carry next to nothing of the tensor are measured against 1 % of the heaviest slice)
+            worst[k] = float((e2.sum(1) / np.maximum(r2.sum(1), 1e-2 * r2.sum(1).max())).max())
+        report = {k: f"{l1[k]:.1e}/{mx[k]:.1e}/{cnt[k]}of{int(np.prod(shape[k]))}/{rows[k]}slices/{worst[k]:.1e}" for k in l1}
         if os.environ.get("SNF_PARITY_VERBOSE"):
-            print("[grad_parity] L1 / max / outliers / rows:", report, flush=True)
+            print("[grad_parity] L1 / max / outliers / slices with one / worst slice L1:", report, flush=True)
         nonprop = [k for k in l1 if not k.startswith("prop_")]
         assert max(l1[k] for k in nonprop) <= l1_tol, report
         assert max([v for k, v in l1.items() if k.startswith("prop_")] or [0.0]) <= 3e-2, report
@@ -90,11 +102,7 @@ def grad_parity():
             if k in strict:
                 continue
             assert mx[k] <= big_tol, (k, report)
-            n = int(np.prod(shape[k]))
-            if k.endswith("_table") or "_table" in k:
-                assert cnt[k] <= table_frac * n, (k, report)
-            elif len(shape[k]) >= 2:
-                assert rows[k] <= max(2, row_frac * shape[k][0]), (k, report)
+            assert worst[k] <= (level_tol if "_table" in k else row_tol), (k, report)
         return report
 
     return check
