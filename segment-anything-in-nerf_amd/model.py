@@ -448,6 +448,20 @@ class SAMModel(NerfactoModel):
                     self._feature_head(h, selected, outputs)
         return outputs
 
+    def _render_program(self):
+        """The eval path's static launch schedule (render_program.RenderProgram), or None when this configuration is outside
+        its scope / SNF_STATIC_RENDER=0 (the chunk loop then goes through `forward`)."""
+        import os
+        if os.environ.get("SNF_STATIC_RENDER", "1") != "1" or not self.device.type == "cuda":
+            return None
+        prog = self.__dict__.get("_render_prog")
+        if prog is None:
+            from .render_program import RenderProgram
+            if RenderProgram.unsupported_reason(self) is not None:
+                return None
+            prog = self.__dict__["_render_prog"] = RenderProgram(self)
+        return prog
+
     def _select_feature_samples(self, ray_samples: RaySamples, weights):
         """sam_model.py:244-255: top-K by weight, sharpen w^T, renormalise, gather the samples -- shared by the heads, as are
         the contracted positions of the selected samples (computed here once, on the caller's stream)."""
@@ -529,6 +543,8 @@ class SAMModel(NerfactoModel):
 
         from . import distributed as D
 
+        prog = self._render_program()
+
         def run(bundle, granule=1, **kw):
             """Render `bundle` in chunks.  In a data-parallel run the rays of the image are SHARDED over the ranks (contiguous
             shares in whole `granule`s, so p x p patches stay on one rank) and the rows gathered (eval)."""
@@ -537,6 +553,16 @@ class SAMModel(NerfactoModel):
             shard = D.collectives_on() and (n + granule - 1) // granule >= D.world_size()
             lo, hi = D.split_range(n, granule) if shard else (0, n)
             local: Dict[str, List[torch.Tensor]] = {}
+            if prog is not None and hi > lo:
+                # the chunk loop as a recorded launch schedule (render_program.py): rays read in place, rows written in place
+                feats = kw.get("get_feature", [])
+                mode = feats[0] if feats else "rgb"
+                o = bundle.origins.reshape(-1, 3).contiguous()
+                d = bundle.directions.reshape(-1, 3).contiguous()
+                res = prog.render(o[lo:hi], d[lo:hi], mode, fast=bool(kw.get("fast", False)), chunk=num_rays_per_chunk)
+                for name, rows in res.items():
+                    outputs_lists.setdefault(name, []).append(D.all_gather_rows(rows) if shard else rows)
+                return
             for i in range(lo, hi, num_rays_per_chunk):
                 rb = bundle.get_row_major_sliced_ray_bundle(i, min(i + num_rays_per_chunk, hi))
                 rb.nears, rb.fars = None, None

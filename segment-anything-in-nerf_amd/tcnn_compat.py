@@ -80,10 +80,10 @@ class Encoding(nn.Module):
 
     PRIME_Y, PRIME_Z = 2654435761, 805459861
 
-    @torch.no_grad()
     # a level counts as reachable-row ("sparse") while fewer than this fraction of its rows can be addressed (SNF_SPARSE_MAX_FRACTION)
     SPARSE_MAX_FRACTION = float(__import__("os").environ.get("SNF_SPARSE_MAX_FRACTION", "0.4"))
 
+    @torch.no_grad()
     def active_rows(self, max_fraction: Optional[float] = None) -> Tuple[int, torch.Tensor]:
         """Rows of the coarse levels that can EVER be addressed.
 

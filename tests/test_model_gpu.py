@@ -158,10 +158,13 @@ def test_train_iterations_reduce_loss():
         assert float(a.grad.abs().max()) == 0.0  # re-zeroed by the fused Adam pass
 
 
-def test_patch_render_eval_path_vs_oracle():
-    """SURVEY 8f rank 1 (samnerf/sam_model.py:337-419): full-image render + SAM / ClipSeg feature maps, eval mode."""
+@pytest.mark.parametrize("static", [True, False])
+def test_patch_render_eval_path_vs_oracle(static, monkeypatch):
+    """SURVEY 8f rank 1 (samnerf/sam_model.py:337-419): full-image render + SAM / ClipSeg feature maps, eval mode -- through the
+    recorded launch schedule (render_program.RenderProgram, the default) and through the plugin classes' chunk loop."""
     from samnerf_amd.interop import load_named_params
     from samnerf_amd.rays import RayBundle
+    monkeypatch.setenv("SNF_STATIC_RENDER", "1" if static else "0")
     H, W, P, S, K, patch, T = 24, 40, 64, 32, 16, 4, 12
     cfg = O.PathConfig(num_proposal_samples=P, num_nerf_samples=S, num_sam_samples=K, patch_size=patch).small(T)
     params = O.init_params(cfg, seed=5, table_scale=0.05)
@@ -175,14 +178,53 @@ def test_patch_render_eval_path_vs_oracle():
     cam = RayBundle(origins=o.cuda(), directions=d.cuda(), pixel_area=torch.full((H, W, 1), 1e-6, device="cuda"),
                     camera_indices=torch.zeros((H, W, 1), dtype=torch.long, device="cuda"))
     out = model.get_outputs_for_camera_ray_bundle(cam)
+    assert (model.__dict__.get("_render_prog") is not None) == static
     fh, fw = O.get_feature_size(H, W)
     assert out["rgb"].shape == (H, W, 3) and out["sam"].shape == (fh, fw, 256) and out["clipseg"].shape == (32, 32, 192)
+    assert set(out) == {"rgb", "accumulation", "depth", "prop_depth_0", "sam", "clipseg"}
     assert md(out["rgb"], ref["rgb"]) <= TOL
     assert md(out["accumulation"], ref["accumulation"]) <= TOL
     assert md(out["sam"], ref["sam"]) <= TOL
     assert md(out["clipseg"], ref["clipseg"]) <= TOL
     rel = (out["depth"].cpu() - ref["depth"]).abs() / ref["depth"].abs()
     assert float(rel.max()) <= 1e-4
+    fast = model.get_outputs_for_camera_ray_bundle(cam, fast=True)
+    assert torch.equal(fast["rgb"], out["rgb"]) and torch.equal(fast["depth"], out["depth"]) and "accumulation" not in fast
+
+
+def test_render_schedule_at_the_size_of_config_5():
+    """BASELINE config #5, render half, AT SIZE: a 512 x 512 camera -> 64 x 64 x 256 SAM map (the [256, 256] feature ray grid
+    in 4 x 4 patches), 32 x 32 x 192 ClipSeg map, full-size tables (T = 19 / 17), P = 64 / S = 128 / K = 16 -- the recorded
+    schedule against the plugin classes' chunk loop on the same model (which the small-image test above holds to the oracle):
+    same kernels, so the maps agree to the order of the heads' last layer and the mean (1e-6), RGB / depth bit for bit."""
+    import os
+    from samnerf_amd.rays import RayBundle
+    H = W = 512
+    model = build_model(64, 128, 16, 4, 19)
+    model.eval()
+    g = torch.Generator(device="cuda").manual_seed(0)
+    o = torch.rand((H, W, 3), device="cuda", generator=g) - 0.5
+    d = torch.nn.functional.normalize(torch.randn((H, W, 3), device="cuda", generator=g), dim=-1)
+    cam = RayBundle(origins=o, directions=d, pixel_area=torch.full((H, W, 1), 1e-6, device="cuda"),
+                    camera_indices=torch.zeros((H, W, 1), dtype=torch.long, device="cuda"))
+    res = {}
+    for static in ("1", "0"):
+        os.environ["SNF_STATIC_RENDER"] = static
+        try:
+            res[static] = model.get_outputs_for_camera_ray_bundle(cam)
+        finally:
+            os.environ.pop("SNF_STATIC_RENDER")
+    a, b = res["1"], res["0"]
+    assert a["sam"].shape == (64, 64, 256) and a["clipseg"].shape == (32, 32, 192) and a["rgb"].shape == (H, W, 3)
+    for k in ("rgb", "accumulation", "depth", "prop_depth_0"):
+        assert torch.equal(a[k], b[k]), k
+    for k in ("sam", "clipseg"):
+        assert torch.isfinite(a[k]).all()
+        assert float((a[k] - b[k]).abs().max()) <= 2e-6 * max(1.0, float(b[k].abs().max())), k
+    # size-independent properties of the renders: colours in [0, 1], accumulation in [0, 1], depth inside [near, far]
+    assert float(a["rgb"].min()) >= 0.0 and float(a["rgb"].max()) <= 1.0
+    assert float(a["accumulation"].min()) >= 0.0 and float(a["accumulation"].max()) <= 1.0 + 1e-5
+    assert float(a["depth"].min()) >= 0.0 and float(a["depth"].max()) <= model.config.far_plane * (1 + 1e-5)
 
 
 _RCCL_SCRIPT = r"""

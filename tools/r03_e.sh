@@ -13,3 +13,7 @@ cd $ROOT
 for frac in 0.4 0.3; do
 SNF_SPARSE_MAX_FRACTION=$frac tools/ab_env.sh SNF_HG_SPARSE_LEVELS=0 snf_hashgrid_bwd_presorted_adam_pair/F8L12+12 snf_adam_step_rows 2>&1 | cut -c1-300 | tee $out/ab$frac.txt
 done
+python -m pytest tests/test_model_gpu.py -q -x -k "render or eval" 2>&1 | tail -3 | cut -c1-300
+python tools/bench_render.py 2>/dev/null | tail -1 | cut -c1-200
+SNF_STATIC_RENDER=0 python tools/bench_render.py 2>/dev/null | tail -1 | cut -c1-200
+RES=1024 python tools/bench_render.py 2>/dev/null | tail -1 | cut -c1-200
