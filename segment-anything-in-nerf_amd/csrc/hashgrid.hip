@@ -1221,7 +1221,8 @@ __global__ __launch_bounds__(HG_SP_T) void k_hg_reduce_sparse(const float* __res
         for (int f = 0; f < F; ++f) {
             const uint32_t eb = (uint32_t)(i * F + f);
             unsigned long long qs = 0ull;
-            for (int c = 0; c < copies; ++c) qs += acc[(eb << csh) + (uint32_t)c];
+            // (lane i starts at copy i: the lanes' reads then fall into different banks -- their elements are copies * 8 B apart)
+            for (int c = 0; c < copies; ++c) qs += acc[(eb << csh) + (((uint32_t)c + (uint32_t)lane) & (uint32_t)(copies - 1))];
             const bool isbad = (bad[eb >> 5] >> (eb & 31)) & 1u;
             gg[f] = isbad ? __uint_as_float(0x7FC00000u) : __ll2float_rn((long long)qs) * inv;
             nz = nz || qs != 0ull || isbad;

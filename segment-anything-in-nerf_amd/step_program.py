@@ -82,6 +82,10 @@ FUSED_MEAN_EPILOGUE = _os.environ.get("SNF_FUSED_MEAN", "1") == "1"  # ... and t
 XSTEP_PROLOGUE = _os.environ.get("SNF_XSTEP_PROLOGUE", "1") == "1"
 
 
+# SNF_ABLATE_SKIP="key,key": launches whose key contains one of these are NOT issued (results are garbage; timing probe only)
+_SKIP = tuple(k for k in _os.environ.get("SNF_ABLATE_SKIP", "").split(",") if k)
+
+
 class _Plan:
     __slots__ = ("entries", "dyn")
 
@@ -980,7 +984,13 @@ class StepProgram:
                 a[i] = v
         # ---- replay
         sel = ops._TIMING["names"]
-        if sel is None:
+        if _SKIP:  # measurement only (tools/ablate_step.sh): what is a kernel's time worth inside the concurrent step?
+            for kind, fn, args, key_, _, _ in plan.entries:
+                if kind != _KERNEL:
+                    fn(*args)
+                elif not any(s_ in key_ for s_ in _SKIP):
+                    fn(*args)
+        elif sel is None:
             for kind, fn, args, key_, _, _ in plan.entries:
                 if kind == _KERNEL:
                     rc = fn(*args)
