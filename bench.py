@@ -37,6 +37,26 @@ WORKLOADS = {
 }
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP32_MATRIX_PEAK_TFLOPS = 157.3  # v_mfma_f32_32x32x2_f32
+BF16_MATRIX_PEAK_TFLOPS = 2500.0  # v_mfma_f32_32x32x16_bf16, dense (MI355X_MICROARCH.md)
+
+
+def mfma_peak(key: str, gemm_mode: int = 1):
+    """(peak in fp32-EQUIVALENT TFLOP/s, what it is) of the matrix instruction a GEMM-shaped entry point issues.  The bf16-split
+    kernels spend several bf16 products per fp32-equivalent multiply-add, so their ceiling is the bf16 dense peak divided by that
+    count -- not the fp32-matrix peak (`snf_linear_bwd_data_rows` "0.84 of 157 TFLOP/s" was 0.16 of its
+    own 833)."""
+    name, _, tag = key.partition("/")
+    if gemm_mode >= 1 and name.startswith("snf_linear"):
+        dims = [int(x) for x in re.sub(r"[a-z]+$", "", tag).split("x")] if tag else []
+        if dims and max(dims) >= 64:  # (the narrow layers -- proposal net -- stay on the fp32 matrix cores)
+            return BF16_MATRIX_PEAK_TFLOPS / 3.0, "v_mfma_f32_32x32x16_bf16, 3 products per fp32-equivalent MAC (hi*hi + hi*lo + lo*hi)"
+    if gemm_mode >= 1 and name == "snf_mlp64_fwd":
+        return BF16_MATRIX_PEAK_TFLOPS / 6.0, "v_mfma_f32_32x32x16_bf16, 6 products per fp32-equivalent MAC (three-piece split)"
+    if gemm_mode >= 1 and name == "snf_mlp64_bwd_fused":
+        # data-gradient chain on the fp32 matrix cores + weight gradients on the 3-product split, half of the counted flops each
+        return 2.0 / (1.0 / FP32_MATRIX_PEAK_TFLOPS + 3.0 / BF16_MATRIX_PEAK_TFLOPS), \
+            "data gradient: v_mfma_f32_32x32x2_f32; weight gradient: bf16 3-product split (harmonic mean of the two peaks)"
+    return FP32_MATRIX_PEAK_TFLOPS, "v_mfma_f32_32x32x2_f32"
 
 
 def algorithmic_model(key: str, w: dict):
@@ -186,6 +206,99 @@ def quick_measure(name: str, rank: int, local_rank: int, world: int, steps: int 
     return {"ms_per_step": round(ms, 4), "value": world * w["R"] * w["S"] * steps / el, "unit": "ray-samples/s", "steps": steps,
             "warmup": warmup, "rays_per_gpu": w["R"], "step_frac_of_hbm_peak": round(b_step / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
             "static_schedule": static}
+
+
+def render_measure(local_rank: int, res: int = 512, reps: int = 5) -> dict:
+    """BASELINE configs[4], render half (samnerf/sam_model.py:337-419): one `res` x `res` camera -> RGB / depth / accumulation, the
+    64 x 64 x 256 SAM map (the [256, 256] feature ray grid in 4 x 4 patches through the conv head) and the 32 x 32 x 192 ClipSeg
+    map; eval mode, full-size tables, P = 64 / S = 128 / K = 16; the recorded launch schedule (render_program.py)."""
+    from samnerf_amd.rays import RayBundle
+    tr = build_trainer(WORKLOADS["distill_4096x128"], local_rank, 1)
+    model = tr.pipeline.model
+    model.eval()
+    dev = model.device
+    g = torch.Generator(device=dev).manual_seed(0)
+    o = torch.rand((res, res, 3), device=dev, generator=g) - 0.5
+    d = torch.nn.functional.normalize(torch.randn((res, res, 3), device=dev, generator=g), dim=-1)
+    cam = RayBundle(origins=o, directions=d, pixel_area=torch.full((res, res, 1), 1e-6, device=dev),
+                    camera_indices=torch.zeros((res, res, 1), dtype=torch.long, device=dev))
+    for _ in range(2):
+        out = model.get_outputs_for_camera_ray_bundle(cam)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        out = model.get_outputs_for_camera_ray_bundle(cam)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / reps * 1e3
+    fh, fw = out["sam"].shape[:2]
+    p = model.config.patch_size
+    rays = res * res + fh * fw * p * p + 32 * 32
+    S, P = model.config.num_nerf_samples_per_ray, model.config.num_proposal_samples_per_ray[0]
+    shapes = {k: list(v.shape) for k, v in out.items() if torch.is_tensor(v)}
+    static = model.__dict__.get("_render_prog") is not None
+    _free(tr)
+    return {"ms_per_image": round(ms, 3), "rays_per_s": rays / (ms * 1e-3), "ray_samples_per_s": rays * S / (ms * 1e-3),
+            "rays_per_image": rays, "samples_per_ray": {"proposal": P, "fine": S}, "outputs": shapes, "images_timed": reps,
+            "static_schedule": static, "note": "eval path: RGB pass over every pixel + SAM feature pass over the patch ray grid + "
+            "ClipSeg pass over 32 x 32 rays, no_grad, full-size fp32 tables"}
+
+
+def vit_measure(reps: int = 5) -> dict:
+    """BASELINE configs[4], encoder half: SAM ViT-H image encoder forward on one 1024 x 1024 image (random weights of the
+    architecture, samnerf/segment_anything/build_sam.py:14-21), every GEMM on the bf16 3-product split."""
+    from samnerf_amd.image_encoder import build_sam_vit_h_encoder
+    enc = build_sam_vit_h_encoder().eval()
+    gen = torch.Generator(device="cuda").manual_seed(0)
+    for prm in enc.parameters():
+        prm.data.copy_(torch.randn(prm.shape, device="cuda", generator=gen) * 0.02)
+    x = torch.randn((1, 3, 1024, 1024), device="cuda", generator=gen)
+    with torch.no_grad():
+        for _ in range(2):
+            y = enc(x)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            y = enc(x)
+        torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / reps * 1e3
+    # multiply-adds of the 32 blocks at 4096 tokens x 1280 channels: qkv 3d^2 + proj d^2 + MLP 8d^2 per token, attention
+    # 2 x keys x d per token (14 x 14 windows in 28 blocks, 64 x 64 global in 4), patch embedding and neck
+    d_, T = 1280, 4096
+    macs = 32 * T * 12 * d_ * d_ + (28 * T * 196 * 2 * d_) + (4 * T * 4096 * 2 * d_) + T * 768 * d_ + T * (d_ * 256 + 2304 * 256)
+    flops = 2.0 * macs
+    peak = BF16_MATRIX_PEAK_TFLOPS / 3.0
+    finite = bool(torch.isfinite(y).all())
+    del enc
+    torch.cuda.empty_cache()
+    return {"ms_per_image": round(ms, 3), "tflops": round(flops / (ms * 1e-3) / 1e12, 1), "peak": round(peak, 1),
+            "frac": round(flops / (ms * 1e-3) / 1e12 / peak, 4), "peak_basis": "bf16 dense 2500 TFLOP/s / 3 products per "
+            "fp32-equivalent MAC", "flops_per_image": flops, "output": list(y.shape), "finite": finite, "images_timed": reps,
+            "note": "ViT-H/16, 32 blocks, 1280 wide, 1024 x 1024 input, windowed + 4 global attention blocks, neck to 256 x 64 x 64"}
+
+
+def exchange_summary(trainer, w: dict, world: int) -> dict:
+    """Bytes one rank SENDS per step in each collective of the active exchange mode -- so that the first real multi-GPU line can be
+    read without a profiler (ring all-reduce / reduce-scatter / all-gather move (W-1)/W of the buffer per rank, all-to-all the
+    share of the other ranks)."""
+    from samnerf_amd import ops as _ops
+    opt = trainer.optimizers
+    f = (world - 1) / max(world, 1)
+    out = {"world": world, "table_parallel": bool(_ops.TABLE_PARALLEL), "sharded_optimizer": bool(opt.sharded)}
+    tables_tp = 0
+    for k, a in opt.arenas.items():
+        tp = sum(t[1] - t[0] for t in opt._tp_tables(k))
+        tables_tp += tp
+        repl = a.numel - tp
+        # replicated part of the arena: reduce-scatter + all-gather (sharded) or one all-reduce -- 2 (W-1)/W x bytes either way
+        out[k] = {"replicated_params": int(repl), "table_parallel_params": int(tp), "grad_exchange_bytes": int(2 * f * repl * 4)}
+    if tables_tp:
+        nk = w["R"] * w["K"]
+        heads = 2 if w["method"] == "samnerf_distill" else 0
+        out["all_gather_positions_bytes"] = int(f * world * nk * 12)
+        out["all_to_all_features_bytes"] = int(heads * 2 * f * nk * 192 * 4)  # encodings forward + their gradient backward
+    out["total_bytes"] = int(sum(v["grad_exchange_bytes"] for v in out.values() if isinstance(v, dict))
+                             + out.get("all_gather_positions_bytes", 0) + out.get("all_to_all_features_bytes", 0))
+    return out
 
 
 def mfma_util() -> dict:
@@ -340,6 +453,9 @@ def main():
     trainer.optimizers.zero_grad_all()
     static_schedule = trainer._program is not None
     static_off = trainer._program_off
+    from samnerf_amd import _lib as _snf_lib
+    gemm_mode = int(_snf_lib.load().snf_get_gemm_mode())
+    exchange_bytes = exchange_summary(trainer, w, world) if multi else None
     n_arena_slots = adam_bytes(trainer)
     backend = dist.get_backend() if multi else None
 
@@ -352,6 +468,11 @@ def main():
         _free(trainer)
         for name in others_req.split(","):
             other_workloads[name] = quick_measure(name, rank, local_rank, world)
+        if world == 1 and args.workload == "distill_4096x128" and args.other_workloads is None:
+            # BASELINE configs[4] on one GPU: the patch-render eval pass and the SAM ViT-H encoder forward that produces its
+            # distillation targets (8 GPUs: the image's rays / the images shard over the ranks, no exchange in either)
+            other_workloads["render_512_patch64"] = render_measure(local_rank)
+            other_workloads["vit_h_1024"] = vit_measure()
 
     if rank == 0:
         R, S, K = w["R"], w["S"], w["K"]
@@ -365,10 +486,12 @@ def main():
             # Adam and the fused backward + Adam: bytes of the actual launches (reported by the launch sites)
             total_units = stat["units"] if stat.get("units", 0) > 0 else units * nl
             achieved = total_units / (total_ms * 1e-3) / (1e9 if bound == "hbm" else 1e12)
-            peak = HBM_PEAK_GBPS if bound == "hbm" else FP32_MATRIX_PEAK_TFLOPS
-            out = {"kernel": key, "bound": bound, "achieved": round(achieved, 2), "peak": peak, "unit": unit,
+            peak, basis = (HBM_PEAK_GBPS, "HBM3E") if bound == "hbm" else mfma_peak(key, gemm_mode)
+            out = {"kernel": key, "bound": bound, "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": unit,
                    "frac": round(achieved / peak, 4), "traffic": None, "avg_launch_ms": round(total_ms / max(nl, 1), 4),
                    "launches_timed": nl, "algorithmic_units_per_launch": total_units / max(nl, 1), "measured": where}
+            if bound != "hbm":
+                out["peak_basis"] = basis
             if key in mu:  # matrix-core busy cycles / shader busy cycles of this entry point's kernels (rocprofv3 PMC pass)
                 out["mfma_busy"] = mu[key]
             return out
@@ -421,7 +544,8 @@ def main():
             "roofline_other_kernels": others,
             "host": {"static_schedule": static_schedule, "static_schedule_off_reason": static_off},
             "rccl": {"backend": backend, "ranks": world, "collectives_on": bool(multi),
-                     "exchange": chosen_mode if multi else None, "exchange_modes_timed": exchange_modes},
+                     "exchange": chosen_mode if multi else None, "exchange_modes_timed": exchange_modes,
+                     "bytes_per_rank_per_step": exchange_bytes},
             "other_workloads": other_workloads,
             "stream_layout_probe_ms": {k: round(v, 3) for k, v in stream_probe.items()},
             "serial_step_ms": round(sum(per_step.values()), 3),

@@ -215,9 +215,25 @@ def test_composed_step_at_full_table_size_against_the_oracle(method, grad_parity
     prog.join_side_streams()
     torch.cuda.synchronize()
     out = prog.outputs()
-    keys = ("rgb", "sam", "clipseg") if distill else ("rgb",)
-    for k in keys:
-        assert float((out[k].cpu().reshape(ref[k].shape) - ref[k].detach()).abs().max()) <= 1e-4, k
+    assert float((out["rgb"].cpu().reshape(ref["rgb"].shape) - ref["rgb"].detach()).abs().max()) <= 1e-4
+    if distill:
+        # The feature heads render the K = 16 samples of a ray with the LARGEST weights (torch.topk, sam_model.py:244): a discrete
+        # choice.  Where the K-th and (K+1)-th weight of a ray agree to fp32 rounding (S = 128 candidates: one ray in ~500 --
+        # tools/debug_fullsize.py: 9.184467e-3 against 9.184429e-3, the HIP path's positions round the second to ...479) either
+        # sample is a correct answer of the reference's arithmetic and the rendered feature differs by that sample's share.
+        # Such rays are identified from the ORACLE's weights alone and left out of the comparison; there must be few of them.
+        wf = ref["weights_fine"].detach().reshape(R, S)
+        top = torch.sort(wf, dim=1, descending=True).values
+        tie = ((top[:, K - 1] - top[:, K]) <= 2e-5 * top[:, K - 1])
+        assert int(tie.sum()) <= max(2, R // 100), int(tie.sum())
+        for k in ("sam", "clipseg"):
+            got, want = out[k].cpu(), ref[k].detach()
+            keep = ~tie
+            if k == "sam" and patch > 1:  # one output row per p x p patch of rays
+                keep = ~tie.view(-1, patch * patch).any(dim=1)
+            err = (got.reshape(want.shape) - want).abs().reshape(want.shape[0], -1).max(dim=1).values
+            assert float(err[keep].max()) <= 1e-4, (k, float(err[keep].max()))
+            assert float(err.max()) <= 5e-3, (k, float(err.max()))  # a tied ray swaps one low-weight sample, nothing more
     for k, v in rl.items():
         assert abs(float(ld[k]) - float(v)) <= 1e-4 * max(1.0, abs(float(v))), k
     grads = named_grads(model)
