@@ -487,9 +487,189 @@ __device__ __forceinline__ void hg_adam1(float& p, float g, float& m, float& v, 
     p = p - a.step_size * (m / denom);
 }
 
+// ==========================================================================================
+// Reachable-row levels (round 3): fixed-point reduce over COMPACT row indices, Adam fused.
+//
+// A level of resolution s can only ever address the <= (s + 3)^3 rows its lattice hashes to (Encoding.active_rows, DESIGN 4.0).
+// On the coarse levels of a T = 19 table that is 19 ... ~900 of a bucket's 2048 rows, each receiving 100 ... 2 records of a
+// 65 536-sample step -- the regime where the float reduce above ranks hundreds of records on ONE LDS counter (same-address
+// atomics serialise: the eight such levels of a 16 -> 128 feature grid took as long as its four dense levels, which move 4x
+// the bytes) and where the plain fixed-point reduce piles its 64-bit atomics on a handful of addresses.
+// Here the bucket's reachable rows (a static, sorted list per (level, bucket)) get compact indices 0 .. nrows-1 through a
+// 2048-entry LDS lookup, and the accumulator array holds as many COPIES of the nrows x F sums as fit (lane j adds into copy
+// j mod copies; 64 copies when nrows <= 16: no two lanes of a wave ever share an address).  Integer sums commute, so the copies
+// are added in any order and the result stays exact and order-independent.  The epilogue applies Adam to exactly the reachable
+// rows -- zero gradient or not, like snf_adam_step_rows -- so these levels write no gradient and need no separate optimizer
+// pass; without ADAM the sums are added to the gradient table.
+// ==========================================================================================
+constexpr int HG_FX_BITS = 38;  // fixed-point resolution: 2^-38 of a level's largest |g| (see the fixed-point reduce below)
+constexpr int HG_SP_T = 512;
+template <int F> constexpr int hg_sp_acc_words() { return F == 8 ? 8192 : 4096; }  // 64-bit accumulators: 64 KB (F = 8), 32 KB (F = 2)
+template <int F> constexpr int hg_sp_max_rows() { return hg_sp_acc_words<F>() / F; }   // reachable rows per bucket this kernel takes
+
+template <int F> inline size_t hg_sp_lds_bytes(int log2rpb) {
+    return (size_t)hg_sp_acc_words<F>() * 8 + (size_t)hg_sp_acc_words<F>() / 32 * 4 + ((size_t)2 << log2rpb);
+}
+
+// The body is shared by the stand-alone kernel below and by k_hg_reduce, whose launches take the reachable-row levels of their
+// table(s) as ordinary (bucket, level) workgroups: the latency-bound compact reduce then runs BESIDE the bandwidth-bound
+// bucket-wide levels instead of in front of them (two launches in a row cost the paired backward 0.12 ms per step).
+// acc: ACC 64-bit words [(row * F + f) * copies + copy]; bad: ACC / 32 words; lookup: rpb half-words.
+template <int F>
+__device__ __forceinline__ void hg_sparse_body(const float* __restrict__ gT, int N, int log2_T, int log2B, int b, int l,
+                                               const uint32_t* __restrict__ bucket_start, const uint2* __restrict__ records,
+                                               float* __restrict__ grad_table, const uint32_t* __restrict__ reach_rows,
+                                               const uint32_t* __restrict__ reach_start,
+                                               const uint32_t* __restrict__ lvl_absmax_bits, const HgAdam& adam, bool adam_on,
+                                               unsigned long long* acc, uint32_t* bad, uint16_t* lookup) {
+    constexpr int ACC = hg_sp_acc_words<F>();
+    const int B = 1 << log2B, log2rpb = log2_T - log2B, rpb = 1 << log2rpb;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const uint32_t rs = reach_start[l * B + b];
+    const int nrows = (int)(reach_start[l * B + b + 1] - rs);
+    if (nrows <= 0) return;  // no row of this bucket can be addressed: no record lands here, nothing to step
+    const uint32_t start = bucket_start[l * (B + 1) + b], end = bucket_start[l * (B + 1) + b + 1];
+    if (!adam_on && start == end) return;
+    int copies = ACC / (nrows * F);
+    copies = copies >= 64 ? 64 : (copies < 1 ? 1 : 1 << (31 - __clz(copies)));  // power of two, at most one per lane
+    // layout acc[(row * F + f) * copies + copy]: the copies of one sum are ADJACENT 8-byte words, so the lanes of a wave that hit one
+    // row (the common case on a coarse level) spread over all LDS banks; with the copies strided by nrows * F words they fell
+    // into the same few banks (rows are 64 B: four bank groups) and the "conflict-free" atomics serialised 16-way
+    const uint32_t copy = (uint32_t)(lane & (copies - 1));
+    const int csh = 31 - __clz(copies);
+    for (int i = tid; i < rpb; i += HG_SP_T) lookup[i] = 0xFFFFu;
+    for (int i = tid; i < copies * nrows * F; i += HG_SP_T) acc[i] = 0ull;
+    for (int i = tid; i < (nrows * F + 31) / 32; i += HG_SP_T) bad[i] = 0u;
+    __syncthreads();
+    for (int i = tid; i < nrows; i += HG_SP_T) lookup[reach_rows[rs + i] & (uint32_t)(rpb - 1)] = (uint16_t)i;
+    int e = 0;
+    frexpf(__uint_as_float(lvl_absmax_bits[l]), &e);
+    int sh = HG_FX_BITS - e;
+    sh = sh > 120 ? 120 : sh;
+    const float scale = ldexpf(1.f, sh), inv = ldexpf(1.f, -sh);
+    const float* __restrict__ gl = gT + (size_t)l * N * F;
+    __syncthreads();
+    constexpr int U = 4;
+    const uint32_t mask_s = (1u << HG_SAMPLE_BITS) - 1u;
+    uint2 rec0[U], rec1[U];
+    float g0[U][F], g1[U][F];
+    auto load_recs = [&](uint32_t c0, uint2 (&r)[U]) {
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const uint32_t i = c0 + tid + (uint32_t)HG_SP_T * j;
+            r[j] = records[i < end ? i : (start < end ? start : 0u)];
+        }
+    };
+    auto gather = [&](const uint2 (&r)[U], float (&g)[U][F]) {
+#pragma unroll
+        for (int j = 0; j < U; ++j) load_row<F>(gl + (size_t)(r[j].x & mask_s) * F, g[j]);
+    };
+    constexpr uint32_t TRIP = HG_SP_T * U;
+    load_recs(start, rec0);
+    gather(rec0, g0);
+    if (start + TRIP < end) load_recs(start + TRIP, rec1);
+    for (uint32_t c0 = start; c0 < end; c0 += TRIP) {
+        uint2 rec2[U];
+        const bool has1 = c0 + TRIP < end, has2 = c0 + 2 * TRIP < end;
+        if (has1) gather(rec1, g1);
+        if (has2) load_recs(c0 + 2 * TRIP, rec2);
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const bool live = c0 + tid + (uint32_t)HG_SP_T * j < end;
+            const uint32_t idx = lookup[rec0[j].x >> HG_SAMPLE_BITS];
+            if (live && idx != 0xFFFFu) {
+                const float w = __uint_as_float(rec0[j].y);
+#pragma unroll
+                for (int f = 0; f < F; ++f) {
+                    const float v = w * g0[j][f];
+                    if (fabsf(v) < INFINITY) {
+                        const long long q = __float2ll_rn(v * scale);
+                        if (q != 0) atomicAdd(&acc[((idx * F + f) << csh) + copy], (unsigned long long)q);
+                    } else {
+                        const uint32_t eb = idx * F + f;
+                        atomicOr(&bad[eb >> 5], 1u << (eb & 31));
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            rec0[j] = rec1[j];
+            rec1[j] = rec2[j];
+#pragma unroll
+            for (int f = 0; f < F; ++f) g0[j][f] = g1[j][f];
+        }
+    }
+    __syncthreads();
+    // ---- epilogue: one thread per reachable row
+    for (int i = tid; i < nrows; i += HG_SP_T) {
+        const size_t o = (size_t)reach_rows[rs + i] * F;  // (the list holds (level << T) + row: an offset into the whole table)
+        float gg[F];
+        bool nz = false;
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+            const uint32_t eb = (uint32_t)(i * F + f);
+            unsigned long long qs = 0ull;
+            // (lane i starts at copy i: the lanes' reads then fall into different banks -- their elements are copies * 8 B apart)
+            for (int c = 0; c < copies; ++c) qs += acc[(eb << csh) + (((uint32_t)c + (uint32_t)lane) & (uint32_t)(copies - 1))];
+            const bool isbad = (bad[eb >> 5] >> (eb & 31)) & 1u;
+            gg[f] = isbad ? __uint_as_float(0x7FC00000u) : __ll2float_rn((long long)qs) * inv;
+            nz = nz || qs != 0ull || isbad;
+        }
+        if (adam_on) {
+            float pp[F], mm[F], vv[F];
+            load_row<F>(adam.p + o, pp);
+            load_row<F>(adam.m + o, mm);
+            load_row<F>(adam.v + o, vv);
+#pragma unroll
+            for (int f = 0; f < F; ++f) hg_adam1(pp[f], gg[f], mm[f], vv[f], adam);
+            if constexpr (F == 2) {
+                *reinterpret_cast<float2*>(adam.p + o) = make_float2(pp[0], pp[1]);
+                *reinterpret_cast<float2*>(adam.m + o) = make_float2(mm[0], mm[1]);
+                *reinterpret_cast<float2*>(adam.v + o) = make_float2(vv[0], vv[1]);
+            } else {
+                reinterpret_cast<float4*>(adam.p + o)[0] = make_float4(pp[0], pp[1], pp[2], pp[3]);
+                reinterpret_cast<float4*>(adam.p + o)[1] = make_float4(pp[4], pp[5], pp[6], pp[7]);
+                reinterpret_cast<float4*>(adam.m + o)[0] = make_float4(mm[0], mm[1], mm[2], mm[3]);
+                reinterpret_cast<float4*>(adam.m + o)[1] = make_float4(mm[4], mm[5], mm[6], mm[7]);
+                reinterpret_cast<float4*>(adam.v + o)[0] = make_float4(vv[0], vv[1], vv[2], vv[3]);
+                reinterpret_cast<float4*>(adam.v + o)[1] = make_float4(vv[4], vv[5], vv[6], vv[7]);
+            }
+        } else if (nz) {
+            row_rmw<F>(grad_table + o, gg);
+        }
+    }
+}
+
+
+template <int F, bool ADAM>
+__global__ __launch_bounds__(HG_SP_T) void k_hg_reduce_sparse(const float* __restrict__ gT, int N, int log2_T, int log2B,
+                                                              const uint32_t* __restrict__ bucket_start,
+                                                              const uint2* __restrict__ records, float* __restrict__ grad_table,
+                                                              const uint32_t* __restrict__ reach_rows,
+                                                              const uint32_t* __restrict__ reach_start,
+                                                              const uint32_t* __restrict__ lvl_absmax_bits, HgAdam adam) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long sp_lds[];
+    constexpr int ACC = hg_sp_acc_words<F>();
+    unsigned long long* acc = sp_lds;
+    uint32_t* bad = reinterpret_cast<uint32_t*>(acc + ACC);
+    uint16_t* lookup = reinterpret_cast<uint16_t*>(bad + ACC / 32);
+    hg_sparse_body<F>(gT, N, log2_T, log2B, (int)blockIdx.x, (int)blockIdx.y, bucket_start, records, grad_table, reach_rows,
+                      reach_start, lvl_absmax_bits, adam, ADAM, acc, bad, lookup);
+}
+
 // A second grid in the same launch (snf_hashgrid_bwd_presorted_adam_pair: the two F = 8 grids of a feature head, same N / T):
 // blockIdx.y covers the levels of both; with `interleave` (equal level counts) even y = first grid, odd y = second, so the
 // latency-bound reachable-row levels of one grid are resident together with the bandwidth-bound dense levels of the other.
+// the reachable-row levels of a table handled inside a k_hg_reduce launch (levels [0, levels) of that table)
+struct HgSparseDev {
+    const uint32_t* rows;
+    const uint32_t* start;
+    const uint32_t* lvlmax;  // per-level largest finite |g| (bits), from k_hg_level_absmax
+    int levels;
+    int step;                // apply Adam to the listed rows (else: add the sums to the gradient table)
+};
+
 struct HgSecond {
     const float* gT;
     const uint32_t* bucket_start;
@@ -498,7 +678,8 @@ struct HgSecond {
     HgAdam adam;
     int first_levels;  // levels of the first grid IN THIS LAUNCH; >= gridDim.y: there is no second grid
     int interleave;
-    int level0;        // first level of the second grid covered by this launch (its leading levels went to k_hg_reduce_sparse)
+    int level0;        // first level of the second grid covered by this launch
+    HgSparseDev sp;    // its reachable-row levels
 };
 
 #ifndef SNF_HG_RT_MINWG
@@ -510,7 +691,8 @@ template <int F, bool ADAM>
 __global__ __launch_bounds__(HG_RT, SNF_HG_RT_MINWG) void k_hg_reduce(const float* __restrict__ gT, int N, int log2_T, int log2B,
                                                      const uint32_t* __restrict__ bucket_start,
                                                      const uint2* __restrict__ records, float* __restrict__ grad_table,
-                                                     uint32_t hg_long, int n_run_levels, int level0, HgAdam adam, HgSecond sec) {
+                                                     uint32_t hg_long, int n_run_levels, int level0, HgAdam adam, HgSparseDev sp,
+                                                     HgSecond sec) {
     constexpr int CHUNK = hg_chunk<F>();
     constexpr int RPT = CHUNK / HG_RT;
     __shared__ uint32_t cnt[HG_MAX_RPB + 1];  // per-row counts, then exclusive offsets
@@ -534,9 +716,22 @@ __global__ __launch_bounds__(HG_RT, SNF_HG_RT_MINWG) void k_hg_reduce(const floa
         if (second) {
             gT = sec.gT; bucket_start = sec.bucket_start; records = sec.records; grad_table = sec.grad_table; adam = sec.adam;
             level0 = sec.level0;
+            sp = sec.sp;
         }
     }
     l += level0;  // (a launch may cover the level sub-range [level0, level0 + n) of its table; all indices below are absolute)
+    if constexpr (F == 8) {
+        if (l < sp.levels) {
+            // a reachable-row level of this table: the compact fixed-point reduce, in the LDS of the sort machinery (val = the 8192
+            // accumulators, cnt = lookup + flags) -- a latency-bound workgroup beside the bandwidth-bound ones of the other levels
+            static_assert(sizeof(val) >= (size_t)hg_sp_acc_words<8>() * 8 && sizeof(cnt) >= HG_MAX_RPB * 2 + hg_sp_acc_words<8>() / 8,
+                          "the compact reduce does not fit the float reduce's LDS");
+            hg_sparse_body<8>(gT, N, log2_T, log2B, b, l, bucket_start, records, grad_table, sp.rows, sp.start, sp.lvlmax, adam,
+                              sp.step != 0, reinterpret_cast<unsigned long long*>(val), cnt + HG_MAX_RPB / 2,
+                              reinterpret_cast<uint16_t*>(cnt));
+            return;
+        }
+    }
     const int lane = tid & 63, wave = tid >> 6;
     const uint32_t start = bucket_start[l * (B + 1) + b], end = bucket_start[l * (B + 1) + b + 1];
     const bool fuse = ADAM && l >= adam.from_level;
@@ -819,7 +1014,6 @@ __global__ __launch_bounds__(HG_RT, SNF_HG_RT_MINWG) void k_hg_reduce(const floa
 #define SNF_FX_T 512
 #endif
 constexpr int HG_FX_T = SNF_FX_T;
-constexpr int HG_FX_BITS = 38;
 
 template <int F>
 __global__ __launch_bounds__(256) void k_hg_level_absmax(const float* __restrict__ gT, int N, uint32_t* __restrict__ out_bits) {
@@ -1099,159 +1293,6 @@ __global__ __launch_bounds__(HG_FX_T) void k_hg_reduce_fx(const float* __restric
     }
 }
 
-// ==========================================================================================
-// Reachable-row levels (round 3): fixed-point reduce over COMPACT row indices, Adam fused.
-//
-// A level of resolution s can only ever address the <= (s + 3)^3 rows its lattice hashes to (Encoding.active_rows, DESIGN 4.0).
-// On the coarse levels of a T = 19 table that is 19 ... ~900 of a bucket's 2048 rows, each receiving 100 ... 2 records of a
-// 65 536-sample step -- the regime where the float reduce above ranks hundreds of records on ONE LDS counter (same-address
-// atomics serialise: the eight such levels of a 16 -> 128 feature grid took as long as its four dense levels, which move 4x
-// the bytes) and where the plain fixed-point reduce piles its 64-bit atomics on a handful of addresses.
-// Here the bucket's reachable rows (a static, sorted list per (level, bucket)) get compact indices 0 .. nrows-1 through a
-// 2048-entry LDS lookup, and the accumulator array holds as many COPIES of the nrows x F sums as fit (lane j adds into copy
-// j mod copies; 64 copies when nrows <= 16: no two lanes of a wave ever share an address).  Integer sums commute, so the copies
-// are added in any order and the result stays exact and order-independent.  The epilogue applies Adam to exactly the reachable
-// rows -- zero gradient or not, like snf_adam_step_rows -- so these levels write no gradient and need no separate optimizer
-// pass; without ADAM the sums are added to the gradient table.
-// ==========================================================================================
-constexpr int HG_SP_T = 512;
-template <int F> constexpr int hg_sp_acc_words() { return F == 8 ? 8192 : 4096; }  // 64-bit accumulators: 64 KB (F = 8), 32 KB (F = 2)
-template <int F> constexpr int hg_sp_max_rows() { return hg_sp_acc_words<F>() / F; }   // reachable rows per bucket this kernel takes
-
-template <int F> inline size_t hg_sp_lds_bytes(int log2rpb) {
-    return (size_t)hg_sp_acc_words<F>() * 8 + (size_t)hg_sp_acc_words<F>() / 32 * 4 + ((size_t)2 << log2rpb);
-}
-
-template <int F, bool ADAM>
-__global__ __launch_bounds__(HG_SP_T) void k_hg_reduce_sparse(const float* __restrict__ gT, int N, int log2_T, int log2B,
-                                                              const uint32_t* __restrict__ bucket_start,
-                                                              const uint2* __restrict__ records, float* __restrict__ grad_table,
-                                                              const uint32_t* __restrict__ reach_rows,
-                                                              const uint32_t* __restrict__ reach_start,
-                                                              const uint32_t* __restrict__ lvl_absmax_bits, HgAdam adam) {
-    extern __shared__ __attribute__((aligned(16))) unsigned long long sp_lds[];
-    constexpr int ACC = hg_sp_acc_words<F>();
-    unsigned long long* acc = sp_lds;                                    // [copies][nrows][F]
-    uint32_t* bad = reinterpret_cast<uint32_t*>(acc + ACC);               // one bit per (row, feature): non-finite contribution
-    uint16_t* lookup = reinterpret_cast<uint16_t*>(bad + ACC / 32);       // row in bucket -> compact index (0xFFFF: unreachable)
-    const int B = 1 << log2B, log2rpb = log2_T - log2B, rpb = 1 << log2rpb;
-    const int tid = threadIdx.x, lane = tid & 63, b = blockIdx.x, l = blockIdx.y;
-    const uint32_t rs = reach_start[l * B + b];
-    const int nrows = (int)(reach_start[l * B + b + 1] - rs);
-    if (nrows <= 0) return;  // no row of this bucket can be addressed: no record lands here, nothing to step
-    const uint32_t start = bucket_start[l * (B + 1) + b], end = bucket_start[l * (B + 1) + b + 1];
-    if (!ADAM && start == end) return;
-    int copies = ACC / (nrows * F);
-    copies = copies >= 64 ? 64 : (copies < 1 ? 1 : 1 << (31 - __clz(copies)));  // power of two, at most one per lane
-    // layout acc[(row * F + f) * copies + copy]: the copies of one sum are ADJACENT 8-byte words, so the lanes of a wave that hit one
-    // row (the common case on a coarse level) spread over all LDS banks; with the copies strided by nrows * F words they fell
-    // into the same few banks (rows are 64 B: four bank groups) and the "conflict-free" atomics serialised 16-way
-    const uint32_t copy = (uint32_t)(lane & (copies - 1));
-    const int csh = 31 - __clz(copies);
-    for (int i = tid; i < rpb; i += HG_SP_T) lookup[i] = 0xFFFFu;
-    for (int i = tid; i < copies * nrows * F; i += HG_SP_T) acc[i] = 0ull;
-    for (int i = tid; i < (nrows * F + 31) / 32; i += HG_SP_T) bad[i] = 0u;
-    __syncthreads();
-    for (int i = tid; i < nrows; i += HG_SP_T) lookup[reach_rows[rs + i] & (uint32_t)(rpb - 1)] = (uint16_t)i;
-    int e = 0;
-    frexpf(__uint_as_float(lvl_absmax_bits[l]), &e);
-    int sh = HG_FX_BITS - e;
-    sh = sh > 120 ? 120 : sh;
-    const float scale = ldexpf(1.f, sh), inv = ldexpf(1.f, -sh);
-    const float* __restrict__ gl = gT + (size_t)l * N * F;
-    __syncthreads();
-    constexpr int U = 4;
-    const uint32_t mask_s = (1u << HG_SAMPLE_BITS) - 1u;
-    uint2 rec0[U], rec1[U];
-    float g0[U][F], g1[U][F];
-    auto load_recs = [&](uint32_t c0, uint2 (&r)[U]) {
-#pragma unroll
-        for (int j = 0; j < U; ++j) {
-            const uint32_t i = c0 + tid + (uint32_t)HG_SP_T * j;
-            r[j] = records[i < end ? i : (start < end ? start : 0u)];
-        }
-    };
-    auto gather = [&](const uint2 (&r)[U], float (&g)[U][F]) {
-#pragma unroll
-        for (int j = 0; j < U; ++j) load_row<F>(gl + (size_t)(r[j].x & mask_s) * F, g[j]);
-    };
-    constexpr uint32_t TRIP = HG_SP_T * U;
-    load_recs(start, rec0);
-    gather(rec0, g0);
-    if (start + TRIP < end) load_recs(start + TRIP, rec1);
-    for (uint32_t c0 = start; c0 < end; c0 += TRIP) {
-        uint2 rec2[U];
-        const bool has1 = c0 + TRIP < end, has2 = c0 + 2 * TRIP < end;
-        if (has1) gather(rec1, g1);
-        if (has2) load_recs(c0 + 2 * TRIP, rec2);
-#pragma unroll
-        for (int j = 0; j < U; ++j) {
-            const bool live = c0 + tid + (uint32_t)HG_SP_T * j < end;
-            const uint32_t idx = lookup[rec0[j].x >> HG_SAMPLE_BITS];
-            if (live && idx != 0xFFFFu) {
-                const float w = __uint_as_float(rec0[j].y);
-#pragma unroll
-                for (int f = 0; f < F; ++f) {
-                    const float v = w * g0[j][f];
-                    if (fabsf(v) < INFINITY) {
-                        const long long q = __float2ll_rn(v * scale);
-                        if (q != 0) atomicAdd(&acc[((idx * F + f) << csh) + copy], (unsigned long long)q);
-                    } else {
-                        const uint32_t eb = idx * F + f;
-                        atomicOr(&bad[eb >> 5], 1u << (eb & 31));
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < U; ++j) {
-            rec0[j] = rec1[j];
-            rec1[j] = rec2[j];
-#pragma unroll
-            for (int f = 0; f < F; ++f) g0[j][f] = g1[j][f];
-        }
-    }
-    __syncthreads();
-    // ---- epilogue: one thread per reachable row
-    for (int i = tid; i < nrows; i += HG_SP_T) {
-        const size_t o = (size_t)reach_rows[rs + i] * F;  // (the list holds (level << T) + row: an offset into the whole table)
-        float gg[F];
-        bool nz = false;
-#pragma unroll
-        for (int f = 0; f < F; ++f) {
-            const uint32_t eb = (uint32_t)(i * F + f);
-            unsigned long long qs = 0ull;
-            // (lane i starts at copy i: the lanes' reads then fall into different banks -- their elements are copies * 8 B apart)
-            for (int c = 0; c < copies; ++c) qs += acc[(eb << csh) + (((uint32_t)c + (uint32_t)lane) & (uint32_t)(copies - 1))];
-            const bool isbad = (bad[eb >> 5] >> (eb & 31)) & 1u;
-            gg[f] = isbad ? __uint_as_float(0x7FC00000u) : __ll2float_rn((long long)qs) * inv;
-            nz = nz || qs != 0ull || isbad;
-        }
-        if constexpr (ADAM) {
-            float pp[F], mm[F], vv[F];
-            load_row<F>(adam.p + o, pp);
-            load_row<F>(adam.m + o, mm);
-            load_row<F>(adam.v + o, vv);
-#pragma unroll
-            for (int f = 0; f < F; ++f) hg_adam1(pp[f], gg[f], mm[f], vv[f], adam);
-            if constexpr (F == 2) {
-                *reinterpret_cast<float2*>(adam.p + o) = make_float2(pp[0], pp[1]);
-                *reinterpret_cast<float2*>(adam.m + o) = make_float2(mm[0], mm[1]);
-                *reinterpret_cast<float2*>(adam.v + o) = make_float2(vv[0], vv[1]);
-            } else {
-                reinterpret_cast<float4*>(adam.p + o)[0] = make_float4(pp[0], pp[1], pp[2], pp[3]);
-                reinterpret_cast<float4*>(adam.p + o)[1] = make_float4(pp[4], pp[5], pp[6], pp[7]);
-                reinterpret_cast<float4*>(adam.m + o)[0] = make_float4(mm[0], mm[1], mm[2], mm[3]);
-                reinterpret_cast<float4*>(adam.m + o)[1] = make_float4(mm[4], mm[5], mm[6], mm[7]);
-                reinterpret_cast<float4*>(adam.v + o)[0] = make_float4(vv[0], vv[1], vv[2], vv[3]);
-                reinterpret_cast<float4*>(adam.v + o)[1] = make_float4(vv[4], vv[5], vv[6], vv[7]);
-            }
-        } else if (nz) {
-            row_rmw<F>(grad_table + o, gg);
-        }
-    }
-}
-
 }  // namespace snf
 
 using namespace snf;
@@ -1461,10 +1502,19 @@ static void hg_reduce_one(hipStream_t st, int F, const float* stage, int N, int 
         if (F == 2) hipLaunchKernelGGL(k_hg_level_absmax<2>, dim3(hg_absmax_blocks(N, F), nfx), dim3(256), 0, st, stage, N, lvlmax);
         else hipLaunchKernelGGL(k_hg_level_absmax<8>, dim3(hg_absmax_blocks(N, F), nfx), dim3(256), 0, st, stage, N, lvlmax);
     }
-    if (s0 > 0) {
-        if (F == 2) hg_launch_sparse<2>(st, stage, N, log2_T, g, w, grad_table, sp, lvlmax, sparse_step, a);
-        else hg_launch_sparse<8>(st, stage, N, log2_T, g, w, grad_table, sp, lvlmax, sparse_step, a);
+    if (F == 8 && s0 > 0) {
+        // one launch for the whole table: its reachable-row levels are workgroups of the same grid (compact reduce in the float
+        // reduce's LDS), resident beside the bucket-wide levels
+        const HgSparseDev sd{sp.rows, sp.start, lvlmax, s0, sparse_step ? 1 : 0};
+        if (adam_on || sparse_step)
+            hipLaunchKernelGGL((k_hg_reduce<8, true>), dim3(B, L), dim3(HG_RT), 0, st, stage, N, log2_T, g.log2B, w.bstart,
+                               (const uint2*)w.records, grad_table, hg_long, 0, 0, a, sd, hg_no_second());
+        else
+            hipLaunchKernelGGL((k_hg_reduce<8, false>), dim3(B, L), dim3(HG_RT), 0, st, stage, N, log2_T, g.log2B, w.bstart,
+                               (const uint2*)w.records, grad_table, hg_long, 0, 0, a, sd, hg_no_second());
+        return;
     }
+    if (s0 > 0) hg_launch_sparse<2>(st, stage, N, log2_T, g, w, grad_table, sp, lvlmax, sparse_step, a);
     const int Lr = L - s0;
     if (Lr <= 0) return;
     const int nrun = n_run_levels > s0 ? n_run_levels - s0 : 0;  // (relative to the launch)
@@ -1478,17 +1528,17 @@ static void hg_reduce_one(hipStream_t st, int F, const float* stage, int N, int 
     } else if (F == 2) {
         if (adam_on)
             hipLaunchKernelGGL((k_hg_reduce<2, true>), dim3(B, Lr), dim3(HG_RT), 0, st, stage, N, log2_T, g.log2B, w.bstart,
-                               (const uint2*)w.records, grad_table, hg_long, nrun, s0, a, hg_no_second());
+                               (const uint2*)w.records, grad_table, hg_long, nrun, s0, a, HgSparseDev{}, hg_no_second());
         else
             hipLaunchKernelGGL((k_hg_reduce<2, false>), dim3(B, Lr), dim3(HG_RT), 0, st, stage, N, log2_T, g.log2B, w.bstart,
-                               (const uint2*)w.records, grad_table, hg_long, nrun, s0, HgAdam{}, hg_no_second());
+                               (const uint2*)w.records, grad_table, hg_long, nrun, s0, HgAdam{}, HgSparseDev{}, hg_no_second());
     } else {
         if (adam_on)
             hipLaunchKernelGGL((k_hg_reduce<8, true>), dim3(B, Lr), dim3(HG_RT), 0, st, stage, N, log2_T, g.log2B, w.bstart,
-                               (const uint2*)w.records, grad_table, hg_long, nrun, s0, a, hg_no_second());
+                               (const uint2*)w.records, grad_table, hg_long, nrun, s0, a, HgSparseDev{}, hg_no_second());
         else
             hipLaunchKernelGGL((k_hg_reduce<8, false>), dim3(B, Lr), dim3(HG_RT), 0, st, stage, N, log2_T, g.log2B, w.bstart,
-                               (const uint2*)w.records, grad_table, hg_long, nrun, s0, HgAdam{}, hg_no_second());
+                               (const uint2*)w.records, grad_table, hg_long, nrun, s0, HgAdam{}, HgSparseDev{}, hg_no_second());
     }
 }
 
@@ -1616,43 +1666,28 @@ extern "C" int snf_hashgrid_bwd_presorted_adam_pair(const float* grad_out0, cons
     HgSecond s2{};
     s2.gT = grad_out1; s2.bucket_start = w1.bstart; s2.records = (const uint2*)w1.records; s2.grad_table = grad_table1;
     hg_fill_adam(s2.adam, param1, exp_avg1, exp_avg_sq1, lr, beta1, beta2, eps, step, grad_scale, fuse_from_level1);
-    // ---- reachable-row levels: per table, fixed-point over compact rows (their largest |g| per level first)
+    // ---- reachable-row levels: fixed-point over compact rows, as workgroups of the SAME launch (their largest |g| per level first)
     uint32_t* lvlmax = (uint32_t*)scratch;
     if (sparse_levels0 + sparse_levels1 > 0) (void)hipMemsetAsync(lvlmax, 0, (size_t)(sparse_levels0 + sparse_levels1) * sizeof(uint32_t), st);
-    if (sparse_levels0 > 0) {
+    if (sparse_levels0 > 0)
         hipLaunchKernelGGL(k_hg_level_absmax<8>, dim3(hg_absmax_blocks(N, 8), sparse_levels0), dim3(256), 0, st, grad_out0, N, lvlmax);
-        hg_launch_sparse<8>(st, grad_out0, N, log2_T, g, w0, grad_table0, HgSparse{reach_rows0, reach_start0, sparse_levels0}, lvlmax, on0, a);
-    }
-    if (sparse_levels1 > 0) {
+    if (sparse_levels1 > 0)
         hipLaunchKernelGGL(k_hg_level_absmax<8>, dim3(hg_absmax_blocks(N, 8), sparse_levels1), dim3(256), 0, st, grad_out1, N,
                            lvlmax + sparse_levels0);
-        hg_launch_sparse<8>(st, grad_out1, N, log2_T, g, w1, grad_table1, HgSparse{reach_rows1, reach_start1, sparse_levels1},
-                            lvlmax + sparse_levels0, on1, s2.adam);
-    }
-    // ---- bucket-wide levels of both tables in one launch
-    const int r0 = L0 - sparse_levels0, r1 = L1 - sparse_levels1;
-    if (r0 + r1 > 0) {
-        static const int interleave = getenv("SNF_HG_PAIR_INTERLEAVE") ? atoi(getenv("SNF_HG_PAIR_INTERLEAVE")) : 1;
-        s2.first_levels = r0;
-        s2.interleave = (interleave && r0 == r1) ? 1 : 0;
-        s2.level0 = sparse_levels1;
-        const float* gfirst = grad_out0;
-        int lvl0 = sparse_levels0;
-        if (r0 == 0) {  // only the second table has bucket-wide levels: it becomes the launch's (single) table
-            a = s2.adam; gfirst = grad_out1; lvl0 = sparse_levels1;
-            s2 = hg_no_second();
-        } else if (r1 == 0) {
-            s2 = hg_no_second();
-        }
-        const HgWs& wf = (r0 == 0) ? w1 : w0;
-        float* gtf = (r0 == 0) ? grad_table1 : grad_table0;
-        if (fuse_from_level0 >= L0 && fuse_from_level1 >= L1)  // nothing bucket-wide to step: plain gradient accumulation
-            hipLaunchKernelGGL((k_hg_reduce<8, false>), dim3(B, r0 + r1), dim3(HG_RT), 0, st, gfirst, N, log2_T, g.log2B, wf.bstart,
-                               (const uint2*)wf.records, gtf, hg_long, 0, lvl0, a, s2);
-        else
-            hipLaunchKernelGGL((k_hg_reduce<8, true>), dim3(B, r0 + r1), dim3(HG_RT), 0, st, gfirst, N, log2_T, g.log2B, wf.bstart,
-                               (const uint2*)wf.records, gtf, hg_long, 0, lvl0, a, s2);
-    }
+    const HgSparseDev sd0{reach_rows0, reach_start0, lvlmax, sparse_levels0, on0 ? 1 : 0};
+    s2.sp = HgSparseDev{reach_rows1, reach_start1, lvlmax + sparse_levels0, sparse_levels1, on1 ? 1 : 0};
+    static const int interleave = getenv("SNF_HG_PAIR_INTERLEAVE") ? atoi(getenv("SNF_HG_PAIR_INTERLEAVE")) : 1;
+    s2.first_levels = L0;
+    s2.interleave = (interleave && L0 == L1) ? 1 : 0;
+    s2.level0 = 0;
+    // (ADAM instantiation whenever anything is stepped: bucket-wide levels >= fuse_from_level, or reachable-row levels with sparse_step)
+    const bool any_step = fuse_from_level0 < L0 || fuse_from_level1 < L1 || (sparse_step && sparse_levels0 + sparse_levels1 > 0);
+    if (!any_step)
+        hipLaunchKernelGGL((k_hg_reduce<8, false>), dim3(B, L0 + L1), dim3(HG_RT), 0, st, grad_out0, N, log2_T, g.log2B, w0.bstart,
+                           (const uint2*)w0.records, grad_table0, hg_long, 0, 0, a, sd0, s2);
+    else
+        hipLaunchKernelGGL((k_hg_reduce<8, true>), dim3(B, L0 + L1), dim3(HG_RT), 0, st, grad_out0, N, log2_T, g.log2B, w0.bstart,
+                           (const uint2*)w0.records, grad_table0, hg_long, 0, 0, a, sd0, s2);
     SNF_LAUNCH_CHECK("snf_hashgrid_bwd_presorted_adam_pair");
     return SNF_OK;
 }
