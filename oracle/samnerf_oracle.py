@@ -303,9 +303,14 @@ def render_depth_median(weights: torch.Tensor, ebins: torch.Tensor) -> torch.Ten
 # --------------------------------------------------------------------------------------------
 # a16 top-K select + sharpen    samnerf/sam_model.py:244-255
 # --------------------------------------------------------------------------------------------
-def topk_sharpen(weights: torch.Tensor, k: int, temperature: float = 10.0):
-    """weights [R,S] -> (sam_weights [R,K] (may contain NaN rows), ids [R,K])."""
-    w_k, ids = torch.topk(weights, k, dim=-1, sorted=False)
+def topk_sharpen(weights: torch.Tensor, k: int, temperature: float = 10.0, ids: Optional[torch.Tensor] = None):
+    """weights [R,S] -> (sam_weights [R,K] (may contain NaN rows), ids [R,K]).
+    ids (test infrastructure only): a selection to use INSTEAD of torch.topk's, for rays whose K-th and (K+1)-th weights agree to
+    fp32 rounding -- there both choices are answers of the reference's arithmetic and a comparison has to fix one of them."""
+    if ids is None:
+        w_k, ids = torch.topk(weights, k, dim=-1, sorted=False)
+    else:
+        w_k = torch.gather(weights, -1, ids)
     w_k = w_k**temperature
     w_k = w_k / w_k.sum(dim=-1, keepdim=True)
     return w_k, ids
@@ -525,7 +530,7 @@ def conv_head(params, feat: torch.Tensor, patch: int) -> torch.Tensor:
 def forward(params: Dict[str, torch.Tensor], cfg: PathConfig, origins, directions, training: bool,
             t_rand: Optional[torch.Tensor] = None, u_rand: Optional[torch.Tensor] = None,
             anneal: float = 1.0, prop_requires_grad: bool = True,
-            get_feature: Sequence[str] = ("sam", "clipseg")) -> Dict[str, torch.Tensor]:
+            get_feature: Sequence[str] = ("sam", "clipseg"), topk_ids: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
     """SAMModel.forward/get_outputs.  samnerf/sam_model.py:226-314.
 
     t_rand/u_rand: the two per-ray jitters ([R,1]) the reference draws with torch.rand in training
@@ -559,7 +564,7 @@ def forward(params: Dict[str, torch.Tensor], cfg: PathConfig, origins, direction
     out["density_fine"], out["rgb_samples"] = dens_f, rgb_f
     # --- feature branch
     if cfg.distill_sam and len(get_feature) > 0:
-        w_k, ids = topk_sharpen(w_f, cfg.num_sam_samples, cfg.sharpening_temperature)
+        w_k, ids = topk_sharpen(w_f, cfg.num_sam_samples, cfg.sharpening_temperature, topk_ids)
         st, en = gather_samples(eb_f, ids)
         pos_k = origins[:, None, :] + directions[:, None, :] * ((st + en) / 2)[..., None]
         out["sam_weights"], out["sam_ids"] = w_k, ids

@@ -542,13 +542,7 @@ __device__ __forceinline__ void hg_sparse_body(const float* __restrict__ gT, int
     for (int i = tid; i < (nrows * F + 31) / 32; i += HG_SP_T) bad[i] = 0u;
     __syncthreads();
     for (int i = tid; i < nrows; i += HG_SP_T) lookup[reach_rows[rs + i] & (uint32_t)(rpb - 1)] = (uint16_t)i;
-    int e = 0;
-    frexpf(__uint_as_float(lvl_absmax_bits[l]), &e);
-    int sh = HG_FX_BITS - e;
-    sh = sh > 120 ? 120 : sh;
-    const float scale = ldexpf(1.f, sh), inv = ldexpf(1.f, -sh);
     const float* __restrict__ gl = gT + (size_t)l * N * F;
-    __syncthreads();
     constexpr int U = 4;
     const uint32_t mask_s = (1u << HG_SAMPLE_BITS) - 1u;
     uint2 rec0[U], rec1[U];
@@ -565,8 +559,49 @@ __device__ __forceinline__ void hg_sparse_body(const float* __restrict__ gT, int
         for (int j = 0; j < U; ++j) load_row<F>(gl + (size_t)(r[j].x & mask_s) * F, g[j]);
     };
     constexpr uint32_t TRIP = HG_SP_T * U;
+    // ---- the fixed-point scale: 2^e above the largest finite |w g| of THIS bucket's records.  The rows of a bucket belong to one
+    // workgroup, so its own maximum is all the scale has to cover (finer than the level-wide maximum of the bucket-wide fixed-point
+    // kernel, and no pre-pass over the staged gradient: two launches less in front of every table backward).  At the step's sizes a
+    // bucket's records are one trip, held in registers for the accumulation below; longer buckets stream their records twice.
+    auto trip_max = [&](uint32_t c0, const uint2 (&r)[U], const float (&g)[U][F]) {
+        float m = 0.f;
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            if (c0 + tid + (uint32_t)HG_SP_T * j < end) {
+                const float w = fabsf(__uint_as_float(r[j].y));
+#pragma unroll
+                for (int f = 0; f < F; ++f) {
+                    const float v = w * fabsf(g[j][f]);
+                    if (v < INFINITY && v > m) m = v;  // (NaN fails both comparisons)
+                }
+            }
+        }
+        return m;
+    };
     load_recs(start, rec0);
     gather(rec0, g0);
+    float lmax = trip_max(start, rec0, g0);
+    const bool single = start + TRIP >= end;
+    if (!single) {
+        for (uint32_t c0 = start + TRIP; c0 < end; c0 += TRIP) {
+            load_recs(c0, rec1);
+            gather(rec1, g1);
+            lmax = fmaxf(lmax, trip_max(c0, rec1, g1));
+        }
+    }
+#pragma unroll
+    for (int dlt = 32; dlt > 0; dlt >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, dlt, 64));
+    __shared__ float sp_wmax[HG_SP_T / 64];
+    if (lane == 0) sp_wmax[tid >> 6] = lmax;
+    __syncthreads();  // (also: the lookup table is complete)
+#pragma unroll
+    for (int q = 0; q < HG_SP_T / 64; ++q) lmax = fmaxf(lmax, sp_wmax[q]);
+    int e = 0;
+    frexpf(lmax, &e);
+    int sh = HG_FX_BITS - e;
+    sh = sh > 120 ? 120 : sh;
+    const float scale = ldexpf(1.f, sh), inv = ldexpf(1.f, -sh);
+    (void)lvl_absmax_bits;
     if (start + TRIP < end) load_recs(start + TRIP, rec1);
     for (uint32_t c0 = start; c0 < end; c0 += TRIP) {
         uint2 rec2[U];
@@ -1496,7 +1531,7 @@ static void hg_reduce_one(hipStream_t st, int F, const float* stage, int N, int 
     static const uint32_t hg_long = getenv("SNF_HG_LONG") ? (uint32_t)atoi(getenv("SNF_HG_LONG")) : (uint32_t)HG_LONG;
     const bool fx = hg_fx_on(F, L, N);
     const int s0 = sp.levels;  // first level of the bucket-wide kernels
-    const int nfx = fx ? L : s0;  // levels whose largest |g| the fixed-point kernels need
+    const int nfx = fx ? L : 0;  // levels whose largest |g| the bucket-wide fixed-point kernel needs (the compact reduce finds its own)
     if (nfx > 0) {
         (void)hipMemsetAsync(lvlmax, 0, nfx * sizeof(uint32_t), st);
         if (F == 2) hipLaunchKernelGGL(k_hg_level_absmax<2>, dim3(hg_absmax_blocks(N, F), nfx), dim3(256), 0, st, stage, N, lvlmax);
@@ -1667,13 +1702,7 @@ extern "C" int snf_hashgrid_bwd_presorted_adam_pair(const float* grad_out0, cons
     s2.gT = grad_out1; s2.bucket_start = w1.bstart; s2.records = (const uint2*)w1.records; s2.grad_table = grad_table1;
     hg_fill_adam(s2.adam, param1, exp_avg1, exp_avg_sq1, lr, beta1, beta2, eps, step, grad_scale, fuse_from_level1);
     // ---- reachable-row levels: fixed-point over compact rows, as workgroups of the SAME launch (their largest |g| per level first)
-    uint32_t* lvlmax = (uint32_t*)scratch;
-    if (sparse_levels0 + sparse_levels1 > 0) (void)hipMemsetAsync(lvlmax, 0, (size_t)(sparse_levels0 + sparse_levels1) * sizeof(uint32_t), st);
-    if (sparse_levels0 > 0)
-        hipLaunchKernelGGL(k_hg_level_absmax<8>, dim3(hg_absmax_blocks(N, 8), sparse_levels0), dim3(256), 0, st, grad_out0, N, lvlmax);
-    if (sparse_levels1 > 0)
-        hipLaunchKernelGGL(k_hg_level_absmax<8>, dim3(hg_absmax_blocks(N, 8), sparse_levels1), dim3(256), 0, st, grad_out1, N,
-                           lvlmax + sparse_levels0);
+    uint32_t* lvlmax = (uint32_t*)scratch;  // (unused by the compact reduce since it scales per bucket; kept in the signature)
     const HgSparseDev sd0{reach_rows0, reach_start0, lvlmax, sparse_levels0, on0 ? 1 : 0};
     s2.sp = HgSparseDev{reach_rows1, reach_start1, lvlmax + sparse_levels0, sparse_levels1, on1 ? 1 : 0};
     static const int interleave = getenv("SNF_HG_PAIR_INTERLEAVE") ? atoi(getenv("SNF_HG_PAIR_INTERLEAVE")) : 1;

@@ -183,10 +183,6 @@ def test_composed_step_at_full_table_size_against_the_oracle(method, grad_parity
     batch = O.synthetic_batch(cfg, R, 23)
     gen = torch.Generator().manual_seed(24)
     t_rand, u_rand = torch.rand((R, 1), generator=gen), torch.rand((R, 1), generator=gen)
-    op = {k: v.clone().requires_grad_(True) for k, v in params.items()}
-    ref = O.forward(op, cfg, o, d, True, t_rand, u_rand, 1.0)
-    rl = O.loss_dict(ref, batch, cfg)
-    sum(rl.values()).backward()
     tc = copy.deepcopy(configs.method_configs[method])
     tc.pipeline.datamanager.train_num_rays_per_batch = R
     mc = tc.pipeline.model
@@ -215,25 +211,36 @@ def test_composed_step_at_full_table_size_against_the_oracle(method, grad_parity
     prog.join_side_streams()
     torch.cuda.synchronize()
     out = prog.outputs()
-    assert float((out["rgb"].cpu().reshape(ref["rgb"].shape) - ref["rgb"].detach()).abs().max()) <= 1e-4
+    # ---- the oracle on the same rays.  The feature heads render the K = 16 samples of a ray with the LARGEST weights (torch.topk,
+    # sam_model.py:244): a discrete choice.  Where the K-th and (K+1)-th weight of a ray agree to fp32 rounding (S = 128 candidates:
+    # about one ray in 100 -- tools/debug_fullsize.py: 9.184467e-3 against 9.184429e-3, which the HIP path's positions round to
+    # ...479) either sample is an answer of the reference's arithmetic, the rendered feature differs by that sample's share (5e-4)
+    # and, with 512 rays, the heads' gradients by a per cent.  Such rays are identified from the ORACLE's weights alone; on them
+    # -- and only on them -- the oracle is evaluated with the selection the HIP path made (which must come from the tied
+    # candidates); everywhere else the selections must agree as sets.
+    op = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    ids_forced = None
     if distill:
-        # The feature heads render the K = 16 samples of a ray with the LARGEST weights (torch.topk, sam_model.py:244): a discrete
-        # choice.  Where the K-th and (K+1)-th weight of a ray agree to fp32 rounding (S = 128 candidates: one ray in ~500 --
-        # tools/debug_fullsize.py: 9.184467e-3 against 9.184429e-3, the HIP path's positions round the second to ...479) either
-        # sample is a correct answer of the reference's arithmetic and the rendered feature differs by that sample's share.
-        # Such rays are identified from the ORACLE's weights alone and left out of the comparison; there must be few of them.
-        wf = ref["weights_fine"].detach().reshape(R, S)
+        with torch.no_grad():
+            first = O.forward(params, cfg, o, d, True, t_rand, u_rand, 1.0)
+        wf = first["weights_fine"].reshape(R, S)
         top = torch.sort(wf, dim=1, descending=True).values
         tie = ((top[:, K - 1] - top[:, K]) <= 2e-5 * top[:, K - 1])
         assert int(tie.sum()) <= max(4, R // 32), int(tie.sum())  # (6 of 512 seen)
-        for k in ("sam", "clipseg"):
-            got, want = out[k].cpu(), ref[k].detach()
-            keep = ~tie
-            if k == "sam" and patch > 1:  # one output row per p x p patch of rays
-                keep = ~tie.view(-1, patch * patch).any(dim=1)
-            err = (got.reshape(want.shape) - want).abs().reshape(want.shape[0], -1).max(dim=1).values
-            assert float(err[keep].max()) <= 1e-4, (k, float(err[keep].max()))
-            assert float(err.max()) <= 5e-3, (k, float(err.max()))  # a tied ray swaps one low-weight sample, nothing more
+        ids_hip = prog.bufs["ids"].cpu().long()
+        ids_ref = first["sam_ids"].reshape(R, K)
+        same = torch.tensor([set(ids_hip[r].tolist()) == set(ids_ref[r].tolist()) for r in range(R)])
+        assert bool(same[~tie].all()), "the top-K selection differs on a ray without a tie"
+        # a tied ray's selection: every chosen sample weighs at least the (K+1)-th largest weight minus the tie margin
+        chosen = torch.gather(wf, 1, ids_hip)
+        assert bool((chosen[tie].min(dim=1).values >= top[tie, K] * (1 - 4e-5)).all())
+        ids_forced = torch.where(tie[:, None], ids_hip, ids_ref)
+    ref = O.forward(op, cfg, o, d, True, t_rand, u_rand, 1.0, topk_ids=ids_forced)
+    rl = O.loss_dict(ref, batch, cfg)
+    sum(rl.values()).backward()
+    keys = ("rgb", "sam", "clipseg") if distill else ("rgb",)
+    for k in keys:
+        assert float((out[k].cpu().reshape(ref[k].shape) - ref[k].detach()).abs().max()) <= 1e-4, k
     for k, v in rl.items():
         assert abs(float(ld[k]) - float(v)) <= 1e-4 * max(1.0, abs(float(v))), k
     grads = named_grads(model)
