@@ -244,4 +244,6 @@ def test_composed_step_at_full_table_size_against_the_oracle(method, grad_parity
     for k, v in rl.items():
         assert abs(float(ld[k]) - float(v)) <= 1e-4 * max(1.0, abs(float(v))), k
     grads = named_grads(model)
-    grad_parity(grads, {k: v.grad.numpy() for k, v in op.items() if v.grad is not None and k in grads})
+    # (proposal network: at P = 64 / S = 128 the interlevel loss is 4.9e-12 in fp32 and 4.4e-12 in fp64 on the oracle itself, its
+    #  gradient 2e-2 apart in relative L1 between the two -- the bound is 5x that)
+    grad_parity(grads, {k: v.grad.numpy() for k, v in op.items() if v.grad is not None and k in grads}, prop_tol=0.1)
