@@ -382,6 +382,11 @@ int snf_nerf_loss_summary(const float* rgb_mse, const float* interlevel_rows, fl
  * snf_attention: out[b*T+i, h*hd..] = softmax(scale * q k^T + rel_h + rel_w) v for every (window b, head h), q/k/v read in
  *   place from the qkv rows; rel may be NULL; head_dim <= 96. */
 int snf_patchify(const float* img, int B, int Cin, int S, int P, float* rows, snf_stream_t stream);
+/* Sam.preprocess (samnerf/segment_anything/modeling/sam.py:164-174), the step between SamPredictor.set_torch_image
+ * (predictor.py:70-97) and the encoder: out[b,c,y,x] = (img[b,c,y,x] - mean[c]) / std[c] inside the h x w image, 0 in the padding
+ * to S x S.  img: uint8 (is_uint8 != 0; what set_image hands over) or fp32, [B,C,h,w]; mean / std [C] on the device. */
+int snf_sam_preprocess(const void* img, int is_uint8, int B, int C, int h, int w, int S, const float* mean, const float* stdv,
+                       float* out, snf_stream_t stream);
 int snf_layernorm(const float* x, const float* residual, int N, int C, const float* weight, const float* bias, float eps,
                   float* sum_out, float* y, snf_stream_t stream);
 int snf_window_partition(const float* x, int B, int H, int W, int C, int ws, float* out, snf_stream_t stream);

@@ -151,3 +151,13 @@ def forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, cfg: ViTConfig, return
     y = F.conv2d(y, sd["neck.2.weight"], padding=1)
     y = layer_norm_2d(y, sd["neck.3.weight"], sd["neck.3.bias"], cfg.ln_eps)
     return (y, trace) if return_tokens else y
+
+
+def sam_preprocess(x: torch.Tensor, mean, std, img_size: int) -> torch.Tensor:
+    """Sam.preprocess (samnerf/segment_anything/modeling/sam.py:164-174): per-channel (x - mean) / std, then zero-pad right and
+    bottom to img_size x img_size.  x [B, 3, h, w], uint8 or float."""
+    m = torch.as_tensor(mean, dtype=torch.float32).view(-1, 1, 1)
+    s = torch.as_tensor(std, dtype=torch.float32).view(-1, 1, 1)
+    y = (x - m) / s
+    h, w = y.shape[-2:]
+    return torch.nn.functional.pad(y, (0, img_size - w, 0, img_size - h))

@@ -127,6 +127,7 @@ SIGNATURES = {
     "snf_adam_step_rows": [P, P, P, P, P, c_int64, I, F, F, F, F, I, F, I, P],
     "snf_set_adam_launch": [I, I, I],
     "snf_patchify": [P, I, I, I, I, P, P],
+    "snf_sam_preprocess": [P, I, I, I, I, I, I, P, P, P, P],
     "snf_layernorm": [P, P, I, I, P, P, F, P, P, P],
     "snf_window_partition": [P, I, I, I, I, I, P, P],
     "snf_window_merge_add": [P, P, I, I, I, I, I, P, P],

@@ -555,6 +555,49 @@ __global__ __launch_bounds__(256, SNF_ATT_WAVES) void k_attention_b3(const float
 
 using namespace snf;
 
+namespace snf {
+// Sam.preprocess (segment_anything/modeling/sam.py:164-174): (x - pixel_mean) / pixel_std per channel, zero-padded right / bottom
+// to the encoder's square S x S input.  One thread per output pixel group of 4; uint8 (what SamPredictor.set_image hands over,
+// predictor.py:58-66) or float input.
+template <typename T>
+__global__ __launch_bounds__(256) void k_sam_preprocess(const T* __restrict__ img, int B, int C, int h, int w, int S,
+                                                        const float* __restrict__ mean, const float* __restrict__ stdv,
+                                                        float* __restrict__ out) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)B * C * S * (S / 4);
+    if (t >= total) return;
+    const int xq = (int)(t % (S / 4));
+    const int y = (int)((t / (S / 4)) % S);
+    const int c = (int)((t / ((long long)(S / 4) * S)) % C);
+    const int b = (int)(t / ((long long)(S / 4) * S * C));
+    const float m = mean[c], sd = stdv[c];
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int x = xq * 4 + j;
+        v[j] = (y < h && x < w) ? ((float)img[(((size_t)b * C + c) * h + y) * w + x] - m) / sd : 0.f;
+    }
+    *reinterpret_cast<float4*>(out + (((size_t)b * C + c) * S + y) * S + xq * 4) = make_float4(v[0], v[1], v[2], v[3]);
+}
+}  // namespace snf
+
+extern "C" int snf_sam_preprocess(const void* img, int is_uint8, int B, int C, int h, int w, int S, const float* mean,
+                                  const float* stdv, float* out, snf_stream_t stream) {
+    SNF_REQUIRE(img && mean && stdv && out, "snf_sam_preprocess: null pointer");
+    SNF_REQUIRE(B > 0 && C > 0 && h > 0 && w > 0 && h <= S && w <= S && S % 4 == 0 && ((uintptr_t)out % 16) == 0,
+                "snf_sam_preprocess: bad shape B=%d C=%d h=%d w=%d S=%d (the image must fit the S x S input, S %% 4 == 0)", B, C, h, w, S);
+    const long long total = (long long)B * C * S * (S / 4);
+    dim3 grid((unsigned)((total + 255) / 256));
+    if (is_uint8)
+        hipLaunchKernelGGL(snf::k_sam_preprocess<unsigned char>, grid, dim3(256), 0, (hipStream_t)stream, (const unsigned char*)img, B, C,
+                           h, w, S, mean, stdv, out);
+    else
+        hipLaunchKernelGGL(snf::k_sam_preprocess<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)img, B, C, h, w, S, mean,
+                           stdv, out);
+    SNF_LAUNCH_CHECK("snf_sam_preprocess");
+    return SNF_OK;
+}
+
 extern "C" int snf_patchify(const float* img, int B, int Cin, int S, int P, float* rows, snf_stream_t stream) {
     SNF_REQUIRE(img && rows && B > 0 && Cin > 0 && P > 0 && S > 0 && S % P == 0, "snf_patchify: bad argument");
     const long long total = (long long)B * (S / P) * (S / P) * Cin * P * P;

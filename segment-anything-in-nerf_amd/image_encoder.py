@@ -99,8 +99,10 @@ class ImageEncoderViT(nn.Module):
                                   LayerNorm2d(out_chans))
 
     @torch.no_grad()
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
-        """[B, in_chans, S, S] -> [B, out_chans, S/patch, S/patch] (image_encoder.py:106-117)."""
+    def forward(self, x: torch.Tensor, trace_blocks=()):
+        """[B, in_chans, S, S] -> [B, out_chans, S/patch, S/patch] (image_encoder.py:106-117).
+        trace_blocks (tests): block indices whose OUTPUT tokens [B, G, G, C] are returned as well (-1: the tokens entering block
+        0) -> (y, {index: tokens}); each costs one extra add, the block's residual being folded into the next block's norm."""
         if not x.is_cuda:
             raise RuntimeError("ImageEncoderViT runs on the HIP kernels only (no CPU path)")
         B, _, S, _ = x.shape
@@ -112,7 +114,10 @@ class ImageEncoderViT(nn.Module):
         if self.pos_embed is not None:
             t = t.view(B, T, -1).add_(self.pos_embed.view(1, T, -1)).view(B * T, -1)
         shortcut, pending = t, None  # `pending`: the previous block's MLP output, still to be added to `shortcut`
-        for blk in self.blocks:
+        trace = {}
+        if -1 in trace_blocks:
+            trace[-1] = t.view(B, G, G, -1).clone()
+        for bi, blk in enumerate(self.blocks):
             a, ws = blk.attn, blk.window_size
             if pending is None:
                 y = ops.layernorm(shortcut, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps)
@@ -132,13 +137,16 @@ class ImageEncoderViT(nn.Module):
             y = ops.layernorm(shortcut, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
             y = ops.linear_nograd(y, blk.mlp.lin1.weight, blk.mlp.lin1.bias, ops.ACT_GELU)
             pending = ops.linear_nograd(y, blk.mlp.lin2.weight, blk.mlp.lin2.bias)
+            if bi in trace_blocks:
+                trace[bi] = ops.window_merge_add(pending, shortcut, B, G, G, 0).view(B, G, G, -1)
         t = ops.window_merge_add(pending, shortcut, B, G, G, 0) if pending is not None else shortcut
         c0, n0, c1, n1 = self.neck[0], self.neck[1], self.neck[2], self.neck[3]
         y = ops.linear_nograd(t, c0.weight.view(c0.weight.shape[0], -1))
         y = ops.layernorm(y, n0.weight, n0.bias, n0.eps)
         y = ops.linear_nograd(ops.patch_unfold(y, G, 3), c1.weight.view(c1.weight.shape[0], -1))
         y = ops.layernorm(y, n1.weight, n1.bias, n1.eps)
-        return y.view(B, G, G, -1).permute(0, 3, 1, 2).contiguous()
+        y = y.view(B, G, G, -1).permute(0, 3, 1, 2).contiguous()
+        return (y, trace) if trace_blocks else y
 
 
 def build_sam_vit_h_encoder(device="cuda") -> ImageEncoderViT:

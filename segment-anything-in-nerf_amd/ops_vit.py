@@ -24,6 +24,21 @@ def linear_nograd(x, w, b=None, act: int = ACT_NONE) -> torch.Tensor:
 
 
 @torch.no_grad()
+def sam_preprocess(img, mean, std, size: int) -> torch.Tensor:
+    """Sam.preprocess (modeling/sam.py:164-174): [B,C,h,w] uint8 / float -> normalised, zero-padded [B,C,size,size] fp32."""
+    if not img.is_cuda:
+        raise RuntimeError("sam_preprocess runs on the HIP kernels only (no CPU path)")
+    img = img.contiguous()
+    if img.dtype != torch.uint8:
+        img = img.float()
+    B, C, h, w = img.shape
+    out = torch.empty((B, C, size, size), device=img.device, dtype=torch.float32)
+    _launch("snf_sam_preprocess", _p(img), int(img.dtype == torch.uint8), B, C, h, w, size, _p(_chk(mean, "mean")),
+            _p(_chk(std, "std")), _p(out), _stream())
+    return out
+
+
+@torch.no_grad()
 def patchify(img, P: int) -> torch.Tensor:
     img = _chk(img, "img")
     B, Cin, S, _ = img.shape

@@ -631,9 +631,27 @@ def _reference_function(path, cls, name):
     node = next(f for c in tree.body if isinstance(c, ast.ClassDef) and c.name == cls
                 for f in c.body if isinstance(f, ast.FunctionDef) and f.name == name)
     mod = ast.Module(body=[node], type_ignores=[])
-    ns = {"np": np, "torch": torch, "math": __import__("math")}
+    ns = {"np": np, "torch": torch, "math": __import__("math"), "F": torch.nn.functional}
     exec(compile(mod, path, "exec"), ns)
     return ns[name]
+
+
+def fx_sam_preprocess():
+    """Sam.preprocess (segment_anything/modeling/sam.py:164-174: (x - pixel_mean) / pixel_std, zero-pad right / bottom to the
+    encoder's square input) -- the step between SamPredictor.set_torch_image (predictor.py:70-97) and the image encoder -- run
+    with the reference's own method body on a stand-in model (its module imports the prompt / mask stack).  uint8 and float
+    inputs, landscape and portrait, the pixel statistics of build_sam.py:99-100."""
+    from types import SimpleNamespace
+    preprocess = _reference_function("samnerf/segment_anything/modeling/sam.py", "Sam", "preprocess")
+    mean = torch.Tensor([123.675, 116.28, 103.53]).view(-1, 1, 1)
+    std = torch.Tensor([58.395, 57.12, 57.375]).view(-1, 1, 1)
+    me = SimpleNamespace(pixel_mean=mean, pixel_std=std, image_encoder=SimpleNamespace(img_size=64))
+    g = torch.Generator().manual_seed(11)
+    a = torch.randint(0, 256, (1, 3, 43, 64), generator=g, dtype=torch.uint8)
+    b = torch.rand((2, 3, 64, 48), generator=g) * 255.0
+    c = torch.rand((1, 3, 64, 64), generator=g) * 255.0
+    npz("sam_preprocess", mean=mean.view(-1), std=std.view(-1), a=a, a_out=preprocess(me, a), b=b, b_out=preprocess(me, b), c=c,
+        c_out=preprocess(me, c))
 
 
 def fx_eval_regroup():
@@ -699,7 +717,7 @@ def fx_eval_regroup():
 if __name__ == "__main__":
     only = set(sys.argv[1:])
     for fn in (fx_spacing, fx_contraction, fx_hashgrid, fx_mlp, fx_sh, fx_weights, fx_pdf, fx_render, fx_topk,
-               fx_losses, fx_ministep, fx_batch_builder, fx_vit, fx_eval_regroup):
+               fx_losses, fx_ministep, fx_batch_builder, fx_vit, fx_eval_regroup, fx_sam_preprocess):
         if only and fn.__name__ not in only:
             continue
         print(fn.__name__)

@@ -240,3 +240,21 @@ def test_gradient_conditioning():
     assert max(mx[k] for k in ("head_w2", "sam_w1", "base_w1")) <= 1e-4, mx
     # the flip signature: outliers of >1e-3 of the largest entry in tensors whose relative L1 error stays at 1e-3
     assert max(mx["field_table"], mx["base_w0"], mx["sam_w0"]) >= 1e-3 >= max(l1["field_table"], l1["base_w0"], l1["sam_w0"]), (l1, mx)
+
+
+def test_sam_preprocess(golden):
+    """oracle/vit_oracle.sam_preprocess against the reference's own Sam.preprocess (modeling/sam.py:164-174) on uint8 / float,
+    landscape / portrait / square inputs; the offline writer's crop (get_image_embeddings.py:29-35) on the shapes it documents."""
+    from oracle import vit_oracle as V
+    g = golden("sam_preprocess")
+    for k in "abc":
+        got = V.sam_preprocess(T(g[k]), g["mean"], g["std"], 64)
+        assert got.shape == g[k + "_out"].shape and torch.equal(got, T(g[k + "_out"])), k
+    import samnerf_amd  # noqa: F401  (repo-root shim; conftest put the root on sys.path)
+    from samnerf_amd.sam_utils import crop_embedding, get_feature_size, set_feature
+    f = torch.arange(2 * 64 * 64, dtype=torch.float32).view(1, 2, 64, 64)
+    assert crop_embedding(f, (683, 1024)).shape == (1, 2, 43, 64) and crop_embedding(f, (1024, 683)).shape == (1, 2, 64, 43)
+    assert crop_embedding(f, (512, 512)).shape == (1, 2, 64, 64)
+    assert crop_embedding(f, (683, 1024)).shape[-2:] == get_feature_size(683, 1024)  # the shape the eval path renders
+    back, _ = set_feature(crop_embedding(f, (683, 1024)).squeeze(0), (683, 1024))  # writer's crop -> set_feature's pad: round trip
+    assert torch.equal(back[..., :43, :], f[..., :43, :]) and float(back[..., 43:, :].abs().max()) == 0.0

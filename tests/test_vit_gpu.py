@@ -122,3 +122,61 @@ def test_vit_h_shaped_block_vs_oracle():
     assert y.shape == (1, 256, 64, 64)
     err = float((y - ref).abs().max())
     assert err <= 2e-4 * max(1.0, float(ref.abs().max())), err
+
+
+def test_full_depth_vit_h_on_one_image():
+    """BASELINE config #5, encoder half, AT SIZE: the full ViT-H (32 blocks, 1280 wide, 16 heads, window 14, global attention at
+    blocks 7 / 15 / 23 / 31; build_sam.py:14-21,53-80) on one 1024 x 1024 image -- output finite and of the right shape, and
+    block-wise parity on the FIRST block (windowed, 64 x 64 tokens padded to 70 x 70) and the LAST one (global, 4096 x 4096
+    attention with decomposed relative positions): the oracle's block on the very tokens the HIP forward fed its block."""
+    from samnerf_amd.image_encoder import build_sam_vit_h_encoder
+    cfg = V.ViTConfig()  # ViT-H defaults
+    assert (cfg.depth, cfg.embed_dim, cfg.num_heads, cfg.window_size) == (32, 1280, 16, 14)
+    sd = V.init_weights(cfg, seed=3)
+    enc = build_sam_vit_h_encoder().eval()
+    enc.load_state_dict(sd, strict=True)
+    x = torch.randn((1, 3, 1024, 1024), generator=torch.Generator().manual_seed(4))
+    y, trace = enc(x.cuda(), trace_blocks=(-1, 0, 30, 31))
+    assert y.shape == (1, 256, 64, 64) and bool(torch.isfinite(y).all())
+    for i in (0, 31):
+        t_in = trace[i - 1].cpu()
+        with torch.no_grad():
+            ref = V.block(sd, i, t_in, cfg)
+        got = trace[i].cpu()
+        scale = max(1.0, float(ref.abs().max()))
+        assert float((got - ref).abs().max()) <= 2e-4 * scale, (i, float((got - ref).abs().max()), scale)
+    # the neck on the last block's tokens
+    with torch.no_grad():
+        t = trace[31].cpu()
+        n = torch.nn.functional.conv2d(t.permute(0, 3, 1, 2), sd["neck.0.weight"])
+        n = V.layer_norm_2d(n, sd["neck.1.weight"], sd["neck.1.bias"], cfg.ln_eps)
+        n = torch.nn.functional.conv2d(n, sd["neck.2.weight"], padding=1)
+        n = V.layer_norm_2d(n, sd["neck.3.weight"], sd["neck.3.bias"], cfg.ln_eps)
+    assert float((y.cpu() - n).abs().max()) <= 2e-4 * max(1.0, float(n.abs().max()))
+
+
+def test_sam_preprocess_kernel(golden):
+    """snf_sam_preprocess against the reference's own Sam.preprocess (modeling/sam.py:164-174; fixture from
+    tests/golden/make_golden.py): uint8 and float, landscape / portrait / square; then the embedder's crop on a small encoder."""
+    from samnerf_amd import ops
+    g = golden("sam_preprocess")
+    mean, std = torch.from_numpy(g["mean"]).cuda(), torch.from_numpy(g["std"]).cuda()
+    for k in "abc":
+        got = ops.sam_preprocess(torch.from_numpy(g[k]).cuda(), mean, std, 64).cpu()
+        want = torch.from_numpy(g[k + "_out"])
+        assert got.shape == want.shape
+        assert float((got - want).abs().max()) <= 2e-6 * float(want.abs().max()), k
+        h, w = g[k].shape[-2:]
+        assert float(got[..., h:, :].abs().max() if h < 64 else 0.0) == 0.0 and float(got[..., :, w:].abs().max() if w < 64 else 0.0) == 0.0
+    from samnerf_amd.sam_utils import SamImageEmbedder
+    cfg = V.ViTConfig(img_size=224, patch_size=16, embed_dim=32, depth=2, num_heads=2, mlp_ratio=2.0, out_chans=16, window_size=5,
+                      global_attn_indexes=(1,))
+    sd = V.init_weights(cfg, seed=4)
+    enc = _build(cfg, sd)
+    emb = SamImageEmbedder(enc)
+    img = torch.randint(0, 256, (1, 3, 150, 224), dtype=torch.uint8, generator=torch.Generator().manual_seed(6))
+    feats = emb.set_torch_image(img.cuda(), (300, 448))
+    with torch.no_grad():
+        ref = V.forward(sd, V.sam_preprocess(img, emb.pixel_mean.cpu(), emb.pixel_std.cpu(), 224), cfg)
+    assert float((feats.cpu() - ref).abs().max()) <= 2e-4 * max(1.0, float(ref.abs().max()))
+    assert emb.embedding().shape == (16, 10, 14)  # ceil(300 / 448 * 14) rows of the 14 x 14 map
