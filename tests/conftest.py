@@ -57,9 +57,10 @@ def grad_parity():
     reference's own arithmetic misses by two orders of magnitude).  What a flip cannot do is change a slice by much: it moves one
     row of a first-layer gradient by ~1 % and leaves the per-level sums of a table where they are.  So every tensor is held to:
       * relative L1 error <= 5e-3 over the tensor (a wrong term or scale is O(1) there; measured 1e-3);
-      * relative L1 error PER SLICE -- every row of a weight matrix, every level of a hash table -- <= 0.15 / 0.03: a wrong
-        contribution confined to a few rows of a weight gradient or to one level of a table is O(1) of THAT slice however small
-        its share of the tensor (the gap of the tensor-wide L1 bound VERDICT r02 pointed out);
+      * relative L1 error PER SLICE -- every row of a weight matrix <= 0.1, every level of a hash table <= 5e-3 (measured over the
+        GPU suite: 2.4e-2 and 5.2e-4; the oracle against itself in fp64: 2.1e-2 and 1.1e-3): a wrong contribution confined to a
+        few rows of a weight gradient or to one level of a table is O(1) of THAT slice however small its share of the tensor
+        (the gap of the tensor-wide L1 bound VERDICT r02 pointed out);
       * largest error <= 6e-2 of the largest entry (a flip moves an entry by a few per cent at most);
       * behind a network's last ReLU (LAST_LAYERS): largest error <= 2e-4 and NO outlier at 1e-4;
     and the report lists, per tensor, L1 / max / outlier count / rows (levels) containing one / worst slice, printed with
@@ -68,7 +69,7 @@ def grad_parity():
     L1 <= 3e-2 only; the loss kernels' own tests (test_ops_gpu.py) check that backward on well-conditioned inputs."""
     import numpy as np
 
-    def check(got, ref, l1_tol=5e-3, max_tol=2e-4, big_tol=6e-2, row_tol=0.15, level_tol=0.03, prop_tol=3e-2):
+    def check(got, ref, l1_tol=5e-3, max_tol=2e-4, big_tol=6e-2, row_tol=0.1, level_tol=5e-3, prop_tol=3e-2):
         l1, mx, cnt, rows, worst, shape = {}, {}, {}, {}, {}, {}
         for k, r in ref.items():
             r = np.asarray(r, dtype=np.float64)
