@@ -107,8 +107,38 @@ __global__ __launch_bounds__(256) void k_hashgrid_fwd(const float* __restrict__ 
     const Corners c = corners_of(u, n, scalings[l], mask);
     const float* __restrict__ slab = table + ((size_t)l << log2_T) * F;
     float f[8][F];
+#ifndef SNF_HG_FWD_PAIR
+#define SNF_HG_FWD_PAIR 1
+#endif
+    if constexpr (F == 2 && SNF_HG_FWD_PAIR) {
+        // The x-neighbours of a cell hash to (fx ^ h) and ((fx + 1) ^ h) with the same h = y P1 ^ z P2: for EVEN fx they differ in
+        // bit 0 only -- an aligned PAIR of 8-byte rows, one 16-byte load instead of two 8-byte ones.  The kernel is bound by the
+        // texture addresser (rocprofv3: TA busy 80 % of the kernel, ~1 scattered address per clock and CU; L1 hits 67 %, L2 hits
+        // 74 %, profiles/r03_f2_counters.txt), so half of the samples issue 4 addresses instead of 8.  (px integral: cx == fx,
+        // the indices are equal, not a pair -- the 8-load path reads the row twice as before.)
+        const bool pair = (c.idx[0] ^ c.idx[3]) == 1u;  // cx ^ fx == 1: the same for the four (y, z) combinations
+        if (pair) {
+            // corner pairs (cx, fx) with equal y, z: (0,3) (1,2) (5,6) (4,7).  The aligned pair starts at the EVEN one of the two
+            // rows -- which of them that is depends on the parity of h, i.e. on the (y, z) combination
+            auto load_pair = [&](int kc, int kf) {
+                const uint32_t rf = c.idx[kf];
+                const float4 t = *reinterpret_cast<const float4*>(slab + (size_t)(rf & ~1u) * 2);
+                const bool f_first = !(rf & 1u);
+                f[kf][0] = f_first ? t.x : t.z; f[kf][1] = f_first ? t.y : t.w;
+                f[kc][0] = f_first ? t.z : t.x; f[kc][1] = f_first ? t.w : t.y;
+            };
+            load_pair(0, 3);
+            load_pair(1, 2);
+            load_pair(5, 6);
+            load_pair(4, 7);
+        } else {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) load_row<F>(slab + (size_t)c.idx[k] * F, f[k]);
+            for (int k = 0; k < 8; ++k) load_row<F>(slab + (size_t)c.idx[k] * F, f[k]);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) load_row<F>(slab + (size_t)c.idx[k] * F, f[k]);
+    }
     const float ox = c.ox, oy = c.oy, oz = c.oz;
     const float mx = 1.f - ox, my = 1.f - oy, mz = 1.f - oz;
     float r[F];
