@@ -37,9 +37,7 @@ __device__ __forceinline__ void load_row(const float* __restrict__ p, float (&o)
 
 // Adam moments of a fused backward + Adam: read once and written once per step, never gathered -- SNF_HG_NT_MV = 1 marks those
 // accesses non-temporal (bit 0: loads, bit 1: stores), a compile-time probe (round 1 measured +9 % for p / m / v together)
-#ifndef SNF_HG_NT_MV
 #define SNF_HG_NT_MV 0
-#endif
 typedef float hg_f4v __attribute__((ext_vector_type(4)));
 template <int F>
 __device__ __forceinline__ void load_row_mv(const float* __restrict__ p, float (&o)[F]) {
@@ -107,9 +105,7 @@ __global__ __launch_bounds__(256) void k_hashgrid_fwd(const float* __restrict__ 
     const Corners c = corners_of(u, n, scalings[l], mask);
     const float* __restrict__ slab = table + ((size_t)l << log2_T) * F;
     float f[8][F];
-#ifndef SNF_HG_FWD_PAIR
 #define SNF_HG_FWD_PAIR 1
-#endif
     if constexpr (F == 2 && SNF_HG_FWD_PAIR) {
         // The x-neighbours of a cell hash to (fx ^ h) and ((fx + 1) ^ h) with the same h = y P1 ^ z P2: for EVEN fx they differ in
         // bit 0 only -- an aligned PAIR of 8-byte rows, one 16-byte load instead of two 8-byte ones.  The kernel is bound by the
@@ -218,17 +214,13 @@ __global__ __launch_bounds__(256) void k_hashgrid_bwd(const float* __restrict__ 
 constexpr int HG_MAX_LOG2B = 12;
 constexpr int HG_RT = 512;       // threads of the reduce workgroup (8 waves; 4 workgroups per CU)
 // records sorted per trip through LDS (16 KB of payload at F = 2, 64 KB at F = 8; a 1024-record chunk for F = 8 measured slower)
-#ifndef SNF_HG_CHUNK8
 #define SNF_HG_CHUNK8 2048
-#endif
 template <int F> constexpr int hg_chunk() { return F == 8 ? SNF_HG_CHUNK8 : 2048; }
 constexpr int HG_MAX_RPB = 2048; // rows per bucket (HG_ROWS_PT per reduce thread)
 constexpr int HG_ROWS_PT = HG_MAX_RPB / HG_RT;
 constexpr int HG_LONG = 48;      // segments longer than this are reduced by a wave (16 until the kernel ran two workgroups per CU:
                                  // 32 .. 64 then measured 5-8 % faster alone, tools/sweep_hg_long.sh)
-#ifndef SNF_HG_EPI
 #define SNF_HG_EPI 2
-#endif
 constexpr int HG_EPI = SNF_HG_EPI;  // rows per thread in flight in the fused Adam epilogue of the float reduce
 
 struct HgGeom {
@@ -341,9 +333,7 @@ constexpr int HG_SAMPLE_BITS = 21;  // N <= 2^21 per launch (row_in_bucket needs
 // counting-sorted by bucket in LDS and leaves as one contiguous run per bucket (~128 B at 256 buckets) instead of 8-byte
 // stores to 256 different cache lines -- the store-transaction count, not the byte count, bounded the direct version
 // (rocprofv3: 84 % of its wave cycles were issue stalls behind the store queue).
-#ifndef SNF_HG_SB_SPT
 #define SNF_HG_SB_SPT 2
-#endif
 constexpr int HG_SB_SPT = SNF_HG_SB_SPT;          // samples per thread per batch (1: 64-B runs, 7 workgroups per CU; 4: 256-B runs, 1)
 constexpr int HG_SB_REC = 256 * HG_SB_SPT * 8;    // 4096 staged records (32 KB)
 
@@ -747,9 +737,7 @@ struct HgSecond {
     HgSparseDev sp;    // its reachable-row levels
 };
 
-#ifndef SNF_HG_RT_MINWG
 #define SNF_HG_RT_MINWG 4
-#endif
 // (HIP: the second launch-bounds value is the minimum WAVES per SIMD.  Two 8-wave workgroups per CU -- LDS allows it at F = 8 --
 // are 4 waves per SIMD, i.e. <= 128 VGPRs; without the hint the compiler took 130: ONE workgroup per CU)
 template <int F, bool ADAM>
@@ -1075,9 +1063,7 @@ __global__ __launch_bounds__(HG_RT, SNF_HG_RT_MINWG) void k_hg_reduce(const floa
 // what a float sum (autograd's) gives.  A workgroup streams its bucket's records once (record + staged-gradient gather,
 // four in flight per thread), one barrier, then converts its rows and applies the Adam step / gradient read-modify-write.
 // ==========================================================================================
-#ifndef SNF_FX_T
 #define SNF_FX_T 512
-#endif
 constexpr int HG_FX_T = SNF_FX_T;
 
 template <int F>
@@ -1179,9 +1165,7 @@ __global__ __launch_bounds__(HG_FX_T) void k_hg_reduce_fx(const float* __restric
     __syncthreads();
     // three-stage software pipeline over trips of U records per thread: the records of trip t+2 and the staged gradients of
     // trip t+1 are in flight while trip t is accumulated, so neither global latency sits on the loop's critical path
-#ifndef SNF_FX_U
 #define SNF_FX_U 4
-#endif
     constexpr int U = SNF_FX_U;
     const uint32_t mask_s = (1u << HG_SAMPLE_BITS) - 1u;
     uint2 rec0[U], rec1[U];      // records of trip t (being processed), t+1 (gathers in flight)
@@ -1415,7 +1399,7 @@ constexpr size_t HG_FX_SCRATCH = 64;  // words (L <= 64 for the fixed-point redu
 // first level of the XCD-aware workgroup order of the fixed-point reduce (k_hg_reduce_fx): the leading `n_run_levels` coarse levels
 // keep the plain order; SNF_HG_XCD=0 switches it off (returns L)
 static int hg_xcd_from(int n_run_levels, int L, int B) {
-    static const int on = getenv("SNF_HG_XCD") ? atoi(getenv("SNF_HG_XCD")) : 1;
+    static const int on = 1;
     if (!on || (B % 8) != 0 || n_run_levels >= L) return L;
     return n_run_levels < 0 ? 0 : n_run_levels;
 }
@@ -1428,12 +1412,12 @@ static HgSecond hg_no_second() {
 
 // leading levels whose equal-row contributions are merged inside lane quads before the LDS atomics (SNF_HG_MERGE=0: none)
 static int hg_merge_levels(int n_run_levels) {
-    static const int on = getenv("SNF_HG_MERGE") ? atoi(getenv("SNF_HG_MERGE")) : 1;
+    static const int on = 1;
     return on ? n_run_levels : 0;
 }
 
 static bool hg_fx_on(int F, int L, int N) {
-    static const int on = getenv("SNF_HG_FX") ? atoi(getenv("SNF_HG_FX")) : 1;
+    static const int on = 1;
     return on && F == 2 && L <= (int)HG_FX_SCRATCH && (N % 2) == 0;
 }
 
@@ -1558,7 +1542,7 @@ static void hg_reduce_one(hipStream_t st, int F, const float* stage, int N, int 
                           float* grad_table, int n_run_levels, bool adam_on, bool sparse_step, HgAdam a, HgSparse sp,
                           uint32_t* lvlmax) {
     const int B = 1 << g.log2B;
-    static const uint32_t hg_long = getenv("SNF_HG_LONG") ? (uint32_t)atoi(getenv("SNF_HG_LONG")) : (uint32_t)HG_LONG;
+    static const uint32_t hg_long = (uint32_t)HG_LONG;
     const bool fx = hg_fx_on(F, L, N);
     const int s0 = sp.levels;  // first level of the bucket-wide kernels
     const int nfx = fx ? L : 0;  // levels whose largest |g| the bucket-wide fixed-point kernel needs (the compact reduce finds its own)
@@ -1724,7 +1708,7 @@ extern "C" int snf_hashgrid_bwd_presorted_adam_pair(const float* grad_out0, cons
     const HgWs w1 = hg_ws_layout(const_cast<void*>(sorted_workspace1), N, L1, g);
     const int B = 1 << g.log2B;
     hipStream_t st = (hipStream_t)stream;
-    static const uint32_t hg_long = getenv("SNF_HG_LONG") ? (uint32_t)atoi(getenv("SNF_HG_LONG")) : (uint32_t)HG_LONG;
+    static const uint32_t hg_long = (uint32_t)HG_LONG;
     const bool on0 = sparse_step != 0, on1 = sparse_step != 0;  // the reachable-row levels are stepped (else: gradients only)
     HgAdam a{};
     hg_fill_adam(a, param0, exp_avg0, exp_avg_sq0, lr, beta1, beta2, eps, step, grad_scale, fuse_from_level0);
@@ -1735,7 +1719,7 @@ extern "C" int snf_hashgrid_bwd_presorted_adam_pair(const float* grad_out0, cons
     uint32_t* lvlmax = (uint32_t*)scratch;  // (unused by the compact reduce since it scales per bucket; kept in the signature)
     const HgSparseDev sd0{reach_rows0, reach_start0, lvlmax, sparse_levels0, on0 ? 1 : 0};
     s2.sp = HgSparseDev{reach_rows1, reach_start1, lvlmax + sparse_levels0, sparse_levels1, on1 ? 1 : 0};
-    static const int interleave = getenv("SNF_HG_PAIR_INTERLEAVE") ? atoi(getenv("SNF_HG_PAIR_INTERLEAVE")) : 1;
+    static const int interleave = 1;
     s2.first_levels = L0;
     s2.interleave = (interleave && L0 == L1) ? 1 : 0;
     s2.level0 = 0;

@@ -471,7 +471,7 @@ extern "C" int snf_linear_bwd_weight(const float* dY, const float* Y, const floa
     const int to = ceil_div(O, 64), ti = ceil_div(I, 64);
     // aim for ~1024 workgroups (measured best for the 64-wide nets: 2048 doubles the atomics of the final accumulation, 512
     // leaves the CUs short of loads in flight); every chunk is a multiple of BK rows
-    static const int target = getenv("SNF_WGRAD_BLOCKS") ? atoi(getenv("SNF_WGRAD_BLOCKS")) : 1024;
+    static const int target = 1024;
     int chunks = target / (to * ti);
     if (chunks < 1) chunks = 1;
     int rows = ceil_div(N, chunks);

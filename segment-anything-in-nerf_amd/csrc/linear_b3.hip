@@ -47,21 +47,9 @@ __device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b) {
 // two fp32 -> packed hi pair and packed lo pair (lo = bf16(x - hi)): 6 VALU instructions.  +-inf gives lo = NaN (inf - inf),
 // i.e. NaN where fp32 arithmetic gives +-inf or NaN; flushing that NaN cost 4 more instructions per pair in kernels whose
 // staging is VALU-bound (compile with -DSNF_B3_FLUSH_NAN to restore it).  NaN inputs propagate as NaN either way.
-__device__ __forceinline__ void split2_flush(float x0, float x1, uint32_t& hi, uint32_t& lo) {
-    hi = cvt_pk_bf16(x0, x1);
-    float r0 = x0 - __uint_as_float(hi << 16), r1 = x1 - __uint_as_float(hi & 0xFFFF0000u);
-    r0 = (r0 == r0) ? r0 : 0.f;
-    r1 = (r1 == r1) ? r1 : 0.f;
-    lo = cvt_pk_bf16(r0, r1);
-}
-
 __device__ __forceinline__ void split2(float x0, float x1, uint32_t& hi, uint32_t& lo) {
-#ifdef SNF_B3_FLUSH_NAN
-    split2_flush(x0, x1, hi, lo);
-#else
     hi = cvt_pk_bf16(x0, x1);
     lo = cvt_pk_bf16(x0 - __uint_as_float(hi << 16), x1 - __uint_as_float(hi & 0xFFFF0000u));
-#endif
 }
 
 __device__ __forceinline__ void split_bf16(float x, uint32_t& hi, uint32_t& lo) {
@@ -137,9 +125,7 @@ __device__ __forceinline__ float4 b3_load_b_planar8(const float* __restrict__ B,
 // BN = columns per workgroup (64 / 128 / 192 / 256): a wave owns 32 rows x BN columns = BN/32 accumulators.  Wider tiles
 // split every A element fewer times and run more MFMAs per staged k-tile; measured on the head shapes 128 is the best
 // (+10 % over 64), 192 / 256 lose it again to register pressure and two-workgroup occupancy (SNF_B3_BN overrides the cap).
-#ifndef SNF_B3_ROWS_WAVES
 #define SNF_B3_ROWS_WAVES 1
-#endif
 template <bool BT, bool DERIV, int BN>
 __global__ __launch_bounds__(256, SNF_B3_ROWS_WAVES) void k_gemm_rows_b3(const float* __restrict__ A, const float* __restrict__ Aux,
                                                       const float* __restrict__ B, const float* __restrict__ bias, int M,
@@ -494,7 +480,7 @@ __global__ __launch_bounds__(256) void k_wgrad_full_reduce(const float* __restri
 }
 
 static int wf_rows_per_wg(int N) {
-    static const int chunks = getenv("SNF_WGRAD_FULL_CHUNKS") ? atoi(getenv("SNF_WGRAD_FULL_CHUNKS")) : 256;
+    static const int chunks = 256;
     int rows = ceil_div(N, chunks > 0 ? chunks : 256);  // default: one workgroup per CU
     rows = ((rows + 15) / 16) * 16;
     if (rows < 64) rows = 64;
@@ -671,9 +657,6 @@ __global__ __launch_bounds__(THREADS) void k_gemm_ws_b3(const float* __restrict_
         for (int b = 0; b < RB; ++b)
             mb[b] = bitmask ? reinterpret_cast<const uint8_t*>(Aux) + (size_t)min(r0 + 32 * b + li, M - 1) * ldaux + half : nullptr;
         auto load8 = [&](int b, int s, int u) {
-#if defined(SNF_WS_ABLATE) && (SNF_WS_ABLATE & 4)
-            if (M > 0) return;
-#endif
             raw[u][b][0] = *reinterpret_cast<const float4*>(pa[b] + s * a_step);
             raw[u][b][1] = *reinterpret_cast<const float4*>(pa[b] + s * a_step + 4);
             if constexpr (DERIV) {
@@ -737,11 +720,7 @@ __global__ __launch_bounds__(THREADS) void k_gemm_ws_b3(const float* __restrict_
                 // refill this buffer D k-steps ahead (unconditional, clamped: see AM above)
 #pragma unroll
                 for (int b = 0; b < RB; ++b) load8(b, min(s + u + D, ksteps - 1), u);
-#if defined(SNF_WS_ABLATE) && (SNF_WS_ABLATE & 2)
-                if (s + u < 0) {
-#else
                 if (s + u < ksteps) {
-#endif
 #pragma unroll
                     for (int t = 0; t < NB; ++t) {
                         if constexpr (CT) {
@@ -763,9 +742,6 @@ __global__ __launch_bounds__(THREADS) void k_gemm_ws_b3(const float* __restrict_
                 }
             }
         }
-#if defined(SNF_WS_ABLATE) && (SNF_WS_ABLATE & 1)
-        if (acc[0][0][0] != 1234.5f) continue;
-#endif
         if constexpr (CT) {
             // transposed accumulators: lane (m = li, half) holds, in registers 4q .. 4q+3, the output features
             // col0 + 32t + 8q + 4*half + {0..3} of row m -> one 16-byte store into level (col0 + 32t)/8 + q of the level-major C
@@ -879,7 +855,7 @@ static void ws_launch(dim3 grid, size_t lds, snf_stream_t stream, const float* A
 // SNF_GEMM_WS_SMALL_LDS=<bytes>: weight slices whose 128-column LDS image exceeds <bytes> take the 64-column kernel (half the
 // LDS, two workgroups per CU) -- a 135 KB workgroup (K = 256) can only start on a CU no co-running kernel occupies
 static int ws_small_lds(size_t lds128) {
-    static const long long limit = getenv("SNF_GEMM_WS_SMALL_LDS") ? atoll(getenv("SNF_GEMM_WS_SMALL_LDS")) : (1LL << 40);
+    static const long long limit = (1LL << 40);
     return (long long)lds128 > limit;
 }
 
@@ -888,7 +864,7 @@ template <bool BT, bool DERIV>
 static int ws_try(const float* A, const float* Aux, const float* W, const float* bias, int M, int K, int Nc, int lda, int ldaux,
                   int ldw, int ldc, int act_in, int act_out, float* C, snf_stream_t stream, const float* rscale = nullptr,
                   int rgroup = 1, int aux_bits = 0, float* hbar = nullptr, uint8_t* ybits = nullptr) {
-    static const int on = getenv("SNF_GEMM_WS") ? atoi(getenv("SNF_GEMM_WS")) : 1;
+    static const int on = 1;
     const bool pa = lda < 0, ct = ldc < 0;  // level-major operands (F = 8): only this kernel reads / writes them
     if (pa || ct) {
         if ((pa && (lda != -8 || !BT || DERIV)) || (ct && (ldc != -8 || BT || !DERIV || (Nc % 8))) || (pa && ct) || (K % 16) ||
@@ -897,7 +873,7 @@ static int ws_try(const float* A, const float* Aux, const float* W, const float*
         const int small = ws_small_lds((size_t)2 * 128 * (K + 8) * sizeof(uint16_t));
         // 96-column slices where they tile the output exactly and 128 does not (192 = 2 x 96: the second 128-column slice would
         // run half its MFMAs on columns that do not exist) -- the data gradient from mask bits only (the step's head layers)
-        static const int bn96_on = getenv("SNF_GEMM_WS_BN96") ? atoi(getenv("SNF_GEMM_WS_BN96")) : 1;
+        static const int bn96_on = 1;
         const bool bn96 = bn96_on && ct && !small && (Nc % 96) == 0 && (Nc % 128) != 0 && act_in != SNF_ACT_NONE && aux_bits;
         const int bn = small ? 64 : bn96 ? 96 : 128, tile_rows = 256;
         const size_t lds = (size_t)2 * bn * (K + 8) * sizeof(uint16_t);
@@ -921,11 +897,11 @@ static int ws_try(const float* A, const float* Aux, const float* W, const float*
         }
         return 1;
     }
-    static const int min_rows = getenv("SNF_GEMM_WS_MIN_ROWS") ? atoi(getenv("SNF_GEMM_WS_MIN_ROWS")) : 4096;
+    static const int min_rows = 4096;
     if (!on || (K % 16) || K > 256 || K < 64 || M < min_rows || Nc < 64 || (Nc % 4) || (lda % 4)) return 0;
     // BN 128, 8 waves x 32 rows, 4 k-steps of A loads in flight (2 and 8 measured the same: the loads are not latency-bound);
     // narrow outputs (Nc <= 64) and SNF_GEMM_WS_VARIANT=1 take BN 64 with 4 waves x 64 rows (two workgroups per CU)
-    static const int variant = getenv("SNF_GEMM_WS_VARIANT") ? atoi(getenv("SNF_GEMM_WS_VARIANT")) : 0;
+    static const int variant = 0;
     const int v = (Nc <= 64 || variant == 1 || ws_small_lds((size_t)2 * 128 * (K + 8) * sizeof(uint16_t))) ? 1 : 0;
     const int bn = v == 1 ? 64 : 128, tile_rows = 256;
     const size_t lds = (size_t)2 * bn * (K + 8) * sizeof(uint16_t);
@@ -948,7 +924,7 @@ static int ws_try(const float* A, const float* Aux, const float* W, const float*
 
 // widest column tile (up to the SNF_B3_BN cap, default 128) that still leaves >= 256 workgroups (one per CU); 64 otherwise
 static int b3_pick_bn(int M, int Nc) {
-    static const int cap = getenv("SNF_B3_BN") ? atoi(getenv("SNF_B3_BN")) : 128;
+    static const int cap = 128;
     const int row_tiles = ceil_div(M, B3_BM);
     const int cands[3] = {256, 192, 128};
     for (int bn : cands) {
@@ -1050,7 +1026,7 @@ long long snf::b3_wgrad_full_workspace_bytes(int N, int I, int O) {
 int snf::b3_try_bwd_weight_full(const float* dY, const float* Y, const float* X, int N, int I, int O, int lddy, int ldy, int ldx,
                                 int act, float* dW, float* dbias, void* workspace, long long workspace_bytes,
                                 snf_stream_t stream, const float* rscale, int rgroup, int aux_bits) {
-    static const int on = getenv("SNF_WGRAD_FULL") ? atoi(getenv("SNF_WGRAD_FULL")) : 1;
+    static const int on = 1;
     const long long need = b3_wgrad_full_workspace_bytes(N, I, O);
     if (!on || need == 0 || dbias != nullptr || workspace == nullptr || workspace_bytes < need || (lddy % 4) ||
         (ldx < 0 ? (ldx != -8 || (I % 8)) : (ldx < I || (ldx % 4))) || (((uintptr_t)dY | (uintptr_t)X | (uintptr_t)workspace) & 15) ||
@@ -1077,7 +1053,7 @@ int snf::b3_try_bwd_weight(const float* dY, const float* Y, const float* X, int 
     rows = ((rows + B3_BK - 1) / B3_BK) * B3_BK;
     if (rows < 4 * B3_BK) rows = 4 * B3_BK;
     chunks = ceil_div(N, rows);
-    static const int xcd_order = getenv("SNF_WGRAD_XCD") ? atoi(getenv("SNF_WGRAD_XCD")) : 0;
+    static const int xcd_order = 0;
     const int chunks8 = (chunks + 7) / 8 * 8;  // whole rounds of the 8 XCDs (surplus workgroups exit at once)
     hipLaunchKernelGGL(k_gemm_wgrad_b3, dim3(to * ti * chunks8), dim3(256), 0, (hipStream_t)stream, dY, Y, X, N, I, O, lddy, ldy,
                        ldx, act, rows, dW, dbias, to, ti, chunks, xcd_order);

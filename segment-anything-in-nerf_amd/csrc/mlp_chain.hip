@@ -431,9 +431,7 @@ constexpr int chain_b3_lds_elems(int NH, int planes = 2) {  // bf16 elements, al
 template <int NH, int PLANES = 2>
 // SNF_CHAIN_FWD_WAVES=2 (<= 256 registers): the two-hidden-layer six-product chain then spills 156 B per lane -- alone 0.079 ->
 // 0.073 ms, but +53 MB of scratch traffic per step (PMC, r02k) in a step that is pinned by its HBM-bound kernels: not the default
-#ifndef SNF_CHAIN_FWD_WAVES
 #define SNF_CHAIN_FWD_WAVES 1
-#endif
 __global__ __launch_bounds__(256, SNF_CHAIN_FWD_WAVES) void k_mlp_chain_fwd_b3(const float* __restrict__ X, int ldx, const float* __restrict__ W0,
                                                           int in_real, const float* __restrict__ W1,
                                                           const float* __restrict__ Wout, int out, int out_act, long long N,
@@ -677,9 +675,7 @@ constexpr int wg_rc_lds_elems(int NH) { return 3 * (MC_H * MC_BP32 + (NH == 2 ? 
 template <int NH, bool RC = false>
 // one hidden layer: 2 waves per SIMD = 252 registers instead of 280, no spills -- a workgroup then fits beside one workgroup of
 // the table reduce on a CU (co-residency); alone 0.129 -> 0.126 ms
-#ifndef SNF_WG_WAVES_NH1
 #define SNF_WG_WAVES_NH1 2
-#endif
 __global__ __launch_bounds__(WG_T) __attribute__((amdgpu_waves_per_eu(NH == 1 ? SNF_WG_WAVES_NH1 : 1, NH == 1 ? SNF_WG_WAVES_NH1 : 1))) void k_mlp_chain_bwd_wg(const float* __restrict__ dY, int lddy, int dy_col_off,
                                                            const float* __restrict__ dY0, const float* __restrict__ Yout,
                                                            int ldy, const float* __restrict__ X, int ldx,
@@ -1024,7 +1020,7 @@ extern "C" int snf_mlp64_fwd(const float* X, int ldx, const float* W0, int in_re
     if (blocks > 256 * 4) blocks = 256 * 4;  // persistent: <= 4 workgroups per CU
     // gemm mode 1 (default): the forward chains on the six-product bf16 split (fp32-level accuracy, 2.7x less matrix time than the
     // fp32 MFMA); SNF_CHAIN_FWD_X6=0 keeps the fp32 MFMA there.  Mode 0: fp32 MFMA.  Mode 2: the three-product split.
-    static const int x6 = getenv("SNF_CHAIN_FWD_X6") ? atoi(getenv("SNF_CHAIN_FWD_X6")) : 1;
+    static const int x6 = 1;
     if (chain_b3_on()) {
         if (n_hidden == 2)
             hipLaunchKernelGGL(k_mlp_chain_fwd_b3<2>, dim3((unsigned)blocks), dim3(256), chain_b3_lds_elems(2) * sizeof(uint16_t),

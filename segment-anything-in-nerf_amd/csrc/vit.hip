@@ -355,9 +355,7 @@ __device__ __forceinline__ int at_key_slot(int kr) {
 
 // two waves per SIMD (<= 256 registers, no spills at head dim 80): with ONE (312 registers) nothing hid the barriers and the
 // load latencies of the key loop -- 14x14 windows 0.207 -> 0.128 ms, 64x64 global without positions 0.85 -> 0.53 ms
-#ifndef SNF_ATT_WAVES
 #define SNF_ATT_WAVES 2
-#endif
 template <int DB>
 __global__ __launch_bounds__(256, SNF_ATT_WAVES) void k_attention_b3(const float* __restrict__ qkv, const float* __restrict__ rel, int T,
                                                       int heads, int hd, int n, float scale, float* __restrict__ out,
@@ -611,7 +609,7 @@ extern "C" int snf_layernorm(const float* x, const float* residual, int N, int C
                              float eps, float* sum_out, float* y, snf_stream_t stream) {
     SNF_REQUIRE(x && weight && bias && y && N > 0 && C > 0, "snf_layernorm: bad argument");
     const bool al16 = ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)weight | (uintptr_t)bias | (uintptr_t)residual | (uintptr_t)sum_out) & 15) == 0);
-    static const int reg_on = getenv("SNF_LN_REG") ? atoi(getenv("SNF_LN_REG")) : 1;
+    static const int reg_on = 1;
     const int nv = (reg_on && al16 && C % 256 == 0) ? C / 256 : 0;
 #define SNF_LN(NV_) hipLaunchKernelGGL(k_layernorm_reg<NV_>, dim3(ceil_div(N, 4)), dim3(256), 0, (hipStream_t)stream, x, residual, N, \
                                        C, weight, bias, eps, sum_out, y)
@@ -663,8 +661,8 @@ extern "C" int snf_attention(const float* qkv, const float* rel, int Bw, int T, 
     SNF_REQUIRE(!rel || (n > 0 && T == n * n), "snf_attention: relative positions need T == n*n");
     dim3 grid(ceil_div(T, 128), Bw * heads);
     const int DB = (head_dim + 31) / 32;
-    static const int b3_env = getenv("SNF_ATT_B3") ? atoi(getenv("SNF_ATT_B3")) : 1;
-    static const int direct_env = getenv("SNF_ATT_REL_DIRECT") ? atoi(getenv("SNF_ATT_REL_DIRECT")) : 1;
+    static const int b3_env = 1;
+    static const int direct_env = 1;
     const int rel_direct = (rel && direct_env && b3_env && b3_enabled() && (n % 32) == 0 && (((uintptr_t)rel) & 15) == 0) ? 1 : 0;
     const size_t lds = (rel && !rel_direct) ? (size_t)4 * 32 * (2 * n + 1) * sizeof(float) : 0;
     SNF_REQUIRE(lds <= 100 * 1024, "snf_attention: grid side n=%d too large for the relative-position staging", n);

@@ -34,10 +34,10 @@ from .ops_sampling import *  # noqa: F401,F403
 from .ops_vit import *  # noqa: F401,F403
 
 HASHGRID_BWD_MODE = "sorted"  # "sorted": bucketed, atomic-free (default) | "atomic": global fp32 atomics
-PRESORT_FIELD_GRID = _os.environ.get("SNF_PRESORT_FIELD", "1") == "1"
-PLANAR_FIELD_ENCODING = _os.environ.get("SNF_PLANAR_FIELD", "1") == "1"
-PRESORT_SIDE_STREAM = _os.environ.get("SNF_PRESORT_SIDE", "1") == "1"  # False: forward-time sorts stay on the caller's stream (bench.py's serial replay)
-HASHGRID_RUN_MAX_RES = float(_os.environ.get("SNF_HG_RUN_MAX_RES", "64"))  # levels up to this resolution aggregate runs
+PRESORT_FIELD_GRID = True      # the field / proposal grids' backward sorts run at forward time (module constants: tests flip them)
+PLANAR_FIELD_ENCODING = True   # level-major hand-off between the field grid and the base MLP
+PRESORT_SIDE_STREAM = True     # False: forward-time sorts stay on the caller's stream (bench.py's serial replay)
+HASHGRID_RUN_MAX_RES = 64.0    # levels up to this resolution merge equal-row contributions before their LDS atomics
 
 # ---------------------------------------------------------------------------------------------
 # stream factory
@@ -45,10 +45,8 @@ HASHGRID_RUN_MAX_RES = float(_os.environ.get("SNF_HG_RUN_MAX_RES", "64"))  # lev
 # The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES (4) hardware queues, and which streams share a queue changes the
 # step time by up to 15 %.  The step therefore runs on exactly 4 streams by default (main, two heads, the forward-time sort).
 # All streams are made here, by name; STREAM_SLOTS[name] = position modulo 4 in the creation sequence (unused filler streams
-# are created to reach it) is a tuning hook for runs with more streams (SNF_WGRAD_SIDE=1).
+# are created to reach it) is a tuning knob for runs with more streams (ops.WGRAD_SIDE_STREAM).
 STREAM_SLOTS = {"sam": 0, "clipseg": 1, "presort": 2, "wgrad:sam": 3, "wgrad:clipseg": 0, "wgrad:main": 1}
-if _os.environ.get("SNF_STREAM_SLOTS"):
-    STREAM_SLOTS.update({k: int(v) for k, v in (kv.split("=") for kv in _os.environ["SNF_STREAM_SLOTS"].split(","))})
 _STREAMS_MADE = {"n": 0, "filler": [], "names": {}}
 
 
@@ -58,9 +56,7 @@ def make_stream(name: str) -> "torch.cuda.Stream":
         while _STREAMS_MADE["n"] % 4 != slot % 4:
             _STREAMS_MADE["filler"].append(torch.cuda.Stream())
             _STREAMS_MADE["n"] += 1
-    # SNF_STREAM_PRIORITY="sam:-1,presort:-1": HIP stream priority per task stream (-1 high, 0 default) -- measurement hook
-    prio = dict(kv.split(":") for kv in _os.environ.get("SNF_STREAM_PRIORITY", "").split(",") if ":" in kv)
-    st = torch.cuda.Stream(priority=int(prio[name])) if name in prio else torch.cuda.Stream()
+    st = torch.cuda.Stream()  # (stream priorities were measured: no effect on the step)
     _STREAMS_MADE["n"] += 1
     _STREAMS_MADE["names"][st.stream_id] = name
     return st
@@ -81,7 +77,7 @@ def stream_name(st) -> str:
 # queues differently from run to run, and about one run in three lands in a 5-15 % slower mode (8 + 8 interleaved runs on one
 # box: 3.84-3.94 ms without companions, 3.87-4.58 ms with); on exactly 4 streams every run is in the fast mode, and the
 # companions' own gain (-1.5 % when measured in r01m) is gone since the table Adam moved into the backward.
-WGRAD_SIDE_STREAM = _os.environ.get("SNF_WGRAD_SIDE", "0") == "1"
+WGRAD_SIDE_STREAM = False
 _WGRAD_STREAMS: dict = {}
 
 

@@ -159,9 +159,9 @@ class Trainer:
         self._start_step = 0
         # run the nerf / SAM-head / ClipSeg-head tasks on separate HIP streams (SNF_OVERLAP=0: one stream, for A/B runs)
         self.overlap = os.environ.get("SNF_OVERLAP", "1") == "1"
-        self.enqueue_order = os.environ.get("SNF_ENQUEUE_ORDER", "heads_first")
+        self.enqueue_order = "heads_first"
         self.pipeline_steps = False  # True: do not join the head streams at the end of a step (see train_iteration)
-        self.presort_host = os.environ.get("SNF_PRESORT_ON", "auto")  # "auto" | "sam" | "clipseg" | "own"
+        self.presort_host = "auto"  # "auto" | "sam" | "clipseg" | "own" (autotune_streams may pick "own")
         self._side = None
         # the step as a static launch schedule (step_program.py) instead of an autograd graph: same kernels, same arguments,
         # ~10x less host time per step, on one rank or many.  SNF_STATIC_STEP=0 keeps the eager autograd path.
@@ -230,8 +230,6 @@ class Trainer:
         if use_side and self._side is None:
             from . import ops
             self._side = {"sam": ops.make_stream("sam"), "clipseg": ops.make_stream("clipseg")}
-            if os.environ.get("SNF_HEADS_ONE_STREAM", "0") == "1":  # A/B: both heads on one side stream
-                self._side["clipseg"] = self._side["sam"]
         if hasattr(model, "feature_streams"):
             model.feature_streams = self._side if use_side else None
         # the forward-time sorts ride on the SAM head's stream, which is idle until the nerfacto forward has produced the

@@ -47,39 +47,37 @@ from . import distributed as D
 _KERNEL, _PY = 0, 1
 import os as _os
 
-PLANAR_HEADS = _os.environ.get("SNF_PLANAR_HEADS", "1") == "1"  # level-major hand-off between the feature grids and the head MLP
+PLANAR_HEADS = True  # level-major hand-off between the feature grids and the head MLP (module constants: tests flip them)
 # fixed-point reduce pass for the F = 8 feature tables as well: measured 12 % slower alone (1.10 vs 0.98 ms per step for the four
 # launches) and no faster inside the concurrent step (3.73-3.77 vs 3.66-3.76 ms, r02o) -- at ~1 record per row the float
 # reduce's in-bucket sort is cheap and its Adam stream already runs at 5 TB/s; off by default, kept for bit-reproducible runs
-FX_F8 = _os.environ.get("SNF_HG_FX8", "0") == "1"
-FUSED_CHAIN_WGRAD = _os.environ.get("SNF_FUSED_CHAIN_WGRAD", "1") == "1"  # weight gradients of the 64-wide nets inside the chain
+FX_F8 = False
+FUSED_CHAIN_WGRAD = True  # weight gradients of the 64-wide nets inside the chain
 # ... and their hidden activations formed again there from the inputs (bit-identical to the forward's) instead of being written
 # by the forward and read back: needs the fused backward and the six-product forward arithmetic of gemm mode 1
-CHAIN_RECOMPUTE = (_os.environ.get("SNF_CHAIN_RECOMPUTE", "1") == "1" and FUSED_CHAIN_WGRAD
-                   and _os.environ.get("SNF_CHAIN_FWD_X6", "1") != "0")
-_pbs = _os.environ.get("SNF_PROP_BWD_SIDE")
-PROP_BWD_SIDE = None if _pbs is None else (_pbs == "1")  # None: on the side stream only when there are no feature heads
-FEATURE_SORTS_ON_HEAD_STREAM = _os.environ.get("SNF_FEAT_SORT_SIDE", "1") == "1"
+CHAIN_RECOMPUTE = True
+PROP_BWD_SIDE = None  # None: the proposal backward goes to the side stream only when there are no feature heads
+FEATURE_SORTS_ON_HEAD_STREAM = True
 # The head's last layer is linear (no bias, no output activation) and the renderer after it is a weighted sum over the K samples
 # of a ray (MeanRenderer, sam_model.py:126-137; the weights are detached, sam_model.py:260-277):
 #     sum_k w_k (W h_k)  =  W (sum_k w_k h_k)
 # so the schedule renders the HIDDEN activations [R*K, 256] -> [R, 256] first and runs the last layer -- forward, data gradient,
 # weight gradient -- on R rows instead of R*K.  Same real-number result, fp32 rounding in a different order (1e-7).
-MEAN_BEFORE_LAST_LAYER = _os.environ.get("SNF_MEAN_BEFORE_LAST", "1") == "1"
-ROWS_OPERAND = _os.environ.get("SNF_ROWS_OPERAND", "1") == "1"  # ... and its gradient broadcast formed inside the GEMM loaders
+MEAN_BEFORE_LAST_LAYER = True
+ROWS_OPERAND = True  # ... and its gradient broadcast formed inside the GEMM loaders
 # The reachable-row (coarse) levels of every hash table are reduced over compact row indices and stepped inside the table backward
 # (k_hg_reduce_sparse, round 3): no gradient is written for them and no snf_adam_step_rows pass follows.  0: round-2 behaviour.
 SPARSE_LEVELS = _os.environ.get("SNF_HG_SPARSE_LEVELS", "1") == "1"
 # ... for the F = 2 tables too (measured: +0.07 ms on the field grid alone -- its coarse levels are bound by the 8-byte gathers of
 # the staged gradient, which the compact reduce does not remove, and the quad-merged bucket-wide kernel already avoids the pile-up)
-SPARSE_LEVELS_F2 = _os.environ.get("SNF_HG_SPARSE_LEVELS_F2", "0") == "1"
-PAIR_GRID_BWD = _os.environ.get("SNF_PAIR_GRID_BWD", "1") == "1"  # both feature grids of a head in one table-backward launch
-FUSED_MEAN_EPILOGUE = _os.environ.get("SNF_FUSED_MEAN", "1") == "1"  # ... and the mean itself in the hidden layer's GEMM epilogue
+SPARSE_LEVELS_F2 = False
+PAIR_GRID_BWD = True  # both feature grids of a head in one table-backward launch
+FUSED_MEAN_EPILOGUE = True  # ... and the mean itself in the hidden layer's GEMM epilogue
 # Without feature heads the step is ONE dependency chain on the main stream.  Its head -- sampling, the proposal network, the
 # resampling, the positions and the backward sorts -- needs last step's PROPOSAL update only, not the field's: it is recorded on
 # the side stream (where the proposal backward + Adam of the previous step already ran) and so runs under the tail of the
 # previous step's field backward.  What it produces and the main stream reads late is double-buffered by step parity.
-XSTEP_PROLOGUE = _os.environ.get("SNF_XSTEP_PROLOGUE", "1") == "1"
+XSTEP_PROLOGUE = True
 
 
 # SNF_ABLATE_SKIP="key,key": launches whose key contains one of these are NOT issued (results are garbage; timing probe only)
@@ -414,7 +412,7 @@ class StepProgram:
         # The backward sorts depend on positions only; they run beside the forward on the LEAST loaded stream.  With the steps
         # pipelined (no join at the end of a step) the SAM stream is the busiest of the three (two 256-wide layers, the conv
         # head, 0.4 GB of table Adam): event timeline of r02d: 3.8 / 3.6 / 2.4 ms busy per 4.06 ms step for sam / main /
-        # clipseg with the sorts on the sam stream -- so they ride on the clipseg stream (SNF_PRESORT_ON overrides); a run
+        # clipseg with the sorts on the sam stream -- so they ride on the clipseg stream (Trainer.presort_host overrides); a run
         # without feature heads gets a stream of its own for them.
         side, sort_st, feat_sort_st, pre = self._side_streams(overlap)
         xstep = pre.stream_id != main.stream_id  # the step's prologue runs on the side stream, under the previous step's tail
@@ -588,7 +586,7 @@ class StepProgram:
         # The proposal network's backward (interlevel loss -> weights -> tiny MLP -> its hash grid) shares nothing with the
         # field's backward but the forward results.  Without feature heads the GPU is otherwise on ONE stream during the
         # backward, so that chain goes to the (then idle) sort stream and runs beside the field backward; with heads the three
-        # streams already saturate the chip and it stays on the main stream (SNF_PROP_BWD_SIDE=1/0 overrides).
+        # streams already saturate the chip and it stays on the main stream (step_program.PROP_BWD_SIDE overrides).
         side_prop = True if xstep else (PROP_BWD_SIDE if PROP_BWD_SIDE is not None else (not self.heads))
         prop_st = sort_st if (updated and side_prop and sort_st.stream_id != main.stream_id) else main
         prop_block = []

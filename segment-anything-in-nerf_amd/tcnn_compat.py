@@ -80,8 +80,7 @@ class Encoding(nn.Module):
 
     PRIME_Y, PRIME_Z = 2654435761, 805459861
 
-    # a level counts as reachable-row ("sparse") while fewer than this fraction of its rows can be addressed (SNF_SPARSE_MAX_FRACTION)
-    SPARSE_MAX_FRACTION = float(__import__("os").environ.get("SNF_SPARSE_MAX_FRACTION", "0.4"))
+    SPARSE_MAX_FRACTION = 0.4  # a level counts as reachable-row ("sparse") while fewer than this fraction of its rows can be addressed
 
     @torch.no_grad()
     def active_rows(self, max_fraction: Optional[float] = None) -> Tuple[int, torch.Tensor]:

@@ -72,7 +72,7 @@ N1 = R * S
 enc = prog.bufs["enc1"].view(16, N1, 2).permute(1, 0, 2).reshape(N1, 32).double()
 W0 = torch.as_tensor(params["base_w0"]).detach().cuda().double().view(64, 32)
 pre = enc @ W0.t()
-hb1 = prog.bufs["hb1"].view(N1, 64)  # (run with SNF_CHAIN_RECOMPUTE=0: by default the schedule does not store the hidden activations)
+hb1 = prog.bufs["hb1"].view(N1, 64)  # (set step_program.CHAIN_RECOMPUTE = False first: by default the schedule does not store the hidden activations)
 for j in (14, 63, 0, 5):
     p = pre[:, j]
     print(f"unit {j}: min|pre| {p.abs().min():.3e}  n(|pre|<1e-6) {(p.abs() < 1e-6).sum().item()}  n(|pre|<1e-4) {(p.abs() < 1e-4).sum().item()} "
