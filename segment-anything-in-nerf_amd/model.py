@@ -233,8 +233,7 @@ class NerfactoModel(Model):
     @staticmethod
     def psnr(pred: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
         """torchmetrics PeakSignalNoiseRatio(data_range=1.0) (nerfacto.py:232,319)."""
-        mse = ops.mse_loss(pred, target) if pred.is_cuda else torch.mean((pred - target) ** 2)
-        return -10.0 * torch.log10(mse)
+        return -10.0 * torch.log10(ops.mse_loss(pred, target))  # (device tensors only: ops raises on a CPU tensor)
 
     def get_param_groups(self) -> Dict[str, List[Parameter]]:
         return {"proposal_networks": list(self.proposal_networks.parameters()),

@@ -21,16 +21,29 @@ class RGBRenderer(nn.Module):
         return ops.composite_rgb(rgb, w, self.training)
 
 
+class _Accumulation(torch.autograd.Function):
+    """sum_s w[r, s] from the compositing kernel; d(accumulation)/d(w) = 1, so the backward broadcasts the ray's gradient."""
+
+    @staticmethod
+    def forward(ctx, w):
+        ctx.shape = tuple(w.shape)
+        return ops.accumulation(w)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.expand(ctx.shape).contiguous()
+
+
 class AccumulationRenderer(nn.Module):
-    """renderers.py:200-223: sum of the weights along a ray.  On the device it is the accumulation output of the compositing
-    kernel (snf_composite_fwd); nothing on this path differentiates through it (it feeds the viewer / metrics only), so the
-    kernel result is returned detached -- a caller that does need d(accumulation)/d(weights) gets torch.sum."""
+    """renderers.py:200-223: sum of the weights along a ray = the accumulation output of the compositing kernel
+    (snf_composite_fwd).  Nothing on this path differentiates through it (it feeds the viewer / metrics only), so by default the
+    result is detached; `differentiable=True` keeps it in the graph (the kernel forward, a broadcast backward)."""
 
     @classmethod
     def forward(cls, weights: torch.Tensor, ray_indices=None, num_rays=None, differentiable: bool = False) -> torch.Tensor:
-        if differentiable or not weights.is_cuda:
-            return torch.sum(weights, dim=-2)
         w = weights[..., 0] if weights.dim() == 3 else weights
+        if differentiable:
+            return _Accumulation.apply(w)
         return ops.accumulation(w.detach())
 
 

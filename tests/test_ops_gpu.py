@@ -312,6 +312,18 @@ def test_render(golden):
     assert maxdiff(depth, g["depth"]) <= 1e-6 * float(np.abs(g["depth"]).max())
 
 
+def test_accumulation_renderer_gradient_goes_through_the_kernel():
+    """AccumulationRenderer(differentiable=True): the compositing kernel's accumulation in the graph, d/dw = 1 (the
+    gradient case used to fall back to torch.sum)."""
+    from samnerf_amd.renderers import AccumulationRenderer
+    w = torch.rand((37, 48, 1), device=DEV, requires_grad=True)
+    acc = AccumulationRenderer.forward(w, differentiable=True)
+    assert maxdiff(acc, w.detach().sum(dim=-2)) <= 1e-6
+    (acc * torch.arange(37, device=DEV).view(37, 1)).sum().backward()
+    assert torch.equal(w.grad[..., 0], torch.arange(37, device=DEV, dtype=torch.float32).view(37, 1).expand(37, 48))
+    assert not AccumulationRenderer.forward(w).requires_grad
+
+
 def test_render_backward():
     gen = torch.Generator().manual_seed(12)
     R, S = 50, 128
