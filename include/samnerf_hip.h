@@ -164,6 +164,18 @@ int snf_hashgrid_bwd_presorted_adam_fx(const float* grad_out, int N, int L, int 
                                        float beta1, float beta2, float eps, int step, float grad_scale, void* scratch,
                                        snf_stream_t stream);
 
+/* Render path only (no backward): a feature head's two F = 8 hash grids and its first, hidden layer in ONE kernel -- SAMField.
+ * get_outputs' grids -> cat -> first CutlassMLP layer (samnerf/sam_field.py:112-140) + ReLU + MeanRenderer over groups of 16 samples
+ * (samnerf/sam_model.py:126-137), as evaluated by the render pass of samnerf/sam_model.py:337-419.  The per-sample features of a
+ * 64-sample tile are interpolated straight into LDS as bf16 hi / lo planes and feed the matrix cores from there; the [N, 8 (LA + LB)]
+ * encoding never reaches HBM.  Hbar [N / 16, O] = sum_k row_weight[n] relu(enc[n] W^T); the caller applies the linear last layer to it.
+ * snf_split_weights_b3 prepares W [O, I] (fp32, constant during a render) as two bf16 planes in matrix-operand order, (O * I) bf16
+ * each.  Needs LA + LB even and <= 32, O in {128, 256}, group == 16, N % 64 == 0. */
+int snf_split_weights_b3(const float* W, int O, int I, void* hi_plane, void* lo_plane, snf_stream_t stream);
+int snf_grid_head_fused_fwd(const float* u, const float* tableA, const float* scalingsA, int LA, const float* tableB,
+                            const float* scalingsB, int LB, int log2_T, const void* Whi, const void* Wlo, int O,
+                            const float* row_weight, int group, float* Hbar, int N, snf_stream_t stream);
+
 /* Arithmetic of the wide (>= 128 input) dense layers: 1 (default) = bf16 3-term split on the bf16 matrix cores with fp32
  * accumulate (max abs error ~1e-6 on head-shaped data, 1/5 of the matrix cycles), 0 = exact fp32 matrix cores,
  * 2 = as 1 and the fused 64-wide chains (snf_mlp64_*) on the same split (opt-in: -9 % on those kernels, 6x their round-off).

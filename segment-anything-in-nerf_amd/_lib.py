@@ -20,7 +20,7 @@ INCLUDE = os.path.join(ROOT, "include")
 LIB_DIR = os.path.join(PKG_DIR, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libsamnerf_hip.so")
 HASH_PATH = LIB_PATH + ".srchash"
-SOURCES = ["vit.hip", "batch.hip", "sampling.hip", "hashgrid.hip", "linear.hip", "linear_b3.hip", "mlp_chain.hip", "mlp_tiny.hip", "patchconv.hip", "render.hip", "losses.hip", "optim.hip"]
+SOURCES = ["vit.hip", "batch.hip", "sampling.hip", "hashgrid.hip", "fused_head.hip", "linear.hip", "linear_b3.hip", "mlp_chain.hip", "mlp_tiny.hip", "patchconv.hip", "render.hip", "losses.hip", "optim.hip"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics"]
 
 
@@ -33,7 +33,7 @@ def _hipcc() -> str:
 
 def _source_hash() -> str:
     h = hashlib.sha256()
-    files = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "common.hpp"),
+    files = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "common.hpp"), os.path.join(CSRC, "grid_device.hpp"),
                                                          os.path.join(INCLUDE, "samnerf_hip.h")]
     for f in files:
         with open(f, "rb") as fh:
@@ -93,6 +93,8 @@ SIGNATURES = {
     "snf_hashgrid_bwd_presorted_adam_sp": [P, I, I, I, I, I, I, I, P, P, P, I, P, P, P, F, F, F, F, I, F, P, P, I, I, I, P, P],
     "snf_hashgrid_bwd_presorted_adam_pair": [P, P, I, I, I, I, P, P, P, P, I, I, P, P, P, P, P, P, P, P, I, P, P, I, I, I, P, F, F, F, F,
                                              I, F, P],
+    "snf_split_weights_b3": [P, I, I, P, P, P],
+    "snf_grid_head_fused_fwd": [P, P, P, I, P, P, I, I, P, P, I, P, I, P, I, P],
     "snf_hashgrid_bucket_bits": [I, I],
     "snf_hashgrid_sparse_max_rows": [I],
     "snf_hashgrid_bwd_presorted_adam_fx": [P, I, I, I, I, I, I, I, P, P, P, I, P, P, P, F, F, F, F, I, F, P, P],

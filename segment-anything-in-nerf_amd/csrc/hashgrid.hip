@@ -10,13 +10,12 @@
 // Launch: grid = (ceil(N/256), L): blockIdx.y is the level, so a workgroup (and its neighbours in x)
 // gather from ONE level slab; a thread owns one (sample, level) pair and keeps all 8 corner loads in flight.
 #include "common.hpp"
+#include "grid_device.hpp"
 #include <math.h>
 #include <stdlib.h>
 
 namespace snf {
 
-constexpr uint32_t PRIME_Y = 2654435761u;
-constexpr uint32_t PRIME_Z = 805459861u;
 
 template <int F> struct Vec;
 template <> struct Vec<2> { float v[2]; };
@@ -59,39 +58,6 @@ __device__ __forceinline__ void store_row8_mv(float* __restrict__ p, const float
         reinterpret_cast<float4*>(p)[0] = make_float4(v[0], v[1], v[2], v[3]);
         reinterpret_cast<float4*>(p)[1] = make_float4(v[4], v[5], v[6], v[7]);
     }
-}
-
-struct Corners {
-    uint32_t idx[8];
-    float ox, oy, oz;
-};
-
-__device__ __forceinline__ Corners corners_of(const float* __restrict__ u, int n, float s, uint32_t mask) {
-    // separately rounded product (no FMA into the subtraction below): the reference rounds `scaled` before
-    // taking floor / the fractional offset, and at resolution 2047 one ulp of `scaled` is 1e-4 of a cell.
-    // (HIP's __fmul_rn is a plain `*`, so contraction has to be switched off with the pragma.)
-#pragma clang fp contract(off)
-    const float px = u[(size_t)n * 3 + 0] * s;
-    const float py = u[(size_t)n * 3 + 1] * s;
-    const float pz = u[(size_t)n * 3 + 2] * s;
-    const float fxf = floorf(px), fyf = floorf(py), fzf = floorf(pz);
-    const uint32_t cx = (uint32_t)(int)ceilf(px), cy = (uint32_t)(int)ceilf(py) * PRIME_Y,
-                   cz = (uint32_t)(int)ceilf(pz) * PRIME_Z;
-    const uint32_t fx = (uint32_t)(int)fxf, fy = (uint32_t)(int)fyf * PRIME_Y, fz = (uint32_t)(int)fzf * PRIME_Z;
-    Corners c;
-    c.ox = px - fxf;
-    c.oy = py - fyf;
-    c.oz = pz - fzf;
-    // corner naming of encodings.py:318-325
-    c.idx[0] = (cx ^ cy ^ cz) & mask;
-    c.idx[1] = (cx ^ fy ^ cz) & mask;
-    c.idx[2] = (fx ^ fy ^ cz) & mask;
-    c.idx[3] = (fx ^ cy ^ cz) & mask;
-    c.idx[4] = (cx ^ cy ^ fz) & mask;
-    c.idx[5] = (cx ^ fy ^ fz) & mask;
-    c.idx[6] = (fx ^ fy ^ fz) & mask;
-    c.idx[7] = (fx ^ cy ^ fz) & mask;
-    return c;
 }
 
 template <int F>

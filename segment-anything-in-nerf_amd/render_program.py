@@ -27,6 +27,9 @@ import torch
 from . import _lib, ops
 
 
+FUSED_GRID_HEAD = True  # feature passes: grids + first head layer + mean in one kernel (module constant: tests flip it)
+
+
 class RenderProgram:
     """Built lazily by `SAMModel.get_outputs_for_camera_ray_bundle`; `render(origins, directions, mode)` renders [n] rays."""
 
@@ -162,23 +165,40 @@ class RenderProgram:
         gemm_b3 = int(self.lib.snf_get_gemm_mode()) >= 1
         planar = gemm_b3 and all(e.n_features_per_level == 8 for e in encs) and total % 16 == 0 and 64 <= total <= 256
         ld_enc = -8 if planar else total
-        enc_out = b("enc", (NK * total,) if planar else (NK, total))
-        col = 0
-        for e in encs:
-            L, F, T = e.n_levels, e.n_features_per_level, e.log2_hashmap_size
-            if planar:
-                k("snf_hashgrid_fwd", uk, e.params, e.scalings, NK, L, F, T, enc_out.data_ptr() + col * NK * 4, 0, 0)
-            else:
-                k("snf_hashgrid_fwd", uk, e.params, e.scalings, NK, L, F, T, enc_out, total, col)
-            col += L * F
         n_lay = len(ws_)
         commute = n_lay >= 2 and net.output_activation == ops.ACT_NONE and ws_[-1].shape[1] % 4 == 0
         wp = ws_[n_lay - 2] if commute else None
         fuse_mean = (commute and gemm_b3 and K == 16 and NK >= 8192 and wp.shape[0] % 32 == 0
                      and 64 <= wp.shape[0] <= 256 and 64 <= wp.shape[1] <= 256 and wp.shape[1] % 16 == 0
                      and int(self.lib.snf_linear_bwd_weight_workspace_bytes(NK, wp.shape[1], wp.shape[0])) > 0)
-        x, hbar = enc_out, None
-        for i, w in enumerate(ws_[:n_lay - 1] if commute else ws_):
+        # The render pass has no backward, so the encoding itself is not needed: grids -> LDS -> first layer -> ReLU -> weighted mean
+        # in one kernel (csrc/fused_head.hip, north_star's "LDS staging of per-sample features") when the hidden layer that is
+        # rendered is the FIRST layer of the head (the samnerf heads: 192 -> 256 -> out).
+        fused = (FUSED_GRID_HEAD and commute and gemm_b3 and K == 16 and n_lay == 2 and len(encs) == 2 and NK % 64 == 0
+                 and wp.shape[0] in (128, 256) and wp.shape[1] == total and total <= 256
+                 and all(e.n_features_per_level == 8 for e in encs) and encs[0].log2_hashmap_size == encs[1].log2_hashmap_size
+                 and (encs[0].n_levels + encs[1].n_levels) % 2 == 0)
+        x, hbar = None, None
+        if fused:
+            O, I = wp.shape
+            whi, wlo = b("w0_hi", (O * I,), torch.int16), b("w0_lo", (O * I,), torch.int16)
+            k("snf_split_weights_b3", wp, O, I, whi, wlo)  # (per chunk: the weights may have been trained since the last render)
+            hbar = b("hbar", (R, O))
+            ea, eb_ = encs
+            k("snf_grid_head_fused_fwd", uk, ea.params, ea.scalings, ea.n_levels, eb_.params, eb_.scalings, eb_.n_levels,
+              ea.log2_hashmap_size, whi, wlo, O, wk, K, hbar, NK)
+        else:
+            enc_out = b("enc", (NK * total,) if planar else (NK, total))
+            col = 0
+            for e in encs:
+                L, F, T = e.n_levels, e.n_features_per_level, e.log2_hashmap_size
+                if planar:
+                    k("snf_hashgrid_fwd", uk, e.params, e.scalings, NK, L, F, T, enc_out.data_ptr() + col * NK * 4, 0, 0)
+                else:
+                    k("snf_hashgrid_fwd", uk, e.params, e.scalings, NK, L, F, T, enc_out, total, col)
+                col += L * F
+            x = enc_out
+        for i, w in enumerate(() if fused else (ws_[:n_lay - 1] if commute else ws_)):
             O, I = w.shape
             act = ops.ACT_RELU if i < n_lay - 1 else net.output_activation
             ldx = ld_enc if i == 0 else I

@@ -803,6 +803,51 @@ def test_pair_launch_with_reachable_row_levels():
         assert float(res[True][gi][3].abs().max()) == 0.0 and float(res[False][gi][3].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("T,N,LA,LB,O", [(14, 4096, 12, 12, 256), (19, 65536, 12, 12, 256), (12, 640, 3, 5, 128)])
+def test_grids_and_first_head_layer_fused_through_lds(T, N, LA, LB, O):
+    """snf_grid_head_fused_fwd (render path: two F = 8 grids -> features in LDS as bf16 hi / lo planes -> first head layer on the
+    matrix cores -> ReLU -> weighted mean over groups of 16 samples) against the oracle's hash grid + fp64 layer + mean:
+    sam_field.py:112-140, sam_model.py:126-137.  bf16 3-product arithmetic: 2e-6 of the largest output."""
+    m = ops()
+    gen = torch.Generator().manual_seed(T + N)
+    ga, gb = O_grid(LA, T, 16, 128), O_grid(LB, T, 128, 512)
+    ta = (torch.rand((ga.rows, 8), generator=gen) * 2 - 1) * 0.3
+    tb = (torch.rand((gb.rows, 8), generator=gen) * 2 - 1) * 0.3
+    u = torch.rand((N, 3), generator=gen)
+    u[:4] = torch.tensor([[0, 0, 0], [1, 1, 1], [0.5, 0.5, 0.5], [1, 0, 0.25]])
+    I = (LA + LB) * 8
+    W = (torch.rand((O, I), generator=gen) * 2 - 1) / I ** 0.5
+    wk = torch.rand((N,), generator=gen)
+    enc = torch.cat([O.hashgrid_fwd(u, ta, ga.scalings(), T), O.hashgrid_fwd(u, tb, gb.scalings(), T)], -1)
+    ref = (wk.double().view(N // 16, 16, 1) * torch.relu(enc.double() @ W.double().t()).view(N // 16, 16, O)).sum(1)
+    Wd = W.to(DEV)
+    whi = torch.empty((O * I,), device=DEV, dtype=torch.int16)
+    wlo = torch.empty((O * I,), device=DEV, dtype=torch.int16)
+    hbar = torch.empty((N // 16, O), device=DEV)
+    st = m._stream()
+    m._launch("snf_split_weights_b3", m._p(Wd), O, I, m._p(whi), m._p(wlo), st)
+    tad, tbd, ud, wkd = ta.reshape(-1).to(DEV), tb.reshape(-1).to(DEV), u.to(DEV), wk.to(DEV)
+    sca, scb = ga.scalings().to(DEV), gb.scalings().to(DEV)
+    m._launch("snf_grid_head_fused_fwd", m._p(ud), m._p(tad), m._p(sca), LA, m._p(tbd), m._p(scb), LB, T, m._p(whi), m._p(wlo), O,
+              m._p(wkd), 16, m._p(hbar), N, st)
+    torch.cuda.synchronize()
+    scale = float(ref.abs().max())
+    assert scale > 0.05 and float((hbar.cpu().double() - ref).abs().max()) <= 2e-6 * max(1.0, scale) + 4e-6 * scale
+    # the split planes reproduce the weights to 2^-16 relative (hi + lo), in matrix-operand order
+    hi = (whi.cpu().to(torch.int32) & 0xFFFF) << 16
+    lo = (wlo.cpu().to(torch.int32) & 0xFFFF) << 16
+    back = (hi.view(torch.float32) + lo.view(torch.float32)).view(I // 16, O // 32, 2, 32, 8)  # [s][t][half][li][e]
+    Wb = back.permute(1, 3, 0, 2, 4).reshape(O, I)  # row 32 t + li, column 16 s + 8 half + e
+    assert float((Wb - W).abs().max()) <= 2.0 ** -15 * float(W.abs().max())
+    with pytest.raises(RuntimeError):
+        m._launch("snf_grid_head_fused_fwd", m._p(ud), m._p(tad), m._p(sca), LA, m._p(tbd), m._p(scb), LB, T, m._p(whi), m._p(wlo), O,
+                  m._p(wkd), 8, m._p(hbar), N, st)
+
+
+def O_grid(L, T, lo, hi):
+    return O.GridSpec(L, 8, T, lo, hi)
+
+
 # ---------------------------------------------------------------------------------------------
 def _planar8(x: torch.Tensor) -> torch.Tensor:
     """row-major [N, C] -> level-major [C/8][N][8] (flat)."""
