@@ -318,7 +318,7 @@ def test_accumulation_renderer_gradient_goes_through_the_kernel():
     from samnerf_amd.renderers import AccumulationRenderer
     w = torch.rand((37, 48, 1), device=DEV, requires_grad=True)
     acc = AccumulationRenderer.forward(w, differentiable=True)
-    assert maxdiff(acc, w.detach().sum(dim=-2)) <= 1e-6
+    assert maxdiff(acc, w.detach().sum(dim=-2)) <= 1e-6 * 48
     (acc * torch.arange(37, device=DEV).view(37, 1)).sum().backward()
     assert torch.equal(w.grad[..., 0], torch.arange(37, device=DEV, dtype=torch.float32).view(37, 1).expand(37, 48))
     assert not AccumulationRenderer.forward(w).requires_grad
@@ -803,8 +803,8 @@ def test_pair_launch_with_reachable_row_levels():
         assert float(res[True][gi][3].abs().max()) == 0.0 and float(res[False][gi][3].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("T,N,LA,LB,O", [(14, 4096, 12, 12, 256), (19, 65536, 12, 12, 256), (12, 640, 3, 5, 128)])
-def test_grids_and_first_head_layer_fused_through_lds(T, N, LA, LB, O):
+@pytest.mark.parametrize("T,N,LA,LB,HID", [(14, 4096, 12, 12, 256), (19, 65536, 12, 12, 256), (12, 640, 3, 5, 128)])
+def test_grids_and_first_head_layer_fused_through_lds(T, N, LA, LB, HID):
     """snf_grid_head_fused_fwd (render path: two F = 8 grids -> features in LDS as bf16 hi / lo planes -> first head layer on the
     matrix cores -> ReLU -> weighted mean over groups of 16 samples) against the oracle's hash grid + fp64 layer + mean:
     sam_field.py:112-140, sam_model.py:126-137.  bf16 3-product arithmetic: 2e-6 of the largest output."""
@@ -816,19 +816,19 @@ def test_grids_and_first_head_layer_fused_through_lds(T, N, LA, LB, O):
     u = torch.rand((N, 3), generator=gen)
     u[:4] = torch.tensor([[0, 0, 0], [1, 1, 1], [0.5, 0.5, 0.5], [1, 0, 0.25]])
     I = (LA + LB) * 8
-    W = (torch.rand((O, I), generator=gen) * 2 - 1) / I ** 0.5
+    W = (torch.rand((HID, I), generator=gen) * 2 - 1) / I ** 0.5
     wk = torch.rand((N,), generator=gen)
     enc = torch.cat([O.hashgrid_fwd(u, ta, ga.scalings(), T), O.hashgrid_fwd(u, tb, gb.scalings(), T)], -1)
-    ref = (wk.double().view(N // 16, 16, 1) * torch.relu(enc.double() @ W.double().t()).view(N // 16, 16, O)).sum(1)
+    ref = (wk.double().view(N // 16, 16, 1) * torch.relu(enc.double() @ W.double().t()).view(N // 16, 16, HID)).sum(1)
     Wd = W.to(DEV)
-    whi = torch.empty((O * I,), device=DEV, dtype=torch.int16)
-    wlo = torch.empty((O * I,), device=DEV, dtype=torch.int16)
-    hbar = torch.empty((N // 16, O), device=DEV)
+    whi = torch.empty((HID * I,), device=DEV, dtype=torch.int16)
+    wlo = torch.empty((HID * I,), device=DEV, dtype=torch.int16)
+    hbar = torch.empty((N // 16, HID), device=DEV)
     st = m._stream()
-    m._launch("snf_split_weights_b3", m._p(Wd), O, I, m._p(whi), m._p(wlo), st)
+    m._launch("snf_split_weights_b3", m._p(Wd), HID, I, m._p(whi), m._p(wlo), st)
     tad, tbd, ud, wkd = ta.reshape(-1).to(DEV), tb.reshape(-1).to(DEV), u.to(DEV), wk.to(DEV)
     sca, scb = ga.scalings().to(DEV), gb.scalings().to(DEV)
-    m._launch("snf_grid_head_fused_fwd", m._p(ud), m._p(tad), m._p(sca), LA, m._p(tbd), m._p(scb), LB, T, m._p(whi), m._p(wlo), O,
+    m._launch("snf_grid_head_fused_fwd", m._p(ud), m._p(tad), m._p(sca), LA, m._p(tbd), m._p(scb), LB, T, m._p(whi), m._p(wlo), HID,
               m._p(wkd), 16, m._p(hbar), N, st)
     torch.cuda.synchronize()
     scale = float(ref.abs().max())
@@ -836,11 +836,11 @@ def test_grids_and_first_head_layer_fused_through_lds(T, N, LA, LB, O):
     # the split planes reproduce the weights to 2^-16 relative (hi + lo), in matrix-operand order
     hi = (whi.cpu().to(torch.int32) & 0xFFFF) << 16
     lo = (wlo.cpu().to(torch.int32) & 0xFFFF) << 16
-    back = (hi.view(torch.float32) + lo.view(torch.float32)).view(I // 16, O // 32, 2, 32, 8)  # [s][t][half][li][e]
-    Wb = back.permute(1, 3, 0, 2, 4).reshape(O, I)  # row 32 t + li, column 16 s + 8 half + e
+    back = (hi.view(torch.float32) + lo.view(torch.float32)).view(I // 16, HID // 32, 2, 32, 8)  # [s][t][half][li][e]
+    Wb = back.permute(1, 3, 0, 2, 4).reshape(HID, I)  # row 32 t + li, column 16 s + 8 half + e
     assert float((Wb - W).abs().max()) <= 2.0 ** -15 * float(W.abs().max())
     with pytest.raises(RuntimeError):
-        m._launch("snf_grid_head_fused_fwd", m._p(ud), m._p(tad), m._p(sca), LA, m._p(tbd), m._p(scb), LB, T, m._p(whi), m._p(wlo), O,
+        m._launch("snf_grid_head_fused_fwd", m._p(ud), m._p(tad), m._p(sca), LA, m._p(tbd), m._p(scb), LB, T, m._p(whi), m._p(wlo), HID,
                   m._p(wkd), 8, m._p(hbar), N, st)
 
 
