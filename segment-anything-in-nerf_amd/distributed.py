@@ -73,10 +73,7 @@ def first_collective_check(rank: int, world: int, backend: str) -> None:
             f"HSA_ENABLE_IPC_MODE_LEGACY=0 (current: {os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')})") from e
     if got != float(world):
         raise RuntimeError(f"rank {rank}/{world}: first all-reduce returned {got}, expected {world} (ranks missing or doubled)")
-    try:
-        dist.destroy_process_group(probe)
-    except Exception:  # noqa: BLE001  (older torch: sub-groups cannot be destroyed one by one; it is idle from here on)
-        pass
+    # (the probe group stays: it is idle from here on, and tearing a communicator down is itself a collective on RCCL)
 
 
 # -- collectives.  backend "nccl" (= RCCL): straight through.  backend "gloo" with device tensors (tests: two ranks sharing
@@ -145,6 +142,20 @@ def shard_bounds(n: int, world: int, rank: int) -> tuple:
     return chunk, chunk * world, rank * chunk, (rank + 1) * chunk
 
 
+def shard_reduce(grad: torch.Tensor, lo: int, hi: int, bulk: int) -> None:
+    """First half of `sharded_step`: the SUM over the ranks of grad[:bulk] lands in this rank's shard grad[lo:hi]."""
+    if dist.get_backend() == "gloo":  # no reduce_scatter in gloo (CPU tests / ranks sharing a GPU): all-reduce, use the own shard
+        _all_reduce(grad[:bulk])
+    else:
+        dist.reduce_scatter_tensor(grad[lo:hi], grad[:bulk], op=dist.ReduceOp.SUM)
+
+
+def shard_gather(param: torch.Tensor, lo: int, hi: int, bulk: int) -> None:
+    """Second half: every rank's updated shard param[lo:hi] into param[:bulk] on all ranks (in place on RCCL: the input is this
+    rank's slot of the output; gloo needs a separate input buffer)."""
+    _all_gather_into(param[:bulk], param[lo:hi].clone() if dist.get_backend() == "gloo" else param[lo:hi])
+
+
 def sharded_step(param: torch.Tensor, grad: torch.Tensor, step_fn) -> None:
     """The exchange step of ray data-parallel training, ZeRO-1 style, on one flat (param, grad) slice pair:
 
@@ -162,17 +173,13 @@ def sharded_step(param: torch.Tensor, grad: torch.Tensor, step_fn) -> None:
     world, rank = dist.get_world_size(), dist.get_rank()
     chunk, bulk, lo, hi = shard_bounds(n, world, rank)
     if chunk > 0:
-        if dist.get_backend() == "gloo":  # no reduce_scatter in gloo (CPU tests): all-reduce, then use the own shard
-            _all_reduce(grad[:bulk])
-        else:
-            dist.reduce_scatter_tensor(grad[lo:hi], grad[:bulk], op=dist.ReduceOp.SUM)
+        shard_reduce(grad, lo, hi, bulk)
         step_fn(lo, hi)
         if lo > 0:
             grad[:lo].zero_()
         if hi < bulk:
             grad[hi:bulk].zero_()
-        # in place (input = this rank's slot of the output) on RCCL; gloo needs a separate input buffer
-        _all_gather_into(param[:bulk], param[lo:hi].clone() if dist.get_backend() == "gloo" else param[lo:hi])
+        shard_gather(param, lo, hi, bulk)
     if bulk < n:
         _all_reduce(grad[bulk:])
         step_fn(bulk, n)

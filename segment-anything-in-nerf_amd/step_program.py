@@ -78,6 +78,9 @@ FUSED_MEAN_EPILOGUE = True  # ... and the mean itself in the hidden layer's GEMM
 # the side stream (where the proposal backward + Adam of the previous step already ran) and so runs under the tail of the
 # previous step's field backward.  What it produces and the main stream reads late is double-buffered by step parity.
 XSTEP_PROLOGUE = True
+# Many ranks: the gradient exchange + optimizer of the replicated groups recorded into the schedule (collectives as list entries, Adam
+# as recorded launches) instead of `Optimizers.exchange_and_step` enqueueing its ~15 torch / C-ABI calls per group eagerly each step
+RECORD_EXCHANGE = True
 
 
 # SNF_ABLATE_SKIP="key,key": launches whose key contains one of these are NOT issued (results are garbage; timing probe only)
@@ -313,25 +316,83 @@ class StepProgram:
             self.opt.exchange_and_step(group, first, last, count_step=count_step, done=done)
 
     def _opt_step(self, st, group: str, lo: int, hi: int, done, first=None, last=None, count_step: bool = True) -> None:
-        """Optimizer step of arena elements [lo, hi) of `group`: recorded Adam launches on one rank, the exchange otherwise."""
-        if self.multi:
-            self._py(self._exchange, st, group, first, last, count_step, list(done))
-        else:
+        """Optimizer step of arena elements [lo, hi) of `group`: recorded Adam launches on one rank; on many ranks the gradient
+        exchange of `Optimizers.exchange_and_step` recorded piece by piece (RECORD_EXCHANGE) -- its collectives as entries of the
+        list, its Adam passes as recorded C-ABI launches -- or, with the switch off, that method called at its place in the list."""
+        if not self.multi:
             self._adam(st, group, lo, hi, done)
+        elif RECORD_EXCHANGE:
+            self._record_exchange(st, group, lo, hi, list(done))
+        else:
+            self._py(self._exchange, st, group, first, last, count_step, list(done))
 
-    def _adam(self, st, group: str, lo: int, hi: int, done) -> None:
+    def _comm(self, st, fn, *args) -> None:
+        with torch.cuda.stream(st):
+            fn(*args)
+
+    def _zero(self, st, t: torch.Tensor) -> None:
+        with torch.cuda.stream(st):
+            t.zero_()
+
+    def _record_exchange(self, st, group: str, lo: int, hi: int, done) -> None:
+        """`Optimizers.exchange_and_step` for arena elements [lo, hi) of `group`, written down once (engine.py:155-213 is the
+        reference for every branch): table-parallel tables -> Adam on the owned levels, no exchange; dense segments -> reduce-scatter,
+        Adam on this rank's 1/W shard, the rest of the gradient slice cleared, all-gather of the parameters (or all-reduce +
+        replicated Adam); reachable-row segments -> only the listed rows travel, every rank steps them.  Gradients arrive SUMMED:
+        1/W is folded into the Adam launches."""
+        opt, a, W = self.opt, self.opt.arenas[group], self.world
+        scale = 1.0 / W
+        owned = opt._tp_tables(group)
+        for seg in opt._plan(group):
+            s0, s1 = max(lo, seg[1]), min(hi, seg[2])
+            if s1 <= s0:
+                continue
+            tp = next((t for t in owned if t[0] <= seg[1] < t[1]), None)
+            if tp is not None:
+                x0, x1 = max(s0, tp[2]), min(s1, tp[3])
+                if x1 > x0:
+                    self._adam(st, group, x0, x1, done, scale)
+                continue
+            if seg[0] == "dense":
+                g, p, n = a.grad[s0:s1], a.param[s0:s1], s1 - s0
+                if opt.sharded:
+                    chunk, bulk, l, h = D.shard_bounds(n, W, self.rank)
+                    if chunk > 0:
+                        self._py(self._comm, st, D.shard_reduce, g, l, h, bulk)
+                        self._adam(st, group, s0 + l, s0 + h, (), scale)
+                        if l > 0:
+                            self._py(self._zero, st, g[:l])
+                        if h < bulk:
+                            self._py(self._zero, st, g[h:bulk])
+                        self._py(self._comm, st, D.shard_gather, p, l, h, bulk)
+                    if bulk < n:
+                        self._py(self._comm, st, D._all_reduce, g[bulk:])
+                        self._adam(st, group, s0 + bulk, s1, (), scale)
+                else:
+                    self._py(self._comm, st, D._all_reduce, g)
+                    self._adam(st, group, s0, s1, (), scale)
+            else:
+                F = seg[4]
+                i0, i1 = opt._cut(group, seg, s0, s1)
+                if i1 > i0:
+                    idx = torch.div(seg[3][i0:i1].long(), F, rounding_mode="floor")
+                    self._keep.append(idx)
+                    self._py(self._comm, st, D.exchange_rows, a.grad.view(-1, F), idx)
+                    self._adam(st, group, s0, s1, (), scale)
+
+    def _adam(self, st, group: str, lo: int, hi: int, done, scale: float = 1.0) -> None:
         a, oc = self.opt.arenas[group], self.opt.config[group]["optimizer"]
         b1, b2, eps = float(oc.betas[0]), float(oc.betas[1]), float(oc.eps)
         for piece in self.opt.adam_pieces(group, lo, hi, done):
             if piece[0] == "dense":
                 x0, x1 = piece[1], piece[2]
                 self._k(st, "snf_adam_step", a.param[x0:x1], a.grad[x0:x1], a.exp_avg[x0:x1], a.exp_avg_sq[x0:x1], x1 - x0,
-                        0.0, b1, b2, eps, 1, 1.0, 1, units=32.0 * (x1 - x0), dyn={("lr", group): 5, ("t", group): 9})
+                        0.0, b1, b2, eps, 1, float(scale), 1, units=32.0 * (x1 - x0), dyn={("lr", group): 5, ("t", group): 9})
             else:
                 rows, F = piece[1], piece[2]
                 self._keep.append(rows)
                 self._k(st, "snf_adam_step_rows", a.param, a.grad, a.exp_avg, a.exp_avg_sq, rows, rows.numel(), int(F), 0.0,
-                        b1, b2, eps, 1, 1.0, 1, units=32.0 * rows.numel() * F, dyn={("lr", group): 7, ("t", group): 11})
+                        b1, b2, eps, 1, float(scale), 1, units=32.0 * rows.numel() * F, dyn={("lr", group): 7, ("t", group): 11})
 
     def _sparse_lists(self, enc, N: int, n_sparse: int):
         """(levels, rows, list offsets, longest list) of a table's reachable-row levels for a backward over N samples, or None
@@ -998,11 +1059,11 @@ class StepProgram:
                     fn(*args)
         else:
             self._replay_timed(plan, sel)
-        if not self.multi:  # (exchange_and_step counts the steps of its group itself)
+        if not self.multi or RECORD_EXCHANGE:  # (the eager exchange_and_step counts the steps of its group itself)
             for g in stepped:
                 if ("t", g) in plan.dyn:  # only groups this schedule has an Adam launch for (not 'conv' without a conv head)
                     opt.step_count[g] += 1
-        elif with_opt:
+        if self.multi and with_opt:
             for p_ in self._tp_params:  # the other ranks' copies of the owned levels are behind now (refreshed before eval / saving)
                 p_._tp_stale = True
         if updated:
