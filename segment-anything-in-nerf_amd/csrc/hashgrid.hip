@@ -64,23 +64,8 @@ template <int F>
 __global__ __launch_bounds__(256) void k_hashgrid_fwd(const float* __restrict__ u, const float* __restrict__ table,
                                                       const float* __restrict__ scalings, int N, int log2_T,
                                                       float* __restrict__ out, int ld_out, int col_off) {
-    int n = blockIdx.x * 256 + threadIdx.x;
+    const int n = blockIdx.x * 256 + threadIdx.x;
     const int l = blockIdx.y;
-    if constexpr (F == 2) {
-        // Lanes of a wave are re-assigned to samples so that the samples whose x-neighbours pair up (below) sit in the LOW lanes:
-        // the paired and the unpaired loads then each run on a contiguous block of lanes, and the texture addresser -- which is
-        // what bounds this kernel -- skips the idle quads of either instruction.  With the parities interleaved every quad was
-        // active in both branches and the pairing bought 8 % instead of the 25 % fewer addresses it issues.
-#pragma clang fp contract(off)
-        const bool valid = n < N;
-        const float px = valid ? u[(size_t)n * 3] * scalings[l] : 0.f;
-        const bool pairable = valid && (((int)ceilf(px) ^ (int)floorf(px)) == 1);
-        const unsigned long long pm = __ballot(pairable);
-        const int lane = threadIdx.x & 63;
-        const unsigned long long below = (1ull << lane) - 1ull;
-        const int dest = pairable ? __popcll(pm & below) : __popcll(pm) + __popcll(~pm & below);
-        n = __builtin_amdgcn_ds_permute(dest << 2, n);  // (a permutation of the wave's lanes: every lane receives one sample)
-    }
     if (n >= N) return;
     const uint32_t mask = (1u << log2_T) - 1u;
     const Corners c = corners_of(u, n, scalings[l], mask);
