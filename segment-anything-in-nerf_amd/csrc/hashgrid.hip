@@ -60,16 +60,26 @@ __device__ __forceinline__ void store_row8_mv(float* __restrict__ p, const float
     }
 }
 
+constexpr int HG_MAX_LOG2B = 12;  // most buckets per level of the bucketed backward (its section below)
+
+// The 8 corners of a sample as 4 x-neighbour pairs (corner order of corners_of: (0,3) (1,2) (4,7) (5,6) differ in x only).  The two
+// rows of a pair differ in their low bits only (x has the hash's unit prime; dense levels: adjacent rows), so they share a bucket
+// unless the pair straddles a bucket boundary (1 in rows-per-bucket): one LDS atomic of 2 instead of two of 1 -- the count and
+// scatter passes are bound by their LDS atomics.
+__device__ __forceinline__ void hg_count_corners(const Corners& c, int log2rpb, uint32_t* __restrict__ hist) {
+    constexpr int PA[4] = {0, 1, 4, 5}, PB[4] = {3, 2, 7, 6};
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const uint32_t ba = c.idx[PA[p]] >> log2rpb, bb = c.idx[PB[p]] >> log2rpb;
+        atomicAdd(&hist[ba], ba == bb ? 2u : 1u);
+        if (ba != bb) atomicAdd(&hist[bb], 1u);
+    }
+}
+
+// one (sample, level): gather the 8 corner rows, trilinear blend in the reference's order, store
 template <int F>
-__global__ __launch_bounds__(256) void k_hashgrid_fwd(const float* __restrict__ u, const float* __restrict__ table,
-                                                      const float* __restrict__ scalings, int N, int log2_T,
-                                                      float* __restrict__ out, int ld_out, int col_off) {
-    const int n = blockIdx.x * 256 + threadIdx.x;
-    const int l = blockIdx.y;
-    if (n >= N) return;
-    const uint32_t mask = (1u << log2_T) - 1u;
-    const Corners c = corners_of(u, n, scalings[l], mask);
-    const float* __restrict__ slab = table + ((size_t)l << log2_T) * F;
+__device__ __forceinline__ void hg_fwd_one(const Corners& c, const float* __restrict__ slab, int n, int l, int N,
+                                           float* __restrict__ out, int ld_out, int col_off) {
     float f[8][F];
 #define SNF_HG_FWD_PAIR 1
     if constexpr (F == 2 && SNF_HG_FWD_PAIR) {
@@ -127,6 +137,18 @@ __global__ __launch_bounds__(256) void k_hashgrid_fwd(const float* __restrict__ 
 }
 
 template <int F>
+__global__ __launch_bounds__(256) void k_hashgrid_fwd(const float* __restrict__ u, const float* __restrict__ table,
+                                                      const float* __restrict__ scalings, int N, int log2_T,
+                                                      float* __restrict__ out, int ld_out, int col_off) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    const int l = blockIdx.y;
+    if (n >= N) return;
+    const uint32_t mask = (1u << log2_T) - 1u;
+    const Corners c = corners_of(u, n, scalings[l], mask);
+    hg_fwd_one<F>(c, table + ((size_t)l << log2_T) * F, n, l, N, out, ld_out, col_off);
+}
+
+template <int F>
 __global__ __launch_bounds__(256) void k_hashgrid_bwd(const float* __restrict__ u, const float* __restrict__ grad_out,
                                                       const float* __restrict__ scalings, int N, int log2_T,
                                                       int ld_out, int col_off, float* __restrict__ grad_table) {
@@ -177,7 +199,6 @@ __global__ __launch_bounds__(256) void k_hashgrid_bwd(const float* __restrict__ 
 //           to the gradient table by exactly one lane with a plain read-modify-write (rows are owned, no atomics).
 // B is sized so that a bucket holds ~2048 records (8N/B), i.e. one LDS chunk.
 // ==========================================================================================
-constexpr int HG_MAX_LOG2B = 12;
 constexpr int HG_RT = 512;       // threads of the reduce workgroup (8 waves; 4 workgroups per CU)
 // records sorted per trip through LDS (16 KB of payload at F = 2, 64 KB at F = 8; a 1024-record chunk for F = 8 measured slower)
 #define SNF_HG_CHUNK8 2048
@@ -221,8 +242,7 @@ __global__ __launch_bounds__(256) void k_hg_count(const float* __restrict__ u, c
         const int n = (blk * spt + j) * 256 + tid;
         if (n < N) {
             const Corners c = corners_of(u, n, s, mask);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) atomicAdd(&hist[c.idx[k] >> log2rpb], 1u);
+            hg_count_corners(c, log2rpb, hist);
         }
     }
     __syncthreads();
@@ -307,9 +327,14 @@ inline size_t hg_scatter_lds_bytes(int log2B) {
     return ((size_t)3 << log2B) * sizeof(uint32_t) + (size_t)HG_SB_REC * (sizeof(uint2) + sizeof(uint16_t));
 }
 
+// SELF: the tile computes its own record offsets from the tile histograms (bucket totals over all tiles -> exclusive scan over
+// the buckets -> plus what the tiles before it put into each bucket) instead of reading them from a scan kernel's output: the
+// whole level's histogram is nblk x B words (64 KB at 64 tiles) from the L2, and the sort is count + scatter.  The tile blk == 0
+// writes the level's bucket_start row.
+template <bool SELF>
 __global__ __launch_bounds__(256) void k_hg_scatter(const float* __restrict__ u, const float* __restrict__ scalings, int N,
                                                     int log2_T, int log2B, int spt, const uint32_t* __restrict__ g_offs,
-                                                    uint2* __restrict__ records) {
+                                                    uint2* __restrict__ records, uint32_t* __restrict__ bucket_start) {
     extern __shared__ __attribute__((aligned(16))) uint32_t hs_lds[];
     const int B = 1 << log2B, log2rpb = log2_T - log2B;
     uint2* stage = reinterpret_cast<uint2*>(hs_lds);                        // [HG_SB_REC]
@@ -320,14 +345,58 @@ __global__ __launch_bounds__(256) void k_hg_scatter(const float* __restrict__ u,
     __shared__ uint32_t wave_tot[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int blk = blockIdx.x, l = blockIdx.y, nblk = gridDim.x;
-    for (int i = tid; i < B; i += 256) {
-        cursor[i] = g_offs[((size_t)l * nblk + blk) * B + i];
-        lcnt[i] = 0u;
+    const int bpt = (B + 255) >> 8;  // buckets per thread in the scans (1 .. 16): thread t owns buckets [t * bpt, (t + 1) * bpt)
+    if constexpr (SELF) {
+        // g_offs = the tile histograms g_hist[l][tile][bucket] here
+        uint32_t tot[16], bef[16], sum = 0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int bb = tid * bpt + q;
+            uint32_t t = 0, f = 0;
+            if (q < bpt && bb < B) {
+                const uint32_t* __restrict__ col = g_offs + (size_t)l * nblk * B + bb;
+#pragma unroll 16
+                for (int t2 = 0; t2 < nblk; ++t2) {
+                    const uint32_t h = col[(size_t)t2 * B];
+                    t += h;
+                    f += t2 < blk ? h : 0u;
+                }
+            }
+            tot[q] = t; bef[q] = f; sum += t;
+        }
+        uint32_t inc = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t t = __shfl_up(inc, d, 64);
+            if (lane >= d) inc += t;
+        }
+        if (lane == 63) wave_tot[wave] = inc;
+        __syncthreads();
+        uint32_t run = (uint32_t)((size_t)l * 8u * (uint32_t)N) + inc - sum;
+        for (int w2 = 0; w2 < wave; ++w2) run += wave_tot[w2];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int bb = tid * bpt + q;
+            if (q < bpt && bb < B) {
+                cursor[bb] = run + bef[q];
+                lcnt[bb] = 0u;
+                if (blk == 0) {
+                    bucket_start[l * (B + 1) + bb] = run;
+                    if (bb == B - 1) bucket_start[l * (B + 1) + B] = run + tot[q];
+                }
+            }
+            run += tot[q];
+        }
+        __syncthreads();  // (wave_tot is reused by the batch scans below)
+    } else {
+        for (int i = tid; i < B; i += 256) {
+            cursor[i] = g_offs[((size_t)l * nblk + blk) * B + i];
+            lcnt[i] = 0u;
+        }
     }
     __syncthreads();
     const uint32_t mask = (1u << log2_T) - 1u, rmask = (1u << log2rpb) - 1u;
     const float s = scalings[l];
-    const int bpt = (B + 255) >> 8;  // buckets per thread in the scan (1 .. 16)
     for (int j0 = 0; j0 < spt; j0 += HG_SB_SPT) {
         // ---- 1: records of this batch, ranked within their bucket
         uint2 rec[HG_SB_SPT * 8];
@@ -349,7 +418,15 @@ __global__ __launch_bounds__(256) void k_hg_scatter(const float* __restrict__ u,
                     const int q = jj * 8 + k;
                     bk[q] = c.idx[k] >> log2rpb;
                     rec[q] = make_uint2((uint32_t)n | ((c.idx[k] & rmask) << HG_SAMPLE_BITS), __float_as_uint(w[k]));
-                    rk[q] = atomicAdd(&lcnt[bk[q]], 1u);
+                }
+                constexpr int PA[4] = {0, 1, 4, 5}, PB[4] = {3, 2, 7, 6};  // x-neighbour pairs: one atomic when they share a bucket
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const int qa = jj * 8 + PA[p], qb = jj * 8 + PB[p];
+                    const bool same = bk[qa] == bk[qb];
+                    rk[qa] = atomicAdd(&lcnt[bk[qa]], same ? 2u : 1u);
+                    rk[qb] = rk[qa] + 1u;
+                    if (!same) rk[qb] = atomicAdd(&lcnt[bk[qb]], 1u);
                 }
             } else {
 #pragma unroll
@@ -1443,6 +1520,30 @@ static HgWs hg_ws_layout(void* workspace, int N, int L, const HgGeom& g) {
     return w;
 }
 
+// second half of the sort from the tile histograms in w.hist: offsets + record scatter.  Up to HG_SELF_SCAN_TILES tiles per level the
+// scatter computes its offsets itself (one launch less: the feature grids' 64-tile sort 76 -> 70 us); at 128 tiles re-reading the
+// level's histogram in every tile costs more than the scan kernel (field grid: 270 vs 261 us), which then writes them out.
+constexpr int HG_SELF_SCAN_TILES = 64;
+static void hg_scatter_from_hist(hipStream_t st, const float* u, const float* scalings, int N, int L, int log2_T, const HgGeom& g,
+                                 const HgWs& w) {
+    static int lds_attr[2] = {0, 0};  // largest dynamic-LDS size each scatter instantiation has been opened for
+    const bool self = g.nblk <= HG_SELF_SCAN_TILES;
+    const int lds = (int)hg_scatter_lds_bytes(g.log2B);
+    if (lds > 48 * 1024 && lds > lds_attr[self ? 1 : 0]) {
+        lds_attr[self ? 1 : 0] = lds;
+        if (self) (void)hipFuncSetAttribute((const void*)k_hg_scatter<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        else (void)hipFuncSetAttribute((const void*)k_hg_scatter<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    }
+    if (self) {
+        hipLaunchKernelGGL(k_hg_scatter<true>, dim3(g.nblk, L), dim3(256), lds, st, u, scalings, N, log2_T, g.log2B, g.spt, w.hist,
+                           (uint2*)w.records, w.bstart);
+    } else {
+        hipLaunchKernelGGL(k_hg_scan, dim3(L), dim3(1024), 0, st, N, g.log2B, g.nblk, w.hist, w.offs, w.bstart);
+        hipLaunchKernelGGL(k_hg_scatter<false>, dim3(g.nblk, L), dim3(256), lds, st, u, scalings, N, log2_T, g.log2B, g.spt, w.offs,
+                           (uint2*)w.records, w.bstart);
+    }
+}
+
 extern "C" int snf_hashgrid_sort(const float* u, const float* scalings, int N, int L, int log2_T, void* workspace,
                                  int64_t workspace_bytes, snf_stream_t stream) {
     SNF_REQUIRE(u && scalings, "snf_hashgrid_sort: null pointer");
@@ -1453,14 +1554,7 @@ extern "C" int snf_hashgrid_sort(const float* u, const float* scalings, int N, i
     const HgWs w = hg_ws_layout(workspace, N, L, g);
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_hg_count, dim3(g.nblk, L), dim3(256), 0, st, u, scalings, N, log2_T, g.log2B, g.spt, w.hist);
-    hipLaunchKernelGGL(k_hg_scan, dim3(L), dim3(1024), 0, st, N, g.log2B, g.nblk, w.hist, w.offs, w.bstart);
-    static int lds_attr = 0;  // largest dynamic-LDS size the scatter kernel has been opened for (one runtime call per growth)
-    if (hg_scatter_lds_bytes(g.log2B) > 48 * 1024 && (int)hg_scatter_lds_bytes(g.log2B) > lds_attr) {
-        lds_attr = (int)hg_scatter_lds_bytes(g.log2B);
-        (void)hipFuncSetAttribute((const void*)k_hg_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, lds_attr);
-    }
-    hipLaunchKernelGGL(k_hg_scatter, dim3(g.nblk, L), dim3(256), hg_scatter_lds_bytes(g.log2B), st, u, scalings, N, log2_T,
-                       g.log2B, g.spt, w.offs, (uint2*)w.records);
+    hg_scatter_from_hist(st, u, scalings, N, L, log2_T, g, w);
     SNF_LAUNCH_CHECK("snf_hashgrid_sort");
     return SNF_OK;
 }
