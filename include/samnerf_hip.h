@@ -409,6 +409,29 @@ int snf_relpos(const float* qkv, int Bw, int T, int heads, int head_dim, int n, 
 int snf_attention(const float* qkv, const float* rel, int Bw, int T, int heads, int head_dim, int n, float scale, float* out,
                   snf_stream_t stream);
 
+/* The encoder block's four token GEMMs (attn.qkv / attn.proj / mlp.lin1 / mlp.lin2, image_encoder.py:164-236, common.py:13-28)
+ * on operands that arrive already split into bf16 hi / lo planes (x = hi + lo; a product = hi*hi + hi*lo + lo*hi on the bf16
+ * matrix cores, fp32 accumulate: the arithmetic of snf_linear_fwd in gemm mode 1, without its per-tile VALU split).
+ *   row-major planes  [Nc][K]      : the constant weights, split once (snf_split_planes; n = Nc*K elements);
+ *   k-blocked planes  [K/8][M][8]  : the activations, written by their producer -- snf_layernorm_planes (LayerNorm, with the
+ *     window partition's row map: token (b,y,x) lands at its window row, padded rows are never written and must be zero),
+ *     snf_attention_planes, or snf_linear_planes_fwd itself (c_hi / c_lo: lin1's GELU output is lin2's operand);
+ *     snf_split_planes_kb converts a row-major fp32 matrix (tests, odd producers).
+ * snf_linear_planes_fwd: C = act(A W^T + bias), act in {NONE, RELU, GELU}; K % 64 == 0, Nc % 64 == 0; fp32 output C [M][Nc]
+ *   and / or plane output [Nc/8][M][8]; all pointers 16-byte aligned. */
+int snf_split_planes(const float* x, int64_t n, uint16_t* hi, uint16_t* lo, snf_stream_t stream);
+int snf_split_planes_kb(const float* x, int M, int K, uint16_t* hi, uint16_t* lo, snf_stream_t stream);
+int snf_linear_planes_fwd(const uint16_t* a_hi, const uint16_t* a_lo, const uint16_t* w_hi, const uint16_t* w_lo, const float* bias,
+                          int M, int K, int Nc, int act, float* C, uint16_t* c_hi, uint16_t* c_lo, snf_stream_t stream);
+/* (tuning / benchmarking: the same with the tile shape (128 rb rows x 32 nb columns) given instead of chosen) */
+int snf_linear_planes_fwd_shape(const uint16_t* a_hi, const uint16_t* a_lo, const uint16_t* w_hi, const uint16_t* w_lo,
+                                const float* bias, int M, int K, int Nc, int act, float* C, uint16_t* c_hi, uint16_t* c_lo, int rb,
+                                int nb, snf_stream_t stream);
+int snf_layernorm_planes(const float* x, const float* residual, int N, int C, const float* weight, const float* bias, float eps,
+                         float* sum_out, uint16_t* y_hi, uint16_t* y_lo, int M_out, int H, int W, int ws, snf_stream_t stream);
+int snf_attention_planes(const float* qkv, const float* rel, int Bw, int T, int heads, int head_dim, int n, float scale,
+                         uint16_t* out_hi, uint16_t* out_lo, snf_stream_t stream);
+
 /* ---- the batch builder in front of the path (images, feature maps and cameras resident in HBM).
  * snf_pixel_indices: PixelSampler (patch == 1: u [B,3]) / PatchPixelSampler (u [B/patch^2,3]) .sample_method without a
  *   mask (nerfstudio/data/pixel_samplers.py:50-75,246-300): u ~ U[0,1) -> indices [B,3] int64 (camera, row, col).

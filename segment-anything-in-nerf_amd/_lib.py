@@ -20,7 +20,7 @@ INCLUDE = os.path.join(ROOT, "include")
 LIB_DIR = os.path.join(PKG_DIR, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libsamnerf_hip.so")
 HASH_PATH = LIB_PATH + ".srchash"
-SOURCES = ["vit.hip", "batch.hip", "sampling.hip", "hashgrid.hip", "fused_head.hip", "linear.hip", "linear_b3.hip", "mlp_chain.hip", "mlp_tiny.hip", "patchconv.hip", "render.hip", "losses.hip", "optim.hip"]
+SOURCES = ["vit.hip", "gemm_planes.hip", "batch.hip", "sampling.hip", "hashgrid.hip", "fused_head.hip", "linear.hip", "linear_b3.hip", "mlp_chain.hip", "mlp_tiny.hip", "patchconv.hip", "render.hip", "losses.hip", "optim.hip"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics"]
 
 
@@ -135,6 +135,12 @@ SIGNATURES = {
     "snf_window_merge_add": [P, P, I, I, I, I, I, P, P],
     "snf_relpos": [P, I, I, I, I, I, P, P, P, P],
     "snf_attention": [P, P, I, I, I, I, I, F, P, P],
+    "snf_split_planes": [P, c_int64, P, P, P],
+    "snf_split_planes_kb": [P, I, I, P, P, P],
+    "snf_linear_planes_fwd": [P, P, P, P, P, I, I, I, I, P, P, P, P],
+    "snf_linear_planes_fwd_shape": [P, P, P, P, P, I, I, I, I, P, P, P, I, I, P],
+    "snf_layernorm_planes": [P, P, I, I, P, P, F, P, P, P, I, I, I, I, P],
+    "snf_attention_planes": [P, P, I, I, I, I, I, F, P, P, P],
     "snf_pixel_indices": [P, I, I, I, I, I, P, P],
     "snf_generate_rays": [P, I, P, P, I, P, P, P, P, P],
     "snf_gather_nearest": [P, I, I, I, P, I, I, I, I, I, I, P, P],

@@ -105,6 +105,70 @@ __global__ __launch_bounds__(256) void k_layernorm_reg(const float* __restrict__
     }
 }
 
+// k_layernorm_reg writing its result as the GEMM's activation operand: bf16 hi / lo k-blocked planes [C/8][M_out][8]
+// (csrc/gemm_planes.hip), at the row the window partition gives the token (ws > 0: token (b, y, x) of the [B, H, W] grid goes to
+// window (y / ws, x / ws), position (y % ws, x % ws); the padded rows of the planes are never written and stay zero, as
+// window_partition pads AFTER the norm, image_encoder.py:170-176,239-261).  A lane owns four consecutive columns: one 8-byte store
+// per plane and quad, the two lanes of a k-block adjacent.
+typedef __bf16 ln_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float ln_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void ln_split2(float x0, float x1, uint32_t& hi, uint32_t& lo) {
+    const ln_f32x2 v = {x0, x1};
+    hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, ln_bf16x2));
+    const ln_f32x2 r = {x0 - __uint_as_float(hi << 16), x1 - __uint_as_float(hi & 0xFFFF0000u)};
+    lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, ln_bf16x2));
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void k_layernorm_planes(const float* __restrict__ x, const float* __restrict__ res, int N, int C,
+                                                          const float* __restrict__ w, const float* __restrict__ b, float eps,
+                                                          float* __restrict__ sum_out, uint16_t* __restrict__ yhi,
+                                                          uint16_t* __restrict__ ylo, int M_out, int H, int W, int ws) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= N) return;
+    const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * C);
+    const float4* rr = res ? reinterpret_cast<const float4*>(res + (size_t)row * C) : nullptr;
+    float4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+        v[q] = xr[lane + 64 * q];
+        if (rr) {
+            const float4 r4 = rr[lane + 64 * q];
+            v[q].x += r4.x; v[q].y += r4.y; v[q].z += r4.z; v[q].w += r4.w;
+        }
+        s += (v[q].x + v[q].y) + (v[q].z + v[q].w);
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float var = 0.f;
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+        const float d0 = v[q].x - mean, d1 = v[q].y - mean, d2 = v[q].z - mean, d3 = v[q].w - mean;
+        var += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+    }
+    const float inv = 1.f / sqrtf(wave_sum(var) / (float)C + eps);
+    int drow = row;
+    if (ws > 0) {
+        const int nWh = (H + ws - 1) / ws, nWw = (W + ws - 1) / ws;
+        const int bb = row / (H * W), yy = (row / W) % H, xx = row % W;
+        drow = ((bb * nWh + yy / ws) * nWw + xx / ws) * (ws * ws) + (yy % ws) * ws + xx % ws;
+    }
+    const float4* w4 = reinterpret_cast<const float4*>(w);
+    const float4* b4 = reinterpret_cast<const float4*>(b);
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+        const int c4 = lane + 64 * q;  // column quad: k-block c4 / 2, elements 4 (c4 & 1) .. + 3 of it
+        if (sum_out) reinterpret_cast<float4*>(sum_out + (size_t)row * C)[c4] = v[q];
+        const float4 ww = w4[c4], bb = b4[c4];
+        uint32_t h0, h1, l0, l1;
+        ln_split2((v[q].x - mean) * inv * ww.x + bb.x, (v[q].y - mean) * inv * ww.y + bb.y, h0, l0);
+        ln_split2((v[q].z - mean) * inv * ww.z + bb.z, (v[q].w - mean) * inv * ww.w + bb.w, h1, l1);
+        const size_t o = ((size_t)(c4 >> 1) * M_out + drow) * 8 + 4 * (c4 & 1);
+        *reinterpret_cast<uint2*>(yhi + o) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2*>(ylo + o) = make_uint2(l0, l1);
+    }
+}
+
 // x [B,H,W,C] -> windows [B * nWh * nWw, ws, ws, C], zero padded to multiples of ws
 __global__ __launch_bounds__(256) void k_window_partition(const float* __restrict__ x, int B, int H, int W, int C, int ws,
                                                           float* __restrict__ out) {
@@ -356,10 +420,11 @@ __device__ __forceinline__ int at_key_slot(int kr) {
 // two waves per SIMD (<= 256 registers, no spills at head dim 80): with ONE (312 registers) nothing hid the barriers and the
 // load latencies of the key loop -- 14x14 windows 0.207 -> 0.128 ms, 64x64 global without positions 0.85 -> 0.53 ms
 #define SNF_ATT_WAVES 2
-template <int DB>
+template <int DB, bool PL = false>
 __global__ __launch_bounds__(256, SNF_ATT_WAVES) void k_attention_b3(const float* __restrict__ qkv, const float* __restrict__ rel, int T,
                                                       int heads, int hd, int n, float scale, float* __restrict__ out,
-                                                      int rel_direct) {
+                                                      int rel_direct, uint16_t* __restrict__ out_hi = nullptr,
+                                                      uint16_t* __restrict__ out_lo = nullptr, int M_out = 0) {
     constexpr int DP = DB * 32;          // padded head dim
     constexpr int KS = DP / 16;          // k-steps over the head dim
     constexpr int KPB = DP + 8;          // bf16 pitch of the K planes  [32 keys][DP]
@@ -536,7 +601,30 @@ __global__ __launch_bounds__(256, SNF_ATT_WAVES) void k_attention_b3(const float
             }
         }
     }
-    if (qlive) {
+    if constexpr (PL) {
+      if (qlive) {
+        // the projection GEMM's operand (csrc/gemm_planes.hip): bf16 hi / lo k-blocked planes [C/8][M_out][8].  Registers 4q .. 4q+3
+        // of a lane are the four consecutive features 32 t + 8 q + 4 half + {0..3} of its query: one 8-byte store per plane
+        // (hd % 8 == 0: a head starts on a k-block)
+        const float inv = 1.f / l_run;
+        const size_t row = (size_t)b * T + qi;
+#pragma unroll
+        for (int t = 0; t < DB; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int d0 = t * 32 + 8 * q + 4 * half;
+                if (d0 < hd) {  // hd % 4 == 0
+                    uint32_t h0, h1, l0, l1;
+                    at_split2(o[t][4 * q] * inv, o[t][4 * q + 1] * inv, h0, l0);
+                    at_split2(o[t][4 * q + 2] * inv, o[t][4 * q + 3] * inv, h1, l1);
+                    const int c = h * hd + d0;
+                    const size_t oo = ((size_t)(c >> 3) * M_out + row) * 8 + (c & 7);
+                    *reinterpret_cast<uint2*>(out_hi + oo) = make_uint2(h0, h1);
+                    *reinterpret_cast<uint2*>(out_lo + oo) = make_uint2(l0, l1);
+                }
+            }
+      }
+    } else if (qlive) {
         const float inv = 1.f / l_run;
         float* op = out + ((size_t)b * T + qi) * C + h * hd;
 #pragma unroll
@@ -623,6 +711,31 @@ extern "C" int snf_layernorm(const float* x, const float* residual, int N, int C
     return SNF_OK;
 }
 
+extern "C" int snf_layernorm_planes(const float* x, const float* residual, int N, int C, const float* weight, const float* bias,
+                                    float eps, float* sum_out, uint16_t* y_hi, uint16_t* y_lo, int M_out, int H, int W, int ws,
+                                    snf_stream_t stream) {
+    SNF_REQUIRE(x && weight && bias && y_hi && y_lo && N > 0 && C > 0, "snf_layernorm_planes: bad argument");
+    SNF_REQUIRE(C % 256 == 0 && C / 256 <= 8 && C / 256 != 7,
+                "snf_layernorm_planes: C=%d (the row is held in registers: a multiple of 256 up to 2048, not 1792)", C);
+    SNF_REQUIRE(((((uintptr_t)x | (uintptr_t)y_hi | (uintptr_t)y_lo | (uintptr_t)weight | (uintptr_t)bias | (uintptr_t)residual |
+                   (uintptr_t)sum_out) & 15) == 0), "snf_layernorm_planes: unaligned pointer");
+    if (ws > 0) {
+        SNF_REQUIRE(H > 0 && W > 0 && N % (H * W) == 0, "snf_layernorm_planes: N=%d is not whole [H=%d, W=%d] grids", N, H, W);
+        const long long wins = (long long)(N / (H * W)) * ((H + ws - 1) / ws) * ((W + ws - 1) / ws);
+        SNF_REQUIRE((long long)M_out == wins * ws * ws, "snf_layernorm_planes: M_out=%d != %lld window rows", M_out, wins * ws * ws);
+    } else {
+        SNF_REQUIRE(M_out == N, "snf_layernorm_planes: M_out=%d != N=%d without windows", M_out, N);
+    }
+    const int nv = C / 256;
+#define SNF_LNP(NV_) hipLaunchKernelGGL(k_layernorm_planes<NV_>, dim3(ceil_div(N, 4)), dim3(256), 0, (hipStream_t)stream, x, residual, \
+                                        N, C, weight, bias, eps, sum_out, y_hi, y_lo, M_out, H, W, ws)
+    if (nv == 1) SNF_LNP(1); else if (nv == 2) SNF_LNP(2); else if (nv == 3) SNF_LNP(3); else if (nv == 4) SNF_LNP(4);
+    else if (nv == 5) SNF_LNP(5); else if (nv == 6) SNF_LNP(6); else SNF_LNP(8);
+#undef SNF_LNP
+    SNF_LAUNCH_CHECK("snf_layernorm_planes");
+    return SNF_OK;
+}
+
 extern "C" int snf_window_partition(const float* x, int B, int H, int W, int C, int ws, float* out, snf_stream_t stream) {
     SNF_REQUIRE(x && out && B > 0 && H > 0 && W > 0 && C > 0 && ws > 0, "snf_window_partition: bad argument");
     const int nW = ((H + ws - 1) / ws) * ((W + ws - 1) / ws);
@@ -654,9 +767,9 @@ extern "C" int snf_relpos(const float* qkv, int Bw, int T, int heads, int head_d
     return SNF_OK;
 }
 
-extern "C" int snf_attention(const float* qkv, const float* rel, int Bw, int T, int heads, int head_dim, int n, float scale,
-                             float* out, snf_stream_t stream) {
-    SNF_REQUIRE(qkv && out && Bw > 0 && T > 0 && heads > 0 && head_dim > 0 && head_dim <= 96,
+static int attention_launch(const float* qkv, const float* rel, int Bw, int T, int heads, int head_dim, int n, float scale,
+                            float* out, uint16_t* out_hi, uint16_t* out_lo, snf_stream_t stream) {
+    SNF_REQUIRE(qkv && (out || out_hi) && Bw > 0 && T > 0 && heads > 0 && head_dim > 0 && head_dim <= 96,
                 "snf_attention: bad argument (head_dim <= 96)");
     SNF_REQUIRE(!rel || (n > 0 && T == n * n), "snf_attention: relative positions need T == n*n");
     dim3 grid(ceil_div(T, 128), Bw * heads);
@@ -677,14 +790,38 @@ extern "C" int snf_attention(const float* qkv, const float* rel, int Bw, int T, 
 #define SNF_ATT_B3(DB_)                                                                                                     \
     do {                                                                                                                    \
         if (lds > 16 * 1024)                                                                                                \
-            hipFuncSetAttribute((const void*)k_attention_b3<DB_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);    \
-        hipLaunchKernelGGL(k_attention_b3<DB_>, grid, dim3(256), lds, (hipStream_t)stream, qkv, rel, T, heads, head_dim, n,   \
-                           scale, out, rel_direct);                                                                         \
+        {                                                                                                                   \
+            (void)hipFuncSetAttribute((const void*)k_attention_b3<DB_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
+            (void)hipFuncSetAttribute((const void*)k_attention_b3<DB_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        }                                                                                                                   \
+        if (out_hi)                                                                                                         \
+            hipLaunchKernelGGL((k_attention_b3<DB_, true>), grid, dim3(256), lds, (hipStream_t)stream, qkv, rel, T, heads,      \
+                               head_dim, n, scale, out, rel_direct, out_hi, out_lo, Bw * T);                                   \
+        else                                                                                                                \
+            hipLaunchKernelGGL((k_attention_b3<DB_, false>), grid, dim3(256), lds, (hipStream_t)stream, qkv, rel, T, heads,     \
+                               head_dim, n, scale, out, rel_direct, out_hi, out_lo, Bw * T);                                   \
     } while (0)
         if (DB == 1) SNF_ATT_B3(1); else if (DB == 2) SNF_ATT_B3(2); else SNF_ATT_B3(3);
 #undef SNF_ATT_B3
-    } else if (DB == 1) SNF_ATT(1); else if (DB == 2) SNF_ATT(2); else SNF_ATT(3);
+    } else {
+        SNF_REQUIRE(out_hi == nullptr, "snf_attention_planes: needs the bf16-split gemm mode (snf_set_gemm_mode(1))");
+        if (DB == 1) SNF_ATT(1); else if (DB == 2) SNF_ATT(2); else SNF_ATT(3);
+    }
 #undef SNF_ATT
     SNF_LAUNCH_CHECK("snf_attention");
     return SNF_OK;
+}
+
+extern "C" int snf_attention(const float* qkv, const float* rel, int Bw, int T, int heads, int head_dim, int n, float scale,
+                             float* out, snf_stream_t stream) {
+    SNF_REQUIRE(out, "snf_attention: null output");
+    return attention_launch(qkv, rel, Bw, T, heads, head_dim, n, scale, out, nullptr, nullptr, stream);
+}
+
+// snf_attention with the output written as the projection GEMM's operand: bf16 hi / lo k-blocked planes [C/8][Bw*T][8]
+extern "C" int snf_attention_planes(const float* qkv, const float* rel, int Bw, int T, int heads, int head_dim, int n, float scale,
+                                    uint16_t* out_hi, uint16_t* out_lo, snf_stream_t stream) {
+    SNF_REQUIRE(out_hi && out_lo && (head_dim % 8) == 0 && (((uintptr_t)out_hi | (uintptr_t)out_lo) & 15) == 0,
+                "snf_attention_planes: null / unaligned planes or head_dim=%d not a multiple of 8", head_dim);
+    return attention_launch(qkv, rel, Bw, T, heads, head_dim, n, scale, nullptr, out_hi, out_lo, stream);
 }

@@ -16,6 +16,10 @@ import torch.nn as nn
 
 from . import ops
 
+# the blocks' GEMMs on operands split by their producers (csrc/gemm_planes.hip); False: every block through the tiled kernel that
+# splits fp32 operands itself (tests compare the two)
+PLANES_PATH = True
+
 
 class LayerNorm2d(nn.Module):
     """common.py:31-43 (parameters only; applied on channel-last rows by ops.layernorm)."""
@@ -94,9 +98,66 @@ class ImageEncoderViT(nn.Module):
                                      rel_pos_zero_init=rel_pos_zero_init,
                                      window_size=window_size if i not in global_attn_indexes else 0,
                                      input_size=(img_size // patch_size, img_size // patch_size)))
+        self._wcache, self._pcache = {}, {}  # split weights / operand-plane buffers of the split-operand block path
         self.neck = nn.Sequential(nn.Conv2d(embed_dim, out_chans, kernel_size=1, bias=False), LayerNorm2d(out_chans),
                                   nn.Conv2d(out_chans, out_chans, kernel_size=3, padding=1, bias=False),
                                   LayerNorm2d(out_chans))
+
+    # ---- the blocks on pre-split GEMM operands (csrc/gemm_planes.hip) --------------------------------------------------------
+    def _planes_ok(self, blk) -> bool:
+        """The split-operand path needs: the bf16-split gemm mode, widths the plane kernels tile (rows held in registers by the
+        norm: C a multiple of 256; GEMM outputs multiples of 128; k multiples of 64), heads that start on a k-block."""
+        if not PLANES_PATH or int(ops._L().snf_get_gemm_mode()) == 0:  # (exact-fp32 mode: the plain path)
+            return False
+        C, M = blk.norm1.weight.shape[0], blk.mlp.lin1.weight.shape[0]
+        hd = C // blk.attn.num_heads
+        return C % 256 == 0 and C // 256 in (1, 2, 3, 4, 5, 6, 8) and M % 64 == 0 and hd % 8 == 0 and hd <= 96
+
+    def _wplanes(self, lin):
+        """bf16 hi / lo planes of a layer's weight, split once and re-split when the parameter is written (load_state_dict)."""
+        key, ver = id(lin.weight), lin.weight._version
+        hit = self._wcache.get(key)
+        if hit is None or hit[0] != ver or hit[1][0].device != lin.weight.device:
+            hit = (ver, ops.split_weight_planes(lin.weight.detach().float().contiguous()))
+            self._wcache[key] = hit
+        return hit[1]
+
+    def _pbuf(self, tag: str, M: int, K: int, device, zero: bool = False):
+        key = (tag, M, K, str(device))
+        buf = self._pcache.get(key)
+        if buf is None:
+            buf = self._pcache[key] = ops.Planes.empty(M, K, device, zero=zero)
+        return buf
+
+    def _block_planes(self, blk, shortcut, pending, B: int, G: int):
+        """Block.forward (image_encoder.py:164-182) with every GEMM operand born split: norm1 writes qkv's operand at the window
+        partition's rows, the attention writes proj's, norm2 lin1's, lin1's GELU epilogue lin2's."""
+        a, ws, dev = blk.attn, blk.window_size, shortcut.device
+        C, Mh = blk.norm1.weight.shape[0], blk.mlp.lin1.weight.shape[0]
+        if ws > 0:
+            nW = (G + ws - 1) // ws
+            n, Bw = ws, B * nW * nW
+            y = self._pbuf("n1w", Bw * ws * ws, C, dev, zero=True)  # padded rows: written by nobody, zero for good
+            grid = (G, G, ws)
+        else:
+            n, Bw = G, B
+            y = self._pbuf("n1", B * G * G, C, dev)
+            grid = None
+        if pending is None:
+            ops.layernorm_planes(shortcut, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps, y, grid=grid)
+        else:
+            _, shortcut = ops.layernorm_planes(shortcut, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps, y, residual=pending,
+                                               want_sum=True, grid=grid)
+        qkv = ops.linear_planes(y, self._wplanes(a.qkv), a.qkv.bias)
+        o = ops.attention_planes(qkv, Bw, n * n, a.num_heads, n, self._pbuf("att", Bw * n * n, C, dev),
+                                 a.rel_pos_h if a.use_rel_pos else None, a.rel_pos_w if a.use_rel_pos else None)
+        o = ops.linear_planes(o, self._wplanes(a.proj), a.proj.bias)
+        shortcut = ops.window_merge_add(o, shortcut, B, G, G, ws)
+        y2 = ops.layernorm_planes(shortcut, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps, self._pbuf("n2", B * G * G, C, dev))
+        h = ops.linear_planes(y2, self._wplanes(blk.mlp.lin1), blk.mlp.lin1.bias, ops.ACT_GELU,
+                              out=self._pbuf("h", B * G * G, Mh, dev))
+        pending = ops.linear_planes(h, self._wplanes(blk.mlp.lin2), blk.mlp.lin2.bias)
+        return shortcut, pending
 
     @torch.no_grad()
     def forward(self, x: torch.Tensor, trace_blocks=()):
@@ -119,6 +180,11 @@ class ImageEncoderViT(nn.Module):
             trace[-1] = t.view(B, G, G, -1).clone()
         for bi, blk in enumerate(self.blocks):
             a, ws = blk.attn, blk.window_size
+            if self._planes_ok(blk):
+                shortcut, pending = self._block_planes(blk, shortcut, pending, B, G)
+                if bi in trace_blocks:
+                    trace[bi] = ops.window_merge_add(pending, shortcut, B, G, G, 0).view(B, G, G, -1)
+                continue
             if pending is None:
                 y = ops.layernorm(shortcut, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps)
             else:  # x = x + mlp(norm2(x)) of the previous block folds into this norm

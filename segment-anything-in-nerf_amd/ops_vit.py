@@ -93,6 +93,95 @@ def attention(qkv, Bw: int, T: int, heads: int, n: int, rel_pos_h=None, rel_pos_
     return out
 
 
+# ---- the block GEMMs on pre-split operands (csrc/gemm_planes.hip) ------------------------------------------------------------
+class Planes:
+    """An activation matrix [M, K] as the GEMM operand: bf16 hi / lo k-blocked planes [K/8, M, 8] (x = hi + lo)."""
+    __slots__ = ("hi", "lo", "M", "K")
+
+    def __init__(self, hi: torch.Tensor, lo: torch.Tensor):
+        assert hi.dtype == torch.bfloat16 and hi.shape == lo.shape and hi.dim() == 3 and hi.shape[2] == 8
+        self.hi, self.lo, self.M, self.K = hi, lo, int(hi.shape[1]), int(hi.shape[0]) * 8
+
+    @staticmethod
+    def empty(M: int, K: int, device, zero: bool = False) -> "Planes":
+        mk = torch.zeros if zero else torch.empty
+        return Planes(mk((K // 8, M, 8), device=device, dtype=torch.bfloat16), mk((K // 8, M, 8), device=device, dtype=torch.bfloat16))
+
+    def float(self) -> torch.Tensor:
+        """[M, K] fp32 (tests)."""
+        return (self.hi.float() + self.lo.float()).permute(1, 0, 2).reshape(self.M, self.K)
+
+
+@torch.no_grad()
+def split_weight_planes(w: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """A constant weight [Nc, K] -> its bf16 hi / lo planes [Nc, K] (once per checkpoint)."""
+    w = _chk(w, "w")
+    hi, lo = torch.empty(w.shape, device=w.device, dtype=torch.bfloat16), torch.empty(w.shape, device=w.device, dtype=torch.bfloat16)
+    _launch("snf_split_planes", _p(w), w.numel(), hi.data_ptr(), lo.data_ptr(), _stream())
+    return hi, lo
+
+
+@torch.no_grad()
+def split_planes_kb(x: torch.Tensor) -> Planes:
+    x = _chk(x, "x")
+    out = Planes.empty(x.shape[0], x.shape[1], x.device)
+    _launch("snf_split_planes_kb", _p(x), x.shape[0], x.shape[1], out.hi.data_ptr(), out.lo.data_ptr(), _stream())
+    return out
+
+
+@torch.no_grad()
+def layernorm_planes(x, weight, bias, eps: float, out: Planes, residual=None, want_sum: bool = False, grid=None):
+    """LayerNorm(x + residual) written as GEMM operand planes; grid = (H, W, ws): rows go where window_partition puts the tokens
+    (`out` must then have been allocated zeroed: the padded rows are never written)."""
+    x = _chk(x, "x")
+    N, C = x.shape
+    s = torch.empty_like(x) if want_sum else None
+    H, W, ws = grid if grid is not None else (0, 0, 0)
+    _launch("snf_layernorm_planes", _p(x), _p(residual), N, C, _p(weight), _p(bias), float(eps), _p(s), out.hi.data_ptr(),
+            out.lo.data_ptr(), out.M, H, W, ws, _stream())
+    return (out, s) if want_sum else out
+
+
+@torch.no_grad()
+def attention_planes(qkv, Bw: int, T: int, heads: int, n: int, out: Planes, rel_pos_h=None, rel_pos_w=None) -> Planes:
+    """`attention` with the result written as the projection GEMM's operand planes."""
+    qkv = _chk(qkv, "qkv")
+    C = qkv.shape[1] // 3
+    hd = C // heads
+    rel = None
+    if rel_pos_h is not None:
+        assert rel_pos_h.shape == (2 * n - 1, hd) and rel_pos_w.shape == (2 * n - 1, hd), "rel-pos tables must have 2n-1 rows"
+        rel = torch.empty((Bw * heads * T, 2 * n), device=qkv.device, dtype=torch.float32)
+        _launch("snf_relpos", _p(qkv), Bw, T, heads, hd, n, _p(_chk(rel_pos_h, "rel_pos_h")), _p(_chk(rel_pos_w, "rel_pos_w")),
+                _p(rel), _stream())
+    assert out.M == Bw * T and out.K == C
+    _launch("snf_attention_planes", _p(qkv), _p(rel), Bw, T, heads, hd, n, float(hd ** -0.5), out.hi.data_ptr(), out.lo.data_ptr(),
+            _stream(), units=4.0 * Bw * heads * T * T * hd)
+    return out
+
+
+@torch.no_grad()
+def linear_planes(a: Planes, w_planes, bias, act: int = ACT_NONE, out: Optional[Planes] = None, shape=None) -> torch.Tensor:
+    """act(A W^T + b) from operand planes; returns the fp32 [M, Nc] result, or writes `out` planes (and returns it) when given.
+    shape = (rb, nb): force the (128 rb) x (32 nb) tile (benchmarks)."""
+    wh, wl = w_planes
+    Nc, K = wh.shape
+    assert K == a.K, (K, a.K)
+    y = None
+    if out is None:
+        y = torch.empty((a.M, Nc), device=wh.device, dtype=torch.float32)
+    else:
+        assert out.M == a.M and out.K == Nc
+    oh, ol = (out.hi.data_ptr(), out.lo.data_ptr()) if out is not None else (None, None)
+    if shape is not None:
+        _launch("snf_linear_planes_fwd_shape", a.hi.data_ptr(), a.lo.data_ptr(), wh.data_ptr(), wl.data_ptr(), _p(bias), a.M, K, Nc,
+                act, _p(y), oh, ol, int(shape[0]), int(shape[1]), _stream(), tag=f"{K}x{Nc}", units=2.0 * a.M * K * Nc)
+    else:
+        _launch("snf_linear_planes_fwd", a.hi.data_ptr(), a.lo.data_ptr(), wh.data_ptr(), wl.data_ptr(), _p(bias), a.M, K, Nc, act,
+                _p(y), oh, ol, _stream(), tag=f"{K}x{Nc}", units=2.0 * a.M * K * Nc)
+    return out if out is not None else y
+
+
 @torch.no_grad()
 def patch_unfold(x, p: int, k: int) -> torch.Tensor:
     x = _chk(x, "x")

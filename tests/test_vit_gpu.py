@@ -109,12 +109,18 @@ def test_layernorm_window_kernels_vs_torch():
     assert torch.equal(rows, ref_rows)
 
 
-def test_vit_h_shaped_block_vs_oracle():
+@pytest.mark.parametrize("mode,planes", [("fp32", False), ("bf16x3", False), ("bf16x3", True)])
+def test_vit_h_shaped_block_vs_oracle(mode, planes, monkeypatch):
     """One windowed and one global block at ViT-H width (1280, 16 heads of 80, window 14, 64 x 64 tokens): oracle on the GPU
-    (torch fp32) against the HIP forward."""
+    (torch fp32) against the HIP forward -- exact-fp32 GEMMs, the bf16-split tiled kernel, and the product default: the blocks'
+    GEMMs on operands split by their producers (csrc/gemm_planes.hip)."""
+    from samnerf_amd import image_encoder, ops
+    ops.set_gemm_mode(mode)
+    monkeypatch.setattr(image_encoder, "PLANES_PATH", planes)
     cfg = V.ViTConfig(depth=2, global_attn_indexes=(1,))
     sd = V.init_weights(cfg, seed=1)
     enc = _build(cfg, sd)
+    assert enc._planes_ok(enc.blocks[0]) == planes
     x = torch.randn((1, 3, 1024, 1024), generator=torch.Generator().manual_seed(2))
     y = enc(x.cuda())
     with torch.no_grad():
@@ -124,17 +130,21 @@ def test_vit_h_shaped_block_vs_oracle():
     assert err <= 2e-4 * max(1.0, float(ref.abs().max())), err
 
 
-def test_full_depth_vit_h_on_one_image():
-    """BASELINE config #5, encoder half, AT SIZE: the full ViT-H (32 blocks, 1280 wide, 16 heads, window 14, global attention at
+@pytest.mark.parametrize("mode", ["fp32", "bf16x3"])
+def test_full_depth_vit_h_on_one_image(mode):
+    """(fp32: exact GEMMs; bf16x3: the product default, the blocks on the split-operand GEMMs.)  BASELINE config #5, encoder half, AT SIZE: the full ViT-H (32 blocks, 1280 wide, 16 heads, window 14, global attention at
     blocks 7 / 15 / 23 / 31; build_sam.py:14-21,53-80) on one 1024 x 1024 image -- output finite and of the right shape, and
     block-wise parity on the FIRST block (windowed, 64 x 64 tokens padded to 70 x 70) and the LAST one (global, 4096 x 4096
     attention with decomposed relative positions): the oracle's block on the very tokens the HIP forward fed its block."""
+    from samnerf_amd import ops
     from samnerf_amd.image_encoder import build_sam_vit_h_encoder
+    ops.set_gemm_mode(mode)
     cfg = V.ViTConfig()  # ViT-H defaults
     assert (cfg.depth, cfg.embed_dim, cfg.num_heads, cfg.window_size) == (32, 1280, 16, 14)
     sd = V.init_weights(cfg, seed=3)
     enc = build_sam_vit_h_encoder().eval()
     enc.load_state_dict(sd, strict=True)
+    assert enc._planes_ok(enc.blocks[0]) == (mode == "bf16x3")
     x = torch.randn((1, 3, 1024, 1024), generator=torch.Generator().manual_seed(4))
     y, trace = enc(x.cuda(), trace_blocks=(-1, 0, 30, 31))
     assert y.shape == (1, 256, 64, 64) and bool(torch.isfinite(y).all())
@@ -180,3 +190,63 @@ def test_sam_preprocess_kernel(golden):
         ref = V.forward(sd, V.sam_preprocess(img, emb.pixel_mean.cpu(), emb.pixel_std.cpu(), 224), cfg)
     assert float((feats.cpu() - ref).abs().max()) <= 2e-4 * max(1.0, float(ref.abs().max()))
     assert emb.embedding().shape == (16, 10, 14)  # ceil(300 / 448 * 14) rows of the 14 x 14 map
+
+
+@pytest.mark.parametrize("M,K,Nc", [(4900, 1280, 3840), (4096, 5120, 1280), (4096, 1280, 5120), (100, 64, 128), (333, 192, 256)])
+def test_split_operand_gemm_vs_fp64(M, K, Nc):
+    """snf_linear_planes_fwd (both tile shapes: 4900 x 3840 takes the 256 x 128 tile, the others 128 x 128) against fp64 on the
+    operands it was given: fp32 output with bias, and the GELU output written as the next GEMM's operand planes."""
+    from samnerf_amd import ops
+    ops.set_gemm_mode("bf16x3")
+    g = torch.Generator(device="cuda").manual_seed(M + K + Nc)
+    a = torch.randn((M, K), device="cuda", generator=g)
+    w = torch.randn((Nc, K), device="cuda", generator=g) * K ** -0.5
+    b = torch.randn((Nc,), device="cuda", generator=g) * 0.1
+    ap, wp = ops.split_planes_kb(a), ops.split_weight_planes(w)
+    # the planes carry x to 2^-17 relative (hi + lo of a 3-term split); rows of the k-blocked layout land where they should
+    assert float((ap.float() - a).abs().max()) <= 2 ** -16 * float(a.abs().max())
+    assert float(((wp[0].float() + wp[1].float()) - w).abs().max()) <= 2 ** -16 * float(w.abs().max())
+    ref = a.double() @ w.double().T + b.double()
+    y = ops.linear_planes(ap, wp, b)
+    scale = float(ref.abs().max())
+    assert float((y.double() - ref).abs().max()) <= 2e-5 * scale
+    out = ops.Planes.empty(M, Nc, "cuda")
+    ops.linear_planes(ap, wp, b, ops.ACT_GELU, out=out)
+    gref = torch.nn.functional.gelu(ref)
+    assert float((out.float().double() - gref).abs().max()) <= 3e-5 * scale
+    # against the tiled kernel that splits fp32 operands itself: the same products, another summation order
+    y_t = ops.linear_nograd(a, w, b)
+    assert float((y - y_t).abs().max()) <= 1e-5 * scale
+
+
+def test_producers_write_operand_planes():
+    """snf_layernorm_planes (with the window partition's row map and untouched zero padding) and snf_attention_planes against
+    the fp32 kernels they replace: the planes hold the same values to the split's 2^-16."""
+    from samnerf_amd import ops
+    ops.set_gemm_mode("bf16x3")
+    g = torch.Generator(device="cuda").manual_seed(11)
+    B, G, C, ws = 2, 20, 512, 7
+    x = torch.randn((B * G * G, C), device="cuda", generator=g)
+    r = torch.randn((B * G * G, C), device="cuda", generator=g)
+    w = 1 + 0.1 * torch.randn((C,), device="cuda", generator=g)
+    b = 0.1 * torch.randn((C,), device="cuda", generator=g)
+    y_ref, s_ref = ops.layernorm(x, w, b, 1e-6, residual=r, want_sum=True)
+    # without windows
+    out = ops.Planes.empty(B * G * G, C, "cuda")
+    _, s = ops.layernorm_planes(x, w, b, 1e-6, out, residual=r, want_sum=True)
+    assert torch.equal(s, s_ref)
+    assert float((out.float() - y_ref).abs().max()) <= 2 ** -16 * float(y_ref.abs().max())
+    # at the window partition's rows (20 -> 3 x 3 windows of 7: one padded row and column of windows)
+    part = ops.window_partition(y_ref, B, G, G, ws)
+    outw = ops.Planes.empty(part.shape[0], C, "cuda", zero=True)
+    ops.layernorm_planes(x, w, b, 1e-6, outw, residual=r, grid=(G, G, ws))
+    assert float((outw.float() - part).abs().max()) <= 2 ** -16 * float(y_ref.abs().max())
+    assert bool((outw.float()[part.abs().sum(1) == 0] == 0).all())
+    # attention
+    Bw, n, heads, hd = 3, 14, 4, 80
+    qkv = torch.randn((Bw * n * n, 3 * heads * hd), device="cuda", generator=g)
+    rh = 0.1 * torch.randn((2 * n - 1, hd), device="cuda", generator=g)
+    rw = 0.1 * torch.randn((2 * n - 1, hd), device="cuda", generator=g)
+    o_ref = ops.attention(qkv, Bw, n * n, heads, n, rh, rw)
+    op = ops.attention_planes(qkv, Bw, n * n, heads, n, ops.Planes.empty(Bw * n * n, heads * hd, "cuda"), rh, rw)
+    assert float((op.float() - o_ref).abs().max()) <= 2 ** -16 * float(o_ref.abs().max())

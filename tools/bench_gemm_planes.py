@@ -1,0 +1,34 @@
+"""The split-operand GEMM (csrc/gemm_planes.hip) on the encoder's four token GEMMs: the library's own tile choice and every tile shape
+forced, same box, HIP-event time of 20 back-to-back launches.  usage: python tools/bench_gemm_planes.py [auto-only]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import samnerf_amd
+from samnerf_amd import ops
+
+SHAPES = [None] if len(sys.argv) > 1 else [None, (2, 5), (2, 4), (1, 5), (1, 4), (2, 2), (1, 2), None]  # (auto first AND last: order effects)
+GEMMS = [("lin1 4096x1280->5120", 4096, 1280, 5120), ("lin2 4096x5120->1280", 4096, 5120, 1280),
+         ("qkv  4900x1280->3840", 4900, 1280, 3840), ("proj 4900x1280->1280", 4900, 1280, 1280)]
+for name, M, K, Nc in GEMMS:
+    g = torch.Generator(device="cuda").manual_seed(1)
+    a = torch.randn((M, K), device="cuda", generator=g)
+    w = torch.randn((Nc, K), device="cuda", generator=g) * K ** -0.5
+    b = torch.randn((Nc,), device="cuda", generator=g)
+    ap, wp = ops.split_planes_kb(a), ops.split_weight_planes(w)
+    row = []
+    for sh in SHAPES:
+        if sh is not None and Nc % (32 * sh[1]):
+            row.append(f"{sh[0]}x{sh[1]}: n/a")
+            continue
+        for _ in range(3):
+            ops.linear_planes(ap, wp, b, shape=sh)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            ops.linear_planes(ap, wp, b, shape=sh)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / 20 * 1e3
+        row.append(f"{'auto' if sh is None else '%dx%d' % sh}: {us:6.1f} us ({2.0 * M * K * Nc / us / 1e6:4.0f} TF/s-eq, {6.0 * M * K * Nc / us / 1e6 / 2500 * 100:4.1f} % bf16 peak)")
+    print(name, " | ".join(row))
