@@ -245,12 +245,14 @@ def render_measure(local_rank: int, res: int = 512, reps: int = 5) -> dict:
 
 def vit_measure(reps: int = 5) -> dict:
     """BASELINE configs[4], encoder half: SAM ViT-H image encoder forward on one 1024 x 1024 image (random weights of the
-    architecture, samnerf/segment_anything/build_sam.py:14-21), every GEMM on the bf16 3-product split."""
+    architecture, samnerf/segment_anything/build_sam.py:14-21), every GEMM on the bf16 3-product split (the blocks' four on operands
+    split by their producers, csrc/gemm_planes.hip)."""
     from samnerf_amd.image_encoder import build_sam_vit_h_encoder
     enc = build_sam_vit_h_encoder().eval()
     gen = torch.Generator(device="cuda").manual_seed(0)
     for prm in enc.parameters():
         prm.data.copy_(torch.randn(prm.shape, device="cuda", generator=gen) * 0.02)
+    enc.reset_weight_cache()  # (the parameters were written through `.data`)
     x = torch.randn((1, 3, 1024, 1024), device="cuda", generator=gen)
     with torch.no_grad():
         for _ in range(2):

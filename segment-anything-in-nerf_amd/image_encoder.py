@@ -115,12 +115,16 @@ class ImageEncoderViT(nn.Module):
 
     def _wplanes(self, lin):
         """bf16 hi / lo planes of a layer's weight, split once and re-split when the parameter is written (load_state_dict)."""
-        key, ver = id(lin.weight), lin.weight._version
+        key, tag = id(lin.weight), (lin.weight._version, lin.weight.data_ptr(), str(lin.weight.device))
         hit = self._wcache.get(key)
-        if hit is None or hit[0] != ver or hit[1][0].device != lin.weight.device:
-            hit = (ver, ops.split_weight_planes(lin.weight.detach().float().contiguous()))
+        if hit is None or hit[0] != tag:  # (writes through `.data` bump no version: call reset_weight_cache() after those)
+            hit = (tag, ops.split_weight_planes(lin.weight.detach().float().contiguous()))
             self._wcache[key] = hit
         return hit[1]
+
+    def reset_weight_cache(self) -> None:
+        """Forget the split weights (after changing parameters in a way autograd's version counter does not see)."""
+        self._wcache.clear()
 
     def _pbuf(self, tag: str, M: int, K: int, device, zero: bool = False):
         key = (tag, M, K, str(device))

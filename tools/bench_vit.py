@@ -9,6 +9,7 @@ from samnerf_amd.image_encoder import build_sam_vit_h_encoder
 enc = build_sam_vit_h_encoder().eval()
 for p in enc.parameters():
     p.data.normal_(0, 0.02)
+enc.reset_weight_cache()
 x = torch.randn((1, 3, 1024, 1024), device="cuda")
 for _ in range(2):
     y = enc(x)
