@@ -458,6 +458,7 @@ __global__ __launch_bounds__(256, SNF_ATT_WAVES) void k_attention_b3(const float
     }
     extern __shared__ float rel_lds[];
     const int RP = 2 * n + 1;
+    const uint32_t inv_n = n > 0 ? (65536u + (uint32_t)n - 1u) / (uint32_t)n : 0u;
     float* relw = rel_lds + (size_t)wave * 32 * RP;
     // rel_direct (grid side a multiple of 32: a 32-key tile lies inside ONE row of keys): the lane reads its query's one row term
     // and 16 column terms per tile straight from global memory (four float4) -- no per-wave copy of the [32][2n] position rows in
@@ -539,6 +540,7 @@ __global__ __launch_bounds__(256, SNF_ATT_WAVES) void k_attention_b3(const float
         }
         // ---- relative-position bias, mask, online softmax (everything per lane = per query)
         float m_tile = -INFINITY;
+        const bool ragged = k0 + 32 > T;
         const int kh0 = rel ? k0 / n : 0, kw0 = rel ? k0 - kh0 * n : 0;
         float rrow = 0.f;
         float4 rcol[4];
@@ -556,21 +558,28 @@ __global__ __launch_bounds__(256, SNF_ATT_WAVES) void k_attention_b3(const float
                 v += rrow + ((r & 3) == 0 ? c4.x : (r & 3) == 1 ? c4.y : (r & 3) == 2 ? c4.z : c4.w);
             }
             if (relq) {
-                int kh = kh0, kw = kw0 + vrow(r, half);
-                while (kw >= n) { kw -= n; ++kh; }
-                if (key < T) v += relq[kh] + relq[n + kw];
+                // key -> (row, column) of the n x n grid with one multiply (exact for key < 2^16, n < 2^8: inv_n = 2^16 / n rounded
+                // up); the while loop this replaces cost ~10 VALU instructions per element
+                const int kc = key < T ? key : T - 1;
+                const int kh = (int)(((uint32_t)kc * inv_n) >> 16), kw = kc - kh * n;
+                v += relq[kh] + relq[n + kw];
             }
-            v = key < T ? v : -INFINITY;
+            if (ragged) v = key < T ? v : -INFINITY;  // (only the last tile of a T that is no multiple of 32 has keys past T)
             s[r] = v;
             m_tile = fmaxf(m_tile, v);
         }
         m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 32, 64));
         const float m_new = fmaxf(m_run, m_tile);
-        const float alpha = expf(m_run - m_new);
+        // e^x = 2^(x log2 e) on the hardware exponential (v_exp_f32, 1 ulp): two instructions per weight where expf() spends ~15
+        // on range reduction the arguments (<= 0, scores of magnitude ~10) do not need; the product's rounding moves a weight by
+        // <= |x| 2^-24 relative -- below the 1e-6 the bf16 split already puts on the scores
+        constexpr float LOG2E = 1.4426950408889634f;
+        const float mb = m_new * LOG2E;
+        const float alpha = __builtin_amdgcn_exp2f(m_run * LOG2E - mb);  // (v_exp_f32; results below 2^-126 flush to 0)
         float l_tile = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float pv = expf(s[r] - m_new);
+            const float pv = __builtin_amdgcn_exp2f(s[r] * LOG2E - mb);
             s[r] = pv;
             l_tile += pv;
         }
@@ -587,10 +596,14 @@ __global__ __launch_bounds__(256, SNF_ATT_WAVES) void k_attention_b3(const float
             ph[s2] = __builtin_bit_cast(at_bf16x8, make_uint4(hp[0], hp[1], hp[2], hp[3]));
             pl[s2] = __builtin_bit_cast(at_bf16x8, make_uint4(lp[0], lp[1], lp[2], lp[3]));
         }
+        // (the running maximum settles after the first tiles: once no lane of the wave moved it, alpha is exactly 1 everywhere)
+        const bool rescale = __any(alpha != 1.f);
 #pragma unroll
         for (int t = 0; t < DB; ++t) {
+            if (rescale) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+                for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+            }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 const at_bf16x8 vh = *reinterpret_cast<const at_bf16x8*>(&Vh[(t * 32 + li) * VPB + 16 * s2 + 8 * half]);
