@@ -259,6 +259,60 @@ __global__ __launch_bounds__(1024) void k_relpos(const float* __restrict__ qkv, 
     }
 }
 
+// The same for SMALL grids (the encoder's 14 x 14 windows): one workgroup per (window, head) instead of one per query row.  With a
+// workgroup per row the launch was 5600 workgroups that each staged the whole rel_pos_w table again for 392 dot products -- 55 us per
+// launch, all of it staging latency.  Here the window's T = n*n queries (63 KB at n = 14, hd = 80) and both tables are staged once and
+// a thread forms four consecutive j of a query per pass (one LDS read of q[c] serves four products; every sum in k_relpos's order).
+__global__ __launch_bounds__(512) void k_relpos_window(const float* __restrict__ qkv, int T, int heads, int hd, int n,
+                                                       const float* __restrict__ rph, const float* __restrict__ rpw,
+                                                       float* __restrict__ rel) {
+    extern __shared__ float rpw_lds[];
+    const int P = hd + 1, R = 2 * n - 1;
+    float* qs = rpw_lds;          // [T][P]
+    float* hs = qs + T * P;       // [2n-1][P]  rel_pos_h
+    float* ws = hs + R * P;       // [2n-1][P]  rel_pos_w
+    const int bh = blockIdx.x, b = bh / heads, h = bh % heads, C = heads * hd, nt = blockDim.x;
+    const int hq = hd >> 2;       // float4 per row (hd % 4 == 0, rows 16-byte aligned: checked by the host)
+    for (int e = threadIdx.x; e < T * hq; e += nt) {
+        const int r = e / hq, c = (e - r * hq) * 4;
+        const float4 v = *reinterpret_cast<const float4*>(qkv + ((size_t)b * T + r) * 3 * C + h * hd + c);
+        float* d = qs + r * P + c;
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+    for (int e = threadIdx.x; e < R * hq; e += nt) {
+        const int r = e / hq, c = (e - r * hq) * 4;
+        const float4 a = *reinterpret_cast<const float4*>(rph + (size_t)r * hd + c);
+        const float4 w = *reinterpret_cast<const float4*>(rpw + (size_t)r * hd + c);
+        float* dh = hs + r * P + c;
+        float* dw = ws + r * P + c;
+        dh[0] = a.x; dh[1] = a.y; dh[2] = a.z; dh[3] = a.w;
+        dw[0] = w.x; dw[1] = w.y; dw[2] = w.z; dw[3] = w.w;
+    }
+    __syncthreads();
+    const int jb = (2 * n + 3) >> 2;  // blocks of four j per query
+    for (int e = threadIdx.x; e < T * jb; e += nt) {
+        const int i = e / jb, j0 = (e - i * jb) * 4;
+        const int ih = i / n, iw = i - ih * n;
+        const float* q = qs + i * P;
+        const float* r[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = min(j0 + u, 2 * n - 1);
+            r[u] = j < n ? hs + (ih - j + n - 1) * P : ws + (iw - (j - n) + n - 1) * P;
+        }
+        float a[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < hd; ++c) {
+            const float qc = q[c];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) a[u] += qc * r[u][c];
+        }
+        float* o = rel + ((size_t)bh * T + i) * 2 * n + j0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (j0 + u < 2 * n) o[u] = a[u];
+    }
+}
+
 // DB = ceil(hd / 32) output blocks of 32 head dims
 template <int DB>
 __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv, const float* __restrict__ rel, int T,
@@ -770,6 +824,20 @@ extern "C" int snf_relpos(const float* qkv, int Bw, int T, int heads, int head_d
                           const float* rel_pos_w, float* rel, snf_stream_t stream) {
     SNF_REQUIRE(qkv && rel_pos_h && rel_pos_w && rel && Bw > 0 && heads > 0 && head_dim > 0 && n > 0 && T == n * n,
                 "snf_relpos: bad argument (T must be n*n)");
+    // small grids: the window's queries and both tables in one workgroup (k_relpos_window)
+    const size_t lds_w = (size_t)(T + 2 * (2 * n - 1)) * (head_dim + 1) * sizeof(float);
+    if (n <= 16 && lds_w <= 100 * 1024 && (head_dim % 4) == 0 &&
+        ((((uintptr_t)qkv | (uintptr_t)rel_pos_h | (uintptr_t)rel_pos_w) & 15) == 0) && ((heads * head_dim) % 4) == 0) {
+        static int attr = 0;
+        if ((int)lds_w > 48 * 1024 && (int)lds_w > attr) {
+            attr = (int)lds_w;
+            (void)hipFuncSetAttribute((const void*)k_relpos_window, hipFuncAttributeMaxDynamicSharedMemorySize, attr);
+        }
+        hipLaunchKernelGGL(k_relpos_window, dim3(Bw * heads), dim3(512), lds_w, (hipStream_t)stream, qkv, T, heads, head_dim, n,
+                           rel_pos_h, rel_pos_w, rel);
+        SNF_LAUNCH_CHECK("snf_relpos");
+        return SNF_OK;
+    }
     const size_t lds = (size_t)(4 * n - 1) * (head_dim + 1) * sizeof(float);
     SNF_REQUIRE(lds <= 160 * 1024, "snf_relpos: n * head_dim too large for the LDS staging");
     if (lds > 48 * 1024) hipFuncSetAttribute((const void*)k_relpos, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
