@@ -102,6 +102,18 @@ int snf_hashgrid_bwd_presorted(const float* grad_out, int N, int L, int F, int l
                                int n_run_levels, float* grad_table, const void* sorted_workspace, float* stage,
                                snf_stream_t stream);
 
+/* The same two halves with x-pair records (F = 2 grids): the two x-neighbour corners of a sample share a bucket for all but 2^-11 of the
+ * pairs and take the same staged gradient, so snf_hashgrid_sort_xp writes ONE 16-byte record per pair (two single records for a split
+ * pair) and snf_hashgrid_bwd_presorted_adam_xp reduces it with one gradient gather per pair -- same sums, bit for bit, as
+ * snf_hashgrid_sort + snf_hashgrid_bwd_presorted(_adam) (64-bit fixed-point accumulation is order-independent).  The two sorts leave
+ * different workspaces: an _xp sort is read by the _xp backward only.  param == NULL: no optimizer step.  N even, L <= 64. */
+int snf_hashgrid_sort_xp(const float* u, const float* scalings, int N, int L, int log2_T, void* workspace, int64_t workspace_bytes,
+                         snf_stream_t stream);
+int snf_hashgrid_bwd_presorted_adam_xp(const float* grad_out, int N, int L, int log2_T, int ld_out, int col_off, int n_run_levels,
+                                       float* grad_table, const void* sorted_workspace, float* stage, int fuse_from_level,
+                                       float* param, float* exp_avg, float* exp_avg_sq, float lr, float beta1, float beta2, float eps,
+                                       int step, float grad_scale, snf_stream_t stream);
+
 /* snf_hashgrid_bwd_presorted with the optimizer step folded into its reduce pass for the levels >= fuse_from_level: the
  * workgroup that owns a bucket of rows holds their complete gradient after its last chunk and applies
  * torch.optim.Adam's update (the arithmetic of snf_adam_step: eps outside the bias-corrected sqrt, gradient pre-scaled by

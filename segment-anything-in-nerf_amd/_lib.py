@@ -89,6 +89,8 @@ SIGNATURES = {
     "snf_hashgrid_bwd_sorted": [P, P, P, I, I, I, I, I, I, P, P, c_int64, P],
     "snf_hashgrid_sort": [P, P, I, I, I, P, c_int64, P],
     "snf_hashgrid_bwd_presorted": [P, I, I, I, I, I, I, I, P, P, P, P],
+    "snf_hashgrid_sort_xp": [P, P, I, I, I, P, c_int64, P],
+    "snf_hashgrid_bwd_presorted_adam_xp": [P, I, I, I, I, I, I, P, P, P, I, P, P, P, F, F, F, F, I, F, P],
     "snf_hashgrid_bwd_presorted_adam": [P, I, I, I, I, I, I, I, P, P, P, I, P, P, P, F, F, F, F, I, F, P],
     "snf_hashgrid_bwd_presorted_adam_sp": [P, I, I, I, I, I, I, I, P, P, P, I, P, P, P, F, F, F, F, I, F, P, P, I, I, I, P, P],
     "snf_hashgrid_bwd_presorted_adam_pair": [P, P, I, I, I, I, P, P, P, P, I, I, P, P, P, P, P, P, P, P, I, P, P, I, I, I, P, F, F, F, F,

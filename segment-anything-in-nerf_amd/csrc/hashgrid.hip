@@ -10,6 +10,7 @@
 // Launch: grid = (ceil(N/256), L): blockIdx.y is the level, so a workgroup (and its neighbours in x)
 // gather from ONE level slab; a thread owns one (sample, level) pair and keeps all 8 corner loads in flight.
 #include "common.hpp"
+#include <type_traits>
 #include "grid_device.hpp"
 #include <math.h>
 #include <stdlib.h>
@@ -229,6 +230,9 @@ inline HgGeom hg_geometry(int N, int log2_T) {
     return g;
 }
 
+// XP ("x-pair records"): one record per PAIR of x-neighbour corners that share a bucket (two single records when they do not), see
+// k_hg_scatter: the count is then one per pair.
+template <bool XP>
 __global__ __launch_bounds__(256) void k_hg_count(const float* __restrict__ u, const float* __restrict__ scalings, int N,
                                                   int log2_T, int log2B, int spt, uint32_t* __restrict__ g_hist) {
     __shared__ uint32_t hist[1 << HG_MAX_LOG2B];
@@ -242,7 +246,17 @@ __global__ __launch_bounds__(256) void k_hg_count(const float* __restrict__ u, c
         const int n = (blk * spt + j) * 256 + tid;
         if (n < N) {
             const Corners c = corners_of(u, n, s, mask);
-            hg_count_corners(c, log2rpb, hist);
+            if constexpr (XP) {
+                constexpr int PA[4] = {0, 1, 4, 5}, PB[4] = {3, 2, 7, 6};
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const uint32_t ba = c.idx[PA[p]] >> log2rpb, bb = c.idx[PB[p]] >> log2rpb;
+                    atomicAdd(&hist[ba], 1u);
+                    if (ba != bb) atomicAdd(&hist[bb], 1u);
+                }
+            } else {
+                hg_count_corners(c, log2rpb, hist);
+            }
         }
     }
     __syncthreads();
@@ -476,6 +490,200 @@ __global__ __launch_bounds__(256) void k_hg_scatter(const float* __restrict__ u,
         __syncthreads();
         // ---- 4: contiguous runs out; advance the cursors
         for (uint32_t i = tid; i < total; i += 256) records[delta[sbkt[i]] + i] = stage[i];
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int bb = tid * bpt + q;
+            if (q < bpt && bb < B) {
+                cursor[bb] += cq[q];
+                lcnt[bb] = 0u;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---- x-pair records (F = 2 grids) -----------------------------------------------------------------------------------------------
+// The two x-neighbour corners of a sample -- rows h(x) and h(x + 1) of the level: the unit prime of x leaves them different in their
+// low bits only -- fall into the same 2048-row bucket for all but 2^-11 of the pairs, and both take the SAME staged gradient in the
+// reduce.  One 16-byte record per pair
+//     { sample | row_a << 21,   row_b | b_valid << 11,   w_a,   w_b }
+// lets one reduce lane serve two rows from ONE gather: the reduce is bound by the texture addresser, which counts gather instructions
+// (not their active lanes: sharing a gather between the lanes of a pair gained nothing), and the scatter ranks and stages half
+// as many records for the same bytes.  A pair that straddles two buckets leaves as two a-only records.  The level's record region
+// holds 8 N records in the worst case (every pair split), as before -- 16 bytes each here.
+constexpr int HG_XP_CAP = 256 * HG_SB_SPT * 4 + 256;  // records staged per batch (4 per sample, + room for split pairs); the rest go direct
+
+inline size_t hg_scatter_xp_lds_bytes(int log2B) {
+    return ((size_t)3 << log2B) * sizeof(uint32_t) + (size_t)HG_XP_CAP * (sizeof(uint4) + sizeof(uint16_t));
+}
+
+template <bool SELF>
+__global__ __launch_bounds__(256) void k_hg_scatter_xp(const float* __restrict__ u, const float* __restrict__ scalings, int N,
+                                                       int log2_T, int log2B, int spt, const uint32_t* __restrict__ g_offs,
+                                                       uint4* __restrict__ records, uint32_t* __restrict__ bucket_start) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t hx_lds[];
+    const int B = 1 << log2B, log2rpb = log2_T - log2B;
+    uint4* stage = reinterpret_cast<uint4*>(hx_lds);                         // [HG_XP_CAP]
+    uint32_t* cursor = hx_lds + 4 * HG_XP_CAP;                               // [B] global write cursor of this tile
+    uint32_t* lcnt = cursor + B;                                             // [B] batch-local count -> exclusive offset
+    uint32_t* delta = lcnt + B;                                              // [B] cursor - local offset
+    uint16_t* sbkt = reinterpret_cast<uint16_t*>(delta + B);                 // [HG_XP_CAP] bucket of a staged record
+    __shared__ uint32_t wave_tot[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int blk = blockIdx.x, l = blockIdx.y, nblk = gridDim.x;
+    const int bpt = (B + 255) >> 8;  // buckets per thread in the scans (1 .. 16): thread t owns buckets [t * bpt, (t + 1) * bpt)
+    if constexpr (SELF) {
+        uint32_t tot[16], bef[16], sum = 0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int bb = tid * bpt + q;
+            uint32_t t = 0, f = 0;
+            if (q < bpt && bb < B) {
+                const uint32_t* __restrict__ col = g_offs + (size_t)l * nblk * B + bb;
+#pragma unroll 16
+                for (int t2 = 0; t2 < nblk; ++t2) {
+                    const uint32_t h = col[(size_t)t2 * B];
+                    t += h;
+                    f += t2 < blk ? h : 0u;
+                }
+            }
+            tot[q] = t; bef[q] = f; sum += t;
+        }
+        uint32_t inc = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t t = __shfl_up(inc, d, 64);
+            if (lane >= d) inc += t;
+        }
+        if (lane == 63) wave_tot[wave] = inc;
+        __syncthreads();
+        uint32_t run = (uint32_t)((size_t)l * 8u * (uint32_t)N) + inc - sum;
+        for (int w2 = 0; w2 < wave; ++w2) run += wave_tot[w2];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int bb = tid * bpt + q;
+            if (q < bpt && bb < B) {
+                cursor[bb] = run + bef[q];
+                lcnt[bb] = 0u;
+                if (blk == 0) {
+                    bucket_start[l * (B + 1) + bb] = run;
+                    if (bb == B - 1) bucket_start[l * (B + 1) + B] = run + tot[q];
+                }
+            }
+            run += tot[q];
+        }
+        __syncthreads();
+    } else {
+        for (int i = tid; i < B; i += 256) {
+            cursor[i] = g_offs[((size_t)l * nblk + blk) * B + i];
+            lcnt[i] = 0u;
+        }
+    }
+    __syncthreads();
+    const uint32_t mask = (1u << log2_T) - 1u, rmask = (1u << log2rpb) - 1u;
+    const float s = scalings[l];
+    constexpr int NP = HG_SB_SPT * 4;  // pairs per thread and batch
+    for (int j0 = 0; j0 < spt; j0 += HG_SB_SPT) {
+        // ---- 1: pair records of this batch, ranked within their bucket (a split pair ranks its b corner in b's bucket too)
+        uint4 rec[NP];
+        uint32_t bka[NP], rka[NP], rkb[NP / 2];  // (rkb: two 16-bit ranks per word; only read for split pairs)
+        uint32_t split = 0u;
+#pragma unroll
+        for (int q = 0; q < NP / 2; ++q) rkb[q] = 0u;
+#pragma unroll
+        for (int jj = 0; jj < HG_SB_SPT; ++jj) {
+            const int j = j0 + jj;
+            const int n = (blk * spt + j) * 256 + tid;
+            const bool live = (j < spt) && (n < N);
+            if (live) {
+                const Corners c = corners_of(u, n, s, mask);
+                const float ox = c.ox, oy = c.oy, oz = c.oz;
+                const float mx = 1.f - ox, my = 1.f - oy, mz = 1.f - oz;
+                float w[8];  // chain-rule weights in autograd's order: ((g*z)*y)*x
+                w[0] = oz * oy * ox; w[3] = oz * oy * mx; w[1] = oz * my * ox; w[2] = oz * my * mx;
+                w[4] = mz * oy * ox; w[7] = mz * oy * mx; w[5] = mz * my * ox; w[6] = mz * my * mx;
+                constexpr int PA[4] = {0, 1, 4, 5}, PB[4] = {3, 2, 7, 6};
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const int q = jj * 4 + p;
+                    const uint32_t ia = c.idx[PA[p]], ib = c.idx[PB[p]];
+                    const uint32_t ba = ia >> log2rpb, bb = ib >> log2rpb;
+                    const bool same = ba == bb;
+                    bka[q] = ba;
+                    // y: row_b | b_valid << 11 | bucket_b << 12 (the bucket only matters for the second record of a split pair)
+                    rec[q] = make_uint4((uint32_t)n | ((ia & rmask) << HG_SAMPLE_BITS), (ib & rmask) | (same ? 0x800u : 0u) | (bb << 12),
+                                        __float_as_uint(w[PA[p]]), __float_as_uint(w[PB[p]]));
+                    rka[q] = atomicAdd(&lcnt[ba], 1u);
+                    if (!same) {
+                        split |= 1u << q;
+                        rkb[q >> 1] |= atomicAdd(&lcnt[bb], 1u) << (16 * (q & 1));
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int p = 0; p < 4; ++p) bka[jj * 4 + p] = 0xFFFFFFFFu;
+            }
+        }
+        __syncthreads();
+        // ---- 2: exclusive scan of the bucket counts
+        uint32_t cq[16];
+        uint32_t sum = 0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int bb = tid * bpt + q;
+            cq[q] = (q < bpt && bb < B) ? lcnt[bb] : 0u;
+            sum += cq[q];
+        }
+        uint32_t inc = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t t = __shfl_up(inc, d, 64);
+            if (lane >= d) inc += t;
+        }
+        if (lane == 63) wave_tot[wave] = inc;
+        __syncthreads();
+        uint32_t run = inc - sum;
+        for (int w2 = 0; w2 < wave; ++w2) run += wave_tot[w2];
+        const uint32_t total = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int bb = tid * bpt + q;
+            if (q < bpt && bb < B) {
+                lcnt[bb] = run;
+                delta[bb] = cursor[bb] - run;
+            }
+            run += cq[q];
+        }
+        __syncthreads();
+        // ---- 3: records to their bucket-sorted slots: staged when the slot lies inside the stage, straight to memory otherwise
+        auto place = [&](uint32_t bk, uint32_t rk, const uint4& r) {
+            const uint32_t slot = lcnt[bk] + rk;
+            if (slot < (uint32_t)HG_XP_CAP) {
+                stage[slot] = r;
+                sbkt[slot] = (uint16_t)bk;
+            } else {
+                records[delta[bk] + slot] = r;
+            }
+        };
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            if (bka[q] != 0xFFFFFFFFu) {
+                uint4 r = rec[q];
+                const bool sp = (split >> q) & 1u;
+                const uint32_t bb = r.y >> 12;
+                r.y &= 0xFFFu;
+                place(bka[q], rka[q], r);
+                if (sp) {  // the b corner alone, as the a corner of a record in its own bucket
+                    const uint32_t n = r.x & ((1u << HG_SAMPLE_BITS) - 1u);
+                    place(bb, (rkb[q >> 1] >> (16 * (q & 1))) & 0xFFFFu, make_uint4(n | ((r.y & 0x7FFu) << HG_SAMPLE_BITS), 0u, r.w, 0u));
+                }
+            }
+        }
+        __syncthreads();
+        // ---- 4: contiguous runs out; advance the cursors
+        const uint32_t staged = total < (uint32_t)HG_XP_CAP ? total : (uint32_t)HG_XP_CAP;
+        for (uint32_t i = tid; i < staged; i += 256) records[delta[sbkt[i]] + i] = stage[i];
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
@@ -1148,12 +1356,16 @@ __global__ __launch_bounds__(256) void k_hg_level_absmax(const float* __restrict
 // SPLIT: workgroups per bucket.  The accumulators of a whole 2048-row bucket are 32 KB at F = 2 but 128 KB at F = 8, so at
 // F = 8 two workgroups share a bucket: each streams ALL of its records (8 bytes each, cheap) but gathers and accumulates
 // only those whose row falls into its half, and owns the Adam step of that half's rows.
-template <int F, bool ADAM, int SPLIT>
+// XP (F = 2, SPLIT = 1): x-pair records (k_hg_scatter_xp): a lane serves the two rows of a pair from one gather.
+template <int F, bool ADAM, int SPLIT, bool XP = false>
 __global__ __launch_bounds__(HG_FX_T) void k_hg_reduce_fx(const float* __restrict__ gT, int N, int log2_T, int log2B,
                                                           const uint32_t* __restrict__ bucket_start,
-                                                          const uint2* __restrict__ records, float* __restrict__ grad_table,
+                                                          const typename std::conditional<XP, uint4, uint2>::type* __restrict__ records,
+                                                          float* __restrict__ grad_table,
                                                           int xcd_from_level, int n_merge_levels, int level0,
                                                           const uint32_t* __restrict__ lvl_absmax_bits, HgAdam adam) {
+    static_assert(!XP || (F == 2 && SPLIT == 1), "x-pair records: F = 2 grids, one workgroup per bucket");
+    using Rec = typename std::conditional<XP, uint4, uint2>::type;
     constexpr int MAXROWS = HG_MAX_RPB / SPLIT;
     __shared__ unsigned long long acc[MAXROWS * F];
     __shared__ uint32_t bad[MAXROWS * F / 32];  // one bit per (row, feature): a non-finite contribution landed there
@@ -1209,18 +1421,21 @@ __global__ __launch_bounds__(HG_FX_T) void k_hg_reduce_fx(const float* __restric
     // three-stage software pipeline over trips of U records per thread: the records of trip t+2 and the staged gradients of
     // trip t+1 are in flight while trip t is accumulated, so neither global latency sits on the loop's critical path
 #define SNF_FX_U 4
-    constexpr int U = SNF_FX_U;
+#ifndef SNF_FX_UXP
+#define SNF_FX_UXP 2
+#endif
+    constexpr int U = XP ? SNF_FX_UXP : SNF_FX_U;  // (a pair record is two corners: the same work in flight with half the registers)
     const uint32_t mask_s = (1u << HG_SAMPLE_BITS) - 1u;
-    uint2 rec0[U], rec1[U];      // records of trip t (being processed), t+1 (gathers in flight)
+    Rec rec0[U], rec1[U];        // records of trip t (being processed), t+1 (gathers in flight)
     float g0[U][F], g1[U][F];
-    auto load_recs = [&](uint32_t c0, uint2 (&r)[U]) {
+    auto load_recs = [&](uint32_t c0, Rec (&r)[U]) {
 #pragma unroll
         for (int j = 0; j < U; ++j) {
             const uint32_t i = c0 + tid + (uint32_t)HG_FX_T * j;
             r[j] = records[i < end ? i : (start < end ? start : 0u)];  // (an empty bucket is still visited when ADAM: never read past the array)
         }
     };
-    auto gather = [&](const uint2 (&r)[U], float (&g)[U][F]) {
+    auto gather = [&](const Rec (&r)[U], float (&g)[U][F]) {
 #pragma unroll
         for (int j = 0; j < U; ++j) {
             // (SPLIT > 1: only the records of this workgroup's rows cost a gather)
@@ -1237,13 +1452,63 @@ __global__ __launch_bounds__(HG_FX_T) void k_hg_reduce_fx(const float* __restric
     gather(rec0, g0);
     if (start + TRIP < end) load_recs(start + TRIP, rec1);
     for (uint32_t c0 = start; c0 < end; c0 += TRIP) {
-        uint2 rec2[U];
+        Rec rec2[U];
         const bool has1 = c0 + TRIP < end, has2 = c0 + 2 * TRIP < end;
         if (has1) gather(rec1, g1);
         if (has2) load_recs(c0 + 2 * TRIP, rec2);
 #pragma unroll
         for (int j = 0; j < U; ++j) {
             bool live = c0 + tid + (uint32_t)HG_FX_T * j < end;
+            if constexpr (XP) {
+                // a pair: rows (row_a, row_b) of the bucket, weights (w_a, w_b), one staged gradient; b may be absent
+                const uint32_t ra = rec0[j].x >> HG_SAMPLE_BITS, rb = rec0[j].y & 0x7FFu;
+                const bool vb = (rec0[j].y & 0x800u) != 0u;
+                const float wa = __uint_as_float(rec0[j].z), wb = __uint_as_float(rec0[j].w);
+                float v[2 * F];
+#pragma unroll
+                for (int f = 0; f < F; ++f) {
+                    v[f] = wa * g0[j][f];
+                    v[F + f] = vb ? wb * g0[j][f] : 0.f;
+                }
+                long long q[2 * F];
+#pragma unroll
+                for (int e2 = 0; e2 < 2 * F; ++e2) {
+                    const bool ok = fabsf(v[e2]) < INFINITY;
+                    q[e2] = ok ? __float2ll_rn(v[e2] * scale) : 0ll;
+                    if (live && !ok) {  // NaN / inf cannot be represented: the element becomes NaN, as a float sum would
+                        const uint32_t eb = (e2 < F ? ra : rb) * F + (uint32_t)(e2 % F);
+                        atomicOr(&bad[eb >> 5], 1u << (eb & 31));
+                    }
+                }
+                int alive = live ? 1 : 0;
+                if (merge) {  // (coarse level: equal pairs inside a quad are added before the atomics, as for single records below)
+                    const uint32_t key = live ? (ra | ((rec0[j].y & 0xFFFu) << 11)) : (0xFF000000u | (uint32_t)lane);
+#define SNF_QUAD_STEP_XP(CTRL, BIT)                                                                                      \
+                    {                                                                                                      \
+                        const uint32_t pk = (uint32_t)__builtin_amdgcn_mov_dpp((int)key, CTRL, 0xF, 0xF, true);           \
+                        const int pa = __builtin_amdgcn_mov_dpp(alive, CTRL, 0xF, 0xF, true);                              \
+                        const bool same = alive && pa && pk == key;                                                        \
+                        _Pragma("unroll") for (int e2 = 0; e2 < 2 * F; ++e2) {                                             \
+                            const int lo = __builtin_amdgcn_mov_dpp((int)(uint32_t)(unsigned long long)q[e2], CTRL, 0xF, 0xF, true);          \
+                            const int hi = __builtin_amdgcn_mov_dpp((int)(uint32_t)((unsigned long long)q[e2] >> 32), CTRL, 0xF, 0xF, true);  \
+                            const long long pq = (long long)(((unsigned long long)(uint32_t)hi << 32) | (unsigned long long)(uint32_t)lo);    \
+                            if (same && !(lane & BIT)) q[e2] += pq;                                                        \
+                        }                                                                                                  \
+                        if (same && (lane & BIT)) alive = 0;                                                               \
+                    }
+                    SNF_QUAD_STEP_XP(0xB1, 1)
+                    SNF_QUAD_STEP_XP(0x4E, 2)
+#undef SNF_QUAD_STEP_XP
+                }
+                if (alive) {
+#pragma unroll
+                    for (int f = 0; f < F; ++f) {
+                        if (q[f] != 0) atomicAdd(&acc[(copy_off + ra) * F + f], (unsigned long long)q[f]);
+                        if (q[F + f] != 0) atomicAdd(&acc[(copy_off + rb) * F + f], (unsigned long long)q[F + f]);
+                    }
+                }
+                continue;
+            }
             const uint32_t row = (rec0[j].x >> HG_SAMPLE_BITS) - row0;  // row inside this workgroup's share
             if (SPLIT > 1) live = live && row < (uint32_t)rpb;
             const float w = __uint_as_float(rec0[j].y);
@@ -1467,9 +1732,10 @@ static bool hg_fx_on(int F, int L, int N) {
 static size_t hg_ws_words(int N, int L, int log2_T) {
     const HgGeom g = hg_geometry(N, log2_T);
     const size_t B = (size_t)1 << g.log2B;
-    // records (8 B each) | tile histograms | tile offsets | bucket starts (padded to 4 words) | per-level scratch of the
-    // fixed-point reduce (HG_FX_SCRATCH words, the only part a BACKWARD writes) | staged gradients
-    return (size_t)L * 8 * (size_t)N * 2 + 2 * (size_t)L * g.nblk * B + (((size_t)L * (B + 1) + 3) & ~(size_t)3) +
+    // records (8 N per level: 8 B each, or 16-byte x-pair records whose worst case -- every pair split -- is 8 N as well) | tile
+    // histograms | tile offsets | bucket starts (padded to 4 words) | per-level scratch of the fixed-point reduce (HG_FX_SCRATCH
+    // words, the only part a BACKWARD writes) | staged gradients
+    return (size_t)L * 8 * (size_t)N * 4 + 2 * (size_t)L * g.nblk * B + (((size_t)L * (B + 1) + 3) & ~(size_t)3) +
            HG_FX_SCRATCH + (size_t)L * (size_t)N * 8;
 }
 
@@ -1512,7 +1778,7 @@ static HgWs hg_ws_layout(void* workspace, int N, int L, const HgGeom& g) {
     const size_t B = (size_t)1 << g.log2B;
     HgWs w;
     w.records = (uint32_t*)workspace;
-    w.hist = w.records + (size_t)L * 8 * (size_t)N * 2;
+    w.hist = w.records + (size_t)L * 8 * (size_t)N * 4;
     w.offs = w.hist + (size_t)L * g.nblk * B;
     w.bstart = w.offs + (size_t)L * g.nblk * B;
     w.fx = w.bstart + (((size_t)L * (B + 1) + 3) & ~(size_t)3);
@@ -1525,9 +1791,27 @@ static HgWs hg_ws_layout(void* workspace, int N, int L, const HgGeom& g) {
 // level's histogram in every tile costs more than the scan kernel (field grid: 270 vs 261 us), which then writes them out.
 constexpr int HG_SELF_SCAN_TILES = 64;
 static void hg_scatter_from_hist(hipStream_t st, const float* u, const float* scalings, int N, int L, int log2_T, const HgGeom& g,
-                                 const HgWs& w) {
+                                 const HgWs& w, bool xp = false) {
     static int lds_attr[2] = {0, 0};  // largest dynamic-LDS size each scatter instantiation has been opened for
     const bool self = g.nblk <= HG_SELF_SCAN_TILES;
+    if (xp) {
+        static int lds_attr_xp[2] = {0, 0};
+        const int ldx = (int)hg_scatter_xp_lds_bytes(g.log2B);
+        if (ldx > 48 * 1024 && ldx > lds_attr_xp[self ? 1 : 0]) {
+            lds_attr_xp[self ? 1 : 0] = ldx;
+            if (self) (void)hipFuncSetAttribute((const void*)k_hg_scatter_xp<true>, hipFuncAttributeMaxDynamicSharedMemorySize, ldx);
+            else (void)hipFuncSetAttribute((const void*)k_hg_scatter_xp<false>, hipFuncAttributeMaxDynamicSharedMemorySize, ldx);
+        }
+        if (self) {
+            hipLaunchKernelGGL(k_hg_scatter_xp<true>, dim3(g.nblk, L), dim3(256), ldx, st, u, scalings, N, log2_T, g.log2B, g.spt, w.hist,
+                               (uint4*)w.records, w.bstart);
+        } else {
+            hipLaunchKernelGGL(k_hg_scan, dim3(L), dim3(1024), 0, st, N, g.log2B, g.nblk, w.hist, w.offs, w.bstart);
+            hipLaunchKernelGGL(k_hg_scatter_xp<false>, dim3(g.nblk, L), dim3(256), ldx, st, u, scalings, N, log2_T, g.log2B, g.spt,
+                               w.offs, (uint4*)w.records, w.bstart);
+        }
+        return;
+    }
     const int lds = (int)hg_scatter_lds_bytes(g.log2B);
     if (lds > 48 * 1024 && lds > lds_attr[self ? 1 : 0]) {
         lds_attr[self ? 1 : 0] = lds;
@@ -1544,19 +1828,32 @@ static void hg_scatter_from_hist(hipStream_t st, const float* u, const float* sc
     }
 }
 
-extern "C" int snf_hashgrid_sort(const float* u, const float* scalings, int N, int L, int log2_T, void* workspace,
-                                 int64_t workspace_bytes, snf_stream_t stream) {
-    SNF_REQUIRE(u && scalings, "snf_hashgrid_sort: null pointer");
-    int rc = hg_sort_checks("snf_hashgrid_sort", N, L, log2_T, workspace, workspace_bytes);
+static int hg_sort_impl(const char* who, const float* u, const float* scalings, int N, int L, int log2_T, void* workspace,
+                        int64_t workspace_bytes, bool xp, snf_stream_t stream) {
+    SNF_REQUIRE(u && scalings, "%s: null pointer", who);
+    int rc = hg_sort_checks(who, N, L, log2_T, workspace, workspace_bytes);
     if (rc) return rc;
     const HgGeom g = hg_geometry(N, log2_T);
-    SNF_REQUIRE((1 << g.log2rpb) <= HG_MAX_RPB, "snf_hashgrid_sort: log2_T=%d too large for the bucketed backward", log2_T);
+    SNF_REQUIRE((1 << g.log2rpb) <= HG_MAX_RPB, "%s: log2_T=%d too large for the bucketed backward", who, log2_T);
     const HgWs w = hg_ws_layout(workspace, N, L, g);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_hg_count, dim3(g.nblk, L), dim3(256), 0, st, u, scalings, N, log2_T, g.log2B, g.spt, w.hist);
-    hg_scatter_from_hist(st, u, scalings, N, L, log2_T, g, w);
-    SNF_LAUNCH_CHECK("snf_hashgrid_sort");
+    if (xp) hipLaunchKernelGGL(k_hg_count<true>, dim3(g.nblk, L), dim3(256), 0, st, u, scalings, N, log2_T, g.log2B, g.spt, w.hist);
+    else hipLaunchKernelGGL(k_hg_count<false>, dim3(g.nblk, L), dim3(256), 0, st, u, scalings, N, log2_T, g.log2B, g.spt, w.hist);
+    hg_scatter_from_hist(st, u, scalings, N, L, log2_T, g, w, xp);
+    SNF_LAUNCH_CHECK(who);
     return SNF_OK;
+}
+
+extern "C" int snf_hashgrid_sort(const float* u, const float* scalings, int N, int L, int log2_T, void* workspace,
+                                 int64_t workspace_bytes, snf_stream_t stream) {
+    return hg_sort_impl("snf_hashgrid_sort", u, scalings, N, L, log2_T, workspace, workspace_bytes, false, stream);
+}
+
+// The sort with x-pair records (see k_hg_scatter_xp): for F = 2 grids; its workspace is consumed by snf_hashgrid_bwd_presorted_adam_xp
+// ONLY (the other backward entry points read 8-byte single-corner records).
+extern "C" int snf_hashgrid_sort_xp(const float* u, const float* scalings, int N, int L, int log2_T, void* workspace,
+                                    int64_t workspace_bytes, snf_stream_t stream) {
+    return hg_sort_impl("snf_hashgrid_sort_xp", u, scalings, N, L, log2_T, workspace, workspace_bytes, true, stream);
 }
 
 // What the reduce pass of ONE table needs besides the records: the reachable-row lists of its leading `levels` levels
@@ -1600,7 +1897,7 @@ static void hg_launch_sparse(hipStream_t st, const float* stage, int N, int log2
 // with Adam fused on the levels >= a.from_level.  lvlmax: per-level scratch of the fixed-point kernels (HG_FX_SCRATCH words).
 static void hg_reduce_one(hipStream_t st, int F, const float* stage, int N, int L, int log2_T, const HgGeom& g, const HgWs& w,
                           float* grad_table, int n_run_levels, bool adam_on, bool sparse_step, HgAdam a, HgSparse sp,
-                          uint32_t* lvlmax) {
+                          uint32_t* lvlmax, bool xp = false) {
     const int B = 1 << g.log2B;
     static const uint32_t hg_long = (uint32_t)HG_LONG;
     const bool fx = hg_fx_on(F, L, N);
@@ -1627,7 +1924,15 @@ static void hg_reduce_one(hipStream_t st, int F, const float* stage, int N, int 
     const int Lr = L - s0;
     if (Lr <= 0) return;
     const int nrun = n_run_levels > s0 ? n_run_levels - s0 : 0;  // (relative to the launch)
-    if (F == 2 && fx) {
+    if (F == 2 && fx && xp) {
+        if (adam_on)
+            hipLaunchKernelGGL((k_hg_reduce_fx<2, true, 1, true>), dim3(B, Lr), dim3(HG_FX_T), 0, st, stage, N, log2_T, g.log2B, w.bstart,
+                               (const uint4*)w.records, grad_table, hg_xcd_from(nrun, Lr, B), hg_merge_levels(nrun), s0, lvlmax, a);
+        else
+            hipLaunchKernelGGL((k_hg_reduce_fx<2, false, 1, true>), dim3(B, Lr), dim3(HG_FX_T), 0, st, stage, N, log2_T, g.log2B,
+                               w.bstart, (const uint4*)w.records, grad_table, hg_xcd_from(nrun, Lr, B), hg_merge_levels(nrun), s0, lvlmax,
+                               HgAdam{});
+    } else if (F == 2 && fx) {
         if (adam_on)
             hipLaunchKernelGGL((k_hg_reduce_fx<2, true, 1>), dim3(B, Lr), dim3(HG_FX_T), 0, st, stage, N, log2_T, g.log2B, w.bstart,
                                (const uint2*)w.records, grad_table, hg_xcd_from(nrun, Lr, B), hg_merge_levels(nrun), s0, lvlmax, a);
@@ -1736,6 +2041,38 @@ extern "C" int snf_hashgrid_bwd_presorted_adam(const float* grad_out, int N, int
     return snf_hashgrid_bwd_presorted_adam_sp(grad_out, N, L, F, log2_T, ld_out, col_off, n_run_levels, grad_table, sorted_workspace,
                                               stage, fuse_from_level, param, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step,
                                               grad_scale, nullptr, nullptr, 0, 0, 0, nullptr, stream);
+}
+
+// snf_hashgrid_bwd_presorted_adam for an F = 2 grid whose workspace was sorted by snf_hashgrid_sort_xp (x-pair records); param NULL:
+// no optimizer step (fuse_from_level is then ignored), the gradient is added to grad_table.
+extern "C" int snf_hashgrid_bwd_presorted_adam_xp(const float* grad_out, int N, int L, int log2_T, int ld_out, int col_off,
+                                                  int n_run_levels, float* grad_table, const void* sorted_workspace, float* stage,
+                                                  int fuse_from_level, float* param, float* exp_avg, float* exp_avg_sq, float lr,
+                                                  float beta1, float beta2, float eps, int step, float grad_scale,
+                                                  snf_stream_t stream) {
+    const bool planar = ld_out == 0;
+    if (!param) fuse_from_level = L;
+    const bool adam_on = fuse_from_level < L;
+    SNF_REQUIRE(grad_out && grad_table && sorted_workspace && (stage || planar) && (!adam_on || (param && exp_avg && exp_avg_sq)),
+                "snf_hashgrid_bwd_presorted_adam_xp: null pointer");
+    SNF_REQUIRE(N > 0 && L > 0 && N <= (1 << HG_SAMPLE_BITS) && (N % 2) == 0 && L <= (int)HG_FX_SCRATCH &&
+                    ((planar && col_off == 0) || ld_out >= col_off + L * 2) && col_off >= 0,
+                "snf_hashgrid_bwd_presorted_adam_xp: bad shape N=%d (even) L=%d (<= 64) ld_out=%d col_off=%d", N, L, ld_out, col_off);
+    SNF_REQUIRE(fuse_from_level >= 0 && fuse_from_level <= L && step >= 1,
+                "snf_hashgrid_bwd_presorted_adam_xp: bad fuse_from_level=%d (L=%d) or step=%d", fuse_from_level, L, step);
+    if (planar) stage = const_cast<float*>(grad_out);
+    SNF_REQUIRE((((uintptr_t)grad_out | (uintptr_t)grad_table | (uintptr_t)stage | (uintptr_t)param | (uintptr_t)exp_avg |
+                  (uintptr_t)exp_avg_sq) & 15) == 0, "snf_hashgrid_bwd_presorted_adam_xp: unaligned pointer");
+    SNF_REQUIRE(hg_fx_on(2, L, N), "snf_hashgrid_bwd_presorted_adam_xp: the fixed-point reduce does not take N=%d L=%d", N, L);
+    const HgGeom g = hg_geometry(N, log2_T);
+    const HgWs w = hg_ws_layout(const_cast<void*>(sorted_workspace), N, L, g);
+    hipStream_t st = (hipStream_t)stream;
+    HgAdam a{};
+    hg_fill_adam(a, param, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step, grad_scale, fuse_from_level);
+    if (!planar) hg_stage(st, 2, grad_out, N, L, ld_out, col_off, stage);
+    hg_reduce_one(st, 2, stage, N, L, log2_T, g, w, grad_table, n_run_levels, adam_on, false, a, HgSparse{nullptr, nullptr, 0}, w.fx, true);
+    SNF_LAUNCH_CHECK("snf_hashgrid_bwd_presorted_adam_xp");
+    return SNF_OK;
 }
 
 // The two F = 8 grids of a feature head (same samples, same table size, level-major gradients): the bucket-wide levels of both in

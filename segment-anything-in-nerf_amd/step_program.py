@@ -78,6 +78,9 @@ FUSED_MEAN_EPILOGUE = True  # ... and the mean itself in the hidden layer's GEMM
 # the side stream (where the proposal backward + Adam of the previous step already ran) and so runs under the tail of the
 # previous step's field backward.  What it produces and the main stream reads late is double-buffered by step parity.
 XSTEP_PROLOGUE = True
+# the F = 2 grids (field, proposal) sorted into x-pair records: one record and one staged-gradient gather per x-neighbour corner pair
+# (snf_hashgrid_sort_xp / snf_hashgrid_bwd_presorted_adam_xp; same sums bit for bit)
+XPAIR_RECORDS = True
 # Many ranks: the gradient exchange + optimizer of the replicated groups recorded into the schedule (collectives as list entries, Adam
 # as recorded launches) instead of `Optimizers.exchange_and_step` enqueueing its ~15 torch / C-ABI calls per group eagerly each step
 RECORD_EXCHANGE = True
@@ -236,6 +239,16 @@ class StepProgram:
         return (a.param[off:off + n], a.grad[off:off + n], a.exp_avg[off:off + n], a.exp_avg_sq[off:off + n], n_sparse,
                 (off + n_sparse * stride, off + n))
 
+    @staticmethod
+    def _xpair(F: int, N: int, L: int, T: int) -> bool:
+        """x-pair records for this grid?  F = 2 and what the fixed-point reduce takes (N even, L <= 64); tables of at least 2^18 rows:
+        below that a bucket's accumulators are replicated per lane group and the pair reduce measured slower (proposal grid, T = 17:
+        sort 52 -> 49 us but reduce 64 -> 70 us)."""
+        return bool(XPAIR_RECORDS and F == 2 and N % 2 == 0 and L <= 64 and T >= 18)
+
+    def _f2_sort(self, F: int, N: int, L: int, T: int) -> str:
+        return "snf_hashgrid_sort_xp" if self._xpair(F, N, L, T) else "snf_hashgrid_sort"
+
     def _grid_bwd(self, st, g, N, enc, group, ld, col, sorted_ws, stage, with_opt: bool, done: list, run=None,
                   grad_scale: float = 1.0) -> None:
         """Table-gradient backward of one grid from the presorted records (+ Adam of its dense levels when with_opt).
@@ -255,6 +268,18 @@ class StepProgram:
             tag = f"F{F}L{L}tp"
         nrun = ops.hashgrid_run_levels(sc) if F == 2 else 0
         fuse = with_opt and self.opt.fuse_table_adam and n_sparse < L
+        if run is None and self._xpair(F, N, L, T):
+            # the workspace holds x-pair records (self._f2_sort): their own backward entry, Adam of the levels >= n_sparse in its reduce
+            oc = self.opt.config[group]["optimizer"]
+            fused = ((L - n_sparse) << T) * F if fuse else 0
+            self._k(st, "snf_hashgrid_bwd_presorted_adam_xp", g, N, L, T, ld, col, nrun, gbuf, sorted_ws, stage, n_sparse if fuse else L,
+                    p if fuse else None, m if fuse else None, v if fuse else None, 0.0, float(oc.betas[0]), float(oc.betas[1]),
+                    float(oc.eps), 1, float(grad_scale), tag=tag,
+                    units=float(N) * 8 * F * 4 * (L + (n_sparse if fuse else L)) + 24.0 * fused,
+                    dyn={("lr", group): 14, ("t", group): 18} if fuse else None)
+            if fuse:
+                done.append(fused_range)
+            return
         sp = self._sparse_lists(enc, N, n_sparse) if (run is None and not (F == 8 and FX_F8)) else None
         if sp is not None:
             # reachable-row levels through the compact fixed-point reduce; with the optimizer on this launch steps the WHOLE table
@@ -504,7 +529,7 @@ class StepProgram:
         if updated:
             ws_p, ws_p_bytes = self._sort_ws("ws_prop", N0, PL, PT)
             self._edge(pre, sort_st, "u0_ready")
-            self._k(sort_st, "snf_hashgrid_sort", u0, penc.scalings, N0, PL, PT, ws_p, ws_p_bytes, tag=f"L{PL}")
+            self._k(sort_st, self._f2_sort(PF, N0, PL, PT), u0, penc.scalings, N0, PL, PT, ws_p, ws_p_bytes, tag=f"L{PL}")
             if sort_st.stream_id != main.stream_id:
                 self._py(self.event("prop_sorted").record, sort_st)
         enc0 = b("enc0", (N0, PL * PF))
@@ -531,7 +556,7 @@ class StepProgram:
         ws_f, ws_f_bytes = self._sort_ws("ws_field", N1, FL, FT, pp)
         self._edge(pre, sort_st, "u1_ready")
         self._edge(pre, main, "prologue_done")
-        self._k(sort_st, "snf_hashgrid_sort", u1, fenc.scalings, N1, FL, FT, ws_f, ws_f_bytes, tag=f"L{FL}")
+        self._k(sort_st, self._f2_sort(FF, N1, FL, FT), u1, fenc.scalings, N1, FL, FT, ws_f, ws_f_bytes, tag=f"L{FL}")
         if sort_st.stream_id != main.stream_id:
             self._py(self.event("field_sorted").record, sort_st)
         enc1 = b("enc1", (FL * FF * N1,))

@@ -26,8 +26,9 @@ def test_library_exports_every_declared_symbol():
     for name in _lib.SIGNATURES:
         assert name in declared
     assert lib.snf_version() >= 100
-    # records | tile histograms + offsets | bucket starts | 64-word scratch of the fixed-point reduce | staged gradients
-    assert lib.snf_hashgrid_bwd_workspace_bytes(65536, 12, 19) == 4 * (12 * 8 * 65536 * 2 + 2 * 12 * 64 * 256 + 3084 + 64
+    # records (8 N per level, 16 bytes each: room for x-pair records) | tile histograms + offsets | bucket starts | 64-word scratch of
+    # the fixed-point reduce | staged gradients
+    assert lib.snf_hashgrid_bwd_workspace_bytes(65536, 12, 19) == 4 * (12 * 8 * 65536 * 4 + 2 * 12 * 64 * 256 + 3084 + 64
                                                                         + 12 * 65536 * 8)
 
 

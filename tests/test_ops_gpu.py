@@ -924,6 +924,57 @@ def test_level_major_feature_grids_feed_the_table_backward():
         assert maxdiff(a, bq) <= 2e-6 * float(a.abs().max())  # (fp32 sums inside a row depend on the LDS ranking order)
 
 
+@pytest.mark.parametrize("N,L,T,clustered", [(524288, 16, 19, True), (262144, 5, 17, True), (70002, 6, 19, False), (600000, 2, 19, False),
+                                             (778, 3, 6, False), (4096, 4, 12, True)])
+def test_x_pair_records_equal_single_records(N, L, T, clustered):
+    """snf_hashgrid_sort_xp + snf_hashgrid_bwd_presorted_adam_xp (one 16-byte record and ONE gradient gather per x-neighbour corner
+    pair) against snf_hashgrid_sort + snf_hashgrid_bwd_presorted(_adam) on an F = 2 grid: the 64-bit fixed-point sums do not depend
+    on the order or grouping of the records, so the table gradient, and the Adam-stepped parameters and moments, are equal BIT FOR
+    BIT -- coarse levels (quad merge), hashed levels, a tiny table (T = 6: several accumulator copies), a sort that takes its
+    offsets from the scan kernel (N = 600000)."""
+    m = ops()
+    F = 2
+    g = torch.Generator(device=DEV).manual_seed(N + T)
+    if clustered:  # samples of a ray march through neighbouring cells (what the quad merge of the coarse levels is for)
+        o = torch.rand((N // 64 + 1, 1, 3), device=DEV, generator=g)
+        d = torch.randn((N // 64 + 1, 1, 3), device=DEV, generator=g) * 0.2
+        t = torch.linspace(0, 1, 64, device=DEV).view(1, 64, 1)
+        u = (o + d * t).reshape(-1, 3)[:N].remainder(1.0).contiguous()
+    else:
+        u = torch.rand((N, 3), device=DEV, generator=g)
+    sc = torch.tensor([16.0 * 1.45 ** i - 1.0 for i in range(L)], device=DEV)
+    grad = torch.randn((N, L * F), device=DEV, generator=g)
+    st = m._stream()
+    nbytes = int(m._L().snf_hashgrid_bwd_workspace_bytes(N, L, T))
+    ws_a = torch.zeros(((nbytes + 3) // 4,), device=DEV, dtype=torch.int32)
+    ws_b = torch.full(((nbytes + 3) // 4,), -1, device=DEV, dtype=torch.int32)
+    m._launch("snf_hashgrid_sort", m._p(u), m._p(sc), N, L, T, m._p(ws_a), nbytes, st)
+    m._launch("snf_hashgrid_sort_xp", m._p(u), m._p(sc), N, L, T, m._p(ws_b), nbytes, st)
+    nrun = m.hashgrid_run_levels(sc)
+    n = (L << T) * F
+    stage = torch.empty((L * N * F,), device=DEV)
+    # gradient only
+    ga, gb = torch.zeros((n,), device=DEV), torch.zeros((n,), device=DEV)
+    m._launch("snf_hashgrid_bwd_presorted", m._p(grad), N, L, F, T, L * F, 0, nrun, m._p(ga), m._p(ws_a), m._p(stage), st)
+    m._launch("snf_hashgrid_bwd_presorted_adam_xp", m._p(grad), N, L, T, L * F, 0, nrun, m._p(gb), m._p(ws_b), m._p(stage), L, None, None,
+              None, 0.0, 0.9, 0.999, 1e-15, 1, 1.0, st)
+    assert torch.equal(ga, gb)
+    assert float(ga.abs().max()) > 0
+    gref = torch.zeros((n,), device=DEV)
+    m._launch("snf_hashgrid_bwd", m._p(u), m._p(grad), m._p(sc), N, L, F, T, L * F, 0, m._p(gref), st)
+    assert maxdiff(gb, gref) <= 2e-5 * float(gref.abs().max())
+    # with the optimizer step in the reduce pass (all levels)
+    pa = torch.randn((n,), device=DEV, generator=g) * 1e-2
+    ma, va = torch.randn((n,), device=DEV, generator=g) * 1e-3, torch.rand((n,), device=DEV, generator=g) * 1e-6
+    pb, mb, vb = pa.clone(), ma.clone(), va.clone()
+    ga.zero_(); gb.zero_()
+    m._launch("snf_hashgrid_bwd_presorted_adam", m._p(grad), N, L, F, T, L * F, 0, nrun, m._p(ga), m._p(ws_a), m._p(stage), 0, m._p(pa),
+              m._p(ma), m._p(va), 1e-2, 0.9, 0.999, 1e-15, 3, 1.0 / 128, st)
+    m._launch("snf_hashgrid_bwd_presorted_adam_xp", m._p(grad), N, L, T, L * F, 0, nrun, m._p(gb), m._p(ws_b), m._p(stage), 0, m._p(pb),
+              m._p(mb), m._p(vb), 1e-2, 0.9, 0.999, 1e-15, 3, 1.0 / 128, st)
+    assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb) and torch.equal(ga, gb)
+
+
 @pytest.mark.parametrize("N,I,O,planar", [(65536, 192, 256, True), (65536, 256, 256, False), (65536, 256, 192, False),
                                           (9000, 64, 72, False), (16411, 200, 128, False)])
 def test_full_width_weight_gradient(N, I, O, planar):
