@@ -443,6 +443,10 @@ int snf_layernorm_planes(const float* x, const float* residual, int N, int C, co
                          float* sum_out, uint16_t* y_hi, uint16_t* y_lo, int M_out, int H, int W, int ws, snf_stream_t stream);
 int snf_attention_planes(const float* qkv, const float* rel, int Bw, int T, int heads, int head_dim, int n, float scale,
                          uint16_t* out_hi, uint16_t* out_lo, snf_stream_t stream);
+/* ... for small grids (2n - 1 <= 32: the 14 x 14 windows) with snf_relpos folded in: the decomposed relative-position terms are formed
+ * inside the kernel, on the matrix cores, from rel_pos_h / rel_pos_w [2n-1][head_dim] (add_decomposed_rel_pos, image_encoder.py:323-361) */
+int snf_attention_planes_rp(const float* qkv, const float* rel_pos_h, const float* rel_pos_w, int Bw, int T, int heads, int head_dim,
+                            int n, float scale, uint16_t* out_hi, uint16_t* out_lo, snf_stream_t stream);
 
 /* ---- the batch builder in front of the path (images, feature maps and cameras resident in HBM).
  * snf_pixel_indices: PixelSampler (patch == 1: u [B,3]) / PatchPixelSampler (u [B/patch^2,3]) .sample_method without a

@@ -478,7 +478,9 @@ template <int DB, bool PL = false>
 __global__ __launch_bounds__(256, SNF_ATT_WAVES) void k_attention_b3(const float* __restrict__ qkv, const float* __restrict__ rel, int T,
                                                       int heads, int hd, int n, float scale, float* __restrict__ out,
                                                       int rel_direct, uint16_t* __restrict__ out_hi = nullptr,
-                                                      uint16_t* __restrict__ out_lo = nullptr, int M_out = 0) {
+                                                      uint16_t* __restrict__ out_lo = nullptr, int M_out = 0,
+                                                      const float* __restrict__ rph = nullptr,
+                                                      const float* __restrict__ rpw = nullptr) {
     constexpr int DP = DB * 32;          // padded head dim
     constexpr int KS = DP / 16;          // k-steps over the head dim
     constexpr int KPB = DP + 8;          // bf16 pitch of the K planes  [32 keys][DP]
@@ -518,6 +520,44 @@ __global__ __launch_bounds__(256, SNF_ATT_WAVES) void k_attention_b3(const float
     // and 16 column terms per tile straight from global memory (four float4) -- no per-wave copy of the [32][2n] position rows in
     // LDS, which at n = 64 was 66 KB per workgroup and left one workgroup per CU
     const float* __restrict__ relg = (rel && rel_direct) ? rel + ((size_t)bh * T + (qlive ? qi : T - 1)) * 2 * n : nullptr;
+    const bool has_rel = rel != nullptr || rph != nullptr;
+    if (rph != nullptr) {
+        // Small grids (2n - 1 <= 32: the encoder's 14 x 14 windows): the decomposed relative-position terms of this wave's 32 queries
+        // are formed HERE, on the matrix cores, from the query fragments already in registers -- P^T[r][q] = rel_pos[r] . q for all
+        // 2n - 1 table rows (one 32-row MFMA tile per table), then rel_h[q][kh] = P_h[q][ih - kh + n - 1], rel_w[q][kw] =
+        // P_w[q][iw - kw + n - 1] scattered into the wave's LDS rows -- instead of a separate kernel (snf_relpos: 37 us per launch, all
+        // staging latency) writing them to memory and this one reading them back.  q is scaled here and unscaled there: x 1 / scale.
+        const int qc = qlive ? qi : T - 1, ih = qc / n, iw = qc - ih * n;
+        const float unscale = 1.f / scale;
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb) {
+            const float* __restrict__ tabrow = (tb == 0 ? rph : rpw) + (size_t)(li < 2 * n - 1 ? li : 2 * n - 2) * hd;
+            f32x16 pacc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pacc[r] = 0.f;
+#pragma unroll
+            for (int s2 = 0; s2 < KS; ++s2) {
+                uint32_t hr[4], lr[4];
+#pragma unroll
+                for (int p2 = 0; p2 < 4; ++p2) {
+                    const int d = 16 * s2 + 8 * half + 2 * p2;
+                    const float x0 = (d < hd && li < 2 * n - 1) ? tabrow[d] : 0.f, x1 = (d + 1 < hd && li < 2 * n - 1) ? tabrow[d + 1] : 0.f;
+                    at_split2(x0, x1, hr[p2], lr[p2]);
+                }
+                const at_bf16x8 rh = __builtin_bit_cast(at_bf16x8, make_uint4(hr[0], hr[1], hr[2], hr[3]));
+                const at_bf16x8 rl = __builtin_bit_cast(at_bf16x8, make_uint4(lr[0], lr[1], lr[2], lr[3]));
+                pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rl, qh[s2], pacc, 0, 0, 0);
+                pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rh, ql[s2], pacc, 0, 0, 0);
+                pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rh, qh[s2], pacc, 0, 0, 0);
+            }
+            const int pos = tb == 0 ? ih : iw;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kk = pos + n - 1 - vrow(r, half);  // table row vrow(r, half) serves key row / column kk of this query
+                if (kk >= 0 && kk < n) relw[li * RP + tb * n + kk] = pacc[r] * unscale;
+            }
+        }
+    }
     if (rel && !rel_direct) {
         for (int e = lane; e < 32 * 2 * n; e += 64) {
             const int r = e / (2 * n), j = e - r * 2 * n;
@@ -525,7 +565,7 @@ __global__ __launch_bounds__(256, SNF_ATT_WAVES) void k_attention_b3(const float
             relw[r * RP + j] = rel[((size_t)bh * T + qq) * 2 * n + j];
         }
     }
-    const float* relq = (rel && !rel_direct) ? relw + li * RP : nullptr;
+    const float* relq = (has_rel && !rel_direct) ? relw + li * RP : nullptr;
     f32x16 o[DB];
 #pragma unroll
     for (int t = 0; t < DB; ++t)
@@ -595,7 +635,7 @@ __global__ __launch_bounds__(256, SNF_ATT_WAVES) void k_attention_b3(const float
         // ---- relative-position bias, mask, online softmax (everything per lane = per query)
         float m_tile = -INFINITY;
         const bool ragged = k0 + 32 > T;
-        const int kh0 = rel ? k0 / n : 0, kw0 = rel ? k0 - kh0 * n : 0;
+        const int kh0 = has_rel ? k0 / n : 0, kw0 = has_rel ? k0 - kh0 * n : 0;
         float rrow = 0.f;
         float4 rcol[4];
         if (relg) {  // registers 4g .. 4g+3 are the keys k0 + 8g + 4 half + {0..3}
@@ -849,7 +889,8 @@ extern "C" int snf_relpos(const float* qkv, int Bw, int T, int heads, int head_d
 }
 
 static int attention_launch(const float* qkv, const float* rel, int Bw, int T, int heads, int head_dim, int n, float scale,
-                            float* out, uint16_t* out_hi, uint16_t* out_lo, snf_stream_t stream) {
+                            float* out, uint16_t* out_hi, uint16_t* out_lo, snf_stream_t stream, const float* rph = nullptr,
+                            const float* rpw = nullptr) {
     SNF_REQUIRE(qkv && (out || out_hi) && Bw > 0 && T > 0 && heads > 0 && head_dim > 0 && head_dim <= 96,
                 "snf_attention: bad argument (head_dim <= 96)");
     SNF_REQUIRE(!rel || (n > 0 && T == n * n), "snf_attention: relative positions need T == n*n");
@@ -858,7 +899,9 @@ static int attention_launch(const float* qkv, const float* rel, int Bw, int T, i
     static const int b3_env = 1;
     static const int direct_env = 1;
     const int rel_direct = (rel && direct_env && b3_env && b3_enabled() && (n % 32) == 0 && (((uintptr_t)rel) & 15) == 0) ? 1 : 0;
-    const size_t lds = (rel && !rel_direct) ? (size_t)4 * 32 * (2 * n + 1) * sizeof(float) : 0;
+    SNF_REQUIRE(!rph || (rpw && !rel && n > 0 && 2 * n - 1 <= 32 && T == n * n && b3_env && b3_enabled()),
+                "snf_attention_planes_rp: tables need T == n*n, 2n-1 <= 32 and the bf16-split gemm mode");
+    const size_t lds = ((rel && !rel_direct) || rph) ? (size_t)4 * 32 * (2 * n + 1) * sizeof(float) : 0;
     SNF_REQUIRE(lds <= 100 * 1024, "snf_attention: grid side n=%d too large for the relative-position staging", n);
 #define SNF_ATT(DB_)                                                                                                        \
     do {                                                                                                                    \
@@ -877,7 +920,7 @@ static int attention_launch(const float* qkv, const float* rel, int Bw, int T, i
         }                                                                                                                   \
         if (out_hi)                                                                                                         \
             hipLaunchKernelGGL((k_attention_b3<DB_, true>), grid, dim3(256), lds, (hipStream_t)stream, qkv, rel, T, heads,      \
-                               head_dim, n, scale, out, rel_direct, out_hi, out_lo, Bw * T);                                   \
+                               head_dim, n, scale, out, rel_direct, out_hi, out_lo, Bw * T, rph, rpw);                         \
         else                                                                                                                \
             hipLaunchKernelGGL((k_attention_b3<DB_, false>), grid, dim3(256), lds, (hipStream_t)stream, qkv, rel, T, heads,     \
                                head_dim, n, scale, out, rel_direct, out_hi, out_lo, Bw * T);                                   \
@@ -897,6 +940,15 @@ extern "C" int snf_attention(const float* qkv, const float* rel, int Bw, int T, 
                              float* out, snf_stream_t stream) {
     SNF_REQUIRE(out, "snf_attention: null output");
     return attention_launch(qkv, rel, Bw, T, heads, head_dim, n, scale, out, nullptr, nullptr, stream);
+}
+
+// snf_attention_planes for small grids (2n - 1 <= 32) with the decomposed relative-position terms formed inside the kernel from the
+// tables rel_pos_h / rel_pos_w [2n-1][head_dim] (snf_relpos + snf_attention_planes in one launch)
+extern "C" int snf_attention_planes_rp(const float* qkv, const float* rel_pos_h, const float* rel_pos_w, int Bw, int T, int heads,
+                                       int head_dim, int n, float scale, uint16_t* out_hi, uint16_t* out_lo, snf_stream_t stream) {
+    SNF_REQUIRE(out_hi && out_lo && rel_pos_h && rel_pos_w && (head_dim % 8) == 0 && (((uintptr_t)out_hi | (uintptr_t)out_lo) & 15) == 0,
+                "snf_attention_planes_rp: null / unaligned pointer or head_dim=%d not a multiple of 8", head_dim);
+    return attention_launch(qkv, nullptr, Bw, T, heads, head_dim, n, scale, nullptr, out_hi, out_lo, stream, rel_pos_h, rel_pos_w);
 }
 
 // snf_attention with the output written as the projection GEMM's operand: bf16 hi / lo k-blocked planes [C/8][Bw*T][8]

@@ -93,6 +93,8 @@ def attention(qkv, Bw: int, T: int, heads: int, n: int, rel_pos_h=None, rel_pos_
     return out
 
 
+FUSED_WINDOW_RELPOS = True  # attention_planes on small grids: snf_relpos inside the attention kernel (tests compare both)
+
 # ---- the block GEMMs on pre-split operands (csrc/gemm_planes.hip) ------------------------------------------------------------
 class Planes:
     """An activation matrix [M, K] as the GEMM operand: bf16 hi / lo k-blocked planes [K/8, M, 8] (x = hi + lo)."""
@@ -149,12 +151,16 @@ def attention_planes(qkv, Bw: int, T: int, heads: int, n: int, out: Planes, rel_
     C = qkv.shape[1] // 3
     hd = C // heads
     rel = None
+    assert out.M == Bw * T and out.K == C
     if rel_pos_h is not None:
         assert rel_pos_h.shape == (2 * n - 1, hd) and rel_pos_w.shape == (2 * n - 1, hd), "rel-pos tables must have 2n-1 rows"
+        if FUSED_WINDOW_RELPOS and 2 * n - 1 <= 32:  # the windowed blocks: the position terms are formed inside the attention kernel
+            _launch("snf_attention_planes_rp", _p(qkv), _p(_chk(rel_pos_h, "rel_pos_h")), _p(_chk(rel_pos_w, "rel_pos_w")), Bw, T, heads,
+                    hd, n, float(hd ** -0.5), out.hi.data_ptr(), out.lo.data_ptr(), _stream(), units=4.0 * Bw * heads * T * T * hd)
+            return out
         rel = torch.empty((Bw * heads * T, 2 * n), device=qkv.device, dtype=torch.float32)
         _launch("snf_relpos", _p(qkv), Bw, T, heads, hd, n, _p(_chk(rel_pos_h, "rel_pos_h")), _p(_chk(rel_pos_w, "rel_pos_w")),
                 _p(rel), _stream())
-    assert out.M == Bw * T and out.K == C
     _launch("snf_attention_planes", _p(qkv), _p(rel), Bw, T, heads, hd, n, float(hd ** -0.5), out.hi.data_ptr(), out.lo.data_ptr(),
             _stream(), units=4.0 * Bw * heads * T * T * hd)
     return out

@@ -219,7 +219,7 @@ def test_split_operand_gemm_vs_fp64(M, K, Nc):
     assert float((y - y_t).abs().max()) <= 1e-5 * scale
 
 
-def test_producers_write_operand_planes():
+def test_producers_write_operand_planes(monkeypatch):
     """snf_layernorm_planes (with the window partition's row map and untouched zero padding) and snf_attention_planes against
     the fp32 kernels they replace: the planes hold the same values to the split's 2^-16."""
     from samnerf_amd import ops
@@ -248,5 +248,21 @@ def test_producers_write_operand_planes():
     rh = 0.1 * torch.randn((2 * n - 1, hd), device="cuda", generator=g)
     rw = 0.1 * torch.randn((2 * n - 1, hd), device="cuda", generator=g)
     o_ref = ops.attention(qkv, Bw, n * n, heads, n, rh, rw)
+    from samnerf_amd import ops_vit
+    monkeypatch.setattr(ops_vit, "FUSED_WINDOW_RELPOS", False)  # snf_relpos + snf_attention_planes: the same scores
     op = ops.attention_planes(qkv, Bw, n * n, heads, n, ops.Planes.empty(Bw * n * n, heads * hd, "cuda"), rh, rw)
     assert float((op.float() - o_ref).abs().max()) <= 2 ** -16 * float(o_ref.abs().max())
+    # the position terms formed inside the kernel on the bf16-split matrix cores (snf_attention_planes_rp): scores of magnitude ~10
+    # move by ~1e-6 relative, the softmax weights by ~1e-5
+    monkeypatch.setattr(ops_vit, "FUSED_WINDOW_RELPOS", True)
+    of = ops.attention_planes(qkv, Bw, n * n, heads, n, ops.Planes.empty(Bw * n * n, heads * hd, "cuda"), rh, rw)
+    assert float((of.float() - o_ref).abs().max()) <= 1e-4
+    q4 = qkv.view(Bw, n * n, 3, heads, hd).permute(2, 0, 3, 1, 4).reshape(3, Bw * heads, n * n, hd).double()
+    qq, kk, vv = q4.unbind(0)
+    att = (qq * hd ** -0.5) @ kk.transpose(-2, -1)
+    Rh, Rw = V.get_rel_pos(n, n, rh.double().cpu()).cuda(), V.get_rel_pos(n, n, rw.double().cpu()).cuda()
+    rq = qq.reshape(-1, n, n, hd)
+    att = (att.view(-1, n, n, n, n) + torch.einsum("bhwc,hkc->bhwk", rq, Rh)[:, :, :, :, None]
+           + torch.einsum("bhwc,wkc->bhwk", rq, Rw)[:, :, :, None, :]).view(-1, n * n, n * n)
+    ref64 = (att.softmax(-1) @ vv).view(Bw, heads, n * n, hd).permute(0, 2, 1, 3).reshape(Bw * n * n, heads * hd)
+    assert float((of.float().double() - ref64).abs().max()) <= 1e-4
