@@ -139,7 +139,15 @@ def test_prologue_on_the_side_stream_keeps_the_trajectory(monkeypatch):
     (a, ca), (c, cc) = run(False, 2), run(True, 2)
     assert ca == cc
     assert torch.equal(a["fields"], c["fields"])
-    assert _rel_to_max(c["proposal_networks"], a["proposal_networks"]) <= 1e-4  # (float atomics: 1.4e-5 seen run to run)
+    # The proposal group: its tiny-MLP weight gradients are float-atomic sums (rounding differs run to run by ~1e-7 relative) of
+    # gradients that are ~1e-10 in this miniature (largest first moment 5e-11) while Adam's eps is 1e-15: an element whose two
+    # steps' gradients nearly cancel takes an lr-sized step in one direction or the other depending on that rounding, and the
+    # second step's moments then differ by up to ~1.3e-3 of the largest one -- between two runs of the SAME schedule as much as
+    # between the two schedules (tools/debug_xstep.py: 1 run in 3, always the same two outcomes).  The bound therefore is the
+    # serial schedule's own run-to-run spread, with a floor well below what a stale or clobbered buffer does (O(0.1 - 1)).
+    a2, _ = run(False, 2)
+    spread = max(_rel_to_max(a2["proposal_networks"], a["proposal_networks"]), 5e-3)
+    assert _rel_to_max(c["proposal_networks"], a["proposal_networks"]) <= 2.0 * spread
     (a, ca), (b, _), (c, cc) = run(False, 16), run(False, 16), run(True, 16)
     assert ca == cc
     for g in a:
