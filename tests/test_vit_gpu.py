@@ -266,3 +266,27 @@ def test_producers_write_operand_planes(monkeypatch):
            + torch.einsum("bhwc,wkc->bhwk", rq, Rw)[:, :, :, None, :]).view(-1, n * n, n * n)
     ref64 = (att.softmax(-1) @ vv).view(Bw, heads, n * n, hd).permute(0, 2, 1, 3).reshape(Bw * n * n, heads * hd)
     assert float((of.float().double() - ref64).abs().max()) <= 1e-4
+
+
+@pytest.mark.parametrize("Bw,n,heads,hd", [(2, 9, 1, 16), (2, 5, 3, 40), (1, 16, 2, 64), (3, 14, 16, 80), (2, 7, 2, 96)])
+def test_windowed_attention_with_in_kernel_position_terms(Bw, n, heads, hd):
+    """snf_attention_planes_rp (relative-position terms formed inside the attention kernel from the 2n-1-row tables) against fp64:
+    grids from 5 x 5 to 16 x 16 (2n - 1 = 31 table rows: the most one MFMA tile takes), head dims of one, two and three 32-blocks,
+    a ragged last query tile and key tile."""
+    from samnerf_amd import ops
+    ops.set_gemm_mode("bf16x3")
+    g = torch.Generator(device="cuda").manual_seed(n * 100 + hd)
+    T, C = n * n, heads * hd
+    qkv = torch.randn((Bw * T, 3 * C), device="cuda", generator=g)
+    rh = 0.3 * torch.randn((2 * n - 1, hd), device="cuda", generator=g)
+    rw = 0.3 * torch.randn((2 * n - 1, hd), device="cuda", generator=g)
+    out = ops.attention_planes(qkv, Bw, T, heads, n, ops.Planes.empty(Bw * T, C, "cuda"), rh, rw).float().double()
+    q4 = qkv.view(Bw, T, 3, heads, hd).permute(2, 0, 3, 1, 4).reshape(3, Bw * heads, T, hd).double()
+    q, k, v = q4.unbind(0)
+    att = (q * hd ** -0.5) @ k.transpose(-2, -1)
+    Rh, Rw = V.get_rel_pos(n, n, rh.double().cpu()).cuda(), V.get_rel_pos(n, n, rw.double().cpu()).cuda()
+    rq = q.reshape(-1, n, n, hd)
+    att = (att.view(-1, n, n, n, n) + torch.einsum("bhwc,hkc->bhwk", rq, Rh)[:, :, :, :, None]
+           + torch.einsum("bhwc,wkc->bhwk", rq, Rw)[:, :, :, None, :]).view(-1, T, T)
+    ref = (att.softmax(-1) @ v).view(Bw, heads, T, hd).permute(0, 2, 1, 3).reshape(Bw * T, C)
+    assert float((out - ref).abs().max()) <= 1e-4
