@@ -474,8 +474,11 @@ __device__ __forceinline__ int at_key_slot(int kr) {
 // two waves per SIMD (<= 256 registers, no spills at head dim 80): with ONE (312 registers) nothing hid the barriers and the
 // load latencies of the key loop -- 14x14 windows 0.207 -> 0.128 ms, 64x64 global without positions 0.85 -> 0.53 ms
 #define SNF_ATT_WAVES 2
-template <int DB, bool PL = false>
-__global__ __launch_bounds__(256, SNF_ATT_WAVES) void k_attention_b3(const float* __restrict__ qkv, const float* __restrict__ rel, int T,
+// NT: threads of the workgroup = 32 queries per wave x NT / 64 waves.  256 everywhere but on the encoder's 14 x 14 windows (T = 196):
+// there ONE workgroup of 7 waves (448 threads: 224 query slots) takes a whole (window, head) -- with 128-query workgroups the second
+// one ran 68 of its 128 slots and both staged every K / V tile.
+template <int DB, bool PL = false, int NT = 256>
+__global__ __launch_bounds__(NT, (NT == 256 ? SNF_ATT_WAVES : 1)) void k_attention_b3(const float* __restrict__ qkv, const float* __restrict__ rel, int T,
                                                       int heads, int hd, int n, float scale, float* __restrict__ out,
                                                       int rel_direct, uint16_t* __restrict__ out_hi = nullptr,
                                                       uint16_t* __restrict__ out_lo = nullptr, int M_out = 0,
@@ -491,7 +494,7 @@ __global__ __launch_bounds__(256, SNF_ATT_WAVES) void k_attention_b3(const float
     __shared__ __attribute__((aligned(16))) uint16_t Vl[DP * VPB];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, half = lane >> 5;
     const int bh = blockIdx.y, b = bh / heads, h = bh % heads, C = heads * hd;
-    const int q0 = (blockIdx.x * 4 + wave) * 32;
+    const int q0 = (blockIdx.x * (NT / 64) + wave) * 32;
     const int qi = q0 + li;
     const bool qlive = qi < T;
     const float* base = qkv + (size_t)b * T * 3 * C + h * hd;
@@ -573,12 +576,12 @@ __global__ __launch_bounds__(256, SNF_ATT_WAVES) void k_attention_b3(const float
         for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
     // staging: K as (key, pair of head dims), V as (pair of keys, head dim); one tile ahead in registers
-    constexpr int PPT = (16 * DP) / 256;  // pairs per thread and matrix
+    constexpr int PPT = (16 * DP + NT - 1) / NT;  // pairs per thread and matrix (NT = 448: the last pass is partial)
     float2 kreg[PPT], vreg[PPT];
     auto fetch = [&](int k0) {
 #pragma unroll
         for (int q = 0; q < PPT; ++q) {
-            const int e = threadIdx.x + 256 * q;
+            const int e = min((int)threadIdx.x + NT * q, 16 * DP - 1);  // (clamped: a partial last pass re-reads the last pair)
             {   // K: e -> (key kr, dims 2*dp, 2*dp + 1)
                 const int kr = e / (DP / 2), d = (e - kr * (DP / 2)) * 2;
                 const int key = k0 + kr;
@@ -602,7 +605,8 @@ __global__ __launch_bounds__(256, SNF_ATT_WAVES) void k_attention_b3(const float
         __syncthreads();  // previous tile consumed
 #pragma unroll
         for (int q = 0; q < PPT; ++q) {
-            const int e = threadIdx.x + 256 * q;
+            const int e = (int)threadIdx.x + NT * q;
+            if ((16 * DP) % NT != 0 && e >= 16 * DP) continue;
             uint32_t hh, ll;
             {
                 const int kr = e / (DP / 2), d = (e - kr * (DP / 2)) * 2;
@@ -903,6 +907,9 @@ static int attention_launch(const float* qkv, const float* rel, int Bw, int T, i
                 "snf_attention_planes_rp: tables need T == n*n, 2n-1 <= 32 and the bf16-split gemm mode");
     const size_t lds = ((rel && !rel_direct) || rph) ? (size_t)4 * 32 * (2 * n + 1) * sizeof(float) : 0;
     SNF_REQUIRE(lds <= 100 * 1024, "snf_attention: grid side n=%d too large for the relative-position staging", n);
+    // one 7-wave workgroup per (window, head) where two 4-wave ones would leave the second mostly empty (the 14 x 14 windows)
+    const bool wide = out_hi != nullptr && T > 128 && T <= 224;
+    const size_t lds7 = lds / 4 * 7;
 #define SNF_ATT(DB_)                                                                                                        \
     do {                                                                                                                    \
         if (lds > 32 * 1024)                                                                                                \
@@ -918,7 +925,12 @@ static int attention_launch(const float* qkv, const float* rel, int Bw, int T, i
             (void)hipFuncSetAttribute((const void*)k_attention_b3<DB_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
             (void)hipFuncSetAttribute((const void*)k_attention_b3<DB_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         }                                                                                                                   \
-        if (out_hi)                                                                                                         \
+        if (out_hi && wide) {                                                                                               \
+            (void)hipFuncSetAttribute((const void*)k_attention_b3<DB_, true, 448>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                                      (int)lds7);                                                                               \
+            hipLaunchKernelGGL((k_attention_b3<DB_, true, 448>), dim3(1, Bw * heads), dim3(448), lds7, (hipStream_t)stream, qkv,   \
+                               rel, T, heads, head_dim, n, scale, out, rel_direct, out_hi, out_lo, Bw * T, rph, rpw);           \
+        } else if (out_hi)                                                                                                  \
             hipLaunchKernelGGL((k_attention_b3<DB_, true>), grid, dim3(256), lds, (hipStream_t)stream, qkv, rel, T, heads,      \
                                head_dim, n, scale, out, rel_direct, out_hi, out_lo, Bw * T, rph, rpw);                         \
         else                                                                                                                \
