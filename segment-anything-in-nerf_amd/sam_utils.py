@@ -90,3 +90,9 @@ class SamImageEmbedder:
         """What get_image_embeddings.py saves for the image last set: the features without their padding rows / columns."""
         assert self.features is not None, "set_torch_image first"
         return crop_embedding(self.features, self.original_size).squeeze()
+
+    def save(self, path: str) -> None:
+        """Write the image's distillation target as get_image_embeddings.py:57-60 does: `np.save(path, feature.squeeze())`, fp32,
+        [C, rows, cols] without the padding -- the file `FeatureDataloader` / `set_feature` read back."""
+        import numpy as np
+        np.save(path, self.embedding().detach().float().cpu().numpy())

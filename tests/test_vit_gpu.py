@@ -190,6 +190,12 @@ def test_sam_preprocess_kernel(golden):
         ref = V.forward(sd, V.sam_preprocess(img, emb.pixel_mean.cpu(), emb.pixel_std.cpu(), 224), cfg)
     assert float((feats.cpu() - ref).abs().max()) <= 2e-4 * max(1.0, float(ref.abs().max()))
     assert emb.embedding().shape == (16, 10, 14)  # ceil(300 / 448 * 14) rows of the 14 x 14 map
+    import os, tempfile
+    with tempfile.TemporaryDirectory() as d:  # the offline writer's file (get_image_embeddings.py:57-60) and the reader's way back
+        emb.save(os.path.join(d, "frame_00001.npy"))
+        back = np.load(os.path.join(d, "frame_00001.npy"))
+    assert back.dtype == np.float32 and back.shape == (16, 10, 14)
+    assert np.array_equal(back, emb.embedding().cpu().numpy())
 
 
 @pytest.mark.parametrize("M,K,Nc", [(4900, 1280, 3840), (4096, 5120, 1280), (4096, 1280, 5120), (100, 64, 128), (333, 192, 256)])
