@@ -441,6 +441,11 @@ int snf_linear_planes_fwd_shape(const uint16_t* a_hi, const uint16_t* a_lo, cons
                                 int nb, snf_stream_t stream);
 int snf_layernorm_planes(const float* x, const float* residual, int N, int C, const float* weight, const float* bias, float eps,
                          float* sum_out, uint16_t* y_hi, uint16_t* y_lo, int M_out, int H, int W, int ws, snf_stream_t stream);
+/* ... with the block's window_unpartition + `shortcut + x` (snf_window_merge_add) folded in: residual_windows are the projection's
+ * output rows in WINDOW order ([B * nWh * nWw * res_ws^2, C]); token (b, y, x) adds the row of its window position; sum_out (required)
+ * receives the merged token rows, the planes their LayerNorm (norm2 of image_encoder.py:176-181). */
+int snf_layernorm_planes_merge(const float* x, const float* residual_windows, int N, int C, const float* weight, const float* bias,
+                               float eps, float* sum_out, uint16_t* y_hi, uint16_t* y_lo, int H, int W, int res_ws, snf_stream_t stream);
 int snf_attention_planes(const float* qkv, const float* rel, int Bw, int T, int heads, int head_dim, int n, float scale,
                          uint16_t* out_hi, uint16_t* out_lo, snf_stream_t stream);
 /* ... for small grids (2n - 1 <= 32: the 14 x 14 windows) with snf_relpos folded in: the decomposed relative-position terms are formed

@@ -142,6 +142,7 @@ SIGNATURES = {
     "snf_linear_planes_fwd": [P, P, P, P, P, I, I, I, I, P, P, P, P],
     "snf_linear_planes_fwd_shape": [P, P, P, P, P, I, I, I, I, P, P, P, I, I, P],
     "snf_layernorm_planes": [P, P, I, I, P, P, F, P, P, P, I, I, I, I, P],
+    "snf_layernorm_planes_merge": [P, P, I, I, P, P, F, P, P, P, I, I, I, P],
     "snf_attention_planes": [P, P, I, I, I, I, I, F, P, P, P],
     "snf_attention_planes_rp": [P, P, P, I, I, I, I, I, F, P, P, P],
     "snf_pixel_indices": [P, I, I, I, I, I, P, P],

@@ -123,11 +123,19 @@ template <int NV>
 __global__ __launch_bounds__(256) void k_layernorm_planes(const float* __restrict__ x, const float* __restrict__ res, int N, int C,
                                                           const float* __restrict__ w, const float* __restrict__ b, float eps,
                                                           float* __restrict__ sum_out, uint16_t* __restrict__ yhi,
-                                                          uint16_t* __restrict__ ylo, int M_out, int H, int W, int ws) {
+                                                          uint16_t* __restrict__ ylo, int M_out, int H, int W, int ws, int res_ws) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= N) return;
     const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * C);
-    const float4* rr = res ? reinterpret_cast<const float4*>(res + (size_t)row * C) : nullptr;
+    // res_ws > 0: the residual is still in WINDOW rows (the projection's output before window_unpartition): token (b, y, x) reads
+    // the row of its window position -- `x = shortcut + window_unpartition(proj)` (image_encoder.py:176-180) folded into norm2
+    int rrow = row;
+    if (res && res_ws > 0) {
+        const int nWh = (H + res_ws - 1) / res_ws, nWw = (W + res_ws - 1) / res_ws;
+        const int bb = row / (H * W), yy = (row / W) % H, xx = row % W;
+        rrow = ((bb * nWh + yy / res_ws) * nWw + xx / res_ws) * (res_ws * res_ws) + (yy % res_ws) * res_ws + xx % res_ws;
+    }
+    const float4* rr = res ? reinterpret_cast<const float4*>(res + (size_t)rrow * C) : nullptr;
     float4 v[NV];
     float s = 0.f;
 #pragma unroll
@@ -822,9 +830,9 @@ extern "C" int snf_layernorm(const float* x, const float* residual, int N, int C
     return SNF_OK;
 }
 
-extern "C" int snf_layernorm_planes(const float* x, const float* residual, int N, int C, const float* weight, const float* bias,
-                                    float eps, float* sum_out, uint16_t* y_hi, uint16_t* y_lo, int M_out, int H, int W, int ws,
-                                    snf_stream_t stream) {
+static int layernorm_planes_launch(const float* x, const float* residual, int N, int C, const float* weight, const float* bias,
+                                   float eps, float* sum_out, uint16_t* y_hi, uint16_t* y_lo, int M_out, int H, int W, int ws, int res_ws,
+                                   snf_stream_t stream) {
     SNF_REQUIRE(x && weight && bias && y_hi && y_lo && N > 0 && C > 0, "snf_layernorm_planes: bad argument");
     SNF_REQUIRE(C % 256 == 0 && C / 256 <= 8 && C / 256 != 7,
                 "snf_layernorm_planes: C=%d (the row is held in registers: a multiple of 256 up to 2048, not 1792)", C);
@@ -839,12 +847,28 @@ extern "C" int snf_layernorm_planes(const float* x, const float* residual, int N
     }
     const int nv = C / 256;
 #define SNF_LNP(NV_) hipLaunchKernelGGL(k_layernorm_planes<NV_>, dim3(ceil_div(N, 4)), dim3(256), 0, (hipStream_t)stream, x, residual, \
-                                        N, C, weight, bias, eps, sum_out, y_hi, y_lo, M_out, H, W, ws)
+                                        N, C, weight, bias, eps, sum_out, y_hi, y_lo, M_out, H, W, ws, res_ws)
     if (nv == 1) SNF_LNP(1); else if (nv == 2) SNF_LNP(2); else if (nv == 3) SNF_LNP(3); else if (nv == 4) SNF_LNP(4);
     else if (nv == 5) SNF_LNP(5); else if (nv == 6) SNF_LNP(6); else SNF_LNP(8);
 #undef SNF_LNP
     SNF_LAUNCH_CHECK("snf_layernorm_planes");
     return SNF_OK;
+}
+
+extern "C" int snf_layernorm_planes(const float* x, const float* residual, int N, int C, const float* weight, const float* bias,
+                                    float eps, float* sum_out, uint16_t* y_hi, uint16_t* y_lo, int M_out, int H, int W, int ws,
+                                    snf_stream_t stream) {
+    return layernorm_planes_launch(x, residual, N, C, weight, bias, eps, sum_out, y_hi, y_lo, M_out, H, W, ws, 0, stream);
+}
+
+// snf_layernorm_planes whose residual is still in window rows ([B * nWh * nWw * res_ws^2, C], the projection's output): the
+// window_unpartition + `shortcut + x` of the block (snf_window_merge_add) folded into norm2; sum_out = the merged token rows
+extern "C" int snf_layernorm_planes_merge(const float* x, const float* residual_windows, int N, int C, const float* weight,
+                                          const float* bias, float eps, float* sum_out, uint16_t* y_hi, uint16_t* y_lo, int H, int W,
+                                          int res_ws, snf_stream_t stream) {
+    SNF_REQUIRE(residual_windows && sum_out && res_ws > 0 && H > 0 && W > 0 && N % (H * W) == 0,
+                "snf_layernorm_planes_merge: bad argument (N=%d must be whole [H=%d, W=%d] grids)", N, H, W);
+    return layernorm_planes_launch(x, residual_windows, N, C, weight, bias, eps, sum_out, y_hi, y_lo, N, H, W, 0, res_ws, stream);
 }
 
 extern "C" int snf_window_partition(const float* x, int B, int H, int W, int C, int ws, float* out, snf_stream_t stream) {

@@ -156,8 +156,12 @@ class ImageEncoderViT(nn.Module):
         o = ops.attention_planes(qkv, Bw, n * n, a.num_heads, n, self._pbuf("att", Bw * n * n, C, dev),
                                  a.rel_pos_h if a.use_rel_pos else None, a.rel_pos_w if a.use_rel_pos else None)
         o = ops.linear_planes(o, self._wplanes(a.proj), a.proj.bias)
-        shortcut = ops.window_merge_add(o, shortcut, B, G, G, ws)
-        y2 = ops.layernorm_planes(shortcut, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps, self._pbuf("n2", B * G * G, C, dev))
+        # x = shortcut + window_unpartition(proj) inside norm2 (its residual input, read at the token's window row)
+        n2 = self._pbuf("n2", B * G * G, C, dev)
+        if ws > 0:
+            y2, shortcut = ops.layernorm_planes_merge(shortcut, o, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps, n2, B, G, G, ws)
+        else:
+            y2, shortcut = ops.layernorm_planes(shortcut, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps, n2, residual=o, want_sum=True)
         h = ops.linear_planes(y2, self._wplanes(blk.mlp.lin1), blk.mlp.lin1.bias, ops.ACT_GELU,
                               out=self._pbuf("h", B * G * G, Mh, dev))
         pending = ops.linear_planes(h, self._wplanes(blk.mlp.lin2), blk.mlp.lin2.bias)

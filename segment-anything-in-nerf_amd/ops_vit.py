@@ -145,6 +145,19 @@ def layernorm_planes(x, weight, bias, eps: float, out: Planes, residual=None, wa
 
 
 @torch.no_grad()
+def layernorm_planes_merge(shortcut, windows, weight, bias, eps: float, out: Planes, B: int, H: int, W: int, ws: int):
+    """x = shortcut + window_unpartition(windows); LayerNorm(x) as operand planes: `window_merge_add` + `layernorm_planes` in one
+    launch.  Returns (planes, x)."""
+    shortcut, windows = _chk(shortcut, "shortcut"), _chk(windows, "windows")
+    N, C = shortcut.shape
+    assert N == B * H * W and out.M == N and ws > 0
+    s = torch.empty_like(shortcut)
+    _launch("snf_layernorm_planes_merge", _p(shortcut), _p(windows), N, C, _p(weight), _p(bias), float(eps), _p(s), out.hi.data_ptr(),
+            out.lo.data_ptr(), H, W, ws, _stream())
+    return out, s
+
+
+@torch.no_grad()
 def attention_planes(qkv, Bw: int, T: int, heads: int, n: int, out: Planes, rel_pos_h=None, rel_pos_w=None) -> Planes:
     """`attention` with the result written as the projection GEMM's operand planes."""
     qkv = _chk(qkv, "qkv")

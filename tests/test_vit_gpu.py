@@ -248,6 +248,12 @@ def test_producers_write_operand_planes(monkeypatch):
     ops.layernorm_planes(x, w, b, 1e-6, outw, residual=r, grid=(G, G, ws))
     assert float((outw.float() - part).abs().max()) <= 2 ** -16 * float(y_ref.abs().max())
     assert bool((outw.float()[part.abs().sum(1) == 0] == 0).all())
+    # norm2 with the window un-partition + residual add folded in == snf_window_merge_add, then the plain kernel (bit for bit)
+    wins = torch.randn((part.shape[0], C), device="cuda", generator=g)
+    merged = ops.window_merge_add(wins, x, B, G, G, ws)
+    ref_pl = ops.layernorm_planes(merged, w, b, 1e-6, ops.Planes.empty(B * G * G, C, "cuda"))
+    got_pl, got_sum = ops.layernorm_planes_merge(x, wins, w, b, 1e-6, ops.Planes.empty(B * G * G, C, "cuda"), B, G, G, ws)
+    assert torch.equal(got_sum, merged) and torch.equal(got_pl.hi, ref_pl.hi) and torch.equal(got_pl.lo, ref_pl.lo)
     # attention
     Bw, n, heads, hd = 3, 14, 4, 80
     qkv = torch.randn((Bw * n * n, 3 * heads * hd), device="cuda", generator=g)
