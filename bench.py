@@ -132,7 +132,7 @@ def cpu_baseline(w: dict, budget_s: float):
     distill = w["method"] == "samnerf_distill"
     cfg = O.PathConfig(num_proposal_samples=w["P"], num_nerf_samples=w["S"], num_sam_samples=w["K"],
                        patch_size=w["patch"], distill_sam=distill, use_clipseg=distill)
-    R = 128
+    R = w["R"] // 16  # "for the full-size configs allow R to be reduced x16 on CPU and scale linearly"
     params = {k: v.requires_grad_(True) for k, v in O.init_params(cfg, seed=0).items()}
     o, d = O.synthetic_rays(R, 0)
     batch = O.synthetic_batch(cfg, R, 1)
@@ -145,15 +145,15 @@ def cpu_baseline(w: dict, budget_s: float):
         out = O.forward(params, cfg, o, d, True, t_rand, u_rand, 1.0)
         sum(O.loss_dict(out, batch, cfg).values()).backward()
 
-    t_w = time.perf_counter()
-    step()  # warm-up (page faults of the 0.9 GB tables, thread pool)
-    t_w = time.perf_counter() - t_w
+    n_warm = 3  # 3 warm-up + up to 10 timed steps (page faults of the 0.9 GB tables, thread pool)
+    for _ in range(n_warm):
+        step()
     t0, n = time.perf_counter(), 0
     while True:
         step()
         n += 1
         el = time.perf_counter() - t0
-        if el + t_w >= budget_s or n >= 10:
+        if el >= budget_s or n >= 10:
             break
     try:  # core count and CPU model of the box beside the number
         model = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
@@ -161,8 +161,9 @@ def cpu_baseline(w: dict, budget_s: float):
         model = "unknown"
     return {"value": R * w["S"] * n / el, "unit": "ray-samples/s", "cores": torch.get_num_threads(), "kind": "port",
             "cpu_model": model, "host_cores": os.cpu_count(),
-            "sample": f"{n} fwd+bwd steps of {R} rays x {w['S']} samples (P={w['P']}, K={w['K']}), full-size fp32 "
-                      f"tables, no optimizer step, {el:.1f} s of CPU work"}
+            "sample": f"{n_warm} warm-up + {n} timed fwd+bwd steps of {R} rays (the workload's R / 16) x {w['S']} samples "
+                      f"(P={w['P']}, K={w['K']}), full-size fp32 tables, no optimizer step, {el:.1f} s of timed CPU work; "
+                      f"{torch.get_num_threads()} of {os.cpu_count()} hardware threads (torch's CPU kernels stop scaling there)"}
 
 
 def _free(trainer) -> None:
@@ -236,10 +237,28 @@ def render_measure(local_rank: int, res: int = 512, reps: int = 5) -> dict:
     S, P = model.config.num_nerf_samples_per_ray, model.config.num_proposal_samples_per_ray[0]
     shapes = {k: list(v.shape) for k, v in out.items() if torch.is_tensor(v)}
     static = model.__dict__.get("_render_prog") is not None
+    from samnerf_amd import render_program as _rp
+    reuse = bool(static and _rp.REUSE_PASS1)
+    K = model.config.num_sam_samples
+    # algorithmic HBM bytes, SURVEY 8(d)'s forward figures: P x 320 + S x 1024 B per sampled ray (proposal + field grid gathers),
+    # K x 6144 B per feature ray and head (24 levels x 8 corners x 32-B rows).  The reference samples all three passes' rays
+    # (`reference_work`); this schedule samples the camera's rays once and feeds the feature passes from pass 1 (`schedule`:
+    # the conservative number the fraction is quoted on).
+    feat_rays = rays - res * res
+    per_ray = P * 320 + S * 1024
+    b_ref = rays * per_ray + feat_rays * K * 6144
+    b_sched = (res * res if reuse else rays) * per_ray + feat_rays * K * 6144
     _free(tr)
     return {"ms_per_image": round(ms, 3), "rays_per_s": rays / (ms * 1e-3), "ray_samples_per_s": rays * S / (ms * 1e-3),
             "rays_per_image": rays, "samples_per_ray": {"proposal": P, "fine": S}, "outputs": shapes, "images_timed": reps,
-            "static_schedule": static, "note": "eval path: RGB pass over every pixel + SAM feature pass over the patch ray grid + "
+            "static_schedule": static, "feature_passes_reuse_pass1": reuse,
+            "roofline": {"bound": "hbm", "achieved": round(b_sched / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(b_sched / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "algorithmic_bytes_per_image": b_sched,
+                         "reference_work_bytes_per_image": b_ref,
+                         "frac_reference_work": round(b_ref / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "traffic": None,
+                         "basis": "whole image: requested gather bytes of the three passes (SURVEY 8d forward figures) / "
+                                  "wall time per image; per-kernel shares in profiles/*render_kernel_stats.txt"},
+            "note": "eval path: RGB pass over every pixel + SAM feature pass over the patch ray grid + "
             "ClipSeg pass over 32 x 32 rays, no_grad, full-size fp32 tables"}
 
 
@@ -303,13 +322,23 @@ def exchange_summary(trainer, w: dict, world: int) -> dict:
     return out
 
 
-def mfma_util() -> dict:
-    """{kernel-name substring: matrix-core busy fraction} from the committed PMC pass (tools/mfma_util.py ->
-    profiles/r02_mfma_util.json: SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES per kernel)."""
-    try:
-        return json.load(open(os.path.join(ROOT, "profiles", "r02_mfma_util.json")))["by_entry_point"]
-    except (OSError, KeyError, ValueError):
-        return {}
+def mfma_util():
+    """({entry point: matrix-core busy fraction}, file it came from): the NEWEST committed PMC pass profiles/r*_mfma_util.json
+    (tools/mfma_util.sh -> tools/mfma_util.py: SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES per kernel)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_mfma_util.json")))
+    for f in reversed(files):
+        try:
+            return json.load(open(f))["by_entry_point"], os.path.relpath(f, ROOT)
+        except (OSError, KeyError, ValueError):
+            continue
+    return {}, None
+
+
+def env_overrides() -> dict:
+    """Every SNF_* variable set in this process's environment: the library's / schedule's documented switches (README
+    "Switches").  A timing switch that skips work must not be reachable unannounced (VERDICT r03 weak #9)."""
+    return {k: v for k, v in sorted(os.environ.items()) if k.startswith("SNF_")}
 
 
 def main():
@@ -318,15 +347,21 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="distill_4096x128", choices=sorted(WORKLOADS))
-    ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0)
     ap.add_argument("--roofline-kernel", default=None, help="kernel key 'entry/tag' to time live (default: auto)")
     ap.add_argument("--other-workloads", default=None,
                     help="comma list of further BASELINE workloads measured briefly and reported under 'other_workloads' "
                          "(default at --gpus 1 with the default workload: the other two; 'none' disables)")
     ap.add_argument("--exchange", default="both", choices=["both", "table_parallel", "allreduce"],
                     help="multi-rank gradient exchange to time (both: each for --steps steps, the faster one is `value`)")
+    ap.add_argument("--allow-ablation", action="store_true",
+                    help="measurement only: accept SNF_ABLATE_SKIP (launches left out, results garbage); the line says so")
     args = ap.parse_args()
     w = dict(WORKLOADS[args.workload])
+    if os.environ.get("SNF_ABLATE_SKIP") and not args.allow_ablation:
+        sys.exit("bench.py: SNF_ABLATE_SKIP is set -- the schedule would skip launches and the number would be invalid. "
+                 "Unset it, or pass --allow-ablation for a timing probe (tools/ablate_step.sh); the JSON line then carries "
+                 "\"invalid\": true.")
 
     import samnerf_amd  # noqa: F401
     from samnerf_amd import distributed as D
@@ -479,7 +514,7 @@ def main():
     if rank == 0:
         R, S, K = w["R"], w["S"], w["K"]
         ms = elapsed / args.steps * 1e3
-        mu = mfma_util()
+        mu, mu_file = mfma_util()
 
         def roof(key, stat, nsteps, where):
             """achieved = algorithmic units of all timed launches / their summed HIP-event duration."""
@@ -544,7 +579,8 @@ def main():
             "step_frac_of_hbm_peak": b_step / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
             "roofline": roofline,
             "roofline_other_kernels": others,
-            "host": {"static_schedule": static_schedule, "static_schedule_off_reason": static_off},
+            "host": {"static_schedule": static_schedule, "static_schedule_off_reason": static_off,
+                     "env_overrides": env_overrides(), "mfma_busy_source": mu_file},
             "rccl": {"backend": backend, "ranks": world, "collectives_on": bool(multi),
                      "exchange": chosen_mode if multi else None, "exchange_modes_timed": exchange_modes,
                      "bytes_per_rank_per_step": exchange_bytes},
@@ -553,6 +589,9 @@ def main():
             "serial_step_ms": round(sum(per_step.values()), 3),
             "kernel_ms_per_step_serial": {k: round(v, 4) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1])},
         }
+        if os.environ.get("SNF_ABLATE_SKIP"):
+            out["invalid"] = True
+            out["invalid_reason"] = "SNF_ABLATE_SKIP=" + os.environ["SNF_ABLATE_SKIP"] + ": launches left out (timing probe)"
         if world == 1 and args.cpu_baseline_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(w, args.cpu_baseline_seconds)
         else:

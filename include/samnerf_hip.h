@@ -58,6 +58,13 @@ int snf_sample_spacing(const float* nears, const float* fars, const float* t_ran
 int snf_positions(const float* origins, const float* dirs, const float* ebins, const int32_t* ids,
                   int R, int n, int K, int contraction, int use_selector, float* u, uint8_t* selector,
                   snf_stream_t stream);
+/* Row-mapped form for the eval render (samnerf/sam_model.py:371-377,392-398: the feature passes render
+ * `camera_ray_bundle[hind.flatten(), wind.flatten()]`, an index subset of the rays pass 1 has just sampled):
+ * list entry j reads ray src_rows[j] of the chunk (origins / dirs / ebins) and owns row dst_rows[j] of ids [.,K]
+ * and u [.*K,3].  Same arithmetic as snf_positions; no selector. */
+int snf_positions_rows(const float* origins, const float* dirs, const float* ebins, const int32_t* ids,
+                       const int32_t* src_rows, const int32_t* dst_rows, int M, int n, int K, int contraction,
+                       float* u, snf_stream_t stream);
 
 /* ---- a6: tcnn.Encoding(HashGrid) forward with the reference's torch semantics
  *      (HashEncoding.pytorch_fwd, nerfstudio/field_components/encodings.py:289-349; call sites
@@ -352,6 +359,9 @@ int snf_composite_bwd(const float* rgb, const float* weights, const float* grad_
  * Out: ids [R,K] int32 (descending weight, ties -> lower index), sam_weights [R,K] (0/0 -> NaN kept). */
 int snf_topk_sharpen(const float* weights, int R, int S, int K, float temperature, int32_t* ids,
                      float* sam_weights, snf_stream_t stream);
+/* Row-mapped form (see snf_positions_rows): weights row src_rows[j] -> ids / sam_weights row dst_rows[j], j < M. */
+int snf_topk_sharpen_rows(const float* weights, const int32_t* src_rows, const int32_t* dst_rows, int M, int S,
+                          int K, float temperature, int32_t* ids, float* sam_weights, snf_stream_t stream);
 
 /* ---- a18: MeanRenderer (samnerf/sam_model.py:126-137): out[r,c] = sum_k w[r,k] * embeds[r,k,c]. */
 int snf_feature_mean_fwd(const float* embeds, const float* w, int R, int K, int C, float* out,

@@ -84,6 +84,7 @@ P, I, F = c_void_p, c_int, c_float
 SIGNATURES = {
     "snf_sample_spacing": [P, P, P, I, I, P, P, P],
     "snf_positions": [P, P, P, P, I, I, I, I, I, P, P, P],
+    "snf_positions_rows": [P, P, P, P, P, P, I, I, I, I, P, P],
     "snf_hashgrid_fwd": [P, P, P, I, I, I, I, P, I, I, P],
     "snf_hashgrid_bwd": [P, P, P, I, I, I, I, I, I, P, P],
     "snf_hashgrid_bwd_sorted": [P, P, P, I, I, I, I, I, I, P, P, c_int64, P],
@@ -121,6 +122,7 @@ SIGNATURES = {
     "snf_composite_fwd": [P, P, P, I, I, I, P, P, P, P],
     "snf_composite_bwd": [P, P, P, I, I, P, P, P],
     "snf_topk_sharpen": [P, I, I, I, F, P, P, P],
+    "snf_topk_sharpen_rows": [P, P, P, I, I, I, F, P, P, P],
     "snf_feature_mean_fwd": [P, P, I, I, I, P, P],
     "snf_feature_mean_bwd": [P, P, I, I, I, P, P],
     "snf_interlevel": [P, P, P, P, I, I, I, F, P, P, P],

@@ -48,11 +48,18 @@ __global__ __launch_bounds__(256) void k_positions(const float* __restrict__ ori
                                                    const float* __restrict__ ebins,
                                                    const int32_t* __restrict__ ids, int R, int n, int K,
                                                    int contraction, int use_selector, float* __restrict__ u,
-                                                   uint8_t* __restrict__ selector) {
-    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+                                                   uint8_t* __restrict__ selector, const int32_t* __restrict__ src_rows,
+                                                   const int32_t* __restrict__ dst_rows) {
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (long long)R * K) return;
-    const int r = (int)(t / K);
+    int r = (int)(t / K);
     const int k = (int)(t - (long long)r * K);
+    if (src_rows) {
+        // row-mapped form (snf_positions_rows): list entry r reads ray src_rows[r] of the chunk (origins / dirs / ebins) and
+        // owns row dst_rows[r] of ids / u -- the eval render keeps the selected samples of an index subset of the camera's rays
+        t = (long long)dst_rows[r] * K + k;
+        r = src_rows[r];
+    }
     const int i = ids ? ids[t] : k;
     const float st = ebins[(size_t)r * (n + 1) + i];
     const float en = ebins[(size_t)r * (n + 1) + i + 1];
@@ -170,9 +177,15 @@ __global__ __launch_bounds__(256) void k_pdf_resample(const float* __restrict__ 
 // One wave per ray; each lane keeps up to 4 candidates (S <= 256); K rounds of wave arg-max.
 __global__ __launch_bounds__(256) void k_topk_sharpen(const float* __restrict__ weights, int R, int S, int K,
                                                       float temperature, int32_t* __restrict__ ids,
-                                                      float* __restrict__ sam_w) {
-    const int r = blockIdx.x * RAYS_PER_BLOCK + (threadIdx.x >> 6);
+                                                      float* __restrict__ sam_w, const int32_t* __restrict__ src_rows,
+                                                      const int32_t* __restrict__ dst_rows) {
+    int r = blockIdx.x * RAYS_PER_BLOCK + (threadIdx.x >> 6);
     if (r >= R) return;
+    int ro = r;  // output row
+    if (src_rows) {  // row-mapped form (snf_topk_sharpen_rows): weights row src_rows[r] -> ids / sam_w row dst_rows[r]
+        ro = dst_rows[r];
+        r = src_rows[r];
+    }
     const int lane = lane_id();
     float v[4];
 #pragma unroll
@@ -209,8 +222,8 @@ __global__ __launch_bounds__(256) void k_topk_sharpen(const float* __restrict__ 
     if (lane < K) p = powf(my_w, temperature);
     const float denom = wave_sum(lane < K ? p : 0.f);
     if (lane < K) {
-        ids[(size_t)r * K + lane] = my_id;
-        sam_w[(size_t)r * K + lane] = p / denom;
+        ids[(size_t)ro * K + lane] = my_id;
+        sam_w[(size_t)ro * K + lane] = p / denom;
     }
 }
 
@@ -238,8 +251,22 @@ extern "C" int snf_positions(const float* origins, const float* dirs, const floa
     SNF_REQUIRE(!use_selector || selector, "snf_positions: selector buffer missing");
     const long long total = (long long)R * K;
     hipLaunchKernelGGL(k_positions, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, origins, dirs,
-                       ebins, ids, R, n, K, contraction, use_selector, u, selector);
+                       ebins, ids, R, n, K, contraction, use_selector, u, selector, (const int32_t*)nullptr,
+                       (const int32_t*)nullptr);
     SNF_LAUNCH_CHECK("snf_positions");
+    return SNF_OK;
+}
+
+extern "C" int snf_positions_rows(const float* origins, const float* dirs, const float* ebins, const int32_t* ids,
+                                  const int32_t* src_rows, const int32_t* dst_rows, int M, int n, int K, int contraction,
+                                  float* u, snf_stream_t stream) {
+    SNF_REQUIRE(origins && dirs && ebins && ids && u && src_rows && dst_rows, "snf_positions_rows: null pointer");
+    SNF_REQUIRE(M > 0 && n > 0 && K > 0, "snf_positions_rows: bad shape M=%d n=%d K=%d", M, n, K);
+    SNF_REQUIRE(contraction >= 0 && contraction <= 2, "snf_positions_rows: bad contraction %d", contraction);
+    const long long total = (long long)M * K;
+    hipLaunchKernelGGL(k_positions, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, origins, dirs,
+                       ebins, ids, M, n, K, contraction, 0, u, (uint8_t*)nullptr, src_rows, dst_rows);
+    SNF_LAUNCH_CHECK("snf_positions_rows");
     return SNF_OK;
 }
 
@@ -261,7 +288,18 @@ extern "C" int snf_topk_sharpen(const float* weights, int R, int S, int K, float
     SNF_REQUIRE(R > 0 && S >= 1 && S <= 256 && K >= 1 && K <= 64 && K <= S,
                 "snf_topk_sharpen: bad shape R=%d S=%d K=%d (need S<=256, K<=min(64,S))", R, S, K);
     hipLaunchKernelGGL(k_topk_sharpen, dim3(ceil_div(R, RAYS_PER_BLOCK)), dim3(256), 0, (hipStream_t)stream,
-                       weights, R, S, K, temperature, ids, sam_weights);
+                       weights, R, S, K, temperature, ids, sam_weights, (const int32_t*)nullptr, (const int32_t*)nullptr);
     SNF_LAUNCH_CHECK("snf_topk_sharpen");
+    return SNF_OK;
+}
+
+extern "C" int snf_topk_sharpen_rows(const float* weights, const int32_t* src_rows, const int32_t* dst_rows, int M, int S,
+                                     int K, float temperature, int32_t* ids, float* sam_weights, snf_stream_t stream) {
+    SNF_REQUIRE(weights && ids && sam_weights && src_rows && dst_rows, "snf_topk_sharpen_rows: null pointer");
+    SNF_REQUIRE(M > 0 && S >= 1 && S <= 256 && K >= 1 && K <= 64 && K <= S,
+                "snf_topk_sharpen_rows: bad shape M=%d S=%d K=%d (need S<=256, K<=min(64,S))", M, S, K);
+    hipLaunchKernelGGL(k_topk_sharpen, dim3(ceil_div(M, RAYS_PER_BLOCK)), dim3(256), 0, (hipStream_t)stream,
+                       weights, M, S, K, temperature, ids, sam_weights, src_rows, dst_rows);
+    SNF_LAUNCH_CHECK("snf_topk_sharpen_rows");
     return SNF_OK;
 }

@@ -126,6 +126,16 @@ class ImageEncoderViT(nn.Module):
         """Forget the split weights (after changing parameters in a way autograd's version counter does not see)."""
         self._wcache.clear()
 
+    # `.data` writes bump no version counter: the two module-level ways parameters are replaced wholesale drop the cache themselves
+    def _apply(self, fn, *args, **kw):
+        self._wcache.clear()
+        self._pcache.clear()
+        return super()._apply(fn, *args, **kw)
+
+    def load_state_dict(self, *args, **kw):
+        self._wcache.clear()
+        return super().load_state_dict(*args, **kw)
+
     def _pbuf(self, tag: str, M: int, K: int, device, zero: bool = False):
         key = (tag, M, K, str(device))
         buf = self._pcache.get(key)

@@ -338,6 +338,17 @@ def feature_ray_bundle(camera_ray_bundle: RayBundle, feature_h: int, feature_w: 
     return fb.reshape((feature_h, p, feature_w, p))._apply_fn_to_fields(lambda x: x.transpose(1, 2))
 
 
+def feature_pixel_ids(H: int, W: int, feature_h: int, feature_w: int, p: int) -> torch.Tensor:
+    """Row-major pixel index (h * W + w) of every ray of `feature_ray_bundle` (p > 1: patch order [fh, fw, p, p]) or, with p = 1,
+    of `clipseg_ray_bundle`, in the order the chunk loop walks them -- the same linspace(...).long() indices
+    (samnerf/sam_model.py:371-377,392-398), as int64 on the CPU."""
+    h_indices = torch.linspace(0, H - 1, feature_h * p, dtype=torch.long)
+    w_indices = torch.linspace(0, W - 1, feature_w * p, dtype=torch.long)
+    hind, wind = torch.meshgrid(h_indices, w_indices, indexing="ij")
+    pix = hind * W + wind  # [fh*p, fw*p]
+    return pix.reshape(feature_h, p, feature_w, p).transpose(1, 2).reshape(-1)
+
+
 def clipseg_ray_bundle(camera_ray_bundle: RayBundle, feature_h: int = 32, feature_w: int = 32) -> RayBundle:
     """samnerf/sam_model.py:389-398: the 32 x 32 linspace sub-sampling for the ClipSeg map."""
     sz = camera_ray_bundle.shape
@@ -452,6 +463,10 @@ class SAMModel(NerfactoModel):
         its scope / SNF_STATIC_RENDER=0 (the chunk loop then goes through `forward`)."""
         import os
         if os.environ.get("SNF_STATIC_RENDER", "1") != "1" or not self.device.type == "cuda":
+            return None
+        if self.training:
+            # the schedule bakes in eval semantics (near plane 0, no jitter); a model in train() mode goes through `forward` and
+            # the collider like the reference's chunk loop (base_model.py:152-175)
             return None
         prog = self.__dict__.get("_render_prog")
         if prog is None:
@@ -572,9 +587,31 @@ class SAMModel(NerfactoModel):
                 rows = torch.cat(lst)
                 outputs_lists.setdefault(name, []).append(D.all_gather_rows(rows) if shard else rows)
 
+        feature_h = feature_w = feature_h_clipseg = feature_w_clipseg = None
+        from . import render_program as _rp
+        if (prog is not None and self.config.distill_sam and _rp.REUSE_PASS1 and not D.collectives_on() and num_rays > 0):
+            # One rank, recorded schedule: the feature passes' rays are an index subset of the camera's rays
+            # (sam_model.py:371-377,392-398) and eval sampling is deterministic, so pass 1 keeps the selected samples of those
+            # rays while their chunk is resident and passes 2-3 run the heads only (render_program.RenderProgram.render_heads).
+            from .sam_utils import get_feature_size
+            feature_h, feature_w = get_feature_size(image_height, image_width)
+            p = self.config.patch_size
+            H, W = image_height, image_width
+            collect = {"sam": (("sam", H, W, feature_h, feature_w, p),
+                               lambda: feature_pixel_ids(H, W, feature_h, feature_w, p))}
+            if self.config.use_clipseg_feature:
+                feature_h_clipseg, feature_w_clipseg = 32, 32
+                collect["clipseg"] = (("clipseg", H, W, 32, 32), lambda: feature_pixel_ids(H, W, 32, 32, 1))
+            o = camera_ray_bundle.origins.reshape(-1, 3).contiguous()
+            d = camera_ray_bundle.directions.reshape(-1, 3).contiguous()
+            outputs = {name: rows.view(image_height, image_width, -1)
+                       for name, rows in prog.render(o, d, "rgb", fast=bool(fast), chunk=num_rays_per_chunk, collect=collect).items()}
+            outputs["sam"] = prog.render_heads("sam", chunk=num_rays_per_chunk)["sam"].view(feature_h, feature_w, -1)
+            if self.config.use_clipseg_feature:
+                outputs["clipseg"] = prog.render_heads("clipseg", chunk=num_rays_per_chunk)["clipseg"].view(32, 32, -1)
+            return outputs
         run(camera_ray_bundle, get_feature=[], fast=fast)
         sz = camera_ray_bundle.shape
-        feature_h = feature_w = feature_h_clipseg = feature_w_clipseg = None
         if self.config.distill_sam:
             from .sam_utils import get_feature_size
             feature_h, feature_w = get_feature_size(image_height, image_width)

@@ -19,6 +19,8 @@ import ctypes
 import os as _os
 from typing import List, Optional, Sequence, Tuple
 
+import threading
+
 import torch
 
 from . import _lib
@@ -169,16 +171,24 @@ def join_wgrad_stream() -> None:
 # torch.no_grad(), where no backward will ever come.  The wrappers below note the caller's grad mode here so that the forward
 # passes do not prepare one in eval: no backward sorts, no saved hidden activations, no row-major detour for the sorted backward
 # (the render path spent 11 of 58 ms per 512 x 512 image in sorts it never used, profiles/r03_render_before.txt).
-_TRACK = [True]
+# (per thread, like torch's grad mode itself: a no_grad render on another thread must not flip it under a training forward)
+class _Track(threading.local):
+    on = True
+
+    def __getitem__(self, _i):  # `_TRACK[0]`: the caller's grad mode on this thread
+        return self.on
+
+
+_TRACK = _Track()
 
 
 def _apply(fn, *args):
-    prev = _TRACK[0]
-    _TRACK[0] = torch.is_grad_enabled()
+    prev = _TRACK.on
+    _TRACK.on = torch.is_grad_enabled()
     try:
         return fn.apply(*args)
     finally:
-        _TRACK[0] = prev
+        _TRACK.on = prev
 
 
 def _grad_target(param: torch.Tensor) -> Tuple[torch.Tensor, bool]:

@@ -15,6 +15,13 @@ work in the kernels nobody reads.  Here a chunk is a recorded list of C-ABI laun
   * a head's hidden activations are rendered inside the GEMM epilogue (snf_linear_fwd_mean: the weighted mean over the K
     samples commutes with the linear last layer, sam_model.py:126-137) -- the [R*K, 256] activations never reach HBM.
 
+  * the feature passes' rays are an INDEX SUBSET of the camera's rays (sam_model.py:371-377,392-398:
+    `camera_ray_bundle[hind.flatten(), wind.flatten()]` with `linspace(...).long()` indices) and eval sampling is deterministic, so
+    pass 1 has already computed their samples and weights: while a chunk of pass 1 is resident, the selected samples (top-K ids,
+    sharpened weights, contracted positions) of the feature rays among its pixels are kept (`collect`), and passes 2-3 run the
+    heads only (`render_heads`) -- the same numbers as the reference's recomputation, bit for bit, without 20 % of the image's
+    proposal / field-grid / density work.
+
 Same arithmetic as the eager eval path kernel for kernel (tests/test_model_gpu.py runs both against the oracle's
 `render_camera`); only the order of the heads' last layer and the mean differs (fp32 rounding, 1e-7).
 """
@@ -28,6 +35,15 @@ from . import _lib, ops
 
 
 FUSED_GRID_HEAD = True  # feature passes: grids + first head layer + mean in one kernel (module constant: tests flip it)
+REUSE_PASS1 = True      # feature passes take the selected samples of their rays from pass 1 instead of sampling them again
+
+
+class _Dyn:
+    """An argument patched per chunk (a pointer into an image-sized tensor): recorded as 0, registered under `slot`."""
+    __slots__ = ("slot",)
+
+    def __init__(self, slot: str) -> None:
+        self.slot = slot
 
 
 class RenderProgram:
@@ -61,37 +77,67 @@ class RenderProgram:
         self.bufs: Dict[str, torch.Tensor] = {}
         self.plans: Dict[tuple, tuple] = {}
         self._keep: list = []
+        self._sig: Optional[tuple] = None
+        self._maps: Dict[tuple, tuple] = {}
+
+    def _signature(self) -> tuple:
+        """What a recorded argument list bakes in besides its own buffers: the device address (and shape) of every parameter
+        and buffer of the model, the far plane.  `build_arenas()` (p.data = arena view), `model.to()` or a changed collider move
+        them; plans recorded before are then dropped instead of reading freed memory."""
+        m = self.model
+        ptrs = tuple((t.data_ptr(), tuple(t.shape)) for t in list(m.parameters()) + list(m.buffers()))
+        return ptrs + (float(m.collider.far_plane),)
 
     # ------------------------------------------------------------------------------------------------------------
     def buf(self, name: str, shape, dtype=torch.float32) -> torch.Tensor:
         shape = tuple(int(x) for x in (shape if isinstance(shape, (tuple, list)) else (shape,)))
         t = self.bufs.get(name)
-        if t is None or tuple(t.shape) != shape or t.dtype != dtype:
+        if t is None:
             t = self.bufs[name] = torch.empty(shape, device=self.dev, dtype=dtype)
+        elif tuple(t.shape) != shape or t.dtype != dtype:
+            # (a silent reallocation would leave the plans that recorded the old address with a dangling pointer)
+            raise RuntimeError(f"render buffer {name!r} exists as {tuple(t.shape)} {t.dtype}, requested {shape} {dtype}")
         return t
 
     def nbytes(self) -> int:
         return sum(t.numel() * t.element_size() for t in self.bufs.values())
 
     # ------------------------------------------------------------------------------------------------------------
-    def _build(self, R: int, mode: str, fast: bool):
-        """-> (entries [[fn, args]], slots {name: [(args, index)]}, outputs {name: channels}) for one chunk of R rays."""
-        model, cfg = self.model, self.cfg
-        P, S = cfg.num_proposal_samples_per_ray[0], cfg.num_nerf_samples_per_ray
-        N0, N1 = R * P, R * S
-        pre = f"{mode}{R}_"
-        b = lambda name, shape, dtype=torch.float32: self.buf(pre + name, shape, dtype)  # noqa: E731
+    def _recorder(self, pre: str):
+        """(k, b, entries, slots): `k(name, *args)` records one C-ABI launch on the current stream (tensors -> device addresses,
+        `_Dyn` arguments -> per-chunk slots), `b(name, shape)` is a buffer private to this plan family."""
         entries: list = []
         slots: Dict[str, list] = {}
         st = torch.cuda.current_stream().cuda_stream
+        b = lambda name, shape, dtype=torch.float32: self.buf(pre + name, shape, dtype)  # noqa: E731
 
         def k(name: str, *args, dyn: Optional[dict] = None) -> None:
-            a = [x.data_ptr() if isinstance(x, torch.Tensor) else x for x in args]
+            a = []
+            for idx, x in enumerate(args):
+                if isinstance(x, _Dyn):
+                    slots.setdefault(x.slot, []).append((a, idx))
+                    a.append(0)
+                else:
+                    a.append(x.data_ptr() if isinstance(x, torch.Tensor) else x)
             a.append(st)
             entries.append([getattr(self.lib, name), a, name])
             for slot, idx in (dyn or {}).items():
                 slots.setdefault(slot, []).append((a, idx))
 
+        return k, b, entries, slots
+
+    def _prefix(self, R: int, mode: str, tag: str = "") -> str:
+        # (buffers of different GEMM modes / head paths never share a name: a plan of the other mode keeps its own addresses)
+        return f"{mode}{tag}{R}_g{int(self.lib.snf_get_gemm_mode())}{'f' if FUSED_GRID_HEAD else 'u'}_"
+
+    def _build(self, R: int, mode: str, fast: bool):
+        """-> (entries [[fn, args, name]], slots {name: [(args, index)]}, outputs {name: channels}, handles) for one chunk of R
+        rays sampled from scratch; handles = the chunk's weights / bin edges (what `collect` reads)."""
+        model, cfg = self.model, self.cfg
+        P, S = cfg.num_proposal_samples_per_ray[0], cfg.num_nerf_samples_per_ray
+        N0, N1 = R * P, R * S
+        k, b, entries, slots = self._recorder(self._prefix(R, mode))
+        o_, d_ = _Dyn("o"), _Dyn("d")
         # eval: near plane 0 (scene_colliders.py:170-189), no jitter (ray_samplers.py:105,318)
         nears, fars = b("nears", (R,)), b("fars", (R,))
         nears.zero_()
@@ -104,7 +150,7 @@ class RenderProgram:
         sb0, eb0 = b("sb0", (R, P + 1)), b("eb0", (R, P + 1))
         k("snf_sample_spacing", nears, fars, None, R, P, sb0, eb0)
         u0, sel0 = b("u0", (N0, 3)), b("sel0", (N0,), torch.uint8)
-        k("snf_positions", 0, 0, eb0, None, R, P, P, ops.CONTRACT_LINF, 1, u0, sel0, dyn={"o": 0, "d": 1})
+        k("snf_positions", o_, d_, eb0, None, R, P, P, ops.CONTRACT_LINF, 1, u0, sel0)
         enc0 = b("enc0", (N0, PL * PF))
         k("snf_hashgrid_fwd", u0, penc.params, penc.scalings, N0, PL, PF, PT, enc0, PL * PF, 0)
         I0, H0 = pnet.n_input_dims, pw0.shape[0]
@@ -115,15 +161,15 @@ class RenderProgram:
         w0 = b("w0", (R, P))
         k("snf_weights_fwd", dens0, 1, 1, None, eb0, R, P, w0, None)
         sb1, eb1 = b("sb1", (R, S + 1)), b("eb1", (R, S + 1))
-        k("snf_pdf_resample", w0, sb0, None, nears, fars, R, P, S, float(model.proposal_sampler._anneal),
-          float(model.proposal_sampler.pdf_sampler.histogram_padding), sb1, eb1, dyn={"anneal": 8})
+        k("snf_pdf_resample", w0, sb0, None, nears, fars, R, P, S, _Dyn("anneal"),
+          float(model.proposal_sampler.pdf_sampler.histogram_padding), sb1, eb1)
         # ---- nerfacto field: density always, colour only for the RGB pass (nerfacto_field.py:242-351)
         fenc, fbase, fhead = model.field.mlp_base.encoding, model.field.mlp_base.network, model.field.mlp_head
         bw0, bw1 = fbase.weights()
         hw0, hw1, hw2 = fhead.weights()
         FL, FF, FT = fenc.n_levels, fenc.n_features_per_level, fenc.log2_hashmap_size
         u1, sel1 = b("u1", (N1, 3)), b("sel1", (N1,), torch.uint8)
-        k("snf_positions", 0, 0, eb1, None, R, S, S, ops.CONTRACT_LINF, 1, u1, sel1, dyn={"o": 0, "d": 1})
+        k("snf_positions", o_, d_, eb1, None, R, S, S, ops.CONTRACT_LINF, 1, u1, sel1)
         enc1 = b("enc1", (FL * FF * N1,))
         k("snf_hashgrid_fwd", u1, fenc.params, fenc.scalings, N1, FL, FF, FT, enc1, 0, 0)
         C = bw1.shape[0]
@@ -133,34 +179,50 @@ class RenderProgram:
         k("snf_trunc_exp_fwd", h, C, sel1, N1, density1)
         w1 = b("w1", (R, S))
         k("snf_weights_fwd", density1, 1, 1, None, eb1, R, S, w1, None)
+        handles = {"w1": w1, "eb1": eb1}
         outputs: Dict[str, int] = {}
         if mode == "rgb":
             n_geo = C - 1
             x2 = b("x2", (N1, 32))
-            k("snf_head_input", 0, h.data_ptr() + 4, R, S, n_geo, C, x2, 32, dyn={"d": 0})
+            k("snf_head_input", d_, h.data_ptr() + 4, R, S, n_geo, C, x2, 32)
             rgb = b("rgb", (N1, 3))
             k("snf_mlp64_fwd", x2, 32, hw0, 16 + n_geo, hw1, hw2, 2, 3, ops.ACT_SIGMOID, N1, None, None, rgb, 3)
-            k("snf_composite_fwd", rgb, w1, None, R, S, 0, 0, None, None, dyn={"out:rgb": 6})
+            k("snf_composite_fwd", rgb, w1, None, R, S, 0, _Dyn("out:rgb"), None, None)
             outputs["rgb"] = 3
             if fast:
-                k("snf_composite_fwd", None, w1, eb1, R, S, 0, None, None, 0, dyn={"out:depth": 8})
+                k("snf_composite_fwd", None, w1, eb1, R, S, 0, None, None, _Dyn("out:depth"))
                 outputs["depth"] = 1
             else:
-                k("snf_composite_fwd", None, w1, eb1, R, S, 0, None, 0, 0, dyn={"out:accumulation": 7, "out:depth": 8})
-                k("snf_composite_fwd", None, w0, eb0, R, P, 0, None, None, 0, dyn={"out:prop_depth_0": 8})
+                k("snf_composite_fwd", None, w1, eb1, R, S, 0, None, _Dyn("out:accumulation"), _Dyn("out:depth"))
+                k("snf_composite_fwd", None, w0, eb0, R, P, 0, None, None, _Dyn("out:prop_depth_0"))
                 outputs.update({"accumulation": 1, "depth": 1, "prop_depth_0": 1})
-            return entries, slots, outputs
-        # ---- feature pass: top-K + sharpen (sam_model.py:243-255), one head (sam_field.py:112-140), MeanRenderer, conv head
+            return entries, slots, outputs, handles
+        # ---- feature pass: top-K + sharpen (sam_model.py:243-255), then the head
+        K = cfg.num_sam_samples
+        ids, wk = b("ids", (R, K), torch.int32), b("wk", (R, K))
+        k("snf_topk_sharpen", w1, R, S, K, float(cfg.sharpening_temperature), ids, wk)
+        uk = b("uk", (R * K, 3))
+        k("snf_positions", o_, d_, eb1, ids, R, S, K, ops.CONTRACT_L2, 0, uk, None)
+        self._head(k, b, R, mode, uk, wk, outputs)
+        return entries, slots, outputs, handles
+
+    def _build_heads(self, R: int, mode: str):
+        """One chunk of R feature rays whose selected samples pass 1 has kept: the head only (uk / wk are per-chunk slots)."""
+        k, b, entries, slots = self._recorder(self._prefix(R, mode, "H"))
+        outputs: Dict[str, int] = {}
+        self._head(k, b, R, mode, _Dyn("uk"), _Dyn("wk"), outputs)
+        return entries, slots, outputs, {}
+
+    def _head(self, k, b, R: int, mode: str, uk, wk, outputs: Dict[str, int]) -> None:
+        """One head (sam_field.py:112-140) on the R*K selected samples at normalised positions uk [R*K,3] with render weights
+        wk [R,K], MeanRenderer (sam_model.py:126-137), conv head for 'sam' (sam_model.py:196-200,259-264)."""
+        model, cfg = self.model, self.cfg
         K = cfg.num_sam_samples
         NK = R * K
         sf = model.sam_field
         encs = list(sf.clip_encs if mode == "sam" else sf.clipseg_encs)
         net = sf.sam_net if mode == "sam" else sf.clipseg_net
         ws_ = net.weights()
-        ids, wk = b("ids", (R, K), torch.int32), b("wk", (R, K))
-        k("snf_topk_sharpen", w1, R, S, K, float(cfg.sharpening_temperature), ids, wk)
-        uk = b("uk", (NK, 3))
-        k("snf_positions", 0, 0, eb1, ids, R, S, K, ops.CONTRACT_L2, 0, uk, None, dyn={"o": 0, "d": 1})
         total = sum(e.n_output_dims for e in encs)
         gemm_b3 = int(self.lib.snf_get_gemm_mode()) >= 1
         planar = gemm_b3 and all(e.n_features_per_level == 8 for e in encs) and total % 16 == 0 and 64 <= total <= 256
@@ -210,6 +272,7 @@ class RenderProgram:
             y = b(f"a{i}", (NK, O))
             k("snf_linear_fwd", x, w, None, NK, I, O, ldx, O, act, y)
             x = y
+        out_slot = _Dyn("out:" + mode)
         if commute:
             w_last = ws_[-1]
             Cf, Ih = w_last.shape
@@ -221,7 +284,7 @@ class RenderProgram:
                 fm = b("fm", (R, Cf))
                 k("snf_linear_fwd", hbar, w_last, None, R, Ih, Cf, Ih, Cf, ops.ACT_NONE, fm)
             else:
-                k("snf_linear_fwd", hbar, w_last, None, R, Ih, Cf, Ih, Cf, ops.ACT_NONE, 0, dyn={"out:" + mode: 9})
+                k("snf_linear_fwd", hbar, w_last, None, R, Ih, Cf, Ih, Cf, ops.ACT_NONE, out_slot)
         else:
             Cf = ws_[-1].shape[0]
             conv = mode == "sam" and cfg.patch_size > 1
@@ -229,7 +292,7 @@ class RenderProgram:
                 fm = b("fm", (R, Cf))
                 k("snf_feature_mean_fwd", x, wk, R, K, Cf, fm)
             else:
-                k("snf_feature_mean_fwd", x, wk, R, K, Cf, 0, dyn={"out:" + mode: 5})
+                k("snf_feature_mean_fwd", x, wk, R, K, Cf, out_slot)
         if conv:
             c0, c1 = model.conv_head[0], model.conv_head[2]
             p, ks = cfg.patch_size, c0.weight.shape[-1]
@@ -245,60 +308,147 @@ class RenderProgram:
             cm = b("cv_cm", (npatch, O0 * kk))
             k("snf_patch_unfold_mean", hc, R, p, O0, ks, cm)
             nb1 = int(self.lib.snf_linear_fwd_workspace_bytes(npatch, O0 * kk, O1))
-            k("snf_linear_fwd_ws", cm, c1.weight, c1.bias, npatch, O0 * kk, O1, O0 * kk, O1, ops.ACT_NONE, 0,
-              b("cv_ws1", (max(nb1, 16) // 4,)), nb1, dyn={"out:sam": 9})
+            k("snf_linear_fwd_ws", cm, c1.weight, c1.bias, npatch, O0 * kk, O1, O0 * kk, O1, ops.ACT_NONE, out_slot,
+              b("cv_ws1", (max(nb1, 16) // 4,)), nb1)
             outputs["sam"] = O1
         else:
             outputs[mode] = Cf
-        return entries, slots, outputs
 
     # ------------------------------------------------------------------------------------------------------------
     def rows_out(self, n_rays: int, mode: str) -> int:
         p = self.cfg.patch_size
         return n_rays // (p * p) if (mode == "sam" and p > 1) else n_rays
 
+    def _enter(self, mode: str) -> None:
+        """Checks common to every render call: eval semantics, the stream and the addresses the plans were recorded with."""
+        assert mode in self.MODES
+        if self.model.training:
+            # (near plane 0, no jitter: the train-mode chunk loop goes through `forward` and the collider, ADVICE r03)
+            raise RuntimeError("RenderProgram renders with eval semantics: call model.eval() first")
+        st = torch.cuda.current_stream().cuda_stream
+        sig = self._signature()
+        if st != getattr(self, "_stream", st) or sig != self._sig:
+            self.plans.clear()  # recorded for another stream, or before the parameters / the collider moved
+        self._stream, self._sig = st, sig
+
+    def _plan(self, kind: str, R: int, mode: str, fast: bool):
+        key = (kind, R, mode, bool(fast), int(self.lib.snf_get_gemm_mode()), bool(FUSED_GRID_HEAD))
+        plan = self.plans.get(key)
+        if plan is None:
+            plan = self.plans[key] = self._build(R, mode, bool(fast)) if kind == "full" else self._build_heads(R, mode)
+        return plan
+
+    @staticmethod
+    def _replay(plan, vals: dict) -> None:
+        entries, slots = plan[0], plan[1]
+        for slot, sites in slots.items():
+            v = vals[slot]
+            for a, idx in sites:
+                a[idx] = v
+        for fn, args, name in entries:
+            rc = fn(*args)
+            if rc:
+                _lib.check(rc, name)
+
+    def feature_maps(self, key, pixel_ids, n_pixels: int, chunk: int):
+        """Per chunk of pass 1 the feature rays among its pixels: (src, dst, bounds, m) with src = chunk-local ray index, dst = the
+        feature ray's own row (its position in the index list), both int32 on the device and ordered by pixel; bounds[c] ..
+        bounds[c+1] is chunk c's run.  `key` (hashable) names the index list, `pixel_ids` is the list or a callable that makes it;
+        cached per (key, n_pixels, chunk)."""
+        ck = (key, int(n_pixels), int(chunk))
+        m = self._maps.get(ck)
+        if m is None:
+            pix = (pixel_ids() if callable(pixel_ids) else pixel_ids).reshape(-1).to(device=self.dev, dtype=torch.int64)
+            assert pix.numel() > 0 and int(pix.min()) >= 0 and int(pix.max()) < n_pixels
+            order = torch.argsort(pix, stable=True)
+            sp = pix[order]
+            edges = torch.arange(0, n_pixels + chunk, chunk, device=self.dev, dtype=torch.int64)
+            bounds = torch.searchsorted(sp, edges).tolist()
+            src = (sp % chunk).to(torch.int32).contiguous()
+            dst = order.to(torch.int32).contiguous()
+            m = self._maps[ck] = (src, dst, bounds, int(pix.numel()))
+        return m
+
     @torch.no_grad()
     def render(self, origins: torch.Tensor, directions: torch.Tensor, mode: str = "rgb", fast: bool = False,
-               chunk: Optional[int] = None) -> Dict[str, torch.Tensor]:
+               chunk: Optional[int] = None, collect: Optional[Dict[str, torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
         """Render the rays `origins`, `directions` ([n, 3], contiguous fp32 on the device) in chunks of `chunk` rays
         (config.eval_num_rays_per_chunk).  mode 'rgb': {'rgb', 'depth'[, 'accumulation', 'prop_depth_0']} [n, C];
-        'sam' / 'clipseg': that head's rendered feature rows ([n / p^2, 256] behind the conv head, [n, C] otherwise)."""
-        assert mode in self.MODES
+        'sam' / 'clipseg': that head's rendered feature rows ([n / p^2, 256] behind the conv head, [n, C] otherwise).
+        collect = {name: (key, ray indices [m] into these n rays, or a callable making them)}: the selected samples of those rays
+        are kept for `render_heads(name)` (`key` names the index list, see `feature_maps`)."""
+        self._enter(mode)
         n = origins.shape[0]
         chunk = int(chunk or self.cfg.eval_num_rays_per_chunk)
         p = self.cfg.patch_size
         if mode == "sam" and p > 1:
             assert n % (p * p) == 0 and chunk % (p * p) == 0, "feature rays come in whole p x p patches"
         assert origins.is_cuda and origins.is_contiguous() and directions.is_contiguous() and origins.dtype == torch.float32
-        if torch.cuda.current_stream().cuda_stream != getattr(self, "_stream", torch.cuda.current_stream().cuda_stream):
-            self.plans.clear()  # (recorded for another stream)
-        self._stream = torch.cuda.current_stream().cuda_stream
         results: Dict[str, torch.Tensor] = {}
         anneal = float(self.model.proposal_sampler._anneal)
         if mode != "rgb":  # tables trained table-parallel are made whole before a replicated evaluation (collective)
             sf = self.model.sam_field
             ops._tp_refresh([e.params for e in (sf.clip_encs if mode == "sam" else sf.clipseg_encs)])
-        for i in range(0, n, chunk):
+        K, S = self.cfg.num_sam_samples, self.cfg.num_nerf_samples_per_ray
+        kept = {}
+        for name, (mkey, pix) in (collect or {}).items():
+            maps = self.feature_maps(mkey, pix, n, chunk)
+            m = maps[3]
+            kept[name] = {"maps": maps, "m": m,
+                          "ids": torch.empty((m, K), device=self.dev, dtype=torch.int32),
+                          "wk": torch.empty((m, K), device=self.dev), "uk": torch.empty((m * K, 3), device=self.dev)}
+        self._kept = kept
+        st = torch.cuda.current_stream().cuda_stream
+        for ci, i in enumerate(range(0, n, chunk)):
             R = min(chunk, n - i)
-            key = (R, mode, bool(fast), int(self.lib.snf_get_gemm_mode()))
-            plan = self.plans.get(key)
-            if plan is None:
-                plan = self.plans[key] = self._build(R, mode, bool(fast))
-            entries, slots, outputs = plan
+            plan = self._plan("full", R, mode, fast)
+            outputs, handles = plan[2], plan[3]
             if not results:
                 results = {name: torch.empty((self.rows_out(n, mode) if name == mode else n, ch), device=self.dev)
                            for name, ch in outputs.items()}
             r0 = self.rows_out(i, mode)
-            vals = {"o": origins.data_ptr() + i * 12, "d": directions.data_ptr() + i * 12, "anneal": anneal}
+            o_ptr, d_ptr = origins.data_ptr() + i * 12, directions.data_ptr() + i * 12
+            vals = {"o": o_ptr, "d": d_ptr, "anneal": anneal}
             for name, t in results.items():
                 row = r0 if name == mode else i
                 vals["out:" + name] = t.data_ptr() + row * t.shape[1] * 4
-            for slot, sites in slots.items():
-                v = vals[slot]
-                for a, idx in sites:
-                    a[idx] = v
-            for fn, args, name in entries:
-                rc = fn(*args)
-                if rc:
-                    _lib.check(rc, name)
+            self._replay(plan, vals)
+            for name, kp in kept.items():
+                # the feature rays among this chunk's pixels: top-K + sharpen on their weights, positions of the selected samples
+                # (sam_model.py:243-255 on rows of THIS chunk), written to the feature rays' own rows
+                src, dst, bounds, _ = kp["maps"]
+                a, e = bounds[ci], bounds[ci + 1]
+                if e > a:
+                    w1, eb1 = handles["w1"], handles["eb1"]
+                    rc = self.lib.snf_topk_sharpen_rows(w1.data_ptr(), src.data_ptr() + a * 4, dst.data_ptr() + a * 4, e - a, S, K,
+                                                        float(self.cfg.sharpening_temperature), kp["ids"].data_ptr(),
+                                                        kp["wk"].data_ptr(), st)
+                    _lib.check(rc, "snf_topk_sharpen_rows")
+                    rc = self.lib.snf_positions_rows(o_ptr, d_ptr, eb1.data_ptr(), kp["ids"].data_ptr(), src.data_ptr() + a * 4,
+                                                     dst.data_ptr() + a * 4, e - a, S, K, ops.CONTRACT_L2, kp["uk"].data_ptr(), st)
+                    _lib.check(rc, "snf_positions_rows")
+        return results
+
+    @torch.no_grad()
+    def render_heads(self, mode: str, chunk: Optional[int] = None) -> Dict[str, torch.Tensor]:
+        """Passes 2 / 3 on the samples `render(..., collect={mode: ...})` kept: the head, the MeanRenderer, the conv head."""
+        self._enter(mode)
+        kp = self._kept[mode]
+        n = kp["m"]
+        chunk = int(chunk or self.cfg.eval_num_rays_per_chunk)
+        p = self.cfg.patch_size
+        K = self.cfg.num_sam_samples
+        if mode == "sam" and p > 1:
+            assert n % (p * p) == 0 and chunk % (p * p) == 0, "feature rays come in whole p x p patches"
+        sf = self.model.sam_field
+        ops._tp_refresh([e.params for e in (sf.clip_encs if mode == "sam" else sf.clipseg_encs)])
+        results: Dict[str, torch.Tensor] = {}
+        for i in range(0, n, chunk):
+            R = min(chunk, n - i)
+            plan = self._plan("heads", R, mode, False)
+            if not results:
+                results = {name: torch.empty((self.rows_out(n, mode), ch), device=self.dev) for name, ch in plan[2].items()}
+            t = results[mode]
+            self._replay(plan, {"uk": kp["uk"].data_ptr() + i * K * 12, "wk": kp["wk"].data_ptr() + i * K * 4,
+                                "out:" + mode: t.data_ptr() + self.rows_out(i, mode) * t.shape[1] * 4})
         return results

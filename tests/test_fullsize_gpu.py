@@ -163,12 +163,20 @@ def test_pair_launch_at_full_table_size():
         assert float(la["gt"][cut:].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("method", ["samnerf_distill", "samnerf_no_distill"])
-def test_composed_step_at_full_table_size_against_the_oracle(method, grad_parity):
+@pytest.mark.parametrize("method,misfit", [("samnerf_distill", False), ("samnerf_no_distill", False),
+                                           ("samnerf_no_distill", True)])
+def test_composed_step_at_full_table_size_against_the_oracle(method, misfit, grad_parity):
     """One train step of the static schedule -- the product path bench.py times -- with the BASELINE sample counts (P = 64,
     S = 128, K = 16, patch 4) and FULL-SIZE tables (T = 19 / 17) against `O.forward` on the same rays: rendered RGB / SAM /
     ClipSeg within 1e-4, every loss term, every parameter gradient.  R x K = 8192: the schedule takes the kernels of the bench
-    configuration (heads rendered inside the GEMMs, paired table backward)."""
+    configuration (heads rendered inside the GEMMs, paired table backward).
+
+    misfit: with freshly initialised fields both densities are nearly flat, the proposal histogram already
+    bounds the fine one, the interlevel loss (nerfstudio/model_components/losses.py:46-120) is ~5e-12 and its gradient -- the ONLY
+    gradient of the proposal network -- is a difference of nearly equal numbers (fp32 and fp64 evaluations of the oracle 2e-2
+    apart): a 10 % bound says little.  Here the FIELD is made peaky (field table x 30, density row of the base net's last layer
+    x 4) while the proposal net stays flat: interlevel loss 1.1e-4, well conditioned (oracle fp32 against fp64: proposal-gradient
+    relative L1 4e-5), so the proposal network's gradient is held to 3e-3 at the bench's sample counts and table sizes."""
     from samnerf_amd import configs, tcnn_compat
     from samnerf_amd.interop import load_named_params, named_grads
     from samnerf_amd.rays import RayBundle
@@ -179,6 +187,10 @@ def test_composed_step_at_full_table_size_against_the_oracle(method, grad_parity
                        use_clipseg=distill)
     assert cfg.field_grid.log2_T == 19 and cfg.prop_grid.log2_T == 17
     params = O.init_params(cfg, seed=21, table_scale=0.05)
+    if misfit:
+        params["field_table"] = params["field_table"] * 30.0
+        params["base_w1"] = params["base_w1"].clone()
+        params["base_w1"][0] *= 4.0
     o, d = O.synthetic_rays(R, 22)
     batch = O.synthetic_batch(cfg, R, 23)
     gen = torch.Generator().manual_seed(24)
@@ -246,4 +258,11 @@ def test_composed_step_at_full_table_size_against_the_oracle(method, grad_parity
     grads = named_grads(model)
     # (proposal network: at P = 64 / S = 128 the interlevel loss is 4.9e-12 in fp32 and 4.4e-12 in fp64 on the oracle itself, its
     #  gradient 2e-2 apart in relative L1 between the two -- the bound is 5x that)
-    grad_parity(grads, {k: v.grad.numpy() for k, v in op.items() if v.grad is not None and k in grads}, prop_tol=0.1)
+    ref_grads = {k: v.grad.numpy() for k, v in op.items() if v.grad is not None and k in grads}
+    if misfit:
+        assert float(rl["interlevel_loss"]) >= 5e-5, float(rl["interlevel_loss"])
+        # (the peaky density makes the base net's first layer flip-prone: oracle fp32 against fp64 3e-3 in relative L1 on base_w0,
+        #  so the tensor-wide bound of the field tensors is 1e-2 here; what this variant pins is the proposal network: 3e-3)
+        grad_parity(grads, ref_grads, prop_tol=3e-3, l1_tol=1e-2, level_tol=1e-2)
+    else:
+        grad_parity(grads, ref_grads, prop_tol=0.1)
