@@ -983,12 +983,16 @@ struct HgSecond {
     float* grad_table;
     HgAdam adam;
     int first_levels;  // levels of the first grid IN THIS LAUNCH; >= gridDim.y: there is no second grid
-    int interleave;
+    int interleave;    // 1: even y = first grid, odd y = second; 2: XCD-aware order, `order` lists (level << 1 | grid) per slot
     int level0;        // first level of the second grid covered by this launch
     HgSparseDev sp;    // its reachable-row levels
+    unsigned char order[64];
 };
 
 #define SNF_HG_RT_MINWG 4
+#ifndef SNF_HG_PAIR_XCD_DEFAULT
+#define SNF_HG_PAIR_XCD_DEFAULT 0
+#endif
 // (HIP: the second launch-bounds value is the minimum WAVES per SIMD.  Two 8-wave workgroups per CU -- LDS allows it at F = 8 --
 // are 4 waves per SIMD, i.e. <= 128 VGPRs; without the hint the compiler took 130: ONE workgroup per CU)
 template <int F, bool ADAM>
@@ -1006,11 +1010,25 @@ __global__ __launch_bounds__(HG_RT, SNF_HG_RT_MINWG) void k_hg_reduce(const floa
     __shared__ uint32_t n_long;
     const int B = 1 << log2B, log2rpb = log2_T - log2B;
     const int rpb = 1 << log2rpb;
-    const int tid = threadIdx.x, b = blockIdx.x;
+    const int tid = threadIdx.x;
+    int b = blockIdx.x;
     int l = blockIdx.y;
     if (sec.first_levels < (int)gridDim.y) {  // (uniform over the workgroup)
         bool second;
-        if (sec.interleave) {
+        if (sec.interleave == 2) {
+            // XCD-aware order.  Workgroups go to the 8 XCDs round-robin by linear id, and every (bucket, level) workgroup gathers
+            // from the WHOLE staged-gradient slab of its level (2 MB at 65 536 samples): in the plain order all 8 XCDs work on the
+            // same few levels at a time and each L2 pulls its own copy of every slab (8 x 50 MB of the launch's fabric reads).
+            // Here XCD c takes a CONTIGUOUS run of the slot-major (slot, bucket) list -- whole levels, one at a time -- and the
+            // host orders the slots so that every XCD gets the same mix of reachable-row and dense levels (`order`).
+            const int lin = (int)blockIdx.x + (int)blockIdx.y * B;
+            const int per_xcd = ((int)gridDim.y * B) >> 3;
+            const int f = (lin & 7) * per_xcd + (lin >> 3);
+            const int slot = f / B;
+            b = f - slot * B;
+            second = sec.order[slot] & 1;
+            l = sec.order[slot] >> 1;
+        } else if (sec.interleave) {
             second = l & 1;
             l >>= 1;
         } else {
@@ -2120,6 +2138,32 @@ extern "C" int snf_hashgrid_bwd_presorted_adam_pair(const float* grad_out0, cons
     s2.first_levels = L0;
     s2.interleave = (interleave && L0 == L1) ? 1 : 0;
     s2.level0 = 0;
+    // SNF_HG_PAIR_XCD=1: XCD-aware slot order (k_hg_reduce, interleave == 2): needs whole levels per XCD
+    static const int xcd_mode = [] { const char* e = getenv("SNF_HG_PAIR_XCD"); return e ? atoi(e) : SNF_HG_PAIR_XCD_DEFAULT; }();
+    if (xcd_mode && (L0 + L1) % 8 == 0 && L0 + L1 <= 64 && B % 8 == 0) {
+        // cheap (reachable-row) levels first round-robin over the XCDs, then the dense ones; XCD c owns slots [c * k, (c + 1) * k)
+        const int n = L0 + L1, k = n / 8;
+        int lists[8][8], cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cheap[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        int next = 0;
+        auto give = [&](int code, bool is_cheap) {
+            while (cnt[next & 7] >= k) ++next;
+            lists[next & 7][cnt[next & 7]++] = code;
+            if (is_cheap) cheap[next & 7]++;
+            ++next;
+        };
+        for (int l = 0; l < sparse_levels0; ++l) give(l << 1, true);
+        for (int l = 0; l < sparse_levels1; ++l) give((l << 1) | 1, true);
+        for (int l = 0; l < (L0 > L1 ? L0 : L1); ++l) {  // dense levels of the two grids alternately
+            if (l >= sparse_levels0 && l < L0) give(l << 1, false);
+            if (l >= sparse_levels1 && l < L1) give((l << 1) | 1, false);
+        }
+        for (int c = 0; c < 8; ++c) {
+            // an XCD runs its slots one after the other: stagger where the latency-bound ones sit so that they do not all coincide
+            const int rot = xcd_mode == 2 ? 0 : (c % k);
+            for (int q = 0; q < k; ++q) s2.order[c * k + (q + rot) % k] = (unsigned char)lists[c][q];
+        }
+        s2.interleave = 2;
+    }
     // (ADAM instantiation whenever anything is stepped: bucket-wide levels >= fuse_from_level, or reachable-row levels with sparse_step)
     const bool any_step = fuse_from_level0 < L0 || fuse_from_level1 < L1 || (sparse_step && sparse_levels0 + sparse_levels1 > 0);
     if (!any_step)

@@ -22,6 +22,11 @@ namespace snf {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// bit 0: the forward chain requests the next tile's input row a tile ahead; bits 1 / 2 (off: they spill, see k_mlp_chain_bwd_wg):
+// the fused backward's input row / output gradients
+#ifndef SNF_CHAIN_PREFETCH
+#define SNF_CHAIN_PREFETCH 1
+#endif
 constexpr int MC_H = 64;        // hidden width
 constexpr int MC_IN = 32;       // (padded) input width
 constexpr int MC_P0 = 33;       // LDS pitch of W0 [64][32]
@@ -461,23 +466,38 @@ __global__ __launch_bounds__(256, SNF_CHAIN_FWD_WAVES) void k_mlp_chain_fwd_b3(c
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 31, half = lane >> 5;
     const long long ntiles = (N + 31) / 32;
-    for (long long tile = (long long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long long)gridDim.x * 4) {
-        const long long s = tile * 32 + li;
-        const bool ok = s < N;
-        const long long sc = ok ? s : N - 1;
-        f32x16 x[1];
+    // A wave is alone on its SIMD (the chain needs the register file), so nothing hides a global load it waits for: the NEXT tile's
+    // input row is requested before this tile's layers run (SNF_CHAIN_PREFETCH; 16 registers) and has landed when they are done.
+    auto load_x = [&](long long tile_, f32x16& xo) {
+        const long long s_ = tile_ * 32 + li;
+        const long long sc_ = s_ < N ? s_ : N - 1;
         if (ldx == 0) {
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                const float2 v = *reinterpret_cast<const float2*>(X + ((long long)(half * 8 + q) * N + sc) * 2);
-                x[0][2 * q] = v.x; x[0][2 * q + 1] = v.y;
+                const float2 v = *reinterpret_cast<const float2*>(X + ((long long)(half * 8 + q) * N + sc_) * 2);
+                xo[2 * q] = v.x; xo[2 * q + 1] = v.y;
             }
         } else {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const float4 v = *reinterpret_cast<const float4*>(X + sc * ldx + half * 16 + 4 * q);
-                x[0][4 * q] = v.x; x[0][4 * q + 1] = v.y; x[0][4 * q + 2] = v.z; x[0][4 * q + 3] = v.w;
+                const float4 v = *reinterpret_cast<const float4*>(X + sc_ * ldx + half * 16 + 4 * q);
+                xo[4 * q] = v.x; xo[4 * q + 1] = v.y; xo[4 * q + 2] = v.z; xo[4 * q + 3] = v.w;
             }
+        }
+    };
+    const long long tstride = (long long)gridDim.x * 4;
+    long long tile0 = (long long)blockIdx.x * 4 + wave;
+    f32x16 xn;
+    if ((SNF_CHAIN_PREFETCH & 1) && tile0 < ntiles) load_x(tile0, xn);
+    for (long long tile = tile0; tile < ntiles; tile += tstride) {
+        const long long s = tile * 32 + li;
+        const bool ok = s < N;
+        f32x16 x[1];
+        if (SNF_CHAIN_PREFETCH & 1) {
+            x[0] = xn;
+            if (tile + tstride < ntiles) load_x(tile + tstride, xn);
+        } else {
+            load_x(tile, x[0]);
         }
 #pragma unroll
         for (int i = 0; i < 16; ++i)
@@ -713,24 +733,73 @@ __global__ __launch_bounds__(WG_T) __attribute__((amdgpu_waves_per_eu(NH == 1 ? 
 #pragma unroll
     for (int i = 0; i < NT; ++i) acc[i] = zero16();
     const long long ntiles = (N + 31) / 32;
-    for (long long tile = (long long)blockIdx.x * WG_WAVES + wave; tile < ntiles; tile += (long long)gridDim.x * WG_WAVES) {
+    // (SNF_CHAIN_PREFETCH, RC only: the next tile's input row and output gradients are requested while this tile is worked on --
+    //  the wave is alone on its SIMD and would otherwise sit out both latencies at the top of every tile)
+    auto load_x = [&](long long tile_, f32x16& xo) {
+        const long long s_ = tile_ * 32 + li;
+        const long long sc_ = s_ < N ? s_ : N - 1;
+        if (ldx == 0) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float2 v = *reinterpret_cast<const float2*>(X + ((long long)(half * 8 + q) * N + sc_) * 2);
+                xo[2 * q] = v.x; xo[2 * q + 1] = v.y;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 v = *reinterpret_cast<const float4*>(X + sc_ * ldx + half * 16 + 4 * q);
+                xo[4 * q] = v.x; xo[4 * q + 1] = v.y; xo[4 * q + 2] = v.z; xo[4 * q + 3] = v.w;
+            }
+        }
+    };
+    constexpr int MAXST = 2;  // output-gradient values a lane may prefetch (hsteps <= 2: out <= 4, the colour net; wider outputs load in place)
+    auto load_dz = [&](long long tile_, float (&dzo)[MAXST]) {
+        const long long s_ = tile_ * 32 + li;
+        const bool ok_ = s_ < N;
+        const long long sc_ = ok_ ? s_ : N - 1;
+#pragma unroll
+        for (int st = 0; st < MAXST; ++st) {
+            const int o = half * hsteps + st;
+            float dz = 0.f;
+            if (st < hsteps && o < out && ok_) {  // rows beyond N contribute nothing to the weight gradients
+                dz = (o == 0 && dY0 != nullptr) ? dY0[sc_] : dY[sc_ * lddy + dy_col_off + o];
+                if (out_act == SNF_ACT_SIGMOID) {
+                    const float yv = Yout[sc_ * ldy + o];
+                    dz *= yv * (1.f - yv);
+                }
+            }
+            dzo[st] = dz;
+        }
+    };
+    // (the register file decides what can be requested a tile ahead: the two-hidden-layer net, alone on its SIMD with 491 of 512
+    //  registers in use, has room for its output gradients but not for the 16-register input row (48 spills); the one-hidden-layer
+    //  net runs two waves per SIMD at 252 registers, which hide each other's loads)
+    const bool pfx = (SNF_CHAIN_PREFETCH & 2) && RC && NH == 2;
+    const bool pfz = (SNF_CHAIN_PREFETCH & 4) && RC && NH == 2 && hsteps <= MAXST;
+    const bool pf = pfz;
+    const long long tstride = (long long)gridDim.x * WG_WAVES;
+    const long long tile0 = (long long)blockIdx.x * WG_WAVES + wave;
+    f32x16 xn;
+    float dzn[MAXST];
+    if (pfx && tile0 < ntiles) load_x(tile0, xn);
+    if (pfz && tile0 < ntiles) load_dz(tile0, dzn);
+    for (long long tile = tile0; tile < ntiles; tile += tstride) {
         const long long s = tile * 32 + li;
         const bool ok = s < N;
         const long long sc = ok ? s : N - 1;
         f32x16 xr[1];  // RC: this lane's half of the input row (features half*16 .. +15), pad columns zero as in the forward
+        float dzc[MAXST];
         if constexpr (RC) {
-            if (ldx == 0) {
+            if (pfz) {
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const float2 v = *reinterpret_cast<const float2*>(X + ((long long)(half * 8 + q) * N + sc) * 2);
-                    xr[0][2 * q] = v.x; xr[0][2 * q + 1] = v.y;
-                }
+                for (int st = 0; st < MAXST; ++st) dzc[st] = dzn[st];
+                if (tile + tstride < ntiles) load_dz(tile + tstride, dzn);
+            }
+            if (pfx) {
+                xr[0] = xn;
+                if (tile + tstride < ntiles) load_x(tile + tstride, xn);
             } else {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float4 v = *reinterpret_cast<const float4*>(X + sc * ldx + half * 16 + 4 * q);
-                    xr[0][4 * q] = v.x; xr[0][4 * q + 1] = v.y; xr[0][4 * q + 2] = v.z; xr[0][4 * q + 3] = v.w;
-                }
+                load_x(tile, xr[0]);
             }
 #pragma unroll
             for (int i = 0; i < 16; ++i)
@@ -745,20 +814,30 @@ __global__ __launch_bounds__(WG_T) __attribute__((amdgpu_waves_per_eu(NH == 1 ? 
         };
         // ---- dZ, dLast^T[k][s] = sum_o Wout[o][k] dZ^T[o][s]; dZ^T goes to its LDS matrix on the way
         f32x16 dl[2] = {zero16(), zero16()};
-        for (int st = 0; st < hsteps; ++st) {
+        auto dz_step = [&](int st, float dz) {
             const int o = half * hsteps + st;
-            float dz = 0.f;
-            if (o < out && ok) {  // rows beyond N contribute nothing to the weight gradients
-                dz = (o == 0 && dY0 != nullptr) ? dY0[sc] : dY[sc * lddy + dy_col_off + o];
-                if (out_act == SNF_ACT_SIGMOID) {
-                    const float yv = Yout[sc * ldy + o];
-                    dz *= yv * (1.f - yv);
-                }
-            }
             if (o < 32) Z[o * WG_TP + li] = dz;
             const int oc = o < 32 ? o : 31;
             dl[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(cw.wo[oc * MC_P1 + li], dz, dl[0], 0, 0, 0);
             dl[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(cw.wo[oc * MC_P1 + 32 + li], dz, dl[1], 0, 0, 0);
+        };
+        if (pf) {
+#pragma unroll
+            for (int st = 0; st < MAXST; ++st)  // (unrolled: dzc stays in registers)
+                if (st < hsteps) dz_step(st, dzc[st]);
+        } else {
+            for (int st = 0; st < hsteps; ++st) {
+                const int o = half * hsteps + st;
+                float dz = 0.f;
+                if (o < out && ok) {  // rows beyond N contribute nothing to the weight gradients
+                    dz = (o == 0 && dY0 != nullptr) ? dY0[sc] : dY[sc * lddy + dy_col_off + o];
+                    if (out_act == SNF_ACT_SIGMOID) {
+                        const float yv = Yout[sc * ldy + o];
+                        dz *= yv * (1.f - yv);
+                    }
+                }
+                dz_step(st, dz);
+            }
         }
         WG_LDS_ORDER();
         mc_bf16x8 zh[2], zl[2];  // A side of dWout: dZ^T rows 0..31, k-steps 0, 1

@@ -27,6 +27,7 @@ Same arithmetic as the eager eval path kernel for kernel (tests/test_model_gpu.p
 """
 from __future__ import annotations
 
+import os as _os
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -35,7 +36,9 @@ from . import _lib, ops
 
 
 FUSED_GRID_HEAD = True  # feature passes: grids + first head layer + mean in one kernel (module constant: tests flip it)
-REUSE_PASS1 = True      # feature passes take the selected samples of their rays from pass 1 instead of sampling them again
+# feature passes take the selected samples of their rays from pass 1 instead of sampling them again (SNF_RENDER_REUSE_PASS1=0: as the
+# reference does, every pass samples its own rays)
+REUSE_PASS1 = _os.environ.get("SNF_RENDER_REUSE_PASS1", "1") == "1"
 
 
 class _Dyn:
