@@ -69,7 +69,7 @@ def algorithmic_model(key: str, w: dict):
         return ("hbm", float(R * K * (int(m.group(1)) + int(m.group(2))) * 8 * 8 * 4 * 2), "GB/s") if m else (None, None, None)
     if name in ("snf_hashgrid_fwd", "snf_hashgrid_bwd", "snf_hashgrid_bwd_sorted", "snf_hashgrid_bwd_sorted_ex",
                 "snf_hashgrid_bwd_presorted", "snf_hashgrid_bwd_presorted_adam", "snf_hashgrid_bwd_presorted_adam_sp",
-                "snf_hashgrid_bwd_presorted_adam_fx"):
+                "snf_hashgrid_bwd_presorted_adam_fx", "snf_hashgrid_bwd_presorted_adam_xp"):
         # (the fused backward + Adam reports its own bytes per launch -- ops._hashgrid_bwd_launch: the corner
         # contributions as below plus 24 B per parameter of the fused levels -- and roof() prefers those)
         m = re.fullmatch(r"F(\d+)L(\d+)(tp)?", tag)
@@ -534,13 +534,17 @@ def main():
             return out
 
         def pmc_traffic(key):
-            """HBM bytes per launch from the committed PMC passes (profiles/pmc_traffic.json, made by tools/gpu_record.sh +
+            """HBM bytes per launch from the committed PMC passes (profiles/pmc_traffic*.json, made by tools/gpu_record.sh +
             tools/pmc_traffic.py from `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this same command)."""
-            try:
-                t = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            except OSError:
-                return None
-            return t["traffic_over_algorithmic"] if t["workload"] == args.workload and t["kernel"] == key and world == 1 else None
+            import glob
+            for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "pmc_traffic*.json"))):
+                try:
+                    t = json.load(open(fn))
+                except (OSError, ValueError):
+                    continue
+                if t.get("workload") == args.workload and t.get("kernel") == key and world == 1:
+                    return t["traffic_over_algorithmic"]
+            return None
 
         roofline = None
         if dom is not None and dom in live:
@@ -555,8 +559,12 @@ def main():
             roofline["serial"] = roof(dom, breakdown[dom], n_break, "HIP events, serial replay (kernel alone on the GPU)")
         others = []
         for k in sorted(per_step, key=lambda kk: -per_step[kk]):
-            if k != dom and (k == "snf_adam_step" or algorithmic_model(k, w)[1]) and len(others) < 7:
+            if k != dom and (k == "snf_adam_step" or algorithmic_model(k, w)[1]) and len(others) < 9:
                 others.append(roof(k, breakdown[k], n_break, "HIP events, serial replay"))
+                ratio = pmc_traffic(k)
+                if ratio:  # (a committed counter pass exists for this kernel too)
+                    others[-1]["traffic"] = ratio * others[-1]["algorithmic_units_per_launch"]
+                    others[-1]["traffic_source"] = f"profiles/pmc_traffic*.json: HBM bytes = {ratio:.4f} x algorithmic bytes"
         # algorithmic bytes of the whole step, for the step-level fraction
         feat = K * 12288 if w["method"] == "samnerf_distill" else 0
         b_step = 3 * (w["P"] * 320 + S * 1024 + feat) * R

@@ -121,22 +121,6 @@ int snf_hashgrid_bwd_presorted_adam_xp(const float* grad_out, int N, int L, int 
                                        float* param, float* exp_avg, float* exp_avg_sq, float lr, float beta1, float beta2, float eps,
                                        int step, float grad_scale, snf_stream_t stream);
 
-/* Table gradient of the COARSE levels of a grid without a sort (backward of HashEncoding.pytorch_fwd,
- * nerfstudio/field_components/encodings.py:289-349, for levels whose lattice (s + 1)^3 is small against the table): contributions
- * are accumulated per LATTICE POINT in LDS (64-bit fixed point, the scale and per-contribution rounding of the sorted fixed-point
- * path: same sums bit for bit), the points of a row -- the lattice points that hash to it -- are added from a static list and the
- * row is stepped (param != NULL: torch.optim.Adam on exactly the listed rows, as snf_adam_step_rows) or added to grad_table.
- *   u [N,3] normalised positions; grad_out level-major [n_levels][N][F] (the staged gradient of THESE levels); resolutions: HOST
- *   array of the levels' integer scalings s_l; grad_table / param / moments: the TABLE's base (rows are (l << log2_T) + row);
- *   csr_rows [n_rows] ascending (l << log2_T) + row, csr_start [n_rows + 1], csr_pts: lattice point ids x + (s+1) (y + (s+1) z)
- *   (Encoding.lattice_lists); workspace: snf_hashgrid_bwd_dense_workspace_bytes.  The sort / sorted backward of the same grid then
- *   cover the remaining levels only (scalings + n_levels, table + (n_levels << log2_T) * F, ...). */
-int64_t snf_hashgrid_bwd_dense_workspace_bytes(const int32_t* resolutions, int n_levels, int F);
-int snf_hashgrid_bwd_dense(const float* u, const float* grad_out, const int32_t* resolutions, int N, int n_levels, int F, int log2_T,
-                           float* grad_table, const uint32_t* csr_rows, const uint32_t* csr_start, const uint32_t* csr_pts,
-                           int n_rows, void* workspace, int64_t workspace_bytes, float* param, float* exp_avg, float* exp_avg_sq,
-                           float lr, float beta1, float beta2, float eps, int step, float grad_scale, snf_stream_t stream);
-
 /* snf_hashgrid_bwd_presorted with the optimizer step folded into its reduce pass for the levels >= fuse_from_level: the
  * workgroup that owns a bucket of rows holds their complete gradient after its last chunk and applies
  * torch.optim.Adam's update (the arithmetic of snf_adam_step: eps outside the bias-corrected sqrt, gradient pre-scaled by

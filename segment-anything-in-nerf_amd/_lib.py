@@ -92,7 +92,6 @@ SIGNATURES = {
     "snf_hashgrid_bwd_presorted": [P, I, I, I, I, I, I, I, P, P, P, P],
     "snf_hashgrid_sort_xp": [P, P, I, I, I, P, c_int64, P],
     "snf_hashgrid_bwd_presorted_adam_xp": [P, I, I, I, I, I, I, P, P, P, I, P, P, P, F, F, F, F, I, F, P],
-    "snf_hashgrid_bwd_dense": [P, P, P, I, I, I, I, P, P, P, P, I, P, c_int64, P, P, P, F, F, F, F, I, F, P],
     "snf_hashgrid_bwd_presorted_adam": [P, I, I, I, I, I, I, I, P, P, P, I, P, P, P, F, F, F, F, I, F, P],
     "snf_hashgrid_bwd_presorted_adam_sp": [P, I, I, I, I, I, I, I, P, P, P, I, P, P, P, F, F, F, F, I, F, P, P, I, I, I, P, P],
     "snf_hashgrid_bwd_presorted_adam_pair": [P, P, I, I, I, I, P, P, P, P, I, I, P, P, P, P, P, P, P, P, I, P, P, I, I, I, P, F, F, F, F,
@@ -189,8 +188,6 @@ def load(auto_build: bool = True) -> ctypes.CDLL:
     lib.snf_get_gemm_mode.argtypes = []
     lib.snf_hashgrid_bwd_workspace_bytes.restype = c_int64
     lib.snf_hashgrid_bwd_workspace_bytes.argtypes = [c_int, c_int, c_int]
-    lib.snf_hashgrid_bwd_dense_workspace_bytes.restype = c_int64
-    lib.snf_hashgrid_bwd_dense_workspace_bytes.argtypes = [c_void_p, c_int, c_int]
     lib.snf_linear_fwd_workspace_bytes.restype = c_int64
     lib.snf_linear_fwd_workspace_bytes.argtypes = [c_int, c_int, c_int]
     lib.snf_mlp64_bwd_fused_workspace_bytes.restype = c_int64

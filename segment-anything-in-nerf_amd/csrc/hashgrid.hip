@@ -1651,177 +1651,6 @@ __global__ __launch_bounds__(HG_FX_T) void k_hg_reduce_fx(const float* __restric
 }
 
 
-// ==========================================================================================
-// Coarse levels WITHOUT a sort (round 4): lattice-indexed accumulation in LDS.
-//
-// A level of resolution s addresses the (s + 1)^3 lattice points of [0, s]^3 -- 4913 ... 205 379 points on the five coarsest
-// levels of the 16 -> 2048 field grid, against 2^19 table rows and 4.2 M corner contributions per level of a 524 288-sample
-// step.  Sorting those contributions into 256 row buckets costs these levels as much as the fine ones (16-byte pair records
-// written and read back) and then piles hundreds of records on every row of the bucket-wide reduce (the five coarse levels were
-// two thirds of its time).  Here such a level needs no records at all: the lattice is cut into slabs of
-// HG_DN_PTS consecutive points (x fastest, then y, then z) whose fixed-point accumulators fit the LDS; a workgroup owns one
-// slab for one slice of the samples, reads the slice's positions and staged gradients COALESCED (sample order), forms the eight
-// corner contributions with the scatter pass's own arithmetic and adds those that fall into its slab as 64-bit integer LDS
-// atomics (a z test rejects samples outside the slab after one multiply); its sums leave as one coalesced block.  A second
-// kernel adds the slices' blocks per lattice point, the points per table row (a static list: lattice points that hash to the same
-// row) and applies the row's Adam step / gradient read-modify-write.  Same fixed-point scale (2^38 over the level's largest |g|)
-// and the same per-contribution rounding as k_hg_reduce_fx: integer sums commute, so the table gradient is BIT-IDENTICAL to the
-// sorted path's.
-// ==========================================================================================
-constexpr int HG_DN_T = 512;
-constexpr int HG_DN_MAXLEV = 8;
-constexpr long long HG_DN_NAN = (long long)0x8000000000000000ull;  // a block element that received a non-finite contribution
-template <int F> constexpr int hg_dn_pts() { return F == 2 ? 4096 : 1024; }  // lattice points per slab (64 KB of accumulators)
-
-struct HgDenseLevel {
-    int res, side, npts, splits, slices, wg0;
-    long long part_off;  // first 64-bit element of this level's blocks: [slice][point][F]
-};
-struct HgDense {
-    HgDenseLevel lv[HG_DN_MAXLEV];
-    int n;
-};
-
-template <int F>
-__global__ __launch_bounds__(HG_DN_T) void k_hg_dense_acc(const float* __restrict__ u, const float* __restrict__ gT, int N, HgDense D,
-                                                          const uint32_t* __restrict__ lvl_absmax_bits,
-                                                          long long* __restrict__ part) {
-    constexpr int PTS = hg_dn_pts<F>();
-    __shared__ unsigned long long acc[PTS * F];
-    __shared__ uint32_t bad[PTS * F / 32];
-    int l = 0;
-#pragma unroll
-    for (int q = 1; q < HG_DN_MAXLEV; ++q)
-        if (q < D.n && (int)blockIdx.x >= D.lv[q].wg0) l = q;
-    const HgDenseLevel lv = D.lv[l];
-    const int local = (int)blockIdx.x - lv.wg0;
-    const int split = local % lv.splits, slice = local / lv.splits;
-    const int p0 = split * PTS;
-    const int rows = min(PTS, lv.npts - p0);
-    const int tid = threadIdx.x;
-    for (int i = tid; i < rows * F; i += HG_DN_T) acc[i] = 0ull;
-    for (int i = tid; i < PTS * F / 32; i += HG_DN_T) bad[i] = 0u;
-    int e = 0;
-    frexpf(__uint_as_float(lvl_absmax_bits[l]), &e);
-    int sh = HG_FX_BITS - e;
-    sh = sh > 120 ? 120 : sh;
-    const float scale = ldexpf(1.f, sh);
-    const int side = lv.side, side2 = side * side;
-    const float zlo = (float)(p0 / side2), zhi = (float)((p0 + rows - 1) / side2);  // lattice planes this slab touches
-    const float s = (float)lv.res;
-    const long long n0 = (long long)N * slice / lv.slices, n1 = (long long)N * (slice + 1) / lv.slices;
-    const float* __restrict__ gl = gT + (size_t)l * N * F;
-    __syncthreads();
-    for (long long n = n0 + tid; n < n1; n += HG_DN_T) {
-        // (the arithmetic of corners_of / k_hg_scatter: separately rounded products, weights in autograd's order)
-#pragma clang fp contract(off)
-        const float pz = u[(size_t)n * 3 + 2] * s;
-        const float fzf = floorf(pz), czf = ceilf(pz);
-        if (czf < zlo || fzf > zhi) continue;
-        const float px = u[(size_t)n * 3 + 0] * s, py = u[(size_t)n * 3 + 1] * s;
-        const float fxf = floorf(px), fyf = floorf(py);
-        const int cx = (int)ceilf(px), cy = (int)ceilf(py), cz = (int)czf;
-        const int fx = (int)fxf, fy = (int)fyf, fz = (int)fzf;
-        if ((unsigned)cx >= (unsigned)side || (unsigned)cy >= (unsigned)side || (unsigned)cz >= (unsigned)side || fx < 0 || fy < 0 ||
-            fz < 0)
-            continue;  // (positions are normalised to [0, 1]: never taken; a point outside the lattice has no accumulator)
-        const float ox = px - fxf, oy = py - fyf, oz = pz - fzf;
-        const float mx = 1.f - ox, my = 1.f - oy, mz = 1.f - oz;
-        float w[8];
-        w[0] = oz * oy * ox; w[3] = oz * oy * mx; w[1] = oz * my * ox; w[2] = oz * my * mx;
-        w[4] = mz * oy * ox; w[7] = mz * oy * mx; w[5] = mz * my * ox; w[6] = mz * my * mx;
-        const int X[8] = {cx, cx, fx, fx, cx, cx, fx, fx};
-        const int Y[8] = {cy, fy, fy, cy, cy, fy, fy, cy};
-        const int Z[8] = {cz, cz, cz, cz, fz, fz, fz, fz};
-        float g[F];
-        load_row<F>(gl + (size_t)n * F, g);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const uint32_t idx = (uint32_t)(X[k] + side * (Y[k] + side * Z[k]) - p0);
-            if (idx < (uint32_t)rows) {
-#pragma unroll
-                for (int f = 0; f < F; ++f) {
-                    const float v = w[k] * g[f];
-                    if (fabsf(v) < INFINITY) {
-                        const long long q = __float2ll_rn(v * scale);
-                        if (q != 0) atomicAdd(&acc[idx * F + f], (unsigned long long)q);
-                    } else {
-                        const uint32_t eb = idx * F + (uint32_t)f;
-                        atomicOr(&bad[eb >> 5], 1u << (eb & 31));
-                    }
-                }
-            }
-        }
-    }
-    __syncthreads();
-    long long* __restrict__ out = part + lv.part_off + ((long long)slice * lv.npts + p0) * F;
-    for (int i = tid; i < rows * F; i += HG_DN_T) out[i] = ((bad[i >> 5] >> (i & 31)) & 1u) ? HG_DN_NAN : (long long)acc[i];
-}
-
-// one thread per table row that a lattice point of these levels hashes to: slices' blocks -> point sums -> row sum -> Adam / gradient
-template <int F, bool ADAM>
-__global__ __launch_bounds__(256) void k_hg_dense_fin(const long long* __restrict__ part, HgDense D, int log2_T,
-                                                      const uint32_t* __restrict__ csr_rows, const uint32_t* __restrict__ csr_start,
-                                                      const uint32_t* __restrict__ csr_pts, int n_rows,
-                                                      const uint32_t* __restrict__ lvl_absmax_bits, float* __restrict__ grad_table,
-                                                      HgAdam adam) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n_rows) return;
-    const uint32_t rid = csr_rows[i];  // (level << T) + row
-    const int l = (int)(rid >> log2_T);
-    const HgDenseLevel lv = D.lv[l];
-    int e = 0;
-    frexpf(__uint_as_float(lvl_absmax_bits[l]), &e);
-    int sh = HG_FX_BITS - e;
-    sh = sh > 120 ? 120 : sh;
-    const float inv = ldexpf(1.f, -sh);
-    long long q[F];
-    bool isbad[F];
-#pragma unroll
-    for (int f = 0; f < F; ++f) { q[f] = 0; isbad[f] = false; }
-    for (uint32_t k = csr_start[i]; k < csr_start[i + 1]; ++k) {
-        const long long* __restrict__ src = part + lv.part_off + (long long)csr_pts[k] * F;
-        for (int c = 0; c < lv.slices; ++c) {
-#pragma unroll
-            for (int f = 0; f < F; ++f) {
-                const long long v = src[(long long)c * lv.npts * F + f];
-                if (v == HG_DN_NAN) isbad[f] = true;
-                else q[f] += v;
-            }
-        }
-    }
-    float gg[F];
-    bool nz = false;
-#pragma unroll
-    for (int f = 0; f < F; ++f) {
-        gg[f] = isbad[f] ? __uint_as_float(0x7FC00000u) : __ll2float_rn(q[f]) * inv;
-        nz = nz || q[f] != 0 || isbad[f];
-    }
-    const size_t o = (size_t)rid * F;
-    if (ADAM) {
-        float pp[F], mm[F], vv[F];
-        load_row<F>(adam.p + o, pp);
-        load_row<F>(adam.m + o, mm);
-        load_row<F>(adam.v + o, vv);
-#pragma unroll
-        for (int f = 0; f < F; ++f) hg_adam1(pp[f], gg[f], mm[f], vv[f], adam);
-        if constexpr (F == 2) {
-            *reinterpret_cast<float2*>(adam.p + o) = make_float2(pp[0], pp[1]);
-            *reinterpret_cast<float2*>(adam.m + o) = make_float2(mm[0], mm[1]);
-            *reinterpret_cast<float2*>(adam.v + o) = make_float2(vv[0], vv[1]);
-        } else {
-            reinterpret_cast<float4*>(adam.p + o)[0] = make_float4(pp[0], pp[1], pp[2], pp[3]);
-            reinterpret_cast<float4*>(adam.p + o)[1] = make_float4(pp[4], pp[5], pp[6], pp[7]);
-            reinterpret_cast<float4*>(adam.m + o)[0] = make_float4(mm[0], mm[1], mm[2], mm[3]);
-            reinterpret_cast<float4*>(adam.m + o)[1] = make_float4(mm[4], mm[5], mm[6], mm[7]);
-            reinterpret_cast<float4*>(adam.v + o)[0] = make_float4(vv[0], vv[1], vv[2], vv[3]);
-            reinterpret_cast<float4*>(adam.v + o)[1] = make_float4(vv[4], vv[5], vv[6], vv[7]);
-        }
-    } else if (nz) {
-        row_rmw<F>(grad_table + o, gg);
-    }
-}
-
 }  // namespace snf
 
 using namespace snf;
@@ -2244,92 +2073,6 @@ extern "C" int snf_hashgrid_bwd_presorted_adam_xp(const float* grad_out, int N, 
     if (!planar) hg_stage(st, 2, grad_out, N, L, ld_out, col_off, stage);
     hg_reduce_one(st, 2, stage, N, L, log2_T, g, w, grad_table, n_run_levels, adam_on, false, a, HgSparse{nullptr, nullptr, 0}, w.fx, true);
     SNF_LAUNCH_CHECK("snf_hashgrid_bwd_presorted_adam_xp");
-    return SNF_OK;
-}
-
-// ---- coarse levels without a sort (k_hg_dense_acc / k_hg_dense_fin) ------------------------------------------------------------
-// plan: slabs of hg_dn_pts<F>() lattice points per level; per level as many sample slices as make ~128 workgroups (a slab's
-// workgroup rejects most samples of its slice by their z plane, so many slabs want few, long slices)
-template <int F>
-static bool hg_dense_plan(const int32_t* res, int n_levels, HgDense& D, long long& part_elems, int& n_wg) {
-    if (n_levels < 1 || n_levels > HG_DN_MAXLEV) return false;
-    constexpr int PTS = hg_dn_pts<F>();
-    D.n = n_levels;
-    part_elems = 0;
-    n_wg = 0;
-    for (int l = 0; l < n_levels; ++l) {
-        HgDenseLevel& lv = D.lv[l];
-        if (res[l] < 1 || res[l] > 400) return false;  // (401^3 points: the index arithmetic below stays inside 32 bits)
-        lv.res = res[l];
-        lv.side = res[l] + 1;
-        lv.npts = lv.side * lv.side * lv.side;
-        lv.splits = (lv.npts + PTS - 1) / PTS;
-        int sl = (128 + lv.splits / 2) / lv.splits;
-        lv.slices = sl < 1 ? 1 : (sl > 64 ? 64 : sl);
-        lv.wg0 = n_wg;
-        lv.part_off = part_elems;
-        n_wg += lv.splits * lv.slices;
-        part_elems += (long long)lv.slices * lv.npts * F;
-    }
-    return true;
-}
-
-extern "C" int64_t snf_hashgrid_bwd_dense_workspace_bytes(const int32_t* resolutions, int n_levels, int F) {
-    HgDense D;
-    long long pe = 0;
-    int nwg = 0;
-    if (!resolutions || !(F == 2 ? hg_dense_plan<2>(resolutions, n_levels, D, pe, nwg) : (F == 8 && hg_dense_plan<8>(resolutions, n_levels, D, pe, nwg))))
-        return 0;
-    return (int64_t)(HG_FX_SCRATCH * sizeof(uint32_t) + (size_t)pe * 8);
-}
-
-extern "C" int snf_hashgrid_bwd_dense(const float* u, const float* grad_out, const int32_t* resolutions, int N, int n_levels, int F,
-                                      int log2_T, float* grad_table, const uint32_t* csr_rows, const uint32_t* csr_start,
-                                      const uint32_t* csr_pts, int n_rows, void* workspace, int64_t workspace_bytes, float* param,
-                                      float* exp_avg, float* exp_avg_sq, float lr, float beta1, float beta2, float eps, int step,
-                                      float grad_scale, snf_stream_t stream) {
-    SNF_REQUIRE(u && grad_out && resolutions && grad_table && csr_rows && csr_start && csr_pts && workspace,
-                "snf_hashgrid_bwd_dense: null pointer");
-    SNF_REQUIRE(F == 2 || F == 8, "snf_hashgrid_bwd_dense: features_per_level must be 2 or 8 (got %d)", F);
-    SNF_REQUIRE(N > 0 && n_rows > 0 && log2_T >= 1 && log2_T <= 26 && step >= 1 && (F != 2 || N % 2 == 0),
-                "snf_hashgrid_bwd_dense: bad N=%d (even for F = 2) rows=%d log2_T=%d step=%d", N, n_rows, log2_T, step);
-    const bool adam_on = param != nullptr;
-    SNF_REQUIRE(!adam_on || (exp_avg && exp_avg_sq), "snf_hashgrid_bwd_dense: Adam needs both moments");
-    HgDense D;
-    long long pe = 0;
-    int nwg = 0;
-    const bool ok = F == 2 ? hg_dense_plan<2>(resolutions, n_levels, D, pe, nwg) : hg_dense_plan<8>(resolutions, n_levels, D, pe, nwg);
-    SNF_REQUIRE(ok, "snf_hashgrid_bwd_dense: 1 .. %d levels of resolution 1 .. 400 (got %d)", HG_DN_MAXLEV, n_levels);
-    SNF_REQUIRE(workspace_bytes >= (int64_t)(HG_FX_SCRATCH * sizeof(uint32_t) + (size_t)pe * 8),
-                "snf_hashgrid_bwd_dense: workspace too small (need %lld bytes)", (long long)(HG_FX_SCRATCH * 4 + pe * 8));
-    SNF_REQUIRE((((uintptr_t)grad_out | (uintptr_t)grad_table | (uintptr_t)workspace | (uintptr_t)param | (uintptr_t)exp_avg |
-                  (uintptr_t)exp_avg_sq) & 15) == 0, "snf_hashgrid_bwd_dense: unaligned pointer");
-    hipStream_t st = (hipStream_t)stream;
-    uint32_t* lvlmax = (uint32_t*)workspace;
-    long long* part = (long long*)(lvlmax + HG_FX_SCRATCH);
-    (void)hipMemsetAsync(lvlmax, 0, n_levels * sizeof(uint32_t), st);
-    HgAdam a{};
-    if (adam_on) hg_fill_adam(a, param, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step, grad_scale, 0);
-    if (F == 2) {
-        hipLaunchKernelGGL(k_hg_level_absmax<2>, dim3(hg_absmax_blocks(N, F), n_levels), dim3(256), 0, st, grad_out, N, lvlmax);
-        hipLaunchKernelGGL(k_hg_dense_acc<2>, dim3(nwg), dim3(HG_DN_T), 0, st, u, grad_out, N, D, lvlmax, part);
-        if (adam_on)
-            hipLaunchKernelGGL((k_hg_dense_fin<2, true>), dim3(ceil_div(n_rows, 256)), dim3(256), 0, st, part, D, log2_T, csr_rows,
-                               csr_start, csr_pts, n_rows, lvlmax, grad_table, a);
-        else
-            hipLaunchKernelGGL((k_hg_dense_fin<2, false>), dim3(ceil_div(n_rows, 256)), dim3(256), 0, st, part, D, log2_T, csr_rows,
-                               csr_start, csr_pts, n_rows, lvlmax, grad_table, a);
-    } else {
-        hipLaunchKernelGGL(k_hg_level_absmax<8>, dim3(hg_absmax_blocks(N, F), n_levels), dim3(256), 0, st, grad_out, N, lvlmax);
-        hipLaunchKernelGGL(k_hg_dense_acc<8>, dim3(nwg), dim3(HG_DN_T), 0, st, u, grad_out, N, D, lvlmax, part);
-        if (adam_on)
-            hipLaunchKernelGGL((k_hg_dense_fin<8, true>), dim3(ceil_div(n_rows, 256)), dim3(256), 0, st, part, D, log2_T, csr_rows,
-                               csr_start, csr_pts, n_rows, lvlmax, grad_table, a);
-        else
-            hipLaunchKernelGGL((k_hg_dense_fin<8, false>), dim3(ceil_div(n_rows, 256)), dim3(256), 0, st, part, D, log2_T, csr_rows,
-                               csr_start, csr_pts, n_rows, lvlmax, grad_table, a);
-    }
-    SNF_LAUNCH_CHECK("snf_hashgrid_bwd_dense");
     return SNF_OK;
 }
 

@@ -527,14 +527,25 @@ __global__ __launch_bounds__(256, SNF_CHAIN_FWD_WAVES) void k_mlp_chain_fwd_b3(c
         if constexpr (PLANES == 3) mc_layer_b6<2, 1, false>(poh, pom, pol, MC_BP64, last, y, li, half);
         else mc_layer_b3<2, 1, false>(poh, pol, MC_BP64, last, y, li, half);
         if (ok) {
+            if (out_act == SNF_ACT_NONE && (out & 3) == 0 && (ldy & 3) == 0) {
+                // accumulator registers 4 q .. 4 q + 3 of a lane are the four CONSECUTIVE outputs 8 q + 4 half .. + 3 of its sample: one
+                // 16-byte store per group instead of four scattered 4-byte ones (the base net's [N, 16] output: 2 stores per lane, not 8)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int o = krow(r, half);
-                if (o < out) {
-                    float v = y[0][r];
-                    if (out_act == SNF_ACT_SIGMOID) v = 1.f / (1.f + expf(-v));
-                    else if (out_act == SNF_ACT_RELU) v = fmaxf(v, 0.f);
-                    Y[s * ldy + o] = v;
+                for (int q = 0; q < 4; ++q) {
+                    const int o = 8 * q + 4 * half;
+                    if (o < out)
+                        *reinterpret_cast<float4*>(Y + s * ldy + o) = make_float4(y[0][4 * q], y[0][4 * q + 1], y[0][4 * q + 2], y[0][4 * q + 3]);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int o = krow(r, half);
+                    if (o < out) {
+                        float v = y[0][r];
+                        if (out_act == SNF_ACT_SIGMOID) v = 1.f / (1.f + expf(-v));
+                        else if (out_act == SNF_ACT_RELU) v = fmaxf(v, 0.f);
+                        Y[s * ldy + o] = v;
+                    }
                 }
             }
         }

@@ -84,11 +84,6 @@ XPAIR_RECORDS = True
 # Many ranks: the gradient exchange + optimizer of the replicated groups recorded into the schedule (collectives as list entries, Adam
 # as recorded launches) instead of `Optimizers.exchange_and_step` enqueueing its ~15 torch / C-ABI calls per group eagerly each step
 RECORD_EXCHANGE = True
-# The reachable-row (coarse) levels of the F = 2 field grid without a sort: their table gradient is accumulated per lattice point in
-# LDS and stepped from a static row list (snf_hashgrid_bwd_dense; bit-identical sums).  The forward-time sort and the sorted backward
-# then cover the fine levels only: 5 of 16 levels' pair records (0.34 GB per step) are neither written nor read, and the bucket-wide
-# reduce loses the levels that pile hundreds of records on a row.
-DENSE_COARSE = _os.environ.get("SNF_HG_DENSE_COARSE", "1") == "1"
 
 
 # SNF_ABLATE_SKIP="key,key": launches whose key contains one of these are NOT issued (results are garbage; timing probe only)
@@ -254,45 +249,10 @@ class StepProgram:
     def _f2_sort(self, F: int, N: int, L: int, T: int) -> str:
         return "snf_hashgrid_sort_xp" if self._xpair(F, N, L, T) else "snf_hashgrid_sort"
 
-    def _dense_levels(self, enc, N: int, group: str) -> int:
-        """Leading levels of `enc` whose table gradient goes through snf_hashgrid_bwd_dense instead of the sort: the table's
-        reachable-row levels (the optimizer's row lists cover them, so the launch can step them), for an F = 2 grid on x-pair
-        records with fine levels left for the sorted path."""
-        F, T, L = enc.n_features_per_level, enc.log2_hashmap_size, enc.n_levels
-        if not (DENSE_COARSE and F == 2 and self.opt.skip_unreachable_rows):
-            return 0
-        nd = min(int(self._table_adam(enc, group)[4]), 8)
-        if nd <= 0 or nd >= L or not self._xpair(F, N, L - nd, T):
-            return 0
-        return nd
-
-    def _grid_bwd_dense(self, st, g, u, N, enc, group, nd: int, with_opt: bool, done: list) -> None:
-        """Leading `nd` levels of `enc` (its reachable-row levels) through snf_hashgrid_bwd_dense: g = the level-major staged
-        gradient of the whole grid, u = the normalised positions; stepped by the launch when with_opt (one rank)."""
-        F, T = enc.n_features_per_level, enc.log2_hashmap_size
-        p, gbuf, m, v, n_sparse, fused_range = self._table_adam(enc, group)
-        assert 0 < nd <= n_sparse
-        res, rows, start, pts = enc.lattice_lists(nd)
-        self._keep.extend((res, rows, start, pts))
-        nb = int(self.lib.snf_hashgrid_bwd_dense_workspace_bytes(res.data_ptr(), nd, F))
-        ws = self.buf(f"dense_ws_{id(enc)}", ((nb + 7) // 8,), torch.int64)
-        step_it = bool(with_opt and self.opt.fuse_table_adam)
-        oc = self.opt.config[group]["optimizer"]
-        stride = (1 << T) * F
-        self._k(st, "snf_hashgrid_bwd_dense", u, g, res.data_ptr(), N, nd, F, T, gbuf, rows, start, pts, int(rows.numel()), ws, nb,
-                p if step_it else None, m if step_it else None, v if step_it else None, 0.0, float(oc.betas[0]), float(oc.betas[1]),
-                float(oc.eps), 1, 1.0, tag=f"F{F}L{nd}",
-                units=float(N) * 8 * F * 4 * nd * (1 if step_it else 2) + (24.0 * F * int(rows.numel()) if step_it else 0.0),
-                dyn={("lr", group): 17, ("t", group): 21} if step_it else None)
-        if step_it:
-            t0 = fused_range[1] - enc.params.numel()
-            done.append((t0, t0 + nd * stride))  # the reachable rows of the leading nd levels
-
     def _grid_bwd(self, st, g, N, enc, group, ld, col, sorted_ws, stage, with_opt: bool, done: list, run=None,
-                  grad_scale: float = 1.0, xp_run: bool = False) -> None:
+                  grad_scale: float = 1.0) -> None:
         """Table-gradient backward of one grid from the presorted records (+ Adam of its dense levels when with_opt).
-        run = (first level, levels): only that level run of the table (table-parallel ownership; xp_run: the fine levels of an
-        F = 2 grid whose coarse levels took `_grid_bwd_dense`, sorted into x-pair records); `g` / the sort are the run's."""
+        run = (first level, levels): only that level run of the table (table-parallel ownership); `g` / the sort are the run's."""
         L, F, T = enc.n_levels, enc.n_features_per_level, enc.log2_hashmap_size
         p, gbuf, m, v, n_sparse, fused_range = self._table_adam(enc, group)
         sc = enc.scalings
@@ -308,7 +268,7 @@ class StepProgram:
             tag = f"F{F}L{L}tp"
         nrun = ops.hashgrid_run_levels(sc) if F == 2 else 0
         fuse = with_opt and self.opt.fuse_table_adam and n_sparse < L
-        if (run is None or xp_run) and self._xpair(F, N, L, T):
+        if run is None and self._xpair(F, N, L, T):
             # the workspace holds x-pair records (self._f2_sort): their own backward entry, Adam of the levels >= n_sparse in its reduce
             oc = self.opt.config[group]["optimizer"]
             fused = ((L - n_sparse) << T) * F if fuse else 0
@@ -593,12 +553,10 @@ class StepProgram:
         FL, FF, FT = fenc.n_levels, fenc.n_features_per_level, fenc.log2_hashmap_size
         u1, sel1 = b("u1", (N1, 3), parity=pp), b("sel1", (N1,), torch.uint8, parity=pp)
         self._k(pre, "snf_positions", o, d, eb1, None, R, S, S, ops.CONTRACT_LINF, 1, u1, sel1)
-        nd_f = self._dense_levels(fenc, N1, "fields")  # coarse levels that need no sort (snf_hashgrid_bwd_dense)
-        ws_f, ws_f_bytes = self._sort_ws("ws_field", N1, FL - nd_f, FT, pp)
+        ws_f, ws_f_bytes = self._sort_ws("ws_field", N1, FL, FT, pp)
         self._edge(pre, sort_st, "u1_ready")
         self._edge(pre, main, "prologue_done")
-        self._k(sort_st, self._f2_sort(FF, N1, FL - nd_f, FT), u1, ops._sc_run(fenc.scalings, nd_f, FL - nd_f) if nd_f else fenc.scalings,
-                N1, FL - nd_f, FT, ws_f, ws_f_bytes, tag=f"L{FL - nd_f}")
+        self._k(sort_st, self._f2_sort(FF, N1, FL, FT), u1, fenc.scalings, N1, FL, FT, ws_f, ws_f_bytes, tag=f"L{FL}")
         if sort_st.stream_id != main.stream_id:
             self._py(self.event("field_sorted").record, sort_st)
         enc1 = b("enc1", (FL * FF * N1,))
@@ -709,12 +667,7 @@ class StepProgram:
             self._py(main.wait_event, self.event("field_sorted"))
         done_f: list = []
         fuse_local = with_opt and not self.multi  # across ranks the gradient mean comes first (exchange_and_step)
-        if nd_f:
-            self._grid_bwd_dense(main, denc1, u1, N1, fenc, "fields", nd_f, fuse_local, done_f)
-            self._grid_bwd(main, self._off(denc1, nd_f * N1 * FF * 4), N1, fenc, "fields", 0, 0, ws_f, None, fuse_local, done_f,
-                           run=(nd_f, FL - nd_f), xp_run=True)
-        else:
-            self._grid_bwd(main, denc1, N1, fenc, "fields", 0, 0, ws_f, None, fuse_local, done_f)
+        self._grid_bwd(main, denc1, N1, fenc, "fields", 0, 0, ws_f, None, fuse_local, done_f)
         done_p: list = []
         # The proposal network's backward (interlevel loss -> weights -> tiny MLP -> its hash grid) shares nothing with the
         # field's backward but the forward results.  Without feature heads the GPU is otherwise on ONE stream during the

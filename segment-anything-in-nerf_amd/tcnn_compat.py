@@ -140,35 +140,6 @@ class Encoding(nn.Module):
             cache[key] = out
         return cache[key]
 
-    def lattice_lists(self, n_levels: int):
-        """For the leading `n_levels` levels: the table rows their LATTICE POINTS hash to, as the static lists
-        snf_hashgrid_bwd_dense takes -- (resolutions int32 on the HOST, csr_rows int32 [(level << T) + row, ascending],
-        csr_start int32 [rows + 1], csr_pts int32 [points]: lattice point ids x + (s + 1) (y + (s + 1) z) of every row, grouped by row).
-        A level of resolution s addresses the points of [0, s]^3 (encodings.py:318-325: floor / ceil of u * s, u in [0, 1])."""
-        cache = self.__dict__.setdefault("_lattice_lists", {})
-        n_levels = int(n_levels)
-        if n_levels not in cache:
-            T, dev = self.log2_hashmap_size, self.params.device
-            mask32, maskT = 0xFFFFFFFF, (1 << T) - 1
-            res, rows, start, pts, base = [], [], [torch.zeros(1, dtype=torch.int64, device=dev)], [], 0
-            for l in range(n_levels):
-                s = int(self.scalings[l].item())
-                res.append(s)
-                c = torch.arange(0, s + 1, device=dev, dtype=torch.int64)
-                x = (c & mask32)[None, None, :]
-                y = ((c * self.PRIME_Y) & mask32)[None, :, None]
-                z = ((c * self.PRIME_Z) & mask32)[:, None, None]
-                row = ((x ^ y ^ z) & maskT).reshape(-1)  # point id = x + side * (y + side * z): x fastest
-                order = torch.argsort(row, stable=True)
-                uniq, counts = torch.unique_consecutive(row[order], return_counts=True)
-                rows.append(uniq + (l << T))
-                pts.append(order)
-                start.append(base + torch.cumsum(counts, 0))
-                base += int(order.numel())
-            cache[n_levels] = (torch.tensor(res, dtype=torch.int32), torch.cat(rows).to(torch.int32).contiguous(),
-                               torch.cat(start).to(torch.int32).contiguous(), torch.cat(pts).to(torch.int32).contiguous())
-        return cache[n_levels]
-
     @property
     def spec(self) -> Tuple[torch.Tensor, int, int, int]:
         return (self.scalings, self.n_levels, self.n_features_per_level, self.log2_hashmap_size)

@@ -975,89 +975,6 @@ def test_x_pair_records_equal_single_records(N, L, T, clustered):
     assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb) and torch.equal(ga, gb)
 
 
-@pytest.mark.parametrize("N,L,T,base,growth,clustered", [(524288, 16, 19, 16, 1.3819, True), (262144, 5, 17, 16, 1.6818, True),
-                                                          (50000, 6, 19, 16, 1.3819, False)])
-def test_dense_coarse_levels_equal_the_sorted_path(N, L, T, base, growth, clustered):
-    """snf_hashgrid_bwd_dense (reachable-row levels accumulated per LATTICE POINT in LDS, no sort, rows stepped from a static list)
-    + the x-pair sort / backward on the remaining levels, against the x-pair path over all levels followed by snf_adam_step_rows on
-    the reachable rows (what the step did before): same fixed-point scale, same per-contribution rounding, integer sums -- table
-    gradient, parameters and both moments equal BIT FOR BIT.  Positions include exact 0 / 1 and lattice-aligned coordinates; one
-    gradient row carries inf / NaN (the element becomes NaN on both paths)."""
-    from samnerf_amd import tcnn_compat
-    m = ops()
-    F = 2
-    enc = tcnn_compat.Encoding(3, {"otype": "HashGrid", "n_levels": L, "n_features_per_level": F, "log2_hashmap_size": T,
-                                   "base_resolution": base, "per_level_scale": growth}, device=DEV)
-    ns, active = enc.active_rows()
-    assert 0 < ns < L
-    g = torch.Generator(device=DEV).manual_seed(N + T)
-    if clustered:
-        o = torch.rand((N // 64 + 1, 1, 3), device=DEV, generator=g)
-        d = torch.randn((N // 64 + 1, 1, 3), device=DEV, generator=g) * 0.2
-        t = torch.linspace(0, 1, 64, device=DEV).view(1, 64, 1)
-        u = (o + d * t).reshape(-1, 3)[:N].remainder(1.0).contiguous()
-    else:
-        u = torch.rand((N, 3), device=DEV, generator=g)
-    u[:7] = torch.tensor([[0, 0, 0], [1, 1, 1], [0.5, 0.25, 1.0], [0, 1, 0.375], [1.0, 0.0, 0.0], [0.0625, 0.125, 0.1875],
-                          [0.99999994, 0.5, 0.5]], device=DEV)
-    sc = enc.scalings
-    grad = torch.randn((L, N, F), device=DEV, generator=g)  # level-major staged gradient
-    grad[1, 11, 0], grad[ns, 12, 1], grad[0, 13, 1] = float("inf"), float("nan"), float("-inf")
-    st = m._stream()
-    lib = m._L()
-    n = (L << T) * F
-    nrun = m.hashgrid_run_levels(sc)
-    res, rows, start, pts = enc.lattice_lists(ns)
-    assert set(rows.tolist()) <= set(active.tolist())
-    nbd = int(lib.snf_hashgrid_bwd_dense_workspace_bytes(res.data_ptr(), ns, F))
-    wsd = torch.empty(((nbd + 7) // 8,), device=DEV, dtype=torch.int64)
-    nb_all = int(lib.snf_hashgrid_bwd_workspace_bytes(N, L, T))
-    nb_fine = int(lib.snf_hashgrid_bwd_workspace_bytes(N, L - ns, T))
-    ws_all = torch.zeros(((nb_all + 3) // 4,), device=DEV, dtype=torch.int32)
-    ws_fine = torch.zeros(((nb_fine + 3) // 4,), device=DEV, dtype=torch.int32)
-    m._launch("snf_hashgrid_sort_xp", m._p(u), m._p(sc), N, L, T, m._p(ws_all), nb_all, st)
-    sc_fine = sc[ns:].contiguous()
-    m._launch("snf_hashgrid_sort_xp", m._p(u), m._p(sc_fine), N, L - ns, T, m._p(ws_fine), nb_fine, st)
-    off_g, off_t = ns * N * F * 4, (ns << T) * F * 4
-    nrun_fine = m.hashgrid_run_levels(sc_fine)
-    # ---- gradient only
-    ga, gb = torch.zeros((n,), device=DEV), torch.zeros((n,), device=DEV)
-    m._launch("snf_hashgrid_bwd_presorted_adam_xp", m._p(grad), N, L, T, 0, 0, nrun, m._p(ga), m._p(ws_all), None, L, None, None, None,
-              0.0, 0.9, 0.999, 1e-15, 1, 1.0, st)
-    m._launch("snf_hashgrid_bwd_dense", m._p(u), m._p(grad), res.data_ptr(), N, ns, F, T, m._p(gb), m._p(rows), m._p(start), m._p(pts),
-              int(rows.numel()), m._p(wsd), nbd, None, None, None, 0.0, 0.9, 0.999, 1e-15, 1, 1.0, st)
-    m._launch("snf_hashgrid_bwd_presorted_adam_xp", m._p(grad) + off_g, N, L - ns, T, 0, 0, nrun_fine, m._p(gb) + off_t, m._p(ws_fine),
-              None, L - ns, None, None, None, 0.0, 0.9, 0.999, 1e-15, 1, 1.0, st)
-    torch.cuda.synchronize()
-    nan_a, nan_b = torch.isnan(ga), torch.isnan(gb)
-    assert torch.equal(nan_a, nan_b) and int(nan_a.sum()) >= 3
-    assert torch.equal(torch.nan_to_num(ga), torch.nan_to_num(gb))
-    assert float(torch.nan_to_num(ga).abs().max()) > 0
-    # ---- with the optimizer: levels >= ns stepped in the reduce pass; the reachable rows by snf_adam_step_rows (before) / by the
-    # dense launch (now).  Moments start non-zero only where a lattice point can land (elsewhere they are zero for the whole run)
-    pa = torch.randn((n,), device=DEV, generator=g) * 1e-2
-    ma, va = torch.randn((n,), device=DEV, generator=g) * 1e-3, torch.rand((n,), device=DEV, generator=g) * 1e-6
-    keep = torch.zeros((n // F,), device=DEV, dtype=torch.bool)
-    keep[rows.long().to(DEV)] = True
-    keep[(ns << T):] = True
-    ma, va = (ma.view(-1, F) * keep[:, None]).reshape(-1).contiguous(), (va.view(-1, F) * keep[:, None]).reshape(-1).contiguous()
-    pb, mb, vb = pa.clone(), ma.clone(), va.clone()
-    grad[1, 11, 0], grad[ns, 12, 1], grad[0, 13, 1] = 0.25, -0.5, 0.125  # (finite again: NaN parameters compare unequal)
-    ga.zero_(); gb.zero_()
-    hyp = (1e-2, 0.9, 0.999, 1e-15, 3, 1.0 / 128)
-    m._launch("snf_hashgrid_bwd_presorted_adam_xp", m._p(grad), N, L, T, 0, 0, nrun, m._p(ga), m._p(ws_all), None, ns, m._p(pa), m._p(ma),
-              m._p(va), *hyp, st)
-    arows = (active * F).to(torch.int32).to(DEV).contiguous()  # (element offsets of the rows)
-    m._launch("snf_adam_step_rows", m._p(pa), m._p(ga), m._p(ma), m._p(va), m._p(arows), int(arows.numel()), F, *hyp, 1, st)
-    m._launch("snf_hashgrid_bwd_dense", m._p(u), m._p(grad), res.data_ptr(), N, ns, F, T, m._p(gb), m._p(rows), m._p(start), m._p(pts),
-              int(rows.numel()), m._p(wsd), nbd, m._p(pb), m._p(mb), m._p(vb), *hyp, st)
-    m._launch("snf_hashgrid_bwd_presorted_adam_xp", m._p(grad) + off_g, N, L - ns, T, 0, 0, nrun_fine, m._p(gb) + off_t, m._p(ws_fine),
-              None, 0, m._p(pb) + off_t, m._p(mb) + off_t, m._p(vb) + off_t, *hyp, st)
-    torch.cuda.synchronize()
-    assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb)
-    assert float(ga.abs().max()) == 0.0 and float(gb.abs().max()) == 0.0  # (both paths leave the gradient table clean)
-
-
 @pytest.mark.parametrize("N,I,O,planar", [(65536, 192, 256, True), (65536, 256, 256, False), (65536, 256, 192, False),
                                           (9000, 64, 72, False), (16411, 200, 128, False)])
 def test_full_width_weight_gradient(N, I, O, planar):

@@ -5,29 +5,37 @@
             = the average fraction of the chip's matrix pipes that were busy while the kernel ran
 (SQ_VALU_MFMA_BUSY_CYCLES counts cycles per SIMD: 32 per v_mfma_f32_32x32x16_bf16, 64 per v_mfma_f32_32x32x2_f32;
 duration from the kernel trace at the nominal 2.4 GHz -- the clock under a profiler is lower, so this is a lower bound.)
-Writes profiles/r02_mfma_util.json (read by bench.py for `roofline_other_kernels[*].mfma_busy`)."""
+Writes profiles/r<NN>_mfma_util.json (bench.py reads the newest for `roofline_other_kernels[*].mfma_busy`)."""
 import collections, csv, glob, json, os, re, sys
 
-d = sys.argv[1]  # directory of the counter pass, or a summary .json written earlier
-out_path = sys.argv[2] if len(sys.argv) > 2 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
-                                                            "profiles", "r02_mfma_util.json")
+# usage: mfma_util.py <out.json> <dir> [<dir> ...]   (directories of counter passes: train step, render, encoder)
+#    or: mfma_util.py <dir | summary.json> [<out.json>]   (round-2 form)
+args = sys.argv[1:]
+if args and args[0].endswith(".json") and len(args) > 1 and os.path.isdir(args[1]):
+    out_path, dirs = args[0], args[1:]
+else:
+    dirs = [args[0]]
+    out_path = args[1] if len(args) > 1 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                           "profiles", "r02_mfma_util.json")
+d = dirs[0]
 CLK_GHZ, SIMDS = 2.4, 1024
 if d.endswith(".json"):  # an earlier summary of this script (the raw CSVs are not kept): only the entry-point table is rebuilt
     by_kernel = json.load(open(d))["by_kernel"]
 else:
-    cc = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)[0]
-    kt = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)[0]
-    dur = {}
-    for r in csv.DictReader(open(kt)):
-        dur[r["Dispatch_Id"]] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
-    for r in csv.DictReader(open(cc)):
-        name = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "").replace("snf::", "")
-        a = agg[name]
-        a[r["Counter_Name"]] += float(r["Counter_Value"])
-        if r["Counter_Name"] == "SQ_BUSY_CYCLES":
-            a["calls"] += 1
-            a["ns"] += dur.get(r["Dispatch_Id"], 0)
+    for d in dirs:
+        cc = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)[0]
+        kt = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)[0]
+        dur = {}
+        for r in csv.DictReader(open(kt)):
+            dur[r["Dispatch_Id"]] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+        for r in csv.DictReader(open(cc)):
+            name = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "").replace("snf::", "")
+            a = agg[name]
+            a[r["Counter_Name"]] += float(r["Counter_Value"])
+            if r["Counter_Name"] == "SQ_BUSY_CYCLES":
+                a["calls"] += 1
+                a["ns"] += dur.get(r["Dispatch_Id"], 0)
     by_kernel = {}
     for name, a in agg.items():
         if a.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) <= 0 or a["ns"] <= 0:
@@ -73,9 +81,13 @@ entry = {
     "snf_linear_bwd_weight/31x64": find("k_gemm_wgrad<true>"), "snf_linear_bwd_weight/32x64": find("k_gemm_wgrad<true>"),
     "snf_linear_bwd_weight/64x16": find("k_gemm_wgrad<true>"), "snf_linear_bwd_weight/64x3": find("k_gemm_wgrad<true>"),
     "snf_linear_fwd_ws/2304x256": find("k_gemm_rows_b3<true, false, 64>"),
+    # config #5: the render pass's fused grids -> first head layer, the encoder's token GEMMs and attention
+    "snf_grid_head_fused_fwd": find("k_grid_head_fused"),
+    "snf_gemm_planes": find("k_gemm_planes"),
+    "snf_attention_planes": find("k_attention_b3"),
 }
 res = {"source": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_{F32,BF16} SQ_BUSY_CYCLES --kernel-trace -- "
-                 "python bench.py --steps 6 --warmup 3 (tools/mfma_util.sh)",
+                 "python bench.py --steps 6 --warmup 3 | tools/bench_render.py | tools/bench_vit.py (tools/mfma_util.sh)",
        "definition": "mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (kernel ns x 2.4 GHz x 1024 SIMDs)",
        "by_kernel": dict(sorted(by_kernel.items(), key=lambda kv: -kv[1]["mfma_busy"])),
        "by_entry_point": {k: v for k, v in entry.items() if v is not None}}

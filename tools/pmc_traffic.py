@@ -27,12 +27,21 @@ def main():
     ap.add_argument("dir")
     ap.add_argument("--regex", default=r"k_hg_reduce<8, ?true>")
     ap.add_argument("--out", default=None)
+    ap.add_argument("--key", default=None, help="entry point of `roofline_other_kernels` instead of the dominant kernel "
+                                                "(e.g. snf_hashgrid_bwd_presorted_adam_xp/F2L16)")
     a = ap.parse_args()
     bench = json.loads(open(os.path.join(a.dir, "pmc_FETCH_SIZE.json")).read().strip().splitlines()[-1])
     roof = bench["roofline"]
     n = int(roof["launches_timed"])
-    f = counter(os.path.join(a.dir, "pmc_FETCH_SIZE", "pmc_counter_collection.csv"), a.regex)[-n:]
-    w = counter(os.path.join(a.dir, "pmc_WRITE_SIZE", "pmc_counter_collection.csv"), a.regex)[-n:]
+    if a.key:
+        roof = next(o for o in bench["roofline_other_kernels"] if o["kernel"] == a.key)
+    f = counter(os.path.join(a.dir, "pmc_FETCH_SIZE", "pmc_counter_collection.csv"), a.regex)
+    w = counter(os.path.join(a.dir, "pmc_WRITE_SIZE", "pmc_counter_collection.csv"), a.regex)
+    if a.key:  # (every launch of that instantiation has the step's shape -- warm-up, serial replay, timed steps: average over all)
+        n = min(len(f), len(w))
+        f, w = f[:n], w[:n]
+    else:
+        f, w = f[-n:], w[-n:]
     assert len(f) == n and len(w) == n, (len(f), len(w), n)
     read_b, write_b = 2.0 * sum(f) * 1024 / n, sum(w) * 1024 / n
     res = {"workload": bench["config"]["name"], "kernel": roof["kernel"], "launches": n,
