@@ -74,25 +74,21 @@ def first_collective_check(rank: int, world: int, backend: str) -> None:
     if got != float(world):
         raise RuntimeError(f"rank {rank}/{world}: first all-reduce returned {got}, expected {world} (ranks missing or doubled)")
     # The DEFAULT group's communicator is created lazily by its first collective, under the 30-minute job timeout: create it now,
-    # inside the start-up window, so a failure specific to that initialisation surfaces here too (every rank is known to be alive
-    # at this point -- the probe all-reduce just completed -- so a hang from here on is the communicator's, and is bounded by the
-    # wait below).  The probe group is then torn down instead of holding a second communicator's device buffers for the job.
+    # right behind the probe (every rank is known to be alive at this point -- the probe all-reduce just completed), so a failure
+    # specific to that initialisation surfaces at start-up with the facts below instead of inside the first train step.
     try:
         t.fill_(1.0)
-        work = dist.all_reduce(t, async_op=True)
-        if not work.wait(timeout=startup) and backend == "gloo":
-            raise RuntimeError("timed out")
+        dist.all_reduce(t)
         if dev != "cpu":
             torch.cuda.synchronize()
-        if float(t.item()) != float(world):
-            raise RuntimeError(f"returned {float(t.item())}, expected {world}")
+        got = float(t.item())
     except Exception as e:  # noqa: BLE001
         raise RuntimeError(f"rank {rank}/{world}: the first collective on the default {backend} group failed "
                            f"({type(e).__name__}: {e}) after the start-up probe on a temporary group had succeeded") from e
-    try:
-        dist.destroy_process_group(probe)
-    except Exception:  # noqa: BLE001  (older backends cannot destroy a sub-group: it stays idle)
-        pass
+    if got != float(world):
+        raise RuntimeError(f"rank {rank}/{world}: first all-reduce on the default group returned {got}, expected {world}")
+    # (the probe group stays: it is idle from here on -- one extra communicator's buffers -- because tearing a communicator down is
+    #  itself a collective on RCCL, and a rank that stalls in it would hang the job this check exists to protect)
 
 
 # -- collectives.  backend "nccl" (= RCCL): straight through.  backend "gloo" with device tensors (tests: two ranks sharing
