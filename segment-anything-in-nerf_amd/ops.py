@@ -52,7 +52,23 @@ STREAM_SLOTS = {"sam": 0, "clipseg": 1, "presort": 2, "wgrad:sam": 3, "wgrad:cli
 _STREAMS_MADE = {"n": 0, "filler": [], "names": {}}
 
 
+STREAM_CACHE = _os.environ.get("SNF_STREAM_CACHE", "1") == "1"
+
+
 def make_stream(name: str) -> "torch.cuda.Stream":
+    """The task stream called `name` on the current device.  One stream per (device, name) and process: a second trainer in the
+    same process (bench.py's other workloads, the second exchange mode of a multi-rank run) takes the FIRST trainer's streams
+    instead of fresh ones -- fresh streams land on other hardware queues, and a trainer built second ran its steps 15 % slower
+    (2.54 -> 2.92 ms, profiles/r04_experiments.txt)."""
+    key = (torch.cuda.current_device(), name)
+    if STREAM_CACHE and key in _STREAMS_MADE.setdefault("by_name", {}):
+        return _STREAMS_MADE["by_name"][key]
+    st = _make_stream(name)
+    _STREAMS_MADE.setdefault("by_name", {})[key] = st
+    return st
+
+
+def _make_stream(name: str) -> "torch.cuda.Stream":
     slot = STREAM_SLOTS.get(name)
     if slot is not None:
         while _STREAMS_MADE["n"] % 4 != slot % 4:

@@ -108,37 +108,35 @@ class ProposalNetworkSampler(Sampler):
         self._step = step
         self._steps_since_update += 1
 
+    def _proposal_round_gets_gradients(self) -> bool:
+        """The `updated` gate of ray_samplers.py:566: proposal densities are differentiated in the first ten steps and then
+        whenever more steps than `update_sched(step)` have passed since the last differentiated round."""
+        return self._step < 10 or self._steps_since_update > self.update_sched(self._step)
+
     def generate_ray_samples(self, ray_bundle: Optional[RayBundle] = None,
                              density_fns: Optional[List[Callable]] = None) -> Tuple[RaySamples, List, List]:
-        assert ray_bundle is not None and density_fns is not None
-        weights_list, ray_samples_list = [], []
-        n = self.num_proposal_network_iterations
-        weights, ray_samples = None, None
-        updated = self._steps_since_update > self.update_sched(self._step) or self._step < 10
+        """-> (fine samples, [weights of every proposal round], [samples of every proposal round]).  Round 0 draws from the
+        piecewise-uniform initial sampler; every later round -- and the final, fine draw -- resamples the previous round's weight
+        histogram (the anneal exponent of ray_samplers.py:583 is applied inside the PDF kernel)."""
+        if ray_bundle is None or density_fns is None:
+            raise ValueError("ray_bundle and density_fns must be provided")
+        rounds = self.num_proposal_network_iterations
+        with_grad = self._proposal_round_gets_gradients()
         if torch.is_grad_enabled():
-            # remembered for the trainer: on a non-update step the proposal parameters have NO gradient in the reference
-            # (grad is None), so torch.optim.Adam skips them entirely -- no moment decay, no step count
-            self.last_updated = bool(updated)
-        for i_level in range(n + 1):
-            is_prop = i_level < n
-            num_samples = self.num_proposal_samples_per_ray[i_level] if is_prop else self.num_nerf_samples_per_ray
-            if i_level == 0:
-                ray_samples = self.initial_sampler(ray_bundle, num_samples=num_samples)
-            else:
-                assert weights is not None
-                # anneal pow (ray_samplers.py:583) is folded into the PDF kernel
-                ray_samples = self.pdf_sampler(ray_bundle, ray_samples, weights, num_samples=num_samples,
-                                               anneal=self._anneal)
-            if is_prop:
-                if updated:
-                    density = density_fns[i_level](ray_samples)
-                else:
-                    with torch.no_grad():
-                        density = density_fns[i_level](ray_samples)
-                weights = ray_samples.get_weights(density)
-                weights_list.append(weights)
-                ray_samples_list.append(ray_samples)
-        if updated:
+            # remembered for the trainer: on a round without gradients the proposal parameters have NO gradient in the
+            # reference (grad is None / zero-filled, see Trainer.zero_grad_adam)
+            self.last_updated = bool(with_grad)
+        history_w: List[torch.Tensor] = []
+        history_s: List[RaySamples] = []
+        samples = self.initial_sampler(ray_bundle, num_samples=self.num_proposal_samples_per_ray[0])
+        for r in range(rounds):
+            with torch.enable_grad() if (with_grad and torch.is_grad_enabled()) else torch.no_grad():
+                density = density_fns[r](samples)
+            w = samples.get_weights(density)
+            history_w.append(w)
+            history_s.append(samples)
+            n_next = self.num_proposal_samples_per_ray[r + 1] if r + 1 < rounds else self.num_nerf_samples_per_ray
+            samples = self.pdf_sampler(ray_bundle, samples, w, num_samples=n_next, anneal=self._anneal)
+        if with_grad:
             self._steps_since_update = 0
-        assert ray_samples is not None
-        return ray_samples, weights_list, ray_samples_list
+        return samples, history_w, history_s

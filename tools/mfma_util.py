@@ -19,11 +19,14 @@ else:
                                                            "profiles", "r02_mfma_util.json")
 d = dirs[0]
 CLK_GHZ, SIMDS = 2.4, 1024
+by_source = {}
 if d.endswith(".json"):  # an earlier summary of this script (the raw CSVs are not kept): only the entry-point table is rebuilt
     by_kernel = json.load(open(d))["by_kernel"]
 else:
-    agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    # one table per counter pass (train step / render / encoder): the chains and GEMMs of the render pass share kernel names with the
+    # train step's but run on 8 x the samples per launch -- their busy fractions must not be averaged together
     for d in dirs:
+        agg = collections.defaultdict(lambda: collections.defaultdict(float))
         cc = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)[0]
         kt = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)[0]
         dur = {}
@@ -36,14 +39,21 @@ else:
             if r["Counter_Name"] == "SQ_BUSY_CYCLES":
                 a["calls"] += 1
                 a["ns"] += dur.get(r["Dispatch_Id"], 0)
-    by_kernel = {}
-    for name, a in agg.items():
-        if a.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) <= 0 or a["ns"] <= 0:
-            continue
-        by_kernel[name] = {"calls": int(a["calls"]), "avg_us": round(a["ns"] / a["calls"] / 1e3, 1),
-                           "mfma_busy": round(a["SQ_VALU_MFMA_BUSY_CYCLES"] / (a["ns"] * CLK_GHZ * SIMDS), 4),
-                           "mfma_mops_f32": a.get("SQ_INSTS_VALU_MFMA_MOPS_F32", 0.0),
-                           "mfma_mops_bf16": a.get("SQ_INSTS_VALU_MFMA_MOPS_BF16", 0.0)}
+        tab = {}
+        for name, a in agg.items():
+            if a.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) <= 0 or a["ns"] <= 0:
+                continue
+            tab[name] = {"calls": int(a["calls"]), "avg_us": round(a["ns"] / a["calls"] / 1e3, 1),
+                         "mfma_busy": round(a["SQ_VALU_MFMA_BUSY_CYCLES"] / (a["ns"] * CLK_GHZ * SIMDS), 4),
+                         "mfma_mops_f32": a.get("SQ_INSTS_VALU_MFMA_MOPS_F32", 0.0),
+                         "mfma_mops_bf16": a.get("SQ_INSTS_VALU_MFMA_MOPS_BF16", 0.0)}
+        by_source[os.path.basename(os.path.normpath(d))] = dict(sorted(tab.items(), key=lambda kv: -kv[1]["mfma_busy"]))
+    by_kernel = by_source.get("step") or next(iter(by_source.values()))  # the train step's table feeds the step's entry points
+
+
+def find_in(src, sub):
+    v = [x["mfma_busy"] for k, x in by_source.get(src, {}).items() if sub in k]
+    return max(v) if v else None
 
 
 def find(sub):
@@ -82,16 +92,19 @@ entry = {
     "snf_linear_bwd_weight/64x16": find("k_gemm_wgrad<true>"), "snf_linear_bwd_weight/64x3": find("k_gemm_wgrad<true>"),
     "snf_linear_fwd_ws/2304x256": find("k_gemm_rows_b3<true, false, 64>"),
     # config #5: the render pass's fused grids -> first head layer, the encoder's token GEMMs and attention
-    "snf_grid_head_fused_fwd": find("k_grid_head_fused"),
-    "snf_gemm_planes": find("k_gemm_planes"),
-    "snf_attention_planes": find("k_attention_b3"),
+    "snf_grid_head_fused_fwd": find_in("render", "k_grid_head_fused"),
+    "snf_gemm_planes": find_in("vit", "k_gemm_planes"),
+    "snf_attention_planes": find_in("vit", "k_attention_b3"),
 }
 res = {"source": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_{F32,BF16} SQ_BUSY_CYCLES --kernel-trace -- "
                  "python bench.py --steps 6 --warmup 3 | tools/bench_render.py | tools/bench_vit.py (tools/mfma_util.sh)",
        "definition": "mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (kernel ns x 2.4 GHz x 1024 SIMDs)",
        "by_kernel": dict(sorted(by_kernel.items(), key=lambda kv: -kv[1]["mfma_busy"])),
+       "by_source": by_source,
        "by_entry_point": {k: v for k, v in entry.items() if v is not None}}
 json.dump(res, open(out_path, "w"), indent=1)
-for k, v in res["by_kernel"].items():
-    print(f"{k[:90]:90s} calls {v['calls']:4d}  avg {v['avg_us']:8.1f} us  mfma_busy {v['mfma_busy']:.3f}")
+for src, tab in (by_source or {"": res["by_kernel"]}).items():
+    print(f"--- {src}")
+    for k, v in tab.items():
+        print(f"{k[:90]:90s} calls {v['calls']:4d}  avg {v['avg_us']:8.1f} us  mfma_busy {v['mfma_busy']:.3f}")
 print("wrote", out_path)
