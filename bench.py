@@ -46,6 +46,7 @@ def mfma_peak(key: str, gemm_mode: int = 1):
     count -- not the fp32-matrix peak (`snf_linear_bwd_data_rows` "0.84 of 157 TFLOP/s" was 0.16 of its
     own 833)."""
     name, _, tag = key.partition("/")
+    name = name[:-3] if name.endswith("_sh") else name  # (the colour net with its input row formed in the loader: same arithmetic)
     if gemm_mode >= 1 and name.startswith("snf_linear"):
         dims = [int(x) for x in re.sub(r"[a-z]+$", "", tag).split("x")] if tag else []
         if dims and max(dims) >= 64:  # (the narrow layers -- proposal net -- stay on the fp32 matrix cores)
@@ -64,6 +65,7 @@ def algorithmic_model(key: str, w: dict):
     (8 corners x F floats x 4 B per level per sample; backward = read-modify-write)."""
     R, P, S, K = w["R"], w["P"], w["S"], w["K"]
     name, _, tag = key.partition("/")
+    name = name[:-3] if name.endswith("_sh") else name
     if name == "snf_hashgrid_bwd_presorted_adam_pair":  # both F = 8 grids of a head in one launch ("F8L12+12"); the launch site
         m = re.fullmatch(r"F8L(\d+)\+(\d+)", tag)        # reports its own bytes (gathers + 24 B per fused parameter)
         return ("hbm", float(R * K * (int(m.group(1)) + int(m.group(2))) * 8 * 8 * 4 * 2), "GB/s") if m else (None, None, None)
@@ -529,8 +531,9 @@ def main():
                    "launches_timed": nl, "algorithmic_units_per_launch": total_units / max(nl, 1), "measured": where}
             if bound != "hbm":
                 out["peak_basis"] = basis
-            if key in mu:  # matrix-core busy cycles / shader busy cycles of this entry point's kernels (rocprofv3 PMC pass)
-                out["mfma_busy"] = mu[key]
+            mkey = key.replace("_sh/", "/")
+            if mkey in mu:  # matrix-core busy cycles / shader busy cycles of this entry point's kernels (rocprofv3 PMC pass)
+                out["mfma_busy"] = mu[mkey]
             return out
 
         def pmc_traffic(key):

@@ -310,6 +310,21 @@ int snf_mlp64_bwd_fused(const float* dY, int lddy, int dy_col_off, const float* 
                         int out_act, int64_t N, const float* H1, const float* H2, float* dX, int lddx, float* dW0, float* dW1,
                         float* dWout, void* workspace, int64_t workspace_bytes, snf_stream_t stream);
 
+/* The colour net (fields/nerfacto_field.py:336-351: `h = cat([SH16(d), geo])` -> mlp_head) with its input row FORMED in the
+ * kernel's loader instead of read: features 0..15 = the degree-4 spherical harmonics of the sample's ray direction (utils/math.py:
+ * 27-73, the arithmetic of snf_head_input bit for bit), features 16..30 = columns 1..15 of the base net's output row base_out
+ * [R*S, ld_base >= 16].  The [N, 32] input tensor of snf_head_input + snf_mlp64_fwd is never written.  gemm mode 1; n_geo = 15.
+ * snf_mlp64_bwd_fused_sh is the matching recomputing backward (H1 = H2 = NULL semantics of snf_mlp64_bwd_fused): dY [N, lddy]
+ * (columns 0 .. out-1), and only the gradient that has a consumer leaves -- d_geo [N, ld_dgeo >= 16], column j = d(feature 16 + j)
+ * (the base net's backward then reads it as its output gradient with dy_col_off = -1). */
+int snf_mlp64_fwd_sh(const float* dirs, int R, int S, const float* base_out, int ld_base, int n_geo, const float* W0,
+                     const float* W1, const float* Wout, int n_hidden, int out, int out_act, float* H1, float* H2, float* Y,
+                     int ldy, snf_stream_t stream);
+int snf_mlp64_bwd_fused_sh(const float* dY, int lddy, const float* Y, int ldy, const float* dirs, int R, int S,
+                           const float* base_out, int ld_base, int n_geo, const float* W0, const float* W1, const float* Wout,
+                           int n_hidden, int out, int out_act, float* d_geo, int ld_dgeo, float* dW0, float* dW1, float* dWout,
+                           void* workspace, int64_t workspace_bytes, snf_stream_t stream);
+
 /* ---- a13: SH degree-4 basis of the raw unit direction (nerfstudio/utils/math.py:27-73) written to
  *      the first 16 columns of the colour-MLP input, with the geo features copied behind it
  *      (torch.cat of fields/nerfacto_field.py:336-343).  dirs [R,3]; geo points at h[:,1] of the

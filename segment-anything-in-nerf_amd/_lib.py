@@ -113,6 +113,8 @@ SIGNATURES = {
     "snf_mlp64_fwd": [P, I, P, I, P, P, I, I, I, c_int64, P, P, P, I, P],
     "snf_mlp64_bwd_data": [P, I, I, P, P, I, P, I, P, P, I, I, I, c_int64, P, P, P, P, P, I, P, I, P],
     "snf_mlp64_bwd_fused": [P, I, I, P, P, I, P, I, P, I, P, P, I, I, I, c_int64, P, P, P, I, P, P, P, P, c_int64, P],
+    "snf_mlp64_fwd_sh": [P, I, I, P, I, I, P, P, P, I, I, I, P, P, P, I, P],
+    "snf_mlp64_bwd_fused_sh": [P, I, P, I, P, I, I, P, I, I, P, P, P, I, I, I, P, I, P, P, P, P, c_int64, P],
     "snf_head_input": [P, P, I, I, I, I, P, I, P],
     "snf_weights_fwd": [P, I, I, P, P, I, I, P, P, P],
     "snf_weights_bwd": [P, I, I, P, P, P, I, I, P, P],

@@ -29,6 +29,30 @@ void set_error(const char* fmt, ...);
 
 constexpr int WAVE = 64;
 
+// Degree-4 real spherical harmonics of a direction (nerfstudio/utils/math.py:27-73 `components_from_spherical_harmonics`, levels = 4).
+// One definition for every kernel that needs it (snf_head_input, the colour net's fused loaders), evaluated WITHOUT FMA contraction:
+// the torch reference rounds every product and sum separately, and all kernels then agree bit for bit.
+__device__ __forceinline__ void sh16_of(float x, float y, float z, float (&o)[16]) {
+#pragma clang fp contract(off)
+    const float xx = x * x, yy = y * y, zz = z * z;
+    o[0] = 0.28209479177387814f;
+    o[1] = 0.4886025119029199f * y;
+    o[2] = 0.4886025119029199f * z;
+    o[3] = 0.4886025119029199f * x;
+    o[4] = 1.0925484305920792f * x * y;
+    o[5] = 1.0925484305920792f * y * z;
+    o[6] = 0.9461746957575601f * zz - 0.31539156525251999f;
+    o[7] = 1.0925484305920792f * x * z;
+    o[8] = 0.5462742152960396f * (xx - yy);
+    o[9] = 0.5900435899266435f * y * (3.f * xx - yy);
+    o[10] = 2.890611442640554f * x * y * z;
+    o[11] = 0.4570457994644658f * y * (5.f * zz - 1.f);
+    o[12] = 0.3731763325901154f * z * (5.f * zz - 3.f);
+    o[13] = 0.4570457994644658f * x * (5.f * zz - 1.f);
+    o[14] = 1.445305721320277f * z * (xx - yy);
+    o[15] = 0.5900435899266435f * x * (xx - 3.f * yy);
+}
+
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
 
 // inclusive prefix sum across the 64 lanes of a wavefront

@@ -433,7 +433,39 @@ constexpr int chain_b3_lds_elems(int NH, int planes = 2) {  // bf16 elements, al
     return planes * (MC_H * MC_BP32 + (NH == 2 ? MC_H * MC_BP64 : 0) + 32 * MC_BP64);
 }
 
-template <int NH, int PLANES = 2>
+// SH: the colour net's input row is FORMED in the loader instead of read -- features 0..15 the degree-4 spherical harmonics of the
+// sample's ray direction, features 16..16+n_geo-1 columns 1.. of the base net's output row (nerfacto_field.py:336-343: `h = cat(d, geo)`)
+// -- so the [N, 32] tensor snf_head_input writes (67 MB per train step, 537 MB per 32 768-ray render chunk: 8 % of a render's kernel
+// time for the write alone) never exists.  X / ldx are then the base net's output and its row length.
+struct ChainSh {
+    const float* dirs;  // [R, 3]
+    int S;              // samples per ray: sample n belongs to ray n / S
+};
+
+// this lane's half of a formed input row: half 0 = the 16 harmonics of the ray's direction, half 1 = columns 1 .. 15 of the base
+// net's output row (16 floats, read as four aligned 16-byte loads) and a zero
+__device__ __forceinline__ void chain_sh_row(const float* __restrict__ Hb, int ldh, const ChainSh& sh, long long s, int half,
+                                             f32x16& xo) {
+    if (half == 0) {
+        const long long r = s / sh.S;
+        float o[16];
+        sh16_of(sh.dirs[r * 3 + 0], sh.dirs[r * 3 + 1], sh.dirs[r * 3 + 2], o);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) xo[i] = o[i];
+    } else {
+        float c[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 v = *reinterpret_cast<const float4*>(Hb + s * ldh + 4 * q);
+            c[4 * q] = v.x; c[4 * q + 1] = v.y; c[4 * q + 2] = v.z; c[4 * q + 3] = v.w;
+        }
+#pragma unroll
+        for (int i = 0; i < 15; ++i) xo[i] = c[i + 1];
+        xo[15] = 0.f;
+    }
+}
+
+template <int NH, int PLANES = 2, bool SH = false>
 // SNF_CHAIN_FWD_WAVES=2 (<= 256 registers): the two-hidden-layer six-product chain then spills 156 B per lane -- alone 0.079 ->
 // 0.073 ms, but +53 MB of scratch traffic per step (PMC, r02k) in a step that is pinned by its HBM-bound kernels: not the default
 #define SNF_CHAIN_FWD_WAVES 1
@@ -441,7 +473,7 @@ __global__ __launch_bounds__(256, SNF_CHAIN_FWD_WAVES) void k_mlp_chain_fwd_b3(c
                                                           int in_real, const float* __restrict__ W1,
                                                           const float* __restrict__ Wout, int out, int out_act, long long N,
                                                           float* __restrict__ H1, float* __restrict__ H2,
-                                                          float* __restrict__ Y, int ldy) {
+                                                          float* __restrict__ Y, int ldy, ChainSh sh = ChainSh{nullptr, 1}) {
     extern __shared__ __attribute__((aligned(16))) uint16_t ldsb[];
     constexpr int SZ0 = MC_H * MC_BP32, SZ1 = (NH == 2 ? MC_H * MC_BP64 : 0), SZO = 32 * MC_BP64;
     uint16_t* p0h = ldsb;                          // W0  [64][MC_BP32]  LIN slots over the 32 inputs
@@ -471,7 +503,9 @@ __global__ __launch_bounds__(256, SNF_CHAIN_FWD_WAVES) void k_mlp_chain_fwd_b3(c
     auto load_x = [&](long long tile_, f32x16& xo) {
         const long long s_ = tile_ * 32 + li;
         const long long sc_ = s_ < N ? s_ : N - 1;
-        if (ldx == 0) {
+        if constexpr (SH) {
+            chain_sh_row(X, ldx, sh, sc_, half, xo);
+        } else if (ldx == 0) {
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const float2 v = *reinterpret_cast<const float2*>(X + ((long long)(half * 8 + q) * N + sc_) * 2);
@@ -488,12 +522,14 @@ __global__ __launch_bounds__(256, SNF_CHAIN_FWD_WAVES) void k_mlp_chain_fwd_b3(c
     const long long tstride = (long long)gridDim.x * 4;
     long long tile0 = (long long)blockIdx.x * 4 + wave;
     f32x16 xn;
-    if ((SNF_CHAIN_PREFETCH & 1) && tile0 < ntiles) load_x(tile0, xn);
+    // (the two-hidden-layer chain with a FORMED input row has no 16 registers left for the row a tile ahead: 16 spills)
+    constexpr bool PF = (SNF_CHAIN_PREFETCH & 1) && !(SH && NH == 2);
+    if (PF && tile0 < ntiles) load_x(tile0, xn);
     for (long long tile = tile0; tile < ntiles; tile += tstride) {
         const long long s = tile * 32 + li;
         const bool ok = s < N;
         f32x16 x[1];
-        if (SNF_CHAIN_PREFETCH & 1) {
+        if (PF) {
             x[0] = xn;
             if (tile + tstride < ntiles) load_x(tile + tstride, xn);
         } else {
@@ -703,7 +739,7 @@ constexpr int wg_partial_floats(int NH) { return 32 * 64 + (NH == 2 ? 64 * 64 : 
 // needed itself) rather than keeping 32 more registers alive.
 constexpr int wg_rc_lds_elems(int NH) { return 3 * (MC_H * MC_BP32 + (NH == 2 ? MC_H * MC_BP64 : 0)); }
 
-template <int NH, bool RC = false>
+template <int NH, bool RC = false, bool SH = false>
 // one hidden layer: 2 waves per SIMD = 252 registers instead of 280, no spills -- a workgroup then fits beside one workgroup of
 // the table reduce on a CU (co-residency); alone 0.129 -> 0.126 ms
 #define SNF_WG_WAVES_NH1 2
@@ -714,7 +750,8 @@ __global__ __launch_bounds__(WG_T) __attribute__((amdgpu_waves_per_eu(NH == 1 ? 
                                                            const float* __restrict__ W1, const float* __restrict__ Wout,
                                                            int out, int out_act, long long N, const float* __restrict__ H1,
                                                            const float* __restrict__ H2, float* __restrict__ dX, int lddx,
-                                                           float* __restrict__ P) {
+                                                           float* __restrict__ P, ChainSh sh = ChainSh{nullptr, 1}) {
+    static_assert(!SH || RC, "the formed input row (SH) goes with the recomputing backward");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     ChainWeights cw;
     load_chain_weights<NH>(lds, cw, W0, in_real, W1, Wout, out);
@@ -749,7 +786,9 @@ __global__ __launch_bounds__(WG_T) __attribute__((amdgpu_waves_per_eu(NH == 1 ? 
     auto load_x = [&](long long tile_, f32x16& xo) {
         const long long s_ = tile_ * 32 + li;
         const long long sc_ = s_ < N ? s_ : N - 1;
-        if (ldx == 0) {
+        if constexpr (SH) {
+            chain_sh_row(X, ldx, sh, sc_, half, xo);
+        } else if (ldx == 0) {
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const float2 v = *reinterpret_cast<const float2*>(X + ((long long)(half * 8 + q) * N + sc_) * 2);
@@ -935,7 +974,14 @@ __global__ __launch_bounds__(WG_T) __attribute__((amdgpu_waves_per_eu(NH == 1 ? 
                     dx = __builtin_amdgcn_mfma_f32_32x32x2f32(cw.w0[(t * 32 + krow(r, half)) * MC_P0 + li], dl[t][r], dx, 0,
                                                               0, 0);
             if (ok) {
-                if (lddx == 0) {
+                if constexpr (SH) {
+                    // only the base net's share of the input has a consumer (the harmonics depend on the ray direction alone): the
+                    // gradient of features 16 .. 31 goes out as a compact [N, lddx >= 16] row, column j = feature 16 + j
+#pragma unroll
+                    for (int q = 2; q < 4; ++q)
+                        *reinterpret_cast<float4*>(dX + s * lddx + 8 * q + 4 * half - 16) =
+                            make_float4(dx[4 * q], dx[4 * q + 1], dx[4 * q + 2], dx[4 * q + 3]);
+                } else if (lddx == 0) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const long long lv = 4 * q + 2 * half;
@@ -1095,6 +1141,40 @@ static int chain_common_checks(const char* who, int in_real, int n_hidden, int o
     return SNF_OK;
 }
 
+// the colour net with its input row formed in the loader (ChainSh): X = the base net's output [N, ldx >= 16], in_real = 16 + n_geo
+static int chain_fwd_sh(const float* dirs, int R, int S, const float* Hb, int ldh, int n_geo, const float* W0, const float* W1,
+                        const float* Wout, int n_hidden, int out, int out_act, float* H1, float* H2, float* Y, int ldy,
+                        snf_stream_t stream) {
+    const long long N = (long long)R * S;
+    int rc = chain_common_checks("snf_mlp64_fwd_sh", 16 + n_geo, n_hidden, out, N);
+    if (rc) return rc;
+    SNF_REQUIRE(dirs && Hb && W0 && Wout && Y && (n_hidden == 1 || W1), "snf_mlp64_fwd_sh: null pointer");
+    SNF_REQUIRE(R > 0 && S > 0 && n_geo == 15 && ldh >= 16 && ldh % 4 == 0 && ((uintptr_t)Hb % 16) == 0,
+                "snf_mlp64_fwd_sh: the base net's output must be [N, ldh >= 16] (ldh %% 4 == 0, 16-byte aligned) with the 15 geo "
+                "features in columns 1 .. 15 (got n_geo=%d ldh=%d)", n_geo, ldh);
+    SNF_REQUIRE(snf_get_gemm_mode() == 1, "snf_mlp64_fwd_sh: gemm mode 1 only (the six-product forward chain)");
+    SNF_REQUIRE(ldy >= out, "snf_mlp64_fwd_sh: ldy < out");
+    SNF_REQUIRE((!H1 || ((uintptr_t)H1 % 16) == 0) && (!H2 || ((uintptr_t)H2 % 16) == 0), "snf_mlp64_fwd_sh: unaligned H");
+    const long long ntiles = (N + 31) / 32;
+    long long blocks = (ntiles + 3) / 4;
+    if (blocks > 256 * 4) blocks = 256 * 4;
+    const ChainSh sh{dirs, S};
+    if (n_hidden == 2)
+        hipLaunchKernelGGL((k_mlp_chain_fwd_b3<2, 3, true>), dim3((unsigned)blocks), dim3(256), chain_b3_lds_elems(2, 3) * sizeof(uint16_t),
+                           (hipStream_t)stream, Hb, ldh, W0, 16 + n_geo, W1, Wout, out, out_act, N, H1, H2, Y, ldy, sh);
+    else
+        hipLaunchKernelGGL((k_mlp_chain_fwd_b3<1, 3, true>), dim3((unsigned)blocks), dim3(256), chain_b3_lds_elems(1, 3) * sizeof(uint16_t),
+                           (hipStream_t)stream, Hb, ldh, W0, 16 + n_geo, W1, Wout, out, out_act, N, H1, H2, Y, ldy, sh);
+    SNF_LAUNCH_CHECK("snf_mlp64_fwd_sh");
+    return SNF_OK;
+}
+
+extern "C" int snf_mlp64_fwd_sh(const float* dirs, int R, int S, const float* base_out, int ld_base, int n_geo, const float* W0,
+                                const float* W1, const float* Wout, int n_hidden, int out, int out_act, float* H1, float* H2,
+                                float* Y, int ldy, snf_stream_t stream) {
+    return chain_fwd_sh(dirs, R, S, base_out, ld_base, n_geo, W0, W1, Wout, n_hidden, out, out_act, H1, H2, Y, ldy, stream);
+}
+
 extern "C" int snf_mlp64_fwd(const float* X, int ldx, const float* W0, int in_real, const float* W1, const float* Wout,
                              int n_hidden, int out, int out_act, int64_t N, float* H1, float* H2, float* Y, int ldy,
                              snf_stream_t stream) {
@@ -1114,17 +1194,17 @@ extern "C" int snf_mlp64_fwd(const float* X, int ldx, const float* W0, int in_re
     if (chain_b3_on()) {
         if (n_hidden == 2)
             hipLaunchKernelGGL(k_mlp_chain_fwd_b3<2>, dim3((unsigned)blocks), dim3(256), chain_b3_lds_elems(2) * sizeof(uint16_t),
-                               (hipStream_t)stream, X, ldx, W0, in_real, W1, Wout, out, out_act, (long long)N, H1, H2, Y, ldy);
+                               (hipStream_t)stream, X, ldx, W0, in_real, W1, Wout, out, out_act, (long long)N, H1, H2, Y, ldy, ChainSh{nullptr, 1});
         else
             hipLaunchKernelGGL(k_mlp_chain_fwd_b3<1>, dim3((unsigned)blocks), dim3(256), chain_b3_lds_elems(1) * sizeof(uint16_t),
-                               (hipStream_t)stream, X, ldx, W0, in_real, W1, Wout, out, out_act, (long long)N, H1, H2, Y, ldy);
+                               (hipStream_t)stream, X, ldx, W0, in_real, W1, Wout, out, out_act, (long long)N, H1, H2, Y, ldy, ChainSh{nullptr, 1});
     } else if (x6 && snf_get_gemm_mode() == 1) {
         if (n_hidden == 2)
             hipLaunchKernelGGL((k_mlp_chain_fwd_b3<2, 3>), dim3((unsigned)blocks), dim3(256), chain_b3_lds_elems(2, 3) * sizeof(uint16_t),
-                               (hipStream_t)stream, X, ldx, W0, in_real, W1, Wout, out, out_act, (long long)N, H1, H2, Y, ldy);
+                               (hipStream_t)stream, X, ldx, W0, in_real, W1, Wout, out, out_act, (long long)N, H1, H2, Y, ldy, ChainSh{nullptr, 1});
         else
             hipLaunchKernelGGL((k_mlp_chain_fwd_b3<1, 3>), dim3((unsigned)blocks), dim3(256), chain_b3_lds_elems(1, 3) * sizeof(uint16_t),
-                               (hipStream_t)stream, X, ldx, W0, in_real, W1, Wout, out, out_act, (long long)N, H1, H2, Y, ldy);
+                               (hipStream_t)stream, X, ldx, W0, in_real, W1, Wout, out, out_act, (long long)N, H1, H2, Y, ldy, ChainSh{nullptr, 1});
     } else if (n_hidden == 2)
         hipLaunchKernelGGL(k_mlp_chain_fwd<2>, dim3((unsigned)blocks), dim3(256), chain_lds_floats(2) * sizeof(float),
                            (hipStream_t)stream, X, ldx, W0, in_real, W1, Wout, out, out_act, (long long)N, H1, H2, Y, ldy);
@@ -1178,13 +1258,45 @@ extern "C" int64_t snf_mlp64_bwd_fused_workspace_bytes(int n_hidden) {
     return (int64_t)256 * wg_partial_floats(n_hidden) * (int64_t)sizeof(float);
 }
 
+static int chain_bwd_fused(const float* dY, int lddy, int dy_col_off, const float* dY0, const float* Y, int ldy,
+                           const float* X, int ldx, const float* W0, int in_real, const float* W1, const float* Wout,
+                           int n_hidden, int out, int out_act, int64_t N, const float* H1, const float* H2, float* dX,
+                           int lddx, float* dW0, float* dW1, float* dWout, void* workspace, int64_t workspace_bytes,
+                           snf_stream_t stream, const float* sh_dirs, int sh_S);
+
 extern "C" int snf_mlp64_bwd_fused(const float* dY, int lddy, int dy_col_off, const float* dY0, const float* Y, int ldy,
                                    const float* X, int ldx, const float* W0, int in_real, const float* W1, const float* Wout,
                                    int n_hidden, int out, int out_act, int64_t N, const float* H1, const float* H2, float* dX,
                                    int lddx, float* dW0, float* dW1, float* dWout, void* workspace, int64_t workspace_bytes,
                                    snf_stream_t stream) {
+    return chain_bwd_fused(dY, lddy, dy_col_off, dY0, Y, ldy, X, ldx, W0, in_real, W1, Wout, n_hidden, out, out_act, N, H1, H2, dX, lddx,
+                           dW0, dW1, dWout, workspace, workspace_bytes, stream, nullptr, 1);
+}
+
+extern "C" int snf_mlp64_bwd_fused_sh(const float* dY, int lddy, const float* Y, int ldy, const float* dirs, int R, int S,
+                                      const float* base_out, int ld_base, int n_geo, const float* W0, const float* W1,
+                                      const float* Wout, int n_hidden, int out, int out_act, float* d_geo, int ld_dgeo, float* dW0,
+                                      float* dW1, float* dWout, void* workspace, int64_t workspace_bytes, snf_stream_t stream) {
+    SNF_REQUIRE(dirs && base_out && R > 0 && S > 0 && n_geo == 15 && ld_base >= 16 && ld_base % 4 == 0 && ((uintptr_t)base_out % 16) == 0,
+                "snf_mlp64_bwd_fused_sh: the base net's output must be [N, ld >= 16] (ld %% 4 == 0, aligned), geo in columns 1 .. 15");
+    SNF_REQUIRE(!d_geo || (ld_dgeo >= 16 && ld_dgeo % 4 == 0 && ((uintptr_t)d_geo % 16) == 0),
+                "snf_mlp64_bwd_fused_sh: d_geo must be [N, ld >= 16] (ld %% 4 == 0, 16-byte aligned)");
+    // (ldx / lddx are passed as 32 to satisfy the shared checks; the SH kernels use ld_base / ld_dgeo through X's and dX's own strides)
+    return chain_bwd_fused(dY, lddy, 0, nullptr, Y, ldy, base_out, -ld_base, W0, 16 + n_geo, W1, Wout, n_hidden, out, out_act,
+                           (int64_t)R * S, nullptr, nullptr, d_geo, -ld_dgeo, dW0, dW1, dWout, workspace, workspace_bytes, stream, dirs, S);
+}
+
+static int chain_bwd_fused(const float* dY, int lddy, int dy_col_off, const float* dY0, const float* Y, int ldy,
+                           const float* X, int ldx, const float* W0, int in_real, const float* W1, const float* Wout,
+                           int n_hidden, int out, int out_act, int64_t N, const float* H1, const float* H2, float* dX,
+                           int lddx, float* dW0, float* dW1, float* dWout, void* workspace, int64_t workspace_bytes,
+                           snf_stream_t stream, const float* sh_dirs, int sh_S) {
     int rc = chain_common_checks("snf_mlp64_bwd_fused", in_real, n_hidden, out, N);
     if (rc) return rc;
+    if (sh_dirs != nullptr) {  // (formed input row: the strides arrive negated so that the row-major checks below do not apply)
+        ldx = -ldx;
+        lddx = -lddx;
+    }
     const bool recompute = H1 == nullptr;  // the hidden activations are formed again from X (six-product forward arithmetic)
     SNF_REQUIRE(dY && X && W0 && Wout && dW0 && dWout && workspace && (n_hidden == 1 || (W1 && dW1 && (recompute || H2))),
                 "snf_mlp64_bwd_fused: null pointer");
@@ -1192,9 +1304,9 @@ extern "C" int snf_mlp64_bwd_fused(const float* dY, int lddy, int dy_col_off, co
                 "snf_mlp64_bwd_fused: H1 = NULL (recompute) needs H2 = NULL and gemm mode 1 (the forward whose arithmetic it repeats)");
     SNF_REQUIRE(out_act != SNF_ACT_SIGMOID || Y, "snf_mlp64_bwd_fused: Y required for the sigmoid derivative");
     SNF_REQUIRE(out_act != SNF_ACT_RELU, "snf_mlp64_bwd_fused: ReLU output activation is not supported");
-    SNF_REQUIRE((ldx == 0 || (ldx >= MC_IN && ldx % 4 == 0)) && ((uintptr_t)X % 16) == 0,
+    SNF_REQUIRE(sh_dirs || ((ldx == 0 || (ldx >= MC_IN && ldx % 4 == 0)) && ((uintptr_t)X % 16) == 0),
                 "snf_mlp64_bwd_fused: X must be [N, ldx>=32] (ldx %% 4 == 0) or level-major (ldx = 0), 16-byte aligned");
-    SNF_REQUIRE(!dX || ((lddx == 0 || (lddx >= MC_IN && lddx % 4 == 0)) && ((uintptr_t)dX % 16) == 0),
+    SNF_REQUIRE(sh_dirs || !dX || ((lddx == 0 || (lddx >= MC_IN && lddx % 4 == 0)) && ((uintptr_t)dX % 16) == 0),
                 "snf_mlp64_bwd_fused: bad dX layout");
     SNF_REQUIRE((!H1 || ((uintptr_t)H1 % 16) == 0) && (!H2 || ((uintptr_t)H2 % 16) == 0) && ((uintptr_t)workspace % 16) == 0,
                 "snf_mlp64_bwd_fused: unaligned H1 / H2 / workspace");
@@ -1212,9 +1324,24 @@ extern "C" int snf_mlp64_bwd_fused(const float* dY, int lddy, int dy_col_off, co
             attr = true;
         }
         hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(WG_T), lds, st, dY, lddy, dy_col_off, dY0, Y, ldy, X, ldx, W0, in_real,
-                           W1, Wout, out, out_act, (long long)N, H1, H2, dX, lddx, P);
+                           W1, Wout, out, out_act, (long long)N, H1, H2, dX, lddx, P, ChainSh{nullptr, 1});
     };
     static bool a20 = false, a21 = false, a10 = false, a11 = false;
+    if (sh_dirs != nullptr) {
+        // the input row formed in the loader (recompute only): X = the base net's output, dX = the compact gradient of its geo columns
+        const ChainSh sh{sh_dirs, sh_S};
+        static bool s2 = false, s1 = false;
+        auto launch_sh = [&](auto kern, bool& attr) {
+            if (!attr) {
+                hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                attr = true;
+            }
+            hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(WG_T), lds, st, dY, lddy, dy_col_off, dY0, Y, ldy, X, ldx, W0, in_real,
+                               W1, Wout, out, out_act, (long long)N, H1, H2, dX, lddx, P, sh);
+        };
+        if (n_hidden == 2) launch_sh(k_mlp_chain_bwd_wg<2, true, true>, s2);
+        else launch_sh(k_mlp_chain_bwd_wg<1, true, true>, s1);
+    } else
     if (n_hidden == 2 && recompute) launch(k_mlp_chain_bwd_wg<2, true>, a21);
     else if (n_hidden == 2) launch(k_mlp_chain_bwd_wg<2, false>, a20);
     else if (recompute) launch(k_mlp_chain_bwd_wg<1, true>, a11);

@@ -17,25 +17,11 @@ __global__ __launch_bounds__(256) void k_head_input(const float* __restrict__ di
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (long long)R * S) return;
     const int r = (int)(t / S);
-    const float x = dirs[r * 3 + 0], y = dirs[r * 3 + 1], z = dirs[r * 3 + 2];
-    const float xx = x * x, yy = y * y, zz = z * z;
+    float sh[16];
+    sh16_of(dirs[r * 3 + 0], dirs[r * 3 + 1], dirs[r * 3 + 2], sh);
     float* o = out + (size_t)t * ld_out;
-    o[0] = 0.28209479177387814f;
-    o[1] = 0.4886025119029199f * y;
-    o[2] = 0.4886025119029199f * z;
-    o[3] = 0.4886025119029199f * x;
-    o[4] = 1.0925484305920792f * x * y;
-    o[5] = 1.0925484305920792f * y * z;
-    o[6] = 0.9461746957575601f * zz - 0.31539156525251999f;
-    o[7] = 1.0925484305920792f * x * z;
-    o[8] = 0.5462742152960396f * (xx - yy);
-    o[9] = 0.5900435899266435f * y * (3.f * xx - yy);
-    o[10] = 2.890611442640554f * x * y * z;
-    o[11] = 0.4570457994644658f * y * (5.f * zz - 1.f);
-    o[12] = 0.3731763325901154f * z * (5.f * zz - 3.f);
-    o[13] = 0.4570457994644658f * x * (5.f * zz - 1.f);
-    o[14] = 1.445305721320277f * z * (xx - yy);
-    o[15] = 0.5900435899266435f * x * (xx - 3.f * yy);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) o[j] = sh[j];
     const float* g = geo + (size_t)t * ld_geo;
     for (int j = 0; j < n_geo; ++j) o[16 + j] = g[j];
     for (int j = 16 + n_geo; j < ld_out; ++j) o[j] = 0.f;  // pad columns (e.g. 31 -> 32 for the fused MLP)
@@ -53,19 +39,10 @@ __global__ __launch_bounds__(256) void k_head_input32(const float* __restrict__ 
     float4 v;
     if (c < 4) {
         const int r = (int)(s / S);
-        const float x = dirs[r * 3 + 0], y = dirs[r * 3 + 1], z = dirs[r * 3 + 2];
-        const float xx = x * x, yy = y * y, zz = z * z;
-        if (c == 0)
-            v = make_float4(0.28209479177387814f, 0.4886025119029199f * y, 0.4886025119029199f * z, 0.4886025119029199f * x);
-        else if (c == 1)
-            v = make_float4(1.0925484305920792f * x * y, 1.0925484305920792f * y * z,
-                            0.9461746957575601f * zz - 0.31539156525251999f, 1.0925484305920792f * x * z);
-        else if (c == 2)
-            v = make_float4(0.5462742152960396f * (xx - yy), 0.5900435899266435f * y * (3.f * xx - yy),
-                            2.890611442640554f * x * y * z, 0.4570457994644658f * y * (5.f * zz - 1.f));
-        else
-            v = make_float4(0.3731763325901154f * z * (5.f * zz - 3.f), 0.4570457994644658f * x * (5.f * zz - 1.f),
-                            1.445305721320277f * z * (xx - yy), 0.5900435899266435f * x * (xx - 3.f * yy));
+        float sh[16];
+        sh16_of(dirs[r * 3 + 0], dirs[r * 3 + 1], dirs[r * 3 + 2], sh);
+        v = c == 0 ? make_float4(sh[0], sh[1], sh[2], sh[3]) : c == 1 ? make_float4(sh[4], sh[5], sh[6], sh[7])
+            : c == 2 ? make_float4(sh[8], sh[9], sh[10], sh[11]) : make_float4(sh[12], sh[13], sh[14], sh[15]);
     } else {
         const float* g = geo + (size_t)s * ld_geo;
         const int j = (c - 4) * 4;

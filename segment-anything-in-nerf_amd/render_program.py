@@ -39,6 +39,7 @@ FUSED_GRID_HEAD = True  # feature passes: grids + first head layer + mean in one
 # feature passes take the selected samples of their rays from pass 1 instead of sampling them again (SNF_RENDER_REUSE_PASS1=0: as the
 # reference does, every pass samples its own rays)
 REUSE_PASS1 = _os.environ.get("SNF_RENDER_REUSE_PASS1", "1") == "1"
+FUSED_SH_INPUT = _os.environ.get("SNF_FUSED_SH_INPUT", "1") == "1"  # colour net input cat(SH16(d), geo) formed in its loader
 
 
 class _Dyn:
@@ -186,10 +187,14 @@ class RenderProgram:
         outputs: Dict[str, int] = {}
         if mode == "rgb":
             n_geo = C - 1
-            x2 = b("x2", (N1, 32))
-            k("snf_head_input", d_, h.data_ptr() + 4, R, S, n_geo, C, x2, 32)
             rgb = b("rgb", (N1, 3))
-            k("snf_mlp64_fwd", x2, 32, hw0, 16 + n_geo, hw1, hw2, 2, 3, ops.ACT_SIGMOID, N1, None, None, rgb, 3)
+            if FUSED_SH_INPUT and int(self.lib.snf_get_gemm_mode()) == 1 and n_geo == 15 and C % 4 == 0:
+                # the colour net forms cat(SH16(d), geo) in its loader: the [N, 32] input (537 MB per 32 768-ray chunk) is never written
+                k("snf_mlp64_fwd_sh", d_, R, S, h, C, n_geo, hw0, hw1, hw2, 2, 3, ops.ACT_SIGMOID, None, None, rgb, 3)
+            else:
+                x2 = b("x2", (N1, 32))
+                k("snf_head_input", d_, h.data_ptr() + 4, R, S, n_geo, C, x2, 32)
+                k("snf_mlp64_fwd", x2, 32, hw0, 16 + n_geo, hw1, hw2, 2, 3, ops.ACT_SIGMOID, N1, None, None, rgb, 3)
             k("snf_composite_fwd", rgb, w1, None, R, S, 0, _Dyn("out:rgb"), None, None)
             outputs["rgb"] = 3
             if fast:
@@ -335,7 +340,7 @@ class RenderProgram:
         self._stream, self._sig = st, sig
 
     def _plan(self, kind: str, R: int, mode: str, fast: bool):
-        key = (kind, R, mode, bool(fast), int(self.lib.snf_get_gemm_mode()), bool(FUSED_GRID_HEAD))
+        key = (kind, R, mode, bool(fast), int(self.lib.snf_get_gemm_mode()), bool(FUSED_GRID_HEAD), bool(FUSED_SH_INPUT))
         plan = self.plans.get(key)
         if plan is None:
             plan = self.plans[key] = self._build(R, mode, bool(fast)) if kind == "full" else self._build_heads(R, mode)

@@ -84,6 +84,10 @@ XPAIR_RECORDS = True
 # Many ranks: the gradient exchange + optimizer of the replicated groups recorded into the schedule (collectives as list entries, Adam
 # as recorded launches) instead of `Optimizers.exchange_and_step` enqueueing its ~15 torch / C-ABI calls per group eagerly each step
 RECORD_EXCHANGE = True
+# The colour net's input row cat(SH16(d), geo) (nerfacto_field.py:336-343) formed inside its forward / recomputing backward
+# (snf_mlp64_fwd_sh / snf_mlp64_bwd_fused_sh) instead of written by snf_head_input and read back twice; the backward writes the
+# geo columns' gradient only ([N, 16] instead of [N, 32]).  Needs the recomputing fused backward (gemm mode 1).
+FUSED_SH_INPUT = _os.environ.get("SNF_FUSED_SH_INPUT", "1") == "1"
 
 
 # SNF_ABLATE_SKIP="key,key": launches whose key contains one of these are NOT issued (results are garbage; timing probe only)
@@ -568,12 +572,18 @@ class StepProgram:
                 tag=f"{FL * FF}x64x{C}")
         density1 = b("density1", (N1,))
         self._k(main, "snf_trunc_exp_fwd", h, C, sel1, N1, density1)
-        x2 = b("x2", (N1, 32))
         n_geo = C - 1
-        self._k(main, "snf_head_input", d, self._off(h, 4), R, S, n_geo, C, x2, 32)
+        sh_in = bool(FUSED_SH_INPUT and rc and FUSED_CHAIN_WGRAD and n_geo == 15 and C % 4 == 0)
         hh1, hh2, rgb = (None if rc else b("hh1", (N1, 64))), (None if rc else b("hh2", (N1, 64))), b("rgb", (N1, 3))
-        self._k(main, "snf_mlp64_fwd", x2, 32, hw0, 16 + n_geo, hw1, hw2, 2, 3, ops.ACT_SIGMOID, N1, hh1, hh2, rgb, 3,
-                tag=f"{16 + n_geo}x64x64x3")
+        if sh_in:
+            x2 = None
+            self._k(main, "snf_mlp64_fwd_sh", d, R, S, h, C, n_geo, hw0, hw1, hw2, 2, 3, ops.ACT_SIGMOID, None, None, rgb, 3,
+                    tag=f"{16 + n_geo}x64x64x3")
+        else:
+            x2 = b("x2", (N1, 32))
+            self._k(main, "snf_head_input", d, self._off(h, 4), R, S, n_geo, C, x2, 32)
+            self._k(main, "snf_mlp64_fwd", x2, 32, hw0, 16 + n_geo, hw1, hw2, 2, 3, ops.ACT_SIGMOID, N1, hh1, hh2, rgb, 3,
+                    tag=f"{16 + n_geo}x64x64x3")
         w1 = b("w1", (R, S))
         self._k(main, "snf_weights_fwd", density1, 1, 1, None, eb1, R, S, w1, None)
         out_rgb, depth, acc, pdepth = b("out_rgb", (R, 3)), b("out_depth", (R, 1)), b("out_acc", (R, 1)), b("out_pdepth", (R, 1))
@@ -655,13 +665,24 @@ class StepProgram:
         self._k(main, "snf_add_scaled", N1, float(cfg.distortion_loss_mult), gw_d, gw)
         gd1 = b("gd1", (N1,))
         self._k(main, "snf_weights_bwd", density1, 1, 1, None, eb1, gw, R, S, gd1)
-        dx2 = b("dx2", (N1, 32))
-        self._mlp64_bwd(main, x2, 32, 16 + n_geo, (hw0, hw1, hw2), ops.ACT_SIGMOID, rgb, hh1, hh2, grgb, 3, 0, None, dx2, 32,
-                        N1, "hd_")
+        if sh_in:
+            # the colour net's backward forms its input row again (harmonics + geo columns of h) and writes d(geo) only, [N, 16]:
+            # the base net reads it as the gradient of its output columns 1 .. 15 (dy_col_off = -1; column 0 comes from graw)
+            dgeo = b("dgeo", (N1, 16))
+            nbw = int(self.lib.snf_mlp64_bwd_fused_workspace_bytes(2))
+            wsb = self.buf("hd_wgrad_ws", (nbw // 4,))
+            self._k(main, "snf_mlp64_bwd_fused_sh", grgb, 3, rgb, 3, d, R, S, h, C, n_geo, hw0, hw1, hw2, 2, 3, ops.ACT_SIGMOID, dgeo,
+                    16, hw0.main_grad, hw1.main_grad, hw2.main_grad, wsb, nbw, tag=f"{16 + n_geo}x64x64x3")
+            dyb, lddyb, offb = dgeo, 16, -1
+        else:
+            dx2 = b("dx2", (N1, 32))
+            self._mlp64_bwd(main, x2, 32, 16 + n_geo, (hw0, hw1, hw2), ops.ACT_SIGMOID, rgb, hh1, hh2, grgb, 3, 0, None, dx2, 32,
+                            N1, "hd_")
+            dyb, lddyb, offb = dx2, 32, 15
         graw = b("graw", (N1,))
         self._k(main, "snf_trunc_exp_bwd", h, C, sel1, gd1, N1, graw, 1)
         denc1 = b("denc1", (FL * FF * N1,))
-        self._mlp64_bwd(main, enc1, 0, FL * FF, (bw0, bw1), ops.ACT_NONE, None, hb1, None, dx2, 32, 15, graw, denc1, 0, N1,
+        self._mlp64_bwd(main, enc1, 0, FL * FF, (bw0, bw1), ops.ACT_NONE, None, hb1, None, dyb, lddyb, offb, graw, denc1, 0, N1,
                         "bs_")
         if sort_st.stream_id != main.stream_id:
             self._py(main.wait_event, self.event("field_sorted"))

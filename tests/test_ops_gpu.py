@@ -924,6 +924,47 @@ def test_level_major_feature_grids_feed_the_table_backward():
         assert maxdiff(a, bq) <= 2e-6 * float(a.abs().max())  # (fp32 sums inside a row depend on the LDS ranking order)
 
 
+@pytest.mark.parametrize("R,S", [(512, 128), (37, 48)])
+def test_colour_net_with_its_input_row_formed_in_the_loader(R, S):
+    """snf_mlp64_fwd_sh / snf_mlp64_bwd_fused_sh (fields/nerfacto_field.py:336-351 with cat(SH16(d), geo) formed inside the kernels)
+    against snf_head_input + snf_mlp64_fwd + the recomputing snf_mlp64_bwd_fused on the written [N, 32] input: the same bits --
+    colours, every weight gradient, and the geo columns of the input gradient (the harmonics' columns have no consumer)."""
+    m = ops()
+    m.set_gemm_mode("bf16x3")
+    N, C, n_geo = R * S, 16, 15
+    g = torch.Generator(device=DEV).manual_seed(R + S)
+    dirs = torch.nn.functional.normalize(torch.randn((R, 3), device=DEV, generator=g), dim=-1).contiguous()
+    h = torch.randn((N, C), device=DEV, generator=g)
+    ws = [torch.randn((64, 31), device=DEV, generator=g) / 31 ** 0.5, torch.randn((64, 64), device=DEV, generator=g) / 8.0,
+          torch.randn((3, 64), device=DEV, generator=g) / 8.0]
+    st = m._stream()
+    x2 = torch.empty((N, 32), device=DEV)
+    m._launch("snf_head_input", m._p(dirs), m._p(h) + 4, R, S, n_geo, C, m._p(x2), 32, st)
+    ya, yb = torch.empty((N, 3), device=DEV), torch.empty((N, 3), device=DEV)
+    m._launch("snf_mlp64_fwd", m._p(x2), 32, m._p(ws[0]), 31, m._p(ws[1]), m._p(ws[2]), 2, 3, m.ACT_SIGMOID, N, None, None, m._p(ya), 3, st)
+    m._launch("snf_mlp64_fwd_sh", m._p(dirs), R, S, m._p(h), C, n_geo, m._p(ws[0]), m._p(ws[1]), m._p(ws[2]), 2, 3, m.ACT_SIGMOID, None,
+              None, m._p(yb), 3, st)
+    torch.cuda.synchronize()
+    assert torch.equal(ya, yb)
+    # the harmonics against the fp64 formula of utils/math.py:27-73 (what snf_head_input wrote)
+    assert float((x2[:, 0] - 0.28209479177387814).abs().max()) == 0.0
+    dy = torch.randn((N, 3), device=DEV, generator=g)
+    nb = int(m._L().snf_mlp64_bwd_fused_workspace_bytes(2))
+    wsb = torch.empty((nb // 4,), device=DEV)
+    ga, gb = [torch.full_like(w, 0.25) for w in ws], [torch.full_like(w, 0.25) for w in ws]
+    dx2 = torch.empty((N, 32), device=DEV)
+    dgeo = torch.full((N, 16), 9.0, device=DEV)
+    m._launch("snf_mlp64_bwd_fused", m._p(dy), 3, 0, None, m._p(ya), 3, m._p(x2), 32, m._p(ws[0]), 31, m._p(ws[1]), m._p(ws[2]), 2, 3,
+              m.ACT_SIGMOID, N, None, None, m._p(dx2), 32, m._p(ga[0]), m._p(ga[1]), m._p(ga[2]), m._p(wsb), nb, st)
+    m._launch("snf_mlp64_bwd_fused_sh", m._p(dy), 3, m._p(yb), 3, m._p(dirs), R, S, m._p(h), C, n_geo, m._p(ws[0]), m._p(ws[1]),
+              m._p(ws[2]), 2, 3, m.ACT_SIGMOID, m._p(dgeo), 16, m._p(gb[0]), m._p(gb[1]), m._p(gb[2]), m._p(wsb), nb, st)
+    torch.cuda.synchronize()
+    assert torch.equal(dgeo, dx2[:, 16:32])
+    for a_, b_ in zip(ga, gb):
+        assert torch.equal(a_, b_)
+    assert float(dgeo[:, :15].abs().max()) > 0
+
+
 @pytest.mark.parametrize("N,L,T,clustered", [(524288, 16, 19, True), (262144, 5, 17, True), (70002, 6, 19, False), (600000, 2, 19, False),
                                              (778, 3, 6, False), (4096, 4, 12, True)])
 def test_x_pair_records_equal_single_records(N, L, T, clustered):
