@@ -22,8 +22,8 @@ namespace snf {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-// bit 0: the forward chain requests the next tile's input row a tile ahead; bits 1 / 2 (off: they spill, see k_mlp_chain_bwd_wg):
-// the fused backward's input row / output gradients
+// bit 0: the forward chain requests the next tile's input row a tile ahead; bit 1 (off): the two-hidden-layer fused backward its input
+// row and output gradients -- measured 0.169 -> 0.176 ms: with the input row formed in the loader the row a tile ahead spills 16 registers
 #ifndef SNF_CHAIN_PREFETCH
 #define SNF_CHAIN_PREFETCH 1
 #endif
@@ -737,6 +737,13 @@ constexpr int wg_partial_floats(int NH) { return 32 * 64 + (NH == 2 ? 64 * 64 : 
 // the weight-gradient operands are the forward's), and the forward does not have to write them: 0.4 GB less written and 0.4 GB
 // less read per step for the two field nets.  The two-hidden-layer net forms H1 twice (once on the way to H2, once when it is
 // needed itself) rather than keeping 32 more registers alive.
+#ifndef SNF_WG_DGRAD_B3
+#define SNF_WG_DGRAD_B3 1
+#endif
+// weights of the data-gradient chain in LDS (floats): transposed bf16 hi / lo planes (DG3) or the fp32 matrices
+constexpr int wg_weight_lds_floats(int NH) {
+    return (SNF_WG_DGRAD_B3 && NH == 2) ? (MC_H * MC_BP32 + MC_H * MC_BP64 + 32 * MC_BP64) : chain_lds_floats(NH);
+}
 constexpr int wg_rc_lds_elems(int NH) { return 3 * (MC_H * MC_BP32 + (NH == 2 ? MC_H * MC_BP64 : 0)); }
 
 template <int NH, bool RC = false, bool SH = false>
@@ -753,11 +760,32 @@ __global__ __launch_bounds__(WG_T) __attribute__((amdgpu_waves_per_eu(NH == 1 ? 
                                                            float* __restrict__ P, ChainSh sh = ChainSh{nullptr, 1}) {
     static_assert(!SH || RC, "the formed input row (SH) goes with the recomputing backward");
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    // Data-gradient chain on the bf16 matrix cores with the 3-term split (SNF_WG_DGRAD_B3, round 4): the transposed weights as hi / lo
+    // planes with the accumulator layout's k permutation (as k_mlp_chain_bwd_b3 stages them), 48 v_mfma_f32_32x32x16_bf16 per tile
+    // instead of 100 v_mfma_f32_32x32x2_f32 (1536 against 6400 matrix cycles for the colour net) and two ds_read_b128 per k-step
+    // instead of one ds_read_b32 per instruction.  The gradients' consumers (the weight gradients below, the table backward) already
+    // work on 3-term products.  0: the fp32 chain.
+    // (two hidden layers only: with one hidden layer and up to 16 outputs the fp32 chain is 48 short instructions, and the split's
+    //  registers cost the kernel its second wave per SIMD -- measured 0.123 -> 0.134 ms for the base net, 0.224 -> 0.168 for the colour net)
+    constexpr bool DG3 = SNF_WG_DGRAD_B3 != 0 && NH == 2;
     ChainWeights cw;
-    load_chain_weights<NH>(lds, cw, W0, in_real, W1, Wout, out);
+    uint16_t* poh = reinterpret_cast<uint16_t*>(lds);      // Wout^T [64 hidden][MC_BP32]  LIN slots over the (<= 32) outputs
+    uint16_t* pol = poh + MC_H * MC_BP32;
+    uint16_t* p1h = pol + MC_H * MC_BP32;                  // W1^T   [64][MC_BP64]  (NH == 2)
+    uint16_t* p1l = p1h + (NH == 2 ? MC_H * MC_BP64 : 0);
+    uint16_t* p0h = p1l + (NH == 2 ? MC_H * MC_BP64 : 0);  // W0^T   [32 inputs][MC_BP64], rows >= in_real zero
+    uint16_t* p0l = p0h + 32 * MC_BP64;
+    if constexpr (DG3) {
+        mc_stage<true>(poh, pol, MC_BP32, MC_H, 32, [&](int k_, int o) { return o < out ? Wout[o * MC_H + k_] : 0.f; });
+        if constexpr (NH == 2) mc_stage<false>(p1h, p1l, MC_BP64, MC_H, MC_H, [&](int k1, int k2) { return W1[k2 * MC_H + k1]; });
+        mc_stage<false>(p0h, p0l, MC_BP64, 32, MC_H, [&](int i, int k1) { return i < in_real ? W0[k1 * in_real + i] : 0.f; });
+        __syncthreads();
+    } else {
+        load_chain_weights<NH>(lds, cw, W0, in_real, W1, Wout, out);
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 31, half = lane >> 5;
-    float* __restrict__ stage_all = lds + chain_lds_floats(NH);           // [WG_WAVES][WG_STAGE]
+    float* __restrict__ stage_all = lds + wg_weight_lds_floats(NH);       // [WG_WAVES][WG_STAGE]
     float* __restrict__ T = stage_all + wave * WG_STAGE;
     float* __restrict__ Z = stage_all + WG_WAVES * WG_STAGE + wave * WG_DZ;  // dZ^T, rows >= out stay zero
     for (int i = lane; i < WG_DZ; i += 64) Z[i] = 0.f;
@@ -802,52 +830,54 @@ __global__ __launch_bounds__(WG_T) __attribute__((amdgpu_waves_per_eu(NH == 1 ? 
             }
         }
     };
-    constexpr int MAXST = 2;  // output-gradient values a lane may prefetch (hsteps <= 2: out <= 4, the colour net; wider outputs load in place)
-    auto load_dz = [&](long long tile_, float (&dzo)[MAXST]) {
+    const long long tstride = (long long)gridDim.x * WG_WAVES;
+    const long long tile0 = (long long)blockIdx.x * WG_WAVES + wave;
+    // The wave is alone on its SIMD: the NEXT tile's input row and (nets with <= 4 outputs: the colour net) output gradients are
+    // requested while this tile is worked on.  Affordable since the data-gradient chain left the fp32 matrix instruction (428 of 512
+    // registers instead of 491; before, the 16-register row spilled 48).
+    constexpr bool PFB = RC && NH == 2 && DG3 && (SNF_CHAIN_PREFETCH & 2) != 0;
+    const bool pfz = PFB && outp <= 4;
+    auto dz_raw = [&](long long tile_, int o) {  // pre-activation output gradient of sample (tile_, li), output o
         const long long s_ = tile_ * 32 + li;
         const bool ok_ = s_ < N;
         const long long sc_ = ok_ ? s_ : N - 1;
-#pragma unroll
-        for (int st = 0; st < MAXST; ++st) {
-            const int o = half * hsteps + st;
-            float dz = 0.f;
-            if (st < hsteps && o < out && ok_) {  // rows beyond N contribute nothing to the weight gradients
-                dz = (o == 0 && dY0 != nullptr) ? dY0[sc_] : dY[sc_ * lddy + dy_col_off + o];
-                if (out_act == SNF_ACT_SIGMOID) {
-                    const float yv = Yout[sc_ * ldy + o];
-                    dz *= yv * (1.f - yv);
-                }
+        float dz = 0.f;
+        if (o < out && ok_) {  // rows beyond N contribute nothing to the weight gradients
+            dz = (o == 0 && dY0 != nullptr) ? dY0[sc_] : dY[sc_ * lddy + dy_col_off + o];
+            if (out_act == SNF_ACT_SIGMOID) {
+                const float yv = Yout[sc_ * ldy + o];
+                dz *= yv * (1.f - yv);
             }
-            dzo[st] = dz;
         }
+        return dz;
     };
-    // (the register file decides what can be requested a tile ahead: the two-hidden-layer net, alone on its SIMD with 491 of 512
-    //  registers in use, has room for its output gradients but not for the 16-register input row (48 spills); the one-hidden-layer
-    //  net runs two waves per SIMD at 252 registers, which hide each other's loads)
-    const bool pfx = (SNF_CHAIN_PREFETCH & 2) && RC && NH == 2;
-    const bool pfz = (SNF_CHAIN_PREFETCH & 4) && RC && NH == 2 && hsteps <= MAXST;
-    const bool pf = pfz;
-    const long long tstride = (long long)gridDim.x * WG_WAVES;
-    const long long tile0 = (long long)blockIdx.x * WG_WAVES + wave;
     f32x16 xn;
-    float dzn[MAXST];
-    if (pfx && tile0 < ntiles) load_x(tile0, xn);
-    if (pfz && tile0 < ntiles) load_dz(tile0, dzn);
+    float dzn[4] = {0.f, 0.f, 0.f, 0.f};
+    if (PFB && tile0 < ntiles) {
+        load_x(tile0, xn);
+        if (pfz && half == 0) {
+#pragma unroll
+            for (int o = 0; o < 4; ++o) dzn[o] = dz_raw(tile0, o);
+        }
+    }
     for (long long tile = tile0; tile < ntiles; tile += tstride) {
         const long long s = tile * 32 + li;
         const bool ok = s < N;
         const long long sc = ok ? s : N - 1;
         f32x16 xr[1];  // RC: this lane's half of the input row (features half*16 .. +15), pad columns zero as in the forward
-        float dzc[MAXST];
+        float dzc[4] = {0.f, 0.f, 0.f, 0.f};
         if constexpr (RC) {
-            if (pfz) {
-#pragma unroll
-                for (int st = 0; st < MAXST; ++st) dzc[st] = dzn[st];
-                if (tile + tstride < ntiles) load_dz(tile + tstride, dzn);
-            }
-            if (pfx) {
+            if (PFB) {
                 xr[0] = xn;
-                if (tile + tstride < ntiles) load_x(tile + tstride, xn);
+#pragma unroll
+                for (int o = 0; o < 4; ++o) dzc[o] = dzn[o];
+                if (tile + tstride < ntiles) {
+                    load_x(tile + tstride, xn);
+                    if (pfz && half == 0) {
+#pragma unroll
+                        for (int o = 0; o < 4; ++o) dzn[o] = dz_raw(tile + tstride, o);
+                    }
+                }
             } else {
                 load_x(tile, xr[0]);
             }
@@ -864,29 +894,27 @@ __global__ __launch_bounds__(WG_T) __attribute__((amdgpu_waves_per_eu(NH == 1 ? 
         };
         // ---- dZ, dLast^T[k][s] = sum_o Wout[o][k] dZ^T[o][s]; dZ^T goes to its LDS matrix on the way
         f32x16 dl[2] = {zero16(), zero16()};
-        auto dz_step = [&](int st, float dz) {
-            const int o = half * hsteps + st;
-            if (o < 32) Z[o * WG_TP + li] = dz;
-            const int oc = o < 32 ? o : 31;
-            dl[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(cw.wo[oc * MC_P1 + li], dz, dl[0], 0, 0, 0);
-            dl[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(cw.wo[oc * MC_P1 + 32 + li], dz, dl[1], 0, 0, 0);
-        };
-        if (pf) {
+        auto dz_of = [&](int o) { return dz_raw(tile, o); };
+        if constexpr (DG3) {
+            f32x16 dzv[1];  // this lane's 16 outputs o = half * 16 + i (LIN k slots)
 #pragma unroll
-            for (int st = 0; st < MAXST; ++st)  // (unrolled: dzc stays in registers)
-                if (st < hsteps) dz_step(st, dzc[st]);
+            for (int i = 0; i < 16; ++i) {
+                const int o = half * 16 + i;
+                dzv[0][i] = 0.f;
+                if (o < outp) {
+                    dzv[0][i] = (pfz && i < 4) ? (half == 0 ? dzc[i < 4 ? i : 0] : 0.f) : dz_of(o);
+                    Z[o * WG_TP + li] = dzv[0][i];
+                }
+            }
+            mc_layer_b3<1, 2, true>(poh, pol, MC_BP32, dzv, dl, li, half);
         } else {
             for (int st = 0; st < hsteps; ++st) {
                 const int o = half * hsteps + st;
-                float dz = 0.f;
-                if (o < out && ok) {  // rows beyond N contribute nothing to the weight gradients
-                    dz = (o == 0 && dY0 != nullptr) ? dY0[sc] : dY[sc * lddy + dy_col_off + o];
-                    if (out_act == SNF_ACT_SIGMOID) {
-                        const float yv = Yout[sc * ldy + o];
-                        dz *= yv * (1.f - yv);
-                    }
-                }
-                dz_step(st, dz);
+                const float dz = dz_of(o);
+                if (o < 32) Z[o * WG_TP + li] = dz;
+                const int oc = o < 32 ? o : 31;
+                dl[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(cw.wo[oc * MC_P1 + li], dz, dl[0], 0, 0, 0);
+                dl[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(cw.wo[oc * MC_P1 + 32 + li], dz, dl[1], 0, 0, 0);
             }
         }
         WG_LDS_ORDER();
@@ -927,15 +955,19 @@ __global__ __launch_bounds__(WG_T) __attribute__((amdgpu_waves_per_eu(NH == 1 ? 
         if constexpr (NH == 2) {
             // dH1^T[k1][s] = sum_k2 W1[k2][k1] dH2^T[k2][s]
             f32x16 d1[2] = {zero16(), zero16()};
+            if constexpr (DG3) {
+                mc_layer_b3<2, 2, false>(p1h, p1l, MC_BP64, dl, d1, li, half);
+            } else {
 #pragma unroll
-            for (int u = 0; u < 2; ++u)
+                for (int u = 0; u < 2; ++u)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int k2 = u * 32 + krow(r, half);
-                    const float b = dl[u][r];
-                    d1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(cw.w1[k2 * MC_P1 + li], b, d1[0], 0, 0, 0);
-                    d1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(cw.w1[k2 * MC_P1 + 32 + li], b, d1[1], 0, 0, 0);
-                }
+                    for (int r = 0; r < 16; ++r) {
+                        const int k2 = u * 32 + krow(r, half);
+                        const float b = dl[u][r];
+                        d1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(cw.w1[k2 * MC_P1 + li], b, d1[0], 0, 0, 0);
+                        d1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(cw.w1[k2 * MC_P1 + 32 + li], b, d1[1], 0, 0, 0);
+                    }
+            }
             // dW1 = dH2^T (A side, staged now) x H1 (B side, staged after the A fragments are in registers)
             WG_LDS_ORDER();
             wg_put64(T, dl, li, half);
@@ -967,12 +999,18 @@ __global__ __launch_bounds__(WG_T) __attribute__((amdgpu_waves_per_eu(NH == 1 ? 
         // ---- dl is dH1^T now.  dX^T[i][s] = sum_k1 W0[k1][i] dH1^T[k1][s]
         if (dX != nullptr) {
             f32x16 dx = zero16();
+            if constexpr (DG3) {
+                f32x16 dxv[1];
+                mc_layer_b3<2, 1, false>(p0h, p0l, MC_BP64, dl, dxv, li, half);
+                dx = dxv[0];
+            } else {
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+                for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    dx = __builtin_amdgcn_mfma_f32_32x32x2f32(cw.w0[(t * 32 + krow(r, half)) * MC_P0 + li], dl[t][r], dx, 0,
-                                                              0, 0);
+                    for (int r = 0; r < 16; ++r)
+                        dx = __builtin_amdgcn_mfma_f32_32x32x2f32(cw.w0[(t * 32 + krow(r, half)) * MC_P0 + li], dl[t][r], dx, 0,
+                                                                  0, 0);
+            }
             if (ok) {
                 if constexpr (SH) {
                     // only the base net's share of the input has a consumer (the harmonics depend on the ray direction alone): the
@@ -1315,7 +1353,7 @@ static int chain_bwd_fused(const float* dY, int lddy, int dy_col_off, const floa
     long long blocks = (ntiles + WG_WAVES - 1) / WG_WAVES;
     if (blocks > 256) blocks = 256;  // persistent: one workgroup per CU (LDS)
     float* P = (float*)workspace;
-    const size_t lds = (size_t)(chain_lds_floats(n_hidden) + WG_WAVES * (WG_STAGE + WG_DZ)) * sizeof(float) +
+    const size_t lds = (size_t)(wg_weight_lds_floats(n_hidden) + WG_WAVES * (WG_STAGE + WG_DZ)) * sizeof(float) +
                        (recompute ? (size_t)wg_rc_lds_elems(n_hidden) * sizeof(uint16_t) : 0);
     hipStream_t st = (hipStream_t)stream;
     auto launch = [&](auto kern, bool& attr) {

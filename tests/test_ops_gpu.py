@@ -1338,7 +1338,10 @@ def test_mlp64_backward_with_fused_weight_gradients(cfg, N):
               in_real, m._p(ws[1]) if nh == 2 else None, m._p(ws[-1]), nh, out, out_act, N, m._p(h1), m._p(h2) if nh == 2 else None,
               m._p(dx), 0 if planar else 32, m._p(gw[0]), m._p(gw[1]) if nh == 2 else None, m._p(gw[-1]), m._p(wsb), nb, st)
     torch.cuda.synchronize()
-    assert torch.equal(dx, dx_ref)
+    # (round 4: the fused kernel's data-gradient chain runs on the bf16 3-term split like its weight gradients -- 16 mantissa bits per
+    #  operand, fp32 accumulate -- where the separate launch keeps the fp32 matrix instruction: equal to the split's round-off)
+    dscale = float(dx_ref.abs().max())
+    assert maxdiff(dx, dx_ref) <= 3e-5 * dscale, maxdiff(dx, dx_ref) / dscale
     # fp64 reference of the weight gradients
     xd = x[:, :in_real].double()
     acts, a = [xd], xd
