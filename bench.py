@@ -53,6 +53,10 @@ def mfma_peak(key: str, gemm_mode: int = 1):
             return BF16_MATRIX_PEAK_TFLOPS / 3.0, "v_mfma_f32_32x32x16_bf16, 3 products per fp32-equivalent MAC (hi*hi + hi*lo + lo*hi)"
     if gemm_mode >= 1 and name == "snf_mlp64_fwd":
         return BF16_MATRIX_PEAK_TFLOPS / 6.0, "v_mfma_f32_32x32x16_bf16, 6 products per fp32-equivalent MAC (three-piece split)"
+    if gemm_mode >= 1 and name == "snf_mlp64_bwd_fused" and tag.count("x") == 3:
+        # two hidden layers (round 4): data-gradient chain AND weight gradients on the 3-product split (the recomputed forward's
+        # six-product work is not counted as useful flops)
+        return BF16_MATRIX_PEAK_TFLOPS / 3.0, "data gradient and weight gradients: v_mfma_f32_32x32x16_bf16, 3 products per fp32-equivalent MAC"
     if gemm_mode >= 1 and name == "snf_mlp64_bwd_fused":
         # data-gradient chain on the fp32 matrix cores + weight gradients on the 3-product split, half of the counted flops each
         return 2.0 / (1.0 / FP32_MATRIX_PEAK_TFLOPS + 3.0 / BF16_MATRIX_PEAK_TFLOPS), \

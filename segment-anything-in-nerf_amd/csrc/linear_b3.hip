@@ -385,18 +385,21 @@ __global__ __launch_bounds__(WF_T) void k_wgrad_full_b3(const float* __restrict_
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[u][t][i] = 0.f;
-    float4 av[2], bv[2];
-    auto fetch = [&](int n0) {
+    // Rows are requested TWO trips ahead (two register sets, the loop unrolled by two): with one trip of lead a trip lasted as long as a
+    // load takes under the step's traffic (55 us for 16 trips of ~0.6 us of matrix work each, round-4 counters: 60 % of the wave cycles
+    // waiting) -- the kernel was a chain of memory latencies.
+    float4 av[2][2], bv[2][2];
+    auto fetch = [&](int n0, float4 (&a_)[2], float4 (&b_)[2]) {
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             const int n = n0 + 2 * kp + p;
-            av[p] = b3_load_a<true>(dY, Y, n, col, n_end, O, lddy, ldy, act, rscale, rgroup, aux_bits);
-            bv[p] = ldx < 0 ? b3_load_b_planar8(X, n, col, n_end, I, N) : b3_load_b(X, n, col, n_end, I, ldx);
+            a_[p] = b3_load_a<true>(dY, Y, n, col, n_end, O, lddy, ldy, act, rscale, rgroup, aux_bits);
+            b_[p] = ldx < 0 ? b3_load_b_planar8(X, n, col, n_end, I, N) : b3_load_b(X, n, col, n_end, I, ldx);
         }
     };
-    auto stage = [&](int buf) {
-        const float a0[4] = {av[0].x, av[0].y, av[0].z, av[0].w}, a1[4] = {av[1].x, av[1].y, av[1].z, av[1].w};
-        const float b0[4] = {bv[0].x, bv[0].y, bv[0].z, bv[0].w}, b1[4] = {bv[1].x, bv[1].y, bv[1].z, bv[1].w};
+    auto stage = [&](int buf, const float4 (&a_)[2], const float4 (&b_)[2]) {
+        const float a0[4] = {a_[0].x, a_[0].y, a_[0].z, a_[0].w}, a1[4] = {a_[1].x, a_[1].y, a_[1].z, a_[1].w};
+        const float b0[4] = {b_[0].x, b_[0].y, b_[0].z, b_[0].w}, b1[4] = {b_[1].x, b_[1].y, b_[1].z, b_[1].w};
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             uint32_t h, l;
@@ -408,13 +411,15 @@ __global__ __launch_bounds__(WF_T) void k_wgrad_full_b3(const float* __restrict_
             *reinterpret_cast<uint32_t*>(&Bl[buf][(col + c) * WF_PITCH + 2 * kp]) = l;
         }
     };
-    fetch(n_begin);
-    stage(0);
+    fetch(n_begin, av[0], bv[0]);
+    stage(0, av[0], bv[0]);
     __syncthreads();
-    if (n_begin + 16 < n_end) fetch(n_begin + 16);
+    if (n_begin + 16 < n_end) fetch(n_begin + 16, av[0], bv[0]);
+    if (n_begin + 32 < n_end) fetch(n_begin + 32, av[1], bv[1]);
     const bool m_on[2] = {64 * wm < O, 64 * wm + 32 < O};
-    int buf = 0;
-    for (int n0 = n_begin; n0 < n_end; n0 += 16, buf ^= 1) {
+    // one trip: fragments of copy `buf`, the NEXT trip's rows (register set `a_`, fetched two trips ago) split into the other copy,
+    // the fetch for the trip after next into the freed set, this trip's MFMAs, barrier
+    auto trip = [&](int n0, int buf, float4 (&a_)[2], float4 (&b_)[2]) {
         bf16x8 bh[4], bl[4], ah[2], al[2];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -426,9 +431,9 @@ __global__ __launch_bounds__(WF_T) void k_wgrad_full_b3(const float* __restrict_
             ah[u] = *reinterpret_cast<const bf16x8*>(&Ah[buf][(64 * wm + 32 * u + li) * WF_PITCH + 8 * half]);
             al[u] = *reinterpret_cast<const bf16x8*>(&Al[buf][(64 * wm + 32 * u + li) * WF_PITCH + 8 * half]);
         }
-        if (n0 + 16 < n_end) {  // the next trip's rows (fetched a trip ago) into the other copy, then the fetch after that
-            stage(buf ^ 1);
-            if (n0 + 32 < n_end) fetch(n0 + 32);
+        if (n0 + 16 < n_end) {
+            stage(buf ^ 1, a_, b_);
+            if (n0 + 48 < n_end) fetch(n0 + 48, a_, b_);
         }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -444,6 +449,10 @@ __global__ __launch_bounds__(WF_T) void k_wgrad_full_b3(const float* __restrict_
             }
         }
         __syncthreads();
+    };
+    for (int n0 = n_begin; n0 < n_end; n0 += 32) {
+        trip(n0, 0, av[0], bv[0]);
+        if (n0 + 16 < n_end) trip(n0 + 16, 1, av[1], bv[1]);
     }
     float* __restrict__ Pw = P + (size_t)blockIdx.x * O * I;
 #pragma unroll

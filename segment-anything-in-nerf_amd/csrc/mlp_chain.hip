@@ -740,16 +740,22 @@ constexpr int wg_partial_floats(int NH) { return 32 * 64 + (NH == 2 ? 64 * 64 : 
 #ifndef SNF_WG_DGRAD_B3
 #define SNF_WG_DGRAD_B3 1
 #endif
+#ifndef SNF_WG_DGRAD_B3_NH1
+#define SNF_WG_DGRAD_B3_NH1 0
+#endif
 // weights of the data-gradient chain in LDS (floats): transposed bf16 hi / lo planes (DG3) or the fp32 matrices
 constexpr int wg_weight_lds_floats(int NH) {
-    return (SNF_WG_DGRAD_B3 && NH == 2) ? (MC_H * MC_BP32 + MC_H * MC_BP64 + 32 * MC_BP64) : chain_lds_floats(NH);
+    return (SNF_WG_DGRAD_B3 && (NH == 2 || SNF_WG_DGRAD_B3_NH1)) ? (MC_H * MC_BP32 + (NH == 2 ? MC_H * MC_BP64 : 0) + 32 * MC_BP64)
+                                                                 : chain_lds_floats(NH);
 }
 constexpr int wg_rc_lds_elems(int NH) { return 3 * (MC_H * MC_BP32 + (NH == 2 ? MC_H * MC_BP64 : 0)); }
 
 template <int NH, bool RC = false, bool SH = false>
 // one hidden layer: 2 waves per SIMD = 252 registers instead of 280, no spills -- a workgroup then fits beside one workgroup of
 // the table reduce on a CU (co-residency); alone 0.129 -> 0.126 ms
+#ifndef SNF_WG_WAVES_NH1
 #define SNF_WG_WAVES_NH1 2
+#endif
 __global__ __launch_bounds__(WG_T) __attribute__((amdgpu_waves_per_eu(NH == 1 ? SNF_WG_WAVES_NH1 : 1, NH == 1 ? SNF_WG_WAVES_NH1 : 1))) void k_mlp_chain_bwd_wg(const float* __restrict__ dY, int lddy, int dy_col_off,
                                                            const float* __restrict__ dY0, const float* __restrict__ Yout,
                                                            int ldy, const float* __restrict__ X, int ldx,
@@ -767,7 +773,7 @@ __global__ __launch_bounds__(WG_T) __attribute__((amdgpu_waves_per_eu(NH == 1 ? 
     // work on 3-term products.  0: the fp32 chain.
     // (two hidden layers only: with one hidden layer and up to 16 outputs the fp32 chain is 48 short instructions, and the split's
     //  registers cost the kernel its second wave per SIMD -- measured 0.123 -> 0.134 ms for the base net, 0.224 -> 0.168 for the colour net)
-    constexpr bool DG3 = SNF_WG_DGRAD_B3 != 0 && NH == 2;
+    constexpr bool DG3 = SNF_WG_DGRAD_B3 != 0 && (NH == 2 || SNF_WG_DGRAD_B3_NH1);
     ChainWeights cw;
     uint16_t* poh = reinterpret_cast<uint16_t*>(lds);      // Wout^T [64 hidden][MC_BP32]  LIN slots over the (<= 32) outputs
     uint16_t* pol = poh + MC_H * MC_BP32;
