@@ -440,29 +440,50 @@ constexpr int chain_b3_lds_elems(int NH, int planes = 2) {  // bf16 elements, al
 struct ChainSh {
     const float* dirs;  // [R, 3]
     int S;              // samples per ray: sample n belongs to ray n / S
+    int log2S;          // S = 2^log2S, or -1 (a 64-bit division per lane and tile costs ~100 instructions: 128 samples per ray is a shift)
 };
+static ChainSh chain_sh(const float* dirs, int S) {
+    int l = -1;
+    if (S > 0 && (S & (S - 1)) == 0) for (l = 0; (1 << l) < S; ++l) {}
+    return ChainSh{dirs, S, l};
+}
 
+// this lane's half of a formed input row: half 0 = the 16 harmonics of the ray's direction, half 1 = columns 1 .. 15 of the base
+// net's output row (16 floats, read as four aligned 16-byte loads) and a zero
+// In two halves so that a kernel can request a row a tile ahead and form it when it is used: `raw` = the 3 direction components
+// (half 0) or the 16 floats of the base net's output row (half 1).
+__device__ __forceinline__ void chain_sh_load(const float* __restrict__ Hb, int ldh, const ChainSh& sh, long long s, int half,
+                                              f32x16& raw) {
+    if (half == 0) {
+        const long long r = sh.log2S >= 0 ? (s >> sh.log2S) : s / sh.S;
+        raw[0] = sh.dirs[r * 3 + 0]; raw[1] = sh.dirs[r * 3 + 1]; raw[2] = sh.dirs[r * 3 + 2];
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 v = *reinterpret_cast<const float4*>(Hb + s * ldh + 4 * q);
+            raw[4 * q] = v.x; raw[4 * q + 1] = v.y; raw[4 * q + 2] = v.z; raw[4 * q + 3] = v.w;
+        }
+    }
+}
+__device__ __forceinline__ void chain_sh_form(const f32x16& raw, int half, f32x16& xo) {
+    if (half == 0) {
+        float o[16];
+        sh16_of(raw[0], raw[1], raw[2], o);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) xo[i] = o[i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 15; ++i) xo[i] = raw[i + 1];
+        xo[15] = 0.f;
+    }
+}
 // this lane's half of a formed input row: half 0 = the 16 harmonics of the ray's direction, half 1 = columns 1 .. 15 of the base
 // net's output row (16 floats, read as four aligned 16-byte loads) and a zero
 __device__ __forceinline__ void chain_sh_row(const float* __restrict__ Hb, int ldh, const ChainSh& sh, long long s, int half,
                                              f32x16& xo) {
-    if (half == 0) {
-        const long long r = s / sh.S;
-        float o[16];
-        sh16_of(sh.dirs[r * 3 + 0], sh.dirs[r * 3 + 1], sh.dirs[r * 3 + 2], o);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) xo[i] = o[i];
-    } else {
-        float c[16];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float4 v = *reinterpret_cast<const float4*>(Hb + s * ldh + 4 * q);
-            c[4 * q] = v.x; c[4 * q + 1] = v.y; c[4 * q + 2] = v.z; c[4 * q + 3] = v.w;
-        }
-#pragma unroll
-        for (int i = 0; i < 15; ++i) xo[i] = c[i + 1];
-        xo[15] = 0.f;
-    }
+    f32x16 raw;
+    chain_sh_load(Hb, ldh, sh, s, half, raw);
+    chain_sh_form(raw, half, xo);
 }
 
 template <int NH, int PLANES = 2, bool SH = false>
@@ -473,7 +494,7 @@ __global__ __launch_bounds__(256, SNF_CHAIN_FWD_WAVES) void k_mlp_chain_fwd_b3(c
                                                           int in_real, const float* __restrict__ W1,
                                                           const float* __restrict__ Wout, int out, int out_act, long long N,
                                                           float* __restrict__ H1, float* __restrict__ H2,
-                                                          float* __restrict__ Y, int ldy, ChainSh sh = ChainSh{nullptr, 1}) {
+                                                          float* __restrict__ Y, int ldy, ChainSh sh = ChainSh{nullptr, 1, 0}) {
     extern __shared__ __attribute__((aligned(16))) uint16_t ldsb[];
     constexpr int SZ0 = MC_H * MC_BP32, SZ1 = (NH == 2 ? MC_H * MC_BP64 : 0), SZO = 32 * MC_BP64;
     uint16_t* p0h = ldsb;                          // W0  [64][MC_BP32]  LIN slots over the 32 inputs
@@ -504,7 +525,7 @@ __global__ __launch_bounds__(256, SNF_CHAIN_FWD_WAVES) void k_mlp_chain_fwd_b3(c
         const long long s_ = tile_ * 32 + li;
         const long long sc_ = s_ < N ? s_ : N - 1;
         if constexpr (SH) {
-            chain_sh_row(X, ldx, sh, sc_, half, xo);
+            chain_sh_load(X, ldx, sh, sc_, half, xo);  // (raw: formed where the row is used, so a row a tile ahead costs no more)
         } else if (ldx == 0) {
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
@@ -522,8 +543,7 @@ __global__ __launch_bounds__(256, SNF_CHAIN_FWD_WAVES) void k_mlp_chain_fwd_b3(c
     const long long tstride = (long long)gridDim.x * 4;
     long long tile0 = (long long)blockIdx.x * 4 + wave;
     f32x16 xn;
-    // (the two-hidden-layer chain with a FORMED input row has no 16 registers left for the row a tile ahead: 16 spills)
-    constexpr bool PF = (SNF_CHAIN_PREFETCH & 1) && !(SH && NH == 2);
+    constexpr bool PF = (SNF_CHAIN_PREFETCH & 1) != 0;
     if (PF && tile0 < ntiles) load_x(tile0, xn);
     for (long long tile = tile0; tile < ntiles; tile += tstride) {
         const long long s = tile * 32 + li;
@@ -534,6 +554,10 @@ __global__ __launch_bounds__(256, SNF_CHAIN_FWD_WAVES) void k_mlp_chain_fwd_b3(c
             if (tile + tstride < ntiles) load_x(tile + tstride, xn);
         } else {
             load_x(tile, x[0]);
+        }
+        if constexpr (SH) {
+            const f32x16 raw = x[0];
+            chain_sh_form(raw, half, x[0]);
         }
 #pragma unroll
         for (int i = 0; i < 16; ++i)
@@ -763,7 +787,7 @@ __global__ __launch_bounds__(WG_T) __attribute__((amdgpu_waves_per_eu(NH == 1 ? 
                                                            const float* __restrict__ W1, const float* __restrict__ Wout,
                                                            int out, int out_act, long long N, const float* __restrict__ H1,
                                                            const float* __restrict__ H2, float* __restrict__ dX, int lddx,
-                                                           float* __restrict__ P, ChainSh sh = ChainSh{nullptr, 1}) {
+                                                           float* __restrict__ P, ChainSh sh = ChainSh{nullptr, 1, 0}) {
     static_assert(!SH || RC, "the formed input row (SH) goes with the recomputing backward");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     // Data-gradient chain on the bf16 matrix cores with the 3-term split (SNF_WG_DGRAD_B3, round 4): the transposed weights as hi / lo
@@ -821,7 +845,7 @@ __global__ __launch_bounds__(WG_T) __attribute__((amdgpu_waves_per_eu(NH == 1 ? 
         const long long s_ = tile_ * 32 + li;
         const long long sc_ = s_ < N ? s_ : N - 1;
         if constexpr (SH) {
-            chain_sh_row(X, ldx, sh, sc_, half, xo);
+            chain_sh_load(X, ldx, sh, sc_, half, xo);  // (raw; formed below)
         } else if (ldx == 0) {
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
@@ -886,6 +910,10 @@ __global__ __launch_bounds__(WG_T) __attribute__((amdgpu_waves_per_eu(NH == 1 ? 
                 }
             } else {
                 load_x(tile, xr[0]);
+            }
+            if constexpr (SH) {
+                const f32x16 raw = xr[0];
+                chain_sh_form(raw, half, xr[0]);
             }
 #pragma unroll
             for (int i = 0; i < 16; ++i)
@@ -1202,7 +1230,7 @@ static int chain_fwd_sh(const float* dirs, int R, int S, const float* Hb, int ld
     const long long ntiles = (N + 31) / 32;
     long long blocks = (ntiles + 3) / 4;
     if (blocks > 256 * 4) blocks = 256 * 4;
-    const ChainSh sh{dirs, S};
+    const ChainSh sh = chain_sh(dirs, S);
     if (n_hidden == 2)
         hipLaunchKernelGGL((k_mlp_chain_fwd_b3<2, 3, true>), dim3((unsigned)blocks), dim3(256), chain_b3_lds_elems(2, 3) * sizeof(uint16_t),
                            (hipStream_t)stream, Hb, ldh, W0, 16 + n_geo, W1, Wout, out, out_act, N, H1, H2, Y, ldy, sh);
@@ -1238,17 +1266,17 @@ extern "C" int snf_mlp64_fwd(const float* X, int ldx, const float* W0, int in_re
     if (chain_b3_on()) {
         if (n_hidden == 2)
             hipLaunchKernelGGL(k_mlp_chain_fwd_b3<2>, dim3((unsigned)blocks), dim3(256), chain_b3_lds_elems(2) * sizeof(uint16_t),
-                               (hipStream_t)stream, X, ldx, W0, in_real, W1, Wout, out, out_act, (long long)N, H1, H2, Y, ldy, ChainSh{nullptr, 1});
+                               (hipStream_t)stream, X, ldx, W0, in_real, W1, Wout, out, out_act, (long long)N, H1, H2, Y, ldy, ChainSh{nullptr, 1, 0});
         else
             hipLaunchKernelGGL(k_mlp_chain_fwd_b3<1>, dim3((unsigned)blocks), dim3(256), chain_b3_lds_elems(1) * sizeof(uint16_t),
-                               (hipStream_t)stream, X, ldx, W0, in_real, W1, Wout, out, out_act, (long long)N, H1, H2, Y, ldy, ChainSh{nullptr, 1});
+                               (hipStream_t)stream, X, ldx, W0, in_real, W1, Wout, out, out_act, (long long)N, H1, H2, Y, ldy, ChainSh{nullptr, 1, 0});
     } else if (x6 && snf_get_gemm_mode() == 1) {
         if (n_hidden == 2)
             hipLaunchKernelGGL((k_mlp_chain_fwd_b3<2, 3>), dim3((unsigned)blocks), dim3(256), chain_b3_lds_elems(2, 3) * sizeof(uint16_t),
-                               (hipStream_t)stream, X, ldx, W0, in_real, W1, Wout, out, out_act, (long long)N, H1, H2, Y, ldy, ChainSh{nullptr, 1});
+                               (hipStream_t)stream, X, ldx, W0, in_real, W1, Wout, out, out_act, (long long)N, H1, H2, Y, ldy, ChainSh{nullptr, 1, 0});
         else
             hipLaunchKernelGGL((k_mlp_chain_fwd_b3<1, 3>), dim3((unsigned)blocks), dim3(256), chain_b3_lds_elems(1, 3) * sizeof(uint16_t),
-                               (hipStream_t)stream, X, ldx, W0, in_real, W1, Wout, out, out_act, (long long)N, H1, H2, Y, ldy, ChainSh{nullptr, 1});
+                               (hipStream_t)stream, X, ldx, W0, in_real, W1, Wout, out, out_act, (long long)N, H1, H2, Y, ldy, ChainSh{nullptr, 1, 0});
     } else if (n_hidden == 2)
         hipLaunchKernelGGL(k_mlp_chain_fwd<2>, dim3((unsigned)blocks), dim3(256), chain_lds_floats(2) * sizeof(float),
                            (hipStream_t)stream, X, ldx, W0, in_real, W1, Wout, out, out_act, (long long)N, H1, H2, Y, ldy);
@@ -1368,12 +1396,12 @@ static int chain_bwd_fused(const float* dY, int lddy, int dy_col_off, const floa
             attr = true;
         }
         hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(WG_T), lds, st, dY, lddy, dy_col_off, dY0, Y, ldy, X, ldx, W0, in_real,
-                           W1, Wout, out, out_act, (long long)N, H1, H2, dX, lddx, P, ChainSh{nullptr, 1});
+                           W1, Wout, out, out_act, (long long)N, H1, H2, dX, lddx, P, ChainSh{nullptr, 1, 0});
     };
     static bool a20 = false, a21 = false, a10 = false, a11 = false;
     if (sh_dirs != nullptr) {
         // the input row formed in the loader (recompute only): X = the base net's output, dX = the compact gradient of its geo columns
-        const ChainSh sh{sh_dirs, sh_S};
+        const ChainSh sh = chain_sh(sh_dirs, sh_S);
         static bool s2 = false, s1 = false;
         auto launch_sh = [&](auto kern, bool& attr) {
             if (!attr) {

@@ -94,7 +94,15 @@ def test_loss_multipliers_scale_the_gradients_like_autograd(monkeypatch):
 @pytest.mark.parametrize("overlap", [True, False])
 def test_trajectory_follows_the_eager_path(overlap):
     """14 steps (the proposal network trains on every step below 10 and on every other step after that, so both variants
-    of the schedule run, on both buffer parities): per-step loss terms agree to 1e-4 relative, step counters are equal."""
+    of the schedule run, on both buffer parities): per-step loss terms agree to 1e-4 relative over the first ten steps and
+    to 5e-4 after, step counters are equal.
+
+    Why the bound widens: the two paths' gradients differ by <= 3e-5 of the largest entry after one step (the one-step test
+    above) and Adam at step counts this low moves every parameter by ~lr whatever the gradient's size, so the difference grows
+    by ~1.6x per step -- measured with tools/trajectory_spread.py (profiles/r04_trajectory_spread.txt): eager vs schedule
+    8e-7 at step 5, 1.1e-5 at step 8, 7e-5 .. 1.2e-4 at step 13, always in the distortion term; the eager path against ITSELF
+    (float atomics in the weight gradients) reaches 5e-5 at step 13.  A stale or clobbered buffer changes a step's samples,
+    i.e. the loss terms by percents from the step it happens on."""
     ref = _trainer("samnerf_distill", False, 256, 12)
     new = _trainer("samnerf_distill", True, 256, 12)
     ref.overlap = new.overlap = overlap
@@ -104,7 +112,8 @@ def test_trajectory_follows_the_eager_path(overlap):
     assert new._program is not None and len(new._program.plans) >= 3  # parities x {updated, not updated}
     for step, (a, b) in enumerate(zip(l_ref, l_new)):
         for k, v in a.items():
-            assert abs(b[k] - v) <= 1e-4 * max(1e-3, abs(v)), (step, k, b[k], v)
+            tol = 1e-4 if step < 10 else 5e-4
+            assert abs(b[k] - v) <= tol * max(1e-3, abs(v)), (step, k, b[k], v)
     assert dict(new.optimizers.step_count) == dict(ref.optimizers.step_count)
     assert dict(new.optimizers.sched_step) == dict(ref.optimizers.sched_step)
     ps_r, ps_n = ref.pipeline.model.proposal_sampler, new.pipeline.model.proposal_sampler

@@ -20,7 +20,7 @@ bash tools/pmc_all.sh $TAG > /dev/null 2>&1
 python tools/pmc_all_summary.py $OUT > $OUT/hbm_bytes_per_kernel.txt 2>&1
 python tools/eager_timeline.py 2>/dev/null | cut -c1-200 > $OUT/timeline_distill.txt
 python tools/host_vs_gpu.py > $OUT/host_vs_gpu.txt 2>&1
-tools/ablate_step.sh $OUT/ablation.txt snf_hashgrid_bwd_presorted_adam_pair snf_hashgrid_bwd_presorted_adam_xp/F2L16 snf_hashgrid_sort_xp/L16 snf_mlp64_bwd_fused/31x64x64x3 snf_mlp64_bwd_fused/32x64x16 snf_mlp64_fwd snf_hashgrid_fwd/F2L16 snf_hashgrid_fwd/F8L12 snf_linear_bwd_weight_rows snf_linear_bwd_data_rows snf_linear_fwd_mean 2304x256 snf_mlp_tiny snf_adam_step_rows snf_linear_ snf_mlp64_ > /dev/null 2>&1
+tools/ablate_step.sh $OUT/ablation.txt snf_hashgrid_bwd_presorted_adam_pair snf_hashgrid_bwd_presorted_adam_xp/F2L16 snf_hashgrid_sort_xp/L16 snf_mlp64_bwd_fused_sh/31x64x64x3 snf_mlp64_bwd_fused/32x64x16 snf_mlp64_fwd snf_hashgrid_fwd/F2L16 snf_hashgrid_fwd/F8L12 snf_linear_bwd_weight_rows snf_linear_bwd_data_rows snf_linear_fwd_mean 2304x256 snf_mlp_tiny snf_adam_step_rows snf_linear_ snf_mlp64_ > /dev/null 2>&1
 bash tools/step_counters.sh $TAG/counters > /dev/null 2>&1
 python tools/bench_vit.py 2>/dev/null | cut -c1-200 > $OUT/vit.txt
 ( python tools/bench_render.py; SNF_RENDER_REUSE_PASS1=0 python tools/bench_render.py; RES=1024 python tools/bench_render.py ) 2>/dev/null | grep "^render" | cut -c1-400 > $OUT/render.txt
