@@ -359,6 +359,15 @@ __global__ __launch_bounds__(256) void k_gemm_wgrad_b3(const float* __restrict__
 // O x I x chunks partial sums (deterministic up to the few-way split of that second pass).
 constexpr int WF_PITCH = 24;  // bf16 per LDS row: 16 k + 8 pad
 constexpr int WF_T = 512;
+#ifndef SNF_WS_MIN_ROWS
+#define SNF_WS_MIN_ROWS 4096  // fewer rows than this: the tiled kernel (a weight-stationary workgroup stages a whole weight slice first)
+#endif
+#ifndef SNF_WF_CHUNKS
+#define SNF_WF_CHUNKS 256  // row chunks (= workgroups, = partial sums P[chunk][O][I]) of the full-width weight gradient
+#endif
+#ifndef SNF_WF_RSPLIT
+#define SNF_WF_RSPLIT 4    // k_wgrad_full_reduce: the chunks of one output element are summed by this many workgroups
+#endif
 
 __global__ __launch_bounds__(WF_T) void k_wgrad_full_b3(const float* __restrict__ dY, const float* __restrict__ Y,
                                                         const float* __restrict__ X, int N, int I, int O, int lddy, int ldy,
@@ -489,8 +498,8 @@ __global__ __launch_bounds__(256) void k_wgrad_full_reduce(const float* __restri
 }
 
 static int wf_rows_per_wg(int N) {
-    static const int chunks = 256;
-    int rows = ceil_div(N, chunks > 0 ? chunks : 256);  // default: one workgroup per CU
+    static const int chunks = SNF_WF_CHUNKS;
+    int rows = ceil_div(N, chunks);  // default: one workgroup per CU
     rows = ((rows + 15) / 16) * 16;
     if (rows < 64) rows = 64;
     return rows;
@@ -906,7 +915,7 @@ static int ws_try(const float* A, const float* Aux, const float* W, const float*
         }
         return 1;
     }
-    static const int min_rows = 4096;
+    static const int min_rows = SNF_WS_MIN_ROWS;
     if (!on || (K % 16) || K > 256 || K < 64 || M < min_rows || Nc < 64 || (Nc % 4) || (lda % 4)) return 0;
     // BN 128, 8 waves x 32 rows, 4 k-steps of A loads in flight (2 and 8 measured the same: the loads are not latency-bound);
     // narrow outputs (Nc <= 64) and SNF_GEMM_WS_VARIANT=1 take BN 64 with 4 waves x 64 rows (two workgroups per CU)
@@ -1045,7 +1054,7 @@ int snf::b3_try_bwd_weight_full(const float* dY, const float* Y, const float* X,
     float* P = (float*)workspace;
     hipLaunchKernelGGL(k_wgrad_full_b3, dim3(chunks), dim3(WF_T), 0, (hipStream_t)stream, dY, Y, X, N, I, O, lddy, ldy, ldx, act,
                        rows, P, rscale, rgroup, aux_bits);
-    hipLaunchKernelGGL(k_wgrad_full_reduce, dim3(ceil_div(O * I, 1024), 4), dim3(256), 0, (hipStream_t)stream, P, chunks, O * I, dW);
+    hipLaunchKernelGGL(k_wgrad_full_reduce, dim3(ceil_div(O * I, 1024), SNF_WF_RSPLIT), dim3(256), 0, (hipStream_t)stream, P, chunks, O * I, dW);
     return 1;
 }
 

@@ -347,7 +347,7 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv
     }
     // the 32 queries' relative-position rows of this wave, staged once (read every key tile: from global memory that was 64
     // cache lines per load instruction and bounded the kernel)
-    extern __shared__ float rel_lds[];
+    extern __shared__ __attribute__((aligned(16))) float rel_lds[];
     const int RP = 2 * n + 1;
     float* relw = rel_lds + (size_t)wave * 32 * RP;
     if (rel) {
@@ -509,28 +509,49 @@ __global__ __launch_bounds__(NT, (NT == 256 ? SNF_ATT_WAVES : 1)) void k_attenti
     // the lane's (scaled) query row as B operands: k-step s holds d = 16s + 8 half + j
     at_bf16x8 qh[KS], ql[KS];
     {
+        // (all loads first, unconditional at clamped dims, the pad dims zeroed after: a guarded load per element was a basic block and a
+        //  wait per element -- 48 memory latencies in a row before the first tile, twice that again for the position tables below; on the
+        //  14 x 14 windows, 7 tiles per workgroup, that prologue was most of the kernel)
         const float* qp = base + (size_t)(qlive ? qi : T - 1) * 3 * C;
+        float2 raw[KS][4];
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int p2 = 0; p2 < 4; ++p2) raw[s][p2] = *reinterpret_cast<const float2*>(qp + min(16 * s + 8 * half + 2 * p2, hd - 2));
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             uint32_t hq[4], lq[4];
 #pragma unroll
             for (int p2 = 0; p2 < 4; ++p2) {
-                const int d = 16 * s + 8 * half + 2 * p2;
-                const float x0 = d < hd ? qp[d] * scale : 0.f, x1 = d + 1 < hd ? qp[d + 1] * scale : 0.f;
-                at_split2(x0, x1, hq[p2], lq[p2]);
+                const bool in = 16 * s + 8 * half + 2 * p2 < hd;  // (head dim even)
+                at_split2(in ? raw[s][p2].x * scale : 0.f, in ? raw[s][p2].y * scale : 0.f, hq[p2], lq[p2]);
             }
             qh[s] = __builtin_bit_cast(at_bf16x8, make_uint4(hq[0], hq[1], hq[2], hq[3]));
             ql[s] = __builtin_bit_cast(at_bf16x8, make_uint4(lq[0], lq[1], lq[2], lq[3]));
         }
     }
-    extern __shared__ float rel_lds[];
+    extern __shared__ __attribute__((aligned(16))) float rel_lds[];
     const int RP = 2 * n + 1;
     const uint32_t inv_n = n > 0 ? (65536u + (uint32_t)n - 1u) / (uint32_t)n : 0u;
     float* relw = rel_lds + (size_t)wave * 32 * RP;
     // rel_direct (grid side a multiple of 32: a 32-key tile lies inside ONE row of keys): the lane reads its query's one row term
     // and 16 column terms per tile straight from global memory (four float4) -- no per-wave copy of the [32][2n] position rows in
     // LDS, which at n = 64 was 66 KB per workgroup and left one workgroup per CU
+    // ... the one ROW term a tile needs is requested a tile ahead; the COLUMN terms (the same n values of a query for every row of keys)
+    // are copied once into the wave's LDS rows [32][n + 4]: read from global memory they were four 16-byte loads per lane and tile at
+    // 2n-float strides -- 256 cache lines per wave and tile, issued between the score MFMAs and the softmax with nothing to hide them
     const float* __restrict__ relg = (rel && rel_direct) ? rel + ((size_t)bh * T + (qlive ? qi : T - 1)) * 2 * n : nullptr;
+    const int RWP = n + 4;
+    if (relg) {
+        float* rw = rel_lds + (size_t)wave * 32 * RWP;
+        for (int r = 0; r < 32; ++r) {
+            const int qq = q0 + r < T ? q0 + r : T - 1;
+            const float* src = rel + ((size_t)bh * T + qq) * 2 * n + n;
+            for (int j = lane; j < n; j += 64) rw[r * RWP + j] = src[j];
+        }
+    }
+    const float* relc = rel_lds + (size_t)wave * 32 * RWP + li * RWP;  // (rel_direct only)
+    float rrow_cur = relg ? relg[0] : 0.f, rrow_nxt = 0.f;
     const bool has_rel = rel != nullptr || rph != nullptr;
     if (rph != nullptr) {
         // Small grids (2n - 1 <= 32: the encoder's 14 x 14 windows): the decomposed relative-position terms of this wave's 32 queries
@@ -542,7 +563,13 @@ __global__ __launch_bounds__(NT, (NT == 256 ? SNF_ATT_WAVES : 1)) void k_attenti
         const float unscale = 1.f / scale;
 #pragma unroll
         for (int tb = 0; tb < 2; ++tb) {
-            const float* __restrict__ tabrow = (tb == 0 ? rph : rpw) + (size_t)(li < 2 * n - 1 ? li : 2 * n - 2) * hd;
+            const bool trow = li < 2 * n - 1;
+            const float* __restrict__ tabrow = (tb == 0 ? rph : rpw) + (size_t)(trow ? li : 2 * n - 2) * hd;
+            float2 raw[KS][4];
+#pragma unroll
+            for (int s2 = 0; s2 < KS; ++s2)
+#pragma unroll
+                for (int p2 = 0; p2 < 4; ++p2) raw[s2][p2] = *reinterpret_cast<const float2*>(tabrow + min(16 * s2 + 8 * half + 2 * p2, hd - 2));
             f32x16 pacc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) pacc[r] = 0.f;
@@ -551,9 +578,8 @@ __global__ __launch_bounds__(NT, (NT == 256 ? SNF_ATT_WAVES : 1)) void k_attenti
                 uint32_t hr[4], lr[4];
 #pragma unroll
                 for (int p2 = 0; p2 < 4; ++p2) {
-                    const int d = 16 * s2 + 8 * half + 2 * p2;
-                    const float x0 = (d < hd && li < 2 * n - 1) ? tabrow[d] : 0.f, x1 = (d + 1 < hd && li < 2 * n - 1) ? tabrow[d + 1] : 0.f;
-                    at_split2(x0, x1, hr[p2], lr[p2]);
+                    const bool in = trow && 16 * s2 + 8 * half + 2 * p2 < hd;
+                    at_split2(in ? raw[s2][p2].x : 0.f, in ? raw[s2][p2].y : 0.f, hr[p2], lr[p2]);
                 }
                 const at_bf16x8 rh = __builtin_bit_cast(at_bf16x8, make_uint4(hr[0], hr[1], hr[2], hr[3]));
                 const at_bf16x8 rl = __builtin_bit_cast(at_bf16x8, make_uint4(lr[0], lr[1], lr[2], lr[3]));
@@ -583,55 +609,61 @@ __global__ __launch_bounds__(NT, (NT == 256 ? SNF_ATT_WAVES : 1)) void k_attenti
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
-    // staging: K as (key, pair of head dims), V as (pair of keys, head dim); one tile ahead in registers
-    constexpr int PPT = (16 * DP + NT - 1) / NT;  // pairs per thread and matrix (NT = 448: the last pass is partial)
-    float2 kreg[PPT], vreg[PPT];
+    // staging (threads 0 .. 255; head dim even), one tile ahead in registers:
+    //   K: thread (key kr = t / 8, c = t % 8) takes the dim pairs 2 (c + 8 q), q < DP / 16 -- 64 contiguous bytes per 8 lanes;
+    //   V: thread (key pair kp2 = t / 16, d0 = t % 16) takes dims d0 + 16 q of the keys 2 kp2, 2 kp2 + 1.
+    // Every address is the wave-uniform head base + a 32-bit lane offset (row term once per tile, the q term a constant), and every load is
+    // unconditional (clamped row / dim, zeroed after): as (e / 48, e % 48) index arithmetic with a branch per guarded load the fetch was 250
+    // VALU instructions and 24 basic blocks per tile, and each branch made the compiler drain the loads in flight.
+    constexpr int SQ = DP / 16;
+    const int st = (int)threadIdx.x;
+    const bool stager = NT == 256 || st < 256;  // (wave-uniform: 256 threads = 4 waves)
+    const int s_kr = (st >> 3) & 31, s_c = st & 7, s_kp2 = (st >> 4) & 15, s_d = st & 15;
+    const int s_slot = at_key_slot(2 * s_kp2);  // keys 2kp2 and 2kp2+1 sit in adjacent slots
+    const int row3c = 3 * C;
+    float2 kreg[SQ], vreg[SQ];
     auto fetch = [&](int k0) {
+        const int kkey = k0 + s_kr, vkey = k0 + 2 * s_kp2;
+        // (unsigned 32-bit offsets from the uniform base: scalar base + vector offset addressing, no 64-bit lane arithmetic; T 3C < 2^31: host)
+        const uint32_t koff = (uint32_t)(min(kkey, T - 1) * row3c + C);
+        const uint32_t voff0 = (uint32_t)(min(vkey, T - 1) * row3c + 2 * C), voff1 = (uint32_t)(min(vkey + 1, T - 1) * row3c + 2 * C);
 #pragma unroll
-        for (int q = 0; q < PPT; ++q) {
-            const int e = min((int)threadIdx.x + NT * q, 16 * DP - 1);  // (clamped: a partial last pass re-reads the last pair)
-            {   // K: e -> (key kr, dims 2*dp, 2*dp + 1)
-                const int kr = e / (DP / 2), d = (e - kr * (DP / 2)) * 2;
-                const int key = k0 + kr;
-                const float* kp = base + (size_t)(key < T ? key : T - 1) * 3 * C + C;
-                kreg[q].x = (key < T && d < hd) ? kp[d] : 0.f;
-                kreg[q].y = (key < T && d + 1 < hd) ? kp[d + 1] : 0.f;
-            }
-            {   // V: e -> (keys 2*kp2, 2*kp2 + 1, dim d)
-                const int kp2 = e / DP, d = e - kp2 * DP;
-                const int key = k0 + 2 * kp2;
-                const int dc = d < hd ? d : 0;
-                const float* v0 = base + (size_t)(key < T ? key : T - 1) * 3 * C + 2 * C + dc;
-                const float* v1 = base + (size_t)(key + 1 < T ? key + 1 : T - 1) * 3 * C + 2 * C + dc;
-                vreg[q].x = (key < T && d < hd) ? v0[0] : 0.f;
-                vreg[q].y = (key + 1 < T && d < hd) ? v1[0] : 0.f;
-            }
+        for (int q = 0; q < SQ; ++q) {
+            const int dk = 2 * (s_c + 8 * q), dv = s_d + 16 * q;
+            kreg[q] = *reinterpret_cast<const float2*>(base + (koff + (uint32_t)min(dk, hd - 2)));
+            vreg[q].x = base[voff0 + (uint32_t)min(dv, hd - 1)];
+            vreg[q].y = base[voff1 + (uint32_t)min(dv, hd - 1)];
         }
     };
-    fetch(0);
+    if (stager) fetch(0);
     for (int k0 = 0; k0 < T; k0 += 32) {
         __syncthreads();  // previous tile consumed
+        if (stager) {
 #pragma unroll
-        for (int q = 0; q < PPT; ++q) {
-            const int e = (int)threadIdx.x + NT * q;
-            if ((16 * DP) % NT != 0 && e >= 16 * DP) continue;
-            uint32_t hh, ll;
-            {
-                const int kr = e / (DP / 2), d = (e - kr * (DP / 2)) * 2;
+            for (int q = 0; q < SQ; ++q) {
+                // (pad dims and keys past T are zeroed HERE, where the values are consumed: a select right behind the load made the fetch
+                //  wait for every load as it issued it)
+                if (16 * q + 16 > hd) {  // wave-uniform: only the passes that reach past the head dim
+                    if (2 * (s_c + 8 * q) >= hd) kreg[q] = make_float2(0.f, 0.f);
+                    if (s_d + 16 * q >= hd) vreg[q] = make_float2(0.f, 0.f);
+                }
+                if (k0 + 32 > T) {  // wave-uniform: only the last tile of a T that is no multiple of 32
+                    if (k0 + s_kr >= T) kreg[q] = make_float2(0.f, 0.f);
+                    if (k0 + 2 * s_kp2 >= T) vreg[q].x = 0.f;
+                    if (k0 + 2 * s_kp2 + 1 >= T) vreg[q].y = 0.f;
+                }
+                uint32_t hh, ll;
                 at_split2(kreg[q].x, kreg[q].y, hh, ll);
-                *reinterpret_cast<uint32_t*>(&Kh[kr * KPB + d]) = hh;
-                *reinterpret_cast<uint32_t*>(&Kl[kr * KPB + d]) = ll;
-            }
-            {
-                const int kp2 = e / DP, d = e - kp2 * DP;
-                const int slot = at_key_slot(2 * kp2);  // keys 2kp2 and 2kp2+1 sit in adjacent slots
+                *reinterpret_cast<uint32_t*>(&Kh[s_kr * KPB + 2 * (s_c + 8 * q)]) = hh;
+                *reinterpret_cast<uint32_t*>(&Kl[s_kr * KPB + 2 * (s_c + 8 * q)]) = ll;
                 at_split2(vreg[q].x, vreg[q].y, hh, ll);
-                *reinterpret_cast<uint32_t*>(&Vh[d * VPB + slot]) = hh;
-                *reinterpret_cast<uint32_t*>(&Vl[d * VPB + slot]) = ll;
+                *reinterpret_cast<uint32_t*>(&Vh[(s_d + 16 * q) * VPB + s_slot]) = hh;
+                *reinterpret_cast<uint32_t*>(&Vl[(s_d + 16 * q) * VPB + s_slot]) = ll;
             }
         }
         __syncthreads();
-        if (k0 + 32 < T) fetch(k0 + 32);
+        if (stager && k0 + 32 < T) fetch(k0 + 32);
+        if (relg) rrow_nxt = relg[min((k0 + 32) / n, n - 1)];
         // ---- S^T[key][query] (already scaled)
         f32x16 s;
 #pragma unroll
@@ -651,9 +683,10 @@ __global__ __launch_bounds__(NT, (NT == 256 ? SNF_ATT_WAVES : 1)) void k_attenti
         float rrow = 0.f;
         float4 rcol[4];
         if (relg) {  // registers 4g .. 4g+3 are the keys k0 + 8g + 4 half + {0..3}
-            rrow = relg[kh0];
+            rrow = rrow_cur;
+            rrow_cur = rrow_nxt;
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) rcol[g4] = *reinterpret_cast<const float4*>(relg + n + kw0 + 8 * g4 + 4 * half);
+            for (int g4 = 0; g4 < 4; ++g4) rcol[g4] = *reinterpret_cast<const float4*>(relc + kw0 + 8 * g4 + 4 * half);
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -927,9 +960,11 @@ static int attention_launch(const float* qkv, const float* rel, int Bw, int T, i
     static const int b3_env = 1;
     static const int direct_env = 1;
     const int rel_direct = (rel && direct_env && b3_env && b3_enabled() && (n % 32) == 0 && (((uintptr_t)rel) & 15) == 0) ? 1 : 0;
-    SNF_REQUIRE(!rph || (rpw && !rel && n > 0 && 2 * n - 1 <= 32 && T == n * n && b3_env && b3_enabled()),
-                "snf_attention_planes_rp: tables need T == n*n, 2n-1 <= 32 and the bf16-split gemm mode");
-    const size_t lds = ((rel && !rel_direct) || rph) ? (size_t)4 * 32 * (2 * n + 1) * sizeof(float) : 0;
+    SNF_REQUIRE(!rph || (rpw && !rel && n > 0 && 2 * n - 1 <= 32 && T == n * n && b3_env && b3_enabled() && (head_dim % 2) == 0 &&
+                         (((uintptr_t)rph | (uintptr_t)rpw | (uintptr_t)qkv) & 7) == 0),
+                "snf_attention_planes_rp: tables need T == n*n, 2n-1 <= 32, an even head dim, 8-byte aligned pointers and the bf16-split gemm mode");
+    const size_t lds = ((rel && !rel_direct) || rph) ? (size_t)4 * 32 * (2 * n + 1) * sizeof(float)
+                                                     : rel_direct ? (size_t)4 * 32 * (n + 4) * sizeof(float) : 0;
     SNF_REQUIRE(lds <= 100 * 1024, "snf_attention: grid side n=%d too large for the relative-position staging", n);
     // one 7-wave workgroup per (window, head) where two 4-wave ones would leave the second mostly empty (the 14 x 14 windows)
     const bool wide = out_hi != nullptr && T > 128 && T <= 224;
@@ -941,7 +976,8 @@ static int attention_launch(const float* qkv, const float* rel, int Bw, int T, i
         hipLaunchKernelGGL(k_attention<DB_>, grid, dim3(256), lds, (hipStream_t)stream, qkv, rel, T, heads, head_dim, n, scale, \
                            out);                                                                                            \
     } while (0)
-    if (b3_env && b3_enabled()) {
+    SNF_REQUIRE((long long)T * 3 * heads * head_dim < (1LL << 31), "snf_attention: T x 3C too large for 32-bit row offsets");
+    if (b3_env && b3_enabled() && (head_dim % 2) == 0 && ((uintptr_t)qkv & 7) == 0) {
 #define SNF_ATT_B3(DB_)                                                                                                     \
     do {                                                                                                                    \
         if (lds > 16 * 1024)                                                                                                \
@@ -949,7 +985,7 @@ static int attention_launch(const float* qkv, const float* rel, int Bw, int T, i
             (void)hipFuncSetAttribute((const void*)k_attention_b3<DB_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
             (void)hipFuncSetAttribute((const void*)k_attention_b3<DB_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         }                                                                                                                   \
-        if (out_hi && wide) {                                                                                               \
+        if (out_hi && wide) {                                                                                        \
             (void)hipFuncSetAttribute((const void*)k_attention_b3<DB_, true, 448>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
                                       (int)lds7);                                                                               \
             hipLaunchKernelGGL((k_attention_b3<DB_, true, 448>), dim3(1, Bw * heads), dim3(448), lds7, (hipStream_t)stream, qkv,   \

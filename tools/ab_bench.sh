@@ -6,7 +6,7 @@ cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 LIB=segment-anything-in-nerf_amd/lib/libsamnerf_hip.so
 cp $LIB /tmp/lib_keep.so
 for r in $(seq 1 ${ROUNDS:-3}); do
-  for v in A B; do
+  for v in ${VARIANTS:-A B}; do
     cp tools/ab/lib$v.so $LIB
     timeout 200 python bench.py --steps ${STEPS:-60} --warmup 10 --cpu-baseline-seconds 0 --other-workloads none 2>/dev/null | python -c "
 import sys,json; d=json.loads(sys.stdin.read()); k=d['kernel_ms_per_step_serial']

@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
 """Per-kernel HBM bytes per train step from tools/pmc_all.sh (all dispatches of the run are summed per kernel name and divided
-by the number of train iterations the run executed: warmup + 3 serial-replay + 1 + steps + 1 + min(steps, 20) fwd/bwd-only).
+by the number of train iterations the run executed: warmup + 3 serial-replay + 8 after the replay + 1 + steps + 1 +
+min(steps, 20) fwd/bwd-only).
 bytes = (2 * FETCH_SIZE + WRITE_SIZE) KiB (gfx950 corrections, see tools/pmc_traffic.py)."""
 import csv, re, sys, collections
 d = sys.argv[1]
-iters = float(sys.argv[2]) if len(sys.argv) > 2 else 3 + 3 + 1 + 6 + 1 + 6
+iters = float(sys.argv[2]) if len(sys.argv) > 2 else 3 + 3 + 8 + 1 + 6 + 1 + 6
 tot = collections.defaultdict(lambda: [0.0, 0.0, 0])
 for i, c in enumerate(("FETCH_SIZE", "WRITE_SIZE")):
     for r in csv.DictReader(open(f"{d}/pmcall_{c}/pmc_counter_collection.csv")):
