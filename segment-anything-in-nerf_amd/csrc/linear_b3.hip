@@ -170,21 +170,42 @@ __global__ __launch_bounds__(256, SNF_B3_ROWS_WAVES) void k_gemm_rows_b3(const f
     constexpr int BQ = BN / 4;                  // B as [K, Nc]: BQ col-quads x (256 / BQ) k rows per pass, NB passes
     const int b_jq = tid % BQ, b_k = tid / BQ;
     float4 av[4], bv[NB];
+    // `fetch` only issues loads at clamped (row, k): out-of-range quads are zeroed when the tile is STAGED, a trip later.  (The loaders
+    // zero right behind the load -- a select that needs the data: the wait for the NEXT tile's operands then stood in front of THIS
+    // tile's MFMAs and the one-tile prefetch hid nothing.  The data gradient's A operand keeps its loader: derivative modes per launch.)
+    auto ldq = [&](const float* __restrict__ Mx, int r, int c, int Rn, int Cn, int ld) {
+        return *reinterpret_cast<const float4*>(Mx + (size_t)(r < Rn ? r : Rn - 1) * ld + (c < Cn ? c : 0));
+    };
     auto fetch = [&](int k0) {
 #pragma unroll
-        for (int p = 0; p < 4; ++p)
-            av[p] = b3_load_a<DERIV>(A, Aux, row0 + a_r + 32 * p, k0 + a_kq * 4, M, K, lda, ldaux, act_in);
+        for (int p = 0; p < 4; ++p) {
+            if constexpr (DERIV) av[p] = b3_load_a<DERIV>(A, Aux, row0 + a_r + 32 * p, k0 + a_kq * 4, M, K, lda, ldaux, act_in);
+            else av[p] = ldq(A, row0 + a_r + 32 * p, k0 + a_kq * 4, M, K, lda);
+        }
         if constexpr (BT) {
 #pragma unroll
-            for (int p = 0; p < NB; ++p) bv[p] = b3_load_b(B, col0 + a_r + 32 * p, k0 + a_kq * 4, Nc, K, ldb);
+            for (int p = 0; p < NB; ++p) bv[p] = ldq(B, col0 + a_r + 32 * p, k0 + a_kq * 4, Nc, K, ldb);
         } else {
 #pragma unroll
-            for (int p = 0; p < NB; ++p) bv[p] = b3_load_b(B, k0 + b_k + (256 / BQ) * p, col0 + b_jq * 4, K, Nc, ldb);
+            for (int p = 0; p < NB; ++p) bv[p] = ldq(B, k0 + b_k + (256 / BQ) * p, col0 + b_jq * 4, K, Nc, ldb);
         }
     };
     fetch(0);
     for (int k0 = 0; k0 < K; k0 += B3_BK) {
         __syncthreads();
+        {
+            const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (!DERIV) {
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+                    if (!(row0 + a_r + 32 * p < M && k0 + a_kq * 4 < K)) av[p] = z4;
+            }
+#pragma unroll
+            for (int p = 0; p < NB; ++p) {
+                const bool ok = BT ? (col0 + a_r + 32 * p < Nc && k0 + a_kq * 4 < K) : (k0 + b_k + (256 / BQ) * p < K && col0 + b_jq * 4 < Nc);
+                if (!ok) bv[p] = z4;
+            }
+        }
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             uint2 hi, lo;
@@ -218,7 +239,7 @@ __global__ __launch_bounds__(256, SNF_B3_ROWS_WAVES) void k_gemm_rows_b3(const f
             }
         }
         __syncthreads();
-        if (k0 + B3_BK < K) fetch(k0 + B3_BK);
+        if (!DERIV || k0 + B3_BK < K) fetch(k0 + B3_BK);  // (forward: unconditional -- clamped addresses, the surplus tile is never staged)
 #pragma unroll
         for (int ks = 0; ks < B3_BK / 16; ++ks) {
             const int ko = ks * 16 + half * 8;
@@ -255,6 +276,12 @@ __global__ __launch_bounds__(256, SNF_B3_ROWS_WAVES) void k_gemm_rows_b3(const f
 // the ROWS, so both operands are staged transposed ([o][k = row] and [i][k = row] bf16 planes): a thread loads two consecutive
 // rows of four columns and writes four packed (k, k+1) pairs per plane.  64 x 64 output tile, waves 2 x 2, 32 rows per trip;
 // partial sums of a row chunk are added to dW with fp32 atomics (as the fp32 kernel does).
+// AM: how act'(Y) arrives -- 0 none, 1 the activations Y; both with row-major X, and their `fetch` only ISSUES the loads (raw dY, Y, X
+// quads of rows clamped into the chunk): the derivative, the bounds and the split happen when the tile is staged, a trip later.  -1: the
+// general loaders (level-major X, any combination decided per launch) -- every load behind a launch-uniform branch with its first use
+// right after it: 40 basic blocks and 33 waits per 32-row trip, the four to six loads of a trip going out one after the other IN FRONT
+// of the trip's MFMAs.
+template <int AM>
 __global__ __launch_bounds__(256) void k_gemm_wgrad_b3(const float* __restrict__ dY, const float* __restrict__ Y,
                                                        const float* __restrict__ X, int N, int I, int O, int lddy, int ldy,
                                                        int ldx, int act, int rows_per_block, float* __restrict__ dW,
@@ -292,19 +319,52 @@ __global__ __launch_bounds__(256) void k_gemm_wgrad_b3(const float* __restrict__
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
     float bsum[4] = {0.f, 0.f, 0.f, 0.f};
     if (tid < 64) bs[tid] = 0.f;
-    float4 av[2], bv[2];
+    float4 av[2], bv[2], yv[AM == 1 ? 2 : 1];
+    const int oq = o0 + q * 4, iq = i0 + q * 4;
+    const bool o_in = oq < O, i_in = iq < I;
+    const size_t a_col = o_in ? oq : 0, b_col = i_in ? iq : 0;
     auto fetch = [&](int n0) {
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             const int n = n0 + 2 * kp + p;
-            av[p] = b3_load_a<true>(dY, Y, n, o0 + q * 4, n_end, O, lddy, ldy, act);
-            bv[p] = ldx < 0 ? b3_load_b_planar8(X, n, i0 + q * 4, n_end, I, N) : b3_load_b(X, n, i0 + q * 4, n_end, I, ldx);
+            if constexpr (AM < 0) {
+                av[p] = b3_load_a<true>(dY, Y, n, oq, n_end, O, lddy, ldy, act);
+                bv[p] = ldx < 0 ? b3_load_b_planar8(X, n, iq, n_end, I, N) : b3_load_b(X, n, iq, n_end, I, ldx);
+            } else {
+                const size_t nc = (size_t)min(n, n_end - 1);
+                av[p] = *reinterpret_cast<const float4*>(dY + nc * lddy + a_col);
+                if constexpr (AM == 1) yv[p] = *reinterpret_cast<const float4*>(Y + nc * ldy + a_col);
+                bv[p] = *reinterpret_cast<const float4*>(X + nc * ldx + b_col);
+            }
         }
     };
     fetch(n_begin);
     for (int n0 = n_begin; n0 < n_end; n0 += B3_BK) {
         __syncthreads();
         {
+            if constexpr (AM >= 0) {  // the rows fetched for THIS trip: derivative and bounds now
+                if constexpr (AM == 1) {
+                    if (act == SNF_ACT_RELU) {  // (one launch-uniform branch around both rows, not one per element)
+#pragma unroll
+                        for (int p = 0; p < 2; ++p) {
+                            av[p].x = yv[p].x > 0.f ? av[p].x : 0.f; av[p].y = yv[p].y > 0.f ? av[p].y : 0.f;
+                            av[p].z = yv[p].z > 0.f ? av[p].z : 0.f; av[p].w = yv[p].w > 0.f ? av[p].w : 0.f;
+                        }
+                    } else {
+#pragma unroll
+                        for (int p = 0; p < 2; ++p) {
+                            av[p].x *= b3_act_deriv(yv[p].x, act); av[p].y *= b3_act_deriv(yv[p].y, act);
+                            av[p].z *= b3_act_deriv(yv[p].z, act); av[p].w *= b3_act_deriv(yv[p].w, act);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    const bool row_in = n0 + 2 * kp + p < n_end;
+                    if (!(row_in && o_in)) av[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (!(row_in && i_in)) bv[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
             const float a0[4] = {av[0].x, av[0].y, av[0].z, av[0].w}, a1[4] = {av[1].x, av[1].y, av[1].z, av[1].w};
             const float b0[4] = {bv[0].x, bv[0].y, bv[0].z, bv[0].w}, b1[4] = {bv[1].x, bv[1].y, bv[1].z, bv[1].w};
 #pragma unroll
@@ -320,7 +380,7 @@ __global__ __launch_bounds__(256) void k_gemm_wgrad_b3(const float* __restrict__
             }
         }
         __syncthreads();
-        if (n0 + B3_BK < n_end) fetch(n0 + B3_BK);
+        if (AM >= 0 || n0 + B3_BK < n_end) fetch(n0 + B3_BK);  // (AM >= 0: unconditional, rows clamped -- past the end the last row again)
 #pragma unroll
         for (int ks = 0; ks < B3_BK / 16; ++ks) {
             const int ko = ks * 16 + half * 8;
@@ -364,6 +424,12 @@ constexpr int WF_T = 512;
 #endif
 #ifndef SNF_WF_CHUNKS
 #define SNF_WF_CHUNKS 256  // row chunks (= workgroups, = partial sums P[chunk][O][I]) of the full-width weight gradient
+#endif
+#ifndef SNF_WGRAD_RAW_LOADS
+#define SNF_WGRAD_RAW_LOADS 1  // 0: the tiled weight gradient through its general loaders (A/B)
+#endif
+#ifndef SNF_WF_BITS_KERNEL
+#define SNF_WF_BITS_KERNEL 1  // 0: the general kernel also for the train step's case (A/B, tests)
 #endif
 #ifndef SNF_WF_RSPLIT
 #define SNF_WF_RSPLIT 4    // k_wgrad_full_reduce: the chunks of one output element are summed by this many workgroups
@@ -462,6 +528,134 @@ __global__ __launch_bounds__(WF_T) void k_wgrad_full_b3(const float* __restrict_
     for (int n0 = n_begin; n0 < n_end; n0 += 32) {
         trip(n0, 0, av[0], bv[0]);
         if (n0 + 16 < n_end) trip(n0 + 16, 1, av[1], bv[1]);
+    }
+    float* __restrict__ Pw = P + (size_t)blockIdx.x * O * I;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int i = i_base + 32 * t + li;
+            if (t < nt && i < I) {
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int o = 64 * wm + 32 * u + (reg & 3) + 8 * (reg >> 2) + 4 * half;
+                    if (o < O) Pw[(size_t)o * I + i] = acc[u][t][reg];
+                }
+            }
+        }
+}
+
+// The same kernel for the case the train step launches (the head's first layer: dY rows = rscale[n] * dYbar[n >> rshift][:] masked by
+// ReLU bits, X level-major [I/8][N][8], whole 16-row trips, O and I multiples of 32), with the loader taken apart: `fetch` only ISSUES
+// loads -- one dYbar row quad (rows 2kp and 2kp+1 share their group: rshift >= 1), the two rows' scales as one 8-byte load, two mask
+// bytes, two X quads -- and `stage`, a trip later, scales, masks and splits.  In the general kernel above every load sits behind a
+// launch-uniform branch (rscale? bits? level-major?) with its first use right behind it: 135 basic blocks and 84 waits per pair of trips,
+// i.e. the six loads of a trip went out one after the other, each waiting for the previous one (a trip took ~8 000 cycles for ~800 of
+// matrix work; requesting rows two trips ahead could not help).  Waves whose 32 columns lie past I skip the X half (wave-uniform).
+__global__ __launch_bounds__(WF_T) void k_wgrad_full_b3_bits(const float* __restrict__ dYbar, const uint8_t* __restrict__ bits,
+                                                             const float* __restrict__ X, int N, int I, int O, int lddy, int ldbits,
+                                                             int rows_per_wg, float* __restrict__ P,
+                                                             const float* __restrict__ rscale, int rshift) {
+    __shared__ __attribute__((aligned(16))) uint16_t Ah[2][256 * WF_PITCH];
+    __shared__ __attribute__((aligned(16))) uint16_t Al[2][256 * WF_PITCH];
+    __shared__ __attribute__((aligned(16))) uint16_t Bh[2][256 * WF_PITCH];
+    __shared__ __attribute__((aligned(16))) uint16_t Bl[2][256 * WF_PITCH];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, half = lane >> 5, wm = wave >> 1, wn = wave & 1;
+    const int n_begin = blockIdx.x * rows_per_wg, n_end = min(N, n_begin + rows_per_wg);  // (n_end - n_begin: a multiple of 16)
+    const int kp = tid & 7, q = tid >> 3;
+    const int col = q * 4;
+    const bool a_on = col < O, b_on = col < I;  // wave-uniform (a wave covers 32 columns; O, I multiples of 32)
+    const int tiles_i = I >> 5, nt = (tiles_i + 1) >> 1, i_base = 32 * nt * wn;
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[u][t][i] = 0.f;
+    // lane-constant parts of the addresses (32-bit element / byte offsets; the host checks the ranges)
+    const uint32_t a_col = (uint32_t)(a_on ? col : 0);
+    const uint32_t m_col = (uint32_t)((a_on ? col : 0) >> 3);
+    const int m_shift = col & 4;
+    const uint32_t x_off = (uint32_t)(((size_t)((b_on ? col : 0) >> 3) * N) * 8 + (col & 7));  // + 8 n
+    struct Raw { float4 a; float2 s; uint32_t m0, m1; float4 b0, b1; };
+    Raw raw[2];
+    auto fetch = [&](int n0, Raw& r) {  // rows n0 + 2 kp, + 1 (inside [n_begin, n_end): whole trips)
+        const uint32_t n = (uint32_t)(n0 + 2 * kp);
+        r.a = *reinterpret_cast<const float4*>(dYbar + ((size_t)(n >> rshift) * lddy + a_col));
+        r.s = *reinterpret_cast<const float2*>(rscale + n);
+        r.m0 = bits[(size_t)n * ldbits + m_col];
+        r.m1 = bits[(size_t)(n + 1) * ldbits + m_col];
+        r.b0 = *reinterpret_cast<const float4*>(X + (x_off + 8u * n));
+        r.b1 = *reinterpret_cast<const float4*>(X + (x_off + 8u * n + 8u));
+    };
+    auto stage = [&](int buf, const Raw& r) {
+        if (a_on) {
+            const float g[4] = {r.a.x, r.a.y, r.a.z, r.a.w};
+            const uint32_t m0 = r.m0 >> m_shift, m1 = r.m1 >> m_shift;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float a0 = ((m0 >> c) & 1u) ? g[c] * r.s.x : 0.f;  // (the product, then the mask: the bits of the general loader)
+                const float a1 = ((m1 >> c) & 1u) ? g[c] * r.s.y : 0.f;
+                uint32_t h, l;
+                split2(a0, a1, h, l);  // rows (2kp, 2kp+1) of column col + c -> k positions (2kp, 2kp+1)
+                *reinterpret_cast<uint32_t*>(&Ah[buf][(col + c) * WF_PITCH + 2 * kp]) = h;
+                *reinterpret_cast<uint32_t*>(&Al[buf][(col + c) * WF_PITCH + 2 * kp]) = l;
+            }
+        }
+        if (b_on) {
+            const float b0[4] = {r.b0.x, r.b0.y, r.b0.z, r.b0.w}, b1[4] = {r.b1.x, r.b1.y, r.b1.z, r.b1.w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                uint32_t h, l;
+                split2(b0[c], b1[c], h, l);
+                *reinterpret_cast<uint32_t*>(&Bh[buf][(col + c) * WF_PITCH + 2 * kp]) = h;
+                *reinterpret_cast<uint32_t*>(&Bl[buf][(col + c) * WF_PITCH + 2 * kp]) = l;
+            }
+        }
+    };
+    const int last = n_end - 16;  // first row of the last trip; fetches past it re-read it (unconditional loads, results unused)
+    fetch(n_begin, raw[0]);
+    fetch(min(n_begin + 16, last), raw[1]);
+    stage(0, raw[0]);
+    __syncthreads();
+    fetch(min(n_begin + 32, last), raw[0]);
+    const bool m_on[2] = {64 * wm < O, 64 * wm + 32 < O};
+    // one trip: fragments of copy `buf`; the NEXT trip's rows (register set r, requested two trips ago) split into the other copy; the
+    // request for the trip after that into the freed set; this trip's MFMAs; barrier
+    auto trip = [&](int n0, int buf, Raw& r) {
+        bf16x8 bh[4], bl[4], ah[2], al[2];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            bh[t] = *reinterpret_cast<const bf16x8*>(&Bh[buf][(i_base + 32 * t + li) * WF_PITCH + 8 * half]);
+            bl[t] = *reinterpret_cast<const bf16x8*>(&Bl[buf][(i_base + 32 * t + li) * WF_PITCH + 8 * half]);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            ah[u] = *reinterpret_cast<const bf16x8*>(&Ah[buf][(64 * wm + 32 * u + li) * WF_PITCH + 8 * half]);
+            al[u] = *reinterpret_cast<const bf16x8*>(&Al[buf][(64 * wm + 32 * u + li) * WF_PITCH + 8 * half]);
+        }
+        stage(buf ^ 1, r);  // (past the last trip: the last trip's rows once more, into the copy nobody reads again)
+        fetch(min(n0 + 48, last), r);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (m_on[u]) {  // wave-uniform
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    if (t < nt && i_base + 32 * t < I) {  // wave-uniform
+                        acc[u][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[u], bh[t], acc[u][t], 0, 0, 0);
+                        acc[u][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[u], bl[t], acc[u][t], 0, 0, 0);
+                        acc[u][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[u], bh[t], acc[u][t], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    };
+    for (int n0 = n_begin; n0 < n_end; n0 += 32) {
+        trip(n0, 0, raw[1]);
+        if (n0 + 16 < n_end) trip(n0 + 16, 1, raw[0]);
     }
     float* __restrict__ Pw = P + (size_t)blockIdx.x * O * I;
 #pragma unroll
@@ -1052,8 +1246,19 @@ int snf::b3_try_bwd_weight_full(const float* dY, const float* Y, const float* X,
         return 0;
     const int rows = wf_rows_per_wg(N), chunks = ceil_div(N, rows);
     float* P = (float*)workspace;
-    hipLaunchKernelGGL(k_wgrad_full_b3, dim3(chunks), dim3(WF_T), 0, (hipStream_t)stream, dY, Y, X, N, I, O, lddy, ldy, ldx, act,
-                       rows, P, rscale, rgroup, aux_bits);
+    // the train step's case (grouped rows, mask bits, level-major X, whole trips): the kernel whose loads are issued together
+    const bool bits_case = SNF_WF_BITS_KERNEL && rscale != nullptr && aux_bits && act == SNF_ACT_RELU && ldx == -8 && rgroup >= 2 &&
+                           (rgroup & (rgroup - 1)) == 0 && (N % 16) == 0 && (O % 32) == 0 && (I % 32) == 0 &&
+                           ((uintptr_t)rscale & 7) == 0 && (long long)I * N < (1LL << 31);
+    if (bits_case) {
+        int rshift = 0;
+        while ((1 << rshift) < rgroup) ++rshift;
+        hipLaunchKernelGGL(k_wgrad_full_b3_bits, dim3(chunks), dim3(WF_T), 0, (hipStream_t)stream, dY, (const uint8_t*)Y, X, N, I, O,
+                           lddy, ldy, rows, P, rscale, rshift);
+    } else {
+        hipLaunchKernelGGL(k_wgrad_full_b3, dim3(chunks), dim3(WF_T), 0, (hipStream_t)stream, dY, Y, X, N, I, O, lddy, ldy, ldx, act,
+                           rows, P, rscale, rgroup, aux_bits);
+    }
     hipLaunchKernelGGL(k_wgrad_full_reduce, dim3(ceil_div(O * I, 1024), SNF_WF_RSPLIT), dim3(256), 0, (hipStream_t)stream, P, chunks, O * I, dW);
     return 1;
 }
@@ -1073,7 +1278,15 @@ int snf::b3_try_bwd_weight(const float* dY, const float* Y, const float* X, int 
     chunks = ceil_div(N, rows);
     static const int xcd_order = 0;
     const int chunks8 = (chunks + 7) / 8 * 8;  // whole rounds of the 8 XCDs (surplus workgroups exit at once)
-    hipLaunchKernelGGL(k_gemm_wgrad_b3, dim3(to * ti * chunks8), dim3(256), 0, (hipStream_t)stream, dY, Y, X, N, I, O, lddy, ldy,
-                       ldx, act, rows, dW, dbias, to, ti, chunks, xcd_order);
+    const int am = (ldx > 0 && SNF_WGRAD_RAW_LOADS) ? (act == SNF_ACT_NONE ? 0 : 1) : -1;
+    if (am == 0)
+        hipLaunchKernelGGL(k_gemm_wgrad_b3<0>, dim3(to * ti * chunks8), dim3(256), 0, (hipStream_t)stream, dY, Y, X, N, I, O, lddy, ldy,
+                           ldx, act, rows, dW, dbias, to, ti, chunks, xcd_order);
+    else if (am == 1)
+        hipLaunchKernelGGL(k_gemm_wgrad_b3<1>, dim3(to * ti * chunks8), dim3(256), 0, (hipStream_t)stream, dY, Y, X, N, I, O, lddy, ldy,
+                           ldx, act, rows, dW, dbias, to, ti, chunks, xcd_order);
+    else
+        hipLaunchKernelGGL(k_gemm_wgrad_b3<-1>, dim3(to * ti * chunks8), dim3(256), 0, (hipStream_t)stream, dY, Y, X, N, I, O, lddy, ldy,
+                           ldx, act, rows, dW, dbias, to, ti, chunks, xcd_order);
     return 1;
 }
