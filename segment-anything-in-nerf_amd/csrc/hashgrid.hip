@@ -1593,6 +1593,18 @@ __global__ __launch_bounds__(HG_FX_T) void k_hg_reduce_fx(const float* __restric
     for (int r0 = tid; r0 < rpb; r0 += HG_FX_T * RU) {
         float gg[RU][F], pp[RU][F], mm[RU][F], vv[RU][F];
         bool on[RU], nz[RU];
+        // fused step: the optimizer state of all RU rows is requested FIRST (unconditional, the row clamped into the bucket) and the
+        // sums come out of LDS under those loads.  With the loads inside the per-row `if (on)` every row's three loads were followed by
+        // their own s_waitcnt vmcnt(0): four memory latencies in a row per thread, after the LDS conversion instead of under it.
+        if (fuse) {
+#pragma unroll
+            for (int j = 0; j < RU; ++j) {
+                const int rc = min(r0 + HG_FX_T * j, rpb - 1);
+                load_row<F>(adam.p + base + (size_t)rc * F, pp[j]);
+                load_row<F>(adam.m + base + (size_t)rc * F, mm[j]);
+                load_row<F>(adam.v + base + (size_t)rc * F, vv[j]);
+            }
+        }
 #pragma unroll
         for (int j = 0; j < RU; ++j) {
             const int r = r0 + HG_FX_T * j;
@@ -1609,13 +1621,7 @@ __global__ __launch_bounds__(HG_FX_T) void k_hg_reduce_fx(const float* __restric
                     gg[j][f] = isbad ? __uint_as_float(0x7FC00000u) : __ll2float_rn(q) * inv;
                     nz[j] = nz[j] || (q != 0) || isbad;
                 }
-                if (fuse) {
-                    load_row<F>(adam.p + base + (size_t)r * F, pp[j]);
-                    load_row<F>(adam.m + base + (size_t)r * F, mm[j]);
-                    load_row<F>(adam.v + base + (size_t)r * F, vv[j]);
-                } else if (nz[j]) {
-                    load_row<F>(slab + (size_t)r * F, pp[j]);  // the running gradient of a level left to the caller's optimizer
-                }
+                if (!fuse && nz[j]) load_row<F>(slab + (size_t)r * F, pp[j]);  // the running gradient of a level left to the caller's optimizer
             }
         }
 #pragma unroll

@@ -866,48 +866,57 @@ __global__ __launch_bounds__(WG_T) __attribute__((amdgpu_waves_per_eu(NH == 1 ? 
     // requested while this tile is worked on.  Affordable since the data-gradient chain left the fp32 matrix instruction (428 of 512
     // registers instead of 491; before, the 16-register row spilled 48).
     constexpr bool PFB = RC && NH == 2 && DG3 && (SNF_CHAIN_PREFETCH & 2) != 0;
-    const bool pfz = PFB && outp <= 4;
-    auto dz_raw = [&](long long tile_, int o) {  // pre-activation output gradient of sample (tile_, li), output o
+    // Pre-activation output gradients of sample (tile_, li) for the outputs o_of(0 .. cnt-1) of this lane (cnt wave-uniform, <= 16): ALL
+    // loads first -- unconditional, the output index clamped into the row, the density column's separate tensor by a pointer select --
+    // then the sigmoid derivative and the bounds.  One guarded load per output with its use behind it compiled to one basic block and one
+    // s_waitcnt vmcnt(0) per output: 8 (colour net: 4 gradients + 4 activations) to 16 (base net) memory latencies in a row at the top of
+    // every 32-sample tile, in a wave that is alone on its SIMD.
+    // (GB outputs per call: with sixteen in flight the one-hidden-layer instances -- two waves per SIMD, 256 registers -- spilled 30-70
+    //  registers, with eight still 11-41; four there, eight with two hidden layers)
+    constexpr int GB = NH == 1 ? 4 : 8;
+    auto dz_gather = [&](long long tile_, int i0, int cnt, auto o_of, float (&dz)[GB]) {
         const long long s_ = tile_ * 32 + li;
         const bool ok_ = s_ < N;
         const long long sc_ = ok_ ? s_ : N - 1;
-        float dz = 0.f;
-        if (o < out && ok_) {  // rows beyond N contribute nothing to the weight gradients
-            dz = (o == 0 && dY0 != nullptr) ? dY0[sc_] : dY[sc_ * lddy + dy_col_off + o];
-            if (out_act == SNF_ACT_SIGMOID) {
-                const float yv = Yout[sc_ * ldy + o];
-                dz *= yv * (1.f - yv);
+        float yr[GB];
+#pragma unroll
+        for (int j = 0; j < GB; ++j) {
+            dz[j] = 0.f;
+            yr[j] = 0.f;
+            if (i0 + j < cnt) {  // wave-uniform
+                const int o = o_of(i0 + j), oc = o < out ? o : out - 1;
+                const float* __restrict__ src = (o == 0 && dY0 != nullptr) ? dY0 + sc_ : dY + (sc_ * lddy + dy_col_off + oc);
+                dz[j] = *src;
             }
         }
-        return dz;
+        if (out_act == SNF_ACT_SIGMOID) {
+#pragma unroll
+            for (int j = 0; j < GB; ++j) {
+                if (i0 + j < cnt) {
+                    const int o = o_of(i0 + j), oc = o < out ? o : out - 1;
+                    yr[j] = Yout[sc_ * ldy + oc];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < GB; ++j) dz[j] *= yr[j] * (1.f - yr[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < GB; ++j) {
+            const bool live = i0 + j < cnt && o_of(i0 + j) < out && ok_;  // rows beyond N contribute nothing to the weight gradients
+            dz[j] = live ? dz[j] : 0.f;
+        }
     };
     f32x16 xn;
-    float dzn[4] = {0.f, 0.f, 0.f, 0.f};
-    if (PFB && tile0 < ntiles) {
-        load_x(tile0, xn);
-        if (pfz && half == 0) {
-#pragma unroll
-            for (int o = 0; o < 4; ++o) dzn[o] = dz_raw(tile0, o);
-        }
-    }
+    if (PFB && tile0 < ntiles) load_x(tile0, xn);
     for (long long tile = tile0; tile < ntiles; tile += tstride) {
         const long long s = tile * 32 + li;
         const bool ok = s < N;
         const long long sc = ok ? s : N - 1;
         f32x16 xr[1];  // RC: this lane's half of the input row (features half*16 .. +15), pad columns zero as in the forward
-        float dzc[4] = {0.f, 0.f, 0.f, 0.f};
         if constexpr (RC) {
             if (PFB) {
                 xr[0] = xn;
-#pragma unroll
-                for (int o = 0; o < 4; ++o) dzc[o] = dzn[o];
-                if (tile + tstride < ntiles) {
-                    load_x(tile + tstride, xn);
-                    if (pfz && half == 0) {
-#pragma unroll
-                        for (int o = 0; o < 4; ++o) dzn[o] = dz_raw(tile + tstride, o);
-                    }
-                }
+                if (tile + tstride < ntiles) load_x(tile + tstride, xn);
             } else {
                 load_x(tile, xr[0]);
             }
@@ -928,27 +937,45 @@ __global__ __launch_bounds__(WG_T) __attribute__((amdgpu_waves_per_eu(NH == 1 ? 
         };
         // ---- dZ, dLast^T[k][s] = sum_o Wout[o][k] dZ^T[o][s]; dZ^T goes to its LDS matrix on the way
         f32x16 dl[2] = {zero16(), zero16()};
-        auto dz_of = [&](int o) { return dz_raw(tile, o); };
         if constexpr (DG3) {
             f32x16 dzv[1];  // this lane's 16 outputs o = half * 16 + i (LIN k slots)
+            const int cnt = outp < 16 ? outp : 16;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int o = half * 16 + i;
-                dzv[0][i] = 0.f;
-                if (o < outp) {
-                    dzv[0][i] = (pfz && i < 4) ? (half == 0 ? dzc[i < 4 ? i : 0] : 0.f) : dz_of(o);
-                    Z[o * WG_TP + li] = dzv[0][i];
+            for (int g = 0; g < 16 / GB; ++g) {
+                float dzr[GB];
+                if (GB * g < cnt) {  // wave-uniform
+                    dz_gather(tile, GB * g, cnt, [&](int i) { return half * 16 + i; }, dzr);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < GB; ++j) dzr[j] = 0.f;
+                }
+#pragma unroll
+                for (int j = 0; j < GB; ++j) {
+                    const int o = half * 16 + GB * g + j;
+                    dzv[0][GB * g + j] = dzr[j];
+                    if (o < outp) Z[o * WG_TP + li] = dzr[j];
                 }
             }
             mc_layer_b3<1, 2, true>(poh, pol, MC_BP32, dzv, dl, li, half);
         } else {
-            for (int st = 0; st < hsteps; ++st) {
-                const int o = half * hsteps + st;
-                const float dz = dz_of(o);
-                if (o < 32) Z[o * WG_TP + li] = dz;
-                const int oc = o < 32 ? o : 31;
-                dl[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(cw.wo[oc * MC_P1 + li], dz, dl[0], 0, 0, 0);
-                dl[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(cw.wo[oc * MC_P1 + 32 + li], dz, dl[1], 0, 0, 0);
+#pragma unroll 1
+            for (int g = 0; g < 16 / GB; ++g) {  // (a real loop: unrolled, the sixteen steps' weight reads were hoisted and spilled)
+                if (GB * g < hsteps) {  // wave-uniform
+                    float dzr[GB];
+                    dz_gather(tile, GB * g, hsteps, [&](int st) { return half * hsteps + st; }, dzr);
+#pragma unroll
+                    for (int j = 0; j < GB; ++j) {
+                        const int st = GB * g + j;
+                        if (st < hsteps) {  // wave-uniform
+                            const int o = half * hsteps + st;
+                            const float dz = dzr[j];
+                            if (o < 32) Z[o * WG_TP + li] = dz;
+                            const int oc = o < 32 ? o : 31;
+                            dl[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(cw.wo[oc * MC_P1 + li], dz, dl[0], 0, 0, 0);
+                            dl[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(cw.wo[oc * MC_P1 + 32 + li], dz, dl[1], 0, 0, 0);
+                        }
+                    }
+                }
             }
         }
         WG_LDS_ORDER();
