@@ -639,19 +639,25 @@ __global__ __launch_bounds__(NT, (NT == 256 ? SNF_ATT_WAVES : 1)) void k_attenti
     for (int k0 = 0; k0 < T; k0 += 32) {
         __syncthreads();  // previous tile consumed
         if (stager) {
+            // (pad dims and keys past T are zeroed HERE, where the values are consumed: a select right behind the load made the fetch
+            //  wait for every load as it issued it; one wave-uniform branch around all passes, not one per pass)
+            if (DP > hd) {
 #pragma unroll
-            for (int q = 0; q < SQ; ++q) {
-                // (pad dims and keys past T are zeroed HERE, where the values are consumed: a select right behind the load made the fetch
-                //  wait for every load as it issued it)
-                if (16 * q + 16 > hd) {  // wave-uniform: only the passes that reach past the head dim
+                for (int q = 0; q < SQ; ++q) {
                     if (2 * (s_c + 8 * q) >= hd) kreg[q] = make_float2(0.f, 0.f);
                     if (s_d + 16 * q >= hd) vreg[q] = make_float2(0.f, 0.f);
                 }
-                if (k0 + 32 > T) {  // wave-uniform: only the last tile of a T that is no multiple of 32
+            }
+            if (k0 + 32 > T) {  // only the last tile of a T that is no multiple of 32
+#pragma unroll
+                for (int q = 0; q < SQ; ++q) {
                     if (k0 + s_kr >= T) kreg[q] = make_float2(0.f, 0.f);
                     if (k0 + 2 * s_kp2 >= T) vreg[q].x = 0.f;
                     if (k0 + 2 * s_kp2 + 1 >= T) vreg[q].y = 0.f;
                 }
+            }
+#pragma unroll
+            for (int q = 0; q < SQ; ++q) {
                 uint32_t hh, ll;
                 at_split2(kreg[q].x, kreg[q].y, hh, ll);
                 *reinterpret_cast<uint32_t*>(&Kh[s_kr * KPB + 2 * (s_c + 8 * q)]) = hh;
@@ -680,29 +686,35 @@ __global__ __launch_bounds__(NT, (NT == 256 ? SNF_ATT_WAVES : 1)) void k_attenti
         float m_tile = -INFINITY;
         const bool ragged = k0 + 32 > T;
         const int kh0 = has_rel ? k0 / n : 0, kw0 = has_rel ? k0 - kh0 * n : 0;
-        float rrow = 0.f;
-        float4 rcol[4];
+        // position bias of the lane's 16 scores, gathered FIRST (one launch-uniform branch around all 16, not one per score: the per-score
+        // `if (relq)` left 16 basic blocks, each waiting for its own two LDS reads)
+        float bias[16];
         if (relg) {  // registers 4g .. 4g+3 are the keys k0 + 8g + 4 half + {0..3}
-            rrow = rrow_cur;
+            const float rrow = rrow_cur;
             rrow_cur = rrow_nxt;
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) rcol[g4] = *reinterpret_cast<const float4*>(relc + kw0 + 8 * g4 + 4 * half);
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const float4 c4 = *reinterpret_cast<const float4*>(relc + kw0 + 8 * g4 + 4 * half);
+                bias[4 * g4] = rrow + c4.x; bias[4 * g4 + 1] = rrow + c4.y; bias[4 * g4 + 2] = rrow + c4.z; bias[4 * g4 + 3] = rrow + c4.w;
+            }
+        } else if (relq) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                // key -> (row, column) of the n x n grid with one multiply (exact for key < 2^16, n < 2^8: inv_n = 2^16 / n rounded
+                // up); the while loop this replaces cost ~10 VALU instructions per element
+                const int key = k0 + vrow(r, half);
+                const int kc = key < T ? key : T - 1;
+                const int kh = (int)(((uint32_t)kc * inv_n) >> 16), kw = kc - kh * n;
+                bias[r] = relq[kh] + relq[n + kw];
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) bias[r] = 0.f;
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int key = k0 + vrow(r, half);
-            float v = s[r];
-            if (relg) {
-                const float4 c4 = rcol[r >> 2];
-                v += rrow + ((r & 3) == 0 ? c4.x : (r & 3) == 1 ? c4.y : (r & 3) == 2 ? c4.z : c4.w);
-            }
-            if (relq) {
-                // key -> (row, column) of the n x n grid with one multiply (exact for key < 2^16, n < 2^8: inv_n = 2^16 / n rounded
-                // up); the while loop this replaces cost ~10 VALU instructions per element
-                const int kc = key < T ? key : T - 1;
-                const int kh = (int)(((uint32_t)kc * inv_n) >> 16), kw = kc - kh * n;
-                v += relq[kh] + relq[n + kw];
-            }
+            float v = s[r] + bias[r];
             if (ragged) v = key < T ? v : -INFINITY;  // (only the last tile of a T that is no multiple of 32 has keys past T)
             s[r] = v;
             m_tile = fmaxf(m_tile, v);
