@@ -22,62 +22,87 @@ namespace snf {
 
 constexpr int PC_MAX_KK = 25;  // k <= 5
 
-// One workgroup per output row (pixel): the k*k neighbour rows are read coalesced into LDS, the C*k*k outputs leave as
-// one contiguous stream.
-__global__ __launch_bounds__(256) void k_patch_unfold(const float* __restrict__ x, int p, int C, int k, float* __restrict__ col) {
-    extern __shared__ float nb[];  // [k*k][C]
-    const int row = blockIdx.x, pp = p * p, kk = k * k, h = k / 2;
-    const int patch = row / pp, y = (row % pp) / p, xx = row % p;
-    for (int e = threadIdx.x; e < kk * C; e += 256) {
-        const int t = e / C, c = e - t * C;
-        const int iy = y + t / k - h, ix = xx + t % k - h;
-        nb[e] = (iy >= 0 && iy < p && ix >= 0 && ix < p) ? x[((size_t)patch * pp + iy * p + ix) * C + c] : 0.f;
-    }
+// All four kernels are templated on the kernel size (KT = 3: the head's; 0: k at run time): with k, k*k and C as run-time divisors every
+// element paid two or three integer divisions (~25 VALU instructions each) -- the "pure data movement" was 70-450 instructions per
+// element and the four launches took 0.09 ms of the SAM stream's serial chain.  Row / tap loops are nested instead of divided out, the
+// channel loop is the lanes', and every sum keeps its order (bit-identical results).
+
+// One workgroup per (patch, image row of the patch): the patch's p*p rows of x [C] go into LDS (pitch C + 1: the transposing reads below
+// hit distinct banks), then the C*k*k outputs of the workgroup's p pixels leave as contiguous streams.
+template <int KT>
+__global__ __launch_bounds__(256) void k_patch_unfold(const float* __restrict__ x, int p, int C, int krt, float* __restrict__ col) {
+    extern __shared__ float nb[];  // [p*p][C + 1]
+    const int k = KT > 0 ? KT : krt, kk = k * k, h = k / 2, pp = p * p, CP = C + 1;
+    const int patch = blockIdx.x;
+    const float* __restrict__ xp = x + (size_t)patch * pp * C;
+    for (int r = 0; r < pp; ++r)
+        for (int c = threadIdx.x; c < C; c += 256) nb[r * CP + c] = xp[(size_t)r * C + c];
     __syncthreads();
-    float* __restrict__ o = col + (size_t)row * C * kk;
-    for (int e = threadIdx.x; e < kk * C; e += 256) {
-        const int c = e / kk, t = e - c * kk;
-        o[e] = nb[t * C + c];
+    const int n = C * kk;
+    // blockIdx.y: the image row of the patch this workgroup writes (p pixels); every workgroup stages the whole patch (L2 hits)
+    for (int r = blockIdx.y * p; r < (int)(blockIdx.y + 1) * p; ++r) {
+        const int y = r / p, xx = r - y * p;
+        float* __restrict__ o = col + ((size_t)patch * pp + r) * n;
+        for (int e = threadIdx.x; e < n; e += 256) {
+            const int c = e / kk, t = e - c * kk;  // (KT > 0: a multiply and a shift)
+            const int ty = t / k, iy = y + ty - h, ix = xx + (t - ty * k) - h;
+            o[e] = (iy >= 0 && iy < p && ix >= 0 && ix < p) ? nb[(iy * p + ix) * CP + c] : 0.f;
+        }
     }
 }
 
 // One workgroup per (patch, chunk of CC channels): the chunk's columns of all p*p rows of dcol are read as contiguous
 // runs into LDS; each thread then sums the <= k*k taps of its outputs.
 constexpr int PC_CC = 32;
-__global__ __launch_bounds__(256) void k_patch_fold(const float* __restrict__ dcol, int p, int C, int k, float* __restrict__ dx) {
+template <int KT>
+__global__ __launch_bounds__(256) void k_patch_fold(const float* __restrict__ dcol, int p, int C, int krt, float* __restrict__ dx) {
     extern __shared__ float sm[];  // [p*p][CC*k*k]
-    const int patch = blockIdx.x, c0 = blockIdx.y * PC_CC, pp = p * p, kk = k * k, h = k / 2;
+    const int k = KT > 0 ? KT : krt, kk = k * k, h = k / 2, pp = p * p;
+    const int patch = blockIdx.x, c0 = blockIdx.y * PC_CC;
     const int cc = min(PC_CC, C - c0), run = cc * kk;
-    for (int e = threadIdx.x; e < pp * run; e += 256) {
-        const int r = e / run, j = e - r * run;
-        sm[r * (PC_CC * kk) + j] = dcol[((size_t)patch * pp + r) * C * kk + (size_t)c0 * kk + j];
+    for (int r = 0; r < pp; ++r) {
+        const float* __restrict__ src = dcol + ((size_t)patch * pp + r) * C * kk + (size_t)c0 * kk;
+        for (int j = threadIdx.x; j < run; j += 256) sm[r * (PC_CC * kk) + j] = src[j];
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < pp * cc; e += 256) {
-        const int r = e / cc, c = e - r * cc;
-        const int y = r / p, xx = r % p;
+    // thread -> (row r = e / CC, channel c = e % CC): CC = 32 is a constant, the lanes of a half-wave take the 32 channels of one row
+    for (int e = threadIdx.x; e < pp * PC_CC; e += 256) {
+        const int r = e / PC_CC, c = e - r * PC_CC;
+        if (c >= cc) continue;
+        const int y = r / p, xx = r - y * p;
         float acc = 0.f;
-        for (int t = 0; t < kk; ++t) {
-            // output pixel (oy, ox) read input (y, xx) through tap t  <=>  oy = y - dy_t, ox = xx - dx_t
-            const int oy = y - (t / k - h), ox = xx - (t % k - h);
-            if (oy >= 0 && oy < p && ox >= 0 && ox < p) acc += sm[(oy * p + ox) * (PC_CC * kk) + c * kk + t];
+#pragma unroll
+        for (int t = 0; t < (KT > 0 ? KT * KT : 1); ++t) {
+            if constexpr (KT > 0) {
+                // output pixel (oy, ox) read input (y, xx) through tap t  <=>  oy = y - dy_t, ox = xx - dx_t
+                const int oy = y - (t / KT - KT / 2), ox = xx - (t % KT - KT / 2);
+                if (oy >= 0 && oy < p && ox >= 0 && ox < p) acc += sm[(oy * p + ox) * (PC_CC * kk) + c * kk + t];
+            }
+        }
+        if constexpr (KT == 0) {
+            for (int t = 0; t < kk; ++t) {
+                const int oy = y - (t / k - h), ox = xx - (t % k - h);
+                if (oy >= 0 && oy < p && ox >= 0 && ox < p) acc += sm[(oy * p + ox) * (PC_CC * kk) + c * kk + t];
+            }
         }
         dx[((size_t)patch * pp + r) * C + c0 + c] = acc;
     }
 }
 
 // One workgroup per patch: h[p*p][C] into LDS, then cm[c*k*k + t] = 1/p^2 * sum of h over the rectangle tap t can see.
-__global__ __launch_bounds__(256) void k_patch_unfold_mean(const float* __restrict__ hh, int p, int C, int k,
+template <int KT>
+__global__ __launch_bounds__(256) void k_patch_unfold_mean(const float* __restrict__ hh, int p, int C, int krt,
                                                            float* __restrict__ cm) {
     extern __shared__ float sm[];  // [p*p][C]
-    const int patch = blockIdx.x, pp = p * p, kk = k * k, h = k / 2;
+    const int k = KT > 0 ? KT : krt, kk = k * k, h = k / 2, pp = p * p;
+    const int patch = blockIdx.x;
     for (int e = threadIdx.x; e < pp * C; e += 256) sm[e] = hh[(size_t)patch * pp * C + e];
     __syncthreads();
     const float inv = 1.f / (float)pp;
     float* __restrict__ o = cm + (size_t)patch * C * kk;
     for (int e = threadIdx.x; e < C * kk; e += 256) {
         const int c = e / kk, t = e - c * kk;
-        const int dy = t / k - h, dx = t % k - h;
+        const int ty = t / k, dy = ty - h, dx = (t - ty * k) - h;
         // output pixel (y, x) reads input (y + dy, x + dx): inputs iy in [max(0,dy), min(p, p+dy))
         float acc = 0.f;
         for (int iy = max(0, dy); iy < min(p, p + dy); ++iy)
@@ -87,22 +112,33 @@ __global__ __launch_bounds__(256) void k_patch_unfold_mean(const float* __restri
 }
 
 // One workgroup per patch: dcm[C*k*k] into LDS, then dh[(y,x), c] = 1/p^2 * sum over the taps whose rectangle holds (y,x).
-__global__ __launch_bounds__(256) void k_patch_fold_mean(const float* __restrict__ dcm, int p, int C, int k,
+template <int KT>
+__global__ __launch_bounds__(256) void k_patch_fold_mean(const float* __restrict__ dcm, int p, int C, int krt,
                                                          float* __restrict__ dh) {
     extern __shared__ float sm[];  // [C*k*k]
-    const int patch = blockIdx.x, pp = p * p, kk = k * k, h = k / 2;
+    const int k = KT > 0 ? KT : krt, kk = k * k, h = k / 2, pp = p * p;
+    const int patch = blockIdx.x;
     for (int e = threadIdx.x; e < C * kk; e += 256) sm[e] = dcm[(size_t)patch * C * kk + e];
     __syncthreads();
     const float inv = 1.f / (float)pp;
-    for (int e = threadIdx.x; e < pp * C; e += 256) {
-        const int r = e / C, c = e - r * C;
-        const int iy = r / p, ix = r % p;
-        float acc = 0.f;
-        for (int t = 0; t < kk; ++t) {
-            const int dy = t / k - h, dx = t % k - h;
-            if (iy >= max(0, dy) && iy < min(p, p + dy) && ix >= max(0, dx) && ix < min(p, p + dx)) acc += sm[c * kk + t];
+    for (int r = 0; r < pp; ++r) {
+        const int iy = r / p, ix = r - iy * p;
+        for (int c = threadIdx.x; c < C; c += 256) {
+            float acc = 0.f;
+            if constexpr (KT > 0) {
+#pragma unroll
+                for (int t = 0; t < KT * KT; ++t) {
+                    const int dy = t / KT - KT / 2, dx = t % KT - KT / 2;
+                    if (iy >= max(0, dy) && iy < min(p, p + dy) && ix >= max(0, dx) && ix < min(p, p + dx)) acc += sm[c * kk + t];
+                }
+            } else {
+                for (int t = 0; t < kk; ++t) {
+                    const int dy = t / k - h, dx = t % k - h;
+                    if (iy >= max(0, dy) && iy < min(p, p + dy) && ix >= max(0, dx) && ix < min(p, p + dx)) acc += sm[c * kk + t];
+                }
+            }
+            dh[((size_t)patch * pp + r) * C + c] = acc * inv;
         }
-        dh[(size_t)patch * pp * C + e] = acc * inv;
     }
 }
 
@@ -120,9 +156,10 @@ static int check_patch(const char* who, const void* a, const void* b, int R, int
 extern "C" int snf_patch_unfold(const float* x, int R, int p, int C, int k, float* col, snf_stream_t stream) {
     int rc = check_patch("snf_patch_unfold", x, col, R, p, C, k);
     if (rc) return rc;
-    const size_t lds = (size_t)k * k * C * sizeof(float);
-    SNF_REQUIRE(lds <= 64 * 1024, "snf_patch_unfold: C*k*k too large");
-    hipLaunchKernelGGL(k_patch_unfold, dim3(R), dim3(256), lds, (hipStream_t)stream, x, p, C, k, col);
+    const size_t lds = (size_t)p * p * (C + 1) * sizeof(float);
+    SNF_REQUIRE(lds <= 64 * 1024, "snf_patch_unfold: patch^2*C too large");
+    if (k == 3) hipLaunchKernelGGL(k_patch_unfold<3>, dim3(R / (p * p), p), dim3(256), lds, (hipStream_t)stream, x, p, C, k, col);
+    else hipLaunchKernelGGL(k_patch_unfold<0>, dim3(R / (p * p), p), dim3(256), lds, (hipStream_t)stream, x, p, C, k, col);
     SNF_LAUNCH_CHECK("snf_patch_unfold");
     return SNF_OK;
 }
@@ -132,8 +169,9 @@ extern "C" int snf_patch_fold(const float* dcol, int R, int p, int C, int k, flo
     if (rc) return rc;
     const size_t lds = (size_t)p * p * PC_CC * k * k * sizeof(float);
     SNF_REQUIRE(lds <= 64 * 1024, "snf_patch_fold: patch too large for the fold kernel (p <= 8 at k = 3)");
-    hipLaunchKernelGGL(k_patch_fold, dim3(R / (p * p), (C + PC_CC - 1) / PC_CC), dim3(256), lds, (hipStream_t)stream, dcol, p,
-                       C, k, dx);
+    const dim3 grid(R / (p * p), (C + PC_CC - 1) / PC_CC);
+    if (k == 3) hipLaunchKernelGGL(k_patch_fold<3>, grid, dim3(256), lds, (hipStream_t)stream, dcol, p, C, k, dx);
+    else hipLaunchKernelGGL(k_patch_fold<0>, grid, dim3(256), lds, (hipStream_t)stream, dcol, p, C, k, dx);
     SNF_LAUNCH_CHECK("snf_patch_fold");
     return SNF_OK;
 }
@@ -143,7 +181,8 @@ extern "C" int snf_patch_unfold_mean(const float* h, int R, int p, int C, int k,
     if (rc) return rc;
     const size_t lds = (size_t)p * p * C * sizeof(float);
     SNF_REQUIRE(lds <= 64 * 1024, "snf_patch_unfold_mean: patch^2*C too large");
-    hipLaunchKernelGGL(k_patch_unfold_mean, dim3(R / (p * p)), dim3(256), lds, (hipStream_t)stream, h, p, C, k, cm);
+    if (k == 3) hipLaunchKernelGGL(k_patch_unfold_mean<3>, dim3(R / (p * p)), dim3(256), lds, (hipStream_t)stream, h, p, C, k, cm);
+    else hipLaunchKernelGGL(k_patch_unfold_mean<0>, dim3(R / (p * p)), dim3(256), lds, (hipStream_t)stream, h, p, C, k, cm);
     SNF_LAUNCH_CHECK("snf_patch_unfold_mean");
     return SNF_OK;
 }
@@ -153,7 +192,8 @@ extern "C" int snf_patch_fold_mean(const float* dcm, int R, int p, int C, int k,
     if (rc) return rc;
     const size_t lds = (size_t)C * k * k * sizeof(float);
     SNF_REQUIRE(lds <= 64 * 1024, "snf_patch_fold_mean: C*k*k too large");
-    hipLaunchKernelGGL(k_patch_fold_mean, dim3(R / (p * p)), dim3(256), lds, (hipStream_t)stream, dcm, p, C, k, dh);
+    if (k == 3) hipLaunchKernelGGL(k_patch_fold_mean<3>, dim3(R / (p * p)), dim3(256), lds, (hipStream_t)stream, dcm, p, C, k, dh);
+    else hipLaunchKernelGGL(k_patch_fold_mean<0>, dim3(R / (p * p)), dim3(256), lds, (hipStream_t)stream, dcm, p, C, k, dh);
     SNF_LAUNCH_CHECK("snf_patch_fold_mean");
     return SNF_OK;
 }
