@@ -51,6 +51,29 @@ __global__ __launch_bounds__(256) void k_patch_unfold(const float* __restrict__ 
     }
 }
 
+// The same for patches too large for LDS (the image encoder's neck: one 64 x 64 "patch"): one workgroup per output ROW, its k*k
+// neighbour rows read coalesced into LDS (pitch C + 1), the C*k*k outputs leave as one contiguous stream.
+template <int KT>
+__global__ __launch_bounds__(256) void k_patch_unfold_row(const float* __restrict__ x, int p, int C, int krt, float* __restrict__ col) {
+    extern __shared__ float nb[];  // [k*k][C + 1]
+    const int k = KT > 0 ? KT : krt, kk = k * k, h = k / 2, pp = p * p, CP = C + 1;
+    const int row = blockIdx.x;
+    const int patch = row / pp, y = (row - patch * pp) / p, xx = row - patch * pp - y * p;
+    for (int t = 0; t < kk; ++t) {
+        const int ty = t / k, iy = y + ty - h, ix = xx + (t - ty * k) - h;
+        const bool in = iy >= 0 && iy < p && ix >= 0 && ix < p;  // workgroup-uniform
+        const float* __restrict__ src = x + ((size_t)patch * pp + (in ? iy * p + ix : 0)) * C;
+        for (int c = threadIdx.x; c < C; c += 256) nb[t * CP + c] = in ? src[c] : 0.f;
+    }
+    __syncthreads();
+    const int n = C * kk;
+    float* __restrict__ o = col + (size_t)row * n;
+    for (int e = threadIdx.x; e < n; e += 256) {
+        const int c = e / kk, t = e - c * kk;
+        o[e] = nb[t * CP + c];
+    }
+}
+
 // One workgroup per (patch, chunk of CC channels): the chunk's columns of all p*p rows of dcol are read as contiguous
 // runs into LDS; each thread then sums the <= k*k taps of its outputs.
 constexpr int PC_CC = 32;
@@ -157,9 +180,15 @@ extern "C" int snf_patch_unfold(const float* x, int R, int p, int C, int k, floa
     int rc = check_patch("snf_patch_unfold", x, col, R, p, C, k);
     if (rc) return rc;
     const size_t lds = (size_t)p * p * (C + 1) * sizeof(float);
-    SNF_REQUIRE(lds <= 64 * 1024, "snf_patch_unfold: patch^2*C too large");
-    if (k == 3) hipLaunchKernelGGL(k_patch_unfold<3>, dim3(R / (p * p), p), dim3(256), lds, (hipStream_t)stream, x, p, C, k, col);
-    else hipLaunchKernelGGL(k_patch_unfold<0>, dim3(R / (p * p), p), dim3(256), lds, (hipStream_t)stream, x, p, C, k, col);
+    if (lds <= 48 * 1024) {  // the patch fits LDS: one workgroup per (patch, image row)
+        if (k == 3) hipLaunchKernelGGL(k_patch_unfold<3>, dim3(R / (p * p), p), dim3(256), lds, (hipStream_t)stream, x, p, C, k, col);
+        else hipLaunchKernelGGL(k_patch_unfold<0>, dim3(R / (p * p), p), dim3(256), lds, (hipStream_t)stream, x, p, C, k, col);
+    } else {
+        const size_t lds_row = (size_t)k * k * (C + 1) * sizeof(float);
+        SNF_REQUIRE(lds_row <= 48 * 1024, "snf_patch_unfold: C*k*k too large");
+        if (k == 3) hipLaunchKernelGGL(k_patch_unfold_row<3>, dim3(R), dim3(256), lds_row, (hipStream_t)stream, x, p, C, k, col);
+        else hipLaunchKernelGGL(k_patch_unfold_row<0>, dim3(R), dim3(256), lds_row, (hipStream_t)stream, x, p, C, k, col);
+    }
     SNF_LAUNCH_CHECK("snf_patch_unfold");
     return SNF_OK;
 }

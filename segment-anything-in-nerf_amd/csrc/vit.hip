@@ -482,6 +482,9 @@ __device__ __forceinline__ int at_key_slot(int kr) {
 // two waves per SIMD (<= 256 registers, no spills at head dim 80): with ONE (312 registers) nothing hid the barriers and the
 // load latencies of the key loop -- 14x14 windows 0.207 -> 0.128 ms, 64x64 global without positions 0.85 -> 0.53 ms
 #define SNF_ATT_WAVES 2
+#ifndef SNF_RELPOS_B3
+#define SNF_RELPOS_B3 1  // 0: snf_relpos on the vector ALU for every grid size (A/B)
+#endif
 // NT: threads of the workgroup = 32 queries per wave x NT / 64 waves.  256 everywhere but on the encoder's 14 x 14 windows (T = 196):
 // there ONE workgroup of 7 waves (448 threads: 224 query slots) takes a whole (window, head) -- with 128-query workgroups the second
 // one ran 68 of its 128 slots and both staged every K / V tile.
@@ -801,6 +804,85 @@ __global__ __launch_bounds__(NT, (NT == 256 ? SNF_ATT_WAVES : 1)) void k_attenti
     }
 }
 
+// snf_relpos for LARGE grids (the encoder's 64 x 64 global blocks) on the matrix cores: rel = Q . table^T is a [T, hd] x [hd, 2n-1]
+// product per (image, head) and table -- 8 GFLOP per launch on the 3-term split -- which k_relpos formed on the vector ALU from LDS
+// (one LDS read per multiply-add: 0.13 ms per launch).  A wave takes 32 queries: its query fragments as in k_attention_b3 (unscaled),
+// the table rows of a 32-row tile straight from global memory (40 KB per table: cache resident) as the first operand, 15 MFMAs per
+// (table, row tile); accumulator register r of lane (query, half) is P[query][row vrow(r, half)], i.e. the term of key row / column
+// kk = i + n - 1 - row of that query, stored where k_relpos stores it.  The products are the in-kernel ones of the windowed blocks
+// (k_attention_b3's `rph` path): same 3-term arithmetic, same order.
+template <int DB>
+__global__ __launch_bounds__(256) void k_relpos_b3(const float* __restrict__ qkv, int T, int heads, int hd, int n,
+                                                   const float* __restrict__ rph, const float* __restrict__ rpw,
+                                                   float* __restrict__ rel) {
+    constexpr int KS = DB * 2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, half = lane >> 5;
+    const int bh = blockIdx.y, b = bh / heads, h = bh % heads, C = heads * hd;
+    const int qi = (blockIdx.x * 4 + wave) * 32 + li;
+    const bool qlive = qi < T;
+    const int qc = qlive ? qi : T - 1, ih = qc / n, iw = qc - ih * n;
+    const float* qp = qkv + ((size_t)b * T + qc) * 3 * C + h * hd;
+    at_bf16x8 qh[KS], ql[KS];
+    {
+        float2 raw[KS][4];
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int p2 = 0; p2 < 4; ++p2) raw[s][p2] = *reinterpret_cast<const float2*>(qp + min(16 * s + 8 * half + 2 * p2, hd - 2));
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            uint32_t hq[4], lq[4];
+#pragma unroll
+            for (int p2 = 0; p2 < 4; ++p2) {
+                const bool in = 16 * s + 8 * half + 2 * p2 < hd;
+                at_split2(in ? raw[s][p2].x : 0.f, in ? raw[s][p2].y : 0.f, hq[p2], lq[p2]);
+            }
+            qh[s] = __builtin_bit_cast(at_bf16x8, make_uint4(hq[0], hq[1], hq[2], hq[3]));
+            ql[s] = __builtin_bit_cast(at_bf16x8, make_uint4(lq[0], lq[1], lq[2], lq[3]));
+        }
+    }
+    float* __restrict__ orow = rel + ((size_t)bh * T + qc) * 2 * n;
+    const int nrows = 2 * n - 1, rtiles = (nrows + 31) >> 5;
+    for (int tb = 0; tb < 2; ++tb) {
+        const float* __restrict__ tab = tb == 0 ? rph : rpw;
+        const int pos = tb == 0 ? ih : iw;
+        for (int rt = 0; rt < rtiles; ++rt) {
+            const int row = rt * 32 + li;
+            const bool trow = row < nrows;
+            const float* __restrict__ tabrow = tab + (size_t)(trow ? row : nrows - 1) * hd;
+            float2 raw[KS][4];
+#pragma unroll
+            for (int s2 = 0; s2 < KS; ++s2)
+#pragma unroll
+                for (int p2 = 0; p2 < 4; ++p2) raw[s2][p2] = *reinterpret_cast<const float2*>(tabrow + min(16 * s2 + 8 * half + 2 * p2, hd - 2));
+            f32x16 pacc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pacc[r] = 0.f;
+#pragma unroll
+            for (int s2 = 0; s2 < KS; ++s2) {
+                uint32_t hr[4], lr[4];
+#pragma unroll
+                for (int p2 = 0; p2 < 4; ++p2) {
+                    const bool in = trow && 16 * s2 + 8 * half + 2 * p2 < hd;
+                    at_split2(in ? raw[s2][p2].x : 0.f, in ? raw[s2][p2].y : 0.f, hr[p2], lr[p2]);
+                }
+                const at_bf16x8 rh = __builtin_bit_cast(at_bf16x8, make_uint4(hr[0], hr[1], hr[2], hr[3]));
+                const at_bf16x8 rl = __builtin_bit_cast(at_bf16x8, make_uint4(lr[0], lr[1], lr[2], lr[3]));
+                pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rl, qh[s2], pacc, 0, 0, 0);
+                pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rh, ql[s2], pacc, 0, 0, 0);
+                pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rh, qh[s2], pacc, 0, 0, 0);
+            }
+            if (qlive) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int kk = pos + n - 1 - (rt * 32 + vrow(r, half));  // table row -> key row / column of this query
+                    if (kk >= 0 && kk < n) orow[tb * n + kk] = pacc[r];
+                }
+            }
+        }
+    }
+}
+
 }  // namespace snf
 
 using namespace snf;
@@ -948,6 +1030,17 @@ extern "C" int snf_relpos(const float* qkv, int Bw, int T, int heads, int head_d
         }
         hipLaunchKernelGGL(k_relpos_window, dim3(Bw * heads), dim3(512), lds_w, (hipStream_t)stream, qkv, T, heads, head_dim, n,
                            rel_pos_h, rel_pos_w, rel);
+        SNF_LAUNCH_CHECK("snf_relpos");
+        return SNF_OK;
+    }
+    // large grids in the bf16-split gemm mode: the matrix-core kernel
+    if (SNF_RELPOS_B3 && b3_enabled() && n >= 32 && head_dim <= 96 && (head_dim % 2) == 0 &&
+        ((((uintptr_t)qkv | (uintptr_t)rel_pos_h | (uintptr_t)rel_pos_w) & 7) == 0) && ((heads * head_dim) % 2) == 0) {
+        const dim3 grid(ceil_div(T, 128), Bw * heads);
+        const int DB = (head_dim + 31) / 32;
+        if (DB == 1) hipLaunchKernelGGL(k_relpos_b3<1>, grid, dim3(256), 0, (hipStream_t)stream, qkv, T, heads, head_dim, n, rel_pos_h, rel_pos_w, rel);
+        else if (DB == 2) hipLaunchKernelGGL(k_relpos_b3<2>, grid, dim3(256), 0, (hipStream_t)stream, qkv, T, heads, head_dim, n, rel_pos_h, rel_pos_w, rel);
+        else hipLaunchKernelGGL(k_relpos_b3<3>, grid, dim3(256), 0, (hipStream_t)stream, qkv, T, heads, head_dim, n, rel_pos_h, rel_pos_w, rel);
         SNF_LAUNCH_CHECK("snf_relpos");
         return SNF_OK;
     }
