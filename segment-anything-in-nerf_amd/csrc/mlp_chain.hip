@@ -54,17 +54,27 @@ __device__ __forceinline__ void load_chain_weights(float* lds, ChainWeights& cw,
     cw.w0 = lds;
     cw.w1 = lds + MC_H * MC_P0;
     cw.wo = cw.w1 + (NH == 2 ? MC_H * MC_P1 : 0);
-    for (int i = threadIdx.x; i < MC_H * MC_IN; i += blockDim.x) {
-        const int o = i / MC_IN, c = i % MC_IN;
-        cw.w0[o * MC_P0 + c] = (c < in_real) ? W0[o * in_real + c] : 0.f;
-    }
+    // (four elements per thread and trip, the loads unconditional and first: see mc_stage)
+    const int nt = (int)blockDim.x;
+    auto stage = [&](int total, auto addr, auto dst) {
+        for (int i0 = threadIdx.x; i0 < total; i0 += 4 * nt) {
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = addr(min(i0 + u * nt, total - 1));
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (i0 + u * nt < total) dst(i0 + u * nt, v[u]);
+        }
+    };
+    stage(MC_H * MC_IN,
+          [&](int i) { const int o = i / MC_IN, c = i % MC_IN; const bool ok = c < in_real; const float v = W0[ok ? o * in_real + c : 0]; return ok ? v : 0.f; },
+          [&](int i, float v) { cw.w0[(i / MC_IN) * MC_P0 + (i % MC_IN)] = v; });
     if constexpr (NH == 2) {
-        for (int i = threadIdx.x; i < MC_H * MC_H; i += blockDim.x) cw.w1[(i / MC_H) * MC_P1 + (i % MC_H)] = W1[i];
+        stage(MC_H * MC_H, [&](int i) { return W1[i]; }, [&](int i, float v) { cw.w1[(i / MC_H) * MC_P1 + (i % MC_H)] = v; });
     }
-    for (int i = threadIdx.x; i < 32 * MC_H; i += blockDim.x) {
-        const int o = i / MC_H, c = i % MC_H;
-        cw.wo[o * MC_P1 + c] = (o < out) ? Wout[o * MC_H + c] : 0.f;
-    }
+    stage(32 * MC_H,
+          [&](int i) { const int o = i / MC_H, c = i % MC_H; const bool ok = o < out; const float v = Wout[ok ? o * MC_H + c : 0]; return ok ? v : 0.f; },
+          [&](int i, float v) { cw.wo[(i / MC_H) * MC_P1 + (i % MC_H)] = v; });
     __syncthreads();
 }
 
@@ -336,17 +346,40 @@ __device__ __forceinline__ int mc_slot_k(int slot) {
     return t * 32 + krow(8 * s + j, half);
 }
 
-// planes[m][slot] = split(get(m, k(slot))) for m < rows, slot < slots (slots even)
+// guarded weight element for the staging below: the load is UNCONDITIONAL (element 0 when the guard fails), the guard a select behind
+// it -- a load under a branch is a basic block with its own wait
+__device__ __forceinline__ float mc_ld(const float* __restrict__ W, int idx, bool ok) {
+    const float v = W[ok ? idx : 0];
+    return ok ? v : 0.f;
+}
+
+// planes[m][slot] = split(get(m, k(slot))) for m < rows, slot < slots (slots even).  Four pairs per thread and trip, all eight loads
+// first: one pair per trip with its split right behind the loads was one memory latency per trip -- 4 + 8 + 4 (+ 4 + 8 for the
+// recomputing backward) trips at the top of a kernel that runs 40 - 160 us.
 template <bool LIN, class G>
 __device__ __forceinline__ void mc_stage(uint16_t* __restrict__ Ph, uint16_t* __restrict__ Pl, int pitch, int rows, int slots,
                                          G get) {
-    const int pairs = slots >> 1;
-    for (int i = threadIdx.x; i < rows * pairs; i += blockDim.x) {
-        const int m = i / pairs, sl = (i - m * pairs) * 2;
-        uint32_t h, l;
-        mc_split2(get(m, mc_slot_k<LIN>(sl)), get(m, mc_slot_k<LIN>(sl + 1)), h, l);
-        *reinterpret_cast<uint32_t*>(&Ph[m * pitch + sl]) = h;
-        *reinterpret_cast<uint32_t*>(&Pl[m * pitch + sl]) = l;
+    const int pairs = slots >> 1, total = rows * pairs, nt = (int)blockDim.x;
+    for (int i0 = threadIdx.x; i0 < total; i0 += 4 * nt) {
+        float a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = min(i0 + u * nt, total - 1);
+            const int m = i / pairs, sl = (i - m * pairs) * 2;
+            a[u] = get(m, mc_slot_k<LIN>(sl));
+            b[u] = get(m, mc_slot_k<LIN>(sl + 1));
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * nt;
+            if (i < total) {
+                const int m = i / pairs, sl = (i - m * pairs) * 2;
+                uint32_t h, l;
+                mc_split2(a[u], b[u], h, l);
+                *reinterpret_cast<uint32_t*>(&Ph[m * pitch + sl]) = h;
+                *reinterpret_cast<uint32_t*>(&Pl[m * pitch + sl]) = l;
+            }
+        }
     }
 }
 
@@ -354,14 +387,28 @@ __device__ __forceinline__ void mc_stage(uint16_t* __restrict__ Ph, uint16_t* __
 template <bool LIN, class G>
 __device__ __forceinline__ void mc_stage3(uint16_t* __restrict__ Ph, uint16_t* __restrict__ Pm, uint16_t* __restrict__ Pl, int pitch,
                                           int rows, int slots, G get) {
-    const int pairs = slots >> 1;
-    for (int i = threadIdx.x; i < rows * pairs; i += blockDim.x) {
-        const int m = i / pairs, sl = (i - m * pairs) * 2;
-        uint32_t h, md, l;
-        mc_split3(get(m, mc_slot_k<LIN>(sl)), get(m, mc_slot_k<LIN>(sl + 1)), h, md, l);
-        *reinterpret_cast<uint32_t*>(&Ph[m * pitch + sl]) = h;
-        *reinterpret_cast<uint32_t*>(&Pm[m * pitch + sl]) = md;
-        *reinterpret_cast<uint32_t*>(&Pl[m * pitch + sl]) = l;
+    const int pairs = slots >> 1, total = rows * pairs, nt = (int)blockDim.x;
+    for (int i0 = threadIdx.x; i0 < total; i0 += 4 * nt) {
+        float a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = min(i0 + u * nt, total - 1);
+            const int m = i / pairs, sl = (i - m * pairs) * 2;
+            a[u] = get(m, mc_slot_k<LIN>(sl));
+            b[u] = get(m, mc_slot_k<LIN>(sl + 1));
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * nt;
+            if (i < total) {
+                const int m = i / pairs, sl = (i - m * pairs) * 2;
+                uint32_t h, md, l;
+                mc_split3(a[u], b[u], h, md, l);
+                *reinterpret_cast<uint32_t*>(&Ph[m * pitch + sl]) = h;
+                *reinterpret_cast<uint32_t*>(&Pm[m * pitch + sl]) = md;
+                *reinterpret_cast<uint32_t*>(&Pl[m * pitch + sl]) = l;
+            }
+        }
     }
 }
 
@@ -507,13 +554,13 @@ __global__ __launch_bounds__(256, SNF_CHAIN_FWD_WAVES) void k_mlp_chain_fwd_b3(c
     uint16_t* p1m = p0m + SZ0;
     uint16_t* pom = p1m + SZ1;
     if constexpr (PLANES == 3) {
-        mc_stage3<true>(p0h, p0m, p0l, MC_BP32, MC_H, MC_IN, [&](int m, int k) { return k < in_real ? W0[m * in_real + k] : 0.f; });
+        mc_stage3<true>(p0h, p0m, p0l, MC_BP32, MC_H, MC_IN, [&](int m, int k) { return mc_ld(W0, m * in_real + k, k < in_real); });
         if constexpr (NH == 2) mc_stage3<false>(p1h, p1m, p1l, MC_BP64, MC_H, MC_H, [&](int m, int k) { return W1[m * MC_H + k]; });
-        mc_stage3<false>(poh, pom, pol, MC_BP64, 32, MC_H, [&](int m, int k) { return m < out ? Wout[m * MC_H + k] : 0.f; });
+        mc_stage3<false>(poh, pom, pol, MC_BP64, 32, MC_H, [&](int m, int k) { return mc_ld(Wout, m * MC_H + k, m < out); });
     } else {
-        mc_stage<true>(p0h, p0l, MC_BP32, MC_H, MC_IN, [&](int m, int k) { return k < in_real ? W0[m * in_real + k] : 0.f; });
+        mc_stage<true>(p0h, p0l, MC_BP32, MC_H, MC_IN, [&](int m, int k) { return mc_ld(W0, m * in_real + k, k < in_real); });
         if constexpr (NH == 2) mc_stage<false>(p1h, p1l, MC_BP64, MC_H, MC_H, [&](int m, int k) { return W1[m * MC_H + k]; });
-        mc_stage<false>(poh, pol, MC_BP64, 32, MC_H, [&](int m, int k) { return m < out ? Wout[m * MC_H + k] : 0.f; });
+        mc_stage<false>(poh, pol, MC_BP64, 32, MC_H, [&](int m, int k) { return mc_ld(Wout, m * MC_H + k, m < out); });
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -628,9 +675,9 @@ __global__ __launch_bounds__(256) void k_mlp_chain_bwd_b3(const float* __restric
     uint16_t* p1l = p1h + (NH == 2 ? MC_H * MC_BP64 : 0);
     uint16_t* p0h = p1l + (NH == 2 ? MC_H * MC_BP64 : 0);  // W0^T [32 inputs][MC_BP64], rows >= in_real zero
     uint16_t* p0l = p0h + 32 * MC_BP64;
-    mc_stage<true>(poh, pol, MC_BP32, MC_H, 32, [&](int k, int o) { return o < out ? Wout[o * MC_H + k] : 0.f; });
+    mc_stage<true>(poh, pol, MC_BP32, MC_H, 32, [&](int k, int o) { return mc_ld(Wout, o * MC_H + k, o < out); });
     if constexpr (NH == 2) mc_stage<false>(p1h, p1l, MC_BP64, MC_H, MC_H, [&](int k1, int k2) { return W1[k2 * MC_H + k1]; });
-    mc_stage<false>(p0h, p0l, MC_BP64, 32, MC_H, [&](int i, int k1) { return i < in_real ? W0[k1 * in_real + i] : 0.f; });
+    mc_stage<false>(p0h, p0l, MC_BP64, 32, MC_H, [&](int i, int k1) { return mc_ld(W0, k1 * in_real + i, i < in_real); });
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 31, half = lane >> 5;
@@ -806,9 +853,9 @@ __global__ __launch_bounds__(WG_T) __attribute__((amdgpu_waves_per_eu(NH == 1 ? 
     uint16_t* p0h = p1l + (NH == 2 ? MC_H * MC_BP64 : 0);  // W0^T   [32 inputs][MC_BP64], rows >= in_real zero
     uint16_t* p0l = p0h + 32 * MC_BP64;
     if constexpr (DG3) {
-        mc_stage<true>(poh, pol, MC_BP32, MC_H, 32, [&](int k_, int o) { return o < out ? Wout[o * MC_H + k_] : 0.f; });
+        mc_stage<true>(poh, pol, MC_BP32, MC_H, 32, [&](int k_, int o) { return mc_ld(Wout, o * MC_H + k_, o < out); });
         if constexpr (NH == 2) mc_stage<false>(p1h, p1l, MC_BP64, MC_H, MC_H, [&](int k1, int k2) { return W1[k2 * MC_H + k1]; });
-        mc_stage<false>(p0h, p0l, MC_BP64, 32, MC_H, [&](int i, int k1) { return i < in_real ? W0[k1 * in_real + i] : 0.f; });
+        mc_stage<false>(p0h, p0l, MC_BP64, 32, MC_H, [&](int i, int k1) { return mc_ld(W0, k1 * in_real + i, i < in_real); });
         __syncthreads();
     } else {
         load_chain_weights<NH>(lds, cw, W0, in_real, W1, Wout, out);
@@ -828,7 +875,7 @@ __global__ __launch_bounds__(WG_T) __attribute__((amdgpu_waves_per_eu(NH == 1 ? 
     uint16_t* __restrict__ r1m = r1h + RS1;
     uint16_t* __restrict__ r1l = r1m + RS1;
     if constexpr (RC) {
-        mc_stage3<true>(r0h, r0m, r0l, MC_BP32, MC_H, MC_IN, [&](int m, int k) { return k < in_real ? W0[m * in_real + k] : 0.f; });
+        mc_stage3<true>(r0h, r0m, r0l, MC_BP32, MC_H, MC_IN, [&](int m, int k) { return mc_ld(W0, m * in_real + k, k < in_real); });
         if constexpr (NH == 2) mc_stage3<false>(r1h, r1m, r1l, MC_BP64, MC_H, MC_H, [&](int m, int k) { return W1[m * MC_H + k]; });
         __syncthreads();
     }
