@@ -419,6 +419,9 @@ __global__ __launch_bounds__(256) void k_gemm_wgrad_b3(const float* __restrict__
 // O x I x chunks partial sums (deterministic up to the few-way split of that second pass).
 constexpr int WF_PITCH = 24;  // bf16 per LDS row: 16 k + 8 pad
 constexpr int WF_T = 512;
+#ifndef SNF_WS_EVEN_TILES
+#define SNF_WS_EVEN_TILES 0
+#endif
 #ifndef SNF_WS_MIN_ROWS
 #define SNF_WS_MIN_ROWS 4096  // fewer rows than this: the tiled kernel (a weight-stationary workgroup stages a whole weight slice first)
 #endif
@@ -1122,6 +1125,11 @@ static int ws_try(const float* A, const float* Aux, const float* W, const float*
     int gx = (256 * per_cu) / gy;
     if (gx < 1) gx = 1;
     if (gx > tiles) gx = tiles;
+#if SNF_WS_EVEN_TILES
+    // every workgroup the same number of row tiles: 16 tiles over 14 workgroups is two rounds for two of them and one for the rest -- the
+    // launch lasts two rounds either way, on 8 workgroups per column slice it leaves the other CUs to the co-running streams
+    while (gx > 1 && (tiles % gx) != 0) --gx;
+#endif
     dim3 grid(gx, gy);
     const int am = !DERIV ? -1 : act_in == SNF_ACT_NONE ? 0 : aux_bits ? 2 : 1;
     if (v == 0 && am == -1) ws_launch<BT, DERIV, 128, 1, 512, 4>(grid, lds, stream, A, Aux, W, bias, M, K, Nc, lda, ldaux, ldw, ldc, act_in, act_out, C, rscale, rgroup, aux_bits, hbar, ybits);

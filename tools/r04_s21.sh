@@ -1,9 +1,5 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 O=gpurun_out/r04s21; mkdir -p $O
-timeout 900 python -m pytest tests -x -q -m gpu -k "conv or patch or ministep or one_step or render or camera" 2>&1 | tail -4 > $O/tests.txt
-VARIANTS="A B" ROUNDS=3 STEPS=60 KEYS="patch_" bash tools/ab_bench.sh > $O/ab.txt 2>&1
-LIB=segment-anything-in-nerf_amd/lib/libsamnerf_hip.so; cp $LIB /tmp/lib_keep.so
-for r in 1 2; do for v in A B; do cp tools/ab/lib$v.so $LIB; echo "render $v $(python tools/bench_render.py 2>/dev/null | grep '^render' | cut -c1-60)" >> $O/ab.txt; done; done
-cp /tmp/lib_keep.so $LIB
-cat $O/tests.txt $O/ab.txt
+VARIANTS="A B" ROUNDS=4 STEPS=60 KEYS="bwd_data/2304" bash tools/ab_bench.sh > $O/ab.txt 2>&1
+cat $O/ab.txt
