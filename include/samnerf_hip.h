@@ -427,7 +427,9 @@ int snf_nerf_loss_summary(const float* rgb_mse, const float* interlevel_rows, fl
  * snf_window_partition / snf_window_merge_add: window_partition with zero padding; window_unpartition fused with the
  *   block's `shortcut + x` (ws == 0: plain add).
  * snf_relpos: rel[bh][i][0..n) = q_i . rel_pos_h[ih-kh+n-1], rel[bh][i][n..2n) = q_i . rel_pos_w[iw-kw+n-1] from the qkv rows
- *   [Bw*T, 3*C] (add_decomposed_rel_pos; tables must have 2n-1 rows).
+ *   [Bw*T, 3*C] (add_decomposed_rel_pos; tables must have 2n-1 rows).  In gemm mode >= 1 grids with n >= 32 (the 64 x 64 global
+ *   blocks) form the products on the matrix cores with the 3-term bf16 split (1e-6 relative, as snf_attention_planes_rp does inside the
+ *   windowed blocks); gemm mode 0 and small grids keep the fp32 vector-ALU kernels.
  * snf_attention: out[b*T+i, h*hd..] = softmax(scale * q k^T + rel_h + rel_w) v for every (window b, head h), q/k/v read in
  *   place from the qkv rows; rel may be NULL; head_dim <= 96. */
 int snf_patchify(const float* img, int B, int Cin, int S, int P, float* rows, snf_stream_t stream);

@@ -420,7 +420,7 @@ __global__ __launch_bounds__(256) void k_gemm_wgrad_b3(const float* __restrict__
 constexpr int WF_PITCH = 24;  // bf16 per LDS row: 16 k + 8 pad
 constexpr int WF_T = 512;
 #ifndef SNF_WS_EVEN_TILES
-#define SNF_WS_EVEN_TILES 0
+#define SNF_WS_EVEN_TILES 1
 #endif
 #ifndef SNF_WS_MIN_ROWS
 #define SNF_WS_MIN_ROWS 4096  // fewer rows than this: the tiled kernel (a weight-stationary workgroup stages a whole weight slice first)
