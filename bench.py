@@ -360,6 +360,8 @@ def main():
                          "(default at --gpus 1 with the default workload: the other two; 'none' disables)")
     ap.add_argument("--exchange", default="both", choices=["both", "table_parallel", "allreduce"],
                     help="multi-rank gradient exchange to time (both: each for --steps steps, the faster one is `value`)")
+    ap.add_argument("--resettle", type=int, default=8,
+                    help="untimed concurrent steps between the serial replay and the timed region (reported in the line)")
     ap.add_argument("--allow-ablation", action="store_true",
                     help="measurement only: accept SNF_ABLATE_SKIP (launches left out, results garbage); the line says so")
     args = ap.parse_args()
@@ -457,7 +459,7 @@ def main():
     # back on the concurrent schedule before timing starts.  The serial replay above is host-bound (two HIP events per launch): the
     # GPU idles through most of it and its clocks come down -- the first ~10 concurrent steps after an idle phase measure the ramp
     # (profiles/r04_experiments.txt: one slow block of 10 after 2 s of idle), which is this script's doing, not the workload's.
-    n_resettle = 8
+    n_resettle = max(0, args.resettle)
     for _ in range(n_resettle):
         trainer.train_iteration(step)
         step += 1
