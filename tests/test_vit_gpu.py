@@ -280,6 +280,39 @@ def test_producers_write_operand_planes(monkeypatch):
     assert float((of.float().double() - ref64).abs().max()) <= 1e-4
 
 
+@pytest.mark.parametrize("n,heads,hd", [(32, 2, 80), (64, 2, 80), (32, 1, 64), (64, 1, 32)])
+def test_position_terms_of_large_grids_on_the_matrix_cores(n, heads, hd):
+    """snf_relpos on grids with n >= 32 (the encoder's 64 x 64 global blocks) in the bf16-split gemm mode runs k_relpos_b3 (query x
+    table products on the matrix cores): against fp64 and against the fp32 vector-ALU kernel of gemm mode 0; every (query, j) written."""
+    from samnerf_amd import ops
+    from samnerf_amd._opcore import _launch, _p, _stream
+    g = torch.Generator(device="cuda").manual_seed(n + hd)
+    T, C, Bw = n * n, heads * hd, 1
+    qkv = torch.randn((Bw * T, 3 * C), device="cuda", generator=g)
+    rh = 0.3 * torch.randn((2 * n - 1, hd), device="cuda", generator=g)
+    rw = 0.3 * torch.randn((2 * n - 1, hd), device="cuda", generator=g)
+
+    def run(mode):
+        ops.set_gemm_mode(mode)
+        rel = torch.full((Bw * heads * T, 2 * n), float("nan"), device="cuda")
+        _launch("snf_relpos", _p(qkv), Bw, T, heads, hd, n, _p(rh), _p(rw), _p(rel), _stream())
+        torch.cuda.synchronize()
+        return rel
+
+    try:
+        r_b3, r_f32 = run("bf16x3"), run("fp32")
+    finally:
+        ops.set_gemm_mode("bf16x3")
+    q = qkv.view(Bw, T, 3, heads, hd)[:, :, 0].permute(0, 2, 1, 3).reshape(Bw * heads, n, n, hd).double()
+    Rh, Rw = V.get_rel_pos(n, n, rh.double().cpu()).cuda(), V.get_rel_pos(n, n, rw.double().cpu()).cuda()
+    ref = torch.cat([torch.einsum("bhwc,hkc->bhwk", q, Rh), torch.einsum("bhwc,wkc->bhwk", q, Rw)], dim=-1).reshape(-1, 2 * n)
+    scale = float(ref.abs().max())
+    assert torch.isfinite(r_b3).all() and torch.isfinite(r_f32).all()
+    assert float((r_f32.double() - ref).abs().max()) <= 2e-6 * scale
+    # (3-term split: every product carries ~2^-16 of |q| |r|, hd = 80 of them per sum -- measured 6.4e-6 of the largest term)
+    assert float((r_b3.double() - ref).abs().max()) <= 1.5e-5 * scale
+
+
 @pytest.mark.parametrize("Bw,n,heads,hd", [(2, 9, 1, 16), (2, 5, 3, 40), (1, 16, 2, 64), (3, 14, 16, 80), (2, 7, 2, 96)])
 def test_windowed_attention_with_in_kernel_position_terms(Bw, n, heads, hd):
     """snf_attention_planes_rp (relative-position terms formed inside the attention kernel from the 2n-1-row tables) against fp64:
