@@ -26,6 +26,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# the host driver of these boxes only supports dmabuf IPC; without this RCCL / device-tensor sharing across processes fails with
+# `hipIpcGetMemHandle: invalid argument`.  Must be in the environment before the HIP runtime starts (i.e. before `import torch`).
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import torch  # noqa: E402
 
@@ -347,6 +350,100 @@ def env_overrides() -> dict:
     return {k: v for k, v in sorted(os.environ.items()) if k.startswith("SNF_")}
 
 
+class _Control:
+    """Control plane of a multi-rank bench run: barriers, the max-over-ranks clock and the per-phase "did every rank get through"
+    vote travel over a gloo group on CPU tensors, never over the collective library that is being measured -- so a mode whose
+    RCCL exchange throws or hangs on some rank is seen as failed by ALL ranks, and the line is still printed."""
+
+    def __init__(self, multi: bool):
+        self.multi = multi
+        self.group = None
+        if multi:
+            import datetime
+            import torch.distributed as dist
+            self.dist = dist
+            to = datetime.timedelta(seconds=float(os.environ.get("SNF_BENCH_CONTROL_TIMEOUT", "900")))
+            self.group = dist.new_group(backend="gloo", timeout=to)  # (collective: every rank creates it)
+
+    def barrier(self) -> None:
+        if self.multi:
+            self.dist.barrier(group=self.group)
+
+    def max(self, x: float) -> float:
+        if not self.multi:
+            return x
+        t = torch.tensor([x], dtype=torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
+        return float(t.item())
+
+    def vote(self, ok: bool, err=None):
+        """-> (every rank ok, ranks that failed, first error text with its rank).  Doubles as a barrier."""
+        if not self.multi:
+            return ok, ([] if ok else [0]), (None if ok else err)
+        got = [None] * self.dist.get_world_size()
+        self.dist.all_gather_object(got, None if ok else str(err), group=self.group)
+        bad = [r for r, e in enumerate(got) if e is not None]
+        first = f"rank {bad[0]}: {got[bad[0]]}" if bad else None
+        return not bad, bad, first
+
+
+class _PhaseHung(Exception):
+    pass
+
+
+def guarded(fn, timeout_s: float, device: int, threaded: bool):
+    """Run `fn()` -> (True, result) or (False, 'ExcType: text').  threaded (multi-rank): on a worker thread joined with
+    `timeout_s` -- a collective that never completes must not take the line with it; a phase that is still running at the
+    deadline is reported as hung (its thread is abandoned: the process leaves through os._exit once the line is out)."""
+    if not threaded:
+        try:
+            return True, fn()
+        except Exception as e:  # noqa: BLE001
+            return False, f"{type(e).__name__}: {e}"
+    import threading
+    box = {}
+
+    def run():
+        try:
+            torch.cuda.set_device(device)  # (the current device is per thread)
+            box["result"] = fn()
+        except BaseException as e:  # noqa: BLE001
+            box["error"] = f"{type(e).__name__}: {e}"
+
+    th = threading.Thread(target=run, daemon=True)
+    th.start()
+    th.join(timeout_s)
+    if th.is_alive():
+        return False, f"_PhaseHung: no completion within {timeout_s:.0f} s (watchdog; SNF_BENCH_MODE_TIMEOUT)"
+    if "error" in box:
+        return False, box["error"]
+    return True, box.get("result")
+
+
+def _inject(mode: str, rank: int) -> None:
+    """SNF_BENCH_INJECT_FAILURE='<mode>:<raise|hang>[:rank]' -- test hook of the fail-soft flow (tests/test_model_gpu.py): the
+    named exchange mode throws / never returns on the given rank (default: the last one) inside its timed steps."""
+    spec = os.environ.get("SNF_BENCH_INJECT_FAILURE", "")
+    if not spec:
+        return
+    parts = spec.split(":")
+    who = int(parts[2]) if len(parts) > 2 else int(os.environ.get("WORLD_SIZE", "1")) - 1
+    if parts[0] == mode and rank == who:
+        if parts[1] == "raise":
+            raise RuntimeError(f"injected failure in exchange mode {mode!r} on rank {rank}")
+        while True:
+            time.sleep(3600)
+
+
+def _rccl_log_tail(path, nbytes: int = 1500):
+    try:
+        with open(path, "rb") as f:
+            data = f.read()
+        return data[-nbytes:].decode("utf-8", "replace") if data else ""
+    except OSError:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -359,9 +456,10 @@ def main():
                     help="comma list of further BASELINE workloads measured briefly and reported under 'other_workloads' "
                          "(default at --gpus 1 with the default workload: the other two; 'none' disables)")
     ap.add_argument("--exchange", default="both", choices=["both", "table_parallel", "allreduce"],
-                    help="multi-rank gradient exchange to time (both: each for --steps steps, the faster one is `value`)")
-    ap.add_argument("--resettle", type=int, default=8,
-                    help="untimed concurrent steps between the serial replay and the timed region (reported in the line)")
+                    help="multi-rank gradient exchange to time (both: north_star's all-reduce first, then the table-parallel "
+                         "one, each for --steps steps; the faster one that completed is `value`)")
+    ap.add_argument("--steady-steps", type=int, default=100,
+                    help="extra steps timed AFTER everything else and reported under 'steady_state' (0 disables)")
     ap.add_argument("--allow-ablation", action="store_true",
                     help="measurement only: accept SNF_ABLATE_SKIP (launches left out, results garbage); the line says so")
     args = ap.parse_args()
@@ -370,6 +468,17 @@ def main():
         sys.exit("bench.py: SNF_ABLATE_SKIP is set -- the schedule would skip launches and the number would be invalid. "
                  "Unset it, or pass --allow-ablation for a timing probe (tools/ablate_step.sh); the JSON line then carries "
                  "\"invalid\": true.")
+
+    rccl_log = None
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("SNF_FORCE_COLLECTIVES") == "1":
+        # RCCL's own warnings into a per-rank file whose tail goes into the line (a first multi-GPU run must explain itself)
+        os.environ.setdefault("NCCL_DEBUG", "WARN")
+        if "NCCL_DEBUG_FILE" not in os.environ:
+            import tempfile
+            rccl_log = os.path.join(tempfile.gettempdir(), f"snf_rccl_{os.getpid()}.log")
+            os.environ["NCCL_DEBUG_FILE"] = rccl_log
+        else:
+            rccl_log = os.environ["NCCL_DEBUG_FILE"]
 
     import samnerf_amd  # noqa: F401
     from samnerf_amd import distributed as D
@@ -386,128 +495,219 @@ def main():
         assert _lib.load().snf_set_adam_launch(*(int(x) for x in os.environ["SNF_ADAM_LAUNCH"].split(","))) == 0
     w["world"] = world
     multi = dist.is_initialized()  # world > 1 (or SNF_FORCE_COLLECTIVES=1 under torchrun: RCCL paths on one GPU)
+    ctl = _Control(multi)
+    mode_timeout = float(os.environ.get("SNF_BENCH_MODE_TIMEOUT", "60"))   # watchdog per exchange mode's timed steps ...
+    build_timeout = float(os.environ.get("SNF_BENCH_BUILD_TIMEOUT", "600"))  # ... and for building + warming a trainer
+    failures = {}
 
-    def barrier():
-        if multi:
-            dist.barrier()
-
-    def timed(trainer, first_step: int, nsteps: int):
-        """EXACTLY nsteps train iterations between barrier + synchronize; max over the ranks."""
-        barrier()
+    def timed(trainer, first_step: int, nsteps: int, mode: str = ""):
+        """EXACTLY nsteps train iterations between barrier + synchronize on both sides; max over the ranks."""
+        ctl.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(nsteps):
             trainer.train_iteration(first_step + i)
+        if mode:
+            _inject(mode, rank)
         torch.cuda.synchronize()
-        barrier()
-        el = time.perf_counter() - t0
-        if multi:
-            t = torch.tensor([el], device="cuda", dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            el = float(t.item())
-        return el
+        return time.perf_counter() - t0
 
-    # ---- multi-rank: both gradient-exchange modes are timed (the default table-parallel one and north_star's plain
-    # all-reduce), each on a trainer of its own; the faster is the line's `value`, both are reported
+    def timed_phase(trainer, first_step: int, nsteps: int, mode: str = ""):
+        """(elapsed max over ranks, None) or (None, error): the closing barrier and the clock vote are on the control group."""
+        ok, res = guarded(lambda: timed(trainer, first_step, nsteps, mode), mode_timeout + nsteps * 0.5, local_rank, multi)
+        all_ok, _, first = ctl.vote(ok, res)  # (the closing barrier: every rank has synchronised its device or given up)
+        if not all_ok:
+            return None, first
+        return ctl.max(res), None
+
+    # ---- warm-up, then the timed region FIRST (this is `value`); every instrumented pass comes after it.
+    # Multi-rank: north_star's plain all-reduce is timed first, then the table-parallel exchange, each on a trainer of its own and
+    # each fenced (exception or watchdog): the line carries whatever completed plus the error text of what did not.
     exchange_modes = {}
     modes = ["single"]
     if multi:
-        modes = ["table_parallel", "allreduce"] if args.exchange == "both" else [args.exchange]
+        modes = ["allreduce", "table_parallel"] if args.exchange == "both" else [args.exchange]
     built = {}
+    hung = False
     for mode in modes:
-        if multi:
-            set_exchange_mode(mode)
-        tr = build_trainer(w, local_rank, world)
-        st = 0
-        for i in range(args.warmup):
-            tr.train_iteration(st)
-            st += 1
-        el = None
-        if len(modes) > 1:
-            el = timed(tr, st, args.steps)
-            st += args.steps
-            exchange_modes[mode] = {"ms_per_step": round(el / args.steps * 1e3, 4),
-                                    "value": world * w["R"] * w["S"] * args.steps / el}
+        if hung:
+            failures[mode] = "skipped: an earlier mode hung, the communicator is not trusted any more"
+            continue
+
+        def build_and_warm(mode=mode):
+            if multi:
+                set_exchange_mode(mode)
+            tr = build_trainer(w, local_rank, world)
+            for i in range(args.warmup):
+                tr.train_iteration(i)
+            torch.cuda.synchronize()
+            return tr
+
+        ok, tr = guarded(build_and_warm, build_timeout, local_rank, multi)
+        all_ok, bad, first = ctl.vote(ok, tr)
+        if not all_ok:
+            failures[mode] = "build / warm-up: " + str(first)
+            # every rank threw (no watchdog): the same deterministic error everywhere, the ranks are still in step and the next
+            # mode may run; anything else leaves ranks at different collectives and nothing more runs on this communicator
+            hung = hung or len(bad) < world or "_PhaseHung" in str(first)
+            continue
+        el, err = timed_phase(tr, args.warmup, args.steps, mode if multi else "")
+        if err is not None:
+            failures[mode] = err
+            hung = True  # a rank threw or hung inside collectives: ranks are out of step, nothing more runs on this communicator
+            continue
+        st = args.warmup + args.steps
+        exchange_modes[mode] = {"ms_per_step": round(el / args.steps * 1e3, 4), "value": world * w["R"] * w["S"] * args.steps / el}
         built[mode] = (tr, st, el)
-    chosen_mode = min(modes, key=lambda m: built[m][2]) if len(modes) > 1 else modes[0]
-    for m in modes:
+
+    def emit(out: dict, code: int) -> None:
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        if multi and (hung or code):
+            os._exit(code)  # abandoned worker threads / a wedged communicator: no orderly teardown to wait for
+
+    def base_line(elapsed, chosen) -> dict:
+        R, S, K = w["R"], w["S"], w["K"]
+        ms = elapsed / args.steps * 1e3 if elapsed else None
+        feat = K * 12288 if w["method"] == "samnerf_distill" else 0
+        b_step = 3 * (w["P"] * 320 + S * 1024 + feat) * R
+        return {
+            "metric": "ray-samples/sec (train step, samnerf_distill 256-d feat head)",
+            "value": (world * R * S * args.steps / elapsed) if elapsed else None, "unit": "ray-samples/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{w['method']} R={R} rays/GPU x S={S} fine samples, P={w['P']} proposal samples, "
+                                   f"K={K} feature samples, patch {w['patch']}, SAM 256-d"
+                                   + (" + ClipSeg 192-d heads" if w["method"] == "samnerf_distill" else "")
+                                   + ", full-size fp32 tables (T=19), fwd+bwd+RCCL grad mean+fused Adam",
+                       "name": args.workload, "rays_per_gpu": R, "parallelism": f"ray-dp{world}"},
+            "rays_per_s": (world * R * args.steps / elapsed) if elapsed else None,
+            "feature_samples_per_s": (world * R * K * args.steps / elapsed) if elapsed else None,
+            "step_algorithmic_GBps": (b_step / (ms * 1e-3) / 1e9) if elapsed else None,
+            "step_frac_of_hbm_peak": (b_step / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if elapsed else None,
+            "untimed_steps_before_timed_region": {"warmup": args.warmup},
+            "rccl": {"backend": (dist.get_backend() if multi else None), "ranks": world, "collectives_on": bool(multi),
+                     "exchange": chosen if multi else None, "exchange_modes_timed": exchange_modes,
+                     "exchange_modes_failed": failures, "debug_log_tail": _rccl_log_tail(rccl_log) if rccl_log else None,
+                     "env": {k: os.environ.get(k) for k in ("HSA_ENABLE_IPC_MODE_LEGACY", "NCCL_DEBUG")}},
+            "host": {"env_overrides": env_overrides()},
+        }
+
+    if not built:  # nothing completed: still one line, with the reasons
+        out = base_line(None, None)
+        out["roofline"], out["cpu_baseline"], out["invalid"] = None, None, True
+        out["invalid_reason"] = "no exchange mode completed its timed steps: " + json.dumps(failures)
+        emit(out, 1)
+        sys.exit(1)
+    chosen_mode = min(built, key=lambda m: built[m][2])
+    for m in list(built):
         if m != chosen_mode:
             _free(built[m][0])
-    if multi:
+    if multi and not hung:
         set_exchange_mode(chosen_mode)
-    trainer, step, _ = built[chosen_mode]
-    # SNF_AUTOTUNE_STREAMS=1: untimed, the trainer times its stream layouts on this device and keeps the faster one
-    stream_probe = trainer.autotune_streams() if os.environ.get("SNF_AUTOTUNE_STREAMS", "0") == "1" else {}
+    trainer, step, elapsed = built[chosen_mode]
+    out = base_line(elapsed, chosen_mode)
+    if hung:  # a later mode failed inside its collectives: print what was measured and leave
+        out["roofline"], out["cpu_baseline"] = None, None
+        out["instrumentation_skipped"] = "an exchange mode failed inside its collectives; see rccl.exchange_modes_failed"
+        emit(out, 0)
+        return
 
-    # ---- warm-up done.  A short SERIAL replay (one stream, every C-ABI launch bracketed by HIP events on its stream)
-    # measures each kernel's own duration and picks the dominant one; the timed region below runs the real
-    # (multi-stream) step and times that kernel live.
-    n_break = 3
-    torch.cuda.synchronize()
-    trainer.overlap = False
-    presort_side, ops.PRESORT_SIDE_STREAM = ops.PRESORT_SIDE_STREAM, False  # keep the replay on one stream
-    wgrad_side, ops.WGRAD_SIDE_STREAM = ops.WGRAD_SIDE_STREAM, False
-    ops.enable_kernel_timing("all")
-    for i in range(n_break):
+    # ---- everything below is instrumentation AFTER the timed region; a failure in it is reported, never fatal to the line
+    def instrument():
+        nonlocal step
+        res = {}
+        # SNF_AUTOTUNE_STREAMS=1: untimed, the trainer times its stream layouts on this device and keeps the faster one
+        res["stream_probe"] = trainer.autotune_streams() if os.environ.get("SNF_AUTOTUNE_STREAMS", "0") == "1" else {}
+        # A short SERIAL replay (one stream, every C-ABI launch bracketed by HIP events on its stream) measures each kernel's own
+        # duration and picks the dominant one; a second short pass of the real (multi-stream) step then times that kernel live.
+        n_break = 3
+        torch.cuda.synchronize()
+        trainer.overlap = False
+        presort_side, ops.PRESORT_SIDE_STREAM = ops.PRESORT_SIDE_STREAM, False  # keep the replay on one stream
+        wgrad_side, ops.WGRAD_SIDE_STREAM = ops.WGRAD_SIDE_STREAM, False
+        ops.enable_kernel_timing("all")
+        for i in range(n_break):
+            trainer.train_iteration(step)
+            step += 1
+        breakdown = ops.kernel_timing_summary()
+        ops.enable_kernel_timing(None)
+        trainer.overlap = True
+        ops.PRESORT_SIDE_STREAM = presort_side
+        ops.WGRAD_SIDE_STREAM = wgrad_side
+        res["breakdown"], res["n_break"] = breakdown, n_break
+        per_step = {k: v["total_ms"] / n_break for k, v in breakdown.items()}
+        res["per_step"] = per_step
+
+        def model_of(key):
+            """(bound, algorithmic units per launch or None, unit).  Adam is modelled per STEP (its launches cover the
+            arenas in pieces whose number differs between the serial and the concurrent schedule)."""
+            if key == "snf_adam_step":
+                return "hbm", adam_bytes(trainer), "GB/s"
+            return algorithmic_model(key, w)
+
+        res["model_of"] = model_of
+        # "Dominant kernel" is meant at the GPU-kernel level (what rocprofv3 --stats ranks).  A C-ABI entry that is a pipeline of
+        # several kernels counts with the share of its largest one: the bucketed hash-grid backward is stage/count/scan/scatter/
+        # reduce, k_hg_reduce being ~60 % of it (profiles/*_kernel_stats.csv).
+        largest_kernel_share = {"snf_hashgrid_bwd_sorted": 0.6, "snf_hashgrid_bwd_sorted_ex": 0.6,
+                                "snf_hashgrid_bwd_presorted": 0.9, "snf_hashgrid_bwd_presorted_adam": 0.95,
+                                "snf_hashgrid_bwd_presorted_adam_sp": 0.9,
+                                "snf_hashgrid_bwd_presorted_adam_pair": 1.0,
+                                "snf_hashgrid_bwd_presorted_adam_fx": 0.95}
+        dom = args.roofline_kernel
+        if dom is None and per_step:
+            modelled = [k for k in per_step if model_of(k)[1]]
+            dom = (max(modelled, key=lambda k: per_step[k] * largest_kernel_share.get(k.partition("/")[0], 1.0))
+                   if modelled else None)
+        res["dom"] = dom
+        # the live pass: the concurrent schedule again (a few untimed steps first: the host-bound replay let the clocks come down),
+        # the dominant kernel bracketed by HIP events on the stream it is launched on
+        n_live = min(args.steps, 20)
+        for _ in range(4):
+            trainer.train_iteration(step)
+            step += 1
+        if dom is not None:
+            ops.enable_kernel_timing([dom])
+        t_live = timed(trainer, step, n_live)
+        step += n_live
+        res["live"] = ops.kernel_timing_summary() if dom is not None else {}
+        res["live_ms_per_step"], res["n_live"] = t_live / n_live * 1e3, n_live
+        ops.enable_kernel_timing(None)
+        # the same step WITHOUT the exchange + optimizer (SURVEY 8d: report both): gradients just accumulate
+        n_fb = min(args.steps, 20)
+        trainer.optimizers.enabled = False
         trainer.train_iteration(step)
-        step += 1
-    breakdown = ops.kernel_timing_summary()
-    ops.enable_kernel_timing(None)
-    trainer.overlap = True
-    ops.PRESORT_SIDE_STREAM = presort_side
-    ops.WGRAD_SIDE_STREAM = wgrad_side
-    # back on the concurrent schedule before timing starts.  The serial replay above is host-bound (two HIP events per launch): the
-    # GPU idles through most of it and its clocks come down -- the first ~10 concurrent steps after an idle phase measure the ramp
-    # (profiles/r04_experiments.txt: one slow block of 10 after 2 s of idle), which is this script's doing, not the workload's.
-    n_resettle = max(0, args.resettle)
-    for _ in range(n_resettle):
-        trainer.train_iteration(step)
-        step += 1
-    per_step = {k: v["total_ms"] / n_break for k, v in breakdown.items()}
+        res["elapsed_fb"], res["n_fb"] = timed(trainer, step, n_fb), n_fb
+        trainer.optimizers.enabled = True
+        trainer.optimizers.zero_grad_all()
+        if args.steady_steps > 0:  # the plateau on record (the proposal-weight anneal makes the first ~100 steps slower)
+            for _ in range(2):
+                trainer.train_iteration(step)
+                step += 1
+            res["steady"] = timed(trainer, step, args.steady_steps)
+            step += args.steady_steps
+        from samnerf_amd import _lib as _snf_lib
+        res["gemm_mode"] = int(_snf_lib.load().snf_get_gemm_mode())
+        res["static_schedule"], res["static_off"] = trainer._program is not None, trainer._program_off
+        res["exchange_bytes"] = exchange_summary(trainer, w, world) if multi else None
+        res["n_arena_slots"] = adam_bytes(trainer)
+        return res
 
-    def model_of(key):
-        """(bound, algorithmic units per launch or None, unit).  Adam is modelled per STEP (its launches cover the
-        arenas in pieces whose number differs between the serial and the concurrent schedule)."""
-        if key == "snf_adam_step":
-            return "hbm", adam_bytes(trainer), "GB/s"
-        return algorithmic_model(key, w)
-
-    # "Dominant kernel" is meant at the GPU-kernel level (what rocprofv3 --stats ranks).  A C-ABI entry that is a pipeline of
-    # several kernels counts with the share of its largest one: the bucketed hash-grid backward is stage/count/scan/scatter/
-    # reduce, k_hg_reduce being ~60 % of it (profiles/*_kernel_stats.csv).
-    largest_kernel_share = {"snf_hashgrid_bwd_sorted": 0.6, "snf_hashgrid_bwd_sorted_ex": 0.6,
-                            "snf_hashgrid_bwd_presorted": 0.9, "snf_hashgrid_bwd_presorted_adam": 0.95,
-                            "snf_hashgrid_bwd_presorted_adam_sp": 0.9,
-                            "snf_hashgrid_bwd_presorted_adam_pair": 1.0,
-                            "snf_hashgrid_bwd_presorted_adam_fx": 0.95}
-    dom = args.roofline_kernel
-    if dom is None and per_step:
-        modelled = [k for k in per_step if model_of(k)[1]]
-        dom = (max(modelled, key=lambda k: per_step[k] * largest_kernel_share.get(k.partition("/")[0], 1.0))
-               if modelled else None)
-    if dom is not None:
-        ops.enable_kernel_timing([dom])
-
-    # ---- timed region: EXACTLY --steps train iterations between barrier + synchronize
-    elapsed = timed(trainer, step, args.steps)
-    step += args.steps
-    live = ops.kernel_timing_summary() if dom is not None else {}
-    ops.enable_kernel_timing(None)
-
-    # ---- the same step WITHOUT the exchange + optimizer (SURVEY 8d: report both): gradients just accumulate
-    n_fb = min(args.steps, 20)
-    trainer.optimizers.enabled = False
-    trainer.train_iteration(step)
-    elapsed_fb = timed(trainer, step, n_fb)
-    trainer.optimizers.enabled = True
-    trainer.optimizers.zero_grad_all()
-    static_schedule = trainer._program is not None
-    static_off = trainer._program_off
-    from samnerf_amd import _lib as _snf_lib
-    gemm_mode = int(_snf_lib.load().snf_get_gemm_mode())
-    exchange_bytes = exchange_summary(trainer, w, world) if multi else None
-    n_arena_slots = adam_bytes(trainer)
-    backend = dist.get_backend() if multi else None
+    ok, ins = guarded(instrument, build_timeout, local_rank, multi)
+    all_ok, _, first = ctl.vote(ok, ins)
+    if not all_ok:
+        out["roofline"], out["cpu_baseline"] = None, None
+        out["instrumentation_failed"] = first
+        hung = True
+        emit(out, 0 if multi else 1)
+        if not multi:
+            sys.exit(1)
+        return
+    if multi:  # (the fwd+bwd-only and steady clocks: max over the ranks like the headline)
+        ins["elapsed_fb"] = ctl.max(ins["elapsed_fb"])
+        if "steady" in ins:
+            ins["steady"] = ctl.max(ins["steady"])
 
     # ---- the other BASELINE workloads, briefly (N = 1, default workload only): configs[1] and the per-rank load of configs[3]
     others_req = args.other_workloads
@@ -525,8 +725,8 @@ def main():
             other_workloads["vit_h_1024"] = vit_measure()
 
     if rank == 0:
-        R, S, K = w["R"], w["S"], w["K"]
-        ms = elapsed / args.steps * 1e3
+        breakdown, per_step, live, dom = ins["breakdown"], ins["per_step"], ins["live"], ins["dom"]
+        model_of, n_break, gemm_mode, n_arena_slots = ins["model_of"], ins["n_break"], ins["gemm_mode"], ins["n_arena_slots"]
         mu, mu_file = mfma_util()
 
         def roof(key, stat, nsteps, where):
@@ -537,15 +737,15 @@ def main():
             total_units = stat["units"] if stat.get("units", 0) > 0 else units * nl
             achieved = total_units / (total_ms * 1e-3) / (1e9 if bound == "hbm" else 1e12)
             peak, basis = (HBM_PEAK_GBPS, "HBM3E") if bound == "hbm" else mfma_peak(key, gemm_mode)
-            out = {"kernel": key, "bound": bound, "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": unit,
-                   "frac": round(achieved / peak, 4), "traffic": None, "avg_launch_ms": round(total_ms / max(nl, 1), 4),
-                   "launches_timed": nl, "algorithmic_units_per_launch": total_units / max(nl, 1), "measured": where}
+            o = {"kernel": key, "bound": bound, "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": unit,
+                 "frac": round(achieved / peak, 4), "traffic": None, "avg_launch_ms": round(total_ms / max(nl, 1), 4),
+                 "launches_timed": nl, "algorithmic_units_per_launch": total_units / max(nl, 1), "measured": where}
             if bound != "hbm":
-                out["peak_basis"] = basis
+                o["peak_basis"] = basis
             mkey = key.replace("_sh/", "/")
             if mkey in mu:  # matrix-core busy cycles / shader busy cycles of this entry point's kernels (rocprofv3 PMC pass)
-                out["mfma_busy"] = mu[mkey]
-            return out
+                o["mfma_busy"] = mu[mkey]
+            return o
 
         def pmc_traffic(key):
             """HBM bytes per launch from the committed PMC passes (profiles/pmc_traffic*.json, made by tools/gpu_record.sh +
@@ -562,9 +762,11 @@ def main():
 
         roofline = None
         if dom is not None and dom in live:
-            # contract: the dominant kernel timed live over the timed region.  The step runs three streams concurrently,
-            # so this duration includes whatever shared the GPU with the kernel (a lower bound on its own roofline).
-            roofline = roof(dom, live[dom], args.steps, "HIP events, timed region (3 concurrent streams)")
+            # contract: the dominant kernel timed live in the concurrent step (HIP events on its own stream).  The step runs three
+            # streams, so this duration includes whatever shared the GPU with the kernel (a lower bound on its own roofline).
+            roofline = roof(dom, live[dom], ins["n_live"], "HIP events, live pass of the concurrent step (3 streams) right after "
+                                                           "the timed region")
+            roofline["live_pass_ms_per_step"] = round(ins["live_ms_per_step"], 4)
             ratio = pmc_traffic(dom)  # measured HBM bytes / algorithmic bytes of the same launches in the PMC passes
             roofline["traffic"] = ratio * roofline["algorithmic_units_per_launch"] if ratio else None
             roofline["traffic_source"] = ("profiles/pmc_traffic.json: rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this command, "
@@ -579,40 +781,25 @@ def main():
                 if ratio:  # (a committed counter pass exists for this kernel too)
                     others[-1]["traffic"] = ratio * others[-1]["algorithmic_units_per_launch"]
                     others[-1]["traffic_source"] = f"profiles/pmc_traffic*.json: HBM bytes = {ratio:.4f} x algorithmic bytes"
-        # algorithmic bytes of the whole step, for the step-level fraction
-        feat = K * 12288 if w["method"] == "samnerf_distill" else 0
-        b_step = 3 * (w["P"] * 320 + S * 1024 + feat) * R
-        out = {
-            "metric": "ray-samples/sec (train step, samnerf_distill 256-d feat head)",
-            "value": world * R * S * args.steps / elapsed, "unit": "ray-samples/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{w['method']} R={R} rays/GPU x S={S} fine samples, P={w['P']} proposal samples, "
-                                   f"K={K} feature samples, patch {w['patch']}, SAM 256-d"
-                                   + (" + ClipSeg 192-d heads" if w["method"] == "samnerf_distill" else "")
-                                   + ", full-size fp32 tables (T=19), fwd+bwd+RCCL grad mean+fused Adam",
-                       "name": args.workload, "rays_per_gpu": R, "parallelism": f"ray-dp{world}"},
-            "rays_per_s": world * R * args.steps / elapsed,
-            "feature_samples_per_s": world * R * K * args.steps / elapsed,
-            "fwd_bwd_only": {"value": world * R * S * n_fb / elapsed_fb, "unit": "ray-samples/s",
-                             "ms_per_step": elapsed_fb / n_fb * 1e3, "steps": n_fb,
-                             "note": "same step without the gradient exchange and the Adam pass"},
-            "step_algorithmic_GBps": b_step / (ms * 1e-3) / 1e9,
-            "step_frac_of_hbm_peak": b_step / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-            "roofline": roofline,
-            "roofline_other_kernels": others,
-            "untimed_steps_before_timed_region": {"warmup": args.warmup, "serial_replay_instrumented": n_break,
-                                                  "after_the_replay": n_resettle},
-            "host": {"static_schedule": static_schedule, "static_schedule_off_reason": static_off,
-                     "env_overrides": env_overrides(), "mfma_busy_source": mu_file},
-            "rccl": {"backend": backend, "ranks": world, "collectives_on": bool(multi),
-                     "exchange": chosen_mode if multi else None, "exchange_modes_timed": exchange_modes,
-                     "bytes_per_rank_per_step": exchange_bytes},
-            "other_workloads": other_workloads,
-            "stream_layout_probe_ms": {k: round(v, 3) for k, v in stream_probe.items()},
-            "serial_step_ms": round(sum(per_step.values()), 3),
-            "kernel_ms_per_step_serial": {k: round(v, 4) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1])},
-        }
+        R, S = w["R"], w["S"]
+        n_fb, elapsed_fb = ins["n_fb"], ins["elapsed_fb"]
+        out["fwd_bwd_only"] = {"value": world * R * S * n_fb / elapsed_fb, "unit": "ray-samples/s",
+                               "ms_per_step": elapsed_fb / n_fb * 1e3, "steps": n_fb,
+                               "note": "same step without the gradient exchange and the Adam pass"}
+        if "steady" in ins:
+            out["steady_state"] = {"ms_per_step": ins["steady"] / args.steady_steps * 1e3, "steps": args.steady_steps,
+                                   "value": world * R * S * args.steady_steps / ins["steady"],
+                                   "note": "timed after everything else (not `value`): the plateau the step reaches once the "
+                                           "proposal-weight anneal has sharpened the samples"}
+        out["roofline"] = roofline
+        out["roofline_other_kernels"] = others
+        out["host"].update({"static_schedule": ins["static_schedule"], "static_schedule_off_reason": ins["static_off"],
+                            "mfma_busy_source": mu_file})
+        out["rccl"]["bytes_per_rank_per_step"] = ins["exchange_bytes"]
+        out["other_workloads"] = other_workloads
+        out["stream_layout_probe_ms"] = {k: round(v, 3) for k, v in ins["stream_probe"].items()}
+        out["serial_step_ms"] = round(sum(per_step.values()), 3)
+        out["kernel_ms_per_step_serial"] = {k: round(v, 4) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1])}
         if os.environ.get("SNF_ABLATE_SKIP"):
             out["invalid"] = True
             out["invalid_reason"] = "SNF_ABLATE_SKIP=" + os.environ["SNF_ABLATE_SKIP"] + ": launches left out (timing probe)"
@@ -620,7 +807,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(w, args.cpu_baseline_seconds)
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
+    emit(out, 0)
     if multi:
         dist.destroy_process_group()
 

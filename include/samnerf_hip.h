@@ -42,6 +42,16 @@ typedef void* snf_stream_t;
 int snf_version(void);
 const char* snf_last_error(void);
 
+/* ---- task streams on part of the chip.  The reference runs its nerfacto branch and its two feature heads back to back on
+ *      torch's current stream (samnerf/sam_model.py:226-301); this library's step schedule runs them as concurrent tasks and may
+ *      confine a task -- or single launches of it -- to a share of the 256 CUs, so that the bandwidth-bound table kernels (which fill
+ *      every CU they touch) leave CUs to the matrix kernels of the other tasks.
+ * snf_stream_create_cu_mask: a HIP stream whose kernels run on `n_cus` CUs only (hipExtStreamCreateWithCUMask with the first n_cus
+ * mask bits set -- the driver spreads mask bits evenly over the 8 XCDs; clamped to [8, CU count]).  The handle is a hipStream_t:
+ * wrap it with torch.cuda.ExternalStream(handle), destroy it with snf_stream_destroy once nothing is enqueued on it. */
+int snf_stream_create_cu_mask(int n_cus, snf_stream_t* out_stream);
+int snf_stream_destroy(snf_stream_t stream);
+
 /* ---- a3: UniformLinDispPiecewiseSampler / SpacedSampler.generate_ray_samples
  *      (nerfstudio/model_components/ray_samplers.py:79-126,223-246).
  * nears,fars [R]; t_rand [R] single per-ray jitter or NULL (eval).  Out: sbins, ebins [R,P+1]. */

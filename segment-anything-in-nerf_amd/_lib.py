@@ -20,7 +20,7 @@ INCLUDE = os.path.join(ROOT, "include")
 LIB_DIR = os.path.join(PKG_DIR, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libsamnerf_hip.so")
 HASH_PATH = LIB_PATH + ".srchash"
-SOURCES = ["vit.hip", "gemm_planes.hip", "batch.hip", "sampling.hip", "hashgrid.hip", "fused_head.hip", "linear.hip", "linear_b3.hip", "mlp_chain.hip", "mlp_tiny.hip", "patchconv.hip", "render.hip", "losses.hip", "optim.hip"]
+SOURCES = ["vit.hip", "gemm_planes.hip", "batch.hip", "sampling.hip", "hashgrid.hip", "fused_head.hip", "linear.hip", "linear_b3.hip", "mlp_chain.hip", "mlp_tiny.hip", "patchconv.hip", "render.hip", "losses.hip", "optim.hip", "streams.hip"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics"]
 
 
@@ -162,6 +162,8 @@ SIGNATURES = {
     "snf_patch_unfold_mean": [P, I, I, I, I, P, P],
     "snf_patch_fold_mean": [P, I, I, I, I, P, P],
     "snf_fill_uniform": [P, c_int64, c_uint64, F, F, P],
+    "snf_stream_create_cu_mask": [I, ctypes.POINTER(c_void_p)],
+    "snf_stream_destroy": [P],
 }
 
 _LIB = None

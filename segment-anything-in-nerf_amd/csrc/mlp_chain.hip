@@ -634,7 +634,7 @@ __global__ __launch_bounds__(256, SNF_CHAIN_FWD_WAVES) void k_mlp_chain_fwd_b3(c
         if constexpr (PLANES == 3) mc_layer_b6<2, 1, false>(poh, pom, pol, MC_BP64, last, y, li, half);
         else mc_layer_b3<2, 1, false>(poh, pol, MC_BP64, last, y, li, half);
         if (ok) {
-            if (out_act == SNF_ACT_NONE && (out & 3) == 0 && (ldy & 3) == 0) {
+            if (out_act == SNF_ACT_NONE && (out & 3) == 0 && (ldy & 3) == 0 && (reinterpret_cast<uintptr_t>(Y) & 15) == 0) {
                 // accumulator registers 4 q .. 4 q + 3 of a lane are the four CONSECUTIVE outputs 8 q + 4 half .. + 3 of its sample: one
                 // 16-byte store per group instead of four scattered 4-byte ones (the base net's [N, 16] output: 2 stores per lane, not 8)
 #pragma unroll
@@ -1427,9 +1427,10 @@ extern "C" int snf_mlp64_bwd_fused_sh(const float* dY, int lddy, const float* Y,
                 "snf_mlp64_bwd_fused_sh: the base net's output must be [N, ld >= 16] (ld %% 4 == 0, aligned), geo in columns 1 .. 15");
     SNF_REQUIRE(!d_geo || (ld_dgeo >= 16 && ld_dgeo % 4 == 0 && ((uintptr_t)d_geo % 16) == 0),
                 "snf_mlp64_bwd_fused_sh: d_geo must be [N, ld >= 16] (ld %% 4 == 0, 16-byte aligned)");
-    // (ldx / lddx are passed as 32 to satisfy the shared checks; the SH kernels use ld_base / ld_dgeo through X's and dX's own strides)
-    return chain_bwd_fused(dY, lddy, 0, nullptr, Y, ldy, base_out, -ld_base, W0, 16 + n_geo, W1, Wout, n_hidden, out, out_act,
-                           (int64_t)R * S, nullptr, nullptr, d_geo, -ld_dgeo, dW0, dW1, dWout, workspace, workspace_bytes, stream, dirs, S);
+    // (X = the base net's output with its own stride, dX = the compact geo gradient: `sh_dirs != NULL` tells the shared body that the
+    //  row-major [N, >= 32] layout checks of the plain entry do not apply -- both layouts were checked above)
+    return chain_bwd_fused(dY, lddy, 0, nullptr, Y, ldy, base_out, ld_base, W0, 16 + n_geo, W1, Wout, n_hidden, out, out_act,
+                           (int64_t)R * S, nullptr, nullptr, d_geo, ld_dgeo, dW0, dW1, dWout, workspace, workspace_bytes, stream, dirs, S);
 }
 
 static int chain_bwd_fused(const float* dY, int lddy, int dy_col_off, const float* dY0, const float* Y, int ldy,
@@ -1439,10 +1440,11 @@ static int chain_bwd_fused(const float* dY, int lddy, int dy_col_off, const floa
                            snf_stream_t stream, const float* sh_dirs, int sh_S) {
     int rc = chain_common_checks("snf_mlp64_bwd_fused", in_real, n_hidden, out, N);
     if (rc) return rc;
-    if (sh_dirs != nullptr) {  // (formed input row: the strides arrive negated so that the row-major checks below do not apply)
-        ldx = -ldx;
-        lddx = -lddx;
-    }
+    // dZ[s][o] is read at dY[s * lddy + dy_col_off + o]: column 0 may come from dY0 instead, and only then may the offset be -1
+    // (the base net below the colour net: d(geo) is [N, 16] holding output columns 1 .. 15 in its columns 0 .. 14)
+    SNF_REQUIRE(dy_col_off >= 0 || (dy_col_off == -1 && dY0 != nullptr),
+                "snf_mlp64_bwd_fused: dy_col_off must be >= 0 (or -1 with dY0 supplying output column 0)");
+    SNF_REQUIRE(lddy >= dy_col_off + out, "snf_mlp64_bwd_fused: lddy < dy_col_off + out (the gradient row does not hold the output columns)");
     const bool recompute = H1 == nullptr;  // the hidden activations are formed again from X (six-product forward arithmetic)
     SNF_REQUIRE(dY && X && W0 && Wout && dW0 && dWout && workspace && (n_hidden == 1 || (W1 && dW1 && (recompute || H2))),
                 "snf_mlp64_bwd_fused: null pointer");

@@ -185,7 +185,7 @@ extern "C" int snf_patch_unfold(const float* x, int R, int p, int C, int k, floa
         else hipLaunchKernelGGL(k_patch_unfold<0>, dim3(R / (p * p), p), dim3(256), lds, (hipStream_t)stream, x, p, C, k, col);
     } else {
         const size_t lds_row = (size_t)k * k * (C + 1) * sizeof(float);
-        SNF_REQUIRE(lds_row <= 48 * 1024, "snf_patch_unfold: C*k*k too large");
+        SNF_REQUIRE(lds_row <= 64 * 1024, "snf_patch_unfold: (C + 1)*k*k floats exceed the 64 KB row staging");
         if (k == 3) hipLaunchKernelGGL(k_patch_unfold_row<3>, dim3(R), dim3(256), lds_row, (hipStream_t)stream, x, p, C, k, col);
         else hipLaunchKernelGGL(k_patch_unfold_row<0>, dim3(R), dim3(256), lds_row, (hipStream_t)stream, x, p, C, k, col);
     }

@@ -1064,7 +1064,10 @@ static int attention_launch(const float* qkv, const float* rel, int Bw, int T, i
     const int DB = (head_dim + 31) / 32;
     static const int b3_env = 1;
     static const int direct_env = 1;
-    const int rel_direct = (rel && direct_env && b3_env && b3_enabled() && (n % 32) == 0 && (((uintptr_t)rel) & 15) == 0) ? 1 : 0;
+    // (the b3 kernel is the only reader of the [32][n + 4] layout: its own launch conditions are part of this one, otherwise the
+    //  fall-back k_attention would stage [32][2n + 1] floats per wave into an LDS sized for the smaller layout)
+    const bool b3_ok = b3_env && b3_enabled() && (head_dim % 2) == 0 && ((uintptr_t)qkv & 7) == 0;
+    const int rel_direct = (rel && direct_env && b3_ok && (n % 32) == 0 && (((uintptr_t)rel) & 15) == 0) ? 1 : 0;
     SNF_REQUIRE(!rph || (rpw && !rel && n > 0 && 2 * n - 1 <= 32 && T == n * n && b3_env && b3_enabled() && (head_dim % 2) == 0 &&
                          (((uintptr_t)rph | (uintptr_t)rpw | (uintptr_t)qkv) & 7) == 0),
                 "snf_attention_planes_rp: tables need T == n*n, 2n-1 <= 32, an even head dim, 8-byte aligned pointers and the bf16-split gemm mode");
@@ -1082,7 +1085,7 @@ static int attention_launch(const float* qkv, const float* rel, int Bw, int T, i
                            out);                                                                                            \
     } while (0)
     SNF_REQUIRE((long long)T * 3 * heads * head_dim < (1LL << 31), "snf_attention: T x 3C too large for 32-bit row offsets");
-    if (b3_env && b3_enabled() && (head_dim % 2) == 0 && ((uintptr_t)qkv & 7) == 0) {
+    if (b3_ok) {
 #define SNF_ATT_B3(DB_)                                                                                                     \
     do {                                                                                                                    \
         if (lds > 16 * 1024)                                                                                                \

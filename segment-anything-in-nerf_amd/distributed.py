@@ -34,6 +34,9 @@ def init_distributed(backend: Optional[str] = None) -> tuple:
     """Initialise torch.distributed from the torchrun environment; returns (rank, local_rank, world_size)."""
     rank, local_rank, world = env_world()
     if (world > 1 or (_force() and "RANK" in os.environ)) and not dist.is_initialized():
+        # dmabuf IPC only on these hosts (RCCL's `hipIpcGetMemHandle: invalid argument` otherwise).  The package sets the same default
+        # at import time, which is before the HIP runtime starts; here it still reaches RCCL's own start-up and child processes.
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:  # SNF_DIST_BACKEND=gloo: CPU collectives with device tensors staged through the host (tests)

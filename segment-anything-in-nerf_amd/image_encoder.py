@@ -136,6 +136,11 @@ class ImageEncoderViT(nn.Module):
         self._wcache.clear()
         return super().load_state_dict(*args, **kw)
 
+    def _load_from_state_dict(self, *args, **kw):
+        # (reached when the state is loaded through a PARENT module, e.g. `sam.load_state_dict`, which never calls the override above)
+        self._wcache.clear()
+        return super()._load_from_state_dict(*args, **kw)
+
     def _pbuf(self, tag: str, M: int, K: int, device, zero: bool = False):
         key = (tag, M, K, str(device))
         buf = self._pcache.get(key)

@@ -68,7 +68,30 @@ def make_stream(name: str) -> "torch.cuda.Stream":
     return st
 
 
+# SNF_STREAM_CUS="sam=192,clipseg=192": the named task streams are created on that many CUs only (snf_stream_create_cu_mask) --
+# a probe of CU partitioning between the tasks of the step (profiles/r05_cu_mask.txt); unset: every stream sees the whole chip
+STREAM_CUS = {k: int(v) for k, v in (kv.split("=") for kv in _os.environ.get("SNF_STREAM_CUS", "").split(",") if "=" in kv)}
+_MASKED: dict = {}
+
+
+def masked_stream(n_cus: int, tag: str = "") -> "torch.cuda.Stream":
+    """A HIP stream whose kernels run on the first `n_cus` CUs (spread evenly over the XCDs by the driver), as a torch stream object.
+    One per (device, n_cus, tag) and process; the handle lives as long as the process."""
+    import ctypes
+    key = (torch.cuda.current_device(), int(n_cus), tag)
+    st = _MASKED.get(key)
+    if st is None:
+        h = ctypes.c_void_p()
+        _lib.check(_L().snf_stream_create_cu_mask(int(n_cus), ctypes.byref(h)), "snf_stream_create_cu_mask")
+        st = _MASKED[key] = torch.cuda.ExternalStream(h.value)
+    return st
+
+
 def _make_stream(name: str) -> "torch.cuda.Stream":
+    if name in STREAM_CUS:
+        st = masked_stream(STREAM_CUS[name], name)
+        _STREAMS_MADE["names"][st.stream_id] = name
+        return st
     slot = STREAM_SLOTS.get(name)
     if slot is not None:
         while _STREAMS_MADE["n"] % 4 != slot % 4:

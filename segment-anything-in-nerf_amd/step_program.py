@@ -92,6 +92,9 @@ FUSED_SH_INPUT = _os.environ.get("SNF_FUSED_SH_INPUT", "1") == "1"
 
 # SNF_ABLATE_SKIP="key,key": launches whose key contains one of these are NOT issued (results are garbage; timing probe only)
 _SKIP = tuple(k for k in _os.environ.get("SNF_ABLATE_SKIP", "").split(",") if k)
+# SNF_CU_ROUTE="key=cus,key=cus": launches whose key contains `key` are issued on a companion stream confined to the first `cus` CUs
+# (ops.masked_stream), fenced by events against the task stream they belong to -- CU partitioning per KERNEL instead of per task.
+CU_ROUTE = tuple((k, int(v)) for k, v in (kv.split("=") for kv in _os.environ.get("SNF_CU_ROUTE", "").split(",") if "=" in kv))
 
 
 class _Plan:
@@ -208,10 +211,20 @@ class StepProgram:
         """Record one C-ABI launch on stream `st`; the stream handle is appended as the last argument."""
         fn = getattr(self.lib, name)
         a = [x.data_ptr() if isinstance(x, torch.Tensor) else x for x in args]
+        key_ = name + ("/" + tag if tag else "")
+        task_st = st
+        if CU_ROUTE and self._overlap:
+            cus = next((c for k, c in CU_ROUTE if k in key_), None)
+            if cus is not None:  # this launch runs on `cus` CUs, between two event edges against its task stream
+                st = ops.masked_stream(cus, ops.stream_name(task_st))
+                self._route_n = getattr(self, "_route_n", 0) + 1
+                self._edge(task_st, st, f"cu_route_in_{self._route_n}")
         a.append(st.cuda_stream)
-        self._plan.entries.append([_KERNEL, fn, a, name + ("/" + tag if tag else ""), units, st])
+        self._plan.entries.append([_KERNEL, fn, a, key_, units, st])
         for key, idx in (dyn or {}).items():
             self._plan.dyn.setdefault(key, []).append((a, idx))
+        if st is not task_st:
+            self._edge(st, task_st, f"cu_route_out_{self._route_n}")
 
     def _py(self, fn, *args) -> None:
         self._plan.entries.append([_PY, fn, list(args), None, 0.0, None])
@@ -494,6 +507,7 @@ class StepProgram:
 
     def _build(self, parity: int, updated: bool, with_opt: bool, overlap: bool, prop_adam_when_idle: bool) -> _Plan:
         plan = self._plan = _Plan()
+        self._overlap = bool(overlap)
         self._keep: list = getattr(self, "_keep", [])
         model, cfg, opt = self.model, self.cfg, self.opt
         R, P, S, K = self.R, self.P, self.S, self.K

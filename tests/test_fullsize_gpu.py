@@ -164,7 +164,7 @@ def test_pair_launch_at_full_table_size():
 
 
 @pytest.mark.parametrize("method,misfit", [("samnerf_distill", False), ("samnerf_no_distill", False),
-                                           ("samnerf_no_distill", True)])
+                                           ("samnerf_no_distill", True), ("samnerf_distill", True)])
 def test_composed_step_at_full_table_size_against_the_oracle(method, misfit, grad_parity):
     """One train step of the static schedule -- the product path bench.py times -- with the BASELINE sample counts (P = 64,
     S = 128, K = 16, patch 4) and FULL-SIZE tables (T = 19 / 17) against `O.forward` on the same rays: rendered RGB / SAM /
