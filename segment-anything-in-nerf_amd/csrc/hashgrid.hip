@@ -37,8 +37,11 @@ __device__ __forceinline__ void load_row(const float* __restrict__ p, float (&o)
 
 // Adam moments of a fused backward + Adam: read once and written once per step, never gathered -- SNF_HG_NT_MV = 1 marks those
 // accesses non-temporal (bit 0: loads, bit 1: stores), a compile-time probe (round 1 measured +9 % for p / m / v together)
+#ifndef SNF_HG_NT_MV
 #define SNF_HG_NT_MV 0
+#endif
 typedef float hg_f4v __attribute__((ext_vector_type(4)));
+
 template <int F>
 __device__ __forceinline__ void load_row_mv(const float* __restrict__ p, float (&o)[F]) {
     if constexpr (F == 8 && (SNF_HG_NT_MV & 1)) {
@@ -208,7 +211,15 @@ constexpr int HG_MAX_RPB = 2048; // rows per bucket (HG_ROWS_PT per reduce threa
 constexpr int HG_ROWS_PT = HG_MAX_RPB / HG_RT;
 constexpr int HG_LONG = 48;      // segments longer than this are reduced by a wave (16 until the kernel ran two workgroups per CU:
                                  // 32 .. 64 then measured 5-8 % faster alone, tools/sweep_hg_long.sh)
+// (round 5: all four rows of a thread in flight -- the row sums parked in the dead sort payload, buffer addressing so that 96 of the
+//  128 registers hold rows -- measured SLOWER: 0.900 -> 0.935 ms per step serial with three rows in flight, 1.05 with four (spills),
+//  and the concurrent step 2.55 -> 2.62 ms: this pass is not short of bytes in flight, profiles/EXPERIMENTS.md r05)
+#ifndef SNF_HG_EPI
 #define SNF_HG_EPI 2
+#endif
+#ifndef SNF_HG_PAD_LDS
+#define SNF_HG_PAD_LDS 0
+#endif
 constexpr int HG_EPI = SNF_HG_EPI;  // rows per thread in flight in the fused Adam epilogue of the float reduce
 
 struct HgGeom {
@@ -1004,6 +1015,10 @@ __global__ __launch_bounds__(HG_RT, SNF_HG_RT_MINWG) void k_hg_reduce(const floa
     __shared__ uint32_t wave_tot[HG_RT / 64];
     __shared__ uint32_t long_rows[CHUNK / 8 + 1];
     __shared__ uint32_t n_long;
+#if SNF_HG_PAD_LDS > 0  // occupancy probe: extra LDS so that fewer workgroups share a CU
+    __shared__ uint32_t lds_pad[SNF_HG_PAD_LDS / 4];
+    if (N < 0) lds_pad[threadIdx.x] = 1u;
+#endif
     const int B = 1 << log2B, log2rpb = log2_T - log2B;
     const int rpb = 1 << log2rpb;
     const int tid = threadIdx.x, b = blockIdx.x;

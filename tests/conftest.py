@@ -69,7 +69,7 @@ def grad_parity():
     L1 <= 3e-2 only; the loss kernels' own tests (test_ops_gpu.py) check that backward on well-conditioned inputs."""
     import numpy as np
 
-    def check(got, ref, l1_tol=5e-3, max_tol=2e-4, big_tol=6e-2, row_tol=0.1, level_tol=5e-3, prop_tol=3e-2):
+    def check(got, ref, l1_tol=5e-3, max_tol=2e-4, big_tol=6e-2, row_tol=0.1, level_tol=5e-3, prop_tol=3e-2, outlier=OUTLIER):
         l1, mx, cnt, rows, worst, shape = {}, {}, {}, {}, {}, {}
         for k, r in ref.items():
             r = np.asarray(r, dtype=np.float64)
@@ -78,7 +78,7 @@ def grad_parity():
             err = np.abs(a.reshape(r.shape) - r)
             top = np.abs(r).max()
             l1[k], mx[k] = float(err.sum() / np.abs(r).sum()), float(err.max() / top)
-            bad = err > OUTLIER * top
+            bad = err > outlier * top
             cnt[k], shape[k] = int(bad.sum()), r.shape
             if "_table" in k:  # slices = levels
                 nl = TABLE_LEVELS.get(k, 12)

@@ -263,6 +263,9 @@ def test_composed_step_at_full_table_size_against_the_oracle(method, misfit, gra
         assert float(rl["interlevel_loss"]) >= 5e-5, float(rl["interlevel_loss"])
         # (the peaky density makes the base net's first layer flip-prone: oracle fp32 against fp64 3e-3 in relative L1 on base_w0,
         #  so the tensor-wide bound of the field tensors is 1e-2 here; what this variant pins is the proposal network: 3e-3)
-        grad_parity(grads, ref_grads, prop_tol=3e-3, l1_tol=1e-2, level_tol=1e-2)
+        # (distill: the peaky weights go through `w_K ** 10` before the heads' weighted mean (sam_model.py:246-249), which amplifies
+        #  their fp32 round-off tenfold: the ORACLE in fp32 against itself in fp64 has 34 entries of clipseg_w1 beyond 1e-4 of the
+        #  largest, worst 1.4e-4 (this path against the fp32 oracle: 54, worst 1.3e-4) -- the outlier mark of this variant is 3e-4)
+        grad_parity(grads, ref_grads, prop_tol=3e-3, l1_tol=1e-2, level_tol=1e-2, **({"outlier": 3e-4} if distill else {}))
     else:
         grad_parity(grads, ref_grads, prop_tol=0.1)

@@ -7,6 +7,8 @@
 #   test:<pytest -k expr> pytest -m gpu -k <expr>
 #   tests                 the whole GPU suite + smoke
 #   py:<file> [args]      a tools/ script
+#   abvar:A,B[:keys]      tools/ab_bench.sh over prebuilt tools/ab/lib{A,B}.so (tools/build_variant.sh), ROUNDS=2; keys = serial kernel times shown
+#   sh:<command>          any shell command (output appended)
 set -u
 TAG=$1; shift
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -32,6 +34,9 @@ for step in "$@"; do
     test:*) timeout 1500 python -m pytest tests -m gpu -x -q -k "${step#test:}" 2>&1 | tail -15 >> $OUT/out.txt ;;
     tests) timeout 3000 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 >> $OUT/out.txt; python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -4 >> $OUT/out.txt ;;
     py:*) python ${step#py:} >> $OUT/out.txt 2>&1 ;;
+    abvar:*) spec=${step#abvar:}; vars=${spec%%:*}; keys=${spec#*:}; [ "$keys" = "$spec" ] && keys=adam_pair
+             VARIANTS="${vars//,/ }" KEYS="$keys" ROUNDS=${ROUNDS:-2} bash tools/ab_bench.sh >> $OUT/out.txt 2>&1 ;;
+    sh:*) bash -c "${step#sh:}" >> $OUT/out.txt 2>&1 ;;
     *) echo "unknown step $step" >> $OUT/out.txt ;;
   esac
 done
