@@ -50,6 +50,8 @@ const char* snf_last_error(void);
  * mask bits set -- the driver spreads mask bits evenly over the 8 XCDs; clamped to [8, CU count]).  The handle is a hipStream_t:
  * wrap it with torch.cuda.ExternalStream(handle), destroy it with snf_stream_destroy once nothing is enqueued on it. */
 int snf_stream_create_cu_mask(int n_cus, snf_stream_t* out_stream);
+/* snf_stream_create_priority: a HIP stream of the given priority (0 default, < 0 higher, > 0 lower; clamped to the device's range). */
+int snf_stream_create_priority(int priority, snf_stream_t* out_stream);
 int snf_stream_destroy(snf_stream_t stream);
 
 /* ---- a3: UniformLinDispPiecewiseSampler / SpacedSampler.generate_ray_samples

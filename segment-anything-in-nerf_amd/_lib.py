@@ -163,6 +163,7 @@ SIGNATURES = {
     "snf_patch_fold_mean": [P, I, I, I, I, P, P],
     "snf_fill_uniform": [P, c_int64, c_uint64, F, F, P],
     "snf_stream_create_cu_mask": [I, ctypes.POINTER(c_void_p)],
+    "snf_stream_create_priority": [I, ctypes.POINTER(c_void_p)],
     "snf_stream_destroy": [P],
 }
 

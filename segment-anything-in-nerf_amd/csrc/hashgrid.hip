@@ -41,6 +41,37 @@ __device__ __forceinline__ void load_row(const float* __restrict__ p, float (&o)
 #define SNF_HG_NT_MV 0
 #endif
 typedef float hg_f4v __attribute__((ext_vector_type(4)));
+typedef float hg_f2v __attribute__((ext_vector_type(2)));
+typedef unsigned int hg_u4v __attribute__((ext_vector_type(4)));
+typedef unsigned int hg_u2v __attribute__((ext_vector_type(2)));
+// Cache-policy probes (round 5).  The sort records and the Adam state are read once / written once per step, while the staged
+// gradient slab of a level (4 MB at N = 2^19: one L2) is gathered from by every workgroup of the level: marked non-temporal, the
+// streams should stop evicting the slab.  Bits: 1 record loads, 2 p/m/v loads, 4 p/m/v stores (F = 2 fixed-point reduce);
+// SNF_XP_NT_STORE: the x-pair scatter's record stores; SNF_HG_NT_REC: record loads of the F = 8 float reduce.
+#ifndef SNF_FX_NT
+#define SNF_FX_NT 7  // measured, same box: field-grid backward 0.340 -> 0.327 ms serial, step 2.465 -> 2.438 ms (profiles/EXPERIMENTS.md r05)
+#endif
+#ifndef SNF_XP_NT_STORE
+#define SNF_XP_NT_STORE 0
+#endif
+#ifndef SNF_HG_NT_REC
+#define SNF_HG_NT_REC 0
+#endif
+
+__device__ __forceinline__ uint4 hg_ld_rec(const uint4* p, bool nt) {
+    if (nt) {
+        const hg_u4v v = __builtin_nontemporal_load(reinterpret_cast<const hg_u4v*>(p));
+        return make_uint4(v.x, v.y, v.z, v.w);
+    }
+    return *p;
+}
+__device__ __forceinline__ uint2 hg_ld_rec(const uint2* p, bool nt) {
+    if (nt) {
+        const hg_u2v v = __builtin_nontemporal_load(reinterpret_cast<const hg_u2v*>(p));
+        return make_uint2(v.x, v.y);
+    }
+    return *p;
+}
 
 template <int F>
 __device__ __forceinline__ void load_row_mv(const float* __restrict__ p, float (&o)[F]) {
@@ -694,7 +725,15 @@ __global__ __launch_bounds__(256) void k_hg_scatter_xp(const float* __restrict__
         __syncthreads();
         // ---- 4: contiguous runs out; advance the cursors
         const uint32_t staged = total < (uint32_t)HG_XP_CAP ? total : (uint32_t)HG_XP_CAP;
-        for (uint32_t i = tid; i < staged; i += 256) records[delta[sbkt[i]] + i] = stage[i];
+        for (uint32_t i = tid; i < staged; i += 256) {
+            if constexpr (SNF_XP_NT_STORE != 0) {
+                const uint4 r = stage[i];
+                const hg_u4v v = {r.x, r.y, r.z, r.w};
+                __builtin_nontemporal_store(v, reinterpret_cast<hg_u4v*>(&records[delta[sbkt[i]] + i]));
+            } else {
+                records[delta[sbkt[i]] + i] = stage[i];
+            }
+        }
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
@@ -1021,8 +1060,12 @@ __global__ __launch_bounds__(HG_RT, SNF_HG_RT_MINWG) void k_hg_reduce(const floa
 #endif
     const int B = 1 << log2B, log2rpb = log2_T - log2B;
     const int rpb = 1 << log2rpb;
-    const int tid = threadIdx.x, b = blockIdx.x;
-    int l = blockIdx.y;
+    const int tid = threadIdx.x;
+    int b = blockIdx.x, l = blockIdx.y;
+    // (round 5: an XCD-aware order of the dense levels -- in rounds of eight levels XCD x owns ONE level, so that a level's staged-gradient
+    //  slab is pulled by one L2 instead of all eight -- measured SLOWER: 0.886 -> 0.931 ms per step serial, step 2.51 -> 2.545 ms.  Like the
+    //  forward's remaps ("XCD mapping"): every L2 on the same level at the same time is the better order; the slab copies come
+    //  out of the Infinity Cache, not out of HBM.  profiles/EXPERIMENTS.md r05)
     if (sec.first_levels < (int)gridDim.y) {  // (uniform over the workgroup)
         bool second;
         if (sec.interleave) {
@@ -1078,7 +1121,7 @@ __global__ __launch_bounds__(HG_RT, SNF_HG_RT_MINWG) void k_hg_reduce(const floa
 #pragma unroll
         for (int j = 0; j < RPT; ++j) {
             const uint32_t i = c0 + tid + (uint32_t)HG_RT * j;
-            r[j] = records[i < end ? i : (start < end ? start : 0u)];  // (an empty bucket is still visited when ADAM)
+            r[j] = hg_ld_rec(&records[i < end ? i : (start < end ? start : 0u)], SNF_HG_NT_REC != 0);  // (an empty bucket is still visited when ADAM)
         }
     };
     auto gather = [&](const auto& r, auto& gg) {
@@ -1447,7 +1490,7 @@ __global__ __launch_bounds__(HG_FX_T) void k_hg_reduce_fx(const float* __restric
 #pragma unroll
         for (int j = 0; j < U; ++j) {
             const uint32_t i = c0 + tid + (uint32_t)HG_FX_T * j;
-            r[j] = records[i < end ? i : (start < end ? start : 0u)];  // (an empty bucket is still visited when ADAM: never read past the array)
+            r[j] = hg_ld_rec(&records[i < end ? i : (start < end ? start : 0u)], (SNF_FX_NT & 1) != 0);  // (an empty bucket is still visited when ADAM: never read past the array)
         }
     };
     auto gather = [&](const Rec (&r)[U], float (&g)[U][F]) {
@@ -1615,9 +1658,16 @@ __global__ __launch_bounds__(HG_FX_T) void k_hg_reduce_fx(const float* __restric
 #pragma unroll
             for (int j = 0; j < RU; ++j) {
                 const int rc = min(r0 + HG_FX_T * j, rpb - 1);
-                load_row<F>(adam.p + base + (size_t)rc * F, pp[j]);
-                load_row<F>(adam.m + base + (size_t)rc * F, mm[j]);
-                load_row<F>(adam.v + base + (size_t)rc * F, vv[j]);
+                if constexpr (F == 2 && (SNF_FX_NT & 2) != 0) {
+                    const hg_f2v a = __builtin_nontemporal_load(reinterpret_cast<const hg_f2v*>(adam.p + base + (size_t)rc * F));
+                    const hg_f2v b2 = __builtin_nontemporal_load(reinterpret_cast<const hg_f2v*>(adam.m + base + (size_t)rc * F));
+                    const hg_f2v c2 = __builtin_nontemporal_load(reinterpret_cast<const hg_f2v*>(adam.v + base + (size_t)rc * F));
+                    pp[j][0] = a.x; pp[j][1] = a.y; mm[j][0] = b2.x; mm[j][1] = b2.y; vv[j][0] = c2.x; vv[j][1] = c2.y;
+                } else {
+                    load_row<F>(adam.p + base + (size_t)rc * F, pp[j]);
+                    load_row<F>(adam.m + base + (size_t)rc * F, mm[j]);
+                    load_row<F>(adam.v + base + (size_t)rc * F, vv[j]);
+                }
             }
         }
 #pragma unroll
@@ -1646,7 +1696,12 @@ __global__ __launch_bounds__(HG_FX_T) void k_hg_reduce_fx(const float* __restric
             if (fuse) {
 #pragma unroll
                 for (int f = 0; f < F; ++f) hg_adam1(pp[j][f], gg[j][f], mm[j][f], vv[j][f], adam);
-                if constexpr (F == 2) {
+                if constexpr (F == 2 && (SNF_FX_NT & 4) != 0) {
+                    const hg_f2v a = {pp[j][0], pp[j][1]}, b2 = {mm[j][0], mm[j][1]}, c2 = {vv[j][0], vv[j][1]};
+                    __builtin_nontemporal_store(a, reinterpret_cast<hg_f2v*>(adam.p + o));
+                    __builtin_nontemporal_store(b2, reinterpret_cast<hg_f2v*>(adam.m + o));
+                    __builtin_nontemporal_store(c2, reinterpret_cast<hg_f2v*>(adam.v + o));
+                } else if constexpr (F == 2) {
                     *reinterpret_cast<float2*>(adam.p + o) = make_float2(pp[j][0], pp[j][1]);
                     *reinterpret_cast<float2*>(adam.m + o) = make_float2(mm[j][0], mm[j][1]);
                     *reinterpret_cast<float2*>(adam.v + o) = make_float2(vv[j][0], vv[j][1]);

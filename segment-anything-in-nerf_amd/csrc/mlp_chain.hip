@@ -533,11 +533,41 @@ __device__ __forceinline__ void chain_sh_row(const float* __restrict__ Hb, int l
     chain_sh_form(raw, half, xo);
 }
 
-template <int NH, int PLANES = 2, bool SH = false>
+// ---- branch-free vector memory for the tile loops (round 5) ------------------------------------------------------------------------
+// A wave is alone on its SIMD in these kernels, so a memory wait is dead time, and on gfx950 loads and stores share ONE counter (vmcnt,
+// in issue order).  Two things turned the "row requested a tile ahead" into a wait per tile (34 % of the wave cycles parked, round-4
+// counters): (i) a load whose destination registers are also written under another exec mask (half-wave 0 = direction, half-wave 1 =
+// the base net's row) makes the compiler wait for the load before the masked writes; (ii) stores under `if (ok)` / `if (o < out)` have a
+// count the compiler cannot know, so the first use of the prefetched row waits for vmcnt(0) -- i.e. for the stores issued just before it.
+// Here every lane issues the same loads and the same number of stores (buffer addressing: a lane with nothing to store points outside
+// the descriptor's range and the hardware drops it), and the prefetched row is consumed at the BOTTOM of the iteration, behind the
+// stores, where the compiler can count them: s_waitcnt vmcnt(<stores>) instead of vmcnt(0).
+typedef __amdgpu_buffer_rsrc_t mc_rsrc_t;
+typedef unsigned int mc_u4 __attribute__((ext_vector_type(4)));
+typedef unsigned int mc_u3 __attribute__((ext_vector_type(3)));
+#ifndef SNF_CHAIN_FWD_T
+#define SNF_CHAIN_FWD_T 512  // threads per workgroup of the forward chains that keep their weight fragments in LDS (256 | 512)
+#endif
+constexpr uint32_t MC_OOR = 0x80000000u;  // a byte offset no descriptor of < 2 GB covers
+
+__device__ __forceinline__ mc_rsrc_t mc_rsrc(const void* p, long long bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)(bytes > 0x7FFFFFFFLL ? 0x7FFFFFFFLL : bytes), 0x00020000);
+}
+
+// epilogue kinds of the forward chain (compile time, so that the stores of an iteration have a static count)
+constexpr int MC_EPI_GENERIC = 0;   // any out / activation: per-output conditional stores (the old path)
+constexpr int MC_EPI_RGB = 1;       // out == 3, sigmoid: one 12-byte store per sample (the colour net)
+constexpr int MC_EPI_LIN16 = 2;     // out == 16, no activation, 16-byte aligned rows: two 16-byte stores per lane (the base net)
+
+// LM: 0 = the input layout is a run-time value (ldx == 0: level-major, else row-major), 1 = level-major, 2 = row-major at compile time --
+// two run-time paths loading into the same registers leave the compiler guessing which loads are pending at the top of the loop
+// THREADS: 256, or 512 for the instantiations that read their weight fragments from LDS inside the tile loop (<= 128 registers): eight
+// waves share one LDS image of the weights, two workgroups per CU = four waves per SIMD to hide each other's LDS and memory waits
+template <int NH, int PLANES = 2, bool SH = false, bool HS = true, int EPI = MC_EPI_GENERIC, int LM = 0, int THREADS = 256>
 // SNF_CHAIN_FWD_WAVES=2 (<= 256 registers): the two-hidden-layer six-product chain then spills 156 B per lane -- alone 0.079 ->
 // 0.073 ms, but +53 MB of scratch traffic per step (PMC, r02k) in a step that is pinned by its HBM-bound kernels: not the default
 #define SNF_CHAIN_FWD_WAVES 1
-__global__ __launch_bounds__(256, SNF_CHAIN_FWD_WAVES) void k_mlp_chain_fwd_b3(const float* __restrict__ X, int ldx, const float* __restrict__ W0,
+__global__ __launch_bounds__(THREADS, THREADS == 512 ? 4 : SNF_CHAIN_FWD_WAVES) void k_mlp_chain_fwd_b3(const float* __restrict__ X, int ldx, const float* __restrict__ W0,
                                                           int in_real, const float* __restrict__ W1,
                                                           const float* __restrict__ Wout, int out, int out_act, long long N,
                                                           float* __restrict__ H1, float* __restrict__ H2,
@@ -566,14 +596,31 @@ __global__ __launch_bounds__(256, SNF_CHAIN_FWD_WAVES) void k_mlp_chain_fwd_b3(c
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 31, half = lane >> 5;
     const long long ntiles = (N + 31) / 32;
-    // A wave is alone on its SIMD (the chain needs the register file), so nothing hides a global load it waits for: the NEXT tile's
-    // input row is requested before this tile's layers run (SNF_CHAIN_PREFETCH; 16 registers) and has landed when they are done.
+    // The NEXT tile's input row is requested before this tile's layers run and consumed (formed, masked) behind this tile's stores:
+    // see "branch-free vector memory" above.  Every lane issues the same loads: rows past the batch are clamped to the last one.
+    const long long n_rays = SH ? (sh.log2S >= 0 ? (N >> sh.log2S) : N / sh.S) : 0;
+    // (a single ray: no 16-byte window inside its 12-byte direction -- the direction comes from three scalar loads here and half-wave 0
+    //  re-reads the base net's row instead)
+    const bool one_ray = SH && n_rays <= 1;
+    float od[3] = {0.f, 0.f, 0.f};
+    if (SH && one_ray) { od[0] = sh.dirs[0]; od[1] = sh.dirs[1]; od[2] = sh.dirs[2]; }
     auto load_x = [&](long long tile_, f32x16& xo) {
         const long long s_ = tile_ * 32 + li;
         const long long sc_ = s_ < N ? s_ : N - 1;
         if constexpr (SH) {
-            chain_sh_load(X, ldx, sh, sc_, half, xo);  // (raw: formed where the row is used, so a row a tile ahead costs no more)
-        } else if (ldx == 0) {
+            // half-wave 1: the base net's row, four 16-byte loads; half-wave 0: its ray's direction -- FOUR floats from dirs + 3 r (one
+            // float early for the last ray, so that the load stays inside the array) by the first load, the other three re-read it
+            // (same line, no new traffic): one set of instructions, one exec mask, no register written under two masks
+            const long long r = sh.log2S >= 0 ? (sc_ >> sh.log2S) : sc_ / sh.S;
+            const float* pr = X + sc_ * ldx;
+            const float* pd = one_ray ? pr : sh.dirs + r * 3 - ((r == n_rays - 1) ? 1 : 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float* pq = half ? pr + 4 * q : pd;
+                const float4 v = *reinterpret_cast<const float4*>(pq);
+                xo[4 * q] = v.x; xo[4 * q + 1] = v.y; xo[4 * q + 2] = v.z; xo[4 * q + 3] = v.w;
+            }
+        } else if (LM == 1 || (LM == 0 && ldx == 0)) {
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const float2 v = *reinterpret_cast<const float2*>(X + ((long long)(half * 8 + q) * N + sc_) * 2);
@@ -587,28 +634,46 @@ __global__ __launch_bounds__(256, SNF_CHAIN_FWD_WAVES) void k_mlp_chain_fwd_b3(c
             }
         }
     };
-    const long long tstride = (long long)gridDim.x * 4;
-    long long tile0 = (long long)blockIdx.x * 4 + wave;
-    f32x16 xn;
-    constexpr bool PF = (SNF_CHAIN_PREFETCH & 1) != 0;
-    if (PF && tile0 < ntiles) load_x(tile0, xn);
-    for (long long tile = tile0; tile < ntiles; tile += tstride) {
-        const long long s = tile * 32 + li;
-        const bool ok = s < N;
-        f32x16 x[1];
-        if (PF) {
-            x[0] = xn;
-            if (tile + tstride < ntiles) load_x(tile + tstride, xn);
-        } else {
-            load_x(tile, x[0]);
-        }
+    // raw row -> the layer's input: harmonics / geo columns (SH), pad columns zeroed
+    auto form_x = [&](long long tile_, const f32x16& raw, f32x16& xo) {
         if constexpr (SH) {
-            const f32x16 raw = x[0];
-            chain_sh_form(raw, half, x[0]);
+            const long long s_ = tile_ * 32 + li;
+            const long long sc_ = s_ < N ? s_ : N - 1;
+            const long long r = sh.log2S >= 0 ? (sc_ >> sh.log2S) : sc_ / sh.S;
+            const bool shifted = r == n_rays - 1;
+            f32x16 rw = raw;
+            if (half == 0) {  // (selects, no loads: the direction sits in [0..2] or, for the last ray, in [1..3])
+                rw[0] = one_ray ? od[0] : shifted ? raw[1] : raw[0];
+                rw[1] = one_ray ? od[1] : shifted ? raw[2] : raw[1];
+                rw[2] = one_ray ? od[2] : shifted ? raw[3] : raw[2];
+            }
+            chain_sh_form(rw, half, xo);
+        } else {
+            xo = raw;
         }
 #pragma unroll
         for (int i = 0; i < 16; ++i)
-            if (half * 16 + i >= in_real) x[0][i] = 0.f;  // pad columns may hold anything (select, not multiply)
+            if (half * 16 + i >= in_real) xo[i] = 0.f;  // pad columns may hold anything (select, not multiply)
+    };
+    const long long tstride = (long long)gridDim.x * (THREADS / 64);
+    const long long tile0 = (long long)blockIdx.x * (THREADS / 64) + wave;
+    if (tile0 >= ntiles) return;
+    const mc_rsrc_t ry = mc_rsrc(Y, N * (long long)ldy * 4);
+    f32x16 x[1];
+    {
+        f32x16 raw0;
+        load_x(tile0, raw0);
+        form_x(tile0, raw0, x[0]);
+    }
+    for (long long tile = tile0; tile < ntiles; tile += tstride) {
+        const long long s = tile * 32 + li;
+        const bool ok = s < N;
+        // (the last tile of a wave requests its own row again: one redundant load instead of a branch around loads)
+        const long long tnext = tile + tstride < ntiles ? tile + tstride : tile;
+        f32x16 rawn;
+        load_x(tnext, rawn);
+        // (the requests stay HERE: left to itself the scheduler sinks them to their use at the bottom of the tile to save 16 registers)
+        if constexpr (EPI != MC_EPI_GENERIC) __builtin_amdgcn_sched_barrier(0);
         f32x16 h1[2];
         if constexpr (PLANES == 3) mc_layer_b6<1, 2, true>(p0h, p0m, p0l, MC_BP32, x, h1, li, half);
         else mc_layer_b3<1, 2, true>(p0h, p0l, MC_BP32, x, h1, li, half);
@@ -616,7 +681,9 @@ __global__ __launch_bounds__(256, SNF_CHAIN_FWD_WAVES) void k_mlp_chain_fwd_b3(c
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) h1[t][r] = fmaxf(h1[t][r], 0.f);
-        if (H1 != nullptr && ok) store_h64(H1, s, h1, half);
+        if constexpr (HS) {
+            if (H1 != nullptr && ok) store_h64(H1, s, h1, half);
+        }
         f32x16 last[2];
         if constexpr (NH == 2) {
             if constexpr (PLANES == 3) mc_layer_b6<2, 2, false>(p1h, p1m, p1l, MC_BP64, h1, last, li, half);
@@ -625,7 +692,9 @@ __global__ __launch_bounds__(256, SNF_CHAIN_FWD_WAVES) void k_mlp_chain_fwd_b3(c
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) last[t][r] = fmaxf(last[t][r], 0.f);
-            if (H2 != nullptr && ok) store_h64(H2, s, last, half);
+            if constexpr (HS) {
+                if (H2 != nullptr && ok) store_h64(H2, s, last, half);
+            }
         } else {
             last[0] = h1[0];
             last[1] = h1[1];
@@ -633,7 +702,25 @@ __global__ __launch_bounds__(256, SNF_CHAIN_FWD_WAVES) void k_mlp_chain_fwd_b3(c
         f32x16 y[1];
         if constexpr (PLANES == 3) mc_layer_b6<2, 1, false>(poh, pom, pol, MC_BP64, last, y, li, half);
         else mc_layer_b3<2, 1, false>(poh, pol, MC_BP64, last, y, li, half);
-        if (ok) {
+        if constexpr (EPI == MC_EPI_RGB) {
+            // outputs 0 .. 2 of a sample are accumulator registers 0 .. 2 of its half-wave-0 lane: one 12-byte store, dropped by the
+            // address check for half-wave 1 and for rows past the batch
+            float v3[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) v3[r] = 1.f / (1.f + expf(-y[0][r]));
+            const mc_u3 pk = {__float_as_uint(v3[0]), __float_as_uint(v3[1]), __float_as_uint(v3[2])};
+            const uint32_t off = (ok && half == 0) ? (uint32_t)(s * ldy) * 4u : MC_OOR;
+            __builtin_amdgcn_raw_buffer_store_b96(pk, ry, off, 0, 0);
+        } else if constexpr (EPI == MC_EPI_LIN16) {
+            // accumulator registers 4 q .. 4 q + 3 of a lane are the four CONSECUTIVE outputs 8 q + 4 half .. + 3 of its sample
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const mc_u4 pk = {__float_as_uint(y[0][4 * q]), __float_as_uint(y[0][4 * q + 1]), __float_as_uint(y[0][4 * q + 2]),
+                                  __float_as_uint(y[0][4 * q + 3])};
+                const uint32_t off = ok ? ((uint32_t)(s * ldy) + 8u * q + 4u * half) * 4u : MC_OOR;
+                __builtin_amdgcn_raw_buffer_store_b128(pk, ry, off, 0, 0);
+            }
+        } else if (ok) {
             if (out_act == SNF_ACT_NONE && (out & 3) == 0 && (ldy & 3) == 0 && (reinterpret_cast<uintptr_t>(Y) & 15) == 0) {
                 // accumulator registers 4 q .. 4 q + 3 of a lane are the four CONSECUTIVE outputs 8 q + 4 half .. + 3 of its sample: one
                 // 16-byte store per group instead of four scattered 4-byte ones (the base net's [N, 16] output: 2 stores per lane, not 8)
@@ -656,6 +743,7 @@ __global__ __launch_bounds__(256, SNF_CHAIN_FWD_WAVES) void k_mlp_chain_fwd_b3(c
                 }
             }
         }
+        form_x(tnext, rawn, x[0]);  // first use of the prefetched row: behind this tile's stores
     }
 }
 
@@ -1305,7 +1393,19 @@ static int chain_fwd_sh(const float* dirs, int R, int S, const float* Hb, int ld
     long long blocks = (ntiles + 3) / 4;
     if (blocks > 256 * 4) blocks = 256 * 4;
     const ChainSh sh = chain_sh(dirs, S);
-    if (n_hidden == 2)
+    // the colour net as the step and the render run it (no stored activations, rgb = sigmoid of 3 outputs): the instantiation whose
+    // stores have a static count (k_mlp_chain_fwd_b3, "branch-free vector memory"); everything else takes the general epilogue
+    const bool rgb = n_hidden == 2 && !H1 && !H2 && out == 3 && out_act == SNF_ACT_SIGMOID && N * (long long)ldy * 4 < 0x7FFFFFFFLL;
+    if (rgb) {
+        constexpr int T = SNF_CHAIN_FWD_T;
+        long long b2 = (ntiles + T / 64 - 1) / (T / 64);
+        const long long cap = 256LL * (T == 512 ? 2 : 4);
+        if (b2 > cap) b2 = cap;
+        hipLaunchKernelGGL((k_mlp_chain_fwd_b3<2, 3, true, false, MC_EPI_RGB, 0, T>), dim3((unsigned)b2), dim3(T),
+                           chain_b3_lds_elems(2, 3) * sizeof(uint16_t), (hipStream_t)stream, Hb, ldh, W0, 16 + n_geo, W1, Wout, out, out_act, N,
+                           H1, H2, Y, ldy, sh);
+    }
+    else if (n_hidden == 2)
         hipLaunchKernelGGL((k_mlp_chain_fwd_b3<2, 3, true>), dim3((unsigned)blocks), dim3(256), chain_b3_lds_elems(2, 3) * sizeof(uint16_t),
                            (hipStream_t)stream, Hb, ldh, W0, 16 + n_geo, W1, Wout, out, out_act, N, H1, H2, Y, ldy, sh);
     else
@@ -1345,7 +1445,22 @@ extern "C" int snf_mlp64_fwd(const float* X, int ldx, const float* W0, int in_re
             hipLaunchKernelGGL(k_mlp_chain_fwd_b3<1>, dim3((unsigned)blocks), dim3(256), chain_b3_lds_elems(1) * sizeof(uint16_t),
                                (hipStream_t)stream, X, ldx, W0, in_real, W1, Wout, out, out_act, (long long)N, H1, H2, Y, ldy, ChainSh{nullptr, 1, 0});
     } else if (x6 && snf_get_gemm_mode() == 1) {
-        if (n_hidden == 2)
+        // (the base net as the step and the render run it: 16 linear outputs, nothing stored but them)
+        const bool lin16 = n_hidden == 1 && !H1 && !H2 && out == 16 && out_act == SNF_ACT_NONE && (ldy & 3) == 0 &&
+                           ((uintptr_t)Y & 15) == 0 && N * (long long)ldy * 4 < 0x7FFFFFFFLL;
+        constexpr int T = SNF_CHAIN_FWD_T;
+        long long b2 = (ntiles + T / 64 - 1) / (T / 64);
+        const long long cap = 256LL * (T == 512 ? 2 : 4);
+        if (b2 > cap) b2 = cap;
+        if (lin16 && ldx == 0)
+            hipLaunchKernelGGL((k_mlp_chain_fwd_b3<1, 3, false, false, MC_EPI_LIN16, 1, T>), dim3((unsigned)b2), dim3(T),
+                               chain_b3_lds_elems(1, 3) * sizeof(uint16_t), (hipStream_t)stream, X, ldx, W0, in_real, W1, Wout, out, out_act,
+                               (long long)N, H1, H2, Y, ldy, ChainSh{nullptr, 1, 0});
+        else if (lin16)
+            hipLaunchKernelGGL((k_mlp_chain_fwd_b3<1, 3, false, false, MC_EPI_LIN16, 2, T>), dim3((unsigned)b2), dim3(T),
+                               chain_b3_lds_elems(1, 3) * sizeof(uint16_t), (hipStream_t)stream, X, ldx, W0, in_real, W1, Wout, out, out_act,
+                               (long long)N, H1, H2, Y, ldy, ChainSh{nullptr, 1, 0});
+        else if (n_hidden == 2)
             hipLaunchKernelGGL((k_mlp_chain_fwd_b3<2, 3>), dim3((unsigned)blocks), dim3(256), chain_b3_lds_elems(2, 3) * sizeof(uint16_t),
                                (hipStream_t)stream, X, ldx, W0, in_real, W1, Wout, out, out_act, (long long)N, H1, H2, Y, ldy, ChainSh{nullptr, 1, 0});
         else

@@ -29,6 +29,21 @@ extern "C" int snf_stream_create_cu_mask(int n_cus, snf_stream_t* out_stream) {
     return SNF_OK;
 }
 
+// priority: 0 = the device's default, negative = higher, positive = lower; clamped to the device's range
+// (hipDeviceGetStreamPriorityRange: -1 .. 1 on gfx950).  The dispatcher serves the queues of higher priority first when CU slots free up.
+extern "C" int snf_stream_create_priority(int priority, snf_stream_t* out_stream) {
+    SNF_REQUIRE(out_stream, "snf_stream_create_priority: null out pointer");
+    int least = 0, greatest = 0;
+    SNF_REQUIRE(hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess, "snf_stream_create_priority: cannot query the range");
+    if (priority > least) priority = least;
+    if (priority < greatest) priority = greatest;
+    hipStream_t st = nullptr;
+    const hipError_t e = hipStreamCreateWithPriority(&st, hipStreamNonBlocking, priority);
+    SNF_REQUIRE(e == hipSuccess, "snf_stream_create_priority: hipStreamCreateWithPriority failed (%s)", hipGetErrorString(e));
+    *out_stream = (snf_stream_t)st;
+    return SNF_OK;
+}
+
 extern "C" int snf_stream_destroy(snf_stream_t stream) {
     SNF_REQUIRE(stream, "snf_stream_destroy: null stream");
     const hipError_t e = hipStreamDestroy((hipStream_t)stream);

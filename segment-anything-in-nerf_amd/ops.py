@@ -70,7 +70,8 @@ def make_stream(name: str) -> "torch.cuda.Stream":
 
 # SNF_STREAM_CUS="sam=192,clipseg=192": the named task streams are created on that many CUs only (snf_stream_create_cu_mask) --
 # a probe of CU partitioning between the tasks of the step (profiles/r05_cu_mask.txt); unset: every stream sees the whole chip
-STREAM_CUS = {k: int(v) for k, v in (kv.split("=") for kv in _os.environ.get("SNF_STREAM_CUS", "").split(",") if "=" in kv)}
+# (`name=p1` / `name=p-1`: a stream of lower / higher priority instead)
+STREAM_CUS = {k: v for k, v in (kv.split("=") for kv in _os.environ.get("SNF_STREAM_CUS", "").split(",") if "=" in kv)}
 _MASKED: dict = {}
 
 
@@ -87,9 +88,22 @@ def masked_stream(n_cus: int, tag: str = "") -> "torch.cuda.Stream":
     return st
 
 
+def priority_stream(priority: int, tag: str = "") -> "torch.cuda.Stream":
+    """A HIP stream of the given priority (snf_stream_create_priority: > 0 lower than default) as a torch stream object."""
+    import ctypes
+    key = (torch.cuda.current_device(), "prio", int(priority), tag)
+    st = _MASKED.get(key)
+    if st is None:
+        h = ctypes.c_void_p()
+        _lib.check(_L().snf_stream_create_priority(int(priority), ctypes.byref(h)), "snf_stream_create_priority")
+        st = _MASKED[key] = torch.cuda.ExternalStream(h.value)
+    return st
+
+
 def _make_stream(name: str) -> "torch.cuda.Stream":
     if name in STREAM_CUS:
-        st = masked_stream(STREAM_CUS[name], name)
+        spec = STREAM_CUS[name]
+        st = priority_stream(int(spec[1:]), name) if spec.startswith("p") else masked_stream(int(spec), name)
         _STREAMS_MADE["names"][st.stream_id] = name
         return st
     slot = STREAM_SLOTS.get(name)

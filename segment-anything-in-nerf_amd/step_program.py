@@ -94,7 +94,8 @@ FUSED_SH_INPUT = _os.environ.get("SNF_FUSED_SH_INPUT", "1") == "1"
 _SKIP = tuple(k for k in _os.environ.get("SNF_ABLATE_SKIP", "").split(",") if k)
 # SNF_CU_ROUTE="key=cus,key=cus": launches whose key contains `key` are issued on a companion stream confined to the first `cus` CUs
 # (ops.masked_stream), fenced by events against the task stream they belong to -- CU partitioning per KERNEL instead of per task.
-CU_ROUTE = tuple((k, int(v)) for k, v in (kv.split("=") for kv in _os.environ.get("SNF_CU_ROUTE", "").split(",") if "=" in kv))
+# (`key=p1`: a companion stream of LOWER priority instead of fewer CUs, `key=p-1` of higher priority)
+CU_ROUTE = tuple((k, v) for k, v in (kv.split("=") for kv in _os.environ.get("SNF_CU_ROUTE", "").split(",") if "=" in kv))
 
 
 class _Plan:
@@ -216,7 +217,8 @@ class StepProgram:
         if CU_ROUTE and self._overlap:
             cus = next((c for k, c in CU_ROUTE if k in key_), None)
             if cus is not None:  # this launch runs on `cus` CUs, between two event edges against its task stream
-                st = ops.masked_stream(cus, ops.stream_name(task_st))
+                st = (ops.priority_stream(int(cus[1:]), ops.stream_name(task_st)) if cus.startswith("p")
+                      else ops.masked_stream(int(cus), ops.stream_name(task_st)))
                 self._route_n = getattr(self, "_route_n", 0) + 1
                 self._edge(task_st, st, f"cu_route_in_{self._route_n}")
         a.append(st.cuda_stream)
