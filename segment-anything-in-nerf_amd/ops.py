@@ -48,7 +48,7 @@ HASHGRID_RUN_MAX_RES = 64.0    # levels up to this resolution merge equal-row co
 # step time by up to 15 %.  The step therefore runs on exactly 4 streams by default (main, two heads, the forward-time sort).
 # All streams are made here, by name; STREAM_SLOTS[name] = position modulo 4 in the creation sequence (unused filler streams
 # are created to reach it) is a tuning knob for runs with more streams (ops.WGRAD_SIDE_STREAM).
-STREAM_SLOTS = {"sam": 0, "clipseg": 1, "presort": 2, "wgrad:sam": 3, "wgrad:clipseg": 0, "wgrad:main": 1}
+STREAM_SLOTS = {"sam": 0, "clipseg": 1, "presort": 2, "wgrad": 2, "wgrad:sam": 3, "wgrad:clipseg": 0, "wgrad:main": 1}
 _STREAMS_MADE = {"n": 0, "filler": [], "names": {}}
 
 

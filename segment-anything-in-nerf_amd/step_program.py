@@ -57,6 +57,8 @@ FUSED_CHAIN_WGRAD = True  # weight gradients of the 64-wide nets inside the chai
 # by the forward and read back: needs the fused backward and the six-product forward arithmetic of gemm mode 1
 CHAIN_RECOMPUTE = True
 PROP_BWD_SIDE = None  # None: the proposal backward goes to the side stream only when there are no feature heads
+if _os.environ.get("SNF_PROP_BWD_SIDE") in ("0", "1"):
+    PROP_BWD_SIDE = _os.environ["SNF_PROP_BWD_SIDE"] == "1"
 FEATURE_SORTS_ON_HEAD_STREAM = True
 # The head's last layer is linear (no bias, no output activation) and the renderer after it is a weighted sum over the K samples
 # of a ray (MeanRenderer, sam_model.py:126-137; the weights are detached, sam_model.py:260-277):
@@ -72,6 +74,13 @@ SPARSE_LEVELS = _os.environ.get("SNF_HG_SPARSE_LEVELS", "1") == "1"
 # the staged gradient, which the compact reduce does not remove, and the quad-merged bucket-wide kernel already avoids the pile-up)
 SPARSE_LEVELS_F2 = False
 PAIR_GRID_BWD = True  # both feature grids of a head in one table-backward launch
+# (both grids in one FORWARD launch as well was built and measured slower inside the step -- 2.56 vs 2.52 ms, same box, twice: one 24-level
+#  launch sits 0.15 ms on the head's chain where the two 12-level launches take 0.04 each -- and removed, profiles/EXPERIMENTS.md r05)
+# The heads' weight gradients feed nothing but the optimizer step of their layers, while their stream's next kernels wait behind them.
+# ONE more stream (the fourth: one per hardware queue of the runtime's default four) takes the weight-gradient launches of BOTH heads and
+# the Adam launches that need them; a head's stream waits for it once, at the end of its task.  (Round 1's per-task companion streams
+# made seven streams, which the runtime multiplexes onto four queues -- the slow mode of DESIGN 5.)
+WGRAD_STREAM = _os.environ.get("SNF_WGRAD_STREAM", "0") == "1"
 FUSED_MEAN_EPILOGUE = True  # ... and the mean itself in the hidden layer's GEMM epilogue
 # Without feature heads the step is ONE dependency chain on the main stream.  Its head -- sampling, the proposal network, the
 # resampling, the positions and the backward sorts -- needs last step's PROPOSAL update only, not the field's: it is recorded on
@@ -762,6 +771,16 @@ class StepProgram:
         NK = R * K
         b = self.buf
         sf = model.sam_field
+        # the stream of this head's weight-gradient launches and of the Adam launches behind them (WGRAD_STREAM; else the head's own)
+        wst = st
+        if WGRAD_STREAM and not self.multi and st.stream_id != self.main.stream_id:
+            wst = ops.make_stream("wgrad")
+        self._wg_n = getattr(self, "_wg_n", 0)
+
+        def to_w(tag_: str) -> None:  # what the head's stream has enqueued so far is input of the next launch on the wgrad stream
+            if wst is not st:
+                self._wg_n += 1
+                self._edge(st, wst, f"wg_in_{hname}_{parity}_{self._wg_n}_{tag_}")
         encs = list(sf.clip_encs if hname == "sam" else sf.clipseg_encs)
         net = sf.sam_net if hname == "sam" else sf.clipseg_net
         ws_ = net.weights()
@@ -876,14 +895,16 @@ class StepProgram:
         self._k(st, "snf_rowmse_loss_bwd", pred, target, rows, Cp, weight, 1, one, out, dpred)
         if conv:
             w0, b0, w1, b1 = c0.weight, c0.bias, c1.weight, c1.bias
-            self._k(st, "snf_linear_bwd_weight", dpred, None, cm, npatch, O0 * kk, O1, O1, O1, O0 * kk, ops.ACT_NONE,
+            to_w("pm")
+            self._k(wst, "snf_linear_bwd_weight", dpred, None, cm, npatch, O0 * kk, O1, O1, O1, O0 * kk, ops.ACT_NONE,
                     w1.main_grad, None if b1 is None else b1.main_grad, tag=f"{O0 * kk}x{O1}pm")
             dcm = b("cv_dcm", (npatch, O0 * kk))
             self._k(st, "snf_linear_bwd_data", dpred, None, w1, npatch, O0 * kk, O1, O1, O1, O0 * kk, ops.ACT_NONE, dcm,
                     tag=f"{O0 * kk}x{O1}pm")
             dh = b("cv_dh", (R, O0))
             self._k(st, "snf_patch_fold_mean", dcm, R, p, O0, k, dh)
-            self._k(st, "snf_linear_bwd_weight", dh, hc, colb, R, Cf * kk, O0, O0, O0, Cf * kk, ops.ACT_RELU, w0.main_grad,
+            to_w("c0")
+            self._k(wst, "snf_linear_bwd_weight", dh, hc, colb, R, Cf * kk, O0, O0, O0, Cf * kk, ops.ACT_RELU, w0.main_grad,
                     None if b0 is None else b0.main_grad, tag=f"{Cf * kk}x{O0}")
             dcol = b("cv_dcol", (R, Cf * kk))
             self._k(st, "snf_linear_bwd_data", dh, hc, w0, R, Cf * kk, O0, O0, O0, Cf * kk, ops.ACT_RELU, dcol,
@@ -896,7 +917,8 @@ class StepProgram:
         wgrad_ws = b(f"{hname}_wgrad_ws", (max(wgrad_bytes, 16) // 4,))
         if commute:
             # last layer on the R rendered rows: dW = dfm^T hbar, d(hbar) = dfm W; then every sample's share w_k d(hbar)
-            self._k(st, "snf_linear_bwd_weight", dfm, None, hbar, R, Ih, Cf, Cf, Cf, Ih, ops.ACT_NONE, w_last.main_grad, None,
+            to_w("r")
+            self._k(wst, "snf_linear_bwd_weight", dfm, None, hbar, R, Ih, Cf, Cf, Cf, Ih, ops.ACT_NONE, w_last.main_grad, None,
                     tag=f"{Ih}x{Cf}r")
             dhbar = b(f"{hname}_dhbar", (R, Ih))
             self._k(st, "snf_linear_bwd_data", dfm, None, w_last, R, Ih, Cf, Cf, Cf, Ih, ops.ACT_NONE, dhbar, tag=f"{Ih}x{Cf}r")
@@ -919,16 +941,18 @@ class StepProgram:
             if rows_ok and i == n_lay - 2:
                 bits, ldy = (1, O // 8) if fuse_mean else (0, O)
                 self._k(st, "snf_linear_bwd_data_rows", gy, wk, K, yout, bits, w, NK, I, O, O, ldy, ldx, act, gx, tag=f"{I}x{O}")
-                self._k(st, "snf_linear_bwd_weight_rows", gy, wk, K, yout, bits, xin, NK, I, O, O, ldy, ldx, act, w.main_grad, wgrad_ws,
+                to_w("rows")
+                self._k(wst, "snf_linear_bwd_weight_rows", gy, wk, K, yout, bits, xin, NK, I, O, O, ldy, ldx, act, w.main_grad, wgrad_ws,
                         nb, tag=f"{I}x{O}")
                 gy = gx
                 continue
             self._k(st, "snf_linear_bwd_data", gy, yout, w, NK, I, O, O, O, ldx, act, gx, tag=f"{I}x{O}")
+            to_w(f"l{i}")
             if nb > 0:  # full-width weight gradient: operands read once, partial sums in a scratch buffer
-                self._k(st, "snf_linear_bwd_weight_ws", gy, yout, xin, NK, I, O, O, O, ldx, act, w.main_grad, None, wgrad_ws, nb,
+                self._k(wst, "snf_linear_bwd_weight_ws", gy, yout, xin, NK, I, O, O, O, ldx, act, w.main_grad, None, wgrad_ws, nb,
                         tag=f"{I}x{O}")
             else:
-                self._k(st, "snf_linear_bwd_weight", gy, yout, xin, NK, I, O, O, O, ldx, act, w.main_grad, None, tag=f"{I}x{O}")
+                self._k(wst, "snf_linear_bwd_weight", gy, yout, xin, NK, I, O, O, O, ldx, act, w.main_grad, None, tag=f"{I}x{O}")
             gy = gx
         done: list = []
         col = 0
@@ -1005,9 +1029,13 @@ class StepProgram:
             names = list(arena.offsets)
             lo = arena.offsets[names[lo_i]][0]
             hi = arena.offsets[names[hi_i]][0] if hi_i < len(names) else arena.numel
-            self._opt_step(st, "sam_field", lo, hi, done, first=lo_i, last=hi_i, count_step=(hname == self.heads[0]))
+            to_w("adam")  # (the table backward's leftover gradients of this head come from its own stream)
+            self._opt_step(wst, "sam_field", lo, hi, done, first=lo_i, last=hi_i, count_step=(hname == self.heads[0]))
             if conv and "conv" in opt.arenas:
-                self._opt_step(st, "conv", 0, opt.arenas["conv"].numel, ())
+                self._opt_step(wst, "conv", 0, opt.arenas["conv"].numel, ())
+        if wst is not st:  # the head's stream ends its task behind the wgrad stream: parameters stepped, gradient buffers free again
+            self._wg_n += 1
+            self._edge(wst, st, f"wg_out_{hname}_{parity}_{self._wg_n}")
 
     # ------------------------------------------------------------------------------------------------------------
     # run-time pieces referenced by the recorded schedule

@@ -797,6 +797,58 @@ def test_bench_with_two_ranks_sharing_the_gpu():
     assert any(k.endswith("tp") for k in d["kernel_ms_per_step_serial"]), "the table-parallel path did not run"
 
 
+@pytest.mark.parametrize("how", ["raise", "hang"])
+def test_bench_still_prints_its_line_when_an_exchange_mode_fails(how):
+    """Fail-soft multi-rank flow: two ranks on the box's one GPU (gloo with host staging), north_star's all-reduce
+    mode timed first, then the table-parallel mode with an injected failure on rank 1 -- an exception, or a rank that never returns
+    (watchdog).  Rank 0 still prints exactly one JSON line: value from the mode that completed, the failed mode with its error text."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "SNF_FORCE_COLLECTIVES")}
+    env.update(SNF_DIST_BACKEND="gloo", SNF_BENCH_DEVICE="0", SNF_BENCH_INJECT_FAILURE=f"table_parallel:{how}:1",
+               SNF_BENCH_MODE_TIMEOUT="20")
+    port = str(29600 + os.getpid() % 90 + (7 if how == "hang" else 0))
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", port, os.path.join(root, "bench.py"),
+                          "--gpus", "2", "--steps", "3", "--warmup", "1", "--cpu-baseline-seconds", "0", "--steady-steps", "0"],
+                         env=env, capture_output=True, text=True, timeout=1200, cwd=root)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, (out.returncode, out.stdout[-800:], out.stderr[-1500:])
+    d = json.loads(lines[0])
+    r = d["rccl"]
+    assert d["n_gpus"] == 2 and d["value"] > 0 and r["exchange"] == "allreduce"
+    assert set(r["exchange_modes_timed"]) == {"allreduce"} and "table_parallel" in r["exchange_modes_failed"]
+    msg = r["exchange_modes_failed"]["table_parallel"]
+    assert ("injected failure" in msg) if how == "raise" else ("_PhaseHung" in msg or "watchdog" in msg), msg
+    assert abs(d["value"] - 2 * 4096 * 128 / (d["ms_per_step"] * 1e-3)) <= 1e-3 * d["value"]
+
+
+def test_cu_masked_and_prioritised_streams_run_kernels():
+    """snf_stream_create_cu_mask / snf_stream_create_priority / snf_stream_destroy: the handles are HIP streams a kernel runs on (wrapped
+    by torch.cuda.ExternalStream) and ordinary events order them against other streams."""
+    import ctypes
+    from samnerf_amd import _lib, ops
+    lib = _lib.load()
+    x = torch.zeros((1 << 20,), device="cuda")
+    m = torch.zeros_like(x)
+    v = torch.zeros_like(x)
+    g = torch.ones_like(x)
+    for make, arg in ((lib.snf_stream_create_cu_mask, 64), (lib.snf_stream_create_priority, 1), (lib.snf_stream_create_priority, -1)):
+        h = ctypes.c_void_p()
+        assert make(arg, ctypes.byref(h)) == 0 and h.value
+        st = torch.cuda.ExternalStream(h.value)
+        st.wait_stream(torch.cuda.current_stream())
+        before = x.clone()
+        rc = lib.snf_adam_step(x.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), x.numel(), 1e-2, 0.9, 0.999, 1e-15, 1, 1.0, 0,
+                               st.cuda_stream)
+        assert rc == 0
+        torch.cuda.current_stream().wait_stream(st)
+        torch.cuda.synchronize()
+        assert float((x - before).abs().min()) > 0  # every element stepped
+        assert lib.snf_stream_destroy(h.value) == 0
+    assert lib.snf_stream_create_cu_mask(64, None) != 0  # (null out pointer: an error code, no crash)
+
+
 def test_autotune_streams_leaves_the_training_state_untouched():
     """Trainer.autotune_streams times the stream layouts with real train steps and must hand back the exact state it found:
     parameters, gradients, Adam moments, step counters, sampler counters and the random streams."""

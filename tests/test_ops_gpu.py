@@ -924,7 +924,35 @@ def test_level_major_feature_grids_feed_the_table_backward():
         assert maxdiff(a, bq) <= 2e-6 * float(a.abs().max())  # (fp32 sums inside a row depend on the LDS ranking order)
 
 
-@pytest.mark.parametrize("R,S", [(512, 128), (37, 48)])
+@pytest.mark.parametrize("N,planar", [(4096 * 8, True), (1000, True), (33, False), (70001, False)])
+def test_base_net_forward_with_static_stores_equals_the_general_epilogue(N, planar):
+    """snf_mlp64_fwd on the base net's shape (32 -> 64 -> 16, no activation, nothing stored but the output) takes the instantiation whose
+    tile loop issues a static number of buffer stores and consumes its prefetched row behind them (csrc/mlp_chain.hip, "branch-free
+    vector memory"); with a hidden-activation buffer supplied the same call takes the general epilogue.  Same arithmetic, so the same
+    bits -- level-major and row-major inputs, ragged last tiles."""
+    m = ops()
+    m.set_gemm_mode("bf16x3")
+    g = torch.Generator(device=DEV).manual_seed(N)
+    x = torch.randn((N, 32), device=DEV, generator=g)
+    w0 = torch.randn((64, 32), device=DEV, generator=g) / 32 ** 0.5
+    w1 = torch.randn((16, 64), device=DEV, generator=g) / 8.0
+    if planar:  # [16 levels][N][2]
+        xin, ldx = x.view(N, 16, 2).permute(1, 0, 2).contiguous(), 0
+    else:
+        xin, ldx = x, 32
+    st = m._stream()
+    ya, yb = torch.full((N, 16), 7.0, device=DEV), torch.full((N, 16), 7.0, device=DEV)
+    h1 = torch.empty((N, 64), device=DEV)
+    m._launch("snf_mlp64_fwd", m._p(xin), ldx, m._p(w0), 32, None, m._p(w1), 1, 16, m.ACT_NONE, N, None, None, m._p(ya), 16, st)
+    m._launch("snf_mlp64_fwd", m._p(xin), ldx, m._p(w0), 32, None, m._p(w1), 1, 16, m.ACT_NONE, N, m._p(h1), None, m._p(yb), 16, st)
+    torch.cuda.synchronize()
+    assert torch.equal(ya, yb)
+    ref = torch.relu(x.double() @ w0.double().T) @ w1.double().T
+    assert float((ya.double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+    assert torch.equal(h1, torch.relu(h1)) and float((h1.double() - torch.relu(x.double() @ w0.double().T)).abs().max()) <= 1e-5
+
+
+@pytest.mark.parametrize("R,S", [(512, 128), (37, 48), (1, 48), (2, 33), (3, 128)])
 def test_colour_net_with_its_input_row_formed_in_the_loader(R, S):
     """snf_mlp64_fwd_sh / snf_mlp64_bwd_fused_sh (fields/nerfacto_field.py:336-351 with cat(SH16(d), geo) formed inside the kernels)
     against snf_head_input + snf_mlp64_fwd + the recomputing snf_mlp64_bwd_fused on the written [N, 32] input: the same bits --

@@ -41,6 +41,15 @@ for t, d in pts:
     hist[lvl] += t - last; last = t; lvl += d
 hist[lvl] += hi - last
 print("C-ABI concurrency histogram (ms):", {k: round(v, 3) for k, v in sorted(hist.items())})
+MIN_MS = float(os.environ.get("MIN_MS", "0.04"))
 for a, b, sid, key in sel:
-    if b - a > 0.04:
+    if b - a > MIN_MS:
         print(f"{a - lo:8.3f} {b - a:7.3f} {name[sid]} {key}")
+if os.environ.get("PER_STREAM") == "1":  # every launch of the window stream by stream, with the idle gap in front of it
+    for sid in sids:
+        print(f"--- {name[sid]}")
+        prev = None
+        for a, b, s2, key in sorted(t for t in sel if t[2] == sid):
+            gap = (a - prev) if prev is not None else 0.0
+            print(f"{a - lo:8.3f} {b - a:7.3f} gap {gap:6.3f}  {key}")
+            prev = b
