@@ -161,7 +161,8 @@ class Trainer:
         self.overlap = os.environ.get("SNF_OVERLAP", "1") == "1"
         self.enqueue_order = "heads_first"
         self.pipeline_steps = False  # True: do not join the head streams at the end of a step (see train_iteration)
-        self.presort_host = "auto"  # "auto" | "sam" | "clipseg" | "own" (autotune_streams may pick "own")
+        # "auto" | "sam" | "clipseg" | "own" | "main": the stream of the forward-time sorts (autotune_streams may pick "own")
+        self.presort_host = os.environ.get("SNF_PRESORT_HOST", "auto")
         self._side = None
         # the step as a static launch schedule (step_program.py) instead of an autograd graph: same kernels, same arguments,
         # ~10x less host time per step, on one rank or many.  SNF_STATIC_STEP=0 keeps the eager autograd path.

@@ -508,6 +508,8 @@ class StepProgram:
                 pref = "clipseg" if "clipseg" in side else ("sam" if "sam" in side else "own")
             if pref in side:
                 sort_st = side[pref]
+            elif pref == "main":
+                sort_st = main
             else:
                 if self._own_sort_stream is None:
                     self._own_sort_stream = ops.make_stream("presort")
