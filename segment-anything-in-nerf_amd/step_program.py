@@ -57,8 +57,8 @@ FUSED_CHAIN_WGRAD = True  # weight gradients of the 64-wide nets inside the chai
 # by the forward and read back: needs the fused backward and the six-product forward arithmetic of gemm mode 1
 CHAIN_RECOMPUTE = True
 PROP_BWD_SIDE = None  # None: the proposal backward goes to the side stream only when there are no feature heads
-if _os.environ.get("SNF_PROP_BWD_SIDE") in ("0", "1"):
-    PROP_BWD_SIDE = _os.environ["SNF_PROP_BWD_SIDE"] == "1"
+if _os.environ.get("SNF_PROP_BWD_SIDE") in ("0", "1", "2"):  # (2: on the heads' shared weight-gradient stream)
+    PROP_BWD_SIDE = int(_os.environ["SNF_PROP_BWD_SIDE"])
 FEATURE_SORTS_ON_HEAD_STREAM = True
 # The head's last layer is linear (no bias, no output activation) and the renderer after it is a weighted sum over the K samples
 # of a ray (MeanRenderer, sam_model.py:126-137; the weights are detached, sam_model.py:260-277):
@@ -80,7 +80,9 @@ PAIR_GRID_BWD = True  # both feature grids of a head in one table-backward launc
 # ONE more stream (the fourth: one per hardware queue of the runtime's default four) takes the weight-gradient launches of BOTH heads and
 # the Adam launches that need them; a head's stream waits for it once, at the end of its task.  (Round 1's per-task companion streams
 # made seven streams, which the runtime multiplexes onto four queues -- the slow mode of DESIGN 5.)
-WGRAD_STREAM = _os.environ.get("SNF_WGRAD_STREAM", "0") == "1"
+# Same box, alternating, bench.py --steps 20 --warmup 5: 2.544 2.515 2.532 2.551 2.553 (3.364) 2.529 2.534 ms without it, 2.510 2.451 2.488
+# 2.486 2.478 2.452 2.524 2.513 2.552 2.509 2.460 2.474 with it (median 2.54 -> 2.49, no slow run in twelve): on by default, one rank.
+WGRAD_STREAM = _os.environ.get("SNF_WGRAD_STREAM", "1") == "1"
 FUSED_MEAN_EPILOGUE = True  # ... and the mean itself in the hidden layer's GEMM epilogue
 # Without feature heads the step is ONE dependency chain on the main stream.  Its head -- sampling, the proposal network, the
 # resampling, the positions and the backward sorts -- needs last step's PROPOSAL update only, not the field's: it is recorded on
@@ -721,8 +723,14 @@ class StepProgram:
         # field's backward but the forward results.  Without feature heads the GPU is otherwise on ONE stream during the
         # backward, so that chain goes to the (then idle) sort stream and runs beside the field backward; with heads the three
         # streams already saturate the chip and it stays on the main stream (step_program.PROP_BWD_SIDE overrides).
-        side_prop = True if xstep else (PROP_BWD_SIDE if PROP_BWD_SIDE is not None else (not self.heads))
+        # (with heads and the shared weight-gradient stream: there -- 2.553 2.549 2.569 2.541 -> 2.532 2.534 2.537 2.525 ms, same box)
+        side_prop = True if xstep else (PROP_BWD_SIDE if PROP_BWD_SIDE is not None else (2 if (self.heads and WGRAD_STREAM) else (not self.heads)))
+        use_wg = bool(side_prop == 2 and WGRAD_STREAM and self.heads and not self.multi and overlap)
+        if side_prop == 2 and not use_wg:
+            side_prop = False  # (no shared weight-gradient stream in this schedule: with heads the chain stays on the main stream)
         prop_st = sort_st if (updated and side_prop and sort_st.stream_id != main.stream_id) else main
+        if updated and use_wg:
+            prop_st = ops.make_stream("wgrad")
         prop_block = []
         if updated:
             mark = len(plan.entries)
