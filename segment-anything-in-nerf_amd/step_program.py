@@ -512,6 +512,8 @@ class StepProgram:
                 sort_st = side[pref]
             elif pref == "main":
                 sort_st = main
+            elif pref == "wgrad":  # the heads' shared weight-gradient stream: idle while the forward runs
+                sort_st = ops.make_stream("wgrad")
             else:
                 if self._own_sort_stream is None:
                     self._own_sort_stream = ops.make_stream("presort")

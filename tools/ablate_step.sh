@@ -5,7 +5,7 @@
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 out=$1; shift
 one() {
-  env SNF_ABLATE_SKIP="$1" python bench.py --allow-ablation --steps 40 --warmup 8 --cpu-baseline-seconds 0 --other-workloads none 2>/dev/null | python -c "
+  env SNF_ABLATE_SKIP="$1" python bench.py --allow-ablation --steps 40 --warmup 8 --cpu-baseline-seconds 0 --other-workloads none --steady-steps 0 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); print('${1:-none}'.ljust(48), 'step', round(d['ms_per_step'],3))"
 }

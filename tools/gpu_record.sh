@@ -12,7 +12,7 @@ cd /tmp && export TMPDIR=/tmp
 # counter passes first: the bench line below quotes their results (profiles/pmc_traffic.json -> roofline.traffic)
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --kernel-trace --kernel-include-regex $KREGEX --output-format csv -d $OUT/pmc_$C -o pmc -- \
-      python $ROOT/bench.py --steps 4 --warmup 2 --cpu-baseline-seconds 0 --other-workloads none > $OUT/pmc_$C.json 2> $OUT/pmc_$C.err
+      python $ROOT/bench.py --steps 4 --warmup 2 --cpu-baseline-seconds 0 --other-workloads none --steady-steps 0 > $OUT/pmc_$C.json 2> $OUT/pmc_$C.err
 done
 python $ROOT/tools/pmc_traffic.py $OUT --out $OUT/pmc_traffic.json > $OUT/pmc_traffic.log 2>&1 && cp $OUT/pmc_traffic.json $ROOT/profiles/pmc_traffic.json
 python $ROOT/bench.py > $OUT/bench.json 2> $OUT/bench.err

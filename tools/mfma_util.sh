@@ -10,7 +10,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 PMC="SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES"
 rocprofv3 --pmc $PMC --kernel-trace --output-format csv -d $OUT/step -o pmc -- \
-    python $ROOT/bench.py --steps 6 --warmup 3 --cpu-baseline-seconds 0 --other-workloads none > $OUT/bench.json 2> $OUT/bench.err
+    python $ROOT/bench.py --steps 6 --warmup 3 --cpu-baseline-seconds 0 --other-workloads none --steady-steps 0 > $OUT/bench.json 2> $OUT/bench.err
 # config #5: the render pass and the encoder (their matrix kernels are not part of the train step)
 rocprofv3 --pmc $PMC --kernel-trace --kernel-include-regex "k_grid_head_fused|k_gemm|k_mlp_chain" --output-format csv -d $OUT/render -o pmc -- \
     python $ROOT/tools/bench_render.py > /dev/null 2> $OUT/render.err

@@ -9,7 +9,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmcall_$C -o pmc -- \
-      python $ROOT/bench.py --steps 6 --warmup 3 --cpu-baseline-seconds 0 --other-workloads none > $OUT/pmcall_$C.json 2> $OUT/pmcall_$C.err
+      python $ROOT/bench.py --steps 6 --warmup 3 --cpu-baseline-seconds 0 --other-workloads none --steady-steps 0 > $OUT/pmcall_$C.json 2> $OUT/pmcall_$C.err
   rm -f $OUT/pmcall_$C/pmc_kernel_trace.csv
 done
 ls -la $OUT/pmcall_*/

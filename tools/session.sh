@@ -22,7 +22,7 @@ r=d.get("roofline") or {}
 print(sys.argv[1], "ms/step", round(d["ms_per_step"],4), "value", "%.4g"%d["value"], "step_frac", round(d["step_frac_of_hbm_peak"],4), "dom", r.get("kernel"), "live_frac", r.get("frac"), "serial_frac", (r.get("serial") or {}).get("frac"), "steady", (d.get("steady_state") or {}).get("ms_per_step"), "fb", (d.get("fwd_bwd_only") or {}).get("ms_per_step"))'
 bench_once() {  # $1 label, rest: env assignments
   local label=$1; shift
-  env "$@" python bench.py --steps 20 --warmup 5 --cpu-baseline-seconds 0 --other-workloads none 2>$OUT/last.err | python -c "$SUM" "$label" >> $OUT/out.txt 2>&1 || { echo "$label FAILED" >> $OUT/out.txt; tail -5 $OUT/last.err >> $OUT/out.txt; }
+  env "$@" python bench.py --steps 20 --warmup 5 --cpu-baseline-seconds 0 --other-workloads none --steady-steps 0 2>$OUT/last.err | python -c "$SUM" "$label" >> $OUT/out.txt 2>&1 || { echo "$label FAILED" >> $OUT/out.txt; tail -5 $OUT/last.err >> $OUT/out.txt; }
 }
 for step in "$@"; do
   echo "== $step" >> $OUT/out.txt
