@@ -742,6 +742,12 @@ def main():
                  "launches_timed": nl, "algorithmic_units_per_launch": total_units / max(nl, 1), "measured": where}
             if bound != "hbm":
                 o["peak_basis"] = basis
+            elif achieved > peak:
+                # SURVEY 8(d) counts REQUESTED gather bytes with no cache credit: once the proposal-weight anneal has pulled a ray's samples
+                # together (the serial replay runs after the timed region), most of a grid forward's gathers are served by L2 / the
+                # Infinity Cache, and the requested-byte rate can exceed what HBM could deliver
+                o["note"] = ("requested (algorithmic) bytes exceed the HBM peak: the gathers are served from L2 / Infinity Cache; "
+                             "this is a rate of requested bytes, not of HBM traffic")
             mkey = key.replace("_sh/", "/")
             if mkey in mu:  # matrix-core busy cycles / shader busy cycles of this entry point's kernels (rocprofv3 PMC pass)
                 o["mfma_busy"] = mu[mkey]
