@@ -423,7 +423,10 @@ constexpr int WF_T = 512;
 #define SNF_WS_EVEN_TILES 1
 #endif
 #ifndef SNF_WS_MIN_ROWS
-#define SNF_WS_MIN_ROWS 4096  // fewer rows than this: the tiled kernel (a weight-stationary workgroup stages a whole weight slice first)
+// fewer rows than this: the tiled kernel (a weight-stationary workgroup stages a whole weight slice first).  8192 since round 5: at 4096
+// rows (the heads' last layers on the rendered rows) the weight-stationary launch is 32 workgroups of 131 KB LDS -- 0.033 / 0.035 ms alone
+// where the tiled kernel's 128 light workgroups take 0.023 / 0.030, and inside the step each of them waits for an EMPTY CU
+#define SNF_WS_MIN_ROWS 8192
 #endif
 #ifndef SNF_WF_CHUNKS
 #define SNF_WF_CHUNKS 256  // row chunks (= workgroups, = partial sums P[chunk][O][I]) of the full-width weight gradient
