@@ -46,16 +46,10 @@ typedef unsigned int hg_u4v __attribute__((ext_vector_type(4)));
 typedef unsigned int hg_u2v __attribute__((ext_vector_type(2)));
 // Cache-policy probes (round 5).  The sort records and the Adam state are read once / written once per step, while the staged
 // gradient slab of a level (4 MB at N = 2^19: one L2) is gathered from by every workgroup of the level: marked non-temporal, the
-// streams should stop evicting the slab.  Bits: 1 record loads, 2 p/m/v loads, 4 p/m/v stores (F = 2 fixed-point reduce);
-// SNF_XP_NT_STORE: the x-pair scatter's record stores; SNF_HG_NT_REC: record loads of the F = 8 float reduce.
+// streams should stop evicting the slab.  Bits: 1 record loads, 2 p/m/v loads, 4 p/m/v stores (F = 2 fixed-point reduce).  (Non-temporal
+// record STORES in the x-pair scatter measured 40 % slower, non-temporal record loads in the F = 8 float reduce noise: not kept.)
 #ifndef SNF_FX_NT
 #define SNF_FX_NT 7  // measured, same box: field-grid backward 0.340 -> 0.327 ms serial, step 2.465 -> 2.438 ms (profiles/EXPERIMENTS.md r05)
-#endif
-#ifndef SNF_XP_NT_STORE
-#define SNF_XP_NT_STORE 0
-#endif
-#ifndef SNF_HG_NT_REC
-#define SNF_HG_NT_REC 0
 #endif
 
 __device__ __forceinline__ uint4 hg_ld_rec(const uint4* p, bool nt) {
@@ -247,9 +241,6 @@ constexpr int HG_LONG = 48;      // segments longer than this are reduced by a w
 //  and the concurrent step 2.55 -> 2.62 ms: this pass is not short of bytes in flight, profiles/EXPERIMENTS.md r05)
 #ifndef SNF_HG_EPI
 #define SNF_HG_EPI 2
-#endif
-#ifndef SNF_HG_PAD_LDS
-#define SNF_HG_PAD_LDS 0
 #endif
 constexpr int HG_EPI = SNF_HG_EPI;  // rows per thread in flight in the fused Adam epilogue of the float reduce
 
@@ -725,15 +716,7 @@ __global__ __launch_bounds__(256) void k_hg_scatter_xp(const float* __restrict__
         __syncthreads();
         // ---- 4: contiguous runs out; advance the cursors
         const uint32_t staged = total < (uint32_t)HG_XP_CAP ? total : (uint32_t)HG_XP_CAP;
-        for (uint32_t i = tid; i < staged; i += 256) {
-            if constexpr (SNF_XP_NT_STORE != 0) {
-                const uint4 r = stage[i];
-                const hg_u4v v = {r.x, r.y, r.z, r.w};
-                __builtin_nontemporal_store(v, reinterpret_cast<hg_u4v*>(&records[delta[sbkt[i]] + i]));
-            } else {
-                records[delta[sbkt[i]] + i] = stage[i];
-            }
-        }
+        for (uint32_t i = tid; i < staged; i += 256) records[delta[sbkt[i]] + i] = stage[i];
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
@@ -1054,10 +1037,6 @@ __global__ __launch_bounds__(HG_RT, SNF_HG_RT_MINWG) void k_hg_reduce(const floa
     __shared__ uint32_t wave_tot[HG_RT / 64];
     __shared__ uint32_t long_rows[CHUNK / 8 + 1];
     __shared__ uint32_t n_long;
-#if SNF_HG_PAD_LDS > 0  // occupancy probe: extra LDS so that fewer workgroups share a CU
-    __shared__ uint32_t lds_pad[SNF_HG_PAD_LDS / 4];
-    if (N < 0) lds_pad[threadIdx.x] = 1u;
-#endif
     const int B = 1 << log2B, log2rpb = log2_T - log2B;
     const int rpb = 1 << log2rpb;
     const int tid = threadIdx.x;
@@ -1121,7 +1100,7 @@ __global__ __launch_bounds__(HG_RT, SNF_HG_RT_MINWG) void k_hg_reduce(const floa
 #pragma unroll
         for (int j = 0; j < RPT; ++j) {
             const uint32_t i = c0 + tid + (uint32_t)HG_RT * j;
-            r[j] = hg_ld_rec(&records[i < end ? i : (start < end ? start : 0u)], SNF_HG_NT_REC != 0);  // (an empty bucket is still visited when ADAM)
+            r[j] = records[i < end ? i : (start < end ? start : 0u)];  // (an empty bucket is still visited when ADAM)
         }
     };
     auto gather = [&](const auto& r, auto& gg) {
