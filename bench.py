@@ -133,19 +133,18 @@ def build_trainer(w: dict, local_rank: int, world: int, seed: int = 0):
     return trainer
 
 
-def cpu_baseline(w: dict, budget_s: float):
-    """Time the CPU oracle (fwd + bwd of the same step, full-size tables) on a bounded number of rays."""
+def _cpu_baseline_worker(w: dict, budget_s: float, threads: int, seed: int) -> dict:
+    """One process of the CPU baseline: the oracle's fwd + bwd on its own R / 16 rays with `threads` torch threads."""
     from oracle import samnerf_oracle as O
-    # torch's CPU kernels stop scaling (and start thrashing) far below the 256 hardware threads of the GPU box
-    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    torch.set_num_threads(threads)
     distill = w["method"] == "samnerf_distill"
     cfg = O.PathConfig(num_proposal_samples=w["P"], num_nerf_samples=w["S"], num_sam_samples=w["K"],
                        patch_size=w["patch"], distill_sam=distill, use_clipseg=distill)
     R = w["R"] // 16  # SURVEY 8(d): "for the full-size configs allow R to be reduced x16 on CPU and scale linearly"
     params = {k: v.requires_grad_(True) for k, v in O.init_params(cfg, seed=0).items()}
-    o, d = O.synthetic_rays(R, 0)
-    batch = O.synthetic_batch(cfg, R, 1)
-    gen = torch.Generator().manual_seed(2)
+    o, d = O.synthetic_rays(R, seed)
+    batch = O.synthetic_batch(cfg, R, 1 + seed)
+    gen = torch.Generator().manual_seed(2 + seed)
     t_rand, u_rand = torch.rand((R, 1), generator=gen), torch.rand((R, 1), generator=gen)
 
     def step():
@@ -164,15 +163,45 @@ def cpu_baseline(w: dict, budget_s: float):
         el = time.perf_counter() - t0
         if el >= budget_s or n >= 10:
             break
+    return {"rays": R, "steps": n, "seconds": el, "warmup": n_warm, "threads": torch.get_num_threads()}
+
+
+def cpu_baseline(w: dict, budget_s: float):
+    """Time the CPU oracle (fwd + bwd of the same step, full-size tables) on a bounded number of rays, on ALL host cores: torch's
+    CPU kernels stop scaling (and start thrashing) near 32 threads, so the host's hardware threads are used as cpu_count // 32
+    processes of 32 threads (at most 8), each on its own rays, running concurrently; `value` is the sum of their rates."""
+    import subprocess
+    ncpu = os.cpu_count() or 1
+    threads = min(ncpu, 32)
+    procs = max(1, min(8, ncpu // 32))
+    spec = json.dumps({k: w[k] for k in ("method", "R", "P", "S", "K", "patch")})
+    cmd = lambda i: [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", spec, "--cpu-baseline-seconds", str(budget_s),  # noqa: E731
+                     "--cpu-baseline-threads", str(threads), "--cpu-baseline-seed", str(i)]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env["HIP_VISIBLE_DEVICES"] = ""  # (the workers never touch the GPU)
+    ps = [subprocess.Popen(cmd(i), stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=env, cwd=ROOT) for i in range(procs)]
+    res = []
+    for p_ in ps:
+        out_, _ = p_.communicate(timeout=60 * 30)
+        lines = [l for l in out_.splitlines() if l.startswith("{")]
+        if p_.returncode == 0 and lines:
+            res.append(json.loads(lines[-1]))
+    if not res:  # (no worker came back: time one in-process, as before)
+        res, procs = [_cpu_baseline_worker(w, budget_s, threads, 0)], 1
     try:  # SURVEY 8d: core count and CPU model of the box beside the number
         model = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
     except (OSError, StopIteration):
         model = "unknown"
-    return {"value": R * w["S"] * n / el, "unit": "ray-samples/s", "cores": torch.get_num_threads(), "kind": "port",
-            "cpu_model": model, "host_cores": os.cpu_count(),
-            "sample": f"{n_warm} warm-up + {n} timed fwd+bwd steps of {R} rays (the workload's R / 16) x {w['S']} samples "
-                      f"(P={w['P']}, K={w['K']}), full-size fp32 tables, no optimizer step, {el:.1f} s of timed CPU work; "
-                      f"{torch.get_num_threads()} of {os.cpu_count()} hardware threads (torch's CPU kernels stop scaling there)"}
+    value = sum(r["rays"] * w["S"] * r["steps"] / r["seconds"] for r in res)
+    used = sum(r["threads"] for r in res)
+    r0 = res[0]
+    return {"value": value, "unit": "ray-samples/s", "cores": used, "kind": "port", "cpu_model": model, "host_cores": ncpu,
+            "processes": len(res), "threads_per_process": r0["threads"],
+            "per_process_ray_samples_per_s": [round(r["rays"] * w["S"] * r["steps"] / r["seconds"], 1) for r in res],
+            "sample": f"{len(res)} concurrent processes x {r0['threads']} threads, each {r0['warmup']} warm-up + {r0['steps']} timed fwd+bwd "
+                      f"steps of {r0['rays']} rays (the workload's R / 16) x {w['S']} samples (P={w['P']}, K={w['K']}), full-size fp32 "
+                      f"tables, no optimizer step, {max(r['seconds'] for r in res):.1f} s of timed CPU work per process; {used} of {ncpu} "
+                      f"hardware threads (one torch process stops scaling near 32 threads: the host is filled with processes instead)"}
 
 
 def _free(trainer) -> None:
@@ -462,7 +491,14 @@ def main():
                     help="extra steps timed AFTER everything else and reported under 'steady_state' (0 disables)")
     ap.add_argument("--allow-ablation", action="store_true",
                     help="measurement only: accept SNF_ABLATE_SKIP (launches left out, results garbage); the line says so")
+    ap.add_argument("--cpu-baseline-worker", default=None, help=argparse.SUPPRESS)   # (internal: one process of cpu_baseline)
+    ap.add_argument("--cpu-baseline-threads", type=int, default=32, help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-baseline-seed", type=int, default=0, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.cpu_baseline_worker:
+        print(json.dumps(_cpu_baseline_worker(json.loads(args.cpu_baseline_worker), args.cpu_baseline_seconds, args.cpu_baseline_threads,
+                                              args.cpu_baseline_seed)))
+        return
     w = dict(WORKLOADS[args.workload])
     if os.environ.get("SNF_ABLATE_SKIP") and not args.allow_ablation:
         sys.exit("bench.py: SNF_ABLATE_SKIP is set -- the schedule would skip launches and the number would be invalid. "

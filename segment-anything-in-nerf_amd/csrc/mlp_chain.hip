@@ -27,6 +27,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef SNF_CHAIN_PREFETCH
 #define SNF_CHAIN_PREFETCH 1
 #endif
+#ifndef SNF_WG_BF
+#define SNF_WG_BF 1  // fused backward of the colour net: the input row by the branch-free loader of the forward (chain_sh_load_bf)
+#endif
 constexpr int MC_H = 64;        // hidden width
 constexpr int MC_IN = 32;       // (padded) input width
 constexpr int MC_P0 = 33;       // LDS pitch of W0 [64][32]
@@ -533,6 +536,49 @@ __device__ __forceinline__ void chain_sh_row(const float* __restrict__ Hb, int l
     chain_sh_form(raw, half, xo);
 }
 
+// The same row with ONE set of loads for all lanes (round 5; "branch-free vector memory" below): half-wave 1 reads the base net's row as
+// four 16-byte loads, half-wave 0 its ray's direction as a 16-byte WINDOW of dirs (one float early for the last ray, so that the window
+// stays inside the array) by the first load and the same address again by the other three (same line, no new traffic) -- no register is
+// written under two exec masks, so nothing forces a wait between the request and its use a tile later.  A single ray has no 16-byte
+// window inside its 12-byte direction: `od` then carries it (three scalar loads by the caller) and half-wave 0 re-reads the base net's row.
+struct ChainShBf {
+    long long n_rays;
+    bool one_ray;
+    float od[3];
+};
+__device__ __forceinline__ ChainShBf chain_sh_bf_init(const ChainSh& sh, long long N) {
+    ChainShBf b;
+    b.n_rays = sh.log2S >= 0 ? (N >> sh.log2S) : N / sh.S;
+    b.one_ray = b.n_rays <= 1;
+    b.od[0] = b.od[1] = b.od[2] = 0.f;
+    if (b.one_ray) { b.od[0] = sh.dirs[0]; b.od[1] = sh.dirs[1]; b.od[2] = sh.dirs[2]; }
+    return b;
+}
+__device__ __forceinline__ void chain_sh_load_bf(const float* __restrict__ Hb, int ldh, const ChainSh& sh, const ChainShBf& bf,
+                                                 long long s, int half, f32x16& xo) {
+    const long long r = sh.log2S >= 0 ? (s >> sh.log2S) : s / sh.S;
+    const float* pr = Hb + s * ldh;
+    const float* pd = bf.one_ray ? pr : sh.dirs + r * 3 - ((r == bf.n_rays - 1) ? 1 : 0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float* pq = half ? pr + 4 * q : pd;
+        const float4 v = *reinterpret_cast<const float4*>(pq);
+        xo[4 * q] = v.x; xo[4 * q + 1] = v.y; xo[4 * q + 2] = v.z; xo[4 * q + 3] = v.w;
+    }
+}
+__device__ __forceinline__ void chain_sh_form_bf(const f32x16& raw, const ChainSh& sh, const ChainShBf& bf, long long s, int half,
+                                                 f32x16& xo) {
+    const long long r = sh.log2S >= 0 ? (s >> sh.log2S) : s / sh.S;
+    const bool shifted = r == bf.n_rays - 1;
+    f32x16 rw = raw;
+    if (half == 0) {  // (selects, no loads: the direction sits in [0..2] or, for the last ray, in [1..3])
+        rw[0] = bf.one_ray ? bf.od[0] : shifted ? raw[1] : raw[0];
+        rw[1] = bf.one_ray ? bf.od[1] : shifted ? raw[2] : raw[1];
+        rw[2] = bf.one_ray ? bf.od[2] : shifted ? raw[3] : raw[2];
+    }
+    chain_sh_form(rw, half, xo);
+}
+
 // ---- branch-free vector memory for the tile loops (round 5) ------------------------------------------------------------------------
 // A wave is alone on its SIMD in these kernels, so a memory wait is dead time, and on gfx950 loads and stores share ONE counter (vmcnt,
 // in issue order).  Two things turned the "row requested a tile ahead" into a wait per tile (34 % of the wave cycles parked, round-4
@@ -598,28 +644,13 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 4 : SNF_CHAIN_FWD_WAVES) 
     const long long ntiles = (N + 31) / 32;
     // The NEXT tile's input row is requested before this tile's layers run and consumed (formed, masked) behind this tile's stores:
     // see "branch-free vector memory" above.  Every lane issues the same loads: rows past the batch are clamped to the last one.
-    const long long n_rays = SH ? (sh.log2S >= 0 ? (N >> sh.log2S) : N / sh.S) : 0;
-    // (a single ray: no 16-byte window inside its 12-byte direction -- the direction comes from three scalar loads here and half-wave 0
-    //  re-reads the base net's row instead)
-    const bool one_ray = SH && n_rays <= 1;
-    float od[3] = {0.f, 0.f, 0.f};
-    if (SH && one_ray) { od[0] = sh.dirs[0]; od[1] = sh.dirs[1]; od[2] = sh.dirs[2]; }
+    ChainShBf bf{};
+    if constexpr (SH) bf = chain_sh_bf_init(sh, N);
     auto load_x = [&](long long tile_, f32x16& xo) {
         const long long s_ = tile_ * 32 + li;
         const long long sc_ = s_ < N ? s_ : N - 1;
         if constexpr (SH) {
-            // half-wave 1: the base net's row, four 16-byte loads; half-wave 0: its ray's direction -- FOUR floats from dirs + 3 r (one
-            // float early for the last ray, so that the load stays inside the array) by the first load, the other three re-read it
-            // (same line, no new traffic): one set of instructions, one exec mask, no register written under two masks
-            const long long r = sh.log2S >= 0 ? (sc_ >> sh.log2S) : sc_ / sh.S;
-            const float* pr = X + sc_ * ldx;
-            const float* pd = one_ray ? pr : sh.dirs + r * 3 - ((r == n_rays - 1) ? 1 : 0);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float* pq = half ? pr + 4 * q : pd;
-                const float4 v = *reinterpret_cast<const float4*>(pq);
-                xo[4 * q] = v.x; xo[4 * q + 1] = v.y; xo[4 * q + 2] = v.z; xo[4 * q + 3] = v.w;
-            }
+            chain_sh_load_bf(X, ldx, sh, bf, sc_, half, xo);
         } else if (LM == 1 || (LM == 0 && ldx == 0)) {
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
@@ -639,15 +670,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 4 : SNF_CHAIN_FWD_WAVES) 
         if constexpr (SH) {
             const long long s_ = tile_ * 32 + li;
             const long long sc_ = s_ < N ? s_ : N - 1;
-            const long long r = sh.log2S >= 0 ? (sc_ >> sh.log2S) : sc_ / sh.S;
-            const bool shifted = r == n_rays - 1;
-            f32x16 rw = raw;
-            if (half == 0) {  // (selects, no loads: the direction sits in [0..2] or, for the last ray, in [1..3])
-                rw[0] = one_ray ? od[0] : shifted ? raw[1] : raw[0];
-                rw[1] = one_ray ? od[1] : shifted ? raw[2] : raw[1];
-                rw[2] = one_ray ? od[2] : shifted ? raw[3] : raw[2];
-            }
-            chain_sh_form(rw, half, xo);
+            chain_sh_form_bf(raw, sh, bf, sc_, half, xo);
         } else {
             xo = raw;
         }
@@ -976,11 +999,14 @@ __global__ __launch_bounds__(WG_T) __attribute__((amdgpu_waves_per_eu(NH == 1 ? 
     const long long ntiles = (N + 31) / 32;
     // (SNF_CHAIN_PREFETCH, RC only: the next tile's input row and output gradients are requested while this tile is worked on --
     //  the wave is alone on its SIMD and would otherwise sit out both latencies at the top of every tile)
+    ChainShBf bfb{};
+    if constexpr (SH && SNF_WG_BF != 0) bfb = chain_sh_bf_init(sh, N);
     auto load_x = [&](long long tile_, f32x16& xo) {
         const long long s_ = tile_ * 32 + li;
         const long long sc_ = s_ < N ? s_ : N - 1;
         if constexpr (SH) {
-            chain_sh_load(X, ldx, sh, sc_, half, xo);  // (raw; formed below)
+            if constexpr (SNF_WG_BF != 0) chain_sh_load_bf(X, ldx, sh, bfb, sc_, half, xo);  // (raw; formed below)
+            else chain_sh_load(X, ldx, sh, sc_, half, xo);
         } else if (ldx == 0) {
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
@@ -1057,7 +1083,8 @@ __global__ __launch_bounds__(WG_T) __attribute__((amdgpu_waves_per_eu(NH == 1 ? 
             }
             if constexpr (SH) {
                 const f32x16 raw = xr[0];
-                chain_sh_form(raw, half, xr[0]);
+                if constexpr (SNF_WG_BF != 0) chain_sh_form_bf(raw, sh, bfb, sc, half, xr[0]);
+                else chain_sh_form(raw, half, xr[0]);
             }
 #pragma unroll
             for (int i = 0; i < 16; ++i)
