@@ -474,10 +474,16 @@ int snf_split_planes(const float* x, int64_t n, uint16_t* hi, uint16_t* lo, snf_
 int snf_split_planes_kb(const float* x, int M, int K, uint16_t* hi, uint16_t* lo, snf_stream_t stream);
 int snf_linear_planes_fwd(const uint16_t* a_hi, const uint16_t* a_lo, const uint16_t* w_hi, const uint16_t* w_lo, const float* bias,
                           int M, int K, int Nc, int act, float* C, uint16_t* c_hi, uint16_t* c_lo, snf_stream_t stream);
-/* (tuning / benchmarking: the same with the tile shape (128 rb rows x 32 nb columns) given instead of chosen) */
+/* (tuning / benchmarking: the same with the tile shape (128 rb rows x 32 nb columns; rb = -1: 256 rows, 512-thread workgroup) given
+ * instead of chosen) */
 int snf_linear_planes_fwd_shape(const uint16_t* a_hi, const uint16_t* a_lo, const uint16_t* w_hi, const uint16_t* w_lo,
                                 const float* bias, int M, int K, int Nc, int act, float* C, uint16_t* c_hi, uint16_t* c_lo, int rb,
                                 int nb, snf_stream_t stream);
+/* ... with the weights k-blocked as well (w_hi / w_lo [K/8][Nc][8] = snf_split_planes_kb of the [Nc][K] matrix): 256 x 320 / 256 x 256
+ * tiles with both operands staged through LDS; K % 64 == 0, Nc % 320 == 0 or Nc % 256 == 0.  Same products in the same order per
+ * output as snf_linear_planes_fwd (bit-identical results). */
+int snf_linear_planes_kb_fwd(const uint16_t* a_hi, const uint16_t* a_lo, const uint16_t* w_hi, const uint16_t* w_lo, const float* bias,
+                             int M, int K, int Nc, int act, float* C, uint16_t* c_hi, uint16_t* c_lo, snf_stream_t stream);
 int snf_layernorm_planes(const float* x, const float* residual, int N, int C, const float* weight, const float* bias, float eps,
                          float* sum_out, uint16_t* y_hi, uint16_t* y_lo, int M_out, int H, int W, int ws, snf_stream_t stream);
 /* ... with the block's window_unpartition + `shortcut + x` (snf_window_merge_add) folded in: residual_windows are the projection's

@@ -145,6 +145,7 @@ SIGNATURES = {
     "snf_split_planes_kb": [P, I, I, P, P, P],
     "snf_linear_planes_fwd": [P, P, P, P, P, I, I, I, I, P, P, P, P],
     "snf_linear_planes_fwd_shape": [P, P, P, P, P, I, I, I, I, P, P, P, I, I, P],
+    "snf_linear_planes_kb_fwd": [P, P, P, P, P, I, I, I, I, P, P, P, P],
     "snf_layernorm_planes": [P, P, I, I, P, P, F, P, P, P, I, I, I, I, P],
     "snf_layernorm_planes_merge": [P, P, I, I, P, P, F, P, P, P, I, I, I, P],
     "snf_attention_planes": [P, P, I, I, I, I, I, F, P, P, P],

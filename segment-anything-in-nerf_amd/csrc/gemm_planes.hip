@@ -25,6 +25,16 @@ typedef __bf16 gp_bf16x2 __attribute__((ext_vector_type(2)));
 typedef float gp_f32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t gp_u32x4 __attribute__((ext_vector_type(4)));  // (native vector: arrays of HIP's uint4 struct stayed in scratch memory)
 
+// GP_ABL (tools/ablate_gp.sh): pieces of the k loop compiled out, results WRONG -- 1: no activation-fragment loads, 2: no weight-fragment
+// LDS reads, 4: no weight chunk staging (global load, LDS store, barrier), 8: the hi*hi products only (a third of the MFMAs),
+// 16: every wave loads the fragments of rows 0 .. 32 RB (cache hits)
+// GP_RING: activation-fragment slots in registers (k-steps requested ahead + 1): 4, or 8 (K % 128 == 0)
+#ifndef GP_RING
+#define GP_RING 4
+#endif
+#ifndef GP_ABL
+#define GP_ABL 0
+#endif
 constexpr int GP_KC = 64;            // k per staged weight chunk (4 MFMA k-steps)
 constexpr int GP_PITCH = GP_KC + 8;  // bf16 per LDS row: 144 B, the b128 fragment reads of 16 lanes fall on distinct banks
 
@@ -82,12 +92,14 @@ __global__ __launch_bounds__(256) void k_split_planes_kb(const float* __restrict
 // an XCD walks a CONTIGUOUS range of the tile list, and the list runs over groups of 8 column tiles, row tiles inside a group,
 // the group's columns fastest -- the ~64 workgroups an XCD has in flight form an 8 x 8 block of tiles and share their operand rows
 // and weight columns in that XCD's L2.
-template <int RB, int NB, bool CT>
-__global__ __launch_bounds__(256, (RB * NB <= 4 ? 2 : 1)) void k_gemm_planes(
+// WAVES = 8: a 512-thread workgroup, (256 RB) rows -- the same wave program, twice the rows behind one staged weight chunk: the
+// bytes a CU pulls through its vector cache per product are 1 / (32 NB) for the fragments + 1 / (32 RB WAVES) for the weights.
+template <int RB, int NB, bool CT, int WAVES = 4>
+__global__ __launch_bounds__(64 * WAVES, (RB * NB <= 4 && WAVES == 4 ? 2 : 1)) void k_gemm_planes(
     const uint16_t* Ahi, const uint16_t* Alo, const uint16_t* Whi, const uint16_t* Wlo,  // (no __restrict__: see GP_PIN)
     const float* __restrict__ bias, int M, int K, int Nc, int act, float* __restrict__ C,
     uint16_t* __restrict__ Chi, uint16_t* __restrict__ Clo, int row_tiles, int col_tiles) {
-    constexpr int BN = 32 * NB, TR = 128 * RB;
+    constexpr int BN = 32 * NB, TR = 32 * WAVES * RB;
     constexpr int BUF = 2 * BN * GP_PITCH;  // bf16 elements per LDS buffer (hi plane, lo plane)
     extern __shared__ __attribute__((aligned(16))) uint16_t gp_lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -114,19 +126,22 @@ __global__ __launch_bounds__(256, (RB * NB <= 4 ? 2 : 1)) void k_gemm_planes(
     int aoff[RB];  // elements; M K < 2^31 checked by the host
 #pragma unroll
     for (int b = 0; b < RB; ++b) {
-        const int r = min(row0 + 32 * b + li, M - 1);  // rows past M are computed on row M - 1 and dropped
+        const int r = (GP_ABL & 16) ? 32 * b + li : min(row0 + 32 * b + li, M - 1);  // rows past M are computed on row M - 1 and dropped
         aoff[b] = (half * M + r) * 8;
     }
     const size_t a_step = (size_t)16 * M;  // elements between the fragments of consecutive k-steps (two k-blocks)
     // a weight chunk = 2 planes x BN rows x 8 pieces of 16 bytes; piece j of thread tid is row (tid >> 3) + 32 (j % NB), k piece
     // tid & 7 of plane j / NB (Nc % BN == 0: no clamp, so the row of piece j is a uniform distance from the row of piece 0)
-    constexpr int PIECES = 2 * NB;
-    const int woff = (tid >> 3) * K + (tid & 7) * 8;            // elements, < 2^31 (host)
-    const int wl = (tid >> 3) * GP_PITCH + (tid & 7) * 8;       // LDS element offset of piece 0
-    const uint16_t* wtile_h = Whi + (size_t)col0 * K;
+    // (8 waves: the plane is a thread's own -- bit 3 of tid -- and it copies NB pieces of it, rows (tid >> 4) + 32 j)
+    constexpr bool W8 = WAVES == 8;
+    constexpr int PIECES = W8 ? NB : 2 * NB;
+    const int wrow = W8 ? tid >> 4 : tid >> 3, wplane = W8 ? (tid >> 3) & 1 : 0;
+    const int woff = wrow * K + (tid & 7) * 8;                                          // elements, < 2^31 (host)
+    const int wl = wplane * BN * GP_PITCH + wrow * GP_PITCH + (tid & 7) * 8;            // LDS element offset of piece 0
+    const uint16_t* wtile_h = (wplane ? Wlo : Whi) + (size_t)col0 * K;
     const uint16_t* wtile_l = Wlo + (size_t)col0 * K;
     gp_u32x4 wreg[PIECES];
-    gp_u32x4 ra[4][RB][2];
+    gp_u32x4 ra[GP_RING][RB][2];
     gp_f32x16 acc[RB][NB];
 #pragma unroll
     for (int b = 0; b < RB; ++b)
@@ -147,12 +162,12 @@ __global__ __launch_bounds__(256, (RB * NB <= 4 ? 2 : 1)) void k_gemm_planes(
     // (macros, not lambdas: with the arrays captured by reference the compiler kept `wreg` in scratch memory)
 #define GP_WLOAD(chunk_)                                                                                                        \
     _Pragma("unroll") for (int j = 0; j < PIECES; ++j) {                                                                        \
-        const uint16_t* ub = (j < NB ? wtile_h : wtile_l) + (size_t)(32 * (j % NB)) * K + (size_t)(chunk_) * GP_KC; \
+        const uint16_t* ub = (W8 || j < NB ? wtile_h : wtile_l) + (size_t)(32 * (j % NB)) * K + (size_t)(chunk_) * GP_KC; \
         wreg[j] = *reinterpret_cast<const gp_u32x4*>(ub + woff);                                                                   \
     }
 #define GP_WSTORE(buf_)                                                                                                         \
     _Pragma("unroll") for (int j = 0; j < PIECES; ++j)                                                                          \
-        *reinterpret_cast<gp_u32x4*>(&gp_lds[(buf_) * BUF + (j < NB ? 0 : BN * GP_PITCH) + 32 * (j % NB) * GP_PITCH + wl]) = wreg[j];
+        *reinterpret_cast<gp_u32x4*>(&gp_lds[(buf_) * BUF + (W8 || j < NB ? 0 : BN * GP_PITCH) + 32 * (j % NB) * GP_PITCH + wl]) = wreg[j];
 #define GP_ALOAD(s_, u_)                                                                                                        \
     {                                                                                                                           \
         const uint16_t* uh = Ahi + (size_t)(s_) * a_step;                                                          \
@@ -169,7 +184,7 @@ __global__ __launch_bounds__(256, (RB * NB <= 4 ? 2 : 1)) void k_gemm_planes(
     }
     GP_WLOAD(0)
 #pragma unroll
-    for (int u = 0; u < 3; ++u) GP_ALOAD(min(u, ksteps - 1), u)  // (slot 3 is filled by the loop's first step)
+    for (int u = 0; u < GP_RING - 1; ++u) GP_ALOAD(min(u, ksteps - 1), u)  // (the last slot is filled by the loop's first step)
     GP_WSTORE(0)
     __syncthreads();
     // Program order is pinned with sched_barrier: left alone, the compiler sinks every global load of the loop body to its end and
@@ -185,7 +200,12 @@ __global__ __launch_bounds__(256, (RB * NB <= 4 ? 2 : 1)) void k_gemm_planes(
     // block before or after the MFMAs and the matrix pipe runs dry meanwhile (~200 of ~970 cycles per step at RB NB = 8).
     constexpr int NM = 3 * RB * NB;
 #define GP_MFMAS()                                                                                                              \
-    if constexpr (CT) {                                                                                                         \
+    if constexpr ((GP_ABL & 8) != 0) {                                                                                          \
+        _Pragma("unroll") for (int tt = 0; tt < NB; ++tt)                                                                       \
+            _Pragma("unroll") for (int b = 0; b < RB; ++b)                                                                      \
+                acc[b][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[b], bh[tt], acc[b][tt], 0, 0, 0);                       \
+        asm volatile("" ::"v"(al[0]), "v"(bl[0]));                                                                              \
+    } else if constexpr (CT) {                                                                                                         \
         _Pragma("unroll") for (int tt = 0; tt < NB; ++tt)                                                                       \
             _Pragma("unroll") for (int b = 0; b < RB; ++b)                                                                      \
                 acc[b][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[tt], al[b], acc[b][tt], 0, 0, 0);                       \
@@ -214,7 +234,11 @@ __global__ __launch_bounds__(256, (RB * NB <= 4 ? 2 : 1)) void k_gemm_planes(
     }
     gp_bf16x8 bh[NB], bl[NB];
     GP_READ_B(gp_lds, 0, bh, bl)
-    for (int c = 0; c < chunks; ++c) {
+    constexpr int CPN = GP_RING / 4;  // chunks per trip: the slot of a k-step is a compile-time number
+    for (int c0 = 0; c0 < chunks; c0 += CPN)
+#pragma unroll
+    for (int cp = 0; cp < CPN; ++cp) {
+        const int c = c0 + cp;
         const uint16_t* __restrict__ Bb = gp_lds + (c & 1) * BUF;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -222,26 +246,33 @@ __global__ __launch_bounds__(256, (RB * NB <= 4 ? 2 : 1)) void k_gemm_planes(
             gp_bf16x8 ah[RB], al[RB], nh[NB], nl[NB];
 #pragma unroll
             for (int b = 0; b < RB; ++b) {
-                ah[b] = __builtin_bit_cast(gp_bf16x8, ra[u][b][0]);
-                al[b] = __builtin_bit_cast(gp_bf16x8, ra[u][b][1]);
+                ah[b] = __builtin_bit_cast(gp_bf16x8, ra[(4 * cp + u) & (GP_RING - 1)][b][0]);
+                al[b] = __builtin_bit_cast(gp_bf16x8, ra[(4 * cp + u) & (GP_RING - 1)][b][1]);
             }
             // (all loads unconditional, clamped: loads under branches make the compiler drain every load in flight first)
-            if (u == 0) GP_WLOAD(min(c + 1, chunks - 1))
-            if (u < 3) GP_READ_B(Bb, u + 1, nh, nl)
-            GP_ALOAD(min(4 * c + u + 3, ksteps - 1), (u + 3) & 3)
+            if (u == 0 && !(GP_ABL & 4)) GP_WLOAD(min(c + 1, chunks - 1))
+            if (u < 3) {
+                if constexpr (GP_ABL & 2) {
+#pragma unroll
+                    for (int tt = 0; tt < NB; ++tt) { nh[tt] = bh[tt]; nl[tt] = bl[tt]; }
+                } else {
+                    GP_READ_B(Bb, u + 1, nh, nl)
+                }
+            }
+            if (!(GP_ABL & 1)) GP_ALOAD(min(4 * c + u + GP_RING - 1, ksteps - 1), (4 * cp + u + GP_RING - 1) & (GP_RING - 1))
             GP_MFMAS()
-            if (u == 3) { GP_WSTORE((c + 1) & 1) }  // (that buffer was last read in chunk c - 1, behind a barrier)
+            if (u == 3 && !(GP_ABL & 4)) { GP_WSTORE((c + 1) & 1) }  // (that buffer was last read in chunk c - 1, behind a barrier)
             if (u < 3) GP_WEAVE(0x100, 2 * NB)
-            GP_WEAVE(0x020, (u == 0 ? 2 * NB : 0) + 2 * RB)
-            if (u == 3) GP_WEAVE(0x200, 2 * NB)
+            GP_WEAVE(0x020, (u == 0 ? PIECES : 0) + 2 * RB)
+            if (u == 3) GP_WEAVE(0x200, PIECES)
             if (u < 3) {
 #pragma unroll
                 for (int tt = 0; tt < NB; ++tt) { bh[tt] = nh[tt]; bl[tt] = nl[tt]; }
             }
         }
         GP_PIN();
-        __syncthreads();
-        GP_READ_B(gp_lds + ((c + 1) & 1) * BUF, 0, bh, bl)
+        if (!(GP_ABL & 4)) __syncthreads();
+        if (!(GP_ABL & 2)) GP_READ_B(gp_lds + ((c + 1) & 1) * BUF, 0, bh, bl)
     }
 #undef GP_MFMAS
 #undef GP_WEAVE
@@ -295,14 +326,238 @@ __global__ __launch_bounds__(256, (RB * NB <= 4 ? 2 : 1)) void k_gemm_planes(
     }
 }
 
-template <int RB, int NB, bool CT>
+template <int RB, int NB, bool CT, int WAVES = 4>
 static void gp_launch(hipStream_t st, const uint16_t* Ahi, const uint16_t* Alo, const uint16_t* Whi, const uint16_t* Wlo,
                       const float* bias, int M, int K, int Nc, int act, float* C, uint16_t* Chi, uint16_t* Clo) {
-    constexpr int BN = 32 * NB, TR = 128 * RB;
+    constexpr int BN = 32 * NB, TR = 32 * WAVES * RB;
     const int row_tiles = (M + TR - 1) / TR, col_tiles = (Nc + BN - 1) / BN;
     const int total = row_tiles * col_tiles, per = (total + 7) >> 3;
     const size_t lds = (size_t)2 * 2 * BN * GP_PITCH * sizeof(uint16_t);
-    auto kern = k_gemm_planes<RB, NB, CT>;
+    auto kern = k_gemm_planes<RB, NB, CT, WAVES>;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(8 * per), dim3(64 * WAVES), lds, st, Ahi, Alo, Whi, Wlo, bias, M, K, Nc, act, C, Chi, Clo, row_tiles,
+                       col_tiles);
+}
+
+
+// ---- both operands through LDS ---------------------------------------------------------------------------------------------------
+// k_gemm_planes above is bound by what a CU pulls through its vector cache (tools/ablate_gp.sh: with the fragment loads compiled out
+// the 256 x 64 tile runs 150 -> 115 us on 4096 x 1280 -> 5120, with every wave loading the SAME rows -- all hits -- still 140, with
+// twice the fragments in flight no different): 81 % of the cache's 64 B/clk at the matrix rate, while the LDS (256 B/clk for b128
+// reads) idles.  Here the workgroup is 4 waves in a 2 x 2 grid, one per SIMD with the whole register file: a wave owns 128 rows x
+// (32 NB) columns (320 accumulator registers at NB = 5), the tile is 256 rows x (64 NB) columns, and BOTH operands are k-blocked
+// planes ([K/8][M][8], [K/8][Nc][8]: the weights are split once, their layout is free) that arrive in LDS by
+// global_load_lds_dwordx4 -- a piece is 64 consecutive rows of one k-block of one plane, 1 KB, LDS image = global image,
+// conflict-free for the b128 fragment reads as it lies.  Per 16 k a CU moves (8 + 2 NB) x 2 KB through the cache for 12 NB x 4 MFMAs
+// (29 % of its rate at NB = 5) and reads (8 + 2 NB) x 4 KB of fragments (15 % of the LDS's).
+// Schedule: a stage = 32 k = two k-steps (72 KB at NB = 5), two stage buffers, ONE barrier per stage, in its middle:
+//     k-step 0 of stage c   [its 12 NB MFMAs | the LDS reads of k-step 1's fragments, other register set]
+//     wait (those reads; this wave's copies of stage c + 1), barrier      -> buffer c & 1 is free, stage c + 1 is visible
+//     k-step 1 of stage c   [MFMAs | the copies of stage c + 2 into buffer c & 1 | the reads of stage c + 1's first fragments]
+// so a copy has a whole stage (~3800 cycles) to land and no fragment read waits behind a barrier.
+// 4096 x 5120 makes exactly 256 tiles of 256 x 320.
+typedef __attribute__((address_space(1))) const void* gp_gptr;
+typedef __attribute__((address_space(3))) void* gp_lptr;
+
+template <int RB, int NB, bool CT>
+__global__ __launch_bounds__(256, 1) void k_gemm_planes_sh(const uint16_t* Ahi, const uint16_t* Alo, const uint16_t* Whi,
+                                                           const uint16_t* Wlo, const float* __restrict__ bias, int M, int K, int Nc,
+                                                           int act, float* __restrict__ C, uint16_t* __restrict__ Chi,
+                                                           uint16_t* __restrict__ Clo, int row_tiles, int col_tiles) {
+    constexpr int TR = 64 * RB, BN = 64 * NB;     // RB in {2, 4}
+    constexpr int KB = 4;                          // k-blocks of 8 per stage
+    constexpr int A_PIECES = 2 * KB * RB;          // (plane, k-block, 64-row group), 1 KB = 512 elements each
+    constexpr int W_PIECES = 2 * KB * NB;          // (plane, k-block, 64-column group)
+    constexpr int STAGE = (A_PIECES + W_PIECES) * 512;  // elements
+    extern __shared__ __attribute__((aligned(16))) uint16_t gp_lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, half = lane >> 5, wr = wave >> 1, wc = wave & 1;
+    // ---- tile of this workgroup (the order of k_gemm_planes)
+    const int total = row_tiles * col_tiles, per = (total + 7) >> 3;
+    const int slot = (int)blockIdx.x >> 3, t = ((int)blockIdx.x & 7) * per + slot;
+    if (slot >= per || t >= total) return;
+    int rt, ct;
+    {
+        const int full = col_tiles >> 3, in_full = full * 8 * row_tiles;
+        if (t < in_full) {
+            const int g = t / (8 * row_tiles), r = t - g * 8 * row_tiles;
+            rt = r >> 3;
+            ct = g * 8 + (r & 7);
+        } else {
+            const int w = col_tiles - full * 8, r = t - in_full;
+            rt = r / w;
+            ct = full * 8 + (r - rt * w);
+        }
+    }
+    // ---- the copies of this wave, per stage: of the activations pieces wave + 4 j of the 8 RB (plane, k-block, 64-row group) pieces
+    // -- always its own row group, wave % RB --, of the weights k-block `wave` of both planes, all NB column groups.  Source =
+    // uniform base + one 32-bit lane offset per operand (bytes; rows past M read row M - 1; Nc % BN == 0)
+    const uint32_t off_a = (uint32_t)min(rt * TR + 64 * (wave % RB) + lane, M - 1) * 16u;
+    const uint32_t off_w = (uint32_t)(wave * Nc + ct * BN + lane) * 16u;
+    const size_t adv_a = (size_t)KB * M * 16, adv_w = (size_t)KB * Nc * 16;  // bytes per stage
+#define GS_COPY(stage_, buf_)                                                                                                   \
+    {                                                                                                                           \
+        const char* ah_ = reinterpret_cast<const char*>(Ahi) + (size_t)(stage_) * adv_a;                                       \
+        const char* al_ = reinterpret_cast<const char*>(Alo) + (size_t)(stage_) * adv_a;                                       \
+        const char* wh_ = reinterpret_cast<const char*>(Whi) + (size_t)(stage_) * adv_w;                                       \
+        const char* wl_ = reinterpret_cast<const char*>(Wlo) + (size_t)(stage_) * adv_w;                                       \
+        _Pragma("unroll") for (int j = 0; j < 2 * RB; ++j) {                                                                    \
+            const int pq_ = (wave + 4 * j) / RB; /* plane * KB + k-block */                                                     \
+            __builtin_amdgcn_global_load_lds((gp_gptr)((pq_ >= KB ? al_ : ah_) + (size_t)(pq_ % KB) * M * 16 + off_a),          \
+                                             (gp_lptr)(gp_lds + (buf_) * STAGE + (4 * j + wave) * 512), 16, 0, 0);             \
+        }                                                                                                                       \
+        _Pragma("unroll") for (int j = 0; j < 2 * NB; ++j)                                                                      \
+            __builtin_amdgcn_global_load_lds((gp_gptr)((j >= NB ? wl_ : wh_) + (j % NB) * 1024 + off_w),                        \
+                                             (gp_lptr)(gp_lds + (buf_) * STAGE +                                                \
+                                                       (A_PIECES + ((j >= NB ? KB : 0) + wave) * NB + (j % NB)) * 512),        \
+                                             16, 0, 0);                                                                         \
+    }
+    gp_f32x16 acc[RB][NB];
+#pragma unroll
+    for (int b = 0; b < RB; ++b)
+#pragma unroll
+        for (int tt = 0; tt < NB; ++tt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[b][tt][i] = 0.f;
+    const int stages = K / (8 * KB);  // even (host)
+    // fragment of lane (li, half), k-step s of a stage: k-block 2 s + half, row / column li of a 32-block
+    const uint16_t* fa = gp_lds + (half * TR + wr * 32 * RB + li) * 8;
+    const uint16_t* fw = gp_lds + A_PIECES * 512 + (half * BN + wc * 32 * NB + li) * 8;
+    gp_bf16x8 xa[2][RB][2], xw[2][NB][2];  // [register set][32-block][plane]
+#define GS_READ(set_, buf_, s_)                                                                                                 \
+    _Pragma("unroll") for (int b = 0; b < RB; ++b) {                                                                            \
+        xa[set_][b][0] = *reinterpret_cast<const gp_bf16x8*>(fa + (buf_) * STAGE + ((2 * (s_)) * TR + 32 * b) * 8);             \
+        xa[set_][b][1] = *reinterpret_cast<const gp_bf16x8*>(fa + (buf_) * STAGE + ((KB + 2 * (s_)) * TR + 32 * b) * 8);        \
+    }                                                                                                                           \
+    _Pragma("unroll") for (int tt = 0; tt < NB; ++tt) {                                                                         \
+        xw[set_][tt][0] = *reinterpret_cast<const gp_bf16x8*>(fw + (buf_) * STAGE + ((2 * (s_)) * BN + 32 * tt) * 8);           \
+        xw[set_][tt][1] = *reinterpret_cast<const gp_bf16x8*>(fw + (buf_) * STAGE + ((KB + 2 * (s_)) * BN + 32 * tt) * 8);      \
+    }
+    // (products in the order of k_gemm_planes: lo*hi, hi*lo, hi*hi per k-step -- the same sums, bit for bit)
+#define GS_MMA(set_)                                                                                                            \
+    if constexpr (CT) {                                                                                                         \
+        _Pragma("unroll") for (int tt = 0; tt < NB; ++tt)                                                                       \
+            _Pragma("unroll") for (int b = 0; b < RB; ++b)                                                                      \
+                acc[b][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xw[set_][tt][0], xa[set_][b][1], acc[b][tt], 0, 0, 0);     \
+        _Pragma("unroll") for (int tt = 0; tt < NB; ++tt)                                                                       \
+            _Pragma("unroll") for (int b = 0; b < RB; ++b)                                                                      \
+                acc[b][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xw[set_][tt][1], xa[set_][b][0], acc[b][tt], 0, 0, 0);     \
+        _Pragma("unroll") for (int tt = 0; tt < NB; ++tt)                                                                       \
+            _Pragma("unroll") for (int b = 0; b < RB; ++b)                                                                      \
+                acc[b][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xw[set_][tt][0], xa[set_][b][0], acc[b][tt], 0, 0, 0);     \
+    } else {                                                                                                                    \
+        _Pragma("unroll") for (int tt = 0; tt < NB; ++tt)                                                                       \
+            _Pragma("unroll") for (int b = 0; b < RB; ++b)                                                                      \
+                acc[b][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[set_][b][1], xw[set_][tt][0], acc[b][tt], 0, 0, 0);     \
+        _Pragma("unroll") for (int tt = 0; tt < NB; ++tt)                                                                       \
+            _Pragma("unroll") for (int b = 0; b < RB; ++b)                                                                      \
+                acc[b][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[set_][b][0], xw[set_][tt][1], acc[b][tt], 0, 0, 0);     \
+        _Pragma("unroll") for (int tt = 0; tt < NB; ++tt)                                                                       \
+            _Pragma("unroll") for (int b = 0; b < RB; ++b)                                                                      \
+                acc[b][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[set_][b][0], xw[set_][tt][0], acc[b][tt], 0, 0, 0);     \
+    }
+    // (masks: 0x008 MFMA, 0x020 VMEM read, 0x100 DS read) one filler behind an MFMA at a time
+#define GS_WEAVE(mask_, n_)                                                                                                     \
+    _Pragma("unroll") for (int i = 0; i < (n_); ++i) {                                                                          \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                                      \
+        __builtin_amdgcn_sched_group_barrier(mask_, 1, 0);                                                                      \
+    }
+    constexpr int NREAD = 2 * (RB + NB), NCOPY = 2 * (RB + NB);
+    // (the copies a barrier releases are waited for by hand: the compiler's own count missed the ones that cross the loop's back edge)
+#define GS_SYNC()                                         \
+    __builtin_amdgcn_sched_barrier(0);                    \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      \
+    __syncthreads();                                      \
+    __builtin_amdgcn_sched_barrier(0);
+    GS_COPY(0, 0)
+    GS_COPY(1, 1)
+    GS_SYNC()
+    GS_READ(0, 0, 0)
+    for (int c = 0; c < stages; c += 2) {
+        // stage c, buffer 0
+        __builtin_amdgcn_sched_barrier(0);
+        GS_READ(1, 0, 1)
+        GS_MMA(0)
+        GS_WEAVE(0x100, NREAD)
+        GS_SYNC()
+        GS_COPY(min(c + 2, stages - 1), 0)  // (past the end: the last stage again, read by nothing)
+        GS_READ(0, 1, 0)
+        GS_MMA(1)
+        GS_WEAVE(0x020, NCOPY)
+        GS_WEAVE(0x100, NREAD)
+        // stage c + 1, buffer 1
+        __builtin_amdgcn_sched_barrier(0);
+        GS_READ(1, 1, 1)
+        GS_MMA(0)
+        GS_WEAVE(0x100, NREAD)
+        GS_SYNC()
+        GS_COPY(min(c + 3, stages - 1), 1)
+        GS_READ(0, 0, 0)  // (past the last stage: stale data, read by nothing)
+        GS_MMA(1)
+        GS_WEAVE(0x020, NCOPY)
+        GS_WEAVE(0x100, NREAD)
+    }
+#undef GS_SYNC
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#undef GS_COPY
+#undef GS_READ
+#undef GS_MMA
+#undef GS_WEAVE
+    // ---- epilogue (the two of k_gemm_planes)
+    const int row0 = rt * TR + wr * 32 * RB, col0 = ct * BN + wc * 32 * NB;
+    if constexpr (CT) {
+#pragma unroll
+        for (int b = 0; b < RB; ++b) {
+            const int row = row0 + 32 * b + li;
+            if (row >= M) continue;
+#pragma unroll
+            for (int tt = 0; tt < NB; ++tt)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int c0 = col0 + 32 * tt + 8 * q + 4 * half;
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = gp_act(acc[b][tt][4 * q + e] + (bias ? bias[c0 + e] : 0.f), act);
+                    if (C) *reinterpret_cast<float4*>(C + (size_t)row * Nc + c0) = make_float4(v[0], v[1], v[2], v[3]);
+                    if (Chi) {
+                        uint32_t h0, h1, l0, l1;
+                        gp_split2(v[0], v[1], h0, l0);
+                        gp_split2(v[2], v[3], h1, l1);
+                        const size_t o = ((size_t)(c0 >> 3) * M + row) * 8 + (c0 & 7);
+                        *reinterpret_cast<uint2*>(Chi + o) = make_uint2(h0, h1);
+                        *reinterpret_cast<uint2*>(Clo + o) = make_uint2(l0, l1);
+                    }
+                }
+        }
+    } else {
+#pragma unroll
+        for (int b = 0; b < RB; ++b)
+#pragma unroll
+            for (int tt = 0; tt < NB; ++tt) {
+                const int cc = col0 + 32 * tt + li;
+                const float bb = bias ? bias[cc] : 0.f;
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int row = row0 + 32 * b + (reg & 3) + 8 * (reg >> 2) + 4 * half;
+                    if (row < M) C[(size_t)row * Nc + cc] = gp_act(acc[b][tt][reg] + bb, act);
+                }
+            }
+    }
+}
+
+template <int RB, int NB, bool CT>
+static void gp_launch_sh(hipStream_t st, const uint16_t* Ahi, const uint16_t* Alo, const uint16_t* Whi, const uint16_t* Wlo,
+                         const float* bias, int M, int K, int Nc, int act, float* C, uint16_t* Chi, uint16_t* Clo) {
+    constexpr int BN = 64 * NB, TR = 64 * RB;
+    const int row_tiles = (M + TR - 1) / TR, col_tiles = Nc / BN;
+    const int total = row_tiles * col_tiles, per = (total + 7) >> 3;
+    const size_t lds = (size_t)2 * 8 * (RB + NB) * 1024;
+    auto kern = k_gemm_planes_sh<RB, NB, CT>;
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -371,16 +626,17 @@ static int gp_forward(const uint16_t* a_hi, const uint16_t* a_lo, const uint16_t
         const float t = rounds * (sh.rb * sh.nb) * ((float)(K / GP_KC) + sh.fixed) * sh.penalty * (tiles < 256 ? 0.95f : 1.f);
         if (rb == 0 || t < best) { best = t; rb = sh.rb; nb = sh.nb; }
     }
-    if (force_rb > 0) { rb = force_rb; nb = force_nb; }
+    int waves = 4;
+    if (force_rb != 0) { rb = force_rb < 0 ? -force_rb : force_rb; nb = force_nb; waves = force_rb < 0 ? 8 : 4; }
     SNF_REQUIRE(rb > 0 && Nc % (32 * nb) == 0, "snf_linear_planes_fwd: no tile shape for Nc=%d (forced shape %d x %d)", Nc, force_rb, force_nb);
     bool launched = false;
-#define GP_TRY(R_, N_)                                                                                          \
-    if (rb == R_ && nb == N_) {                                                                                 \
-        if (ct) gp_launch<R_, N_, true>(st, a_hi, a_lo, w_hi, w_lo, bias, M, K, Nc, act, C, c_hi, c_lo);        \
-        else gp_launch<R_, N_, false>(st, a_hi, a_lo, w_hi, w_lo, bias, M, K, Nc, act, C, c_hi, c_lo);          \
-        launched = true;                                                                                        \
+#define GP_TRY(R_, N_, W_)                                                                                          \
+    if (rb == R_ && nb == N_ && waves == W_) {                                                                      \
+        if (ct) gp_launch<R_, N_, true, W_>(st, a_hi, a_lo, w_hi, w_lo, bias, M, K, Nc, act, C, c_hi, c_lo);        \
+        else gp_launch<R_, N_, false, W_>(st, a_hi, a_lo, w_hi, w_lo, bias, M, K, Nc, act, C, c_hi, c_lo);          \
+        launched = true;                                                                                            \
     }
-    GP_TRY(1, 2) GP_TRY(2, 2) GP_TRY(1, 4) GP_TRY(2, 4) GP_TRY(1, 5) GP_TRY(2, 5)
+    GP_TRY(1, 2, 4) GP_TRY(2, 2, 4) GP_TRY(1, 4, 4) GP_TRY(2, 4, 4) GP_TRY(1, 5, 4) GP_TRY(2, 5, 4) GP_TRY(1, 4, 8) GP_TRY(1, 5, 8)
 #undef GP_TRY
     SNF_REQUIRE(launched, "snf_linear_planes_fwd: tile shape %d x %d is not built", rb, nb);
     SNF_LAUNCH_CHECK("snf_linear_planes_fwd");
@@ -393,11 +649,44 @@ extern "C" int snf_linear_planes_fwd(const uint16_t* a_hi, const uint16_t* a_lo,
     return gp_forward(a_hi, a_lo, w_hi, w_lo, bias, M, K, Nc, act, C, c_hi, c_lo, 0, 0, stream);
 }
 
-// the same with the tile shape given: (128 rb) rows x (32 nb) columns, (rb, nb) in {1, 2} x {2, 4, 5} -- tools/bench_gemm_planes.py
+// the same with the tile shape given: (128 rb) rows x (32 nb) columns, (rb, nb) in {1, 2} x {2, 4, 5}; rb = -1: the 8-wave workgroup,
+// 256 rows x (32 nb) columns, nb in {4, 5} -- tools/bench_gemm_planes.py
 // times every shape against the choice above
 extern "C" int snf_linear_planes_fwd_shape(const uint16_t* a_hi, const uint16_t* a_lo, const uint16_t* w_hi, const uint16_t* w_lo,
                                            const float* bias, int M, int K, int Nc, int act, float* C, uint16_t* c_hi,
                                            uint16_t* c_lo, int rb, int nb, snf_stream_t stream) {
-    SNF_REQUIRE((rb == 1 || rb == 2) && (nb == 2 || nb == 4 || nb == 5), "snf_linear_planes_fwd_shape: rb=%d nb=%d", rb, nb);
+    SNF_REQUIRE(((rb == 1 || rb == 2) && (nb == 2 || nb == 4 || nb == 5)) || (rb == -1 && (nb == 4 || nb == 5)),
+                "snf_linear_planes_fwd_shape: rb=%d nb=%d", rb, nb);
     return gp_forward(a_hi, a_lo, w_hi, w_lo, bias, M, K, Nc, act, C, c_hi, c_lo, rb, nb, stream);
+}
+
+// the same product with the WEIGHTS k-blocked too ([K/8][Nc][8]: snf_split_planes_kb of the [Nc][K] matrix) -- k_gemm_planes_sh, both
+// operands through LDS: 256 x 320 tiles (Nc % 320 == 0) or 256 x 256 (Nc % 256 == 0); K % 64 == 0
+extern "C" int snf_linear_planes_kb_fwd(const uint16_t* a_hi, const uint16_t* a_lo, const uint16_t* w_hi, const uint16_t* w_lo,
+                                        const float* bias, int M, int K, int Nc, int act, float* C, uint16_t* c_hi, uint16_t* c_lo,
+                                        snf_stream_t stream) {
+    SNF_REQUIRE(a_hi && a_lo && w_hi && w_lo && (C || c_hi), "snf_linear_planes_kb_fwd: null pointer");
+    SNF_REQUIRE(M > 0 && K >= 64 && (K % 64) == 0 && Nc > 0 && ((Nc % 320) == 0 || (Nc % 256) == 0),
+                "snf_linear_planes_kb_fwd: M=%d K=%d Nc=%d (K must be a multiple of 64, Nc of 320 or 256)", M, K, Nc);
+    SNF_REQUIRE((long long)M * K < (1LL << 31) && (long long)Nc * K < (1LL << 31) && (long long)M * Nc < (1LL << 31),
+                "snf_linear_planes_kb_fwd: M=%d K=%d Nc=%d: operand offsets are 32-bit", M, K, Nc);
+    SNF_REQUIRE((c_hi == nullptr) == (c_lo == nullptr), "snf_linear_planes_kb_fwd: c_hi and c_lo go together");
+    SNF_REQUIRE(act == SNF_ACT_NONE || act == SNF_ACT_RELU || act == SNF_ACT_GELU, "snf_linear_planes_kb_fwd: act=%d", act);
+    SNF_REQUIRE((((uintptr_t)a_hi | (uintptr_t)a_lo | (uintptr_t)w_hi | (uintptr_t)w_lo | (uintptr_t)C | (uintptr_t)c_hi |
+                  (uintptr_t)c_lo) % 16) == 0, "snf_linear_planes_kb_fwd: unaligned pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const bool ct = c_hi != nullptr;
+    static const int force = getenv("SNF_GEMM_SH_TILE") ? atoi(getenv("SNF_GEMM_SH_TILE")) : 0;  // 25 / 44 / 24 (bench)
+    const int shape = force ? force : (Nc % 320) == 0 ? 25 : 44;
+    SNF_REQUIRE((shape == 25 && Nc % 320 == 0) || ((shape == 44 || shape == 24) && Nc % 256 == 0),
+                "snf_linear_planes_kb_fwd: tile %d does not divide Nc=%d", shape, Nc);
+#define GS_TRY(R_, N_)                                                                                              \
+    if (shape == 10 * R_ + N_) {                                                                                    \
+        if (ct) gp_launch_sh<R_, N_, true>(st, a_hi, a_lo, w_hi, w_lo, bias, M, K, Nc, act, C, c_hi, c_lo);         \
+        else gp_launch_sh<R_, N_, false>(st, a_hi, a_lo, w_hi, w_lo, bias, M, K, Nc, act, C, c_hi, c_lo);           \
+    }
+    GS_TRY(2, 5) GS_TRY(4, 4) GS_TRY(2, 4)
+#undef GS_TRY
+    SNF_LAUNCH_CHECK("snf_linear_planes_kb_fwd");
+    return SNF_OK;
 }

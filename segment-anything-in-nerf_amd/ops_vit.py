@@ -123,6 +123,12 @@ def split_weight_planes(w: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     return hi, lo
 
 
+def split_weight_planes_kb(w: torch.Tensor) -> "Planes":
+    """A constant weight [Nc, K] -> k-blocked planes [K/8, Nc, 8] (the layout of the activations): linear_planes then takes the
+    kernel that stages both operands through LDS (Nc % 320 == 0 or Nc % 256 == 0)."""
+    return split_planes_kb(w)
+
+
 @torch.no_grad()
 def split_planes_kb(x: torch.Tensor) -> Planes:
     x = _chk(x, "x")
@@ -183,8 +189,13 @@ def attention_planes(qkv, Bw: int, T: int, heads: int, n: int, out: Planes, rel_
 def linear_planes(a: Planes, w_planes, bias, act: int = ACT_NONE, out: Optional[Planes] = None, shape=None) -> torch.Tensor:
     """act(A W^T + b) from operand planes; returns the fp32 [M, Nc] result, or writes `out` planes (and returns it) when given.
     shape = (rb, nb): force the (128 rb) x (32 nb) tile (benchmarks)."""
-    wh, wl = w_planes
-    Nc, K = wh.shape
+    kb = isinstance(w_planes, Planes)  # k-blocked weights (split_weight_planes_kb): the kernel with both operands through LDS
+    if kb:
+        wh, wl, Nc, K = w_planes.hi, w_planes.lo, w_planes.M, w_planes.K
+        assert shape is None
+    else:
+        wh, wl = w_planes
+        Nc, K = wh.shape
     assert K == a.K, (K, a.K)
     y = None
     if out is None:
@@ -192,7 +203,10 @@ def linear_planes(a: Planes, w_planes, bias, act: int = ACT_NONE, out: Optional[
     else:
         assert out.M == a.M and out.K == Nc
     oh, ol = (out.hi.data_ptr(), out.lo.data_ptr()) if out is not None else (None, None)
-    if shape is not None:
+    if kb:
+        _launch("snf_linear_planes_kb_fwd", a.hi.data_ptr(), a.lo.data_ptr(), wh.data_ptr(), wl.data_ptr(), _p(bias), a.M, K, Nc, act,
+                _p(y), oh, ol, _stream(), tag=f"{K}x{Nc}", units=2.0 * a.M * K * Nc)
+    elif shape is not None:
         _launch("snf_linear_planes_fwd_shape", a.hi.data_ptr(), a.lo.data_ptr(), wh.data_ptr(), wl.data_ptr(), _p(bias), a.M, K, Nc,
                 act, _p(y), oh, ol, int(shape[0]), int(shape[1]), _stream(), tag=f"{K}x{Nc}", units=2.0 * a.M * K * Nc)
     else:

@@ -225,6 +225,49 @@ def test_split_operand_gemm_vs_fp64(M, K, Nc):
     assert float((y - y_t).abs().max()) <= 1e-5 * scale
 
 
+@pytest.mark.parametrize("M,K,Nc", [(700, 192, 640), (4900, 1280, 1280)])
+def test_split_operand_gemm_tile_shapes_agree(M, K, Nc):
+    """Every tile shape of snf_linear_planes_fwd (snf_linear_planes_fwd_shape: 4-wave workgroups of 128 / 256 rows x 64 / 128 / 160
+    columns, 8-wave workgroups of 256 rows) runs the same products in the same order per output: bit-identical results, fp32 and
+    plane outputs, ragged last row tile included."""
+    from samnerf_amd import ops
+    ops.set_gemm_mode("bf16x3")
+    g = torch.Generator(device="cuda").manual_seed(5)
+    a = torch.randn((M, K), device="cuda", generator=g)
+    w = torch.randn((Nc, K), device="cuda", generator=g) * K ** -0.5
+    b = torch.randn((Nc,), device="cuda", generator=g) * 0.1
+    ap, wp = ops.split_planes_kb(a), ops.split_weight_planes(w)
+    y0 = ops.linear_planes(ap, wp, b)
+    p0 = ops.linear_planes(ap, wp, b, ops.ACT_GELU, out=ops.Planes.empty(M, Nc, "cuda"))
+    for sh in [(1, 2), (2, 2), (1, 4), (2, 4), (1, 5), (2, 5), (-1, 4), (-1, 5)]:
+        y = ops.linear_planes(ap, wp, b, shape=sh)
+        assert torch.equal(y, y0), sh
+        p = ops.linear_planes(ap, wp, b, ops.ACT_GELU, out=ops.Planes.empty(M, Nc, "cuda"), shape=sh)
+        assert torch.equal(p.hi, p0.hi) and torch.equal(p.lo, p0.lo), sh
+
+
+@pytest.mark.parametrize("M,K,Nc", [(700, 192, 640), (4900, 1280, 3840), (4096, 1280, 5120), (300, 128, 512), (257, 64, 256)])
+def test_split_operand_gemm_with_both_operands_through_lds(M, K, Nc):
+    """snf_linear_planes_kb_fwd (k-blocked weights, 256 x 320 / 256 x 256 tiles, LDS-DMA staging) == snf_linear_planes_fwd bit for
+    bit: fp32 output with bias, GELU plane output, ragged last row tile; repeated launches agree (the staging has no race)."""
+    from samnerf_amd import ops
+    ops.set_gemm_mode("bf16x3")
+    g = torch.Generator(device="cuda").manual_seed(7 + M)
+    a = torch.randn((M, K), device="cuda", generator=g)
+    w = torch.randn((Nc, K), device="cuda", generator=g) * K ** -0.5
+    b = torch.randn((Nc,), device="cuda", generator=g) * 0.1
+    ap, wp, wkb = ops.split_planes_kb(a), ops.split_weight_planes(w), ops.split_weight_planes_kb(w)
+    y0 = ops.linear_planes(ap, wp, b)
+    p0 = ops.linear_planes(ap, wp, b, ops.ACT_GELU, out=ops.Planes.empty(M, Nc, "cuda"))
+    for _ in range(5):
+        y = ops.linear_planes(ap, wkb, b)
+        assert torch.equal(y, y0)
+        p = ops.linear_planes(ap, wkb, b, ops.ACT_GELU, out=ops.Planes.empty(M, Nc, "cuda"))
+        assert torch.equal(p.hi, p0.hi) and torch.equal(p.lo, p0.lo)
+    y = ops.linear_planes(ap, wkb, None)
+    assert torch.equal(y, ops.linear_planes(ap, wp, None))
+
+
 def test_producers_write_operand_planes(monkeypatch):
     """snf_layernorm_planes (with the window partition's row map and untouched zero padding) and snf_attention_planes against
     the fp32 kernels they replace: the planes hold the same values to the split's 2^-16."""
