@@ -27,7 +27,7 @@ typedef uint32_t gp_u32x4 __attribute__((ext_vector_type(4)));  // (native vecto
 
 // GP_ABL (tools/ablate_gp.sh): pieces of the k loop compiled out, results WRONG -- 1: no activation-fragment loads, 2: no weight-fragment
 // LDS reads, 4: no weight chunk staging (global load, LDS store, barrier), 8: the hi*hi products only (a third of the MFMAs),
-// 16: every wave loads the fragments of rows 0 .. 32 RB (cache hits)
+// 16: every wave loads the fragments of rows 0 .. 32 RB (cache hits); k_gemm_planes_sh: 32: no LDS copies in the loop, 64: no barriers
 // GP_RING: activation-fragment slots in registers (k-steps requested ahead + 1): 4, or 8 (K % 128 == 0)
 #ifndef GP_RING
 #define GP_RING 4
@@ -345,39 +345,37 @@ static void gp_launch(hipStream_t st, const uint16_t* Ahi, const uint16_t* Alo, 
 
 
 // ---- both operands through LDS ---------------------------------------------------------------------------------------------------
-// k_gemm_planes above is bound by what a CU pulls through its vector cache (tools/ablate_gp.sh: with the fragment loads compiled out
-// the 256 x 64 tile runs 150 -> 115 us on 4096 x 1280 -> 5120, with every wave loading the SAME rows -- all hits -- still 140, with
-// twice the fragments in flight no different): 81 % of the cache's 64 B/clk at the matrix rate, while the LDS (256 B/clk for b128
-// reads) idles.  Here the workgroup is 4 waves in a 2 x 2 grid, one per SIMD with the whole register file: a wave owns 128 rows x
-// (32 NB) columns (320 accumulator registers at NB = 5), the tile is 256 rows x (64 NB) columns, and BOTH operands are k-blocked
-// planes ([K/8][M][8], [K/8][Nc][8]: the weights are split once, their layout is free) that arrive in LDS by
-// global_load_lds_dwordx4 -- a piece is 64 consecutive rows of one k-block of one plane, 1 KB, LDS image = global image,
-// conflict-free for the b128 fragment reads as it lies.  Per 16 k a CU moves (8 + 2 NB) x 2 KB through the cache for 12 NB x 4 MFMAs
-// (29 % of its rate at NB = 5) and reads (8 + 2 NB) x 4 KB of fragments (15 % of the LDS's).
-// Schedule: a stage = 32 k = two k-steps (72 KB at NB = 5), two stage buffers, ONE barrier per stage, in its middle:
-//     k-step 0 of stage c   [its 12 NB MFMAs | the LDS reads of k-step 1's fragments, other register set]
-//     wait (those reads; this wave's copies of stage c + 1), barrier      -> buffer c & 1 is free, stage c + 1 is visible
-//     k-step 1 of stage c   [MFMAs | the copies of stage c + 2 into buffer c & 1 | the reads of stage c + 1's first fragments]
-// so a copy has a whole stage (~3800 cycles) to land and no fragment read waits behind a barrier.
-// 4096 x 5120 makes exactly 256 tiles of 256 x 320.
+// k_gemm_planes above is bound by what a CU pulls through its vector cache (tools/ablate_gp.sh on 4096 x 1280 -> 5120, 256 x 64 tile:
+// 150 us; fragment loads compiled out 115; every wave loading the SAME rows -- all cache hits -- still 140; twice the fragments in
+// flight: no different): 81 % of the cache's 64 B/clk at the matrix rate, while the LDS (256 B/clk for b128 reads) idles.  Here BOTH
+// operands are k-blocked planes ([K/8][M][8], [K/8][Nc][8]: the weights are split once, their layout is free) that arrive in LDS by
+// global_load_lds_dwordx4 -- a piece is 64 consecutive rows of one k-block of one plane, 1 KB, LDS image = global image, conflict-free
+// for the b128 fragment reads as it lies.  8 waves in a 4 x 2 grid, a wave owns 64 rows x (32 NB) columns, the tile is 256 rows x
+// (64 NB) columns: per 16 k a CU moves (8 + 2 NB) x 2 KB through the cache for 6 NB x 8 MFMAs (29 % of its rate at NB = 5) and
+// reads 8 x (2 + NB) x 2 KB of fragments (23 % of the LDS's).  4096 x 5120 makes exactly 256 tiles of 256 x 320.
+// Two waves per SIMD with 256 registers each, because an LDS copy costs its wave ~100 issue cycles (MI355X_MICROARCH: 60 among bare
+// MFMAs, more in a busy phase): a wave that is alone on its SIMD pays them in matrix time (the 4-wave / 512-register variant of this
+// kernel with two full fragment sets ran 172 us where this one runs 137), here the SIMD's other wave issues MFMAs meanwhile.
+// A stage is 32 k (72 KB at NB = 5), two stage buffers, one barrier at the END of a stage; the copies of stage c + 1 go out one
+// behind the first MFMAs of each item of stage c and have landed (vmcnt(0), by hand) before that barrier.
+// Measured (tools/bench_gemm_planes.py, k slope from K = 1280 / 2560 / 5120): 104.6 us per 1280 k + 32 us fixed against 119.5 + 25
+// for the 256 x 64 tile; without copies and barriers 94.4 per 1280 k -- the matrix pipe at 0.68 of its zero-operand rate.
 typedef __attribute__((address_space(1))) const void* gp_gptr;
 typedef __attribute__((address_space(3))) void* gp_lptr;
 
-template <int RB, int NB, bool CT>
-__global__ __launch_bounds__(256, 1) void k_gemm_planes_sh(const uint16_t* Ahi, const uint16_t* Alo, const uint16_t* Whi,
-                                                           const uint16_t* Wlo, const float* __restrict__ bias, int M, int K, int Nc,
-                                                           int act, float* __restrict__ C, uint16_t* __restrict__ Chi,
-                                                           uint16_t* __restrict__ Clo, int row_tiles, int col_tiles) {
-    constexpr int TR = 64 * RB, BN = 64 * NB;     // RB in {2, 4}
-    constexpr int KB = 4;                          // k-blocks of 8 per stage
-    constexpr int A_PIECES = 2 * KB * RB;          // (plane, k-block, 64-row group), 1 KB = 512 elements each
-    constexpr int W_PIECES = 2 * KB * NB;          // (plane, k-block, 64-column group)
-    constexpr int STAGE = (A_PIECES + W_PIECES) * 512;  // elements
+template <int NB, bool CT>
+__global__ __launch_bounds__(512, 1) void k_gemm_planes_sh(const uint16_t* Ahi, const uint16_t* Alo, const uint16_t* Whi,
+                                                            const uint16_t* Wlo, const float* __restrict__ bias, int M, int K, int Nc,
+                                                            int act, float* __restrict__ C, uint16_t* __restrict__ Chi,
+                                                            uint16_t* __restrict__ Clo, int row_tiles, int col_tiles) {
+    constexpr int RB = 2, TR = 256, BN = 64 * NB;
+    constexpr int KB = 4;
+    constexpr int A_PIECES = 2 * KB * 4, W_PIECES = 2 * KB * NB;
+    constexpr int STAGE = (A_PIECES + W_PIECES) * 512;
     extern __shared__ __attribute__((aligned(16))) uint16_t gp_lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, half = lane >> 5, wr = wave >> 1, wc = wave & 1;
-    // ---- tile of this workgroup (the order of k_gemm_planes)
     const int total = row_tiles * col_tiles, per = (total + 7) >> 3;
     const int slot = (int)blockIdx.x >> 3, t = ((int)blockIdx.x & 7) * per + slot;
     if (slot >= per || t >= total) return;
@@ -394,29 +392,12 @@ __global__ __launch_bounds__(256, 1) void k_gemm_planes_sh(const uint16_t* Ahi, 
             ct = full * 8 + (r - rt * w);
         }
     }
-    // ---- the copies of this wave, per stage: of the activations pieces wave + 4 j of the 8 RB (plane, k-block, 64-row group) pieces
-    // -- always its own row group, wave % RB --, of the weights k-block `wave` of both planes, all NB column groups.  Source =
-    // uniform base + one 32-bit lane offset per operand (bytes; rows past M read row M - 1; Nc % BN == 0)
-    const uint32_t off_a = (uint32_t)min(rt * TR + 64 * (wave % RB) + lane, M - 1) * 16u;
-    const uint32_t off_w = (uint32_t)(wave * Nc + ct * BN + lane) * 16u;
-    const size_t adv_a = (size_t)KB * M * 16, adv_w = (size_t)KB * Nc * 16;  // bytes per stage
-#define GS_COPY(stage_, buf_)                                                                                                   \
-    {                                                                                                                           \
-        const char* ah_ = reinterpret_cast<const char*>(Ahi) + (size_t)(stage_) * adv_a;                                       \
-        const char* al_ = reinterpret_cast<const char*>(Alo) + (size_t)(stage_) * adv_a;                                       \
-        const char* wh_ = reinterpret_cast<const char*>(Whi) + (size_t)(stage_) * adv_w;                                       \
-        const char* wl_ = reinterpret_cast<const char*>(Wlo) + (size_t)(stage_) * adv_w;                                       \
-        _Pragma("unroll") for (int j = 0; j < 2 * RB; ++j) {                                                                    \
-            const int pq_ = (wave + 4 * j) / RB; /* plane * KB + k-block */                                                     \
-            __builtin_amdgcn_global_load_lds((gp_gptr)((pq_ >= KB ? al_ : ah_) + (size_t)(pq_ % KB) * M * 16 + off_a),          \
-                                             (gp_lptr)(gp_lds + (buf_) * STAGE + (4 * j + wave) * 512), 16, 0, 0);             \
-        }                                                                                                                       \
-        _Pragma("unroll") for (int j = 0; j < 2 * NB; ++j)                                                                      \
-            __builtin_amdgcn_global_load_lds((gp_gptr)((j >= NB ? wl_ : wh_) + (j % NB) * 1024 + off_w),                        \
-                                             (gp_lptr)(gp_lds + (buf_) * STAGE +                                                \
-                                                       (A_PIECES + ((j >= NB ? KB : 0) + wave) * NB + (j % NB)) * 512),        \
-                                             16, 0, 0);                                                                         \
-    }
+    // copies of this wave per stage: activations, pieces wave + 8 j (j < 4): row group wave & 3, (plane, k-block) = (wave >> 2) + 2 j;
+    // weights: plane wave >> 2, k-block wave & 3, the NB column groups
+    const uint32_t off_a = (uint32_t)min(rt * TR + 64 * (wave & 3) + lane, M - 1) * 16u;
+    const uint32_t off_w = (uint32_t)((wave & 3) * Nc + ct * BN + lane) * 16u;
+    const size_t adv_a = (size_t)KB * M * 16, adv_w = (size_t)KB * Nc * 16;
+    const char* wsel = reinterpret_cast<const char*>(wave >> 2 ? Wlo : Whi);
     gp_f32x16 acc[RB][NB];
 #pragma unroll
     for (int b = 0; b < RB; ++b)
@@ -425,89 +406,95 @@ __global__ __launch_bounds__(256, 1) void k_gemm_planes_sh(const uint16_t* Ahi, 
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[b][tt][i] = 0.f;
     const int stages = K / (8 * KB);  // even (host)
-    // fragment of lane (li, half), k-step s of a stage: k-block 2 s + half, row / column li of a 32-block
     const uint16_t* fa = gp_lds + (half * TR + wr * 32 * RB + li) * 8;
     const uint16_t* fw = gp_lds + A_PIECES * 512 + (half * BN + wc * 32 * NB + li) * 8;
-    gp_bf16x8 xa[2][RB][2], xw[2][NB][2];  // [register set][32-block][plane]
-#define GS_READ(set_, buf_, s_)                                                                                                 \
+    // one k-step: fragments, then per 32-column block its 3 RB products (lo*hi, hi*lo, hi*hi per accumulator, the order of
+    // k_gemm_planes) -- the first MFMAs need the first column block only
+    // A stage = 2 NB items (k-step s, 32-column block tt): 2 weight-fragment reads + 3 RB MFMAs each (lo*hi, hi*lo, hi*hi per
+    // accumulator, the order of k_gemm_planes).  The weight fragments run through a ring of 3 register slots, requested two items
+    // ahead; the activation fragments of k-step 1 are requested during k-step 0 -- 216 registers instead of the 272 two full
+    // fragment sets would take, and no MFMA waits on a read issued right in front of it (one fragment set: the loop without copies
+    // and barriers still ran 133 of 143 us).  One copy of the next stage goes out behind the first MFMAs of an item.
+    gp_bf16x8 xa[2][RB][2], xw[3][2];
+#define GS_LDA(set_, buf_, s_)                                                                                                  \
     _Pragma("unroll") for (int b = 0; b < RB; ++b) {                                                                            \
         xa[set_][b][0] = *reinterpret_cast<const gp_bf16x8*>(fa + (buf_) * STAGE + ((2 * (s_)) * TR + 32 * b) * 8);             \
         xa[set_][b][1] = *reinterpret_cast<const gp_bf16x8*>(fa + (buf_) * STAGE + ((KB + 2 * (s_)) * TR + 32 * b) * 8);        \
-    }                                                                                                                           \
-    _Pragma("unroll") for (int tt = 0; tt < NB; ++tt) {                                                                         \
-        xw[set_][tt][0] = *reinterpret_cast<const gp_bf16x8*>(fw + (buf_) * STAGE + ((2 * (s_)) * BN + 32 * tt) * 8);           \
-        xw[set_][tt][1] = *reinterpret_cast<const gp_bf16x8*>(fw + (buf_) * STAGE + ((KB + 2 * (s_)) * BN + 32 * tt) * 8);      \
     }
-    // (products in the order of k_gemm_planes: lo*hi, hi*lo, hi*hi per k-step -- the same sums, bit for bit)
-#define GS_MMA(set_)                                                                                                            \
-    if constexpr (CT) {                                                                                                         \
-        _Pragma("unroll") for (int tt = 0; tt < NB; ++tt)                                                                       \
-            _Pragma("unroll") for (int b = 0; b < RB; ++b)                                                                      \
-                acc[b][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xw[set_][tt][0], xa[set_][b][1], acc[b][tt], 0, 0, 0);     \
-        _Pragma("unroll") for (int tt = 0; tt < NB; ++tt)                                                                       \
-            _Pragma("unroll") for (int b = 0; b < RB; ++b)                                                                      \
-                acc[b][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xw[set_][tt][1], xa[set_][b][0], acc[b][tt], 0, 0, 0);     \
-        _Pragma("unroll") for (int tt = 0; tt < NB; ++tt)                                                                       \
-            _Pragma("unroll") for (int b = 0; b < RB; ++b)                                                                      \
-                acc[b][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xw[set_][tt][0], xa[set_][b][0], acc[b][tt], 0, 0, 0);     \
+#define GS_LDW(slot_, buf_, s_, tt_)                                                                                            \
+    {                                                                                                                           \
+        xw[slot_][0] = *reinterpret_cast<const gp_bf16x8*>(fw + (buf_) * STAGE + ((2 * (s_)) * BN + 32 * (tt_)) * 8);           \
+        xw[slot_][1] = *reinterpret_cast<const gp_bf16x8*>(fw + (buf_) * STAGE + ((KB + 2 * (s_)) * BN + 32 * (tt_)) * 8);      \
+    }
+#define GS_COPY1(stage_, buf_, j_)                                                                                              \
+    if ((j_) < 4) {                                                                                                             \
+        const int pq_ = (wave >> 2) + 2 * (j_);                                                                                 \
+        const char* a_ = reinterpret_cast<const char*>(pq_ >= KB ? Alo : Ahi) + (size_t)(stage_) * adv_a;                      \
+        __builtin_amdgcn_global_load_lds((gp_gptr)(a_ + (size_t)(pq_ % KB) * M * 16 + off_a),                                   \
+                                         (gp_lptr)(gp_lds + (buf_) * STAGE + (8 * (j_) + wave) * 512), 16, 0, 0);               \
     } else {                                                                                                                    \
-        _Pragma("unroll") for (int tt = 0; tt < NB; ++tt)                                                                       \
-            _Pragma("unroll") for (int b = 0; b < RB; ++b)                                                                      \
-                acc[b][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[set_][b][1], xw[set_][tt][0], acc[b][tt], 0, 0, 0);     \
-        _Pragma("unroll") for (int tt = 0; tt < NB; ++tt)                                                                       \
-            _Pragma("unroll") for (int b = 0; b < RB; ++b)                                                                      \
-                acc[b][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[set_][b][0], xw[set_][tt][1], acc[b][tt], 0, 0, 0);     \
-        _Pragma("unroll") for (int tt = 0; tt < NB; ++tt)                                                                       \
-            _Pragma("unroll") for (int b = 0; b < RB; ++b)                                                                      \
-                acc[b][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[set_][b][0], xw[set_][tt][0], acc[b][tt], 0, 0, 0);     \
+        __builtin_amdgcn_global_load_lds((gp_gptr)(wsel + (size_t)(stage_) * adv_w + ((j_) - 4) * 1024 + off_w),                \
+                                         (gp_lptr)(gp_lds + (buf_) * STAGE + (A_PIECES + wave * NB + (j_) - 4) * 512), 16, 0,   \
+                                         0);                                                                                    \
     }
-    // (masks: 0x008 MFMA, 0x020 VMEM read, 0x100 DS read) one filler behind an MFMA at a time
-#define GS_WEAVE(mask_, n_)                                                                                                     \
-    _Pragma("unroll") for (int i = 0; i < (n_); ++i) {                                                                          \
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                                      \
-        __builtin_amdgcn_sched_group_barrier(mask_, 1, 0);                                                                      \
+#define GS_ITEM_MMA(set_, slot_, tt_)                                                                                           \
+    if constexpr (CT) {                                                                                                         \
+        _Pragma("unroll") for (int b = 0; b < RB; ++b)                                                                          \
+            acc[b][tt_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xw[slot_][0], xa[set_][b][1], acc[b][tt_], 0, 0, 0);          \
+        _Pragma("unroll") for (int b = 0; b < RB; ++b)                                                                          \
+            acc[b][tt_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xw[slot_][1], xa[set_][b][0], acc[b][tt_], 0, 0, 0);          \
+        _Pragma("unroll") for (int b = 0; b < RB; ++b)                                                                          \
+            acc[b][tt_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xw[slot_][0], xa[set_][b][0], acc[b][tt_], 0, 0, 0);          \
+    } else {                                                                                                                    \
+        _Pragma("unroll") for (int b = 0; b < RB; ++b)                                                                          \
+            acc[b][tt_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[set_][b][1], xw[slot_][0], acc[b][tt_], 0, 0, 0);          \
+        _Pragma("unroll") for (int b = 0; b < RB; ++b)                                                                          \
+            acc[b][tt_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[set_][b][0], xw[slot_][1], acc[b][tt_], 0, 0, 0);          \
+        _Pragma("unroll") for (int b = 0; b < RB; ++b)                                                                          \
+            acc[b][tt_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[set_][b][0], xw[slot_][0], acc[b][tt_], 0, 0, 0);          \
     }
-    constexpr int NREAD = 2 * (RB + NB), NCOPY = 2 * (RB + NB);
-    // (the copies a barrier releases are waited for by hand: the compiler's own count missed the ones that cross the loop's back edge)
+    // (sched_group_barrier masks: 0x008 MFMA, 0x020 VMEM read, 0x100 DS read)
+#define GS_ITEM(buf_, next_stage_, it)                                                                                          \
+    if constexpr ((it) < 2 * NB) {                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                                      \
+        if constexpr ((it) + 2 < 2 * NB) GS_LDW(((it) + 2) % 3, buf_, ((it) + 2) / NB, ((it) + 2) % NB)                         \
+        if constexpr ((it) == 1) { GS_LDA(1, buf_, 1) }                                                                         \
+        if constexpr ((it) < 4 + NB && !(GP_ABL & 32)) { GS_COPY1(next_stage_, (buf_) ^ 1, it) }                                \
+        GS_ITEM_MMA((it) / NB, (it) % 3, (it) % NB)                                                                             \
+        __builtin_amdgcn_sched_group_barrier(0x100, ((it) + 2 < 2 * NB ? 2 : 0) + ((it) == 1 ? 2 * RB : 0), 0);                 \
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                                      \
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                                                      \
+        __builtin_amdgcn_sched_group_barrier(0x008, 3 * RB - 2, 0);                                                             \
+    }
+#define GS_STAGE(buf_, next_stage_)                                                                                             \
+    GS_LDA(0, buf_, 0)                                                                                                          \
+    GS_LDW(0, buf_, 0, 0)                                                                                                       \
+    GS_LDW(1, buf_, 0, 1)                                                                                                       \
+    GS_ITEM(buf_, next_stage_, 0) GS_ITEM(buf_, next_stage_, 1) GS_ITEM(buf_, next_stage_, 2) GS_ITEM(buf_, next_stage_, 3)     \
+    GS_ITEM(buf_, next_stage_, 4) GS_ITEM(buf_, next_stage_, 5) GS_ITEM(buf_, next_stage_, 6) GS_ITEM(buf_, next_stage_, 7)     \
+    GS_ITEM(buf_, next_stage_, 8) GS_ITEM(buf_, next_stage_, 9)
 #define GS_SYNC()                                         \
     __builtin_amdgcn_sched_barrier(0);                    \
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      \
-    __syncthreads();                                      \
+    if (!(GP_ABL & 64)) __syncthreads();                   \
     __builtin_amdgcn_sched_barrier(0);
-    GS_COPY(0, 0)
-    GS_COPY(1, 1)
+#pragma unroll
+    for (int j = 0; j < 4 + NB; ++j) { GS_COPY1(0, 0, j) }
     GS_SYNC()
-    GS_READ(0, 0, 0)
     for (int c = 0; c < stages; c += 2) {
-        // stage c, buffer 0
-        __builtin_amdgcn_sched_barrier(0);
-        GS_READ(1, 0, 1)
-        GS_MMA(0)
-        GS_WEAVE(0x100, NREAD)
+        GS_STAGE(0, c + 1)
         GS_SYNC()
-        GS_COPY(min(c + 2, stages - 1), 0)  // (past the end: the last stage again, read by nothing)
-        GS_READ(0, 1, 0)
-        GS_MMA(1)
-        GS_WEAVE(0x020, NCOPY)
-        GS_WEAVE(0x100, NREAD)
-        // stage c + 1, buffer 1
-        __builtin_amdgcn_sched_barrier(0);
-        GS_READ(1, 1, 1)
-        GS_MMA(0)
-        GS_WEAVE(0x100, NREAD)
+        GS_STAGE(1, min(c + 2, stages - 1))  // (past the end: the last stage again, read by nothing)
         GS_SYNC()
-        GS_COPY(min(c + 3, stages - 1), 1)
-        GS_READ(0, 0, 0)  // (past the last stage: stale data, read by nothing)
-        GS_MMA(1)
-        GS_WEAVE(0x020, NCOPY)
-        GS_WEAVE(0x100, NREAD)
     }
-#undef GS_SYNC
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#undef GS_COPY
-#undef GS_READ
-#undef GS_MMA
-#undef GS_WEAVE
+#undef GS_LDA
+#undef GS_LDW
+#undef GS_COPY1
+#undef GS_ITEM_MMA
+#undef GS_ITEM
+#undef GS_STAGE
+#undef GS_SYNC
     // ---- epilogue (the two of k_gemm_planes)
     const int row0 = rt * TR + wr * 32 * RB, col0 = ct * BN + wc * 32 * NB;
     if constexpr (CT) {
@@ -550,20 +537,20 @@ __global__ __launch_bounds__(256, 1) void k_gemm_planes_sh(const uint16_t* Ahi, 
     }
 }
 
-template <int RB, int NB, bool CT>
+template <int NB, bool CT>
 static void gp_launch_sh(hipStream_t st, const uint16_t* Ahi, const uint16_t* Alo, const uint16_t* Whi, const uint16_t* Wlo,
-                         const float* bias, int M, int K, int Nc, int act, float* C, uint16_t* Chi, uint16_t* Clo) {
-    constexpr int BN = 64 * NB, TR = 64 * RB;
+                          const float* bias, int M, int K, int Nc, int act, float* C, uint16_t* Chi, uint16_t* Clo) {
+    constexpr int BN = 64 * NB, TR = 256;
     const int row_tiles = (M + TR - 1) / TR, col_tiles = Nc / BN;
     const int total = row_tiles * col_tiles, per = (total + 7) >> 3;
-    const size_t lds = (size_t)2 * 8 * (RB + NB) * 1024;
-    auto kern = k_gemm_planes_sh<RB, NB, CT>;
+    const size_t lds = (size_t)2 * 8 * (4 + NB) * 1024;
+    auto kern = k_gemm_planes_sh<NB, CT>;
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr = true;
     }
-    hipLaunchKernelGGL(kern, dim3(8 * per), dim3(256), lds, st, Ahi, Alo, Whi, Wlo, bias, M, K, Nc, act, C, Chi, Clo, row_tiles,
+    hipLaunchKernelGGL(kern, dim3(8 * per), dim3(512), lds, st, Ahi, Alo, Whi, Wlo, bias, M, K, Nc, act, C, Chi, Clo, row_tiles,
                        col_tiles);
 }
 
@@ -614,19 +601,22 @@ static int gp_forward(const uint16_t* a_hi, const uint16_t* a_lo, const uint16_t
     // why the short-k layers (qkv, lin1: 20 chunks) take the 256 x 64 / 128 x 128 tiles and the long one (lin2: 80 chunks, 1280
     // columns) the 128 x 160 tile that makes exactly 256 workgroups; a launch that leaves CUs idle runs its workgroups a little faster (clock,
     // L2 share): x 0.95.
-    struct Shape { int rb, nb, per_cu; float fixed, penalty; };
-    static const Shape shapes[] = {{2, 2, 2, 10.f, 1.00f}, {1, 4, 2, 10.f, 1.00f}, {2, 5, 1, 12.f, 1.00f}, {2, 4, 1, 12.f, 1.00f},
-                                   {1, 5, 1, 12.f, 1.17f}, {1, 2, 4, 6.5f, 1.35f}};
-    int rb = 0, nb = 0;
+    // (the 8-wave 256 x 128 tile: one workgroup per CU, its two waves per SIMD share the staged weights -- the 4900 x 1280 -> 1280
+    // projection in one round of 200 workgroups, 54 us against 58)
+    struct Shape { int rb, nb, waves, per_cu; float fixed, penalty; };
+    static const Shape shapes[] = {{2, 2, 4, 2, 10.f, 1.00f}, {1, 4, 4, 2, 10.f, 1.00f}, {2, 5, 4, 1, 12.f, 1.00f},
+                                   {2, 4, 4, 1, 12.f, 1.00f}, {1, 5, 4, 1, 12.f, 1.17f}, {1, 2, 4, 4, 6.5f, 1.35f},
+                                   {1, 4, 8, 1, 10.f, 1.00f}};
+    int rb = 0, nb = 0, waves = 4;
     float best = 0.f;
     for (const Shape& sh : shapes) {
         if (Nc % (32 * sh.nb)) continue;
-        const long long tiles = (long long)((M + 128 * sh.rb - 1) / (128 * sh.rb)) * (Nc / (32 * sh.nb));
+        const int tr = 32 * sh.waves * sh.rb;
+        const long long tiles = (long long)((M + tr - 1) / tr) * (Nc / (32 * sh.nb));
         const float rounds = (float)((tiles * sh.per_cu + 255) / 256) / (float)sh.per_cu;
-        const float t = rounds * (sh.rb * sh.nb) * ((float)(K / GP_KC) + sh.fixed) * sh.penalty * (tiles < 256 ? 0.95f : 1.f);
-        if (rb == 0 || t < best) { best = t; rb = sh.rb; nb = sh.nb; }
+        const float t = rounds * (sh.rb * sh.nb * sh.waves / 4) * ((float)(K / GP_KC) + sh.fixed) * sh.penalty * (tiles < 256 ? 0.95f : 1.f);
+        if (rb == 0 || t < best) { best = t; rb = sh.rb; nb = sh.nb; waves = sh.waves; }
     }
-    int waves = 4;
     if (force_rb != 0) { rb = force_rb < 0 ? -force_rb : force_rb; nb = force_nb; waves = force_rb < 0 ? 8 : 4; }
     SNF_REQUIRE(rb > 0 && Nc % (32 * nb) == 0, "snf_linear_planes_fwd: no tile shape for Nc=%d (forced shape %d x %d)", Nc, force_rb, force_nb);
     bool launched = false;
@@ -676,17 +666,13 @@ extern "C" int snf_linear_planes_kb_fwd(const uint16_t* a_hi, const uint16_t* a_
                   (uintptr_t)c_lo) % 16) == 0, "snf_linear_planes_kb_fwd: unaligned pointer");
     hipStream_t st = (hipStream_t)stream;
     const bool ct = c_hi != nullptr;
-    static const int force = getenv("SNF_GEMM_SH_TILE") ? atoi(getenv("SNF_GEMM_SH_TILE")) : 0;  // 25 / 44 / 24 (bench)
-    const int shape = force ? force : (Nc % 320) == 0 ? 25 : 44;
-    SNF_REQUIRE((shape == 25 && Nc % 320 == 0) || ((shape == 44 || shape == 24) && Nc % 256 == 0),
-                "snf_linear_planes_kb_fwd: tile %d does not divide Nc=%d", shape, Nc);
-#define GS_TRY(R_, N_)                                                                                              \
-    if (shape == 10 * R_ + N_) {                                                                                    \
-        if (ct) gp_launch_sh<R_, N_, true>(st, a_hi, a_lo, w_hi, w_lo, bias, M, K, Nc, act, C, c_hi, c_lo);         \
-        else gp_launch_sh<R_, N_, false>(st, a_hi, a_lo, w_hi, w_lo, bias, M, K, Nc, act, C, c_hi, c_lo);           \
+    if ((Nc % 320) == 0) {
+        if (ct) gp_launch_sh<5, true>(st, a_hi, a_lo, w_hi, w_lo, bias, M, K, Nc, act, C, c_hi, c_lo);
+        else gp_launch_sh<5, false>(st, a_hi, a_lo, w_hi, w_lo, bias, M, K, Nc, act, C, c_hi, c_lo);
+    } else {
+        if (ct) gp_launch_sh<4, true>(st, a_hi, a_lo, w_hi, w_lo, bias, M, K, Nc, act, C, c_hi, c_lo);
+        else gp_launch_sh<4, false>(st, a_hi, a_lo, w_hi, w_lo, bias, M, K, Nc, act, C, c_hi, c_lo);
     }
-    GS_TRY(2, 5) GS_TRY(4, 4) GS_TRY(2, 4)
-#undef GS_TRY
     SNF_LAUNCH_CHECK("snf_linear_planes_kb_fwd");
     return SNF_OK;
 }

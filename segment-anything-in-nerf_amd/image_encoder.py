@@ -11,10 +11,14 @@ from __future__ import annotations
 from functools import partial
 from typing import Optional, Tuple, Type
 
+import os
+
 import torch
 import torch.nn as nn
 
 from . import ops
+
+_GEMM_LDS = os.environ.get("SNF_VIT_GEMM_LDS", "1") != "0"
 
 # the blocks' GEMMs on operands split by their producers (csrc/gemm_planes.hip); False: every block through the tiled kernel that
 # splits fp32 operands itself (tests compare the two)
@@ -113,12 +117,17 @@ class ImageEncoderViT(nn.Module):
         hd = C // blk.attn.num_heads
         return C % 256 == 0 and C // 256 in (1, 2, 3, 4, 5, 6, 8) and M % 64 == 0 and hd % 8 == 0 and hd <= 96
 
-    def _wplanes(self, lin):
-        """bf16 hi / lo planes of a layer's weight, split once and re-split when the parameter is written (load_state_dict)."""
-        key, tag = id(lin.weight), (lin.weight._version, lin.weight.data_ptr(), str(lin.weight.device))
+    def _wplanes(self, lin, M: int = 0):
+        """bf16 hi / lo planes of a layer's weight, split once and re-split when the parameter is written (load_state_dict).
+        M (rows of the product) given: k-blocked planes where 256 x 320 tiles fill the chip in one round -- the GEMM with both
+        operands through LDS (ViT-H: attn.qkv, mlp.lin1; SNF_VIT_GEMM_LDS=0: never)."""
+        Nc, K = lin.weight.shape
+        kb = bool(M) and _GEMM_LDS and K % 64 == 0 and Nc % 320 == 0 and 160 <= -(-M // 256) * (Nc // 320) <= 256
+        key, tag = (id(lin.weight), kb), (lin.weight._version, lin.weight.data_ptr(), str(lin.weight.device))
         hit = self._wcache.get(key)
         if hit is None or hit[0] != tag:  # (writes through `.data` bump no version: call reset_weight_cache() after those)
-            hit = (tag, ops.split_weight_planes(lin.weight.detach().float().contiguous()))
+            w = lin.weight.detach().float().contiguous()
+            hit = (tag, ops.split_weight_planes_kb(w) if kb else ops.split_weight_planes(w))
             self._wcache[key] = hit
         return hit[1]
 
@@ -167,7 +176,7 @@ class ImageEncoderViT(nn.Module):
         else:
             _, shortcut = ops.layernorm_planes(shortcut, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps, y, residual=pending,
                                                want_sum=True, grid=grid)
-        qkv = ops.linear_planes(y, self._wplanes(a.qkv), a.qkv.bias)
+        qkv = ops.linear_planes(y, self._wplanes(a.qkv, y.M), a.qkv.bias)
         o = ops.attention_planes(qkv, Bw, n * n, a.num_heads, n, self._pbuf("att", Bw * n * n, C, dev),
                                  a.rel_pos_h if a.use_rel_pos else None, a.rel_pos_w if a.use_rel_pos else None)
         o = ops.linear_planes(o, self._wplanes(a.proj), a.proj.bias)
@@ -177,7 +186,7 @@ class ImageEncoderViT(nn.Module):
             y2, shortcut = ops.layernorm_planes_merge(shortcut, o, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps, n2, B, G, G, ws)
         else:
             y2, shortcut = ops.layernorm_planes(shortcut, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps, n2, residual=o, want_sum=True)
-        h = ops.linear_planes(y2, self._wplanes(blk.mlp.lin1), blk.mlp.lin1.bias, ops.ACT_GELU,
+        h = ops.linear_planes(y2, self._wplanes(blk.mlp.lin1, y2.M), blk.mlp.lin1.bias, ops.ACT_GELU,
                               out=self._pbuf("h", B * G * G, Mh, dev))
         pending = ops.linear_planes(h, self._wplanes(blk.mlp.lin2), blk.mlp.lin2.bias)
         return shortcut, pending

@@ -13,6 +13,7 @@ if os.environ.get("GP_SHAPES"):
     SHAPES = [tuple(int(v) for v in t.split("x")) for t in os.environ["GP_SHAPES"].split(",")]
 GEMMS = [("lin1 4096x1280->5120", 4096, 1280, 5120), ("lin2 4096x5120->1280", 4096, 5120, 1280),
          ("qkv  4900x1280->3840", 4900, 1280, 3840), ("proj 4900x1280->1280", 4900, 1280, 1280)]
+GEMMS += [("lin1k2 4096x2560->5120", 4096, 2560, 5120), ("lin1k4 4096x5120->5120", 4096, 5120, 5120)]  # (k slope: GP_GEMMS=lin1,lin1k2,lin1k4)
 if os.environ.get("GP_GEMMS"):
     GEMMS = [g for g in GEMMS if g[0].split()[0] in os.environ["GP_GEMMS"].split(",")]
 for name, M, K, Nc in GEMMS:
