@@ -10,6 +10,7 @@
 // Launch: grid = (ceil(N/256), L): blockIdx.y is the level, so a workgroup (and its neighbours in x)
 // gather from ONE level slab; a thread owns one (sample, level) pair and keeps all 8 corner loads in flight.
 #include "common.hpp"
+#include <algorithm>
 #include <type_traits>
 #include "grid_device.hpp"
 #include <math.h>
@@ -105,6 +106,21 @@ __device__ __forceinline__ void hg_count_corners(const Corners& c, int log2rpb, 
     }
 }
 
+// The trilinear blend, a x + b (1 - x) along x, then y, then z (encodings.py:327-337), with its roundings spelled out: the first
+// product rounded, the second fused into the sum -- what the compiler made of `a * o + b * m` in k_hashgrid_fwd; written with fmaf so
+// that every kernel that blends through it rounds the same way whatever the compiler contracts around it (a second forward kernel
+// with the very same source differed from k_hashgrid_fwd in the last bit of 59 % of its outputs, round 5).
+__device__ __forceinline__ float hg_blend(float f0, float f1, float f2, float f3, float f4, float f5, float f6, float f7, float ox,
+                                          float oy, float oz, float mx, float my, float mz) {
+    const float f03 = fmaf(f3, mx, f0 * ox);
+    const float f12 = fmaf(f2, mx, f1 * ox);
+    const float f56 = fmaf(f6, mx, f5 * ox);
+    const float f47 = fmaf(f7, mx, f4 * ox);
+    const float f0312 = fmaf(f12, my, f03 * oy);
+    const float f4756 = fmaf(f56, my, f47 * oy);
+    return fmaf(f4756, mz, f0312 * oz);
+}
+
 // one (sample, level): gather the 8 corner rows, trilinear blend in the reference's order, store
 template <int F>
 __device__ __forceinline__ void hg_fwd_one(const Corners& c, const float* __restrict__ slab, int n, int l, int N,
@@ -144,15 +160,8 @@ __device__ __forceinline__ void hg_fwd_one(const Corners& c, const float* __rest
     const float mx = 1.f - ox, my = 1.f - oy, mz = 1.f - oz;
     float r[F];
 #pragma unroll
-    for (int j = 0; j < F; ++j) {
-        const float f03 = f[0][j] * ox + f[3][j] * mx;
-        const float f12 = f[1][j] * ox + f[2][j] * mx;
-        const float f56 = f[5][j] * ox + f[6][j] * mx;
-        const float f47 = f[4][j] * ox + f[7][j] * mx;
-        const float f0312 = f03 * oy + f12 * my;
-        const float f4756 = f47 * oy + f56 * my;
-        r[j] = f0312 * oz + f4756 * mz;
-    }
+    for (int j = 0; j < F; ++j)
+        r[j] = hg_blend(f[0][j], f[1][j], f[2][j], f[3][j], f[4][j], f[5][j], f[6][j], f[7][j], ox, oy, oz, mx, my, mz);
     // ld_out == 0: level-major ("planar") output [L][N][F] -- consecutive samples of a level are contiguous, so a wave
     // writes whole lines (row-major [N, L*F] output is 8 / 32 bytes per 128-byte row from a level-at-a-time kernel:
     // rocprofv3 WRITE_SIZE showed 4x the algorithmic bytes for the F=2 field grid)
@@ -168,9 +177,9 @@ __device__ __forceinline__ void hg_fwd_one(const Corners& c, const float* __rest
 template <int F>
 __global__ __launch_bounds__(256) void k_hashgrid_fwd(const float* __restrict__ u, const float* __restrict__ table,
                                                       const float* __restrict__ scalings, int N, int log2_T,
-                                                      float* __restrict__ out, int ld_out, int col_off) {
+                                                      float* __restrict__ out, int ld_out, int col_off, int l0) {
     const int n = blockIdx.x * 256 + threadIdx.x;
-    const int l = blockIdx.y;
+    const int l = blockIdx.y + l0;
     if (n >= N) return;
     const uint32_t mask = (1u << log2_T) - 1u;
     const Corners c = corners_of(u, n, scalings[l], mask);
@@ -1732,10 +1741,10 @@ extern "C" int snf_hashgrid_fwd(const float* u, const float* table, const float*
     dim3 grid(ceil_div(N, 256), L);
     if (F == 2)
         hipLaunchKernelGGL(k_hashgrid_fwd<2>, grid, dim3(256), 0, (hipStream_t)stream, u, table, scalings, N, log2_T,
-                           out, ld_out, col_off);
+                           out, ld_out, col_off, 0);
     else
         hipLaunchKernelGGL(k_hashgrid_fwd<8>, grid, dim3(256), 0, (hipStream_t)stream, u, table, scalings, N, log2_T,
-                           out, ld_out, col_off);
+                           out, ld_out, col_off, 0);
     SNF_LAUNCH_CHECK("snf_hashgrid_fwd");
     return SNF_OK;
 }

@@ -388,6 +388,17 @@ def _hashgrid_bwd_launch(u, g, sc, N, L, F, T, ld, col, buf, adam: Optional[Fuse
     return False
 
 
+
+@torch.no_grad()
+def hashgrid_fwd_raw(u, table, scalings, L: int, F: int, T: int, planar: bool = False):
+    """snf_hashgrid_fwd without autograd: [N, L F] (planar: level-major [L, N, F]) -- tools/bench_hashgrid_fwd.py."""
+    u, table = _chk(u, "u"), _chk(table, "table")
+    N = u.shape[0]
+    out = torch.empty((L, N, F) if planar else (N, L * F), device=u.device, dtype=torch.float32)
+    _launch("snf_hashgrid_fwd", _p(u), _p(table), _p(scalings), N, L, F, T, _p(out), 0 if planar else L * F, 0, _stream(),
+            tag=f"F{F}L{L}")
+    return out
+
 class _HashGridMulti(torch.autograd.Function):
     """One or more hash grids evaluated at the same points, outputs concatenated along the feature axis."""
 
