@@ -25,4 +25,16 @@ for name, S, L, T, lo, hi, planar in [("proposal", 64, 5, 17, 16, 128, False), (
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / 5 * 1e3
+    per = []
+    for l in range(L):  # one level at a time (the kernel's grid runs level by level anyway)
+        tl, sl = table[l << T:(l + 1) << T], sc[l:l + 1].contiguous()
+        ops.hashgrid_fwd_raw(u, tl, sl, 1, 2, T, planar)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(5):
+            ops.hashgrid_fwd_raw(u, tl, sl, 1, 2, T, planar)
+        e1.record()
+        torch.cuda.synchronize()
+        per.append(e0.elapsed_time(e1) / 5 * 1e3)
+    print(f"{name:9s} per level (resolution: us): " + "  ".join(f"{int(r)}: {t:.0f}" for r, t in zip(sc.tolist(), per)))
     print(f"{name:9s} N={N} L={L} T={T}: {us:7.1f} us  ({N * L / us:6.1f} M (sample, level) / s x 1e-6, {N * L * 6 / us / 256 / 2.1e3:5.2f} lane addresses / clock / CU at 6 per item, 2.1 GHz)")
