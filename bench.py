@@ -50,6 +50,7 @@ def mfma_peak(key: str, gemm_mode: int = 1):
     own 833)."""
     name, _, tag = key.partition("/")
     name = name[:-3] if name.endswith("_sh") else name  # (the colour net with its input row formed in the loader: same arithmetic)
+    name = name[:-8] if name.endswith("_density") else name  # (the base net with trunc_exp in its epilogue)
     if gemm_mode >= 1 and name.startswith("snf_linear"):
         dims = [int(x) for x in re.sub(r"[a-z]+$", "", tag).split("x")] if tag else []
         if dims and max(dims) >= 64:  # (the narrow layers -- proposal net -- stay on the fp32 matrix cores)
@@ -73,6 +74,7 @@ def algorithmic_model(key: str, w: dict):
     R, P, S, K = w["R"], w["P"], w["S"], w["K"]
     name, _, tag = key.partition("/")
     name = name[:-3] if name.endswith("_sh") else name
+    name = name[:-8] if name.endswith("_density") else name
     if name == "snf_hashgrid_bwd_presorted_adam_pair":  # both F = 8 grids of a head in one launch ("F8L12+12"); the launch site
         m = re.fullmatch(r"F8L(\d+)\+(\d+)", tag)        # reports its own bytes (gathers + 24 B per fused parameter)
         return ("hbm", float(R * K * (int(m.group(1)) + int(m.group(2))) * 8 * 8 * 4 * 2), "GB/s") if m else (None, None, None)

@@ -299,6 +299,12 @@ int snf_patch_fold_mean(const float* dcm, int R, int p, int C, int k, float* dh,
 int snf_mlp64_fwd(const float* X, int ldx, const float* W0, int in_real, const float* W1, const float* Wout,
                   int n_hidden, int out, int out_act, int64_t N, float* H1, float* H2, float* Y, int ldy,
                   snf_stream_t stream);
+/* snf_mlp64_fwd + snf_trunc_exp_fwd(Y, ldy, selector, N, density) in one call (the field's base MLP followed by trunc_exp of its output
+ * 0, nerfacto_field.py:244-252): for the base net's shape (one hidden layer, 16 linear outputs, H1 = H2 = NULL) the density leaves from
+ * the chain's epilogue instead of being re-read at a 64-byte stride; any other shape runs the two kernels.  Identical values. */
+int snf_mlp64_fwd_density(const float* X, int ldx, const float* W0, int in_real, const float* W1, const float* Wout, int n_hidden,
+                          int out, int out_act, int64_t N, float* H1, float* H2, float* Y, int ldy, const uint8_t* selector,
+                          float* density, snf_stream_t stream);
 /* data-gradient chain of the same net: dZ[s][o] = dY[s*lddy + dy_col_off + o] (column 0 taken from dY0[s] when dY0 !=
  * NULL), times the sigmoid derivative of Y when out_act == SIGMOID.  Writes the ReLU-masked hidden gradients dH2, dH1
  * ([N,64]), the pre-activation output gradient dZ ([N, lddz >= out], may be NULL) and dX ([N, lddx >= 32], may be NULL).  The

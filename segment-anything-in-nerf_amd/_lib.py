@@ -111,6 +111,7 @@ SIGNATURES = {
     "snf_linear_bwd_data_rows": [P, P, I, P, I, P, I, I, I, I, I, I, I, P, P],
     "snf_linear_bwd_weight_rows": [P, P, I, P, I, P, I, I, I, I, I, I, I, P, P, c_int64, P],
     "snf_mlp64_fwd": [P, I, P, I, P, P, I, I, I, c_int64, P, P, P, I, P],
+    "snf_mlp64_fwd_density": [P, I, P, I, P, P, I, I, I, c_int64, P, P, P, I, P, P, P],
     "snf_mlp64_bwd_data": [P, I, I, P, P, I, P, I, P, P, I, I, I, c_int64, P, P, P, P, P, I, P, I, P],
     "snf_mlp64_bwd_fused": [P, I, I, P, P, I, P, I, P, I, P, P, I, I, I, c_int64, P, P, P, I, P, P, P, P, c_int64, P],
     "snf_mlp64_fwd_sh": [P, I, I, P, I, I, P, P, P, I, I, I, P, P, P, I, P],

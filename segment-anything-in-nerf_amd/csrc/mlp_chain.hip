@@ -491,11 +491,15 @@ struct ChainSh {
     const float* dirs;  // [R, 3]
     int S;              // samples per ray: sample n belongs to ray n / S
     int log2S;          // S = 2^log2S, or -1 (a 64-bit division per lane and tile costs ~100 instructions: 128 samples per ray is a shift)
+    // the base net's 16-output epilogue (MC_EPI_LIN16) also writes density[n] = exp(output 0) * selector[n] -- k_trunc_exp_fwd's
+    // arithmetic on the value it would read back at a 64-byte stride (snf_mlp64_fwd_density)
+    const uint8_t* dens_sel;
+    float* dens;
 };
 static ChainSh chain_sh(const float* dirs, int S) {
     int l = -1;
     if (S > 0 && (S & (S - 1)) == 0) for (l = 0; (1 << l) < S; ++l) {}
-    return ChainSh{dirs, S, l};
+    return ChainSh{dirs, S, l, nullptr, nullptr};
 }
 
 // this lane's half of a formed input row: half 0 = the 16 harmonics of the ray's direction, half 1 = columns 1 .. 15 of the base
@@ -742,6 +746,11 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 4 : SNF_CHAIN_FWD_WAVES) 
                                   __float_as_uint(y[0][4 * q + 3])};
                 const uint32_t off = ok ? ((uint32_t)(s * ldy) + 8u * q + 4u * half) * 4u : MC_OOR;
                 __builtin_amdgcn_raw_buffer_store_b128(pk, ry, off, 0, 0);
+            }
+            if (sh.dens != nullptr && ok && half == 0) {  // (output 0 of a sample: register 0 of its half-wave-0 lane)
+                float d = expf(y[0][0]);
+                if (sh.dens_sel) d *= (float)sh.dens_sel[s];
+                sh.dens[s] = d;
             }
         } else if (ok) {
             if (out_act == SNF_ACT_NONE && (out & 3) == 0 && (ldy & 3) == 0 && (reinterpret_cast<uintptr_t>(Y) & 15) == 0) {
@@ -1448,9 +1457,14 @@ extern "C" int snf_mlp64_fwd_sh(const float* dirs, int R, int S, const float* ba
     return chain_fwd_sh(dirs, R, S, base_out, ld_base, n_geo, W0, W1, Wout, n_hidden, out, out_act, H1, H2, Y, ldy, stream);
 }
 
-extern "C" int snf_mlp64_fwd(const float* X, int ldx, const float* W0, int in_real, const float* W1, const float* Wout,
-                             int n_hidden, int out, int out_act, int64_t N, float* H1, float* H2, float* Y, int ldy,
-                             snf_stream_t stream) {
+extern "C" int snf_trunc_exp_fwd(const float* raw, int raw_stride, const uint8_t* selector, int64_t N, float* density,
+                                 snf_stream_t stream);
+
+// dens != nullptr: density[n] = exp(Y[n][0]) * selector[n] as well -- inside the base net's epilogue where that one exists, by
+// snf_trunc_exp_fwd behind the chain otherwise
+static int chain_fwd_plain(const float* X, int ldx, const float* W0, int in_real, const float* W1, const float* Wout,
+                           int n_hidden, int out, int out_act, int64_t N, float* H1, float* H2, float* Y, int ldy,
+                           const uint8_t* dens_sel, float* dens, snf_stream_t stream) {
     int rc = chain_common_checks("snf_mlp64_fwd", in_real, n_hidden, out, N);
     if (rc) return rc;
     SNF_REQUIRE(X && W0 && Wout && Y && (n_hidden == 1 || W1), "snf_mlp64_fwd: null pointer");
@@ -1458,6 +1472,7 @@ extern "C" int snf_mlp64_fwd(const float* X, int ldx, const float* W0, int in_re
                 "snf_mlp64_fwd: X must be [N, ldx>=32] with ldx %% 4 == 0 and 16-byte aligned rows (pad columns readable)");
     SNF_REQUIRE(ldy >= out, "snf_mlp64_fwd: ldy < out");
     SNF_REQUIRE((!H1 || ((uintptr_t)H1 % 16) == 0) && (!H2 || ((uintptr_t)H2 % 16) == 0), "snf_mlp64_fwd: unaligned H");
+    bool dens_done = false;
     const long long ntiles = (N + 31) / 32;
     long long blocks = (ntiles + 3) / 4;
     if (blocks > 256 * 4) blocks = 256 * 4;  // persistent: <= 4 workgroups per CU
@@ -1479,14 +1494,15 @@ extern "C" int snf_mlp64_fwd(const float* X, int ldx, const float* W0, int in_re
         long long b2 = (ntiles + T / 64 - 1) / (T / 64);
         const long long cap = 256LL * (T == 512 ? 2 : 4);
         if (b2 > cap) b2 = cap;
+        dens_done = lin16;
         if (lin16 && ldx == 0)
             hipLaunchKernelGGL((k_mlp_chain_fwd_b3<1, 3, false, false, MC_EPI_LIN16, 1, T>), dim3((unsigned)b2), dim3(T),
                                chain_b3_lds_elems(1, 3) * sizeof(uint16_t), (hipStream_t)stream, X, ldx, W0, in_real, W1, Wout, out, out_act,
-                               (long long)N, H1, H2, Y, ldy, ChainSh{nullptr, 1, 0});
+                               (long long)N, H1, H2, Y, ldy, ChainSh{nullptr, 1, 0, dens_sel, dens});
         else if (lin16)
             hipLaunchKernelGGL((k_mlp_chain_fwd_b3<1, 3, false, false, MC_EPI_LIN16, 2, T>), dim3((unsigned)b2), dim3(T),
                                chain_b3_lds_elems(1, 3) * sizeof(uint16_t), (hipStream_t)stream, X, ldx, W0, in_real, W1, Wout, out, out_act,
-                               (long long)N, H1, H2, Y, ldy, ChainSh{nullptr, 1, 0});
+                               (long long)N, H1, H2, Y, ldy, ChainSh{nullptr, 1, 0, dens_sel, dens});
         else if (n_hidden == 2)
             hipLaunchKernelGGL((k_mlp_chain_fwd_b3<2, 3>), dim3((unsigned)blocks), dim3(256), chain_b3_lds_elems(2, 3) * sizeof(uint16_t),
                                (hipStream_t)stream, X, ldx, W0, in_real, W1, Wout, out, out_act, (long long)N, H1, H2, Y, ldy, ChainSh{nullptr, 1, 0});
@@ -1500,7 +1516,24 @@ extern "C" int snf_mlp64_fwd(const float* X, int ldx, const float* W0, int in_re
         hipLaunchKernelGGL(k_mlp_chain_fwd<1>, dim3((unsigned)blocks), dim3(256), chain_lds_floats(1) * sizeof(float),
                            (hipStream_t)stream, X, ldx, W0, in_real, W1, Wout, out, out_act, (long long)N, H1, H2, Y, ldy);
     SNF_LAUNCH_CHECK("snf_mlp64_fwd");
+    if (dens != nullptr && !dens_done) return snf_trunc_exp_fwd(Y, ldy, dens_sel, N, dens, stream);
     return SNF_OK;
+}
+
+extern "C" int snf_mlp64_fwd(const float* X, int ldx, const float* W0, int in_real, const float* W1, const float* Wout,
+                             int n_hidden, int out, int out_act, int64_t N, float* H1, float* H2, float* Y, int ldy,
+                             snf_stream_t stream) {
+    return chain_fwd_plain(X, ldx, W0, in_real, W1, Wout, n_hidden, out, out_act, N, H1, H2, Y, ldy, nullptr, nullptr, stream);
+}
+
+// snf_mlp64_fwd followed by snf_trunc_exp_fwd(Y, ldy, selector, N, density) (trunc_exp of output 0: nerfacto_field.py:244-252 after
+// the base MLP), the density written from the chain's epilogue when it is the base net's (one hidden layer, 16 linear outputs,
+// nothing else stored) instead of re-read at a 64-byte stride -- identical values
+extern "C" int snf_mlp64_fwd_density(const float* X, int ldx, const float* W0, int in_real, const float* W1, const float* Wout,
+                                     int n_hidden, int out, int out_act, int64_t N, float* H1, float* H2, float* Y, int ldy,
+                                     const uint8_t* selector, float* density, snf_stream_t stream) {
+    SNF_REQUIRE(density != nullptr, "snf_mlp64_fwd_density: null density");
+    return chain_fwd_plain(X, ldx, W0, in_real, W1, Wout, n_hidden, out, out_act, N, H1, H2, Y, ldy, selector, density, stream);
 }
 
 extern "C" int snf_mlp64_bwd_data(const float* dY, int lddy, int dy_col_off, const float* dY0, const float* Y, int ldy,

@@ -40,6 +40,7 @@ FUSED_GRID_HEAD = True  # feature passes: grids + first head layer + mean in one
 # reference does, every pass samples its own rays)
 REUSE_PASS1 = _os.environ.get("SNF_RENDER_REUSE_PASS1", "1") == "1"
 FUSED_SH_INPUT = _os.environ.get("SNF_FUSED_SH_INPUT", "1") == "1"  # colour net input cat(SH16(d), geo) formed in its loader
+FUSED_DENSITY = _os.environ.get("SNF_FUSED_DENSITY", "1") == "1"  # trunc_exp of the base net's output 0 in its epilogue
 
 
 class _Dyn:
@@ -178,9 +179,12 @@ class RenderProgram:
         k("snf_hashgrid_fwd", u1, fenc.params, fenc.scalings, N1, FL, FF, FT, enc1, 0, 0)
         C = bw1.shape[0]
         h = b("h", (N1, C))
-        k("snf_mlp64_fwd", enc1, 0, bw0, FL * FF, None, bw1, 1, C, ops.ACT_NONE, N1, None, None, h, C)
         density1 = b("density1", (N1,))
-        k("snf_trunc_exp_fwd", h, C, sel1, N1, density1)
+        if FUSED_DENSITY:  # (trunc_exp of output 0 from the base net's epilogue)
+            k("snf_mlp64_fwd_density", enc1, 0, bw0, FL * FF, None, bw1, 1, C, ops.ACT_NONE, N1, None, None, h, C, sel1, density1)
+        else:
+            k("snf_mlp64_fwd", enc1, 0, bw0, FL * FF, None, bw1, 1, C, ops.ACT_NONE, N1, None, None, h, C)
+            k("snf_trunc_exp_fwd", h, C, sel1, N1, density1)
         w1 = b("w1", (R, S))
         k("snf_weights_fwd", density1, 1, 1, None, eb1, R, S, w1, None)
         handles = {"w1": w1, "eb1": eb1}

@@ -99,6 +99,7 @@ RECORD_EXCHANGE = True
 # (snf_mlp64_fwd_sh / snf_mlp64_bwd_fused_sh) instead of written by snf_head_input and read back twice; the backward writes the
 # geo columns' gradient only ([N, 16] instead of [N, 32]).  Needs the recomputing fused backward (gemm mode 1).
 FUSED_SH_INPUT = _os.environ.get("SNF_FUSED_SH_INPUT", "1") == "1"
+FUSED_DENSITY = _os.environ.get("SNF_FUSED_DENSITY", "1") == "1"  # trunc_exp of the base net's output 0 in its epilogue
 
 
 # SNF_ABLATE_SKIP="key,key": launches whose key contains one of these are NOT issued (results are garbage; timing probe only)
@@ -599,10 +600,15 @@ class StepProgram:
         C = bw1.shape[0]  # 1 + geo
         rc = self._chain_recompute()  # the hidden activations of the two field nets are not stored
         hb1, h = (None if rc else b("hb1", (N1, 64))), b("h", (N1, C))
-        self._k(main, "snf_mlp64_fwd", enc1, 0, bw0, FL * FF, None, bw1, 1, C, ops.ACT_NONE, N1, hb1, None, h, C,
-                tag=f"{FL * FF}x64x{C}")
         density1 = b("density1", (N1,))
-        self._k(main, "snf_trunc_exp_fwd", h, C, sel1, N1, density1)
+        # (trunc_exp of output 0 from the chain's epilogue where the base net stores nothing but its 16 outputs; else two kernels)
+        if FUSED_DENSITY:
+            self._k(main, "snf_mlp64_fwd_density", enc1, 0, bw0, FL * FF, None, bw1, 1, C, ops.ACT_NONE, N1, hb1, None, h, C, sel1,
+                    density1, tag=f"{FL * FF}x64x{C}")
+        else:
+            self._k(main, "snf_mlp64_fwd", enc1, 0, bw0, FL * FF, None, bw1, 1, C, ops.ACT_NONE, N1, hb1, None, h, C,
+                    tag=f"{FL * FF}x64x{C}")
+            self._k(main, "snf_trunc_exp_fwd", h, C, sel1, N1, density1)
         n_geo = C - 1
         sh_in = bool(FUSED_SH_INPUT and rc and FUSED_CHAIN_WGRAD and n_geo == 15 and C % 4 == 0)
         hh1, hh2, rgb = (None if rc else b("hh1", (N1, 64))), (None if rc else b("hh2", (N1, 64))), b("rgb", (N1, 3))

@@ -924,6 +924,41 @@ def test_level_major_feature_grids_feed_the_table_backward():
         assert maxdiff(a, bq) <= 2e-6 * float(a.abs().max())  # (fp32 sums inside a row depend on the LDS ranking order)
 
 
+
+@pytest.mark.parametrize("N,planar,hid", [(70_001, True, False), (4096, False, False), (5000, True, True)])
+def test_base_net_density_from_the_epilogue_equals_trunc_exp(N, planar, hid):
+    """snf_mlp64_fwd_density == snf_mlp64_fwd + snf_trunc_exp_fwd bit for bit (outputs AND density): the base net's shape with the
+    density written from the chain's epilogue (level-major and row-major input), and a launch that stores its hidden layer -- not
+    the fused epilogue's shape -- where the entry point runs the two kernels."""
+    import ctypes
+    from samnerf_amd import _lib
+    L = _lib.load()
+    g = torch.Generator(device="cuda").manual_seed(9)
+    x = torch.randn((32, N) if planar else (N, 32), device="cuda", generator=g) * 0.5
+    w0 = torch.randn((64, 32), device="cuda", generator=g) * 0.2
+    w1 = torch.randn((16, 64), device="cuda", generator=g) * 0.2
+    sel = (torch.rand((N,), device="cuda", generator=g) > 0.1).to(torch.uint8)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    ldx = 0 if planar else 32
+    outs = []
+    for fused in (False, True):
+        h = torch.empty((N, 16), device="cuda")
+        d = torch.empty((N,), device="cuda")
+        hb = torch.empty((N, 64), device="cuda") if hid else None
+        if fused:
+            _lib.check(L.snf_mlp64_fwd_density(P(x), ldx, P(w0), 32, None, P(w1), 1, 16, 0, N, P(hb), None, P(h), 16, P(sel), P(d), st),
+                       "snf_mlp64_fwd_density")
+        else:
+            _lib.check(L.snf_mlp64_fwd(P(x), ldx, P(w0), 32, None, P(w1), 1, 16, 0, N, P(hb), None, P(h), 16, st), "snf_mlp64_fwd")
+            _lib.check(L.snf_trunc_exp_fwd(P(h), 16, P(sel), N, P(d), st), "snf_trunc_exp_fwd")
+        outs.append((h, d, hb))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    if hid:
+        assert torch.equal(outs[0][2], outs[1][2])
+    assert float(outs[1][1].max()) > 0 and bool((outs[1][1][sel == 0] == 0).all())
+
+
 @pytest.mark.parametrize("N,planar", [(4096 * 8, True), (1000, True), (33, False), (70001, False)])
 def test_base_net_forward_with_static_stores_equals_the_general_epilogue(N, planar):
     """snf_mlp64_fwd on the base net's shape (32 -> 64 -> 16, no activation, nothing stored but the output) takes the instantiation whose

@@ -65,6 +65,7 @@ def find(sub):
 entry = {
     "snf_mlp64_fwd/31x64x64x3": find("k_mlp_chain_fwd_b3<2,") or find("k_mlp_chain_fwd<2"),
     "snf_mlp64_fwd/32x64x16": find("k_mlp_chain_fwd_b3<1,") or find("k_mlp_chain_fwd<1"),
+    "snf_mlp64_fwd_density/32x64x16": find("k_mlp_chain_fwd_b3<1,") or find("k_mlp_chain_fwd<1"),
     "snf_mlp64_bwd_data/31x64x64x3": find("k_mlp_chain_bwd<2"), "snf_mlp64_bwd_data/32x64x16": find("k_mlp_chain_bwd<1"),
     "snf_mlp64_bwd_fused/31x64x64x3": find("k_mlp_chain_bwd_wg<2"), "snf_mlp64_bwd_fused/32x64x16": find("k_mlp_chain_bwd_wg<1"),
     "snf_linear_fwd/192x256": find("k_gemm_ws_b3<true, false, 128, 1, 512, 4, true"),
