@@ -199,13 +199,13 @@ class RenderProgram:
                 x2 = b("x2", (N1, 32))
                 k("snf_head_input", d_, h.data_ptr() + 4, R, S, n_geo, C, x2, 32)
                 k("snf_mlp64_fwd", x2, 32, hw0, 16 + n_geo, hw1, hw2, 2, 3, ops.ACT_SIGMOID, N1, None, None, rgb, 3)
-            k("snf_composite_fwd", rgb, w1, None, R, S, 0, _Dyn("out:rgb"), None, None)
+            # (colour, accumulation and median depth of a ray in ONE pass over its weights)
             outputs["rgb"] = 3
             if fast:
-                k("snf_composite_fwd", None, w1, eb1, R, S, 0, None, None, _Dyn("out:depth"))
+                k("snf_composite_fwd", rgb, w1, eb1, R, S, 0, _Dyn("out:rgb"), None, _Dyn("out:depth"))
                 outputs["depth"] = 1
             else:
-                k("snf_composite_fwd", None, w1, eb1, R, S, 0, None, _Dyn("out:accumulation"), _Dyn("out:depth"))
+                k("snf_composite_fwd", rgb, w1, eb1, R, S, 0, _Dyn("out:rgb"), _Dyn("out:accumulation"), _Dyn("out:depth"))
                 k("snf_composite_fwd", None, w0, eb0, R, P, 0, None, None, _Dyn("out:prop_depth_0"))
                 outputs.update({"accumulation": 1, "depth": 1, "prop_depth_0": 1})
             return entries, slots, outputs, handles
