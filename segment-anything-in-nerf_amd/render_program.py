@@ -41,6 +41,10 @@ FUSED_GRID_HEAD = True  # feature passes: grids + first head layer + mean in one
 REUSE_PASS1 = _os.environ.get("SNF_RENDER_REUSE_PASS1", "1") == "1"
 FUSED_SH_INPUT = _os.environ.get("SNF_FUSED_SH_INPUT", "1") == "1"  # colour net input cat(SH16(d), geo) formed in its loader
 FUSED_DENSITY = _os.environ.get("SNF_FUSED_DENSITY", "1") == "1"  # trunc_exp of the base net's output 0 in its epilogue
+# pass 1: consecutive chunks on this many alternating streams, each with its own intermediates -- a chunk's grid forwards (bound by the
+# texture path) beside the previous chunk's MLP chains (matrix cores + streaming).  Measured SLOWER: 16.6 ms on one stream, 17.7 on two,
+# 19.0 on three (the level-at-a-time forward lives on its 4 MB slab staying in L2; the chains' 800 MB per chunk stream through it)
+LANES = max(1, int(_os.environ.get("SNF_RENDER_LANES", "1")))
 
 
 class _Dyn:
@@ -132,8 +136,9 @@ class RenderProgram:
         return k, b, entries, slots
 
     def _prefix(self, R: int, mode: str, tag: str = "") -> str:
-        # (buffers of different GEMM modes / head paths never share a name: a plan of the other mode keeps its own addresses)
-        return f"{mode}{tag}{R}_g{int(self.lib.snf_get_gemm_mode())}{'f' if FUSED_GRID_HEAD else 'u'}_"
+        # (buffers of different GEMM modes / head paths / lanes never share a name: a plan of the other kind keeps its own addresses)
+        lane = getattr(self, "_lane", 0)
+        return f"{mode}{tag}{R}_g{int(self.lib.snf_get_gemm_mode())}{'f' if FUSED_GRID_HEAD else 'u'}{'L%d' % lane if lane else ''}_"
 
     def _build(self, R: int, mode: str, fast: bool):
         """-> (entries [[fn, args, name]], slots {name: [(args, index)]}, outputs {name: channels}, handles) for one chunk of R
@@ -343,12 +348,25 @@ class RenderProgram:
             self.plans.clear()  # recorded for another stream, or before the parameters / the collider moved
         self._stream, self._sig = st, sig
 
-    def _plan(self, kind: str, R: int, mode: str, fast: bool):
-        key = (kind, R, mode, bool(fast), int(self.lib.snf_get_gemm_mode()), bool(FUSED_GRID_HEAD), bool(FUSED_SH_INPUT))
+    def _plan(self, kind: str, R: int, mode: str, fast: bool, lane: int = 0):
+        """The recorded launches of one chunk.  lane > 0: recorded on that lane's stream (`_lane_stream`) with its own buffers."""
+        key = (kind, R, mode, bool(fast), int(self.lib.snf_get_gemm_mode()), bool(FUSED_GRID_HEAD), bool(FUSED_SH_INPUT), lane)
         plan = self.plans.get(key)
         if plan is None:
-            plan = self.plans[key] = self._build(R, mode, bool(fast)) if kind == "full" else self._build_heads(R, mode)
+            self._lane = lane
+            try:
+                if lane:
+                    with torch.cuda.stream(self._lane_stream(lane)):
+                        plan = self._build(R, mode, bool(fast)) if kind == "full" else self._build_heads(R, mode)
+                else:
+                    plan = self._build(R, mode, bool(fast)) if kind == "full" else self._build_heads(R, mode)
+            finally:
+                self._lane = 0
+            self.plans[key] = plan
         return plan
+
+    def _lane_stream(self, lane: int) -> "torch.cuda.Stream":
+        return ops.make_stream(f"render{lane}")
 
     @staticmethod
     def _replay(plan, vals: dict) -> None:
@@ -410,10 +428,19 @@ class RenderProgram:
                           "ids": torch.empty((m, K), device=self.dev, dtype=torch.int32),
                           "wk": torch.empty((m, K), device=self.dev), "uk": torch.empty((m * K, 3), device=self.dev)}
         self._kept = kept
-        st = torch.cuda.current_stream().cuda_stream
+        cur = torch.cuda.current_stream()
+        n_chunks = (n + chunk - 1) // chunk
+        lanes = LANES if n_chunks > 1 else 1
+        if lanes > 1:  # lane l = chunks l, l + lanes, ...: lane 0 is the caller's stream, the others start behind what it has queued
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            for l in range(1, lanes):
+                self._lane_stream(l).wait_event(ev)
         for ci, i in enumerate(range(0, n, chunk)):
             R = min(chunk, n - i)
-            plan = self._plan("full", R, mode, fast)
+            lane = ci % lanes
+            st = (self._lane_stream(lane) if lane else cur).cuda_stream
+            plan = self._plan("full", R, mode, fast, lane)
             outputs, handles = plan[2], plan[3]
             if not results:
                 results = {name: torch.empty((self.rows_out(n, mode) if name == mode else n, ch), device=self.dev)
@@ -439,6 +466,10 @@ class RenderProgram:
                     rc = self.lib.snf_positions_rows(o_ptr, d_ptr, eb1.data_ptr(), kp["ids"].data_ptr(), src.data_ptr() + a * 4,
                                                      dst.data_ptr() + a * 4, e - a, S, K, ops.CONTRACT_L2, kp["uk"].data_ptr(), st)
                     _lib.check(rc, "snf_positions_rows")
+        for l in range(1, lanes):  # the caller's stream continues behind every lane
+            ev = torch.cuda.Event()
+            ev.record(self._lane_stream(l))
+            cur.wait_event(ev)
         return results
 
     @torch.no_grad()
