@@ -274,6 +274,11 @@ int snf_linear_bwd_weight_rows(const float* dYg, const float* row_scale, int gro
 int snf_mlp_tiny_supported(int I, int H, int O);
 int snf_mlp_tiny_fwd(const float* X, int ldx, const float* W0, const float* W1, int I, int H, int64_t N, float* Hid,
                      float* Y, snf_stream_t stream);
+/* The proposal density of the eval path in one launch (HashMLPDensityField.get_density, density_fields.py:99-127, no gradients):
+ * density[n] = exp(mlp(hashgrid(u[n]))) * selector[n] == snf_hashgrid_fwd (row-major) + snf_mlp_tiny_fwd + snf_trunc_exp_fwd, identical
+ * values, no [N, 10] encoding written.  L = 5, F = 2, H = 16 only (snf_mlp_tiny_supported). */
+int snf_prop_density_fwd(const float* u, const float* table, const float* scalings, int N, int L, int F, int log2_T, const float* W0,
+                         const float* W1, int H, const uint8_t* selector, float* density, snf_stream_t stream);
 int snf_mlp_tiny_bwd(const float* dY, const float* X, int ldx, const float* Hid, const float* W0, const float* W1, int I,
                      int H, int64_t N, float* dX, int lddx, float* dW0, float* dW1, snf_stream_t stream);
 

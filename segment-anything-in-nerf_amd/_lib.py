@@ -34,7 +34,7 @@ def _hipcc() -> str:
 def _source_hash() -> str:
     h = hashlib.sha256()
     files = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "common.hpp"), os.path.join(CSRC, "grid_device.hpp"),
-                                                         os.path.join(INCLUDE, "samnerf_hip.h")]
+                                                         os.path.join(CSRC, "mlp_tiny_device.hpp"), os.path.join(INCLUDE, "samnerf_hip.h")]
     for f in files:
         with open(f, "rb") as fh:
             h.update(fh.read())
@@ -120,6 +120,7 @@ SIGNATURES = {
     "snf_weights_fwd": [P, I, I, P, P, I, I, P, P, P],
     "snf_weights_bwd": [P, I, I, P, P, P, I, I, P, P],
     "snf_trunc_exp_fwd": [P, I, P, c_int64, P, P],
+    "snf_prop_density_fwd": [P, P, P, I, I, I, I, P, P, I, P, P, P],
     "snf_trunc_exp_bwd": [P, I, P, P, c_int64, P, I, P],
     "snf_pdf_resample": [P, P, P, P, P, I, I, I, F, F, P, P, P],
     "snf_composite_fwd": [P, P, P, I, I, I, P, P, P, P],

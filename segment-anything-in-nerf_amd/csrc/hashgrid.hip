@@ -10,6 +10,7 @@
 // Launch: grid = (ceil(N/256), L): blockIdx.y is the level, so a workgroup (and its neighbours in x)
 // gather from ONE level slab; a thread owns one (sample, level) pair and keeps all 8 corner loads in flight.
 #include "common.hpp"
+#include "mlp_tiny_device.hpp"
 #include <algorithm>
 #include <type_traits>
 #include "grid_device.hpp"
@@ -123,8 +124,7 @@ __device__ __forceinline__ float hg_blend(float f0, float f1, float f2, float f3
 
 // one (sample, level): gather the 8 corner rows, trilinear blend in the reference's order, store
 template <int F>
-__device__ __forceinline__ void hg_fwd_one(const Corners& c, const float* __restrict__ slab, int n, int l, int N,
-                                           float* __restrict__ out, int ld_out, int col_off) {
+__device__ __forceinline__ void hg_eval(const Corners& c, const float* __restrict__ slab, float (&r)[F]) {
     float f[8][F];
 #define SNF_HG_FWD_PAIR 1
     if constexpr (F == 2 && SNF_HG_FWD_PAIR) {
@@ -158,10 +158,16 @@ __device__ __forceinline__ void hg_fwd_one(const Corners& c, const float* __rest
     }
     const float ox = c.ox, oy = c.oy, oz = c.oz;
     const float mx = 1.f - ox, my = 1.f - oy, mz = 1.f - oz;
-    float r[F];
 #pragma unroll
     for (int j = 0; j < F; ++j)
         r[j] = hg_blend(f[0][j], f[1][j], f[2][j], f[3][j], f[4][j], f[5][j], f[6][j], f[7][j], ox, oy, oz, mx, my, mz);
+}
+
+template <int F>
+__device__ __forceinline__ void hg_fwd_one(const Corners& c, const float* __restrict__ slab, int n, int l, int N,
+                                           float* __restrict__ out, int ld_out, int col_off) {
+    float r[F];
+    hg_eval<F>(c, slab, r);
     // ld_out == 0: level-major ("planar") output [L][N][F] -- consecutive samples of a level are contiguous, so a wave
     // writes whole lines (row-major [N, L*F] output is 8 / 32 bytes per 128-byte row from a level-at-a-time kernel:
     // rocprofv3 WRITE_SIZE showed 4x the algorithmic bytes for the F=2 field grid)
@@ -184,6 +190,39 @@ __global__ __launch_bounds__(256) void k_hashgrid_fwd(const float* __restrict__ 
     const uint32_t mask = (1u << log2_T) - 1u;
     const Corners c = corners_of(u, n, scalings[l], mask);
     hg_fwd_one<F>(c, table + ((size_t)l << log2_T) * F, n, l, N, out, ld_out, col_off);
+}
+
+// The eval render's proposal stage in one kernel (density_fields.py:99-127 without gradients): the L = 5 levels of the F = 2 proposal
+// grid, the 10 -> 16 -> 1 density net and trunc_exp per sample, in registers -- snf_hashgrid_fwd + snf_mlp_tiny_fwd + snf_trunc_exp_fwd
+// wrote and re-read a [N, 10] encoding (8 bytes per 40-byte row from each level's pass) that nothing else looks at.  Same device
+// functions, same values.
+template <int L>
+__global__ __launch_bounds__(256) void k_prop_density_fwd(const float* __restrict__ u, const float* __restrict__ table,
+                                                          const float* __restrict__ scalings, int N, int log2_T,
+                                                          const float* __restrict__ W0, const float* __restrict__ W1,
+                                                          const uint8_t* __restrict__ selector, float* __restrict__ density) {
+    constexpr int I = 2 * L, H = 16;
+    __shared__ float w0[H * I], w1[H], sc[L];
+    for (int i = threadIdx.x; i < H * I; i += 256) w0[i] = W0[i];
+    if (threadIdx.x < H) w1[threadIdx.x] = W1[threadIdx.x];
+    if (threadIdx.x < L) sc[threadIdx.x] = scalings[threadIdx.x];
+    __syncthreads();
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const uint32_t mask = (1u << log2_T) - 1u;
+    float x[I];
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        const Corners c = corners_of(u, n, sc[l], mask);
+        float r[2];
+        hg_eval<2>(c, table + ((size_t)l << log2_T) * 2, r);
+        x[2 * l] = r[0];
+        x[2 * l + 1] = r[1];
+    }
+    float h[H];
+    float d = expf(mt_forward<I, H>(x, w0, w1, h));
+    if (selector) d *= (float)selector[n];
+    density[n] = d;
 }
 
 template <int F>
@@ -1746,6 +1785,20 @@ extern "C" int snf_hashgrid_fwd(const float* u, const float* table, const float*
         hipLaunchKernelGGL(k_hashgrid_fwd<8>, grid, dim3(256), 0, (hipStream_t)stream, u, table, scalings, N, log2_T,
                            out, ld_out, col_off, 0);
     SNF_LAUNCH_CHECK("snf_hashgrid_fwd");
+    return SNF_OK;
+}
+
+// density[n] = exp(mlp(hashgrid(u[n]))) * selector[n]: snf_hashgrid_fwd (row-major) + snf_mlp_tiny_fwd + snf_trunc_exp_fwd in one
+// launch, for the proposal net's shape (L = 5 levels, F = 2, 10 -> 16 -> 1: snf_mlp_tiny_supported); no intermediate is written
+extern "C" int snf_prop_density_fwd(const float* u, const float* table, const float* scalings, int N, int L, int F, int log2_T,
+                                    const float* W0, const float* W1, int H, const uint8_t* selector, float* density,
+                                    snf_stream_t stream) {
+    SNF_REQUIRE(u && table && scalings && W0 && W1 && density && N > 0, "snf_prop_density_fwd: bad argument");
+    SNF_REQUIRE(L == 5 && F == 2 && H == 16, "snf_prop_density_fwd: only the 5-level F = 2 grid with the 10 -> 16 -> 1 net is built (L=%d F=%d H=%d)", L, F, H);
+    SNF_REQUIRE(log2_T >= 1 && log2_T <= 26 && ((uintptr_t)table % 16) == 0, "snf_prop_density_fwd: bad table");
+    hipLaunchKernelGGL(k_prop_density_fwd<5>, dim3(ceil_div(N, 256)), dim3(256), 0, (hipStream_t)stream, u, table, scalings, N, log2_T,
+                       W0, W1, selector, density);
+    SNF_LAUNCH_CHECK("snf_prop_density_fwd");
     return SNF_OK;
 }
 

@@ -7,6 +7,7 @@
 // k_mlp_tiny_bwd), folds the waves through LDS and issues ONE set of global atomics per workgroup -- the three GEMM launches + two
 // wgrad launches this replaces spent most of their time on 10-wide unaligned rows.
 #include "common.hpp"
+#include "mlp_tiny_device.hpp"
 
 namespace snf {
 
@@ -29,16 +30,8 @@ __global__ __launch_bounds__(256) void k_mlp_tiny_fwd(const float* __restrict__ 
         const float2 t = *reinterpret_cast<const float2*>(xp + i);
         x[i] = t.x; x[i + 1] = t.y;
     }
-    float y = 0.f;
     float h[H];
-#pragma unroll
-    for (int j = 0; j < H; ++j) {
-        float a = 0.f;
-#pragma unroll
-        for (int i = 0; i < I; ++i) a += w0[j * I + i] * x[i];
-        h[j] = fmaxf(a, 0.f);
-        y += w1[j] * h[j];
-    }
+    const float y = mt_forward<I, H>(x, w0, w1, h);
     if (Hid != nullptr) {
 #pragma unroll
         for (int j = 0; j < H; j += 4)

@@ -41,6 +41,7 @@ FUSED_GRID_HEAD = True  # feature passes: grids + first head layer + mean in one
 REUSE_PASS1 = _os.environ.get("SNF_RENDER_REUSE_PASS1", "1") == "1"
 FUSED_SH_INPUT = _os.environ.get("SNF_FUSED_SH_INPUT", "1") == "1"  # colour net input cat(SH16(d), geo) formed in its loader
 FUSED_DENSITY = _os.environ.get("SNF_FUSED_DENSITY", "1") == "1"  # trunc_exp of the base net's output 0 in its epilogue
+FUSED_PROP = _os.environ.get("SNF_FUSED_PROP", "1") == "1"  # proposal grid + density net + trunc_exp in one launch (eval)
 # pass 1: consecutive chunks on this many alternating streams, each with its own intermediates -- a chunk's grid forwards (bound by the
 # texture path) beside the previous chunk's MLP chains (matrix cores + streaming).  Measured SLOWER: 16.6 ms on one stream, 17.7 on two,
 # 19.0 on three (the level-at-a-time forward lives on its 4 MB slab staying in L2; the chains' 800 MB per chunk stream through it)
@@ -161,13 +162,17 @@ class RenderProgram:
         k("snf_sample_spacing", nears, fars, None, R, P, sb0, eb0)
         u0, sel0 = b("u0", (N0, 3)), b("sel0", (N0,), torch.uint8)
         k("snf_positions", o_, d_, eb0, None, R, P, P, ops.CONTRACT_LINF, 1, u0, sel0)
-        enc0 = b("enc0", (N0, PL * PF))
-        k("snf_hashgrid_fwd", u0, penc.params, penc.scalings, N0, PL, PF, PT, enc0, PL * PF, 0)
         I0, H0 = pnet.n_input_dims, pw0.shape[0]
-        raw0 = b("raw0", (N0, 1))
-        k("snf_mlp_tiny_fwd", enc0, I0, pw0, pw1, I0, H0, N0, None, raw0)
         dens0 = b("dens0", (N0,))
-        k("snf_trunc_exp_fwd", raw0, 1, sel0, N0, dens0)
+        if FUSED_PROP and PL == 5 and PF == 2 and H0 == 16 and I0 == 10 and pw1.shape[0] == 1:
+            # grid + density net + trunc_exp per sample in registers: the [N, 10] encoding is never written
+            k("snf_prop_density_fwd", u0, penc.params, penc.scalings, N0, PL, PF, PT, pw0, pw1, H0, sel0, dens0)
+        else:
+            enc0 = b("enc0", (N0, PL * PF))
+            k("snf_hashgrid_fwd", u0, penc.params, penc.scalings, N0, PL, PF, PT, enc0, PL * PF, 0)
+            raw0 = b("raw0", (N0, 1))
+            k("snf_mlp_tiny_fwd", enc0, I0, pw0, pw1, I0, H0, N0, None, raw0)
+            k("snf_trunc_exp_fwd", raw0, 1, sel0, N0, dens0)
         w0 = b("w0", (R, P))
         k("snf_weights_fwd", dens0, 1, 1, None, eb0, R, P, w0, None)
         sb1, eb1 = b("sb1", (R, S + 1)), b("eb1", (R, S + 1))

@@ -86,6 +86,39 @@ def test_hashgrid_golden(golden, name, log2_T):
     assert maxdiff(table.grad, g["grad_table"]) <= 2e-5
 
 
+@pytest.mark.parametrize("N,T", [(100_003, 17), (4096, 10)])
+def test_proposal_density_in_one_launch_equals_the_three_kernels(N, T):
+    """snf_prop_density_fwd == snf_hashgrid_fwd + snf_mlp_tiny_fwd + snf_trunc_exp_fwd bit for bit (the eval render's proposal stage),
+    samples on cell faces and outside [0, 1] included, with and without a selector."""
+    import ctypes
+    from samnerf_amd import _lib
+    L_ = _lib.load()
+    gen = torch.Generator().manual_seed(4)
+    spec = O.GridSpec(5, 2, T, 16, 128)
+    table = ((torch.rand((spec.rows, 2), generator=gen) * 2 - 1) * 0.5).to(DEV)
+    u = torch.rand((N, 3), generator=gen)
+    u[:500] = torch.randint(0, 17, (500, 3), generator=gen).float() / 16.0
+    u[500:600] = u[500:600] * 1.2 - 0.1
+    u = u.to(DEV)
+    sc = spec.scalings().to(DEV)
+    w0 = (torch.randn((16, 10), generator=gen) * 0.8).to(DEV)
+    w1 = (torch.randn((1, 16), generator=gen) * 0.8).to(DEV)
+    sel = (torch.rand((N,), generator=gen) > 0.2).to(torch.uint8).to(DEV)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    for s_ in (sel, None):
+        enc = torch.empty((N, 10), device=DEV)
+        raw = torch.empty((N,), device=DEV)
+        ref = torch.empty((N,), device=DEV)
+        _lib.check(L_.snf_hashgrid_fwd(P(u), P(table), P(sc), N, 5, 2, T, P(enc), 10, 0, st), "snf_hashgrid_fwd")
+        _lib.check(L_.snf_mlp_tiny_fwd(P(enc), 10, P(w0), P(w1), 10, 16, N, None, P(raw), st), "snf_mlp_tiny_fwd")
+        _lib.check(L_.snf_trunc_exp_fwd(P(raw), 1, P(s_), N, P(ref), st), "snf_trunc_exp_fwd")
+        got = torch.empty((N,), device=DEV)
+        _lib.check(L_.snf_prop_density_fwd(P(u), P(table), P(sc), N, 5, 2, T, P(w0), P(w1), 16, P(s_), P(got), st), "snf_prop_density_fwd")
+        assert torch.equal(got, ref)
+        assert float(ref.max()) > 0
+
+
 def test_hashgrid_two_grids_concat_and_large():
     """two F=8 grids into one [N,192] buffer (the SAM head layout) at a size the oracle still handles."""
     gen = torch.Generator().manual_seed(0)
