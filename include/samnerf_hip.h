@@ -540,6 +540,26 @@ int snf_adam_step(float* p, float* g, float* m, float* v, int64_t n, float lr, f
 int snf_adam_step_rows(float* p, float* g, float* m, float* v, const int32_t* rows, int64_t nrows, int F, float lr,
                        float beta1, float beta2, float eps, int step, float grad_scale, int zero_grad, snf_stream_t stream);
 
+/* Non-finite-gradient guard.  Replaces torch.cuda.amp.GradScaler's inf / NaN check around the optimizer step
+ * (nerfstudio/engine/trainer.py:419-437, engine/optimizers.py:138-149: `grad_scaler.step(optimizer)` does not call
+ * optimizer.step() when a gradient of that optimizer is inf / NaN -- parameters, moments and state['step'] stay).  Adam is fused
+ * into the table backward here, so the verdict has to exist BEFORE those launches and the host must not wait for it: a guard is a
+ * device record int32[2] = {veto, skipped}, zero-initialised by the caller, one per group of losses whose gradients reach the
+ * same parameters.
+ *   snf_guard_update(values, n, guard): first commits the previous verdict (veto set -> skipped += 1), then veto = any of the n
+ *     loss values is inf / NaN.  Enqueued behind the loss kernels of a step, in front of its optimizer-side launches.
+ *   snf_guard_scan(x, n, guard): veto |= any of x[0 .. n) is inf / NaN.  For the dense parameters (MLP / conv weights) of the group:
+ *     a loss can stay finite over an inf weight -- fmaxf(NaN, 0) = 0 in a ReLU, sigmoid(inf) = 1 -- while the gradients behind it are
+ *     NaN (0 * inf); with finite losses AND finite weights every gradient of this fp32 path is finite unless a product overflows.
+ *   snf_step_guard(guard): binds `guard` (or NULL: none) for the calling host thread.  The optimizer-side entry points issued while
+ *     it is bound -- snf_adam_step, snf_adam_step_rows, snf_hashgrid_bwd_presorted_adam / _sp / _xp / _pair / _fx -- read the
+ *     record on the device: on a vetoed step p / exp_avg / exp_avg_sq are left as they are (gradients are still cleared where
+ *     zero_grad asks for it) and the bias corrections use `step - skipped`, so a vetoed step does not count.  With veto = skipped = 0
+ *     every result is bit-identical to an unguarded launch. */
+int snf_step_guard(const int32_t* guard);
+int snf_guard_update(const float* values, int n, int32_t* guard, snf_stream_t stream);
+int snf_guard_scan(const float* x, int64_t n, int32_t* guard, snf_stream_t stream);
+
 /* Tuning hook: launch shape of the Adam kernel (grid cap, threads per block in {64,128,256}, independent 16-byte groups
  * per thread in {1,2,4}).  Process-wide; the default is the measured best for MI355X. */
 int snf_set_adam_launch(int max_blocks, int threads, int unroll);

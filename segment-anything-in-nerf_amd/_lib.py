@@ -136,6 +136,9 @@ SIGNATURES = {
     "snf_adam_step": [P, P, P, P, c_int64, F, F, F, F, I, F, I, P],
     "snf_adam_step_rows": [P, P, P, P, P, c_int64, I, F, F, F, F, I, F, I, P],
     "snf_set_adam_launch": [I, I, I],
+    "snf_step_guard": [P],
+    "snf_guard_update": [P, I, P, P],
+    "snf_guard_scan": [P, c_int64, P, P],
     "snf_patchify": [P, I, I, I, I, P, P],
     "snf_sam_preprocess": [P, I, I, I, I, I, I, P, P, P, P],
     "snf_layernorm": [P, P, I, I, P, P, F, P, P, P],

@@ -29,6 +29,36 @@ void set_error(const char* fmt, ...);
 
 constexpr int WAVE = 64;
 
+// ---- non-finite-gradient guard (snf_step_guard, optim.hip) ---------------------------------------------------------------
+// A guard is a device record int32[2] = {veto, skipped}: `veto` != 0 means the loss of the step in flight was not finite (written by
+// snf_guard_update), `skipped` counts the steps vetoed before it.  Every optimizer-side kernel (snf_adam_step, snf_adam_step_rows, the
+// fused backward + Adam epilogues of hashgrid.hip) launched while a guard is bound leaves p / exp_avg / exp_avg_sq untouched on a vetoed
+// step and takes its bias corrections from `step - skipped` -- what torch.cuda.amp.GradScaler.step does when it finds an inf / NaN
+// gradient (nerfstudio/engine/trainer.py:419-437, engine/optimizers.py:138-149): the optimizer's step is not called, its state['step']
+// does not advance.  The host never reads the record inside a step.
+const int32_t* current_guard();  // the record bound by snf_step_guard on this host thread, or nullptr
+
+struct GuardAdam {
+    bool veto;
+    float step_size, inv_sqrt_bc2;
+};
+// `guard` is a kernel argument (wave-uniform address: scalar loads).  With skipped == 0 -- always, unless a loss has been non-finite
+// before -- the host's bias corrections are kept bit for bit.
+__device__ __forceinline__ GuardAdam guard_adam(const int32_t* __restrict__ guard, float lr, float b1, float b2, int step,
+                                               float step_size, float inv_sqrt_bc2) {
+    GuardAdam r{false, step_size, inv_sqrt_bc2};
+    if (guard != nullptr) {
+        const int veto = guard[0], skipped = guard[1];
+        r.veto = veto != 0;
+        if (skipped > 0) {
+            const float t = (float)(step - skipped > 1 ? step - skipped : 1);
+            r.step_size = lr / (1.f - powf(b1, t));
+            r.inv_sqrt_bc2 = 1.f / sqrtf(1.f - powf(b2, t));
+        }
+    }
+    return r;
+}
+
 // Degree-4 real spherical harmonics of a direction (nerfstudio/utils/math.py:27-73 `components_from_spherical_harmonics`, levels = 4).
 // One definition for every kernel that needs it (snf_head_input, the colour net's fused loaders), evaluated WITHOUT FMA contraction:
 // the torch reference rounds every product and sum separately, and all kernels then agree bit for bit.

@@ -829,9 +829,22 @@ struct HgAdam {
     float *p, *m, *v;
     float b1, b2, step_size, inv_sqrt_bc2, eps, gs;
     int from_level;
+    // the non-finite-gradient guard bound when the launch was issued (snf_step_guard, common.hpp), or nullptr; resolved once at the top
+    // of a kernel by hg_guard: `veto` set = this step leaves p / m / v as they are
+    const int32_t* guard;
+    float lr;
+    int step, veto;
 };
 
+__device__ __forceinline__ void hg_guard(HgAdam& a) {
+    const GuardAdam ga = guard_adam(a.guard, a.lr, a.b1, a.b2, a.step, a.step_size, a.inv_sqrt_bc2);
+    a.step_size = ga.step_size;
+    a.inv_sqrt_bc2 = ga.inv_sqrt_bc2;
+    a.veto = ga.veto ? 1 : 0;
+}
+
 __device__ __forceinline__ void hg_adam1(float& p, float g, float& m, float& v, const HgAdam& a) {  // == optim.hip adam1
+    if (a.veto) return;  // (kernel-uniform)
     const float gg = g * a.gs;
     m = m + (gg - m) * (1.f - a.b1);
     v = v * a.b2 + (1.f - a.b2) * gg * gg;
@@ -1041,6 +1054,7 @@ __global__ __launch_bounds__(HG_SP_T) void k_hg_reduce_sparse(const float* __res
     unsigned long long* acc = sp_lds;
     uint32_t* bad = reinterpret_cast<uint32_t*>(acc + ACC);
     uint16_t* lookup = reinterpret_cast<uint16_t*>(bad + ACC / 32);
+    if constexpr (ADAM) hg_guard(adam);
     hg_sparse_body<F>(gT, N, log2_T, log2B, (int)blockIdx.x, (int)blockIdx.y, bucket_start, records, grad_table, reach_rows,
                       reach_start, lvl_absmax_bits, adam, ADAM, acc, bad, lookup);
 }
@@ -1108,6 +1122,7 @@ __global__ __launch_bounds__(HG_RT, SNF_HG_RT_MINWG) void k_hg_reduce(const floa
             sp = sec.sp;
         }
     }
+    if constexpr (ADAM) hg_guard(adam);
     l += level0;  // (a launch may cover the level sub-range [level0, level0 + n) of its table; all indices below are absolute)
     if constexpr (F == 8) {
         if (l < sp.levels) {
@@ -1451,6 +1466,7 @@ __global__ __launch_bounds__(HG_FX_T) void k_hg_reduce_fx(const float* __restric
                                                           const uint32_t* __restrict__ lvl_absmax_bits, HgAdam adam) {
     static_assert(!XP || (F == 2 && SPLIT == 1), "x-pair records: F = 2 grids, one workgroup per bucket");
     using Rec = typename std::conditional<XP, uint4, uint2>::type;
+    if constexpr (ADAM) hg_guard(adam);
     constexpr int MAXROWS = HG_MAX_RPB / SPLIT;
     __shared__ unsigned long long acc[MAXROWS * F];
     __shared__ uint32_t bad[MAXROWS * F / 32];  // one bit per (row, feature): a non-finite contribution landed there
@@ -1989,6 +2005,7 @@ static void hg_fill_adam(HgAdam& a, float* param, float* exp_avg, float* exp_avg
     a.p = param; a.m = exp_avg; a.v = exp_avg_sq;
     a.b1 = beta1; a.b2 = beta2; a.step_size = (float)((double)lr / bc1); a.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
     a.eps = eps; a.gs = grad_scale; a.from_level = from_level;
+    a.guard = current_guard(); a.lr = lr; a.step = step; a.veto = 0;
 }
 
 template <int F>

@@ -13,6 +13,9 @@ namespace snf {
 
 static thread_local char g_err[512] = "";
 
+static thread_local const int32_t* g_guard = nullptr;
+const int32_t* current_guard() { return g_guard; }
+
 void set_error(const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
@@ -41,7 +44,8 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 template <int U>
 __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                               float* __restrict__ v, long long n, float b1, float b2, float step_size,
-                                              float inv_sqrt_bc2, float eps, float gs, int zero_grad) {
+                                              float inv_sqrt_bc2, float eps, float gs, int zero_grad,
+                                              const int32_t* __restrict__ guard, float lr, int step) {
     const long long n4 = n >> 2;
     const long long stride = (long long)gridDim.x * blockDim.x;
     f4* p4 = reinterpret_cast<f4*>(p);
@@ -50,6 +54,17 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, float* __re
     f4* v4 = reinterpret_cast<f4*>(v);
     const f4 zero = {0.f, 0.f, 0.f, 0.f};
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const GuardAdam ga = guard_adam(guard, lr, b1, b2, step, step_size, inv_sqrt_bc2);
+    step_size = ga.step_size;
+    inv_sqrt_bc2 = ga.inv_sqrt_bc2;
+    if (ga.veto) {  // a vetoed step: parameters and moments stay, the gradient is cleared as zero_grad would
+        if (zero_grad) {
+            for (; i < n4; i += stride) stnt(g4 + i, zero);
+            const long long t = (n4 << 2) + (long long)blockIdx.x * blockDim.x + threadIdx.x;
+            if (t < n) g[t] = 0.f;
+        }
+        return;
+    }
     for (; i + (U - 1) * stride < n4; i += U * stride) {
         f4 P[U], G[U], M[U], V[U];
 #pragma unroll
@@ -99,12 +114,23 @@ template <int F>
 __global__ __launch_bounds__(256) void k_adam_rows(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, const int* __restrict__ rows, long long nrows,
                                                    float b1, float b2, float step_size, float inv_sqrt_bc2, float eps,
-                                                   float gs, int zero_grad) {
+                                                   float gs, int zero_grad, const int32_t* __restrict__ guard, float lr,
+                                                   int step) {
     constexpr int VPR = F == 8 ? 2 : 1;  // vector accesses per row (float4 x 2 or float2 x 1)
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
     if (t >= nrows * VPR) return;
     const long long r = t / VPR;
     const size_t off = (size_t)rows[r] + (size_t)(t - r * VPR) * 4;
+    const GuardAdam ga = guard_adam(guard, lr, b1, b2, step, step_size, inv_sqrt_bc2);
+    step_size = ga.step_size;
+    inv_sqrt_bc2 = ga.inv_sqrt_bc2;
+    if (ga.veto) {
+        if (zero_grad) {
+            if constexpr (F == 8) *reinterpret_cast<f4*>(g + off) = f4{0.f, 0.f, 0.f, 0.f};
+            else g[off] = g[off + 1] = 0.f;
+        }
+        return;
+    }
     if constexpr (F == 8) {
         f4 P = *reinterpret_cast<f4*>(p + off), G = *reinterpret_cast<f4*>(g + off);
         f4 M = *reinterpret_cast<f4*>(m + off), V = *reinterpret_cast<f4*>(v + off);
@@ -165,7 +191,7 @@ extern "C" int snf_adam_step(float* p, float* g, float* m, float* v, int64_t n, 
     if (blocks < 1) blocks = 1;
 #define SNF_ADAM_LAUNCH(UU)                                                                                             \
     hipLaunchKernelGGL(k_adam<UU>, dim3((unsigned)blocks), dim3(threads), 0, (hipStream_t)stream, p, g, m, v, (long long)n, \
-                       beta1, beta2, step_size, inv_sqrt_bc2, eps, grad_scale, zero_grad)
+                       beta1, beta2, step_size, inv_sqrt_bc2, eps, grad_scale, zero_grad, current_guard(), lr, step)
     if (U == 1) SNF_ADAM_LAUNCH(1); else if (U == 4) SNF_ADAM_LAUNCH(4); else SNF_ADAM_LAUNCH(2);
 #undef SNF_ADAM_LAUNCH
     SNF_LAUNCH_CHECK("snf_adam_step");
@@ -188,11 +214,55 @@ extern "C" int snf_adam_step_rows(float* p, float* g, float* m, float* v, const 
     const unsigned blocks = (unsigned)((threads + 255) / 256);
     if (F == 8)
         hipLaunchKernelGGL(k_adam_rows<8>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (const int*)rows,
-                           (long long)nrows, beta1, beta2, step_size, inv_sqrt_bc2, eps, grad_scale, zero_grad);
+                           (long long)nrows, beta1, beta2, step_size, inv_sqrt_bc2, eps, grad_scale, zero_grad, current_guard(), lr,
+                           step);
     else
         hipLaunchKernelGGL(k_adam_rows<2>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (const int*)rows,
-                           (long long)nrows, beta1, beta2, step_size, inv_sqrt_bc2, eps, grad_scale, zero_grad);
+                           (long long)nrows, beta1, beta2, step_size, inv_sqrt_bc2, eps, grad_scale, zero_grad, current_guard(), lr,
+                           step);
     SNF_LAUNCH_CHECK("snf_adam_step_rows");
+    return SNF_OK;
+}
+
+// ---- the non-finite-gradient guard (common.hpp has the device side) ----------------------------------------------------------
+// snf_guard_update: one thread.  First commits the previous step's verdict (a vetoed step counts as skipped), then judges this step's:
+// veto = any of the n loss values is inf / NaN.
+__global__ void k_guard_update(const float* __restrict__ values, int n, int32_t* __restrict__ guard) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (guard[0] != 0) guard[1] += 1;
+    int bad = 0;
+    for (int i = 0; i < n; ++i) {
+        const float x = values[i];
+        bad |= !(fabsf(x) <= FLT_MAX);  // false for NaN and for +-inf
+    }
+    guard[0] = bad;
+}
+
+// veto |= any of x[0 .. n) is inf / NaN (grid-stride; one atomic per workgroup that saw one)
+__global__ __launch_bounds__(256) void k_guard_scan(const float* __restrict__ x, long long n, int32_t* __restrict__ guard) {
+    int bad = 0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) bad |= !(fabsf(x[i]) <= FLT_MAX);
+    if (__syncthreads_or(bad) && threadIdx.x == 0) atomicOr(guard, 1);
+}
+
+extern "C" int snf_guard_scan(const float* x, int64_t n, int32_t* guard, snf_stream_t stream) {
+    SNF_REQUIRE(x && guard && n >= 1, "snf_guard_scan: bad argument");
+    long long blocks = (n + 256 * 8 - 1) / (256 * 8);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(k_guard_scan, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, (long long)n, guard);
+    SNF_LAUNCH_CHECK("snf_guard_scan");
+    return SNF_OK;
+}
+
+extern "C" int snf_step_guard(const int32_t* guard) {
+    g_guard = guard;
+    return SNF_OK;
+}
+
+extern "C" int snf_guard_update(const float* values, int n, int32_t* guard, snf_stream_t stream) {
+    SNF_REQUIRE(values && guard && n >= 1, "snf_guard_update: bad argument");
+    hipLaunchKernelGGL(k_guard_update, dim3(1), dim3(64), 0, (hipStream_t)stream, values, n, guard);
+    SNF_LAUNCH_CHECK("snf_guard_update");
     return SNF_OK;
 }
 

@@ -109,6 +109,16 @@ def _all_reduce(t: torch.Tensor) -> None:
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
 
 
+def _all_reduce_max(t: torch.Tensor) -> None:
+    """MAX over the ranks, in place (the veto word of a step guard: one rank's non-finite loss vetoes the step everywhere)."""
+    if _staged(t):
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.MAX)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+
+
 def _broadcast(t: torch.Tensor, src: int) -> None:
     if _staged(t):
         h = t.cpu()

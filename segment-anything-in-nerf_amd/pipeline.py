@@ -375,6 +375,9 @@ class Trainer:
         (the table-parallel levels and the sharded Adam moments are gathered first), rank 0 writes the file -- the reference's
         `if self.local_rank == 0: save` pattern around this call would deadlock in consolidate_state."""
         self.synchronize()
+        if self._program is not None:
+            torch.cuda.synchronize()
+            self._program.fold_guards()  # steps a non-finite loss vetoed do not count (GradScaler.step semantics)
         self.optimizers.consolidate_state()
         if not D.collectives_on() or torch.distributed.get_rank() == 0:
             torch.save({"step": step, "pipeline": self.pipeline.state_dict(), "optimizers": self.optimizers.state_dict()}, path)

@@ -100,6 +100,15 @@ RECORD_EXCHANGE = True
 # geo columns' gradient only ([N, 16] instead of [N, 32]).  Needs the recomputing fused backward (gemm mode 1).
 FUSED_SH_INPUT = _os.environ.get("SNF_FUSED_SH_INPUT", "1") == "1"
 FUSED_DENSITY = _os.environ.get("SNF_FUSED_DENSITY", "1") == "1"  # trunc_exp of the base net's output 0 in its epilogue
+# Non-finite-gradient guard (trainer.py:419-437, optimizers.py:138-149: GradScaler.step skips an optimizer whose gradients hold an inf / NaN).
+# Adam is fused into the table backward here, so a poisoned step cannot be vetoed afterwards: each group of losses owns a device record
+# {veto, skipped} (include/samnerf_hip.h, snf_step_guard) -- written behind its loss kernels by snf_guard_update, read by every
+# optimizer-side launch of the parameters those losses reach.  Domains: "nerf" (rgb + interlevel + distortion -> `fields`,
+# `proposal_networks`), "sam" (the SAM head's loss -> its slice of `sam_field` and `conv`), "clipseg" (its slice of `sam_field`).  The
+# reference has ONE optimizer for both heads; a guard per head keeps the two head streams independent (a shared verdict would make
+# each head's table backward wait for the other head's loss).  The host never reads a record inside a step: `opt.step_count` counts
+# optimistically and the kernels subtract `skipped` on the device; `StepProgram.guard_report()` reads them (synchronising).
+STEP_GUARD = _os.environ.get("SNF_STEP_GUARD", "1") == "1"
 
 
 # SNF_ABLATE_SKIP="key,key": launches whose key contains one of these are NOT issued (results are garbage; timing probe only)
@@ -189,6 +198,7 @@ class StepProgram:
         self.world = D.world_size() if self.multi else 1
         self.rank = torch.distributed.get_rank() if self.multi else 0
         self._tp_params: list = []  # tables whose levels are spread over the ranks (stale elsewhere after a step)
+        self._head_domain: Optional[str] = None  # the head whose task is being recorded (guard domain of `sam_field` / `conv`)
         self._own_sort_stream = None
         self._feat_sorted = None
         self._feat_sort_stream_id = None
@@ -242,6 +252,90 @@ class StepProgram:
 
     def _py(self, fn, *args) -> None:
         self._plan.entries.append([_PY, fn, list(args), None, 0.0, None])
+
+    # -- the non-finite-gradient guard (STEP_GUARD above) ----------------------------------------------------------------------
+    def _guard(self, domain: str) -> Optional[torch.Tensor]:
+        if not STEP_GUARD:
+            return None
+        return self.buf(f"guard_{domain}", (2,), torch.int32, zero=True)
+
+    def _guard_of_group(self, group: str) -> Optional[torch.Tensor]:
+        """The record the optimizer-side launches of `group` recorded NOW obey: the head being recorded for `sam_field` / `conv`."""
+        if group in ("sam_field", "conv"):
+            return self._guard(self._head_domain) if self._head_domain else None
+        return self._guard("nerf")
+
+    def _dense_ranges(self, group: str, first: int = 0, last: Optional[int] = None):
+        """Contiguous arena ranges [(offset, elements)] of the parameters first .. last-1 of `group` that are NOT hash tables."""
+        a = self.opt.arenas[group]
+        names = list(a.offsets)
+        out: list = []
+        for i in range(first, len(names) if last is None else last):
+            if names[i] in a.tables:
+                continue
+            off = a.offsets[names[i]][0]
+            end = a.offsets[names[i + 1]][0] if i + 1 < len(names) else a.numel
+            if out and out[-1][0] + out[-1][1] == off:
+                out[-1] = (out[-1][0], out[-1][1] + end - off)
+            else:
+                out.append((off, end - off))
+        return out
+
+    def _guard_update(self, st, domain: str, values: torch.Tensor, n: int = 1) -> None:
+        """Behind the loss kernels of `domain` on their stream: commit last step's verdict, judge this step's -- from the loss values
+        and from the dense weights of the domain (an inf weight can hide from the loss behind a ReLU and still make the gradients NaN)."""
+        g = self._guard(domain)
+        if g is None:
+            return
+        self._k(st, "snf_guard_update", values, n, g)
+        if domain == "nerf":
+            spans = [("fields", r) for r in self._dense_ranges("fields")] + \
+                    [("proposal_networks", r) for r in self._dense_ranges("proposal_networks")]
+        else:
+            lo_i, hi_i = self.tr._head_param_ranges()[domain]
+            spans = [("sam_field", r) for r in self._dense_ranges("sam_field", lo_i, hi_i)]
+            if domain == "sam" and "conv" in self.opt.arenas and self.cfg.patch_size > 1:
+                spans += [("conv", r) for r in self._dense_ranges("conv")]
+        for group, (off, cnt) in spans:
+            self._k(st, "snf_guard_scan", self.opt.arenas[group].param[off:off + cnt], cnt, g)
+        if self.multi:  # every rank obeys the same verdict: one rank's NaN reaches all of them through the gradient exchange
+            self._py(self._comm, st, D._all_reduce_max, g[0:1])
+
+    def _kg(self, st, group: str, name: str, *args, **kw) -> None:
+        """`_k` for an optimizer-side entry point: issued with the group's guard bound on this host thread (snf_step_guard)."""
+        g = self._guard_of_group(group)
+        if g is None:
+            self._k(st, name, *args, **kw)
+            return
+        self._py(self.lib.snf_step_guard, g.data_ptr())
+        self._k(st, name, *args, **kw)
+        self._py(self.lib.snf_step_guard, None)
+
+    def fold_guards(self) -> None:
+        """Vetoed steps into the host's counters (call with the streams joined: checkpoints, Trainer.synchronize users): a group's
+        step_count drops by the steps its guard vetoed and the records start again at zero, so that what is saved is what
+        torch.optim.Adam's state['step'] would hold.  (`sam_field` has two guards, one per head: the larger count is taken.)"""
+        rep = self.guard_report()
+        if not rep:
+            return
+        n = {d: r["veto"] + r["skipped"] for d, r in rep.items()}
+        heads = max([n.get(h, 0) for h in self.heads] or [0])
+        for g, k in (("fields", n.get("nerf", 0)), ("proposal_networks", n.get("nerf", 0)), ("sam_field", heads), ("conv", n.get("sam", 0))):
+            if g in self.opt.step_count and k:
+                self.opt.step_count[g] = max(self.opt.step_count[g] - k, 0)
+        for name, t in self.bufs.items():
+            if name.startswith("guard_"):
+                t.zero_()
+
+    def guard_report(self) -> Dict[str, Dict[str, int]]:
+        """{domain: {veto, skipped}} read from the device (synchronises): `skipped` = steps whose losses were inf / NaN so far (their
+        optimizer step did not happen and does not count), `veto` = the last judged step is one of them."""
+        out = {}
+        for name, t in self.bufs.items():
+            if name.startswith("guard_"):
+                v = t.cpu().tolist()
+                out[name[6:]] = {"veto": int(v[0]), "skipped": int(v[1])}
+        return out
 
     def _edge(self, src, dst, name: str) -> None:
         """dst waits for everything enqueued on src so far (no-op when they are the same stream)."""
@@ -303,7 +397,7 @@ class StepProgram:
             # the workspace holds x-pair records (self._f2_sort): their own backward entry, Adam of the levels >= n_sparse in its reduce
             oc = self.opt.config[group]["optimizer"]
             fused = ((L - n_sparse) << T) * F if fuse else 0
-            self._k(st, "snf_hashgrid_bwd_presorted_adam_xp", g, N, L, T, ld, col, nrun, gbuf, sorted_ws, stage, n_sparse if fuse else L,
+            self._kg(st, group, "snf_hashgrid_bwd_presorted_adam_xp", g, N, L, T, ld, col, nrun, gbuf, sorted_ws, stage, n_sparse if fuse else L,
                     p if fuse else None, m if fuse else None, v if fuse else None, 0.0, float(oc.betas[0]), float(oc.betas[1]),
                     float(oc.eps), 1, float(grad_scale), tag=tag,
                     units=float(N) * 8 * F * 4 * (L + (n_sparse if fuse else L)) + 24.0 * fused,
@@ -322,7 +416,7 @@ class StepProgram:
             fused = ((L - n_sparse) << T) * F if step_it else 0
             reach_params = int(rows.numel()) * F if step_it else 0
             left = (n_sparse - ns) if step_it else L  # levels whose gradient is written back
-            self._k(st, "snf_hashgrid_bwd_presorted_adam_sp", g, N, L, F, T, ld, col, nrun, gbuf, sorted_ws, stage,
+            self._kg(st, group, "snf_hashgrid_bwd_presorted_adam_sp", g, N, L, F, T, ld, col, nrun, gbuf, sorted_ws, stage,
                     n_sparse if step_it else L, p if step_it else None, m if step_it else None, v if step_it else None, 0.0,
                     float(oc.betas[0]), float(oc.betas[1]), float(oc.eps), 1, float(grad_scale), rows, start, ns, longest,
                     1 if step_it else 0, scratch, tag=tag,
@@ -340,7 +434,7 @@ class StepProgram:
             scratch = self.buf(f"fx_scratch_{id(enc)}_{run}", (64,), torch.int32)
             from_level = n_sparse if fuse else L
             fused = ((L - from_level) << T) * F
-            self._k(st, "snf_hashgrid_bwd_presorted_adam_fx", g, N, L, F, T, ld, col, nrun, gbuf, sorted_ws, stage, from_level,
+            self._kg(st, group, "snf_hashgrid_bwd_presorted_adam_fx", g, N, L, F, T, ld, col, nrun, gbuf, sorted_ws, stage, from_level,
                     p, m, v, 0.0, float(oc.betas[0]), float(oc.betas[1]), float(oc.eps), 1, float(grad_scale), scratch,
                     tag=tag, units=float(N) * 8 * F * 4 * (L + from_level) + 24.0 * fused,
                     dyn={("lr", group): 15, ("t", group): 19})
@@ -350,7 +444,7 @@ class StepProgram:
         if fuse:
             oc = self.opt.config[group]["optimizer"]
             fused = ((L - n_sparse) << T) * F
-            self._k(st, "snf_hashgrid_bwd_presorted_adam", g, N, L, F, T, ld, col, nrun, gbuf, sorted_ws, stage, n_sparse,
+            self._kg(st, group, "snf_hashgrid_bwd_presorted_adam", g, N, L, F, T, ld, col, nrun, gbuf, sorted_ws, stage, n_sparse,
                     p, m, v, 0.0, float(oc.betas[0]), float(oc.betas[1]), float(oc.eps), 1, float(grad_scale), tag=tag,
                     units=float(N) * 8 * F * 4 * (L + n_sparse) + 24.0 * fused, dyn={("lr", group): 15, ("t", group): 19})
             done.append(fused_range)
@@ -442,12 +536,12 @@ class StepProgram:
         for piece in self.opt.adam_pieces(group, lo, hi, done):
             if piece[0] == "dense":
                 x0, x1 = piece[1], piece[2]
-                self._k(st, "snf_adam_step", a.param[x0:x1], a.grad[x0:x1], a.exp_avg[x0:x1], a.exp_avg_sq[x0:x1], x1 - x0,
+                self._kg(st, group, "snf_adam_step", a.param[x0:x1], a.grad[x0:x1], a.exp_avg[x0:x1], a.exp_avg_sq[x0:x1], x1 - x0,
                         0.0, b1, b2, eps, 1, float(scale), 1, units=32.0 * (x1 - x0), dyn={("lr", group): 5, ("t", group): 9})
             else:
                 rows, F = piece[1], piece[2]
                 self._keep.append(rows)
-                self._k(st, "snf_adam_step_rows", a.param, a.grad, a.exp_avg, a.exp_avg_sq, rows, rows.numel(), int(F), 0.0,
+                self._kg(st, group, "snf_adam_step_rows", a.param, a.grad, a.exp_avg, a.exp_avg_sq, rows, rows.numel(), int(F), 0.0,
                         b1, b2, eps, 1, float(scale), 1, units=32.0 * rows.numel() * F, dyn={("lr", group): 7, ("t", group): 11})
 
     def _sparse_lists(self, enc, N: int, n_sparse: int):
@@ -683,6 +777,9 @@ class StepProgram:
         summary = b("loss_summary", (8,))
         self._k(main, "snf_nerf_loss_summary", mse_out, rows_i, float(cfg.interlevel_loss_mult) / float(R * S), rows_d,
                 1.0 / float(R), float(cfg.distortion_loss_mult), R, summary)
+        self._guard_update(main, "nerf", summary)
+        if STEP_GUARD and pre.stream_id != main.stream_id:  # (an Adam launch of this step on the prologue's stream reads the verdict)
+            self._py(self.event("guard_nerf_set").record, main)
         if xstep:
             self._py(self.event("losses_done").record, main)
         self._losses_mark = len(plan.entries)  # the proposal backward's inputs exist from here on
@@ -690,7 +787,9 @@ class StepProgram:
         # ================= feature heads: one task per head on its own stream =================
         for hname in self.heads:
             st = side[hname]
+            self._head_domain = hname
             self._head_task(st, hname, parity, with_opt, geo_ws)
+            self._head_domain = None
             if st.stream_id != main.stream_id:
                 self._py(self._mark_head_busy, st, parity, hname)
 
@@ -764,6 +863,8 @@ class StepProgram:
             if (updated and prop_st.stream_id == main.stream_id) or (not updated and prop_adam_when_idle):
                 # (a step without a proposal backward: zero gradients, the moments decay.  With the prologue on the side stream
                 # it goes there too -- the next prologue reads these parameters)
+                if STEP_GUARD and pre.stream_id != main.stream_id:
+                    self._py(pre.wait_event, self.event("guard_nerf_set"))
                 self._opt_step(pre, "proposal_networks", 0, opt.arenas["proposal_networks"].numel, done_p)
         if prop_block:
             ev_in, ev_out = self.event("prop_bwd_inputs"), self.event("prop_bwd_done")
@@ -907,6 +1008,7 @@ class StepProgram:
         weight = float(cfg.sam_loss_weight if hname == "sam" else cfg.clipseg_loss_weight)
         acc, out = b(f"mse_acc_{hname}", (516,), zero=True), b(f"mse_out_{hname}", (2,))
         self._k(st, "snf_rowmse_loss_fwd", pred, target, rows, Cp, weight, 1, acc, out)
+        self._guard_update(st, hname, out)
         # ---- backward
         one = b("one", (1,))
         dpred = b(f"{hname}_dpred", (rows, Cp))
@@ -1016,7 +1118,7 @@ class StepProgram:
                     units += float(NK) * 8 * 8 * 4 * (e.n_levels + left) + 24.0 * (((e.n_levels - f) << T) * 8)
                     if fuse and sp is not None:
                         units += 24.0 * 8 * int(sp[1].numel())
-                self._k(st, "snf_hashgrid_bwd_presorted_adam_pair", gy, self._off(gy, e0.n_levels * 8 * NK * 4), NK, e0.n_levels,
+                self._kg(st, "sam_field", "snf_hashgrid_bwd_presorted_adam_pair", gy, self._off(gy, e0.n_levels * 8 * NK * 4), NK, e0.n_levels,
                         e1.n_levels, T, tabs[0][1], tabs[1][1], geo_ws[ops._geometry_key(e0.scalings, e0.n_levels, T)],
                         geo_ws[ops._geometry_key(e1.scalings, e1.n_levels, T)], frm[0], frm[1], tabs[0][0], tabs[0][2], tabs[0][3],
                         tabs[1][0], tabs[1][2], tabs[1][3],

@@ -395,3 +395,149 @@ def test_rendered_head_path_against_the_oracle(grad_parity):
         assert abs(float(ld[k]) - float(v)) <= 1e-4 * max(1.0, abs(float(v))), k
     grads = named_grads(model)
     grad_parity(grads, {k: v.grad.numpy() for k, v in op.items() if v.grad is not None and k in grads})
+
+
+def _snapshot(trainer):
+    return {g: (a.param.clone(), a.exp_avg.clone(), a.exp_avg_sq.clone()) for g, a in trainer.optimizers.arenas.items()}
+
+
+def _head_slices(trainer):
+    """{head: (lo, hi)} element ranges of the two heads inside the `sam_field` arena."""
+    arena = trainer.optimizers.arenas["sam_field"]
+    names = list(arena.offsets)
+    out = {}
+    for h, (lo_i, hi_i) in trainer._head_param_ranges().items():
+        out[h] = (arena.offsets[names[lo_i]][0], arena.offsets[names[hi_i]][0] if hi_i < len(names) else arena.numel)
+    return out
+
+
+def test_non_finite_head_loss_vetoes_the_optimizer_step_of_that_head():
+    """trainer.py:419-437 / optimizers.py:138-149: GradScaler.step does not step an optimizer whose gradients hold an inf / NaN.
+    Here Adam is fused into the table backward, so the veto is a device record read by the optimizer-side kernels (snf_step_guard).
+    Every SAM target row NaN at step 2 (nanmean of no rows = NaN): parameters AND moments of the SAM head and of the conv head keep
+    their bits, everything else steps; the next step steps the SAM head again and the vetoed step does not count."""
+    tr = _trainer("samnerf_distill", True, 512, 13)
+    dm = tr.pipeline.datamanager
+    orig, poison = dm.next_train, {"step": -1}
+
+    def next_train(step):
+        rb, batch = orig(step)
+        if step == poison["step"]:
+            batch = dict(batch)
+            batch["sam"] = torch.full_like(batch["sam"], float("nan"))
+        return rb, batch
+
+    dm.next_train = next_train
+    _run(tr, 2)
+    assert tr._program is not None, tr._program_off
+    before = _snapshot(tr)
+    poison["step"] = 2
+    torch.manual_seed(5)
+    tr.train_iteration(2)
+    tr.synchronize()
+    torch.cuda.synchronize()
+    after = _snapshot(tr)
+    rep = tr._program.guard_report()
+    assert rep["sam"] == {"veto": 1, "skipped": 0} and rep["clipseg"]["veto"] == 0 and rep["nerf"]["veto"] == 0, rep
+    sl = _head_slices(tr)
+    lo, hi = sl["sam"]
+    for i in range(3):  # param, exp_avg, exp_avg_sq of the vetoed head and of the conv head: bit-identical
+        assert torch.equal(after["sam_field"][i][lo:hi], before["sam_field"][i][lo:hi]), i
+        assert torch.equal(after["conv"][i], before["conv"][i]), i
+    lo, hi = sl["clipseg"]
+    assert not torch.equal(after["sam_field"][0][lo:hi], before["sam_field"][0][lo:hi])
+    assert not torch.equal(after["fields"][0], before["fields"][0])
+    assert not torch.equal(after["proposal_networks"][0], before["proposal_networks"][0])
+    for g, a in tr.optimizers.arenas.items():
+        assert bool(torch.isfinite(a.param).all()) and bool(torch.isfinite(a.exp_avg).all()), g
+        assert float(a.grad.abs().max()) == 0.0, g  # the vetoed step's (NaN) gradients were cleared all the same
+    # the next step is a normal one: the head moves again, the record has counted the vetoed step
+    tr.train_iteration(3)
+    tr.synchronize()
+    torch.cuda.synchronize()
+    lo, hi = sl["sam"]
+    assert not torch.equal(tr.optimizers.arenas["sam_field"].param[lo:hi], after["sam_field"][0][lo:hi])
+    assert not torch.equal(tr.optimizers.arenas["conv"].param, after["conv"][0])
+    rep = tr._program.guard_report()
+    assert rep["sam"] == {"veto": 0, "skipped": 1}, rep
+    assert bool(torch.isfinite(tr.optimizers.arenas["sam_field"].param).all())
+    tr._program.fold_guards()
+    assert tr.optimizers.step_count["conv"] == 3 and tr.optimizers.step_count["fields"] == 4
+    assert tr._program.guard_report()["sam"] == {"veto": 0, "skipped": 0}
+
+
+def test_one_inf_weight_vetoes_the_nerf_groups():
+    """An inf in the colour net's first layer does NOT show in the loss (the neuron's pre-activation is NaN and fmaxf(NaN, 0) = 0), but
+    the gradients behind it are NaN (0 * inf) -- GradScaler would find them; here snf_guard_scan finds the weight.  `fields` and
+    `proposal_networks` keep parameters and moments (the table of 16.8 M parameters included: its Adam runs inside the backward
+    kernel); once the weight is finite again the groups step and the vetoed step has not counted."""
+    tr = _trainer("samnerf_no_distill", True, 512, 13)
+    _run(tr, 2)
+    w = tr.pipeline.model.field.mlp_head.weights()[0]
+    keep = w.detach().clone()
+    w.data.view(-1)[7] = float("inf")
+    before = _snapshot(tr)
+    torch.manual_seed(5)
+    tr.train_iteration(2)
+    tr.synchronize()
+    torch.cuda.synchronize()
+    after = _snapshot(tr)
+    assert tr._program.guard_report()["nerf"] == {"veto": 1, "skipped": 0}
+    for g in ("fields", "proposal_networks"):
+        for i in range(3):
+            assert torch.equal(after[g][i], before[g][i]), (g, i)
+        assert float(tr.optimizers.arenas[g].grad.abs().nan_to_num(1.0).max()) == 0.0, g
+    w.data.copy_(keep)
+    tr.train_iteration(3)
+    tr.synchronize()
+    torch.cuda.synchronize()
+    assert tr._program.guard_report()["nerf"] == {"veto": 0, "skipped": 1}
+    assert not torch.equal(tr.optimizers.arenas["fields"].param, after["fields"][0])
+    assert bool(torch.isfinite(tr.optimizers.arenas["fields"].param).all())
+
+
+def test_guarded_adam_skips_and_recounts():
+    """snf_adam_step under a bound guard: veto -> p / m / v untouched and g cleared; skipped = 1 at step 5 -> the update of an
+    unguarded step 4 (bias corrections from step - skipped); an all-zero record -> bit-identical to an unguarded launch."""
+    from samnerf_amd import _lib
+    lib = _lib.load()
+    n = 4096 + 3
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    p0, g0 = torch.randn(n, device="cuda", generator=gen), torch.randn(n, device="cuda", generator=gen)
+    m0, v0 = 0.1 * torch.randn(n, device="cuda", generator=gen), torch.rand(n, device="cuda", generator=gen)
+
+    def step(t, guard):
+        p, g, m, v = p0.clone(), g0.clone(), m0.clone(), v0.clone()
+        st = torch.cuda.current_stream().cuda_stream
+        lib.snf_step_guard(guard.data_ptr() if guard is not None else None)
+        rc = lib.snf_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), n, 1e-2, 0.9, 0.999, 1e-15, t, 1.0, 1, st)
+        lib.snf_step_guard(None)
+        assert rc == 0
+        torch.cuda.synchronize()
+        return p, g, m, v
+
+    plain5, plain4 = step(5, None), step(4, None)
+    clear = step(5, torch.zeros(2, dtype=torch.int32, device="cuda"))
+    for a, b in zip(clear, plain5):
+        assert torch.equal(a, b)
+    veto = step(5, torch.tensor([1, 0], dtype=torch.int32, device="cuda"))
+    assert torch.equal(veto[0], p0) and torch.equal(veto[2], m0) and torch.equal(veto[3], v0) and float(veto[1].abs().max()) == 0.0
+    late = step(5, torch.tensor([0, 1], dtype=torch.int32, device="cuda"))
+    assert torch.equal(late[2], plain4[2]) and torch.equal(late[3], plain4[3])
+    # (the device forms the bias corrections in fp32 where the host uses double: a few ulp of the parameter)
+    assert float((late[0] - plain4[0]).abs().max()) <= 1e-6 * float(p0.abs().max())
+    assert float((late[0] - plain5[0]).abs().max()) > 1e-4 * float((plain5[0] - p0).abs().max())
+    # snf_guard_update: commit, then judge
+    rec = torch.tensor([1, 2], dtype=torch.int32, device="cuda")
+    vals = torch.tensor([0.5, float("inf")], device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    assert lib.snf_guard_update(vals.data_ptr(), 2, rec.data_ptr(), st) == 0
+    assert rec.cpu().tolist() == [1, 3]
+    assert lib.snf_guard_update(vals.data_ptr(), 1, rec.data_ptr(), st) == 0
+    assert rec.cpu().tolist() == [0, 4]
+    big = torch.zeros(1 << 20, device="cuda")
+    assert lib.snf_guard_scan(big.data_ptr(), big.numel(), rec.data_ptr(), st) == 0
+    assert rec.cpu().tolist() == [0, 4]
+    big[777777] = float("nan")
+    assert lib.snf_guard_scan(big.data_ptr(), big.numel(), rec.data_ptr(), st) == 0
+    assert rec.cpu().tolist() == [1, 4]
