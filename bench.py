@@ -135,8 +135,10 @@ def build_trainer(w: dict, local_rank: int, world: int, seed: int = 0):
     return trainer
 
 
-def _cpu_baseline_worker(w: dict, budget_s: float, threads: int, seed: int) -> dict:
-    """One process of the CPU baseline: the oracle's fwd + bwd on its own R / 16 rays with `threads` torch threads."""
+def _cpu_baseline_worker(w: dict, budget_s: float, threads: int, seed: int, sync_dir: str = "") -> dict:
+    """One process of the CPU baseline: the oracle's fwd + bwd on its own R / 16 rays with `threads` torch threads.  With `sync_dir` the
+    worker reports `ready.<seed>` after its warm-up and starts its clock when the parent has written `go` (all workers warm: the timed
+    windows then overlap, every process is timed on a fully loaded host)."""
     from oracle import samnerf_oracle as O
     torch.set_num_threads(threads)
     distill = w["method"] == "samnerf_distill"
@@ -158,6 +160,11 @@ def _cpu_baseline_worker(w: dict, budget_s: float, threads: int, seed: int) -> d
     n_warm = 3  # 3 warm-up + up to 10 timed steps (page faults of the 0.9 GB tables, thread pool)
     for _ in range(n_warm):
         step()
+    if sync_dir:
+        open(os.path.join(sync_dir, f"ready.{seed}"), "w").close()
+        t_wait = time.perf_counter()
+        while not os.path.exists(os.path.join(sync_dir, "go")) and time.perf_counter() - t_wait < 600:
+            time.sleep(0.01)
     t0, n = time.perf_counter(), 0
     while True:
         step()
@@ -173,23 +180,36 @@ def cpu_baseline(w: dict, budget_s: float):
     CPU kernels stop scaling (and start thrashing) near 32 threads, so the host's hardware threads are used as cpu_count // 32
     processes of 32 threads (at most 8), each on its own rays, running concurrently; `value` is the sum of their rates."""
     import subprocess
+    import tempfile
     ncpu = os.cpu_count() or 1
     threads = min(ncpu, 32)
     procs = max(1, min(8, ncpu // 32))
     spec = json.dumps({k: w[k] for k in ("method", "R", "P", "S", "K", "patch")})
+    sync_dir = tempfile.mkdtemp(prefix="snf_cpu_baseline_")
     cmd = lambda i: [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", spec, "--cpu-baseline-seconds", str(budget_s),  # noqa: E731
-                     "--cpu-baseline-threads", str(threads), "--cpu-baseline-seed", str(i)]
+                     "--cpu-baseline-threads", str(threads), "--cpu-baseline-seed", str(i), "--cpu-baseline-sync", sync_dir]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
     env["HIP_VISIBLE_DEVICES"] = ""  # (the workers never touch the GPU)
     ps = [subprocess.Popen(cmd(i), stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=env, cwd=ROOT) for i in range(procs)]
+    # the workers' timed windows start together: when every live worker is warm (or after 10 minutes) the parent writes `go`
+    t_wait = time.perf_counter()
+    while time.perf_counter() - t_wait < 600:
+        live = [i for i, p_ in enumerate(ps) if p_.poll() is None]
+        if all(os.path.exists(os.path.join(sync_dir, f"ready.{i}")) for i in live):
+            break
+        time.sleep(0.05)
+    open(os.path.join(sync_dir, "go"), "w").close()
     res = []
     for p_ in ps:
         out_, _ = p_.communicate(timeout=60 * 30)
         lines = [l for l in out_.splitlines() if l.startswith("{")]
         if p_.returncode == 0 and lines:
             res.append(json.loads(lines[-1]))
+    failed = procs - len(res)
     if not res:  # (no worker came back: time one in-process, as before)
         res, procs = [_cpu_baseline_worker(w, budget_s, threads, 0)], 1
+    import shutil
+    shutil.rmtree(sync_dir, ignore_errors=True)
     try:  # SURVEY 8d: core count and CPU model of the box beside the number
         model = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
     except (OSError, StopIteration):
@@ -198,11 +218,12 @@ def cpu_baseline(w: dict, budget_s: float):
     used = sum(r["threads"] for r in res)
     r0 = res[0]
     return {"value": value, "unit": "ray-samples/s", "cores": used, "kind": "port", "cpu_model": model, "host_cores": ncpu,
-            "processes": len(res), "threads_per_process": r0["threads"],
+            "processes": len(res), "processes_failed": failed, "threads_per_process": r0["threads"],
             "per_process_ray_samples_per_s": [round(r["rays"] * w["S"] * r["steps"] / r["seconds"], 1) for r in res],
             "sample": f"{len(res)} concurrent processes x {r0['threads']} threads, each {r0['warmup']} warm-up + {r0['steps']} timed fwd+bwd "
                       f"steps of {r0['rays']} rays (the workload's R / 16) x {w['S']} samples (P={w['P']}, K={w['K']}), full-size fp32 "
-                      f"tables, no optimizer step, {max(r['seconds'] for r in res):.1f} s of timed CPU work per process; {used} of {ncpu} "
+                      f"tables, no optimizer step, timed windows started together (all processes warm), "
+                      f"{max(r['seconds'] for r in res):.1f} s of timed CPU work per process; {used} of {ncpu} "
                       f"hardware threads (one torch process stops scaling near 32 threads: the host is filled with processes instead)"}
 
 
@@ -496,10 +517,11 @@ def main():
     ap.add_argument("--cpu-baseline-worker", default=None, help=argparse.SUPPRESS)   # (internal: one process of cpu_baseline)
     ap.add_argument("--cpu-baseline-threads", type=int, default=32, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-baseline-seed", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-baseline-sync", default="", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_worker:
         print(json.dumps(_cpu_baseline_worker(json.loads(args.cpu_baseline_worker), args.cpu_baseline_seconds, args.cpu_baseline_threads,
-                                              args.cpu_baseline_seed)))
+                                              args.cpu_baseline_seed, args.cpu_baseline_sync)))
         return
     w = dict(WORKLOADS[args.workload])
     if os.environ.get("SNF_ABLATE_SKIP") and not args.allow_ablation:
@@ -528,6 +550,10 @@ def main():
     # SNF_BENCH_DEVICE: ranks sharing one device (tests/test_model_gpu.py runs two gloo ranks on a 1-GPU box)
     local_rank = int(os.environ.get("SNF_BENCH_DEVICE", local_rank))
     torch.cuda.set_device(local_rank)
+    if os.environ.get("SNF_BENCH_MAIN_STREAM", "0") == "1":
+        # probe: the step's main stream is torch's current stream, by default the legacy NULL stream, against which every
+        # BLOCKING stream (hipExtStreamCreateWithCUMask makes only those) synchronises implicitly; 1 = run everything on a stream of our own
+        torch.cuda.set_stream(torch.cuda.Stream())
     if os.environ.get("SNF_ADAM_LAUNCH"):  # tuning: "max_blocks,threads,unroll"
         from samnerf_amd import _lib
         assert _lib.load().snf_set_adam_launch(*(int(x) for x in os.environ["SNF_ADAM_LAUNCH"].split(","))) == 0
@@ -537,14 +563,18 @@ def main():
     mode_timeout = float(os.environ.get("SNF_BENCH_MODE_TIMEOUT", "60"))   # watchdog per exchange mode's timed steps ...
     build_timeout = float(os.environ.get("SNF_BENCH_BUILD_TIMEOUT", "600"))  # ... and for building + warming a trainer
     failures = {}
+    counts = {"updated": 0}  # steps of the last timed() call whose proposal network received a gradient (ray_samplers.py:586-591)
 
     def timed(trainer, first_step: int, nsteps: int, mode: str = ""):
         """EXACTLY nsteps train iterations between barrier + synchronize on both sides; max over the ranks."""
         ctl.barrier()
         torch.cuda.synchronize()
+        ps = trainer.pipeline.model.proposal_sampler
+        counts["updated"] = 0
         t0 = time.perf_counter()
         for i in range(nsteps):
             trainer.train_iteration(first_step + i)
+            counts["updated"] += 1 if getattr(ps, "last_updated", True) else 0  # (a host flag: no device access)
         if mode:
             _inject(mode, rank)
         torch.cuda.synchronize()
@@ -595,7 +625,8 @@ def main():
             hung = True  # a rank threw or hung inside collectives: ranks are out of step, nothing more runs on this communicator
             continue
         st = args.warmup + args.steps
-        exchange_modes[mode] = {"ms_per_step": round(el / args.steps * 1e3, 4), "value": world * w["R"] * w["S"] * args.steps / el}
+        exchange_modes[mode] = {"ms_per_step": round(el / args.steps * 1e3, 4), "value": world * w["R"] * w["S"] * args.steps / el,
+                                "proposal_update_steps": counts["updated"]}
         built[mode] = (tr, st, el)
 
     def emit(out: dict, code: int) -> None:
@@ -608,12 +639,21 @@ def main():
         R, S, K = w["R"], w["S"], w["K"]
         ms = elapsed / args.steps * 1e3 if elapsed else None
         feat = K * 12288 if w["method"] == "samnerf_distill" else 0
-        b_step = 3 * (w["P"] * 320 + S * 1024 + feat) * R
+        # B_step = 3 B_f - 2 P g_prop [proposal under no_grad]: the proposal grid's backward bytes only count on the steps
+        # where the sampler's `updated` gate let its gradient through (`proposal_update_steps` of the timed region)
+        n_upd = exchange_modes.get(chosen, {}).get("proposal_update_steps", args.steps) if chosen else args.steps
+        b_step = 3 * (w["P"] * 320 + S * 1024 + feat) * R - 2 * w["P"] * 320 * R * (1.0 - n_upd / max(args.steps, 1))
+        prog = getattr(built[chosen][0], "_program", None) if chosen in built else None
         return {
             "metric": "ray-samples/sec (train step, samnerf_distill 256-d feat head)",
             "value": (world * R * S * args.steps / elapsed) if elapsed else None, "unit": "ray-samples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "dtype_detail": "fp32 tables, activations, gradients, Adam state and accumulators; products of the layers >= 64 wide on "
+                            "v_mfma_f32_32x32x16_bf16 with hi/lo(/mid) bf16 operand splits (3 products per fp32 MAC in the backward and "
+                            "the heads, 6 in the field nets' forward), fp32 accumulate (SNF_GEMM_MODE=1)",
+            "data": "synthetic",
+            "schedule": prog.schedule_info() if prog is not None else None,
             "config": {"workload": f"{w['method']} R={R} rays/GPU x S={S} fine samples, P={w['P']} proposal samples, "
                                    f"K={K} feature samples, patch {w['patch']}, SAM 256-d"
                                    + (" + ClipSeg 192-d heads" if w["method"] == "samnerf_distill" else "")
@@ -623,6 +663,7 @@ def main():
             "feature_samples_per_s": (world * R * K * args.steps / elapsed) if elapsed else None,
             "step_algorithmic_GBps": (b_step / (ms * 1e-3) / 1e9) if elapsed else None,
             "step_frac_of_hbm_peak": (b_step / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if elapsed else None,
+            "step_algorithmic_bytes": b_step, "proposal_update_steps": n_upd,
             "untimed_steps_before_timed_region": {"warmup": args.warmup},
             "rccl": {"backend": (dist.get_backend() if multi else None), "ranks": world, "collectives_on": bool(multi),
                      "exchange": chosen if multi else None, "exchange_modes_timed": exchange_modes,

@@ -100,6 +100,8 @@ RECORD_EXCHANGE = True
 # geo columns' gradient only ([N, 16] instead of [N, 32]).  Needs the recomputing fused backward (gemm mode 1).
 FUSED_SH_INPUT = _os.environ.get("SNF_FUSED_SH_INPUT", "1") == "1"
 FUSED_DENSITY = _os.environ.get("SNF_FUSED_DENSITY", "1") == "1"  # trunc_exp of the base net's output 0 in its epilogue
+# steps without a proposal update: the proposal stage's forward as ONE launch (no encoding / hidden activations stored for a backward)
+FUSED_PROP_FWD = _os.environ.get("SNF_FUSED_PROP_FWD", "1") == "1"
 # Non-finite-gradient guard (trainer.py:419-437, optimizers.py:138-149: GradScaler.step skips an optimizer whose gradients hold an inf / NaN).
 # Adam is fused into the table backward here, so a poisoned step cannot be vetoed afterwards: each group of losses owns a device record
 # {veto, skipped} (include/samnerf_hip.h, snf_step_guard) -- written behind its loss kernels by snf_guard_update, read by every
@@ -662,14 +664,21 @@ class StepProgram:
             self._k(sort_st, self._f2_sort(PF, N0, PL, PT), u0, penc.scalings, N0, PL, PT, ws_p, ws_p_bytes, tag=f"L{PL}")
             if sort_st.stream_id != main.stream_id:
                 self._py(self.event("prop_sorted").record, sort_st)
-        enc0 = b("enc0", (N0, PL * PF))
-        self._k(pre, "snf_hashgrid_fwd", u0, penc.params, penc.scalings, N0, PL, PF, PT, enc0, PL * PF, 0, tag=f"F{PF}L{PL}")
         I0, H0 = pnet.n_input_dims, pw0.shape[0]
-        hid0 = b("hid0", (N0, H0)) if updated else None
-        raw0 = b("raw0", (N0, 1))
-        self._k(pre, "snf_mlp_tiny_fwd", enc0, I0, pw0, pw1, I0, H0, N0, hid0, raw0, tag=f"{I0}x{H0}x1")
         dens0 = b("dens0", (N0,))
-        self._k(pre, "snf_trunc_exp_fwd", raw0, 1, sel0, N0, dens0)
+        if (not updated) and FUSED_PROP_FWD and PL == 5 and PF == 2 and H0 == 16 and I0 == 10 and pw1.shape[0] == 1:
+            # a step whose proposal network receives no gradient (ray_samplers.py:586-591: the `updated` gate) needs neither the
+            # [N, 10] encoding nor the hidden activations: grid + density net + trunc_exp per sample in registers, one launch
+            # (snf_prop_density_fwd, the eval render's proposal stage: bit-identical densities)
+            self._k(pre, "snf_prop_density_fwd", u0, penc.params, penc.scalings, N0, PL, PF, PT, pw0, pw1, H0, sel0, dens0,
+                    tag=f"F{PF}L{PL}")
+        else:
+            enc0 = b("enc0", (N0, PL * PF))
+            self._k(pre, "snf_hashgrid_fwd", u0, penc.params, penc.scalings, N0, PL, PF, PT, enc0, PL * PF, 0, tag=f"F{PF}L{PL}")
+            hid0 = b("hid0", (N0, H0)) if updated else None
+            raw0 = b("raw0", (N0, 1))
+            self._k(pre, "snf_mlp_tiny_fwd", enc0, I0, pw0, pw1, I0, H0, N0, hid0, raw0, tag=f"{I0}x{H0}x1")
+            self._k(pre, "snf_trunc_exp_fwd", raw0, 1, sel0, N0, dens0)
         w0 = b("w0", (R, P))
         self._k(pre, "snf_weights_fwd", dens0, 1, 1, None, eb0, R, P, w0, None)
         sb1, eb1 = b("sb1", (R, S + 1), parity=pp), b("eb1", (R, S + 1), parity=pp)
@@ -1293,6 +1302,19 @@ class StepProgram:
         if self.heads and not (overlap and tr.pipeline_steps):
             loss = loss + sum(loss_dict[tr.HEAD_LOSS[h]] for h in self.heads)
         return loss, loss_dict, metrics_dict
+
+    def schedule_info(self) -> Dict[str, object]:
+        """What ran, for the bench line: HIP streams the recorded launches of a step go to, whether the heads' weight gradients have
+        the shared fourth stream (one rank only: many ranks leave that hardware queue to RCCL), launches per step, the guard."""
+        plan = max(self.plans.values(), key=lambda p: len(p.entries)) if self.plans else None
+        if plan is None:
+            return {}
+        kern = [e for e in plan.entries if e[0] == _KERNEL]
+        return {"streams": len({e[5].stream_id for e in kern}),
+                "wgrad_stream": bool(WGRAD_STREAM and self.heads and not self.multi and self.tr.overlap),
+                "launches_per_step": len(kern), "launches_on_main_stream": sum(1 for e in kern if e[5].stream_id == self.main.stream_id),
+                "pipeline_steps": bool(getattr(self.tr, "pipeline_steps", False)), "step_guard": bool(STEP_GUARD),
+                "ranks": self.world}
 
     def join_side_streams(self) -> None:
         """Order the main stream after everything the schedule has put on its own side stream (the forward-time sorts and,
