@@ -241,10 +241,16 @@ class StepProgram:
         if CU_ROUTE and self._overlap:
             cus = next((c for k, c in CU_ROUTE if k in key_), None)
             if cus is not None:  # this launch runs on `cus` CUs, between two event edges against its task stream
-                st = (ops.priority_stream(int(cus[1:]), ops.stream_name(task_st)) if cus.startswith("p")
-                      else ops.masked_stream(int(cus), ops.stream_name(task_st)))
+                if cus.startswith("lane"):  # `key=lane<name>`: ONE shared stream for every routed launch of every task (a lane by kernel type)
+                    st = ops.make_stream(cus)
+                else:
+                    st = (ops.priority_stream(int(cus[1:]), ops.stream_name(task_st)) if cus.startswith("p")
+                          else ops.masked_stream(int(cus), ops.stream_name(task_st)))
                 self._route_n = getattr(self, "_route_n", 0) + 1
-                self._edge(task_st, st, f"cu_route_in_{self._route_n}")
+                if st.stream_id == task_st.stream_id:
+                    st = task_st
+                else:
+                    self._edge(task_st, st, f"cu_route_in_{self._route_n}")
         a.append(st.cuda_stream)
         self._plan.entries.append([_KERNEL, fn, a, key_, units, st])
         for key, idx in (dyn or {}).items():
