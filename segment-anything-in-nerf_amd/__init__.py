@@ -6,10 +6,7 @@ registers this package under that name).  The package needs libsamnerf_hip.so (b
 """
 __version__ = "0.1.0"
 
-import os as _os
-
-# One process per GPU over RCCL: the host driver of the MI355X boxes supports dmabuf IPC only; the HIP runtime reads this when it
-# starts (first device call), so the default is set as early as the package can (an explicit value in the environment wins).
-_os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-
+# (Importing the package does not touch the process environment.  One process per GPU over RCCL needs HSA_ENABLE_IPC_MODE_LEGACY=0 on
+#  the MI355X hosts -- dmabuf IPC only: `distributed.init_distributed` sets that default before its first device call and warns when the
+#  HIP runtime was already up without it; launchers (bench.py) set it before importing torch.)
 from . import _lib  # noqa: F401

@@ -563,10 +563,13 @@ __device__ __forceinline__ void chain_sh_load_bf(const float* __restrict__ Hb, i
     const long long r = sh.log2S >= 0 ? (s >> sh.log2S) : s / sh.S;
     const float* pr = Hb + s * ldh;
     const float* pd = bf.one_ray ? pr : sh.dirs + r * 3 - ((r == bf.n_rays - 1) ? 1 : 0);
+    // (the direction window starts at a 12-byte stride: a 16-byte load of a 4-byte-aligned address -- legal for global_load_dwordx4 on
+    //  gfx9, and typed as such so that the compiler does not assume 16-byte alignment; N = R * S at both entry points keeps it in bounds)
+    typedef float mc_f4a4 __attribute__((ext_vector_type(4), aligned(4)));
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const float* pq = half ? pr + 4 * q : pd;
-        const float4 v = *reinterpret_cast<const float4*>(pq);
+        const mc_f4a4 v = *reinterpret_cast<const mc_f4a4*>(pq);
         xo[4 * q] = v.x; xo[4 * q + 1] = v.y; xo[4 * q + 2] = v.z; xo[4 * q + 3] = v.w;
     }
 }

@@ -34,9 +34,16 @@ def init_distributed(backend: Optional[str] = None) -> tuple:
     """Initialise torch.distributed from the torchrun environment; returns (rank, local_rank, world_size)."""
     rank, local_rank, world = env_world()
     if (world > 1 or (_force() and "RANK" in os.environ)) and not dist.is_initialized():
-        # dmabuf IPC only on these hosts (RCCL's `hipIpcGetMemHandle: invalid argument` otherwise).  The package sets the same default
-        # at import time, which is before the HIP runtime starts; here it still reaches RCCL's own start-up and child processes.
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # dmabuf IPC only on these hosts (RCCL's `hipIpcGetMemHandle: invalid argument` otherwise).  The HIP runtime reads the variable
+        # when it starts (first device call): this is THE place the default is set -- before `set_device` below -- and a process whose
+        # runtime is already up without it is told so (the variable then only reaches RCCL's own start-up and child processes).
+        if "HSA_ENABLE_IPC_MODE_LEGACY" not in os.environ:
+            if torch.cuda.is_available() and torch.cuda.is_initialized():
+                import warnings
+                warnings.warn("HSA_ENABLE_IPC_MODE_LEGACY was not set when the HIP runtime started: multi-process GPU work on this host "
+                              "needs HSA_ENABLE_IPC_MODE_LEGACY=0 in the environment BEFORE the first device call (RCCL otherwise fails "
+                              "with `hipIpcGetMemHandle: invalid argument`)", RuntimeWarning, stacklevel=2)
+            os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:  # SNF_DIST_BACKEND=gloo: CPU collectives with device tensors staged through the host (tests)

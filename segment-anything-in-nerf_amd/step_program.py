@@ -110,7 +110,13 @@ FUSED_PROP_FWD = _os.environ.get("SNF_FUSED_PROP_FWD", "1") == "1"
 # reference has ONE optimizer for both heads; a guard per head keeps the two head streams independent (a shared verdict would make
 # each head's table backward wait for the other head's loss).  The host never reads a record inside a step: `opt.step_count` counts
 # optimistically and the kernels subtract `skipped` on the device; `StepProgram.guard_report()` reads them (synchronising).
-STEP_GUARD = _os.environ.get("SNF_STEP_GUARD", "1") == "1"
+# Many ranks: the verdict has to be the same on every rank (one rank's NaN reaches all of them through the gradient exchange), which costs
+# three 4-byte MAX-all-reduces per step, each issued where its loss is ready -- on torch's one RCCL stream they queue in host order between
+# the step's real collectives, and a verdict whose loss comes late (the SAM head's) would hold the collectives issued after it.  That has
+# never been measured on real links, so the guard is ON for one rank and OPT-IN for many (SNF_STEP_GUARD=all); 0 records no guard at all.
+_SG = _os.environ.get("SNF_STEP_GUARD", "1")
+STEP_GUARD = _SG in ("1", "all")
+STEP_GUARD_MULTI = _SG == "all"
 
 
 # SNF_ABLATE_SKIP="key,key": launches whose key contains one of these are NOT issued (results are garbage; timing probe only)
@@ -263,7 +269,7 @@ class StepProgram:
 
     # -- the non-finite-gradient guard (STEP_GUARD above) ----------------------------------------------------------------------
     def _guard(self, domain: str) -> Optional[torch.Tensor]:
-        if not STEP_GUARD:
+        if not STEP_GUARD or (self.multi and not STEP_GUARD_MULTI):
             return None
         return self.buf(f"guard_{domain}", (2,), torch.int32, zero=True)
 
@@ -793,7 +799,7 @@ class StepProgram:
         self._k(main, "snf_nerf_loss_summary", mse_out, rows_i, float(cfg.interlevel_loss_mult) / float(R * S), rows_d,
                 1.0 / float(R), float(cfg.distortion_loss_mult), R, summary)
         self._guard_update(main, "nerf", summary)
-        if STEP_GUARD and pre.stream_id != main.stream_id:  # (an Adam launch of this step on the prologue's stream reads the verdict)
+        if self._guard("nerf") is not None and pre.stream_id != main.stream_id:  # (an Adam launch of this step on the prologue's stream reads the verdict)
             self._py(self.event("guard_nerf_set").record, main)
         if xstep:
             self._py(self.event("losses_done").record, main)
@@ -878,7 +884,7 @@ class StepProgram:
             if (updated and prop_st.stream_id == main.stream_id) or (not updated and prop_adam_when_idle):
                 # (a step without a proposal backward: zero gradients, the moments decay.  With the prologue on the side stream
                 # it goes there too -- the next prologue reads these parameters)
-                if STEP_GUARD and pre.stream_id != main.stream_id:
+                if self._guard("nerf") is not None and pre.stream_id != main.stream_id:
                     self._py(pre.wait_event, self.event("guard_nerf_set"))
                 self._opt_step(pre, "proposal_networks", 0, opt.arenas["proposal_networks"].numel, done_p)
         if prop_block:
@@ -1319,7 +1325,7 @@ class StepProgram:
         return {"streams": len({e[5].stream_id for e in kern}),
                 "wgrad_stream": bool(WGRAD_STREAM and self.heads and not self.multi and self.tr.overlap),
                 "launches_per_step": len(kern), "launches_on_main_stream": sum(1 for e in kern if e[5].stream_id == self.main.stream_id),
-                "pipeline_steps": bool(getattr(self.tr, "pipeline_steps", False)), "step_guard": bool(STEP_GUARD),
+                "pipeline_steps": bool(getattr(self.tr, "pipeline_steps", False)), "step_guard": self._guard("nerf") is not None,
                 "ranks": self.world}
 
     def join_side_streams(self) -> None:
