@@ -414,7 +414,9 @@ constexpr int HG_SAMPLE_BITS = 21;  // N <= 2^21 per launch (row_in_bucket needs
 // counting-sorted by bucket in LDS and leaves as one contiguous run per bucket (~128 B at 256 buckets) instead of 8-byte
 // stores to 256 different cache lines -- the store-transaction count, not the byte count, bounded the direct version
 // (rocprofv3: 84 % of its wave cycles were issue stalls behind the store queue).
+#ifndef SNF_HG_SB_SPT
 #define SNF_HG_SB_SPT 2
+#endif
 constexpr int HG_SB_SPT = SNF_HG_SB_SPT;          // samples per thread per batch (1: 64-B runs, 7 workgroups per CU; 4: 256-B runs, 1)
 constexpr int HG_SB_REC = 256 * HG_SB_SPT * 8;    // 4096 staged records (32 KB)
 
@@ -593,7 +595,11 @@ __global__ __launch_bounds__(256) void k_hg_scatter(const float* __restrict__ u,
 // (not their active lanes: sharing a gather between the lanes of a pair gained nothing), and the scatter ranks and stages half
 // as many records for the same bytes.  A pair that straddles two buckets leaves as two a-only records.  The level's record region
 // holds 8 N records in the worst case (every pair split), as before -- 16 bytes each here.
-constexpr int HG_XP_CAP = 256 * HG_SB_SPT * 4 + 256;  // records staged per batch (4 per sample, + room for split pairs); the rest go direct
+#ifndef SNF_HG_XP_SPT
+#define SNF_HG_XP_SPT SNF_HG_SB_SPT
+#endif
+constexpr int HG_XP_SPT = SNF_HG_XP_SPT;  // samples per thread per batch of the x-pair scatter (A/B: its own switch)
+constexpr int HG_XP_CAP = 256 * HG_XP_SPT * 4 + 256;  // records staged per batch (4 per sample, + room for split pairs); the rest go direct
 
 inline size_t hg_scatter_xp_lds_bytes(int log2B) {
     return ((size_t)3 << log2B) * sizeof(uint32_t) + (size_t)HG_XP_CAP * (sizeof(uint4) + sizeof(uint16_t));
@@ -664,8 +670,8 @@ __global__ __launch_bounds__(256) void k_hg_scatter_xp(const float* __restrict__
     __syncthreads();
     const uint32_t mask = (1u << log2_T) - 1u, rmask = (1u << log2rpb) - 1u;
     const float s = scalings[l];
-    constexpr int NP = HG_SB_SPT * 4;  // pairs per thread and batch
-    for (int j0 = 0; j0 < spt; j0 += HG_SB_SPT) {
+    constexpr int NP = HG_XP_SPT * 4;  // pairs per thread and batch
+    for (int j0 = 0; j0 < spt; j0 += HG_XP_SPT) {
         // ---- 1: pair records of this batch, ranked within their bucket (a split pair ranks its b corner in b's bucket too)
         uint4 rec[NP];
         uint32_t bka[NP], rka[NP], rkb[NP / 2];  // (rkb: two 16-bit ranks per word; only read for split pairs)
@@ -673,7 +679,7 @@ __global__ __launch_bounds__(256) void k_hg_scatter_xp(const float* __restrict__
 #pragma unroll
         for (int q = 0; q < NP / 2; ++q) rkb[q] = 0u;
 #pragma unroll
-        for (int jj = 0; jj < HG_SB_SPT; ++jj) {
+        for (int jj = 0; jj < HG_XP_SPT; ++jj) {
             const int j = j0 + jj;
             const int n = (blk * spt + j) * 256 + tid;
             const bool live = (j < spt) && (n < N);
