@@ -761,6 +761,19 @@ def test_two_ranks_on_one_gpu_match_accumulated_single_process(tmp_path, static)
             assert float(d.max()) <= (1e-2 if static else 2e-3) * max(float(a[k].abs().max()), 1e-30), (k, float(d.max()))
 
 
+def test_two_ranks_with_the_step_guard_agree_on_the_verdict(tmp_path, monkeypatch):
+    """SNF_STEP_GUARD=all: on many ranks the guard's veto word is MAX-all-reduced behind snf_guard_update (three 4-byte collectives per
+    step, recorded into the schedule on the streams of their losses).  With finite losses the guarded two-rank step must give the
+    unguarded result: exp_avg = 0.1 x mean gradient after one step, every gradient slot re-zeroed."""
+    monkeypatch.setenv("SNF_STEP_GUARD", "all")
+    a, b = _run_two_rank(tmp_path, 1, True)
+    for k in [k for k in a if k.endswith(".exp_avg")]:
+        scale = float(a[k].abs().max())
+        assert scale > 0 and float((a[k] - b[k]).abs().max()) <= 1e-5 * scale, (k, scale, float((a[k] - b[k]).abs().max()))
+    for k in [k for k in b if k.endswith(".grad")]:
+        assert float(b[k].abs().max()) == 0.0, k
+
+
 def test_eight_ranks_on_one_gpu_match_accumulated_single_process(tmp_path):
     """The world size of BASELINE configs[3] / [4]: EIGHT ranks (sharing the box's one GPU, gloo with host staging) through the
     static schedule -- 24 feature slabs / 8 ranks = 3 (grid, level) slabs per rank and head, so a rank's run straddles the two
