@@ -168,7 +168,13 @@ __global__ __launch_bounds__(256, SNF_B3_ROWS_WAVES) void k_gemm_rows_b3(const f
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
     const int a_kq = tid & 7, a_r = tid >> 3;  // 8 k-quads x 32 rows (A: 4 passes, B^T: NB passes)
     constexpr int BQ = BN / 4;                  // B as [K, Nc]: BQ col-quads x (256 / BQ) k rows per pass, NB passes
-    const int b_jq = tid % BQ, b_k = tid / BQ;
+    // B as [K, Nc] is transposed while it is staged.  A thread takes the k PAIR b_kp (rows 2 b_kp, 2 b_kp + 1 of the 32-k tile) of column
+    // quad b_jq2 (+ 16 per pass) and writes one packed (k, k+1) 32-bit word per column and plane: the 16 k-pairs of a quarter-wave are 16
+    // consecutive LDS words and the wave's four column quads start 80 words apart (16 banks): conflict-free.  (Until round 6: one k row x
+    // four columns per thread as 16-bit stores 80 B apart across the lanes -- four banks for 32 lanes, 85 % of the kernel's LDS cycles were
+    // bank conflicts, profiles/r06_step_counters.txt.)
+    static_assert(BT || (NB % 2 == 0 && BQ % 16 == 0), "the transposing stage takes 16 column quads per pass");
+    const int b_kp = tid & 15, b_jq2 = tid >> 4;
     float4 av[4], bv[NB];
     // `fetch` only issues loads at clamped (row, k): out-of-range quads are zeroed when the tile is STAGED, a trip later.  (The loaders
     // zero right behind the load -- a select that needs the data: the wait for the NEXT tile's operands then stood in front of THIS
@@ -186,8 +192,11 @@ __global__ __launch_bounds__(256, SNF_B3_ROWS_WAVES) void k_gemm_rows_b3(const f
 #pragma unroll
             for (int p = 0; p < NB; ++p) bv[p] = ldq(B, col0 + a_r + 32 * p, k0 + a_kq * 4, Nc, K, ldb);
         } else {
+            // (thread = k-pair b_kp x column quad b_jq2: two consecutive k rows of four columns per pass, see the staging below)
 #pragma unroll
-            for (int p = 0; p < NB; ++p) bv[p] = ldq(B, k0 + b_k + (256 / BQ) * p, col0 + b_jq * 4, K, Nc, ldb);
+            for (int p = 0; p < NB / 2; ++p)
+#pragma unroll
+                for (int r = 0; r < 2; ++r) bv[2 * p + r] = ldq(B, k0 + 2 * b_kp + r, col0 + (b_jq2 + 16 * p) * 4, K, Nc, ldb);
         }
     };
     fetch(0);
@@ -202,7 +211,8 @@ __global__ __launch_bounds__(256, SNF_B3_ROWS_WAVES) void k_gemm_rows_b3(const f
             }
 #pragma unroll
             for (int p = 0; p < NB; ++p) {
-                const bool ok = BT ? (col0 + a_r + 32 * p < Nc && k0 + a_kq * 4 < K) : (k0 + b_k + (256 / BQ) * p < K && col0 + b_jq * 4 < Nc);
+                const bool ok = BT ? (col0 + a_r + 32 * p < Nc && k0 + a_kq * 4 < K)
+                                   : (k0 + 2 * b_kp + (p & 1) < K && col0 + (b_jq2 + 16 * (p >> 1)) * 4 < Nc);
                 if (!ok) bv[p] = z4;
             }
         }
@@ -226,15 +236,17 @@ __global__ __launch_bounds__(256, SNF_B3_ROWS_WAVES) void k_gemm_rows_b3(const f
         } else {
             // transpose while staging: W[k][j..j+3] -> B planes [j][k]
 #pragma unroll
-            for (int p = 0; p < NB; ++p) {
-                const int kk = b_k + (256 / BQ) * p;
-                const float e[4] = {bv[p].x, bv[p].y, bv[p].z, bv[p].w};
+            for (int p = 0; p < NB / 2; ++p) {
+                const float e0[4] = {bv[2 * p].x, bv[2 * p].y, bv[2 * p].z, bv[2 * p].w};
+                const float e1[4] = {bv[2 * p + 1].x, bv[2 * p + 1].y, bv[2 * p + 1].z, bv[2 * p + 1].w};
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    uint32_t h, l;
-                    split_bf16(e[q], h, l);
-                    Bh[(b_jq * 4 + q) * B3_PITCH + kk] = (uint16_t)h;
-                    Bl[(b_jq * 4 + q) * B3_PITCH + kk] = (uint16_t)l;
+                    uint32_t h0, l0, h1, l1;
+                    split_bf16(e0[q], h0, l0);
+                    split_bf16(e1[q], h1, l1);
+                    const int off = ((b_jq2 + 16 * p) * 4 + q) * B3_PITCH + 2 * b_kp;
+                    *reinterpret_cast<uint32_t*>(&Bh[off]) = (h0 & 0xFFFFu) | (h1 << 16);
+                    *reinterpret_cast<uint32_t*>(&Bl[off]) = (l0 & 0xFFFFu) | (l1 << 16);
                 }
             }
         }
