@@ -379,15 +379,20 @@ __global__ __launch_bounds__(256) void k_gemm_wgrad_b3(const float* __restrict__
             }
             const float a0[4] = {av[0].x, av[0].y, av[0].z, av[0].w}, a1[4] = {av[1].x, av[1].y, av[1].z, av[1].w};
             const float b0[4] = {bv[0].x, bv[0].y, bv[0].z, bv[0].w}, b1[4] = {bv[1].x, bv[1].y, bv[1].z, bv[1].w};
+            // The 8-k chunks of a plane row sit XOR-swizzled by (row >> 4) & 3: the 16 column quads of a store instruction are rows
+            // 80 words apart (16 banks), i.e. FOUR banks for sixteen lanes in the plain layout (77 % of this kernel's LDS cycles were
+            // bank conflicts, profiles/r06_step_counters.txt); with the swizzle the quads q, q + 4, q + 8, q + 12 land in different
+            // chunks -- 64 lanes, 64 banks.  The fragment reads below apply the same XOR (the 16 lanes of a read group share row >> 4).
+            const int wsw = ((kp >> 2) ^ ((q >> 2) & 3)) * 8 + 2 * (kp & 3);  // element offset of this thread's (k, k + 1) pair in its rows
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 uint32_t h, l;
                 split2(a0[c], a1[c], h, l);  // rows (2kp, 2kp+1) of column o0 + 4q + c -> k positions (2kp, 2kp+1)
-                *reinterpret_cast<uint32_t*>(&Ah[(q * 4 + c) * B3_PITCH + 2 * kp]) = h;
-                *reinterpret_cast<uint32_t*>(&Al[(q * 4 + c) * B3_PITCH + 2 * kp]) = l;
+                *reinterpret_cast<uint32_t*>(&Ah[(q * 4 + c) * B3_PITCH + wsw]) = h;
+                *reinterpret_cast<uint32_t*>(&Al[(q * 4 + c) * B3_PITCH + wsw]) = l;
                 split2(b0[c], b1[c], h, l);
-                *reinterpret_cast<uint32_t*>(&Bh[(q * 4 + c) * B3_PITCH + 2 * kp]) = h;
-                *reinterpret_cast<uint32_t*>(&Bl[(q * 4 + c) * B3_PITCH + 2 * kp]) = l;
+                *reinterpret_cast<uint32_t*>(&Bh[(q * 4 + c) * B3_PITCH + wsw]) = h;
+                *reinterpret_cast<uint32_t*>(&Bl[(q * 4 + c) * B3_PITCH + wsw]) = l;
                 bsum[c] += a0[c] + a1[c];
             }
         }
@@ -395,11 +400,11 @@ __global__ __launch_bounds__(256) void k_gemm_wgrad_b3(const float* __restrict__
         if (AM >= 0 || n0 + B3_BK < n_end) fetch(n0 + B3_BK);  // (AM >= 0: unconditional, rows clamped -- past the end the last row again)
 #pragma unroll
         for (int ks = 0; ks < B3_BK / 16; ++ks) {
-            const int ko = ks * 16 + half * 8;
-            const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&Ah[(wm * 32 + li) * B3_PITCH + ko]);
-            const bf16x8 al = *reinterpret_cast<const bf16x8*>(&Al[(wm * 32 + li) * B3_PITCH + ko]);
-            const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&Bh[(wn * 32 + li) * B3_PITCH + ko]);
-            const bf16x8 bl = *reinterpret_cast<const bf16x8*>(&Bl[(wn * 32 + li) * B3_PITCH + ko]);
+            const int ca = ((ks * 2 + half) ^ (((wm * 32 + li) >> 4) & 3)) * 8, cb = ((ks * 2 + half) ^ (((wn * 32 + li) >> 4) & 3)) * 8;
+            const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&Ah[(wm * 32 + li) * B3_PITCH + ca]);
+            const bf16x8 al = *reinterpret_cast<const bf16x8*>(&Al[(wm * 32 + li) * B3_PITCH + ca]);
+            const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&Bh[(wn * 32 + li) * B3_PITCH + cb]);
+            const bf16x8 bl = *reinterpret_cast<const bf16x8*>(&Bl[(wn * 32 + li) * B3_PITCH + cb]);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
