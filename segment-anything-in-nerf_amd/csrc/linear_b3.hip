@@ -758,6 +758,9 @@ __device__ __forceinline__ void ws_split2(float x0, float x1, uint32_t& hi, uint
 //     -1: decided per launch from act_in / aux_bits (loads under launch-uniform branches: the compiler then waits for ALL loads in
 //     flight before every k-step, s_waitcnt vmcnt(0), and the D-deep prefetch hides nothing).  All loads of the k loop are
 //     unconditional for that reason too: the refill past the last k-step re-reads the last one.
+#ifndef SNF_WS_DEPTH
+#define SNF_WS_DEPTH 4  // k-steps of raw A fragments in flight per wave (512-thread instances)
+#endif
 template <bool BT, bool DERIV, int BN, int RB, int THREADS, int DEPTH, bool PA = false, bool CT = false, int AM = -1>
 __global__ __launch_bounds__(THREADS) void k_gemm_ws_b3(const float* __restrict__ A, const float* __restrict__ Aux,
                                                         const float* __restrict__ W, const float* __restrict__ bias, int M,
@@ -1122,15 +1125,15 @@ static int ws_try(const float* A, const float* Aux, const float* W, const float*
         if (gx > tiles) gx = tiles;
         dim3 grid(gx, gy);
         if constexpr (BT && !DERIV) {
-            if (pa && !small) ws_launch<true, false, 128, 1, 512, 4, true, false>(grid, lds, stream, A, Aux, W, bias, M, K, Nc, lda, ldaux, ldw, ldc, act_in, act_out, C, rscale, rgroup, 0, hbar, ybits);
+            if (pa && !small) ws_launch<true, false, 128, 1, 512, SNF_WS_DEPTH, true, false>(grid, lds, stream, A, Aux, W, bias, M, K, Nc, lda, ldaux, ldw, ldc, act_in, act_out, C, rscale, rgroup, 0, hbar, ybits);
             if (pa && small) ws_launch<true, false, 64, 2, 256, 2, true, false>(grid, lds, stream, A, Aux, W, bias, M, K, Nc, lda, ldaux, ldw, ldc, act_in, act_out, C, rscale, rgroup, 0, hbar, ybits);
         }
         if constexpr (!BT && DERIV) {
             const int am = act_in == SNF_ACT_NONE ? 0 : aux_bits ? 2 : 1;
-            if (ct && !small && am == 0) ws_launch<false, true, 128, 1, 512, 4, false, true, 0>(grid, lds, stream, A, Aux, W, bias, M, K, Nc, lda, ldaux, ldw, ldc, act_in, act_out, C, rscale, rgroup, aux_bits);
-            if (ct && !small && am == 1) ws_launch<false, true, 128, 1, 512, 4, false, true, 1>(grid, lds, stream, A, Aux, W, bias, M, K, Nc, lda, ldaux, ldw, ldc, act_in, act_out, C, rscale, rgroup, aux_bits);
-            if (ct && bn96) ws_launch<false, true, 96, 1, 512, 4, false, true, 2>(grid, lds, stream, A, Aux, W, bias, M, K, Nc, lda, ldaux, ldw, ldc, act_in, act_out, C, rscale, rgroup, aux_bits);
-            if (ct && !small && am == 2 && !bn96) ws_launch<false, true, 128, 1, 512, 4, false, true, 2>(grid, lds, stream, A, Aux, W, bias, M, K, Nc, lda, ldaux, ldw, ldc, act_in, act_out, C, rscale, rgroup, aux_bits);
+            if (ct && !small && am == 0) ws_launch<false, true, 128, 1, 512, SNF_WS_DEPTH, false, true, 0>(grid, lds, stream, A, Aux, W, bias, M, K, Nc, lda, ldaux, ldw, ldc, act_in, act_out, C, rscale, rgroup, aux_bits);
+            if (ct && !small && am == 1) ws_launch<false, true, 128, 1, 512, SNF_WS_DEPTH, false, true, 1>(grid, lds, stream, A, Aux, W, bias, M, K, Nc, lda, ldaux, ldw, ldc, act_in, act_out, C, rscale, rgroup, aux_bits);
+            if (ct && bn96) ws_launch<false, true, 96, 1, 512, SNF_WS_DEPTH, false, true, 2>(grid, lds, stream, A, Aux, W, bias, M, K, Nc, lda, ldaux, ldw, ldc, act_in, act_out, C, rscale, rgroup, aux_bits);
+            if (ct && !small && am == 2 && !bn96) ws_launch<false, true, 128, 1, 512, SNF_WS_DEPTH, false, true, 2>(grid, lds, stream, A, Aux, W, bias, M, K, Nc, lda, ldaux, ldw, ldc, act_in, act_out, C, rscale, rgroup, aux_bits);
             if (ct && small) ws_launch<false, true, 64, 2, 256, 2, false, true>(grid, lds, stream, A, Aux, W, bias, M, K, Nc, lda, ldaux, ldw, ldc, act_in, act_out, C, rscale, rgroup, aux_bits);
         }
         return 1;
@@ -1155,11 +1158,11 @@ static int ws_try(const float* A, const float* Aux, const float* W, const float*
 #endif
     dim3 grid(gx, gy);
     const int am = !DERIV ? -1 : act_in == SNF_ACT_NONE ? 0 : aux_bits ? 2 : 1;
-    if (v == 0 && am == -1) ws_launch<BT, DERIV, 128, 1, 512, 4>(grid, lds, stream, A, Aux, W, bias, M, K, Nc, lda, ldaux, ldw, ldc, act_in, act_out, C, rscale, rgroup, aux_bits, hbar, ybits);
+    if (v == 0 && am == -1) ws_launch<BT, DERIV, 128, 1, 512, SNF_WS_DEPTH>(grid, lds, stream, A, Aux, W, bias, M, K, Nc, lda, ldaux, ldw, ldc, act_in, act_out, C, rscale, rgroup, aux_bits, hbar, ybits);
     if constexpr (DERIV) {
-        if (v == 0 && am == 0) ws_launch<BT, DERIV, 128, 1, 512, 4, false, false, 0>(grid, lds, stream, A, Aux, W, bias, M, K, Nc, lda, ldaux, ldw, ldc, act_in, act_out, C, rscale, rgroup, aux_bits, hbar, ybits);
-        if (v == 0 && am == 1) ws_launch<BT, DERIV, 128, 1, 512, 4, false, false, 1>(grid, lds, stream, A, Aux, W, bias, M, K, Nc, lda, ldaux, ldw, ldc, act_in, act_out, C, rscale, rgroup, aux_bits, hbar, ybits);
-        if (v == 0 && am == 2) ws_launch<BT, DERIV, 128, 1, 512, 4, false, false, 2>(grid, lds, stream, A, Aux, W, bias, M, K, Nc, lda, ldaux, ldw, ldc, act_in, act_out, C, rscale, rgroup, aux_bits, hbar, ybits);
+        if (v == 0 && am == 0) ws_launch<BT, DERIV, 128, 1, 512, SNF_WS_DEPTH, false, false, 0>(grid, lds, stream, A, Aux, W, bias, M, K, Nc, lda, ldaux, ldw, ldc, act_in, act_out, C, rscale, rgroup, aux_bits, hbar, ybits);
+        if (v == 0 && am == 1) ws_launch<BT, DERIV, 128, 1, 512, SNF_WS_DEPTH, false, false, 1>(grid, lds, stream, A, Aux, W, bias, M, K, Nc, lda, ldaux, ldw, ldc, act_in, act_out, C, rscale, rgroup, aux_bits, hbar, ybits);
+        if (v == 0 && am == 2) ws_launch<BT, DERIV, 128, 1, 512, SNF_WS_DEPTH, false, false, 2>(grid, lds, stream, A, Aux, W, bias, M, K, Nc, lda, ldaux, ldw, ldc, act_in, act_out, C, rscale, rgroup, aux_bits, hbar, ybits);
     }
     if (v != 0) ws_launch<BT, DERIV, 64, 2, 256, 2>(grid, lds, stream, A, Aux, W, bias, M, K, Nc, lda, ldaux, ldw, ldc, act_in, act_out, C, rscale, rgroup, aux_bits, hbar, ybits);
     return 1;
