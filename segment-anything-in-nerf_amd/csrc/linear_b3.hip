@@ -10,6 +10,7 @@
 // Tile: 128 rows x 64 cols x 32 k per workgroup (4 waves x 32 rows x two 32x32 accumulators), operands in LDS as
 // row-major bf16 planes [row][k] with an 80-byte pitch: one conflict-free ds_read_b128 per operand fragment.
 #include "common.hpp"
+#include <type_traits>
 #include <stdlib.h>
 
 namespace snf {
@@ -1005,7 +1006,9 @@ __global__ __launch_bounds__(THREADS) void k_gemm_ws_b3(const float* __restrict_
         } else if (BT && !DERIV && hbar != nullptr) {
             // rendered epilogue (see the header): registers 0..7 of a lane are rows of the block's first group of 16, 8..15 of its
             // second; the other half-wave holds the other 8 rows of each group
-#pragma unroll
+            // (the activations themselves are only stored when the caller wants them: decided ONCE -- as a per-element `C != nullptr &&`
+            //  it was 64 exec-mask round trips per wave and tile in the step's launches, which pass C = NULL)
+            auto rendered = [&](auto store_c) {
             // the mask words of a row (32 columns each, one per column tile) are gathered in lane (reg, half) of the row's register
             // and leave as ONE store of NB words per row (a 4-byte store per row and column tile by lane 0 before: 64 store
             // instructions and as many exec-mask round trips per wave and tile)
@@ -1030,7 +1033,9 @@ __global__ __launch_bounds__(THREADS) void k_gemm_ws_b3(const float* __restrict_
                         const uint32_t mine = half ? (uint32_t)(bal >> 32) : (uint32_t)bal;
                         mw[t] = li == reg ? mine : mw[t];
                         if (reg < 8) s0 += wr[reg] * v; else s1 += wr[reg] * v;
-                        if (C != nullptr && row < M && c < Nc) C[(size_t)row * ldc + c] = v;
+                        if constexpr (decltype(store_c)::value) {
+                            if (row < M && c < Nc) C[(size_t)row * ldc + c] = v;
+                        }
                     }
                     s0 += __shfl_xor(s0, 32, 64);
                     s1 += __shfl_xor(s1, 32, 64);
@@ -1056,6 +1061,9 @@ __global__ __launch_bounds__(THREADS) void k_gemm_ws_b3(const float* __restrict_
                     }
                 }
             }
+            };
+            if (C != nullptr) rendered(std::true_type{});
+            else rendered(std::false_type{});
         } else {
         // epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
 #pragma unroll
