@@ -7,7 +7,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $ROOT/bench.py --steps 4 --warmup 3 --cpu-baseline-seconds 0 --other-workloads none --steady-steps 0"
+CMD=${COUNTERS_CMD:-"python $ROOT/bench.py --steps 4 --warmup 3 --cpu-baseline-seconds 0 --other-workloads none --steady-steps 0"}  # COUNTERS_CMD: another workload (tools/bench_render.py, tools/bench_vit.py)
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE \
     --kernel-trace --kernel-include-regex "$KRE" --output-format csv -d $OUT/p1 -o pmc -- $CMD > /dev/null 2> $OUT/p1.err
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES \
