@@ -157,6 +157,10 @@ def _dp_worker(rank, world, port, q):
         ok = ok and torch.equal(a.grad, expect)
     # the mean the fused Adam applies: grad_scale = 1/world
     ok = ok and D.world_size() == world
+    # the step guard's verdict word (step_program._guard_update on many ranks): MAX over the ranks, in place, on the veto word only
+    rec = torch.tensor([1 if rank == world - 1 else 0, 3], dtype=torch.int32)
+    D._all_reduce_max(rec[0:1])
+    ok = ok and rec.tolist() == [1, 3]
     q.put((rank, bool(ok)))
     torch.distributed.destroy_process_group()
 
